@@ -1,0 +1,116 @@
+"""Pin the CPU oracle against the golden vectors captured from the reference.
+
+CPU-only (no GPU): covers oracle/condense_np.py, oracle/mpc_oracle.c.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import all_cases, kkt_residuals, load_case
+
+BUILD_KEYS = ("P", "q", "G", "h", "Phi", "Psi", "phi_last", "psi_last", "e")
+
+
+def _close(a, b, rtol=1e-13):
+    scale = max(1.0, float(np.abs(b).max()) if b.size else 1.0)
+    return float(np.abs(a - b).max()) <= rtol * scale if a.size else True
+
+
+@pytest.mark.parametrize("name", all_cases())
+def test_numpy_condense_matches_reference(name):
+    p, z = load_case(name)
+    cq = oracle.condense(p)
+    for key in BUILD_KEYS:
+        got, want = getattr(cq, key), z["out_" + key]
+        assert got.shape == want.shape, key
+        assert got.dtype == np.float64
+        # same operations in the same order as mpc_qp.py -> bitwise equal here
+        assert np.array_equal(got, want), (name, key, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("name", all_cases())
+def test_c_condense_matches_reference(name):
+    p, z = load_case(name)
+    out = oracle.condense_one(p)
+    for key in ("P", "q", "G", "h", "Phi", "Psi", "phi_last", "psi_last"):
+        assert out[key].shape == z["out_" + key].shape, key
+        assert _close(out[key], z["out_" + key]), (name, key)
+
+
+@pytest.mark.parametrize("name", all_cases(solved_only=True))
+def test_gi_matches_certified_solution(name):
+    p, z = load_case(name)
+    P, q, G, h = z["out_P"], z["out_q"], z["out_G"], z["out_h"]
+    x, lam, status, iters = oracle.gi_solve(P, q, G, h)
+    assert status == 0
+    scale = max(1.0, np.abs(z["U_star"]).max())
+    assert np.abs(x - z["U_star"]).max() <= 1e-8 * scale
+    stat, prim, dual, comp = kkt_residuals(P, q, G, h, x, lam)
+    qs = 1.0 + np.abs(q).max()
+    assert stat <= 1e-9 * qs and prim <= 1e-9 and dual <= 1e-12 and comp <= 1e-8 * qs
+    assert abs(0.5 * x @ P @ x + q @ x - float(z["obj_star"])) <= 1e-9 * max(1.0, abs(float(z["obj_star"])))
+    assert set(np.nonzero(lam > 1e-9 * (1 + lam.max()))[0]) <= set(z["active_set"].tolist())
+
+
+def test_reference_known_answer_wip_zero():
+    """tests/test_wheeled_inverted_pendulum.py:23-41: x0 = goal = targets = 0
+    -> the plan's first input keeps the plant at rest (U* = 0)."""
+    p, z = load_case("wip_n12_zero")
+    U, status, _ = oracle.solve_mpc_like_reference(p)
+    assert status == 0 and np.abs(U).max() <= 6e-8
+    assert np.array_equal(z["U_star"], np.zeros(12))
+
+
+def test_reference_humanoid_first_rows_zero():
+    """tests/test_humanoid_one_step.py:72-75: |G[0:2]| == 0 (Psi_0 = 0, D = None)."""
+    p, _ = load_case("humanoid_one_step")
+    assert np.linalg.norm(oracle.condense(p).G[0:2]) == 0.0
+    assert np.linalg.norm(oracle.condense_one(p)["G"][0:2]) == 0.0
+
+
+def test_reference_update_constraint_vector():
+    """tests/test_update_constraint_vector.py:71-80 + the q/h update pair."""
+    p, _ = load_case("humanoid_one_step")
+    cq = oracle.condense(p)
+    assert np.array_equal(cq.h, oracle.constraint_vector(cq, p))
+    z = np.load(__import__("os").path.join(__import__("golden_util").GOLDEN, "humanoid_update_vectors.npz"))
+    p.update_initial_state(z["new_initial_state"])
+    p.update_goal_state(z["new_goal_state"])
+    assert np.allclose(oracle.cost_vector(cq, p), z["q_updated"], rtol=0, atol=1e-15)
+    assert np.allclose(oracle.constraint_vector(cq, p), z["h_updated"], rtol=0, atol=1e-15)
+    assert np.allclose(z["q_updated"], z["q_fresh"], atol=1e-14)
+
+
+@pytest.mark.parametrize("name", all_cases(solved_only=True))
+def test_rollout_matches_plan_states(name):
+    p, z = load_case(name)
+    X = oracle.integrate(p, p.initial_state, z["plan_inputs"])
+    assert np.array_equal(X, z["plan_states"])
+    s = oracle.capi.stack_problem(p)
+    X2 = oracle.rollout_one(s["A"], s["B"], p.initial_state, z["plan_inputs"])
+    assert np.allclose(X2, z["plan_states"], rtol=1e-13, atol=1e-13 * max(1, np.abs(X).max()))
+
+
+def test_batch_driver_equals_single_calls():
+    p, z = load_case("triple_integrator")
+    s = oracle.capi.stack_problem(p)
+    rng = np.random.default_rng(0)
+    B = 5
+    x0 = np.stack([z["initial_state"] + 0.1 * rng.standard_normal(3) for _ in range(B)])
+    goal = np.tile(z["goal_state"], (B, 1))
+    U, lam, status, iters = oracle.build_solve_batch(
+        s["nx"], s["nu"], s["N"], s["mk"], s["flags"], s["wt"], s["wx"], s["wu"],
+        s["A"], s["B"], s["C"], s["D"], s["e"], x0, goal, None)
+    assert (status == 0).all()
+    for b in range(B):
+        p.update_initial_state(x0[b])
+        Ub, st, _ = oracle.solve_mpc_like_reference(p)
+        assert np.abs(U[b] - Ub.ravel()).max() <= 1e-9 * max(1, np.abs(Ub).max())
+
+
+def test_infeasible_and_not_pd_statuses():
+    P = np.eye(2)
+    x, lam, st, _ = oracle.gi_solve(P, np.zeros(2), np.array([[1.0, 0.0], [-1.0, 0.0]]), np.array([-1.0, -1.0]))
+    assert st == 2
+    x, lam, st, _ = oracle.gi_solve(np.array([[1.0, 2.0], [2.0, 1.0]]), np.zeros(2), np.zeros((0, 2)), np.zeros(0))
+    assert st == 3
