@@ -1,0 +1,164 @@
+/*
+ * mpcqp.h -- C ABI of libmpcqp_hip.so, the MI355X (gfx950) implementation of
+ * qpmpc's hot path:  MPCProblem -> MPCQP (condense) -> dense QP solve -> inputs.
+ *
+ * The reference (stephane-caron/qpmpc v3.1.0) is pure Python and has no FFI
+ * layer of its own; its operator boundary for this path is
+ *     solve_mpc(problem, solver, sparse=False, **kw) -> Plan   qpmpc/solve_mpc.py:16-44
+ *     MPCQP(problem, sparse=False)                             qpmpc/mpc_qp.py:39-122
+ * Each entry point below names the reference code it replaces. A Python
+ * maintainer binds them with ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *    caller (the library never allocates or frees device memory);
+ *  - every call is asynchronous on the caller's hipStream_t (passed as void*;
+ *    NULL = the null stream), re-entrant, no global state;
+ *  - return value: 0 ok, <0 bad argument (MPCQP_E*), >0 a hipError_t;
+ *    per-problem outcome is reported in status[b], never by the return value;
+ *  - matrices are row-major and densely packed; one batch item after another
+ *    unless a stride says otherwise;
+ *  - constraints are  G u <= h ; the QP is  min 1/2 u'Pu + q'u.
+ */
+#ifndef MPCQP_H_
+#define MPCQP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCQP_ABI_VERSION 1
+
+/* element type of every floating-point buffer of a call */
+#define MPCQP_F64 0
+#define MPCQP_F32 1
+
+/* MpcqpDims.flags -- which cost terms enter P and q. They differ on purpose:
+ * the reference adds a term to P when its weight "is not None"
+ * (mpc_qp.py:102,104) but to q only when weight > 1e-10 and the matching
+ * state is defined (mpc_problem.py:141-166, mpc_qp.py:119-122). */
+#define MPCQP_P_TERMINAL 1
+#define MPCQP_P_STAGE 2
+#define MPCQP_Q_TERMINAL 4
+#define MPCQP_Q_STAGE 8
+
+/* per-problem status[b]  (Plan.is_empty <=> status != 0, plan.py:35-40) */
+#define MPCQP_SOLVED 0
+#define MPCQP_MAX_ITER 1
+#define MPCQP_INFEASIBLE 2
+#define MPCQP_NOT_PD 3
+
+/* negative return codes */
+#define MPCQP_EINVAL (-1)    /* NULL/negative/inconsistent argument           */
+#define MPCQP_ETOOLARGE (-2) /* problem does not fit the on-chip (LDS) path   */
+#define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
+#define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
+
+/* Problem dimensions and cost weights (mpc_problem.py:88-139).
+ * n = N*nu decision variables, m = N*mk inequality rows. Problems whose
+ * per-step row count varies are padded by the host to mk rows with C=D=0 and
+ * e=+1e30 (an inequality that can never be active). */
+typedef struct MpcqpDims {
+    int32_t nx;    /* state_dim                                   */
+    int32_t nu;    /* input_dim                                   */
+    int32_t N;     /* nb_timesteps                                */
+    int32_t mk;    /* inequality rows per step (after padding)    */
+    int32_t dtype; /* MPCQP_F64 | MPCQP_F32                       */
+    int32_t flags; /* MPCQP_P_* | MPCQP_Q_*                       */
+    double w_terminal; /* terminal_cost_weight     (ignored unless flagged) */
+    double w_stage;    /* stage_state_cost_weight  (ignored unless flagged) */
+    double w_input;    /* stage_input_cost_weight  > 0                      */
+} MpcqpDims;
+
+/* One operand of a batch of problems, addressed as
+ *     ptr + b*batch_stride + k*step_stride      (strides in ELEMENTS)
+ * batch_stride == 0: shared by every problem of the batch;
+ * step_stride  == 0: time-invariant (the reference's "array, not list" case,
+ *                    mpc_problem.py:177-245); otherwise it must equal the
+ *                    block size (rows*cols) so a problem's steps are packed.
+ * ptr == NULL means "None" where the reference allows it (C, D, goal, targets). */
+typedef struct MpcqpOperand {
+    const void *ptr;
+    int64_t batch_stride;
+    int64_t step_stride;
+} MpcqpOperand;
+
+typedef struct MpcqpProblem {
+    MpcqpOperand A;       /* [N] nx x nx   transition_state_matrix              */
+    MpcqpOperand B;       /* [N] nx x nu   transition_input_matrix              */
+    MpcqpOperand C;       /* [N] mk x nx   ineq_state_matrix        (nullable)  */
+    MpcqpOperand D;       /* [N] mk x nu   ineq_input_matrix        (nullable)  */
+    MpcqpOperand e;       /* [N] mk        ineq_vector                          */
+    MpcqpOperand x0;      /* nx            initial_state   (step_stride unused) */
+    MpcqpOperand goal;    /* nx            goal_state      (nullable)           */
+    MpcqpOperand targets; /* N*nx          target_states   (nullable)           */
+} MpcqpProblem;
+
+typedef struct MpcqpSolveOpts {
+    int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
+    int32_t reserved;
+    double feas_tol;  /* a row is violated when (h_i-G_i u)/(1+|h_i|) < -tol;
+                         <=0 -> 1e-12 (f64) / 1e-5 (f32)                         */
+} MpcqpSolveOpts;
+
+/* ABI version of the loaded library (== MPCQP_ABI_VERSION of its build). */
+int mpcqp_abi_version(void);
+
+/* Static text for a return code (<0: MPCQP_E*, >0: hipGetErrorString). */
+const char *mpcqp_error_string(int code);
+
+/* Dynamic LDS bytes one problem of these dimensions needs on the fused path;
+ * MPCQP_ETOOLARGE when it exceeds the 160 KiB of a gfx950 CU. */
+int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes);
+
+/* Replaces MPCQP.__init__ (mpc_qp.py:39-122) for a batch: Phi/Psi propagation
+ * (:53-54,:88-90), G_k/h_k (:62-78), P (:99-105), q (:129-149).
+ * Outputs per problem, packed: P[n*n], q[n], G[m*n], h[m];
+ * Phi[(N+1)*nx*nx] (blocks Phi_0..Phi_N; the last one is phi_last) and
+ * Psi[(N+1)*nx*n]  (blocks Psi_0..Psi_N; the last one is psi_last) may be NULL. */
+int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
+                         int64_t batch, void *P, void *q, void *G, void *h,
+                         void *Phi, void *Psi, void *stream);
+
+/* Replaces MPCQP.update_cost_vector (mpc_qp.py:129-149) and
+ * MPCQP.update_constraint_vector (mpc_qp.py:151-163) for a batch, from the
+ * Phi/Psi kept by mpcqp_condense_batch (same packing; batch strides
+ * phi_batch_stride/psi_batch_stride in elements, 0 = one shared copy) and new
+ * x0/goal/targets. Reads problem->C, ->e, ->x0, ->goal, ->targets only.
+ * q and/or h may be NULL to skip that update. */
+int mpcqp_update_vectors_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
+                               const void *Phi, int64_t phi_batch_stride,
+                               const void *Psi, int64_t psi_batch_stride,
+                               int64_t batch, void *q, void *h, void *stream);
+
+/* Replaces qpsolvers.solve_problem(Problem(P,q,G,h), solver=...) at its call
+ * site qpmpc/solve_mpc.py:43 for a batch of dense strictly convex QPs:
+ * x[batch*n], lam[batch*m] (multipliers of G u <= h, nullable),
+ * status[batch], iters[batch] (nullable). Dual active-set method. */
+int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P,
+                      const void *q, const void *G, const void *h, int64_t batch,
+                      const MpcqpSolveOpts *opts, void *x, void *lam,
+                      int32_t *status, int32_t *iters, void *stream);
+
+/* Replaces the whole of solve_mpc (qpmpc/solve_mpc.py:42-44) for a batch, fused:
+ * P, G and their factors never leave the CU. U[batch*n] is the stacked input
+ * sequence (Plan.inputs = U.reshape(N, nu), plan.py:36-39). */
+int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
+                            int64_t batch, const MpcqpSolveOpts *opts, void *U,
+                            void *lam, int32_t *status, int32_t *iters,
+                            void *stream);
+
+/* Replaces MPCProblem.integrate (mpc_problem.py:316-335) as used by Plan.states
+ * (plan.py:81-109) for a batch: X[batch*(N+1)*nx], X_0 = x0,
+ * X_{k+1} = A_k X_k + B_k U_k. U is packed [batch*N*nu]. */
+int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A,
+                        const MpcqpOperand *B, const MpcqpOperand *x0,
+                        const void *U, int64_t batch, void *X, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQP_H_ */

@@ -17,5 +17,6 @@ from .capi import (  # noqa: F401
     gi_solve,
     rollout_one,
     solve_mpc_like_reference,
+    solve_workload,
 )
 from .condense_np import condense, constraint_vector, cost_vector, integrate  # noqa: F401

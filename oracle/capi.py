@@ -217,3 +217,52 @@ def solve_mpc_like_reference(problem, max_iter: int = 10000, tol: float = 1e-12)
     if st != 0:
         return None, st, it
     return x.reshape(problem.nb_timesteps, problem.input_dim), st, it
+
+
+def _strides(a, block_ndim: int, block: int, N: int):
+    """(batch_stride, step_stride) of an operand shaped [..], [N,..] or [B,N|1,..]."""
+    extra = a.ndim - block_ndim
+    if extra == 0:
+        return (0, 0)
+    if extra == 1:
+        return (0, block if a.shape[0] > 1 else 0)
+    steps = a.shape[1]
+    return (block * steps if a.shape[0] > 1 else 0, block if steps > 1 else 0)
+
+
+def workload_flags(w: dict) -> int:
+    f = 0
+    if w["wt"] is not None:
+        f |= FLAG_P_TERMINAL
+        if w["wt"] > 1e-10 and w["goal"] is not None:
+            f |= FLAG_Q_TERMINAL
+    if w["wx"] is not None:
+        f |= FLAG_P_STAGE
+        if w["wx"] > 1e-10 and w["targets"] is not None:
+            f |= FLAG_Q_STAGE
+    return f
+
+
+def solve_workload(w: dict, max_iter: int = 10000, tol: float = 1e-12, count: Optional[int] = None):
+    """Run the all-C oracle on a workload dict (qpmpc_amd.workloads layout: A, B,
+    C, D, e, N, wt, wx, wu, x0, goal, targets). ``count`` limits it to the first
+    problems of the batch. Returns (U, lam, status, iters)."""
+    A = np.ascontiguousarray(w["A"], dtype=float)
+    Bm = np.ascontiguousarray(w["B"], dtype=float)
+    e = np.ascontiguousarray(w["e"], dtype=float)
+    nx, nu, N, mk = A.shape[-1], Bm.shape[-1], int(w["N"]), e.shape[-1]
+    x0 = np.ascontiguousarray(w["x0"], dtype=float)
+    if count is not None:
+        x0 = x0[:count]
+    layout = dict(A=_strides(A, 2, nx * nx, N), B=_strides(Bm, 2, nx * nu, N), e=_strides(e, 1, mk, N))
+    Cm = D = None
+    if w["C"] is not None:
+        Cm = np.ascontiguousarray(w["C"], dtype=float)
+        layout["C"] = _strides(Cm, 2, mk * nx, N)
+    if w["D"] is not None:
+        D = np.ascontiguousarray(w["D"], dtype=float)
+        layout["D"] = _strides(D, 2, mk * nu, N)
+    goal = None if w["goal"] is None else np.ascontiguousarray(w["goal"], dtype=float)
+    tgt = None if w["targets"] is None else np.ascontiguousarray(w["targets"], dtype=float)
+    return build_solve_batch(nx, nu, N, mk, workload_flags(w), w["wt"] or 0.0, w["wx"] or 0.0, w["wu"],
+                             A, Bm, Cm, D, e, x0, goal, tgt, max_iter=max_iter, tol=tol, layout=layout)

@@ -1,0 +1,117 @@
+"""ctypes binding of libmpcqp_hip.so (the C ABI of include/mpcqp.h).
+
+The library is looked up in-tree (qpmpc_amd/lib/) only. If it is missing or a
+call fails this module raises ``BackendError``: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .exceptions import BackendError
+
+F64, F32 = 0, 1
+P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
+SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
+ABI_VERSION = 1
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
+
+EXPORTS = (
+    "mpcqp_abi_version",
+    "mpcqp_error_string",
+    "mpcqp_lds_bytes",
+    "mpcqp_condense_batch",
+    "mpcqp_update_vectors_batch",
+    "mpcqp_solve_batch",
+    "mpcqp_build_solve_batch",
+    "mpcqp_rollout_batch",
+)
+
+
+class Dims(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int32), ("nu", C.c_int32), ("N", C.c_int32), ("mk", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32),
+        ("w_terminal", C.c_double), ("w_stage", C.c_double), ("w_input", C.c_double),
+    ]
+
+
+class Operand(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("batch_stride", C.c_int64), ("step_stride", C.c_int64)]
+
+
+class Problem(C.Structure):
+    _fields_ = [(name, Operand) for name in ("A", "B", "C", "D", "e", "x0", "goal", "targets")]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("feas_tol", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and declare its prototypes (once)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    # torch must be imported first: its wheel bundles the HIP runtime this process
+    # uses, and stream handles passed to the library are only valid inside that
+    # runtime instance (loading the system libamdhip64 first creates a second one).
+    import torch  # noqa: F401
+
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exn:  # pragma: no cover - depends on the host's ROCm install
+        raise BackendError(f"cannot load {LIB_PATH}: {exn}") from exn
+    vp, i64, i32p = C.c_void_p, C.c_int64, C.POINTER(C.c_int32)
+    lib.mpcqp_abi_version.restype = C.c_int
+    lib.mpcqp_abi_version.argtypes = []
+    lib.mpcqp_error_string.restype = C.c_char_p
+    lib.mpcqp_error_string.argtypes = [C.c_int]
+    lib.mpcqp_lds_bytes.restype = C.c_int
+    lib.mpcqp_lds_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
+    lib.mpcqp_condense_batch.restype = C.c_int
+    lib.mpcqp_condense_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcqp_update_vectors_batch.restype = C.c_int
+    lib.mpcqp_update_vectors_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), vp, i64, vp, i64, i64, vp, vp, vp]
+    lib.mpcqp_solve_batch.restype = C.c_int
+    lib.mpcqp_solve_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, i64,
+                                      C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
+    lib.mpcqp_build_solve_batch.restype = C.c_int
+    lib.mpcqp_build_solve_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts),
+                                            vp, vp, vp, vp, vp]
+    lib.mpcqp_rollout_batch.restype = C.c_int
+    lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
+                                        C.POINTER(Operand), vp, i64, vp, vp]
+    del i32p
+    if lib.mpcqp_abi_version() != ABI_VERSION:
+        raise BackendError(f"ABI mismatch: library {lib.mpcqp_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    """Turn a non-zero return code of the C ABI into ``BackendError``."""
+    if code != 0:
+        msg = load().mpcqp_error_string(code).decode()
+        raise BackendError(f"{what} failed with code {code}: {msg}")
+
+
+def require_gpu():
+    """Return the torch CUDA(ROCm) device or raise: the product path needs a GPU."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise BackendError(
+            "no ROCm GPU visible to torch: qpmpc_amd computes only on MI355X-class "
+            "devices and has no CPU fallback"
+        )
+    return torch.device("cuda", torch.cuda.current_device())

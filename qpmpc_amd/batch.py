@@ -1,0 +1,507 @@
+"""Batched problems on the device: the data-parallel entry points.
+
+A batch is ``B`` independent MPC problems with common dimensions. Operands live
+in HBM as packed row-major tensors; an operand that is the same for every
+problem (or every step) is stored ONCE and addressed with a zero stride, which
+is how the reference's "array, not list" (LTI) case is expressed
+(qpmpc/mpc_problem.py:177-245).
+
+    A        [B|1, N|1, nx, nx]      B  [B|1, N|1, nx, nu]
+    C        [B|1, N|1, mk, nx]|None D  [B|1, N|1, mk, nu]|None
+    e        [B|1, N|1, mk]
+    x0       [B, nx]   goal [B|1, nx]|None   targets [B|1, N*nx]|None
+
+``solve_mpc_batch`` replaces a Python loop of ``solve_mpc`` calls
+(qpmpc/solve_mpc.py:42-44) by one fused kernel launch; one problem per
+workgroup, no host round trip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+from .exceptions import BackendError, ProblemDefinitionError, StateError
+
+PAD_BOUND = 1e30  # bound of padded inequality rows (0 . u <= 1e30 is never active)
+HIP_SOLVERS = ("hip", "hip_gi", "mpcqp_hip")
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _dtype_code(dtype) -> int:
+    torch = _torch()
+    if dtype == torch.float64:
+        return _capi.F64
+    if dtype == torch.float32:
+        return _capi.F32
+    raise ProblemDefinitionError(f"dtype must be torch.float64 or torch.float32, not {dtype}")
+
+
+def _as_tensor(x, dtype, device):
+    torch = _torch()
+    if x is None:
+        return None
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=dtype)
+    return torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=dtype, device=device)
+
+
+def _canon(x, tail: Sequence[int], name: str):
+    """Bring an operand to [Bx, Nx, *tail] with Bx, Nx possibly 1; contiguous."""
+    if x is None:
+        return None
+    t = len(tail)
+    if x.dim() == t:
+        x = x.reshape(1, 1, *x.shape)
+    elif x.dim() == t + 1:
+        x = x.reshape(1, *x.shape)
+    elif x.dim() != t + 2:
+        raise ProblemDefinitionError(f"{name}: expected {t}, {t + 1} or {t + 2} dimensions, got {x.dim()}")
+    if tuple(x.shape[2:]) != tuple(tail):
+        raise ProblemDefinitionError(f"{name}: trailing shape {tuple(x.shape[2:])} != {tuple(tail)}")
+    return x.contiguous()
+
+
+class BatchMPCProblem:
+    """``B`` linear time-variant MPC problems resident on one GPU.
+
+    Same cost/constraint model and the same validation as
+    :class:`qpmpc_amd.MPCProblem` (reference mpc_problem.py:88-139): weights are
+    shared by the batch; states may differ per problem.
+    """
+
+    def __init__(
+        self,
+        transition_state_matrix,
+        transition_input_matrix,
+        ineq_state_matrix,
+        ineq_input_matrix,
+        ineq_vector,
+        nb_timesteps: int,
+        terminal_cost_weight: Optional[float],
+        stage_state_cost_weight: Optional[float],
+        stage_input_cost_weight: float,
+        initial_state,
+        goal_state=None,
+        target_states=None,
+        dtype=None,
+        device=None,
+    ) -> None:
+        torch = _torch()
+        if stage_input_cost_weight <= 0.0:
+            raise ProblemDefinitionError("stage non-negative control weight needed for regularization")
+        if terminal_cost_weight is None and stage_state_cost_weight is None:
+            raise ProblemDefinitionError("either terminal or stage state cost should be set")
+        self.dtype = dtype if dtype is not None else torch.float64
+        self.device = device if device is not None else _capi.require_gpu()
+        _dtype_code(self.dtype)
+        N = int(nb_timesteps)
+        A = _as_tensor(transition_state_matrix, self.dtype, self.device)
+        Bm = _as_tensor(transition_input_matrix, self.dtype, self.device)
+        nx, nu = int(A.shape[-1]), int(Bm.shape[-1])
+        self.state_dim, self.input_dim, self.nb_timesteps = nx, nu, N
+        self.A = _canon(A, (nx, nx), "transition_state_matrix")
+        self.B = _canon(Bm, (nx, nu), "transition_input_matrix")
+        e = _as_tensor(ineq_vector, self.dtype, self.device)
+        mk = int(e.shape[-1])
+        self.ineq_dim = mk
+        self.e = _canon(e, (mk,), "ineq_vector")
+        self.C = _canon(_as_tensor(ineq_state_matrix, self.dtype, self.device), (mk, nx), "ineq_state_matrix")
+        self.D = _canon(_as_tensor(ineq_input_matrix, self.dtype, self.device), (mk, nu), "ineq_input_matrix")
+        for name, op in (("A", self.A), ("B", self.B), ("C", self.C), ("D", self.D), ("e", self.e)):
+            if op is not None and op.shape[1] not in (1, N):
+                raise ProblemDefinitionError(f"{name}: step dimension {op.shape[1]} is neither 1 nor N={N}")
+        self.terminal_cost_weight = terminal_cost_weight
+        self.stage_state_cost_weight = stage_state_cost_weight
+        self.stage_input_cost_weight = float(stage_input_cost_weight)
+        self.initial_state = None
+        self.goal_state = None
+        self.target_states = None
+        if initial_state is None:
+            raise ProblemDefinitionError("initial state is undefined")
+        self.update_initial_state(initial_state)
+        if goal_state is not None:
+            self.update_goal_state(goal_state)
+        if target_states is not None:
+            self.update_target_states(target_states)
+        B_ = self.batch_size
+        for name, op in (("A", self.A), ("B", self.B), ("C", self.C), ("D", self.D), ("e", self.e)):
+            if op is not None and op.shape[0] not in (1, B_):
+                raise ProblemDefinitionError(f"{name}: batch dimension {op.shape[0]} is neither 1 nor B={B_}")
+        # row mask for problems whose per-step row count was padded (from_problems)
+        self.valid_rows: Optional[np.ndarray] = None
+
+    # ------------------------------------------------------------------ state
+    @property
+    def batch_size(self) -> int:
+        return int(self.initial_state.shape[0])
+
+    @property
+    def nb_variables(self) -> int:
+        return self.nb_timesteps * self.input_dim
+
+    @property
+    def nb_constraints(self) -> int:
+        return self.nb_timesteps * self.ineq_dim
+
+    def _state(self, x, width: int, what: str, per_batch_required: bool):
+        x = _as_tensor(x, self.dtype, self.device)
+        if x.dim() == 1 or (not per_batch_required and x.numel() == width):
+            x = x.reshape(1, -1)
+        x = x.reshape(x.shape[0], -1)
+        if x.shape[1] != width:
+            raise StateError(f"{what} of shape {tuple(x.shape)} does not match dimension ({width})")
+        return x.contiguous()
+
+    def update_initial_state(self, initial_state) -> None:
+        """x0 per problem, [B, nx] (a 1-D vector makes a batch of one)."""
+        x = _as_tensor(initial_state, self.dtype, self.device)
+        if x.dim() == 1:
+            x = x.reshape(1, -1)
+        x = x.reshape(x.shape[0], -1)
+        if x.shape[1] != self.state_dim:
+            raise StateError(
+                f"Initial state of shape {tuple(x.shape)} does not match state dimension ({self.state_dim})"
+            )
+        if self.initial_state is not None and x.shape[0] != self.batch_size:
+            raise StateError(f"batch size changed from {self.batch_size} to {x.shape[0]}")
+        self.initial_state = x.contiguous()
+
+    def update_goal_state(self, goal_state) -> None:
+        """Goal per problem [B, nx] or shared [nx]."""
+        g = self._state(goal_state, self.state_dim, "goal state", False)
+        if g.shape[0] not in (1, self.batch_size):
+            raise StateError(f"goal state batch {g.shape[0]} is neither 1 nor {self.batch_size}")
+        self.goal_state = g
+
+    def update_target_states(self, target_states) -> None:
+        """Stage targets per problem [B, N*nx] (or [B, N, nx]) or shared [N*nx]."""
+        width = self.state_dim * self.nb_timesteps
+        t = _as_tensor(target_states, self.dtype, self.device)
+        if t.numel() == width:
+            t = t.reshape(1, width)
+        else:
+            t = t.reshape(t.shape[0], -1)
+        if t.shape[1] != width or t.shape[0] not in (1, self.batch_size):
+            raise StateError(
+                f"Reference state trajectory of shape {tuple(t.shape)} does not match "
+                f"nb_timesteps * state dimension = {self.nb_timesteps} * {self.state_dim} = {width}"
+            )
+        self.target_states = t.contiguous()
+
+    # ------------------------------------------------------------ C ABI views
+    def cost_flags(self) -> int:
+        """MPCQP_P_* / MPCQP_Q_* bits (see include/mpcqp.h for why they differ)."""
+        f = 0
+        wt, wx = self.terminal_cost_weight, self.stage_state_cost_weight
+        if wt is not None:
+            f |= _capi.P_TERMINAL
+        if wx is not None:
+            f |= _capi.P_STAGE
+        t_on = wt is not None and wt > 1e-10
+        s_on = wx is not None and wx > 1e-10
+        if t_on and self.goal_state is None:
+            return f  # the reference raises before accumulating anything (mpc_qp.py:119-122)
+        if t_on:
+            f |= _capi.Q_TERMINAL
+        if s_on and self.target_states is not None:
+            f |= _capi.Q_STAGE
+        return f
+
+    def dims(self) -> _capi.Dims:
+        return _capi.Dims(
+            self.state_dim, self.input_dim, self.nb_timesteps, self.ineq_dim, _dtype_code(self.dtype),
+            self.cost_flags(),
+            0.0 if self.terminal_cost_weight is None else float(self.terminal_cost_weight),
+            0.0 if self.stage_state_cost_weight is None else float(self.stage_state_cost_weight),
+            self.stage_input_cost_weight,
+        )
+
+    @staticmethod
+    def _operand(t) -> _capi.Operand:
+        if t is None:
+            return _capi.Operand(None, 0, 0)
+        block = int(np.prod(t.shape[2:])) if t.dim() > 2 else 0
+        steps = t.shape[1] if t.dim() > 2 else 1
+        bs = 0 if t.shape[0] == 1 else int(t.stride(0))
+        ks = 0 if (t.dim() <= 2 or steps == 1) else block
+        return _capi.Operand(t.data_ptr(), bs, ks)
+
+    def c_problem(self) -> _capi.Problem:
+        return _capi.Problem(
+            self._operand(self.A), self._operand(self.B), self._operand(self.C), self._operand(self.D),
+            self._operand(self.e), self._operand(self.initial_state), self._operand(self.goal_state),
+            self._operand(self.target_states),
+        )
+
+    # ------------------------------------------------------------- factories
+    @classmethod
+    def from_problems(cls, problems: List, dtype=None, device=None) -> "BatchMPCProblem":
+        """Stack host ``MPCProblem`` objects of equal dimensions into one batch.
+
+        Per-step row counts may vary (lists of different-height C_k/D_k/e_k);
+        they are padded to the maximum with zero rows and ``PAD_BOUND`` bounds and
+        ``valid_rows`` remembers which rows are real.
+        """
+        p0 = problems[0]
+        N, nx, nu = p0.nb_timesteps, p0.state_dim, p0.input_dim
+        if p0.initial_state is None:
+            raise ProblemDefinitionError("initial state is undefined")
+        mks = [len(np.asarray(p0.get_ineq_vector(k)).ravel()) for k in range(N)]
+        mk = max(mks)
+        Bn = len(problems)
+        A = np.zeros((Bn, N, nx, nx))
+        Bm = np.zeros((Bn, N, nx, nu))
+        e = np.full((Bn, N, mk), PAD_BOUND)
+        anyC = any(p.get_ineq_state_matrix(k) is not None for p in problems for k in range(N))
+        anyD = any(p.get_ineq_input_matrix(k) is not None for p in problems for k in range(N))
+        Cm = np.zeros((Bn, N, mk, nx)) if anyC else None
+        Dm = np.zeros((Bn, N, mk, nu)) if anyD else None
+        for b, p in enumerate(problems):
+            if (p.nb_timesteps, p.state_dim, p.input_dim) != (N, nx, nu):
+                raise ProblemDefinitionError("problems of a batch must share (N, nx, nu)")
+            if p.initial_state is None:
+                raise ProblemDefinitionError("initial state is undefined")
+            for k in range(N):
+                A[b, k] = np.asarray(p.get_transition_state_matrix(k), dtype=float).reshape(nx, nx)
+                Bm[b, k] = np.asarray(p.get_transition_input_matrix(k), dtype=float).reshape(nx, nu)
+                ek = np.asarray(p.get_ineq_vector(k), dtype=float).ravel()
+                if len(ek) != mks[k]:
+                    raise ProblemDefinitionError("problems of a batch must share per-step row counts")
+                e[b, k, : mks[k]] = ek
+                Ck, Dk = p.get_ineq_state_matrix(k), p.get_ineq_input_matrix(k)
+                if Ck is not None:
+                    Cm[b, k, : mks[k]] = np.asarray(Ck, dtype=float).reshape(mks[k], nx)
+                if Dk is not None:
+                    Dm[b, k, : mks[k]] = np.asarray(Dk, dtype=float).reshape(mks[k], nu)
+        x0 = np.stack([np.asarray(p.initial_state, dtype=float) for p in problems])
+        goals = [p.goal_state for p in problems]
+        tgts = [p.target_states for p in problems]
+        bp = cls(
+            A, Bm, Cm, Dm, e, N, p0.terminal_cost_weight, p0.stage_state_cost_weight,
+            p0.stage_input_cost_weight, x0,
+            goal_state=None if any(g is None for g in goals) else np.stack(goals),
+            target_states=None if any(t is None for t in tgts) else np.stack(tgts),
+            dtype=dtype, device=device,
+        )
+        bp.valid_rows = np.concatenate([k * mk + np.arange(mks[k]) for k in range(N)])
+        return bp
+
+
+def _stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _opts(max_iter=None, feas_tol=None):
+    return _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))
+
+
+class BatchPlan:
+    """Solutions of a batch (the batched counterpart of ``Plan``, plan.py:18-109).
+
+    ``inputs`` [B, N, nu]; rows of problems that were not solved are zero and
+    flagged in ``found`` (status: 0 solved, 1 iteration limit, 2 infeasible,
+    3 P not positive definite).
+    """
+
+    def __init__(self, problem: BatchMPCProblem, U, status, iters, multipliers=None):
+        self.problem = problem
+        self.U = U
+        self.status = status
+        self.iters = iters
+        self.multipliers = multipliers
+        self._states = None
+
+    @property
+    def inputs(self):
+        p = self.problem
+        return self.U.view(p.batch_size, p.nb_timesteps, p.input_dim)
+
+    @property
+    def found(self):
+        return self.status == 0
+
+    @property
+    def first_input(self):
+        return self.inputs[:, 0, :]
+
+    @property
+    def states(self):
+        """[B, N+1, nx], rolled out on the device and memoised (plan.py:81-109)."""
+        if self._states is None:
+            self._states = rollout_batch(self.problem, self.U)
+        return self._states
+
+
+def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_multipliers: bool = False,
+                    max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> BatchPlan:
+    """Build and solve every problem of the batch in ONE fused launch
+    (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem)."""
+    if solver not in HIP_SOLVERS:
+        raise BackendError(f"solver '{solver}' is not a batched backend; available: {HIP_SOLVERS}")
+    torch = _torch()
+    lib = _capi.load()
+    Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
+    U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
+    lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
+    status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+    iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+    dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol)
+    rc = lib.mpcqp_build_solve_batch(
+        C.byref(dims), C.byref(cp), Bn, C.byref(opts), U.data_ptr(),
+        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), _stream_ptr())
+    _capi.check(rc, "mpcqp_build_solve_batch")
+    return BatchPlan(problem, U, status, iters, lam)
+
+
+class PreparedSolve:
+    """A fused build+solve bound to fixed device buffers: ``launch()`` costs one
+    C call (no allocation, no struct marshalling), so a receding-horizon loop or a
+    benchmark can enqueue steps back-to-back or capture them in a HIP graph.
+
+    Update problem data IN PLACE (``problem.initial_state.copy_(x)``) between
+    launches; if a tensor of the problem is replaced, call ``rebind()``.
+    """
+
+    def __init__(self, problem: BatchMPCProblem, return_multipliers: bool = False,
+                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None):
+        torch = _torch()
+        self._lib = _capi.load()
+        self.problem = problem
+        Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
+        self.U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
+        self.lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
+        self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+        self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+        self._opts = _opts(max_iter, feas_tol)
+        self.rebind()
+
+    def rebind(self) -> None:
+        self._dims, self._cp = self.problem.dims(), self.problem.c_problem()
+        self._args = (
+            C.byref(self._dims), C.byref(self._cp), self.problem.batch_size, C.byref(self._opts),
+            self.U.data_ptr(), None if self.lam is None else self.lam.data_ptr(),
+            self.status.data_ptr(), self.iters.data_ptr(),
+        )
+
+    def launch(self, stream=None) -> None:
+        """Enqueue one fused build+solve of the whole batch on ``stream``
+        (default: torch's current stream). Asynchronous."""
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        rc = self._lib.mpcqp_build_solve_batch(*self._args, sp)
+        if rc != 0:
+            _capi.check(rc, "mpcqp_build_solve_batch")
+
+    @property
+    def plan(self) -> BatchPlan:
+        return BatchPlan(self.problem, self.U, self.status, self.iters, self.lam)
+
+
+class BatchMPCQP:
+    """Condensed QPs of a batch, kept in HBM (batched ``MPCQP``, mpc_qp.py:21-163)."""
+
+    def __init__(self, problem: BatchMPCProblem, keep_propagators: bool = True):
+        torch = _torch()
+        lib = _capi.load()
+        Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
+        nx, N = problem.state_dim, problem.nb_timesteps
+        mk = lambda *shape: torch.empty(shape, dtype=problem.dtype, device=problem.device)  # noqa: E731
+        self.P, self.q, self.G, self.h = mk(Bn, n, n), mk(Bn, n), mk(Bn, m, n), mk(Bn, m)
+        self.Phi_all = mk(Bn, (N + 1) * nx, nx) if keep_propagators else None
+        self.Psi_all = mk(Bn, (N + 1) * nx, n) if keep_propagators else None
+        dims, cp = problem.dims(), problem.c_problem()
+        rc = lib.mpcqp_condense_batch(
+            C.byref(dims), C.byref(cp), Bn, self.P.data_ptr(), self.q.data_ptr(), self.G.data_ptr(),
+            self.h.data_ptr(), None if self.Phi_all is None else self.Phi_all.data_ptr(),
+            None if self.Psi_all is None else self.Psi_all.data_ptr(), _stream_ptr())
+        _capi.check(rc, "mpcqp_condense_batch")
+        self.nb_timesteps, self.state_dim = N, nx
+
+    def _update(self, problem: BatchMPCProblem, do_q: bool, do_h: bool) -> None:
+        if self.Phi_all is None:
+            raise ProblemDefinitionError("BatchMPCQP was built with keep_propagators=False")
+        lib = _capi.load()
+        dims, cp = problem.dims(), problem.c_problem()
+        rc = lib.mpcqp_update_vectors_batch(
+            C.byref(dims), C.byref(cp), self.Phi_all.data_ptr(), int(self.Phi_all.stride(0)),
+            self.Psi_all.data_ptr(), int(self.Psi_all.stride(0)), problem.batch_size,
+            self.q.data_ptr() if do_q else None, self.h.data_ptr() if do_h else None, _stream_ptr())
+        _capi.check(rc, "mpcqp_update_vectors_batch")
+
+    def update_cost_vector(self, problem: BatchMPCProblem) -> None:
+        """q for new x0 / goal / targets (mpc_qp.py:129-149)."""
+        self._update(problem, True, False)
+
+    def update_constraint_vector(self, problem: BatchMPCProblem) -> None:
+        """h = e - C Phi x0 for a new x0 (mpc_qp.py:151-163)."""
+        self._update(problem, False, True)
+
+    def solve(self, return_multipliers: bool = False, max_iter=None, feas_tol=None):
+        return solve_qp_batch(self.P, self.q, self.G, self.h, return_multipliers, max_iter, feas_tol)
+
+
+def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, feas_tol=None):
+    """Batched dense QP solve, ``min 1/2 x'Px + q'x s.t. Gx <= h`` per item
+    (replaces ``qpsolvers.solve_problem`` at solve_mpc.py:43).
+    Returns (x [B,n], lam [B,m] | None, status [B], iters [B])."""
+    torch = _torch()
+    lib = _capi.load()
+    P, q = P.contiguous(), q.contiguous()
+    Bn, n = q.shape
+    m = 0 if G is None else int(G.shape[1])
+    G = None if G is None else G.contiguous()
+    h = None if h is None else h.contiguous()
+    x = torch.empty((Bn, n), dtype=P.dtype, device=P.device)
+    lam = torch.empty((Bn, m), dtype=P.dtype, device=P.device) if return_multipliers else None
+    status = torch.empty((Bn,), dtype=torch.int32, device=P.device)
+    iters = torch.empty((Bn,), dtype=torch.int32, device=P.device)
+    opts = _opts(max_iter, feas_tol)
+    rc = lib.mpcqp_solve_batch(
+        n, m, _dtype_code(P.dtype), P.data_ptr(), q.data_ptr(), None if m == 0 else G.data_ptr(),
+        None if m == 0 else h.data_ptr(), Bn, C.byref(opts), x.data_ptr(),
+        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), _stream_ptr())
+    _capi.check(rc, "mpcqp_solve_batch")
+    return x, lam, status, iters
+
+
+def rollout_batch(problem: BatchMPCProblem, U, initial_state=None):
+    """X [B, N+1, nx] from U [B, N*nu] (``mpcqp_rollout_batch``; mpc_problem.py:316-335)."""
+    torch = _torch()
+    lib = _capi.load()
+    x0 = problem.initial_state if initial_state is None else initial_state
+    Bn = int(x0.shape[0])
+    U = U.reshape(Bn, -1).contiguous()
+    X = torch.empty((Bn, problem.nb_timesteps + 1, problem.state_dim), dtype=problem.dtype, device=problem.device)
+    dims = problem.dims()
+    opA, opB, opx = problem._operand(problem.A), problem._operand(problem.B), problem._operand(x0)
+    rc = lib.mpcqp_rollout_batch(C.byref(dims), C.byref(opA), C.byref(opB), C.byref(opx), U.data_ptr(), Bn,
+                                 X.data_ptr(), _stream_ptr())
+    _capi.check(rc, "mpcqp_rollout_batch")
+    return X
+
+
+def rollout_single(problem, initial_state, inputs) -> np.ndarray:
+    """``MPCProblem.integrate`` for one host problem, computed by the rollout kernel."""
+    torch = _torch()
+    device = _capi.require_gpu()
+    N, nx, nu = problem.nb_timesteps, problem.state_dim, problem.input_dim
+    A = np.stack([np.asarray(problem.get_transition_state_matrix(k), dtype=float).reshape(nx, nx) for k in range(N)])
+    Bm = np.stack([np.asarray(problem.get_transition_input_matrix(k), dtype=float).reshape(nx, nu) for k in range(N)])
+    bp = BatchMPCProblem.__new__(BatchMPCProblem)
+    bp.dtype, bp.device = torch.float64, device
+    bp.state_dim, bp.input_dim, bp.nb_timesteps, bp.ineq_dim = nx, nu, N, 0
+    bp.A = _canon(_as_tensor(A, bp.dtype, device), (nx, nx), "A")
+    bp.B = _canon(_as_tensor(Bm, bp.dtype, device), (nx, nu), "B")
+    bp.C = bp.D = bp.e = bp.goal_state = bp.target_states = None
+    bp.terminal_cost_weight, bp.stage_state_cost_weight, bp.stage_input_cost_weight = 1.0, None, 1.0
+    bp.initial_state = _as_tensor(np.asarray(initial_state, dtype=float).reshape(1, nx), bp.dtype, device)
+    U = _as_tensor(np.asarray(inputs, dtype=float).reshape(1, N * nu), bp.dtype, device)
+    return rollout_batch(bp, U).cpu().numpy()[0]

@@ -1,0 +1,232 @@
+// mpcqp_capi.hip -- the extern "C" boundary declared in include/mpcqp.h.
+// Argument validation happens here, on the host, before any launch; kernels
+// live in mpcqp_lds.hip.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+using namespace mpcqp;
+
+namespace {
+
+size_t elem_size(int dtype) { return dtype == MPCQP_F64 ? 8 : 4; }
+
+int check_dims(const MpcqpDims *d)
+{
+    if (!d) return MPCQP_EINVAL;
+    if (d->dtype != MPCQP_F64 && d->dtype != MPCQP_F32) return MPCQP_EDTYPE;
+    if (d->nx <= 0 || d->nu <= 0 || d->N <= 0 || d->mk < 0) return MPCQP_EINVAL;
+    if (!(d->w_input > 0.0)) return MPCQP_EINVAL;  // mpc_problem.py:104-107
+    return 0;
+}
+
+int check_step(const MpcqpOperand &op, int64_t block)
+{
+    if (op.ptr && op.step_stride != 0 && op.step_stride != block) return MPCQP_ELAYOUT;
+    return 0;
+}
+
+int check_problem(const MpcqpDims *d, const MpcqpProblem *p)
+{
+    if (!p || !p->A.ptr || !p->B.ptr || !p->x0.ptr) return MPCQP_EINVAL;
+    if (d->mk > 0 && !p->e.ptr) return MPCQP_EINVAL;
+    if ((d->flags & MPCQP_Q_TERMINAL) && !p->goal.ptr) return MPCQP_EINVAL;
+    if ((d->flags & MPCQP_Q_STAGE) && !p->targets.ptr) return MPCQP_EINVAL;
+    int rc;
+    if ((rc = check_step(p->A, (int64_t)d->nx * d->nx))) return rc;
+    if ((rc = check_step(p->B, (int64_t)d->nx * d->nu))) return rc;
+    if ((rc = check_step(p->C, (int64_t)d->mk * d->nx))) return rc;
+    if ((rc = check_step(p->D, (int64_t)d->mk * d->nu))) return rc;
+    if ((rc = check_step(p->e, (int64_t)d->mk))) return rc;
+    return 0;
+}
+
+void fill_args(KernelArgs &ka, const MpcqpDims *d, const MpcqpProblem *p)
+{
+    memset(&ka, 0, sizeof(ka));
+    ka.nx = d->nx;
+    ka.nu = d->nu;
+    ka.N = d->N;
+    ka.mk = d->mk;
+    ka.n = d->N * d->nu;
+    ka.m = d->N * d->mk;
+    ka.flags = d->flags;
+    ka.wt = d->w_terminal;
+    ka.wx = d->w_stage;
+    ka.wu = d->w_input;
+    if (p) {
+        ka.A = p->A;
+        ka.B = p->B;
+        ka.C = p->C;
+        ka.D = p->D;
+        ka.e = p->e;
+        ka.x0 = p->x0;
+        ka.goal = p->goal;
+        ka.targets = p->targets;
+    }
+}
+
+void fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
+{
+    ka.max_iter = (o && o->max_iter > 0) ? o->max_iter : 10 * (ka.n + ka.m) + 10;
+    ka.tol = (o && o->feas_tol > 0.0) ? o->feas_tol : (dtype == MPCQP_F64 ? 1e-12 : 1e-5);
+}
+
+int layout_for(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype, Layout &L)
+{
+    L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, stepA, stepB, mode, elem_size(dtype));
+    if ((size_t)L.total * elem_size(dtype) > kLdsBytesPerCU) return MPCQP_ETOOLARGE;
+    if (ka.n > 256) return MPCQP_ETOOLARGE;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpcqp_abi_version(void) { return MPCQP_ABI_VERSION; }
+
+const char *mpcqp_error_string(int code)
+{
+    switch (code) {
+    case 0: return "ok";
+    case MPCQP_EINVAL: return "invalid argument";
+    case MPCQP_ETOOLARGE: return "problem does not fit the on-chip (LDS) path";
+    case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
+    case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}
+
+int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!bytes) return MPCQP_EINVAL;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, true, true, MODE_FUSED, elem_size(dims->dtype));
+    *bytes = (size_t)L.total * elem_size(dims->dtype);
+    return (*bytes > kLdsBytesPerCU || ka.n > 256) ? MPCQP_ETOOLARGE : 0;
+}
+
+int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, void *P,
+                         void *q, void *G, void *h, void *Phi, void *Psi, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_problem(dims, problem))) return rc;
+    if (batch < 0 || !P || !q || (dims->mk > 0 && (!G || !h))) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    ka.P = P;
+    ka.q = q;
+    ka.G = G;
+    ka.h = h;
+    ka.Phi = Phi;
+    ka.Psi = Psi;
+    Layout L;
+    if ((rc = layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_CONDENSE, dims->dtype, L)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = dispatch_lds<MODE_CONDENSE>(ka, L, dims->dtype, batch, st))) return rc;
+    if (Phi) rc = launch_phi(ka, dims->dtype, batch, st);
+    return rc;
+}
+
+int mpcqp_update_vectors_batch(const MpcqpDims *dims, const MpcqpProblem *problem, const void *Phi,
+                               int64_t phi_batch_stride, const void *Psi, int64_t psi_batch_stride,
+                               int64_t batch, void *q, void *h, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!problem || !problem->x0.ptr || !Phi || batch < 0) return MPCQP_EINVAL;
+    if (q && !Psi) return MPCQP_EINVAL;
+    if (h && dims->mk > 0 && !problem->e.ptr) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_TERMINAL) && q && !problem->goal.ptr) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_STAGE) && q && !problem->targets.ptr) return MPCQP_EINVAL;
+    if (batch == 0 || (!q && !h)) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    ka.Phi = const_cast<void *>(Phi);
+    ka.Psi = const_cast<void *>(Psi);
+    ka.q = q;
+    ka.h = h;
+    return launch_update(ka, dims->dtype, phi_batch_stride, psi_batch_stride, batch, (hipStream_t)stream);
+}
+
+int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const void *q, const void *G,
+                      const void *h, int64_t batch, const MpcqpSolveOpts *opts, void *x, void *lam,
+                      int32_t *status, int32_t *iters, void *stream)
+{
+    if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
+    if (n <= 0 || m < 0 || batch < 0 || !P || !q || !x || (m > 0 && (!G || !h))) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.n = n;
+    ka.m = m;
+    ka.nx = 1;
+    ka.nu = 1;
+    ka.N = n;
+    ka.P = const_cast<void *>(P);
+    ka.q = const_cast<void *>(q);
+    ka.G = const_cast<void *>(G);
+    ka.h = const_cast<void *>(h);
+    ka.U = x;
+    ka.lam = lam;
+    ka.status = status;
+    ka.iters = iters;
+    fill_opts(ka, opts, dtype);
+    Layout L;
+    int rc = layout_for(ka, false, false, MODE_SOLVE, dtype, L);
+    if (rc) return rc;
+    return dispatch_lds<MODE_SOLVE>(ka, L, dtype, batch, (hipStream_t)stream);
+}
+
+int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
+                            const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status,
+                            int32_t *iters, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_problem(dims, problem))) return rc;
+    if (batch < 0 || !U) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    ka.U = U;
+    ka.lam = lam;
+    ka.status = status;
+    ka.iters = iters;
+    fill_opts(ka, opts, dims->dtype);
+    Layout L;
+    if ((rc = layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_FUSED, dims->dtype, L)))
+        return rc;
+    return dispatch_lds<MODE_FUSED>(ka, L, dims->dtype, batch, (hipStream_t)stream);
+}
+
+int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const MpcqpOperand *B,
+                        const MpcqpOperand *x0, const void *U, int64_t batch, void *X, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!A || !B || !x0 || !A->ptr || !B->ptr || !x0->ptr || !U || !X || batch < 0) return MPCQP_EINVAL;
+    if (dims->nx > 64) return MPCQP_ETOOLARGE;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    ka.A = *A;
+    ka.B = *B;
+    ka.x0 = *x0;
+    ka.U = const_cast<void *>(U);
+    ka.X = X;
+    return launch_rollout(ka, dims->dtype, batch, (hipStream_t)stream);
+}
+
+}  // extern "C"

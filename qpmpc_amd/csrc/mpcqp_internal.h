@@ -1,0 +1,91 @@
+// Internal declarations shared by the kernel translation units and the C ABI.
+#ifndef MPCQP_INTERNAL_H_
+#define MPCQP_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+
+namespace mpcqp {
+
+enum { MODE_FUSED = 0, MODE_CONDENSE = 1, MODE_SOLVE = 2 };
+
+constexpr size_t kLdsBytesPerCU = 160 * 1024;  // gfx950: 160 KiB per CU
+
+// Everything a kernel needs, passed by value (kernarg segment, scalar loads).
+struct KernelArgs {
+    int nx, nu, N, mk, n, m, flags, max_iter;
+    double wt, wx, wu, tol;
+    MpcqpOperand A, B, C, D, e, x0, goal, targets;
+    // QP buffers: outputs of CONDENSE, inputs of SOLVE
+    void *P, *q, *G, *h, *Phi, *Psi;
+    // solve outputs
+    void *U, *lam;
+    int32_t *status, *iters;
+    // rollout
+    void *X;
+};
+
+// LDS carve, in elements of T. Matrices are row-major with odd row stride ld.
+struct Layout {
+    int ld;
+    int off_A, off_B, off_x0;  // staged dynamics (build only)
+    int off_X;                 // union: Psi blocks 1..N (build) | Q, S (solve)
+    int off_P, off_M;          // P -> L ; G -> M = G L^-T, row m holds q -> L^-1 q
+    int off_h, off_hs, off_s, off_y, off_z, off_d, off_r, off_u, off_cs, off_sn, off_inv, off_xs, off_red;
+    int off_int;               // int act[n+2], where[m], redi[8]
+    int total;
+};
+
+inline Layout make_layout(int nx, int nu, int N, int n, int m, bool stepA, bool stepB, int mode, size_t esz)
+{
+    Layout L{};
+    L.ld = (n + 1) | 1;
+    int o = 0;
+    auto take = [&](int cnt) {
+        int at = o;
+        o += (cnt + 1) & ~1;  // keep 8-byte alignment for float too
+        return at;
+    };
+    if (mode != MODE_SOLVE) {
+        L.off_A = take((stepA ? N : 1) * nx * nx);
+        L.off_B = take((stepB ? N : 1) * nx * nu);
+        L.off_x0 = take(nx);
+        const int psi = N * nx * L.ld, qs = 2 * n * L.ld;
+        L.off_X = take(psi > qs ? psi : qs);
+    } else {
+        L.off_A = L.off_B = L.off_x0 = 0;
+        L.off_X = take(2 * n * L.ld);
+    }
+    L.off_P = take(n * L.ld);
+    L.off_M = take((m + 1) * L.ld);
+    L.off_h = take(m);
+    L.off_hs = take(m);
+    L.off_s = take(m);
+    L.off_y = take(n);
+    L.off_z = take(n);
+    L.off_d = take(n);
+    L.off_r = take(n);
+    L.off_u = take(n + 1);
+    L.off_cs = take(n);
+    L.off_sn = take(n);
+    L.off_inv = take(n);
+    L.off_xs = take(n);
+    L.off_red = take(8);
+    L.off_int = o;
+    const int ints = (n + 2) + m + 8;
+    o += (int)(((size_t)ints * 4 + esz - 1) / esz);
+    o = (o + 1) & ~1;
+    L.total = o;
+    return L;
+}
+
+template <int MODE>
+int dispatch_lds(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st);
+int launch_phi(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st);
+int launch_update(const KernelArgs &ka, int dtype, int64_t phi_bs, int64_t psi_bs, int64_t batch, hipStream_t st);
+int launch_rollout(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st);
+
+}  // namespace mpcqp
+#endif

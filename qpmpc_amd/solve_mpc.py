@@ -1,0 +1,60 @@
+"""``solve_mpc``: one MPC problem in, one ``Plan`` out.
+
+Drop-in for the reference's entry point (qpmpc/solve_mpc.py:16-44). With a HIP
+solver name the whole of ``MPCQP(problem)`` + ``solve_problem`` runs in one fused
+kernel (``mpcqp_build_solve_batch``, batch of one). Any other name follows the
+reference literally -- condense (on the GPU) then hand ``mpc_qp.problem`` to
+``qpsolvers.solve_problem`` -- and needs that package installed.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .batch import HIP_SOLVERS, BatchMPCProblem, solve_mpc_batch
+from .exceptions import BackendError, ProblemDefinitionError
+from .mpc_problem import MPCProblem
+from .mpc_qp import MPCQP
+from .plan import Plan, Solution
+
+available_solvers = list(HIP_SOLVERS)
+
+
+def solve_mpc(problem: MPCProblem, solver: str = "hip_gi", sparse: bool = False, **kwargs) -> Plan:
+    """Solve a linear time-variant MPC problem.
+
+    Args:
+        problem: problem to solve (its initial state must be set).
+        solver: ``"hip_gi"`` (aliases ``"hip"``, ``"mpcqp_hip"``) for the fused
+            MI355X path; any qpsolvers backend name if qpsolvers is installed.
+        sparse: only meaningful for qpsolvers backends (CSC wrappers, as upstream).
+        kwargs: ``max_iter``, ``feas_tol`` for the HIP solver; forwarded verbatim
+            to ``qpsolvers.solve_problem`` otherwise.
+
+    Returns:
+        A ``Plan``; empty (``is_empty``) when no solution was found.
+    """
+    if problem.initial_state is None:
+        raise ProblemDefinitionError("initial state is undefined")
+    if solver in HIP_SOLVERS:
+        bp = BatchMPCProblem.from_problems([problem])
+        bplan = solve_mpc_batch(bp, solver=solver, return_multipliers=True,
+                                max_iter=kwargs.get("max_iter"), feas_tol=kwargs.get("feas_tol"))
+        status = int(bplan.status[0].item())
+        x = bplan.U[0].cpu().numpy()
+        z = bplan.multipliers[0].cpu().numpy()[bp.valid_rows]
+        qpsol = Solution(None, x=x if status == 0 else None, z=z if status == 0 else None,
+                         found=(status == 0), extras={"status": status, "iters": int(bplan.iters[0].item())})
+        return Plan(problem, qpsol)
+    try:
+        from qpsolvers import solve_problem
+    except ImportError as exn:
+        raise BackendError(
+            f"solver '{solver}' needs the qpsolvers package, which is not installed; "
+            f"HIP solvers available: {available_solvers}"
+        ) from exn
+    mpc_qp = MPCQP(problem, sparse=sparse)
+    qpsol = solve_problem(mpc_qp.problem, solver=solver, **kwargs)
+    return Plan(problem, qpsol)
+
+
+__all__ = ["solve_mpc", "available_solvers", "np"]

@@ -1,0 +1,289 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI vs the CPU oracle
+and vs the golden vectors captured from the reference.
+
+Tolerances (float64): condensed matrices 1e-12 relative to their max entry
+(different summation order than NumPy/BLAS, same algebra); solutions
+|u - u_ref|_inf <= 1e-6 * max(1, |u_ref|_inf) as BASELINE.json states, with the
+typical observed error ~1e-9.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import GOLDEN, all_cases, kkt_residuals, load_case
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max()) / max(1.0, float(np.abs(b).max()))
+
+
+def oracle_batch(w, max_iter=10000, tol=1e-12):
+    """CPU oracle on a workload dict -> (U, lam, status, iters)."""
+    return oracle.solve_workload(w, max_iter=max_iter, tol=tol)
+
+
+# ---------------------------------------------------------------- build half
+@pytest.mark.parametrize("name", all_cases())
+def test_mpcqp_matches_reference_fixture(name):
+    from qpmpc_amd import MPCQP
+
+    p, z = load_case(name)
+    qp = MPCQP(p)
+    for key in ("P", "q", "G", "h", "Phi", "Psi", "phi_last", "psi_last", "e"):
+        got, want = getattr(qp, key), z["out_" + key]
+        assert got.shape == want.shape, (name, key)
+        assert got.dtype == np.float64
+        assert _rel(got, want) <= 1e-12, (name, key, _rel(got, want))
+    assert np.array_equal(qp.P, qp.P.T)  # exactly symmetric like the reference
+
+
+def test_humanoid_first_rows_zero_and_update_vectors():
+    """Reference tests test_humanoid_one_step.py:72-75 and
+    test_update_constraint_vector.py:71-80, on the HIP path."""
+    from qpmpc_amd import MPCQP
+
+    p, _ = load_case("humanoid_one_step")
+    qp = MPCQP(p)
+    assert np.linalg.norm(qp.problem.G[0:2]) == 0.0
+    h0 = qp.h.copy()
+    qp.update_constraint_vector(p)
+    np.testing.assert_allclose(h0, qp.h, rtol=0, atol=1e-15)
+    z = np.load(os.path.join(GOLDEN, "humanoid_update_vectors.npz"))
+    p.update_initial_state(z["new_initial_state"])
+    p.update_goal_state(z["new_goal_state"])
+    qp.update_cost_vector(p)
+    qp.update_constraint_vector(p)
+    assert _rel(qp.q, z["q_updated"]) <= 1e-12
+    assert _rel(qp.h, z["h_updated"]) <= 1e-12
+
+
+def test_sparse_flag_wraps_csc():
+    from scipy.sparse import issparse
+
+    from qpmpc_amd import MPCQP
+
+    p, z = load_case("triple_integrator")
+    qp = MPCQP(p, sparse=True)
+    assert issparse(qp.P) and issparse(qp.G)
+    assert _rel(qp.P.toarray(), z["out_P"]) <= 1e-12
+
+
+# ---------------------------------------------------------------- solve half
+@pytest.mark.parametrize("name", all_cases(solved_only=True))
+def test_solve_mpc_matches_certified_solution(name):
+    from qpmpc_amd import solve_mpc
+
+    p, z = load_case(name)
+    plan = solve_mpc(p, solver="hip_gi")
+    assert not plan.is_empty
+    N, nu, nx = p.nb_timesteps, p.input_dim, p.state_dim
+    assert plan.inputs.shape == (N, nu)
+    assert plan.states.shape == (N + 1, nx)
+    assert plan.inputs.flatten().shape == (N * nu,)  # test_humanoid_one_step.py:77-85
+    assert plan.states.flatten().shape == ((N + 1) * nx,)
+    U = plan.inputs.ravel()
+    assert _rel(U, z["U_star"]) <= 1e-6, _rel(U, z["U_star"])
+    assert _rel(U, z["U_star"]) <= 1e-8  # what the method actually delivers in f64
+    stat, prim, dual, comp = kkt_residuals(z["out_P"], z["out_q"], z["out_G"], z["out_h"], U, plan.qpsol.z)
+    qs = 1.0 + np.abs(z["out_q"]).max()
+    assert stat <= 1e-9 * qs and prim <= 1e-9 and dual <= 1e-12 and comp <= 1e-8 * qs
+    assert _rel(plan.states, z["plan_states"]) <= 1e-8
+    np.testing.assert_allclose(plan.first_input, plan.inputs[0])
+
+
+def test_reference_known_answer_wip_stays_at_rest():
+    """tests/test_wheeled_inverted_pendulum.py:19-41 restated on the HIP path."""
+    from qpmpc_amd import solve_mpc
+    from qpmpc_amd.systems import WheeledInvertedPendulum
+
+    pend = WheeledInvertedPendulum()
+    assert pend.horizon_duration > 0.1 and pend.omega > 0.1
+    prob = pend.build_mpc_problem(terminal_cost_weight=10.0, stage_state_cost_weight=1.0, stage_input_cost_weight=1e-3)
+    x0 = np.zeros(pend.STATE_DIM)
+    prob.update_initial_state(x0)
+    prob.update_goal_state(x0.copy())
+    prob.update_target_states(np.zeros(pend.nb_timesteps * pend.STATE_DIM))
+    plan = solve_mpc(prob, solver="hip_gi")
+    assert plan is not None and plan.first_input is not None
+    state = pend.integrate(x0, plan.first_input, pend.sampling_period)
+    assert np.allclose(state, x0)
+
+
+def test_wip_plant_matches_reference_fixture():
+    from qpmpc_amd.systems import WheeledInvertedPendulum
+
+    z = np.load(os.path.join(GOLDEN, "wip_plant.npz"))
+    pend = WheeledInvertedPendulum()
+    A, B = pend.discretized_dynamics()
+    assert np.array_equal(A, z["A_default"]) and np.allclose(B, z["B_default"], rtol=1e-15, atol=0)
+    nxt = np.array([pend.integrate(s, a, float(z["dt"])) for s, a in zip(z["states"], z["accels"])])
+    np.testing.assert_allclose(nxt, z["next_states"], rtol=1e-14, atol=1e-15)
+    got = pend.integrate_batch(torch.tensor(z["states"], device="cuda"), torch.tensor(z["accels"], device="cuda"), float(z["dt"]))
+    np.testing.assert_allclose(got.cpu().numpy(), z["next_states"], rtol=1e-13, atol=1e-14)
+
+
+# ---------------------------------------------------------------- batches
+def _check_batch(w, nsample=None, utol=1e-6):
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    bp = to_batch_problem(w)
+    plan = solve_mpc_batch(bp, return_multipliers=True)
+    torch.cuda.synchronize()
+    U = plan.U.cpu().numpy()
+    status = plan.status.cpu().numpy()
+    Uo, lamo, sto, ito = oracle_batch(w)
+    assert np.array_equal(status == 0, sto == 0), (np.sum(status != 0), np.sum(sto != 0))
+    ok = sto == 0
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    err = np.abs(U[ok] - Uo[ok]) / scale
+    assert err.max() <= utol, err.max()
+    return plan, U, status, Uo, sto, err.max()
+
+
+def test_config2_triple_integrator_batch_4096_heterogeneous():
+    from qpmpc_amd.workloads import triple_integrator_batch
+
+    w = triple_integrator_batch(4096)
+    plan, U, status, Uo, sto, err = _check_batch(w)
+    assert (status == 0).all()
+    assert err <= 1e-8
+    # rollout kernel vs oracle rollout on a few items
+    X = plan.states.cpu().numpy()
+    for b in (0, 17, 4095):
+        Xo = oracle.rollout_one(w["A"][b], w["B"][b], w["x0"][b], Uo[b])
+        assert _rel(X[b], Xo) <= 1e-8
+
+
+def test_config2_shared_lti_mode_equals_heterogeneous():
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem, triple_integrator_batch
+
+    wh = triple_integrator_batch(512)
+    ws = triple_integrator_batch(512, heterogeneous=False)
+    Uh = solve_mpc_batch(to_batch_problem(wh)).U
+    Us = solve_mpc_batch(to_batch_problem(ws)).U
+    assert torch.equal(Uh, Us)
+
+
+def test_config4_humanoid_sweep_with_infeasible_items():
+    from qpmpc_amd.workloads import humanoid_batch
+
+    w = humanoid_batch(8192)
+    plan, U, status, Uo, sto, err = _check_batch(w)
+    assert set(np.unique(status)) <= {0, 2}
+    assert np.array_equal(status == 2, sto == 2)
+    assert (U[status != 0] == 0).all()  # unsolved rows are zeroed, never NaN
+    assert np.isfinite(U).all()
+
+
+def test_config3_wip_n50_batch():
+    from qpmpc_amd.workloads import wip_batch
+
+    w = wip_batch(64)
+    _check_batch(w)
+    # a saturating state so that the input box is active
+    w2 = wip_batch(32, seed=9)
+    w2["x0"][:, 1] += 0.3
+    w2["x0"][:, 3] += 1.0
+    pend = w2["pendulum"]
+    ts = np.stack([pend.target_states(x, 0.5) for x in w2["x0"]])
+    w2["goal"], w2["targets"] = ts[:, -4:], ts[:, :-4]
+    plan, U, status, Uo, sto, err = _check_batch(w2)
+    assert np.abs(U).max() >= 10.0 - 1e-9  # the box is hit
+
+
+def test_random_ltv_batch_with_c_and_d():
+    rng = np.random.default_rng(42)
+    B, nx, nu, N, mk = 200, 5, 2, 7, 3
+    A = np.eye(nx) + 0.3 * rng.standard_normal((B, N, nx, nx))
+    Bm = rng.standard_normal((B, N, nx, nu))
+    Cm = rng.standard_normal((B, N, mk, nx))
+    D = rng.standard_normal((B, N, mk, nu))
+    x0 = 0.1 * rng.standard_normal((B, nx))
+    e = np.zeros((B, N, mk))
+    for b in range(B):
+        x = x0[b].copy()
+        for k in range(N):
+            e[b, k] = Cm[b, k] @ x + 0.05 + 0.5 * np.abs(rng.standard_normal(mk))
+            x = A[b, k] @ x
+    w = dict(A=A, B=Bm, C=Cm, D=D, e=e, N=N, wt=2.0, wx=0.5, wu=1e-2, x0=x0,
+             goal=rng.standard_normal((B, nx)), targets=rng.standard_normal((B, N * nx)))
+    _check_batch(w)
+
+
+def test_solve_qp_batch_random_dense_qps():
+    from qpmpc_amd import solve_qp_batch
+
+    rng = np.random.default_rng(3)
+    Bn, n, m = 300, 10, 24
+    Ps, qs, Gs, hs = [], [], [], []
+    for _ in range(Bn):
+        M = rng.standard_normal((n, n))
+        Ps.append(M @ M.T + 1e-2 * np.eye(n))
+        qs.append(3 * rng.standard_normal(n))
+        Gs.append(rng.standard_normal((m, n)))
+        hs.append(rng.standard_normal(m) + 0.3)
+    P, q, G, h = (torch.tensor(np.stack(a), device="cuda") for a in (Ps, qs, Gs, hs))
+    x, lam, status, iters = solve_qp_batch(P, q, G, h, return_multipliers=True)
+    x, lam, status = x.cpu().numpy(), lam.cpu().numpy(), status.cpu().numpy()
+    for b in range(Bn):
+        xo, lo, so, _ = oracle.gi_solve(Ps[b], qs[b], Gs[b], hs[b])
+        assert (status[b] == 0) == (so == 0)
+        if so == 0:
+            assert _rel(x[b], xo) <= 1e-7
+            stat, prim, dual, comp = kkt_residuals(Ps[b], qs[b], Gs[b], hs[b], x[b], lam[b])
+            assert stat <= 1e-8 and prim <= 1e-9 and dual <= 1e-12
+        else:
+            assert status[b] == so
+
+
+def test_status_codes_not_pd_and_unconstrained():
+    from qpmpc_amd import solve_qp_batch
+
+    P = torch.tensor([[[1.0, 2.0], [2.0, 1.0]], [[2.0, 0.0], [0.0, 2.0]]], device="cuda")
+    q = torch.tensor([[0.0, 0.0], [-2.0, 4.0]], device="cuda")
+    G = torch.zeros((2, 1, 2), device="cuda", dtype=torch.float64)
+    h = torch.ones((2, 1), device="cuda", dtype=torch.float64)
+    x, _, status, _ = solve_qp_batch(P, q, G, h)
+    assert status.cpu().tolist() == [3, 0]
+    np.testing.assert_allclose(x[1].cpu().numpy(), [1.0, -2.0], atol=1e-14)
+
+
+def test_float32_path_tolerance():
+    """fp32 instantiation: tolerance 1e-3 * max(1, |u|) vs the f64 oracle."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
+
+    w = humanoid_batch(256)
+    plan = solve_mpc_batch(to_batch_problem(w, dtype=torch.float32))
+    U = plan.U.double().cpu().numpy()
+    st = plan.status.cpu().numpy()
+    Uo, _, sto, _ = oracle_batch(w)
+    ok = (st == 0) & (sto == 0)
+    assert ok.sum() >= 0.9 * (sto == 0).sum()
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-3
+
+
+def test_c_abi_argument_errors():
+    from qpmpc_amd import _capi
+
+    lib = _capi.load()
+    d = _capi.Dims(3, 1, 16, 2, 7, 0, 1.0, 0.0, 1e-6)
+    b = C.c_size_t(0)
+    assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == -3  # MPCQP_EDTYPE
+    d = _capi.Dims(3, 1, 16, 2, 0, 0, 1.0, 0.0, -1.0)
+    assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == -1  # w_input must be > 0
+    d = _capi.Dims(12, 4, 64, 16, 0, 15, 10.0, 1.0, 1e-2)
+    assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == -2  # does not fit LDS
