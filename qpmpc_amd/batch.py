@@ -296,8 +296,17 @@ class BatchMPCProblem:
 
 
 def _stream_ptr():
+    """hipStream_t of torch's current stream; raises BackendError without a GPU
+    (every launch goes through here, so nothing can silently run elsewhere)."""
     torch = _torch()
+    _capi.require_gpu()
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_on_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and t.device.type != "cuda":
+            raise BackendError(f"operand on {t.device}: the HIP path needs device-resident tensors (no CPU fallback)")
 
 
 def _opts(max_iter=None, feas_tol=None):
@@ -349,6 +358,7 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
         raise BackendError(f"solver '{solver}' is not a batched backend; available: {HIP_SOLVERS}")
     torch = _torch()
     lib = _capi.load()
+    _require_on_gpu(problem.initial_state)
     Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
     U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
     lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
@@ -375,6 +385,7 @@ class PreparedSolve:
                  max_iter: Optional[int] = None, feas_tol: Optional[float] = None):
         torch = _torch()
         self._lib = _capi.load()
+        _require_on_gpu(problem.initial_state)
         self.problem = problem
         Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
         self.U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
@@ -411,6 +422,7 @@ class BatchMPCQP:
     def __init__(self, problem: BatchMPCProblem, keep_propagators: bool = True):
         torch = _torch()
         lib = _capi.load()
+        _require_on_gpu(problem.initial_state)
         Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
         nx, N = problem.state_dim, problem.nb_timesteps
         mk = lambda *shape: torch.empty(shape, dtype=problem.dtype, device=problem.device)  # noqa: E731
@@ -454,6 +466,7 @@ def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, 
     Returns (x [B,n], lam [B,m] | None, status [B], iters [B])."""
     torch = _torch()
     lib = _capi.load()
+    _require_on_gpu(P, q, G, h)
     P, q = P.contiguous(), q.contiguous()
     Bn, n = q.shape
     m = 0 if G is None else int(G.shape[1])
