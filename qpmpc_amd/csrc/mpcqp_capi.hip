@@ -2,6 +2,7 @@
 // Argument validation happens here, on the host, before any launch; kernels
 // live in mpcqp_lds.hip.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "mpcqp.h"
@@ -80,6 +81,24 @@ int layout_for(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype
     if ((size_t)L.total * elem_size(dtype) > kLdsBytesPerCU) return MPCQP_ETOOLARGE;
     if (ka.n > 256) return MPCQP_ETOOLARGE;
     return 0;
+}
+
+// MPCQP_FORCE_LDS=1 routes small problems through the general LDS kernel too
+// (A/B measurements and cross-checking the two solver formulations).
+bool force_lds()
+{
+    const char *v = getenv("MPCQP_FORCE_LDS");
+    return v && v[0] == '1';
+}
+
+template <int MODE>
+int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t batch, hipStream_t st)
+{
+    if (!force_lds() && w64_eligible(ka, MODE, dtype)) return launch_w64(ka, MODE, dtype, batch, st);
+    Layout L;
+    int rc = layout_for(ka, stepA, stepB, MODE, dtype, L);
+    if (rc) return rc;
+    return dispatch_lds<MODE>(ka, L, dtype, batch, st);
 }
 
 }  // namespace
@@ -183,10 +202,7 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const 
     ka.status = status;
     ka.iters = iters;
     fill_opts(ka, opts, dtype);
-    Layout L;
-    int rc = layout_for(ka, false, false, MODE_SOLVE, dtype, L);
-    if (rc) return rc;
-    return dispatch_lds<MODE_SOLVE>(ka, L, dtype, batch, (hipStream_t)stream);
+    return run_solver<MODE_SOLVE>(ka, false, false, dtype, batch, (hipStream_t)stream);
 }
 
 int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
@@ -205,10 +221,9 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     ka.status = status;
     ka.iters = iters;
     fill_opts(ka, opts, dims->dtype);
-    Layout L;
-    if ((rc = layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_FUSED, dims->dtype, L)))
-        return rc;
-    return dispatch_lds<MODE_FUSED>(ka, L, dims->dtype, batch, (hipStream_t)stream);
+    if (const char *dbg = getenv("MPCQP_STAMP_PTR")) ka.X = (void *)strtoull(dbg, nullptr, 0);  // dev probe only
+    return run_solver<MODE_FUSED>(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, dims->dtype, batch,
+                                  (hipStream_t)stream);
 }
 
 int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const MpcqpOperand *B,

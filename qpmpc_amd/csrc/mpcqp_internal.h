@@ -83,6 +83,9 @@ inline Layout make_layout(int nx, int nu, int N, int n, int m, bool stepA, bool 
 
 template <int MODE>
 int dispatch_lds(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st);
+// small-problem kernel (mpcqp_w64.hip): one problem per wavefront
+bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
+int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);
 int launch_phi(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st);
 int launch_update(const KernelArgs &ka, int dtype, int64_t phi_bs, int64_t psi_bs, int64_t batch, hipStream_t st);
 int launch_rollout(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st);

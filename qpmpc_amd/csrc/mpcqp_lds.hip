@@ -290,9 +290,14 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
         Qm[i] = (a == b) ? T(1) : T(0);
         Sm[i] = T(0);
     }
+    // hs[i] = 1/|M_i|: rows are ranked by their distance to the hyperplane in the
+    // P^-1 metric (classic Goldfarb-Idnani rule: fewest iterations, hardly any drop)
     for (int i = tid; i < m; i += BS) {
         where[i] = -1;
-        hs[i] = T(1) / (T(1) + fabs(hv[i]));
+        const T *row = Mm + i * ld;
+        T nn = T(0);
+        for (int k = 0; k < n; ++k) nn += row[k] * row[k];
+        hs[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
     }
     for (int i = tid; i <= n; i += BS) u[i] = T(0);
     bsync();
@@ -309,14 +314,15 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
             T s = hv[i];
             for (int k = 0; k < n; ++k) s -= row[k] * y[k];
             sv[i] = s;
-            const T key = (where[i] >= 0) ? INF : s * hs[i];
+            const bool violated = (where[i] < 0) && (s < -(tol + tol * fabs(hv[i])));
+            const T key = violated ? s * hs[i] : INF;
             if (key < best) {
                 best = key;
                 bi = i;
             }
         }
         block_argmin<T, WAVES>(best, bi, redv, redi, tid);
-        if (!(best < -tol)) {
+        if (!(best < INF)) {
             status = MPCQP_SOLVED;
             break;
         }

@@ -1,0 +1,851 @@
+// mpcqp_w64.hip -- gfx950 kernel for SMALL problems (n <= 16 variables,
+// m <= 63 inequality rows, nx <= 4): ONE PROBLEM PER WAVEFRONT.
+//
+// Replaces the same reference code as mpcqp_lds.hip (qpmpc/mpc_qp.py:53-149 for
+// the build, qpsolvers.solve_problem at qpmpc/solve_mpc.py:43 for the solve),
+// for the sizes of BASELINE configs 1, 2 and 4 (nx=3, nu=1, N=16 -> n=16, m=32).
+//
+// Design rule (measured): with four wavefronts per SIMD the
+// kernel is bound by INSTRUCTION ISSUE, so everything is arranged to need few,
+// wide instructions: 16-element vectors are exchanged through LDS and read back
+// as broadcast ds_read_b128; row data that is only ever indexed statically lives
+// in VGPRs; nothing is indexed dynamically in registers; no per-element uniform
+// branches; the active set lives in 16 fixed SLOTS (no compaction on a drop).
+//
+// Lane roles:
+//   lane i <  m   constraint i : row M_i of M = G L^-T in 16 registers, slack s_i
+//   lane m        the q row    : L^-1 q  (-> y0)
+//   lane a < 16   slot a of the active set: multiplier lam_a, constraint act_a;
+//                 during the factorisation: row a of P -> L in 16 registers;
+//                 at the end: y_a -> u_a.
+// LDS per problem (7 KB): W = (M_A M_A')^-1 as 16 padded rows, the active rows
+// M_A by slot, L, and five 16-vectors used as broadcast buffers.
+//
+// Solver = dual active set (Goldfarb-Idnani 1983) in "inverse Gram" form; the
+// primal iterate is implied by the multipliers (y = y0 - M_A' lam):
+//   k_i = M_i . M_p ;  r = W k_A ;  z = -M_p + M_A' r ;  d2 = |z|^2
+//   step t = min(t1 = min lam_a / r_a, t2 = -s_p / d2) ;  s_i -= t M_i . z
+//   add : W <- [[W + r r'/d2, -r/d2], [-r'/d2, 1/d2]] into a free slot
+//   drop: W <- W - w_l w_l'/W_ll, slot l cleared
+// d2 comes from z itself (no cancellation); the final multipliers get one step of
+// iterative refinement and the slacks are re-evaluated from scratch before the
+// solution is accepted.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace w64 {
+
+constexpr int NV = 16;  // padded number of variables / slots
+
+// ------------------------------------------------------------ lane primitives
+__device__ __forceinline__ double bcast(double x, int lane)  // lane must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bcast(float x, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+__device__ __forceinline__ int bcast(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+
+template <int CTRL> __device__ __forceinline__ int dpp(int x)
+{
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ unsigned dpp(unsigned x) { return (unsigned)dpp<CTRL>((int)x); }
+template <int CTRL> __device__ __forceinline__ float dpp(float x) { return __int_as_float(dpp<CTRL>(__float_as_int(x))); }
+template <int CTRL> __device__ __forceinline__ double dpp(double x)
+{
+    return __hiloint2double(dpp<CTRL>(__double2hiint(x)), dpp<CTRL>(__double2loint(x)));
+}
+constexpr int ROR8 = 0x128, ROR4 = 0x124, ROR2 = 0x122, ROR1 = 0x121;  // rotate within a row of 16
+
+template <typename T> __device__ __forceinline__ T row_sum(T v)  // all-reduce inside each row of 16
+{
+    v += dpp<ROR8>(v);
+    v += dpp<ROR4>(v);
+    v += dpp<ROR2>(v);
+    v += dpp<ROR1>(v);
+    return v;
+}
+__device__ __forceinline__ unsigned row_min(unsigned v)
+{
+    v = min(v, dpp<ROR8>(v));
+    v = min(v, dpp<ROR4>(v));
+    v = min(v, dpp<ROR2>(v));
+    v = min(v, dpp<ROR1>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min(unsigned v)  // uniform result
+{
+    v = row_min(v);
+    const unsigned a = (unsigned)bcast((int)v, 0), b = (unsigned)bcast((int)v, 16);
+    const unsigned c = (unsigned)bcast((int)v, 32), d = (unsigned)bcast((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// order-preserving map of a floating-point value onto unsigned integers
+__device__ __forceinline__ void ordered(double x, unsigned &hi, unsigned &lo)
+{
+    const unsigned h = (unsigned)__double2hiint(x), l = (unsigned)__double2loint(x);
+    const bool neg = h & 0x80000000u;
+    hi = neg ? ~h : (h | 0x80000000u);
+    lo = neg ? ~l : l;
+}
+__device__ __forceinline__ void ordered(float x, unsigned &hi, unsigned &lo)
+{
+    const unsigned h = __float_as_uint(x);
+    hi = (h & 0x80000000u) ? ~h : (h | 0x80000000u);
+    lo = 0;
+}
+// arg-min over row 0 (lanes 0..15) with take==true; ties -> lowest lane; 64 if none.
+// Exact except for the 6 low mantissa bits replaced by the lane id.
+template <typename T> __device__ __forceinline__ int argmin_row0(T x, bool take, int lane)
+{
+    unsigned hi, lo;
+    ordered(x, hi, lo);
+    hi = take ? hi : 0xffffffffu;
+    const unsigned mhi = (unsigned)bcast((int)row_min(hi), 0);
+    if (mhi == 0xffffffffu) return 64;
+    const unsigned low = (sizeof(T) == 8) ? ((lo & ~63u) | (unsigned)lane) : (unsigned)lane;
+    const unsigned k2 = (take && hi == mhi) ? low : 0xffffffffu;
+    return (int)((unsigned)bcast((int)row_min(k2), 0) & 63u);
+}
+// cheap selection over the wavefront (heuristic quality is enough): one reduction
+template <typename T> __device__ __forceinline__ int argmin_coarse(T x, bool take, int lane)
+{
+    unsigned hi, lo;
+    ordered(x, hi, lo);
+    const unsigned key = take ? ((hi & ~63u) | (unsigned)lane) : 0xffffffffu;
+    const unsigned mk = wave_min(key);
+    return mk == 0xffffffffu ? 64 : (int)(mk & 63u);
+}
+
+// ------------------------------------------------------------ 16-vectors in LDS
+template <typename T> struct Vec;
+template <> struct Vec<double> {
+    using type = double2;
+    static constexpr int W = 2;
+    static constexpr int LDW = 18;  // W row stride: 144 B, 16 lanes hit 16 distinct 16-B slots
+};
+template <> struct Vec<float> {
+    using type = float4;
+    static constexpr int W = 4;
+    static constexpr int LDW = 20;  // 80 B rows, same property
+};
+template <typename T> __device__ __forceinline__ void ld16(T (&d)[NV], const T *src)
+{
+    using V = typename Vec<T>::type;
+    const V *p = reinterpret_cast<const V *>(src);
+#pragma unroll
+    for (int i = 0; i < NV / Vec<T>::W; ++i) {
+        const V t = p[i];
+        if constexpr (Vec<T>::W == 2) {
+            d[2 * i] = t.x;
+            d[2 * i + 1] = t.y;
+        } else {
+            d[4 * i] = t.x;
+            d[4 * i + 1] = t.y;
+            d[4 * i + 2] = t.z;
+            d[4 * i + 3] = t.w;
+        }
+    }
+}
+template <typename T> __device__ __forceinline__ void st16(T *dst, const T (&s)[NV])
+{
+    using V = typename Vec<T>::type;
+    V *p = reinterpret_cast<V *>(dst);
+#pragma unroll
+    for (int i = 0; i < NV / Vec<T>::W; ++i) {
+        V t;
+        if constexpr (Vec<T>::W == 2) {
+            t.x = s[2 * i];
+            t.y = s[2 * i + 1];
+        } else {
+            t.x = s[4 * i];
+            t.y = s[4 * i + 1];
+            t.z = s[4 * i + 2];
+            t.w = s[4 * i + 3];
+        }
+        p[i] = t;
+    }
+}
+// Register pressure is what decides occupancy here (4 wavefronts per SIMD need
+// <= 128 VGPRs), so 16-vectors coming from LDS are consumed in two halves of 8 and
+// a scheduling barrier keeps the second half's loads from being hoisted.
+constexpr int HV = 8;
+template <typename T> __device__ __forceinline__ void ld8(T (&d)[HV], const T *src)
+{
+    using V = typename Vec<T>::type;
+    const V *p = reinterpret_cast<const V *>(src);
+#pragma unroll
+    for (int i = 0; i < HV / Vec<T>::W; ++i) {
+        const V t = p[i];
+        if constexpr (Vec<T>::W == 2) {
+            d[2 * i] = t.x;
+            d[2 * i + 1] = t.y;
+        } else {
+            d[4 * i] = t.x;
+            d[4 * i + 1] = t.y;
+            d[4 * i + 2] = t.z;
+            d[4 * i + 3] = t.w;
+        }
+    }
+}
+__device__ __forceinline__ void half_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Make a value opaque at this point: the compiler can neither sink the
+// computation that produced it below here nor keep its operands alive instead
+// (without this the trailing updates of the factorisation are deferred and every
+// exchanged column stays live -> hundreds of bytes of scratch).
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(float &x) { asm volatile("" : "+v"(x)); }
+
+// sum_k a[k] * v[k] with a in registers and v a 16-vector in LDS (broadcast reads)
+template <typename T> __device__ __forceinline__ T dot_reg_lds(const T (&a)[NV], const T *v)
+{
+    T acc0 = T(0), acc1 = T(0);
+#pragma unroll
+    for (int h = 0; h < NV; h += HV) {
+        T b[HV];
+        ld8(b, v + h);
+#pragma unroll
+        for (int k = 0; k < HV; k += 2) {
+            acc0 += a[h + k] * b[k];
+            acc1 += a[h + k + 1] * b[k + 1];
+        }
+        half_fence();
+    }
+    return acc0 + acc1;
+}
+// sum_k a[k] * v[k] with both operands in LDS (a: per-lane row, v: broadcast vector)
+template <typename T> __device__ __forceinline__ T dot_lds_lds(const T *a, const T *v)
+{
+    T acc0 = T(0), acc1 = T(0);
+#pragma unroll
+    for (int h = 0; h < NV; h += HV) {
+        T x[HV], b[HV];
+        ld8(x, a + h);
+        ld8(b, v + h);
+#pragma unroll
+        for (int k = 0; k < HV; k += 2) {
+            acc0 += x[k] * b[k];
+            acc1 += x[k + 1] * b[k + 1];
+        }
+        half_fence();
+    }
+    return acc0 + acc1;
+}
+// row[k] += c * v[k] for a 16-row in LDS (read-modify-write) and a broadcast vector v;
+// zero==true clears the row instead
+template <typename T> __device__ __forceinline__ void axpy_row_lds(T *row, T c, const T *v, bool zero)
+{
+    using V = typename Vec<T>::type;
+#pragma unroll
+    for (int h = 0; h < NV; h += HV) {
+        T x[HV], b[HV];
+        ld8(x, row + h);
+        ld8(b, v + h);
+#pragma unroll
+        for (int k = 0; k < HV; ++k) x[k] = zero ? T(0) : x[k] + c * b[k];
+        V *p = reinterpret_cast<V *>(row + h);
+#pragma unroll
+        for (int i = 0; i < HV / Vec<T>::W; ++i) {
+            V t;
+            if constexpr (Vec<T>::W == 2) {
+                t.x = x[2 * i];
+                t.y = x[2 * i + 1];
+            } else {
+                t.x = x[4 * i];
+                t.y = x[4 * i + 1];
+                t.z = x[4 * i + 2];
+                t.w = x[4 * i + 3];
+            }
+            p[i] = t;
+        }
+        half_fence();
+    }
+}
+// acc += sum_a v[a] * col[a * NV] : a 16-vector against a strided column (slot rows)
+template <typename T> __device__ __forceinline__ T dot_vec_col(const T *v, const T *col, T acc)
+{
+    T acc1 = T(0);
+#pragma unroll
+    for (int h = 0; h < NV; h += HV) {
+        T b[HV];
+        ld8(b, v + h);
+#pragma unroll
+        for (int a = 0; a < HV; a += 2) {
+            acc += b[a] * col[(h + a) * NV];
+            acc1 += b[a + 1] * col[(h + a + 1) * NV];
+        }
+        half_fence();
+    }
+    return acc + acc1;
+}
+// wavefront-level ordering of LDS traffic (a 64-thread workgroup needs no s_barrier)
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+template <typename T> struct Cst;
+template <> struct Cst<double> {
+    static __device__ __forceinline__ double inf() { return HUGE_VAL; }
+    static __device__ __forceinline__ double dep() { return 1e-14; }  // |z|^2/|M_p|^2 below: dependent
+    static __device__ __forceinline__ double rs(double x) { return rsqrt(x); }
+};
+template <> struct Cst<float> {
+    static __device__ __forceinline__ float inf() { return HUGE_VALF; }
+    static __device__ __forceinline__ float dep() { return 1e-6f; }
+    static __device__ __forceinline__ float rs(float x) { return rsqrtf(x); }
+};
+
+// Stores that only lanes 0..15 should perform are made UNCONDITIONAL: lanes >= 16
+// are pointed at shadow ("junk") copies -- a 17th row of W and of M_A, and a second
+// set of the six vectors -- so the hot loops carry no exec-mask branches.
+constexpr int NVEC = 6;
+struct Lay {    // LDS carve in elements of T (host-computed, passed by value)
+    int off_W;  // main loop: W 17 x LDW | build: G image (m+1) x 16 starts here too
+    int off_MA; // main loop: active rows by slot, 17 x 16
+    int off_L;  // L, 16 x 16 (build: exchange buffers, then the staged operands)
+    int off_v;  // six 16-vectors followed by their shadows
+    int off_stage, nA, nB, nC, nD;  // build: staged operands (inside the L region)
+    int total;
+};
+
+}  // namespace w64
+
+using namespace w64;
+
+// MODE_FUSED: build from the MPC problem (A..targets). MODE_SOLVE: gA=P, gB=q, gC=G, ge=h.
+template <typename T, int NX, int MODE>
+__global__ void __launch_bounds__(64, 4)
+    mpcqp_w64_kernel(const T *__restrict__ gA, const T *__restrict__ gB, const T *__restrict__ gC,
+                     const T *__restrict__ gD, const T *__restrict__ ge, const T *__restrict__ gx0,
+                     const T *__restrict__ ggoal, const T *__restrict__ gtgt, T *__restrict__ oU,
+                     T *__restrict__ olam, int32_t *__restrict__ ostatus, int32_t *__restrict__ oiters,
+                     const KernelArgs ka, const Lay L)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sm = (T *)smem_raw;
+    constexpr int LDW = Vec<T>::LDW;
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15;
+    const bool low = lane < NV;
+    const int vofs = low ? lane : NVEC * NV + l15;  // element of a 16-vector (shadow for lanes >= 16)
+    const int wrow = low ? lane : NV;               // row of W (shadow row 16 for lanes >= 16)
+    const int64_t prob = blockIdx.x;
+    const int n = ka.n, m = ka.m;
+    const T INF = Cst<T>::inf();
+    T *Wl = sm + L.off_W, *MAl = sm + L.off_MA, *Ll = sm + L.off_L;
+    T *mpv = sm + L.off_v, *kAv = mpv + NV, *rv = kAv + NV, *zv = rv + NV, *y0v = zv + NV, *invv = y0v + NV;
+    T *Gimg = sm + L.off_W;  // build only
+
+    T Mr[NV];  // this lane's row of G, then of M (lane m: q, then L^-1 q)
+    T Pr[NV];  // lane a < 16: row a of P, then of L
+    T hval = INF;
+    // optional phase timestamps (tools/probe_phases.py): ka.X -> long long[8] per problem
+    long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
+    auto tick = [&](int slot) {
+        if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
+    };
+    tick(0);
+
+    if constexpr (MODE == MODE_SOLVE) {
+        const T *P = gA + prob * (int64_t)n * n;
+        const T *G = gC + prob * (int64_t)m * n;
+        const T *q = gB + prob * (int64_t)n;
+#pragma unroll
+        for (int b = 0; b < NV; ++b)
+            Pr[b] = (lane < n && b < n) ? P[lane * n + b] : ((lane == b) ? T(1) : T(0));
+        if (lane < m) hval = ge[prob * (int64_t)m + lane];
+        // rows of G (lane m: q) are parked in the LDS image until P is factorised,
+        // so that P's rows and G's rows are never live in registers together
+        for (int i = lane; i < (m + 1) * NV; i += 64) {
+            const int row = i / NV, b = i - row * NV;
+            Gimg[i] = (b < n) ? (row < m ? G[row * n + b] : q[b]) : T(0);
+        }
+        wsync();
+    } else {
+        // ---------------------------------------------------------------- build
+        // nx == NX here (the host dispatches on it), so the small loops are exact.
+        constexpr int nx = NX;
+        const int nu = ka.nu, N = ka.N, mk = ka.mk;
+        const T *A = gA + prob * ka.A.batch_stride;
+        const T *B = gB + prob * ka.B.batch_stride;
+        const T *Cm = gC ? gC + prob * ka.C.batch_stride : nullptr;
+        const T *Dm = gD ? gD + prob * ka.D.batch_stride : nullptr;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = gtgt ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0;
+        const int sC = ka.C.step_stride ? mk * nx : 0, sD = ka.D.step_stride ? mk * nu : 0;
+        const bool stageP = ka.flags & MPCQP_P_STAGE, stageQ = (ka.flags & MPCQP_Q_STAGE) && tgt;
+        const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
+        T *ex = Ll;            // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
+        T *hp = Ll + 4 * 32;   // hp[row] = C_k Phi_k x0 (m <= 63 entries)
+        // One coalesced pass stages the problem's operands in LDS: a single HBM
+        // latency instead of one per horizon step (a problem's steps are packed).
+        T *As = sm + L.off_stage, *Bs = As + L.nA, *Cs = Bs + L.nB, *Ds = Cs + L.nC;
+        for (int i = lane; i < L.nA; i += 64) As[i] = A[i];
+        for (int i = lane; i < L.nB; i += 64) Bs[i] = B[i];
+        for (int i = lane; i < L.nC; i += 64) Cs[i] = Cm[i];
+        for (int i = lane; i < L.nD; i += 64) Ds[i] = Dm[i];
+        const bool isx = (lane == NV), col = (lane < n);
+        const int j = col ? lane / nu : -1, ii = col ? lane - j * nu : 0;
+        if (lane < m) hval = ge[prob * ka.e.batch_stride + (lane / mk) * ka.e.step_stride + (lane % mk)];
+        T v[NX], gref[NX];
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            v[s] = isx ? x0[s] : T(0);
+            gref[s] = (isx && termQ) ? goal[s] : T(0);
+        }
+        const T wu = (T)ka.wu;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) Pr[b] = (lane == b) ? (col ? wu : T(1)) : T(0);
+        T qa = T(0);
+        wsync();
+        T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
+#pragma unroll
+        for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
+
+        // Gram accumulation of one block: Pr[b] += w v_a . v_b, qa += w resid . v_a;
+        // ref[] is this lane's reference (non-zero only in lane 16).
+        auto gram = [&](T w, bool useP, bool useQ, const T (&ref)[NX]) {
+            if (!useP && !useQ) return;
+            wsync();
+            if (lane < 32) {
+#pragma unroll
+                for (int s = 0; s < NX; ++s) ex[s * 32 + lane] = v[s] - ref[s];
+            }
+            wsync();
+#pragma unroll
+            for (int s = 0; s < NX; ++s) {
+                const T t = w * v[s];
+                if (useP) {
+#pragma unroll
+                    for (int h = 0; h < NV; h += HV) {
+                        T vb[HV];
+                        ld8(vb, ex + s * 32 + h);
+#pragma unroll
+                        for (int b = 0; b < HV; ++b) {
+                            Pr[h + b] += t * vb[b];
+                            pin(Pr[h + b]);
+                        }
+                        half_fence();
+                    }
+                }
+                if (useQ) qa += t * ex[s * 32 + NV];
+            }
+        };
+
+        // G rows of step k from v = Psi_k[:, lane] (lane 16: Phi_k x0); lanes 0..15 fill
+        // column `lane` of the G image, lane 16 the C_k Phi_k x0 part of h (mpc_qp.py:62-78)
+        T *gd = low ? (Gimg + lane) : hp;
+        const int gs = low ? NV : 1;
+        auto g_rows = [&](int k) {
+            const bool here = (j == k);
+            for (int i2 = 0; i2 < mk; ++i2) {
+                T acc = T(0);
+                if (L.nC) {
+                    const T *Ci = Cs + k * sC + i2 * nx;  // broadcast LDS reads
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) acc += Ci[s] * v[s];
+                }
+                if (L.nD) {
+                    const T dv = Ds[k * sD + i2 * nu + ii];
+                    acc += here ? dv : T(0);
+                }
+                gd[(k * mk + i2) * gs] = acc;
+            }
+        };
+        // Psi_{k+1} = A_k Psi_k, then column block k <- B_k (mpc_qp.py:88-90)
+        auto advance = [&](int k) {
+            const T *Ak = As + k * sA;
+            const bool here = (j == k);
+            T w[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                T acc = T(0);
+#pragma unroll
+                for (int s = 0; s < NX; ++s) acc += Ak[r * nx + s] * v[s];
+                w[r] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
+        };
+        if (!stageP && !stageQ) {
+            // terminal cost only (configs 1, 2, 4): a lean, branch-free chain on 17 lanes
+            if (lane <= NV) {
+                for (int k = 0; k < N; ++k) {
+                    g_rows(k);
+                    advance(k);
+                }
+            }
+        } else {
+            for (int k = 0; k < N; ++k) {
+                if (lane <= NV) g_rows(k);
+                if (k >= 1) {
+                    T tref[NX];
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) tref[s] = (isx && stageQ) ? tgt[k * nx + s] : T(0);
+                    gram((T)ka.wx, stageP, stageQ, tref);
+                }
+                advance(k);
+            }
+        }
+        gram((T)ka.wt, termP, termQ, gref);  // v = Psi_N
+        wsync();
+        if (low) Gimg[m * NV + lane] = col ? qa : T(0);  // the q row
+        wsync();
+        // h_i = e_i - C_k Phi_k x0 ; the rows of G stay in the LDS image for now
+        if (lane < m && L.nC) hval -= hp[lane];
+        wsync();
+    }
+
+    tick(1);
+    // ------------------------------------------------------------ factorise
+    // Right-looking Cholesky on the rows held by lanes 0..15. Column j is exchanged
+    // through LDS once and read back as broadcast; the trailing update needs no sqrt:
+    // P[i][k] -= P[i][j] P[k][j] / piv.
+    bool notpd = false;  // 1 / L_jj goes to the LDS vector invv
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        zv[vofs] = Pr[j];
+        wsync();
+        const T piv = zv[j];
+        if (!(piv > T(0))) notpd = true;
+        const T rinv = Cst<T>::rs(piv);
+        const T lij = Pr[j] * rinv;  // L[i][j] (lane j: sqrt(piv))
+        const T t2 = lij * rinv;     // P[i][j] / piv
+        Pr[j] = lij;
+        invv[j] = rinv;  // wave-uniform value, every lane stores the same
+#pragma unroll
+        for (int h = (j + 1) / HV * HV; h < NV; h += HV) {
+            T c[HV];
+            ld8(c, zv + h);
+#pragma unroll
+            for (int k = 0; k < HV; ++k)
+                if (h + k > j) {
+                    Pr[h + k] -= t2 * c[k];
+                    pin(Pr[h + k]);
+                }
+            half_fence();
+        }
+        wsync();
+    }
+    tick(2);
+    int status = MPCQP_MAX_ITER, iters = 0;
+    T xsol = T(0), lam_out = T(0);
+    if (notpd) {
+        status = MPCQP_NOT_PD;
+    } else {
+        if (low) st16(Ll + lane * NV, Pr);  // L image (upper part is don't-care)
+        // rows of G by lane (lane m: q), fetched only now (register pressure)
+        if (lane <= m) {
+            ld16(Mr, Gimg + lane * NV);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) Mr[k] = T(0);
+        }
+        wsync();
+        // M = G L^-T, one row per lane (lane m: L^-1 q)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            T acc = Mr[j];
+#pragma unroll
+            for (int h = 0; h < j; h += HV) {
+                T lrow[HV];
+                ld8(lrow, Ll + j * NV + h);  // broadcast row j of L
+#pragma unroll
+                for (int k = 0; k < HV; ++k)
+                    if (h + k < j) acc -= Mr[h + k] * lrow[k];
+                half_fence();
+            }
+            Mr[j] = acc * invv[j];
+            pin(Mr[j]);
+        }
+        tick(3);
+        if (lane == m) st16(y0v, Mr);  // w = L^-1 q ; y0 = -w
+        // clear W and the slot rows
+        for (int i = lane; i < (NV + 1) * LDW; i += 64) Wl[i] = T(0);
+        for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
+        wsync();
+        T s = hval + dot_reg_lds(Mr, y0v);  // h - M y0  (y0 = -L^-1 q)
+        s = (lane < m) ? s : INF;
+        // Selection rule (the classic Goldfarb-Idnani one): among the rows violated
+        // beyond the tolerance, take the one FARTHEST from its hyperplane in the
+        // P^-1 metric, s_i / |M_i|. On the triple-integrator family this needs
+        // 10.8 iterations on average and 15 at most, against 12.3 / 24 when the
+        // slack is only scaled by 1 + |h_i|, and it practically removes the drops.
+        T invn;
+        {
+            T nn = T(0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) nn += Mr[k] * Mr[k];
+            invn = (nn > T(0)) ? Cst<T>::rs(nn) : T(1);
+        }
+        const bool selectable = (lane < m) && (hval < T(1e29));
+        const T tol = (T)ka.tol;
+        const T tolh = tol + tol * fabs(hval);  // row i is violated when s_i < -tol (1 + |h_i|)
+        const int max_iter = ka.max_iter;
+
+        T lam = T(0);
+        int myact = 0, pos = -1, nq = 0;
+        bool occ = false;
+        unsigned mask = 0;  // occupied slots (wave-uniform)
+        bool fail = false;
+
+        tick(4);
+        for (int round = 0; round < 4 && !fail; ++round) {
+            // ===================================================== active-set loop
+            for (;;) {
+                const int p = argmin_coarse<T>(s * invn, selectable && pos < 0 && s < -tolh, lane);
+                if (p == 64) {
+                    status = MPCQP_SOLVED;
+                    break;
+                }
+                // broadcast row p of M through LDS; k_i = M_i . M_p
+                wsync();
+                if (lane == p) st16(mpv, Mr);
+                wsync();
+                const T kcol = dot_reg_lds(Mr, mpv);
+                const T kpp = bcast(kcol, p);
+                T up = T(0);
+                bool added = false;
+                while (!added) {
+                    if (iters >= max_iter) {
+                        fail = true;
+                        break;
+                    }
+                    ++iters;
+                    // k_A by slot
+                    T kA = __shfl(kcol, myact);
+                    kA = occ ? kA : T(0);
+                    kAv[vofs] = kA;
+                    wsync();
+                    // r = W k_A (lane a < 16: row a)
+                    T r = dot_lds_lds(Wl + wrow * LDW, kAv);
+                    r = occ ? r : T(0);
+                    rv[vofs] = r;
+                    wsync();
+                    // z = -M_p + M_A' r (lane k < 16)
+                    T z = dot_vec_col(rv, MAl + l15, -mpv[l15]);  // lane k: -M_p[k] + ...
+                    z = low ? z : T(0);
+                    zv[vofs] = z;
+                    const T d2 = bcast(row_sum(z * z), 0);
+                    // ratio test on the multipliers
+                    const bool cand = occ && (r > T(0));
+                    const T ratio = cand ? lam / r : INF;
+                    const int l = argmin_row0<T>(ratio, cand, lane);
+                    const T t1 = (l < 64) ? bcast(ratio, l) : INF;
+                    const bool can_move = (nq < n) && (d2 > Cst<T>::dep() * kpp) && (d2 > T(0));
+                    const T sp = bcast(s, p);
+                    const T t2 = can_move ? -sp / d2 : INF;
+                    const T t = t1 < t2 ? t1 : t2;
+                    if (!(t < INF)) {
+                        status = MPCQP_INFEASIBLE;
+                        fail = true;
+                        break;
+                    }
+                    // the implied primal point moves by t z: s_i -= t M_i . z
+                    wsync();
+                    {
+                        const T mz = dot_reg_lds(Mr, zv);
+                        if (lane < m) s = (pos >= 0) ? T(0) : s - t * mz;
+                    }
+                    lam -= t * r;
+                    lam = (occ && lam < T(0)) ? T(0) : lam;
+                    up += t;
+                    if (t2 <= t1) {
+                        // full step: p takes the lowest free slot; W by bordering
+                        const int sl = __builtin_ctz(~mask);
+                        const T inv = T(1) / d2;
+                        const T ri = r * inv;
+                        const T coef = (lane == sl) ? -inv : ri;
+                        axpy_row_lds(Wl + wrow * LDW, coef, rv, false);
+                        Wl[wrow * LDW + sl] = (lane == sl) ? inv : -ri;  // column sl / the diagonal
+                        MAl[(low ? sl : NV) * NV + l15] = mpv[l15];
+                        if (lane == sl) {
+                            lam = up;
+                            myact = p;
+                            occ = true;
+                        }
+                        if (lane == p) {
+                            pos = sl;
+                            s = T(0);
+                        }
+                        mask |= 1u << sl;
+                        ++nq;
+                        added = true;
+                    } else {
+                        // partial step: slot l leaves.  W <- W - w_l w_l' / W_ll, row/column l cleared
+                        const int cl = bcast(myact, l);
+                        {
+                            const T wal = Wl[wrow * LDW + l];
+                            const T f = wal / bcast(wal, l);
+                            // row l is copied out first: it is both an operand and a target
+                            if (lane == l) {
+                                T tmp[NV];
+                                ld16(tmp, Wl + l * LDW);
+                                st16(kAv, tmp);
+                            }
+                            wsync();
+                            axpy_row_lds(Wl + wrow * LDW, -f, kAv, lane == l);
+                            Wl[wrow * LDW + l] = T(0);
+                        }
+                        if (lane == l) {
+                            lam = T(0);
+                            occ = false;
+                        }
+                        if (lane == cl) pos = -1;
+                        mask &= ~(1u << l);
+                        --nq;
+                    }
+                    wsync();
+                }
+                if (fail) break;
+            }
+            if (fail) break;
+            tick(5);
+            // ================================== refine multipliers, verify slacks
+            // y = y0 - M_A' lam (lane k < 16)
+            wsync();
+            rv[vofs] = lam;
+            wsync();
+            T y = -y0v[l15] - dot_vec_col(rv, MAl + l15, T(0));  // y0 = -L^-1 q
+            zv[vofs] = y;
+            wsync();
+            T fresh = hval - dot_reg_lds(Mr, zv);
+            fresh = (lane < m) ? fresh : INF;
+            if (nq > 0) {
+                // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A
+                T rho = __shfl(fresh, myact);
+                rho = occ ? rho : T(0);
+                wsync();
+                kAv[vofs] = rho;
+                wsync();
+                T dl = -dot_lds_lds(Wl + wrow * LDW, kAv);
+                dl = occ ? dl : T(0);
+                lam += dl;
+                lam = (occ && lam < T(0)) ? T(0) : lam;
+                rv[vofs] = dl;
+                wsync();
+                y -= dot_vec_col(rv, MAl + l15, T(0));
+                wsync();
+                zv[vofs] = y;
+                wsync();
+                fresh = hval - dot_reg_lds(Mr, zv);
+                fresh = (lane < m) ? fresh : INF;
+            }
+            // accept when no inactive row is violated at the re-evaluated point
+            const bool clean = __ballot(selectable && pos < 0 && fresh < -T(4) * tolh) == 0ull;
+            if (clean || round == 3) {
+                // u = L^-T y (lane k < 16 holds y_k; column sweep from the last row)
+                T yy = low ? y : T(0);
+#pragma unroll
+                for (int i = NV - 1; i >= 0; --i) {
+                    const T xi = bcast(yy, i) * invv[i];
+                    if (lane == i) xsol = xi;
+                    if (lane < i) yy -= Ll[i * NV + lane] * xi;
+                }
+                status = clean ? MPCQP_SOLVED : MPCQP_MAX_ITER;
+                break;
+            }
+            // otherwise continue the active-set loop from the re-evaluated slacks
+            s = (pos >= 0) ? T(0) : fresh;
+            status = MPCQP_MAX_ITER;
+        }
+        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+        if (status == MPCQP_SOLVED && olam) {
+            const T lv = __shfl(lam, pos < 0 ? 0 : pos);
+            lam_out = (pos >= 0) ? lv : T(0);
+        }
+    }
+
+    tick(6);
+    const bool ok = (status == MPCQP_SOLVED);
+    if (lane < n) oU[prob * (int64_t)n + lane] = ok ? xsol : T(0);
+    if (olam && lane < m) olam[prob * (int64_t)m + lane] = ok ? lam_out : T(0);
+    if (lane == 0) {
+        if (ostatus) ostatus[prob] = status;
+        if (oiters) oiters[prob] = iters;
+    }
+}
+
+// ------------------------------------------------------------ host side
+template <typename T> static Lay make_lay(const KernelArgs &ka)
+{
+    Lay L{};
+    int o = 0;
+    auto take = [&](int cnt) {
+        const int at = o;
+        o += (cnt + 3) & ~3;  // keep 16-byte alignment for float and double
+        return at;
+    };
+    const int wma = (NV + 1) * Vec<T>::LDW + (NV + 1) * NV;  // W followed by M_A (+ shadow rows)
+    const int gimg = (ka.m + 1) * NV;            // build-time image of G (+ q row)
+    L.off_W = take(wma > gimg ? wma : gimg);
+    L.off_MA = L.off_W + (((NV + 1) * Vec<T>::LDW + 3) & ~3);
+    int scratch = 4 * 32 + 64;  // ex (4 x 32), hp
+    if (ka.A.ptr) {  // fused mode: room for the staged operands behind the exchange buffers
+        auto al = [](int c) { return (c + 3) & ~3; };
+        L.nA = (ka.A.step_stride ? ka.N : 1) * ka.nx * ka.nx;
+        L.nB = (ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
+        L.nC = ka.C.ptr ? (ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx : 0;
+        L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
+        scratch += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
+    }
+    L.off_L = take(NV * NV > scratch ? NV * NV : scratch);
+    L.off_stage = L.off_L + 4 * 32 + 64;
+    L.off_v = take(2 * NVEC * NV);
+    L.total = o;
+    return L;
+}
+
+// float64 only: in single precision the explicit inverse Gram matrix W loses too
+// much on ill-conditioned active sets (cond up to 2e8 in the humanoid sweep);
+// float32 problems go to the Q-based kernel of mpcqp_lds.hip instead.
+bool w64_eligible(const KernelArgs &ka, int mode, int dtype)
+{
+    if (dtype != MPCQP_F64) return false;
+    if (ka.n > NV || ka.m > 63) return false;
+    if (mode == MODE_FUSED && ka.nx != 3 && ka.nx != 4) return false;
+    return mode == MODE_FUSED || mode == MODE_SOLVE;
+}
+
+template <typename T, int MODE, int NX>
+static int launch_w64_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    const Lay L = make_lay<T>(ka);
+    const size_t bytes = (size_t)L.total * sizeof(T);
+    if constexpr (MODE == MODE_FUSED) {
+        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE>), dim3((unsigned)batch), dim3(64), bytes, st,
+                           (const T *)ka.A.ptr, (const T *)ka.B.ptr, (const T *)ka.C.ptr, (const T *)ka.D.ptr,
+                           (const T *)ka.e.ptr, (const T *)ka.x0.ptr, (const T *)ka.goal.ptr,
+                           (const T *)ka.targets.ptr, (T *)ka.U, (T *)ka.lam, ka.status, ka.iters, ka, L);
+    } else {
+        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE>), dim3((unsigned)batch), dim3(64), bytes, st,
+                           (const T *)ka.P, (const T *)ka.q, (const T *)ka.G, (const T *)nullptr,
+                           (const T *)ka.h, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr,
+                           (T *)ka.U, (T *)ka.lam, ka.status, ka.iters, ka, L);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st)
+{
+    (void)dtype;  // w64_eligible() admits MPCQP_F64 only
+    if (mode == MODE_FUSED) {
+        if (ka.nx == 3) return launch_w64_t<double, MODE_FUSED, 3>(ka, batch, st);
+        return launch_w64_t<double, MODE_FUSED, 4>(ka, batch, st);
+    }
+    return launch_w64_t<double, MODE_SOLVE, 4>(ka, batch, st);
+}
+
+}  // namespace mpcqp
