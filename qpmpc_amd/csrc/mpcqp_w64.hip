@@ -18,15 +18,17 @@
 //   lane a < 16   slot a of the active set: multiplier lam_a, constraint act_a;
 //                 during the factorisation: row a of P -> L in 16 registers;
 //                 at the end: y_a -> u_a.
-// LDS per problem (7 KB): W = (M_A M_A')^-1 as 16 padded rows, the active rows
-// M_A by slot, L, and five 16-vectors used as broadcast buffers.
+// LDS per problem (~9 KB): T as 16 padded rows, the active rows M_A by slot, L,
+// and six 16-vectors used as broadcast buffers (each with a shadow for lanes >= 16).
 //
-// Solver = dual active set (Goldfarb-Idnani 1983) in "inverse Gram" form; the
-// primal iterate is implied by the multipliers (y = y0 - M_A' lam):
-//   k_i = M_i . M_p ;  r = W k_A ;  z = -M_p + M_A' r ;  d2 = |z|^2
+// Solver = dual active set (Goldfarb-Idnani 1983) with their operator
+// N* = (M_A M_A')^-1 M_A kept EXPLICITLY as T (16 slot rows of 16): no factor, no
+// Gram column, no gather. The primal iterate is implied by the multipliers
+// (y = y0 - M_A' lam). Per step, for the selected row p:
+//   r = T M_p ;  z = -M_p + M_A' r ;  d2 = |z|^2
 //   step t = min(t1 = min lam_a / r_a, t2 = -s_p / d2) ;  s_i -= t M_i . z
-//   add : W <- [[W + r r'/d2, -r/d2], [-r'/d2, 1/d2]] into a free slot
-//   drop: W <- W - w_l w_l'/W_ll, slot l cleared
+//   add  : T_a += (r_a/d2) z  (a active),  T_new = -z/d2  -> one rank-1 update by z
+//   drop : T_a -= (T_a.T_l / T_l.T_l) T_l,  slot l cleared   (W = T T' is implicit)
 // d2 comes from z itself (no cancellation); the final multipliers get one step of
 // iterative refinement and the slacks are re-evaluated from scratch before the
 // solution is accepted.
@@ -273,8 +275,8 @@ template <typename T> __device__ __forceinline__ void axpy_row_lds(T *row, T c, 
         half_fence();
     }
 }
-// acc += sum_a v[a] * col[a * NV] : a 16-vector against a strided column (slot rows)
-template <typename T> __device__ __forceinline__ T dot_vec_col(const T *v, const T *col, T acc)
+// acc += sum_a v[a] * col[a * STRIDE] : a 16-vector against a strided column (slot rows)
+template <int STRIDE, typename T> __device__ __forceinline__ T dot_vec_col(const T *v, const T *col, T acc)
 {
     T acc1 = T(0);
 #pragma unroll
@@ -283,12 +285,28 @@ template <typename T> __device__ __forceinline__ T dot_vec_col(const T *v, const
         ld8(b, v + h);
 #pragma unroll
         for (int a = 0; a < HV; a += 2) {
-            acc += b[a] * col[(h + a) * NV];
-            acc1 += b[a + 1] * col[(h + a + 1) * NV];
+            acc += b[a] * col[(h + a) * STRIDE];
+            acc1 += b[a + 1] * col[(h + a + 1) * STRIDE];
         }
         half_fence();
     }
     return acc + acc1;
+}
+// 1/x from the hardware estimate plus Newton steps (a full IEEE division costs ~3x
+// the instructions; the operands here are never subnormal or zero when the result is used)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ float fast_rcp(float x)
+{
+    float y = __builtin_amdgcn_rcpf(x);
+    const float e = fmaf(-x, y, 1.0f);
+    return fmaf(y, e, y);
 }
 // wavefront-level ordering of LDS traffic (a 64-thread workgroup needs no s_barrier)
 __device__ __forceinline__ void wsync() { __syncthreads(); }
@@ -546,12 +564,14 @@ __global__ void __launch_bounds__(64, 4)
         status = MPCQP_NOT_PD;
     } else {
         if (low) st16(Ll + lane * NV, Pr);  // L image (upper part is don't-care)
-        // rows of G by lane (lane m: q), fetched only now (register pressure)
+        // rows of G by lane (lane m: q), fetched only now (register pressure). Lanes
+        // m+1 .. m+16 carry the identity: the forward substitution turns them into the
+        // rows of L^-T, so that u = L^-T y is one dot product at the end.
         if (lane <= m) {
             ld16(Mr, Gimg + lane * NV);
         } else {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) Mr[k] = T(0);
+            for (int k = 0; k < NV; ++k) Mr[k] = (lane == m + 1 + k) ? T(1) : T(0);
         }
         wsync();
         // M = G L^-T, one row per lane (lane m: L^-1 q)
@@ -572,7 +592,7 @@ __global__ void __launch_bounds__(64, 4)
         }
         tick(3);
         if (lane == m) st16(y0v, Mr);  // w = L^-1 q ; y0 = -w
-        // clear W and the slot rows
+        // clear T and the slot rows (incl. the shadow rows)
         for (int i = lane; i < (NV + 1) * LDW; i += 64) Wl[i] = T(0);
         for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
         wsync();
@@ -581,7 +601,7 @@ __global__ void __launch_bounds__(64, 4)
         // Selection rule (the classic Goldfarb-Idnani one): among the rows violated
         // beyond the tolerance, take the one FARTHEST from its hyperplane in the
         // P^-1 metric, s_i / |M_i|. On the triple-integrator family this needs
-        // 10.8 iterations on average and 15 at most, against 12.3 / 24 when the
+        // 10.8 iterations on average and 16 at most, against 12.3 / 26 when the
         // slack is only scaled by 1 + |h_i|, and it practically removes the drops.
         T invn;
         {
@@ -594,13 +614,13 @@ __global__ void __launch_bounds__(64, 4)
         const T tol = (T)ka.tol;
         const T tolh = tol + tol * fabs(hval);  // row i is violated when s_i < -tol (1 + |h_i|)
         const int max_iter = ka.max_iter;
+        T *Tl = Wl;  // T = N*: slot rows, stride LDW
 
         T lam = T(0);
         int myact = 0, pos = -1, nq = 0;
         bool occ = false;
         unsigned mask = 0;  // occupied slots (wave-uniform)
         bool fail = false;
-
         tick(4);
         for (int round = 0; round < 4 && !fail; ++round) {
             // ===================================================== active-set loop
@@ -610,12 +630,11 @@ __global__ void __launch_bounds__(64, 4)
                     status = MPCQP_SOLVED;
                     break;
                 }
-                // broadcast row p of M through LDS; k_i = M_i . M_p
+                // broadcast row p of M through LDS
                 wsync();
                 if (lane == p) st16(mpv, Mr);
                 wsync();
-                const T kcol = dot_reg_lds(Mr, mpv);
-                const T kpp = bcast(kcol, p);
+                const T ip = bcast(invn, p);  // 1 / |M_p|
                 T up = T(0);
                 bool added = false;
                 while (!added) {
@@ -624,29 +643,25 @@ __global__ void __launch_bounds__(64, 4)
                         break;
                     }
                     ++iters;
-                    // k_A by slot
-                    T kA = __shfl(kcol, myact);
-                    kA = occ ? kA : T(0);
-                    kAv[vofs] = kA;
-                    wsync();
-                    // r = W k_A (lane a < 16: row a)
-                    T r = dot_lds_lds(Wl + wrow * LDW, kAv);
+                    // r = T M_p (lane a < 16: slot a)
+                    T r = dot_lds_lds(Tl + wrow * LDW, mpv);
                     r = occ ? r : T(0);
                     rv[vofs] = r;
                     wsync();
                     // z = -M_p + M_A' r (lane k < 16)
-                    T z = dot_vec_col(rv, MAl + l15, -mpv[l15]);  // lane k: -M_p[k] + ...
+                    T z = dot_vec_col<NV>(rv, MAl + l15, -mpv[l15]);
                     z = low ? z : T(0);
                     zv[vofs] = z;
                     const T d2 = bcast(row_sum(z * z), 0);
                     // ratio test on the multipliers
                     const bool cand = occ && (r > T(0));
-                    const T ratio = cand ? lam / r : INF;
+                    const T ratio = cand ? lam * fast_rcp(r) : INF;
                     const int l = argmin_row0<T>(ratio, cand, lane);
                     const T t1 = (l < 64) ? bcast(ratio, l) : INF;
-                    const bool can_move = (nq < n) && (d2 > Cst<T>::dep() * kpp) && (d2 > T(0));
+                    const bool can_move = (nq < n) && (d2 * ip * ip > Cst<T>::dep()) && (d2 > T(0));
                     const T sp = bcast(s, p);
-                    const T t2 = can_move ? -sp / d2 : INF;
+                    const T inv = can_move ? fast_rcp(d2) : T(0);
+                    const T t2 = can_move ? -sp * inv : INF;
                     const T t = t1 < t2 ? t1 : t2;
                     if (!(t < INF)) {
                         status = MPCQP_INFEASIBLE;
@@ -663,13 +678,11 @@ __global__ void __launch_bounds__(64, 4)
                     lam = (occ && lam < T(0)) ? T(0) : lam;
                     up += t;
                     if (t2 <= t1) {
-                        // full step: p takes the lowest free slot; W by bordering
+                        // full step: p takes the lowest free slot sl.
+                        // T_a += (r_a / d2) z for the active rows, T_sl = -z / d2 (row sl was zero)
                         const int sl = __builtin_ctz(~mask);
-                        const T inv = T(1) / d2;
-                        const T ri = r * inv;
-                        const T coef = (lane == sl) ? -inv : ri;
-                        axpy_row_lds(Wl + wrow * LDW, coef, rv, false);
-                        Wl[wrow * LDW + sl] = (lane == sl) ? inv : -ri;  // column sl / the diagonal
+                        const T coef = (lane == sl) ? -inv : r * inv;
+                        axpy_row_lds(Tl + wrow * LDW, coef, zv, false);
                         MAl[(low ? sl : NV) * NV + l15] = mpv[l15];
                         if (lane == sl) {
                             lam = up;
@@ -684,21 +697,18 @@ __global__ void __launch_bounds__(64, 4)
                         ++nq;
                         added = true;
                     } else {
-                        // partial step: slot l leaves.  W <- W - w_l w_l' / W_ll, row/column l cleared
+                        // partial step: slot l leaves. With W = T T' implicit,
+                        // T_a -= (T_a . T_l / T_l . T_l) T_l and row l is cleared.
                         const int cl = bcast(myact, l);
-                        {
-                            const T wal = Wl[wrow * LDW + l];
-                            const T f = wal / bcast(wal, l);
-                            // row l is copied out first: it is both an operand and a target
-                            if (lane == l) {
-                                T tmp[NV];
-                                ld16(tmp, Wl + l * LDW);
-                                st16(kAv, tmp);
-                            }
-                            wsync();
-                            axpy_row_lds(Wl + wrow * LDW, -f, kAv, lane == l);
-                            Wl[wrow * LDW + l] = T(0);
+                        if (lane == l) {  // row l is both an operand and a target: copy it out
+                            T tmp[NV];
+                            ld16(tmp, Tl + l * LDW);
+                            st16(kAv, tmp);
                         }
+                        wsync();
+                        const T tl = dot_lds_lds(Tl + wrow * LDW, kAv);
+                        const T f = tl * fast_rcp(bcast(tl, l));
+                        axpy_row_lds(Tl + wrow * LDW, -f, kAv, lane == l);
                         if (lane == l) {
                             lam = T(0);
                             occ = false;
@@ -718,25 +728,31 @@ __global__ void __launch_bounds__(64, 4)
             wsync();
             rv[vofs] = lam;
             wsync();
-            T y = -y0v[l15] - dot_vec_col(rv, MAl + l15, T(0));  // y0 = -L^-1 q
+            T y = dot_vec_col<NV>(rv, MAl + l15, T(0));
+            y = -y0v[l15] - y;  // y0 = -L^-1 q
             zv[vofs] = y;
             wsync();
             T fresh = hval - dot_reg_lds(Mr, zv);
             fresh = (lane < m) ? fresh : INF;
             if (nq > 0) {
-                // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A
+                // active residuals rho_a = h_a - M_a y should vanish:
+                // dlam = -W rho_A = -T (T' rho_A)
                 T rho = __shfl(fresh, myact);
                 rho = occ ? rho : T(0);
                 wsync();
                 kAv[vofs] = rho;
                 wsync();
-                T dl = -dot_lds_lds(Wl + wrow * LDW, kAv);
+                const T uk = dot_vec_col<LDW>(kAv, Tl + l15, T(0));  // (T' rho)_k, lane k < 16
+                rv[vofs] = low ? uk : T(0);
+                wsync();
+                T dl = -dot_lds_lds(Tl + wrow * LDW, rv);
                 dl = occ ? dl : T(0);
                 lam += dl;
                 lam = (occ && lam < T(0)) ? T(0) : lam;
+                wsync();
                 rv[vofs] = dl;
                 wsync();
-                y -= dot_vec_col(rv, MAl + l15, T(0));
+                y -= dot_vec_col<NV>(rv, MAl + l15, T(0));
                 wsync();
                 zv[vofs] = y;
                 wsync();
@@ -746,13 +762,18 @@ __global__ void __launch_bounds__(64, 4)
             // accept when no inactive row is violated at the re-evaluated point
             const bool clean = __ballot(selectable && pos < 0 && fresh < -T(4) * tolh) == 0ull;
             if (clean || round == 3) {
-                // u = L^-T y (lane k < 16 holds y_k; column sweep from the last row)
-                T yy = low ? y : T(0);
+                if (m + 1 + NV <= 64) {
+                    // u = L^-T y: lane m+1+k holds row k of L^-T (zv holds y)
+                    xsol = dot_reg_lds(Mr, zv);
+                } else {
+                    // column sweep from the last row (lane k < 16 holds y_k)
+                    T yy = low ? y : T(0);
 #pragma unroll
-                for (int i = NV - 1; i >= 0; --i) {
-                    const T xi = bcast(yy, i) * invv[i];
-                    if (lane == i) xsol = xi;
-                    if (lane < i) yy -= Ll[i * NV + lane] * xi;
+                    for (int i = NV - 1; i >= 0; --i) {
+                        const T xi = bcast(yy, i) * invv[i];
+                        if (lane == i) xsol = xi;
+                        if (lane < i) yy -= Ll[i * NV + lane] * xi;
+                    }
                 }
                 status = clean ? MPCQP_SOLVED : MPCQP_MAX_ITER;
                 break;
@@ -770,7 +791,10 @@ __global__ void __launch_bounds__(64, 4)
 
     tick(6);
     const bool ok = (status == MPCQP_SOLVED);
-    if (lane < n) oU[prob * (int64_t)n + lane] = ok ? xsol : T(0);
+    {
+        const int k = (m + 1 + NV <= 64) ? lane - (m + 1) : lane;  // which u_k this lane holds
+        if (k >= 0 && k < n) oU[prob * (int64_t)n + k] = ok ? xsol : T(0);
+    }
     if (olam && lane < m) olam[prob * (int64_t)m + lane] = ok ? lam_out : T(0);
     if (lane == 0) {
         if (ostatus) ostatus[prob] = status;
