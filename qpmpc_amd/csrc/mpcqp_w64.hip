@@ -341,7 +341,9 @@ struct Lay {    // LDS carve in elements of T (host-computed, passed by value)
 using namespace w64;
 
 // MODE_FUSED: build from the MPC problem (A..targets). MODE_SOLVE: gA=P, gB=q, gC=G, ge=h.
-template <typename T, int NX, int MODE>
+// MK > 0: compile-time number of inequality rows per step for the software-pipelined
+// chain (terminal cost only, state constraints only); MK == 0: generic chain.
+template <typename T, int NX, int MODE, int MK>
 __global__ void __launch_bounds__(64, 4)
     mpcqp_w64_kernel(const T *__restrict__ gA, const T *__restrict__ gB, const T *__restrict__ gC,
                      const T *__restrict__ gD, const T *__restrict__ ge, const T *__restrict__ gx0,
@@ -362,11 +364,11 @@ __global__ void __launch_bounds__(64, 4)
     const T INF = Cst<T>::inf();
     T *Wl = sm + L.off_W, *MAl = sm + L.off_MA, *Ll = sm + L.off_L;
     T *mpv = sm + L.off_v, *kAv = mpv + NV, *rv = kAv + NV, *zv = rv + NV, *y0v = zv + NV, *invv = y0v + NV;
+    T *hv = sm + L.off_L + NV * NV;  // h_i per constraint lane (kept out of registers); behind L, in the dead staging area
     T *Gimg = sm + L.off_W;  // build only
 
     T Mr[NV];  // this lane's row of G, then of M (lane m: q, then L^-1 q)
     T Pr[NV];  // lane a < 16: row a of P, then of L
-    T hval = INF;
     // optional phase timestamps (tools/probe_phases.py): ka.X -> long long[8] per problem
     long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
     auto tick = [&](int slot) {
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
         for (int b = 0; b < NV; ++b)
             Pr[b] = (lane < n && b < n) ? P[lane * n + b] : ((lane == b) ? T(1) : T(0));
-        if (lane < m) hval = ge[prob * (int64_t)m + lane];
+        hv[lane] = (lane < m) ? ge[prob * (int64_t)m + lane] : INF;
         // rows of G (lane m: q) are parked in the LDS image until P is factorised,
         // so that P's rows and G's rows are never live in registers together
         for (int i = lane; i < (m + 1) * NV; i += 64) {
@@ -416,7 +418,7 @@ __global__ void __launch_bounds__(64, 4)
         for (int i = lane; i < L.nD; i += 64) Ds[i] = Dm[i];
         const bool isx = (lane == NV), col = (lane < n);
         const int j = col ? lane / nu : -1, ii = col ? lane - j * nu : 0;
-        if (lane < m) hval = ge[prob * ka.e.batch_stride + (lane / mk) * ka.e.step_stride + (lane % mk)];
+        const T eval = (lane < m) ? ge[prob * ka.e.batch_stride + (lane / mk) * ka.e.step_stride + (lane % mk)] : INF;
         T v[NX], gref[NX];
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
@@ -497,8 +499,49 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
             for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
         };
-        if (!stageP && !stageQ) {
-            // terminal cost only (configs 1, 2, 4): a lean, branch-free chain on 17 lanes
+        if constexpr (MK > 0) {
+            // Terminal cost only, C only, mk == MK (configs 1, 2, 4; the host checks).
+            // Software-pipelined chain on 17 lanes: the broadcast reads of A_{k+1}, C_{k+1}
+            // are in flight while step k computes [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k.
+            if (lane <= NV) {
+                T a0[NX * NX], c0[MK * NX];
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e) a0[e] = As[e];
+#pragma unroll
+                for (int e = 0; e < MK * NX; ++e) c0[e] = Cs[e];
+                for (int k = 0; k < N; ++k) {
+                    const int kn = (k + 1 < N) ? k + 1 : k;
+                    T a1[NX * NX], c1[MK * NX];
+#pragma unroll
+                    for (int e = 0; e < NX * NX; ++e) a1[e] = As[kn * sA + e];
+#pragma unroll
+                    for (int e = 0; e < MK * NX; ++e) c1[e] = Cs[kn * sC + e];
+#pragma unroll
+                    for (int i2 = 0; i2 < MK; ++i2) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int s2 = 0; s2 < NX; ++s2) acc += c0[i2 * NX + s2] * v[s2];
+                        gd[(k * MK + i2) * gs] = acc;
+                    }
+                    const bool here = (j == k);
+                    T w[NX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int s2 = 0; s2 < NX; ++s2) acc += a0[r * NX + s2] * v[s2];
+                        w[r] = acc;
+                    }
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
+#pragma unroll
+                    for (int e = 0; e < NX * NX; ++e) a0[e] = a1[e];
+#pragma unroll
+                    for (int e = 0; e < MK * NX; ++e) c0[e] = c1[e];
+                }
+            }
+        } else if (!stageP && !stageQ) {
+            // terminal cost only: a branch-light chain on 17 lanes
             if (lane <= NV) {
                 for (int k = 0; k < N; ++k) {
                     g_rows(k);
@@ -521,8 +564,8 @@ __global__ void __launch_bounds__(64, 4)
         wsync();
         if (low) Gimg[m * NV + lane] = col ? qa : T(0);  // the q row
         wsync();
-        // h_i = e_i - C_k Phi_k x0 ; the rows of G stay in the LDS image for now
-        if (lane < m && L.nC) hval -= hp[lane];
+        // h_i = e_i - C_k Phi_k x0 goes to LDS; the rows of G stay in the LDS image for now
+        hv[lane] = (lane < m && L.nC) ? eval - hp[lane] : eval;
         wsync();
     }
 
@@ -596,6 +639,7 @@ __global__ void __launch_bounds__(64, 4)
         for (int i = lane; i < (NV + 1) * LDW; i += 64) Wl[i] = T(0);
         for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
         wsync();
+        const T hval = hv[lane];
         T s = hval + dot_reg_lds(Mr, y0v);  // h - M y0  (y0 = -L^-1 q)
         s = (lane < m) ? s : INF;
         // Selection rule (the classic Goldfarb-Idnani one): among the rows violated
@@ -732,7 +776,7 @@ __global__ void __launch_bounds__(64, 4)
             y = -y0v[l15] - y;  // y0 = -L^-1 q
             zv[vofs] = y;
             wsync();
-            T fresh = hval - dot_reg_lds(Mr, zv);
+            T fresh = hv[lane] - dot_reg_lds(Mr, zv);
             fresh = (lane < m) ? fresh : INF;
             if (nq > 0) {
                 // active residuals rho_a = h_a - M_a y should vanish:
@@ -756,7 +800,7 @@ __global__ void __launch_bounds__(64, 4)
                 wsync();
                 zv[vofs] = y;
                 wsync();
-                fresh = hval - dot_reg_lds(Mr, zv);
+                fresh = hv[lane] - dot_reg_lds(Mr, zv);
                 fresh = (lane < m) ? fresh : INF;
             }
             // accept when no inactive row is violated at the re-evaluated point
@@ -825,7 +869,7 @@ template <typename T> static Lay make_lay(const KernelArgs &ka)
         L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
         scratch += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
     }
-    L.off_L = take(NV * NV > scratch ? NV * NV : scratch);
+    L.off_L = take(NV * NV + 64 > scratch ? NV * NV + 64 : scratch);  // L, then hv[64]
     L.off_stage = L.off_L + 4 * 32 + 64;
     L.off_v = take(2 * NVEC * NV);
     L.total = o;
@@ -843,18 +887,18 @@ bool w64_eligible(const KernelArgs &ka, int mode, int dtype)
     return mode == MODE_FUSED || mode == MODE_SOLVE;
 }
 
-template <typename T, int MODE, int NX>
+template <typename T, int MODE, int NX, int MK>
 static int launch_w64_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     const Lay L = make_lay<T>(ka);
     const size_t bytes = (size_t)L.total * sizeof(T);
     if constexpr (MODE == MODE_FUSED) {
-        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE>), dim3((unsigned)batch), dim3(64), bytes, st,
+        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE, MK>), dim3((unsigned)batch), dim3(64), bytes, st,
                            (const T *)ka.A.ptr, (const T *)ka.B.ptr, (const T *)ka.C.ptr, (const T *)ka.D.ptr,
                            (const T *)ka.e.ptr, (const T *)ka.x0.ptr, (const T *)ka.goal.ptr,
                            (const T *)ka.targets.ptr, (T *)ka.U, (T *)ka.lam, ka.status, ka.iters, ka, L);
     } else {
-        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE>), dim3((unsigned)batch), dim3(64), bytes, st,
+        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE, MK>), dim3((unsigned)batch), dim3(64), bytes, st,
                            (const T *)ka.P, (const T *)ka.q, (const T *)ka.G, (const T *)nullptr,
                            (const T *)ka.h, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr,
                            (T *)ka.U, (T *)ka.lam, ka.status, ka.iters, ka, L);
@@ -866,10 +910,15 @@ int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStre
 {
     (void)dtype;  // w64_eligible() admits MPCQP_F64 only
     if (mode == MODE_FUSED) {
-        if (ka.nx == 3) return launch_w64_t<double, MODE_FUSED, 3>(ka, batch, st);
-        return launch_w64_t<double, MODE_FUSED, 4>(ka, batch, st);
+        // the pipelined chain: terminal cost only, state constraints only, two rows per step
+        const bool lean = ka.mk == 2 && ka.C.ptr && !ka.D.ptr && !(ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
+        if (ka.nx == 3)
+            return lean ? launch_w64_t<double, MODE_FUSED, 3, 2>(ka, batch, st)
+                        : launch_w64_t<double, MODE_FUSED, 3, 0>(ka, batch, st);
+        return lean ? launch_w64_t<double, MODE_FUSED, 4, 2>(ka, batch, st)
+                    : launch_w64_t<double, MODE_FUSED, 4, 0>(ka, batch, st);
     }
-    return launch_w64_t<double, MODE_SOLVE, 4>(ka, batch, st);
+    return launch_w64_t<double, MODE_SOLVE, 4, 0>(ka, batch, st);
 }
 
 }  // namespace mpcqp
