@@ -12,14 +12,20 @@
 // in VGPRs; nothing is indexed dynamically in registers; no per-element uniform
 // branches; the active set lives in 16 fixed SLOTS (no compaction on a drop).
 //
-// Lane roles:
-//   lane i <  m   constraint i : row M_i of M = G L^-T in 16 registers, slack s_i
-//   lane m        the q row    : L^-1 q  (-> y0)
-//   lane a < 16   slot a of the active set: multiplier lam_a, constraint act_a;
-//                 during the factorisation: row a of P -> L in 16 registers;
-//                 at the end: y_a -> u_a.
-// LDS per problem (~9 KB): T as 16 padded rows, the active rows M_A by slot, L,
-// and six 16-vectors used as broadcast buffers (each with a shadow for lanes >= 16).
+// Lane roles (a 64-wide wavefront is the whole machine of one problem):
+//   lanes  0..15  SLOT a of the active set: multiplier lam_a, constraint act_a and
+//                 row a of T = N* in 16 registers. Earlier: row a of P -> L during
+//                 the factorisation; lane 0 carries q through the forward substitution.
+//   lanes 16..47  CONSTRAINT i = lane-16 (m <= 32): row M_i of M = G L^-T in the
+//                 same 16 registers, slack s_i.
+//   lanes 48..63  row k = lane-48 of L^-T (identity rows pushed through the forward
+//                 substitution), so that u = L^-T y is one dot product at the end.
+// Every lane owns ONE 16-register row R; "r = T M_p", "M_i . z" and the rank-1
+// update of T are the same instruction stream over R for all three roles.
+// LDS per problem (9.6 KB, 16 wavefronts per CU): the image of M (row-p broadcast),
+// the active rows M_A by slot, and a few 16-vectors used as broadcast buffers. The
+// counters say the kernel is bound by the CU-shared LDS pipe, so T lives in
+// registers and nothing is read-modify-written in LDS inside the loop.
 //
 // Solver = dual active set (Goldfarb-Idnani 1983) with their operator
 // N* = (M_A M_A')^-1 M_A kept EXPLICITLY as T (16 slot rows of 16): no factor, no
@@ -324,15 +330,17 @@ template <> struct Cst<float> {
 };
 
 // Stores that only lanes 0..15 should perform are made UNCONDITIONAL: lanes >= 16
-// are pointed at shadow ("junk") copies -- a 17th row of W and of M_A, and a second
-// set of the six vectors -- so the hot loops carry no exec-mask branches.
-constexpr int NVEC = 6;
+// are pointed at shadow ("junk") copies -- a 17th row of M_A and a second set of
+// the exchange vectors -- so the hot loops carry no exec-mask branches.
+constexpr int CB = 16;    // first constraint lane
+constexpr int LB = 48;    // first L^-T lane
+constexpr int MMAX = 32;  // constraints this kernel can hold
 struct Lay {    // LDS carve in elements of T (host-computed, passed by value)
-    int off_W;  // main loop: W 17 x LDW | build: G image (m+1) x 16 starts here too
-    int off_MA; // main loop: active rows by slot, 17 x 16
-    int off_L;  // L, 16 x 16 (build: exchange buffers, then the staged operands)
-    int off_v;  // six 16-vectors followed by their shadows
-    int off_stage, nA, nB, nC, nD;  // build: staged operands (inside the L region)
+    int off_X;  // build: G image (m+1) x 16 | main: M_A 17 x 16, then the T image 16 x 16 (refinement)
+    int off_Y;  // build: exchange + staged operands | L 16 x 16 | main: M image m x 16
+    int off_hv; // h_i by lane (64), inside Y behind everything else
+    int off_v;  // kAv, rv, zv, their shadows, y0v, invv
+    int off_stage, nA, nB, nC, nD;
     int total;
 };
 
@@ -353,21 +361,20 @@ __global__ void __launch_bounds__(64, 4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sm = (T *)smem_raw;
-    constexpr int LDW = Vec<T>::LDW;
     const int lane = threadIdx.x;
     const int l15 = lane & 15;
     const bool low = lane < NV;
-    const int vofs = low ? lane : NVEC * NV + l15;  // element of a 16-vector (shadow for lanes >= 16)
-    const int wrow = low ? lane : NV;               // row of W (shadow row 16 for lanes >= 16)
+    const int vofs = low ? lane : 3 * NV + l15;  // element of an exchange vector (shadow for lanes >= 16)
     const int64_t prob = blockIdx.x;
     const int n = ka.n, m = ka.m;
+    const int cid = lane - CB;                   // constraint id of this lane
+    const bool isc = (lane >= CB) && (cid < m);  // this lane owns a constraint
     const T INF = Cst<T>::inf();
-    T *Wl = sm + L.off_W, *MAl = sm + L.off_MA, *Ll = sm + L.off_L;
-    T *mpv = sm + L.off_v, *kAv = mpv + NV, *rv = kAv + NV, *zv = rv + NV, *y0v = zv + NV, *invv = y0v + NV;
-    T *hv = sm + L.off_L + NV * NV;  // h_i per constraint lane (kept out of registers); behind L, in the dead staging area
-    T *Gimg = sm + L.off_W;  // build only
+    T *Gimg = sm + L.off_X, *MAl = sm + L.off_X, *Timg = sm + L.off_X + (NV + 1) * NV;
+    T *Ll = sm + L.off_Y, *Ml = sm + L.off_Y, *hv = sm + L.off_hv;
+    T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV, *y0v = zv + 4 * NV, *invv = y0v + NV;
 
-    T Mr[NV];  // this lane's row of G, then of M (lane m: q, then L^-1 q)
+    T R[NV];   // this lane's row: T_a (slots) | M_i (constraints) | row of L^-T
     T Pr[NV];  // lane a < 16: row a of P, then of L
     // optional phase timestamps (tools/probe_phases.py): ka.X -> long long[8] per problem
     long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
@@ -383,8 +390,8 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
         for (int b = 0; b < NV; ++b)
             Pr[b] = (lane < n && b < n) ? P[lane * n + b] : ((lane == b) ? T(1) : T(0));
-        hv[lane] = (lane < m) ? ge[prob * (int64_t)m + lane] : INF;
-        // rows of G (lane m: q) are parked in the LDS image until P is factorised,
+        hv[lane] = isc ? ge[prob * (int64_t)m + cid] : INF;
+        // rows of G (row m: q) are parked in the LDS image until P is factorised,
         // so that P's rows and G's rows are never live in registers together
         for (int i = lane; i < (m + 1) * NV; i += 64) {
             const int row = i / NV, b = i - row * NV;
@@ -407,8 +414,8 @@ __global__ void __launch_bounds__(64, 4)
         const int sC = ka.C.step_stride ? mk * nx : 0, sD = ka.D.step_stride ? mk * nu : 0;
         const bool stageP = ka.flags & MPCQP_P_STAGE, stageQ = (ka.flags & MPCQP_Q_STAGE) && tgt;
         const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
-        T *ex = Ll;            // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
-        T *hp = Ll + 4 * 32;   // hp[row] = C_k Phi_k x0 (m <= 63 entries)
+        T *ex = sm + L.off_Y;           // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
+        T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries)
         // One coalesced pass stages the problem's operands in LDS: a single HBM
         // latency instead of one per horizon step (a problem's steps are packed).
         T *As = sm + L.off_stage, *Bs = As + L.nA, *Cs = Bs + L.nB, *Ds = Cs + L.nC;
@@ -418,7 +425,7 @@ __global__ void __launch_bounds__(64, 4)
         for (int i = lane; i < L.nD; i += 64) Ds[i] = Dm[i];
         const bool isx = (lane == NV), col = (lane < n);
         const int j = col ? lane / nu : -1, ii = col ? lane - j * nu : 0;
-        const T eval = (lane < m) ? ge[prob * ka.e.batch_stride + (lane / mk) * ka.e.step_stride + (lane % mk)] : INF;
+        const T eval = isc ? ge[prob * ka.e.batch_stride + (cid / mk) * ka.e.step_stride + (cid % mk)] : INF;
         T v[NX], gref[NX];
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
@@ -565,7 +572,7 @@ __global__ void __launch_bounds__(64, 4)
         if (low) Gimg[m * NV + lane] = col ? qa : T(0);  // the q row
         wsync();
         // h_i = e_i - C_k Phi_k x0 goes to LDS; the rows of G stay in the LDS image for now
-        hv[lane] = (lane < m && L.nC) ? eval - hp[lane] : eval;
+        hv[lane] = (isc && L.nC) ? eval - hp[cid] : eval;
         wsync();
     }
 
@@ -607,41 +614,48 @@ __global__ void __launch_bounds__(64, 4)
         status = MPCQP_NOT_PD;
     } else {
         if (low) st16(Ll + lane * NV, Pr);  // L image (upper part is don't-care)
-        // rows of G by lane (lane m: q), fetched only now (register pressure). Lanes
-        // m+1 .. m+16 carry the identity: the forward substitution turns them into the
-        // rows of L^-T, so that u = L^-T y is one dot product at the end.
-        if (lane <= m) {
-            ld16(Mr, Gimg + lane * NV);
-        } else {
+        // Rows fetched only now (register pressure): lane 0 takes q, constraint lanes
+        // their row of G, lanes 48.. the identity (-> rows of L^-T), all others zero.
+        {
+            const bool fetch = isc || lane == 0;
+            const int row = isc ? cid : m;
+            if (fetch) {
+                ld16(R, Gimg + row * NV);
+            } else {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) Mr[k] = (lane == m + 1 + k) ? T(1) : T(0);
+                for (int k = 0; k < NV; ++k) R[k] = (lane == LB + k) ? T(1) : T(0);
+            }
         }
         wsync();
-        // M = G L^-T, one row per lane (lane m: L^-1 q)
+        // R <- R L^-T, one row per lane
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            T acc = Mr[j];
+            T acc = R[j];
 #pragma unroll
             for (int h = 0; h < j; h += HV) {
                 T lrow[HV];
                 ld8(lrow, Ll + j * NV + h);  // broadcast row j of L
 #pragma unroll
                 for (int k = 0; k < HV; ++k)
-                    if (h + k < j) acc -= Mr[h + k] * lrow[k];
+                    if (h + k < j) acc -= R[h + k] * lrow[k];
                 half_fence();
             }
-            Mr[j] = acc * invv[j];
-            pin(Mr[j]);
+            R[j] = acc * invv[j];
+            pin(R[j]);
         }
         tick(3);
-        if (lane == m) st16(y0v, Mr);  // w = L^-1 q ; y0 = -w
-        // clear T and the slot rows (incl. the shadow rows)
-        for (int i = lane; i < (NV + 1) * LDW; i += 64) Wl[i] = T(0);
+        wsync();  // every lane is done with the L image: the M image takes its place
+        if (lane == 0) st16(y0v, R);           // w = L^-1 q ; y0 = -w
+        if (isc) st16(Ml + cid * NV, R);       // image of M for the row-p broadcasts
         for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
+        if (low) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) R[k] = T(0);  // T = N* starts empty
+        }
         wsync();
         const T hval = hv[lane];
-        T s = hval + dot_reg_lds(Mr, y0v);  // h - M y0  (y0 = -L^-1 q)
-        s = (lane < m) ? s : INF;
+        T s = hval + dot_reg_lds(R, y0v);  // h - M y0  (y0 = -L^-1 q)
+        s = isc ? s : INF;
         // Selection rule (the classic Goldfarb-Idnani one): among the rows violated
         // beyond the tolerance, take the one FARTHEST from its hyperplane in the
         // P^-1 metric, s_i / |M_i|. On the triple-integrator family this needs
@@ -651,14 +665,13 @@ __global__ void __launch_bounds__(64, 4)
         {
             T nn = T(0);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) nn += Mr[k] * Mr[k];
+            for (int k = 0; k < NV; ++k) nn += R[k] * R[k];
             invn = (nn > T(0)) ? Cst<T>::rs(nn) : T(1);
         }
-        const bool selectable = (lane < m) && (hval < T(1e29));
+        const bool selectable = isc && (hval < T(1e29));
         const T tol = (T)ka.tol;
         const T tolh = tol + tol * fabs(hval);  // row i is violated when s_i < -tol (1 + |h_i|)
         const int max_iter = ka.max_iter;
-        T *Tl = Wl;  // T = N*: slot rows, stride LDW
 
         T lam = T(0);
         int myact = 0, pos = -1, nq = 0;
@@ -674,92 +687,122 @@ __global__ void __launch_bounds__(64, 4)
                     status = MPCQP_SOLVED;
                     break;
                 }
-                // broadcast row p of M through LDS
-                wsync();
-                if (lane == p) st16(mpv, Mr);
-                wsync();
-                const T ip = bcast(invn, p);  // 1 / |M_p|
+                const T *mprow = Ml + (p - CB) * NV;  // row p of M, read as broadcast
+                const T ip = bcast(invn, p);          // 1 / |M_p|
                 T up = T(0);
                 bool added = false;
+                // Each trip of this loop makes exactly ONE pass "R += c * vec" over the row
+                // registers: either the step along z (s and, on a full step, T are updated)
+                // or, right after a partial step, the removal of slot ldrop from T. Keeping
+                // a single modification site of R is what keeps R in registers.
+                bool dropping = false;
+                int ldrop = 0;
                 while (!added) {
-                    if (iters >= max_iter) {
-                        fail = true;
-                        break;
-                    }
-                    ++iters;
-                    // r = T M_p (lane a < 16: slot a)
-                    T r = dot_lds_lds(Tl + wrow * LDW, mpv);
-                    r = occ ? r : T(0);
-                    rv[vofs] = r;
-                    wsync();
-                    // z = -M_p + M_A' r (lane k < 16)
-                    T z = dot_vec_col<NV>(rv, MAl + l15, -mpv[l15]);
-                    z = low ? z : T(0);
-                    zv[vofs] = z;
-                    const T d2 = bcast(row_sum(z * z), 0);
-                    // ratio test on the multipliers
-                    const bool cand = occ && (r > T(0));
-                    const T ratio = cand ? lam * fast_rcp(r) : INF;
-                    const int l = argmin_row0<T>(ratio, cand, lane);
-                    const T t1 = (l < 64) ? bcast(ratio, l) : INF;
-                    const bool can_move = (nq < n) && (d2 * ip * ip > Cst<T>::dep()) && (d2 > T(0));
-                    const T sp = bcast(s, p);
-                    const T inv = can_move ? fast_rcp(d2) : T(0);
-                    const T t2 = can_move ? -sp * inv : INF;
-                    const T t = t1 < t2 ? t1 : t2;
-                    if (!(t < INF)) {
-                        status = MPCQP_INFEASIBLE;
-                        fail = true;
-                        break;
-                    }
-                    // the implied primal point moves by t z: s_i -= t M_i . z
-                    wsync();
-                    {
-                        const T mz = dot_reg_lds(Mr, zv);
-                        if (lane < m) s = (pos >= 0) ? T(0) : s - t * mz;
-                    }
-                    lam -= t * r;
-                    lam = (occ && lam < T(0)) ? T(0) : lam;
-                    up += t;
-                    if (t2 <= t1) {
-                        // full step: p takes the lowest free slot sl.
-                        // T_a += (r_a / d2) z for the active rows, T_sl = -z / d2 (row sl was zero)
-                        const int sl = __builtin_ctz(~mask);
-                        const T coef = (lane == sl) ? -inv : r * inv;
-                        axpy_row_lds(Tl + wrow * LDW, coef, zv, false);
-                        MAl[(low ? sl : NV) * NV + l15] = mpv[l15];
-                        if (lane == sl) {
-                            lam = up;
-                            myact = p;
-                            occ = true;
+                    const T *vec;
+                    T c, t = T(0), r = T(0);
+                    bool full = false;
+                    int sl = 0;
+                    if (!dropping) {
+                        if (iters >= max_iter) {
+                            fail = true;
+                            break;
                         }
-                        if (lane == p) {
-                            pos = sl;
-                            s = T(0);
-                        }
-                        mask |= 1u << sl;
-                        ++nq;
-                        added = true;
-                    } else {
-                        // partial step: slot l leaves. With W = T T' implicit,
-                        // T_a -= (T_a . T_l / T_l . T_l) T_l and row l is cleared.
-                        const int cl = bcast(myact, l);
-                        if (lane == l) {  // row l is both an operand and a target: copy it out
-                            T tmp[NV];
-                            ld16(tmp, Tl + l * LDW);
-                            st16(kAv, tmp);
-                        }
+                        ++iters;
+                        // r = T M_p (slot lanes; the other roles compute and ignore)
+                        r = dot_reg_lds(R, mprow);
+                        r = occ ? r : T(0);
+                        rv[vofs] = r;
                         wsync();
-                        const T tl = dot_lds_lds(Tl + wrow * LDW, kAv);
-                        const T f = tl * fast_rcp(bcast(tl, l));
-                        axpy_row_lds(Tl + wrow * LDW, -f, kAv, lane == l);
-                        if (lane == l) {
+                        // z = -M_p + M_A' r (lane k < 16)
+                        T z = dot_vec_col<NV>(rv, MAl + l15, -mprow[l15]);
+                        z = low ? z : T(0);
+                        zv[vofs] = z;
+                        const T d2 = bcast(row_sum(z * z), 0);
+                        // ratio test on the multipliers
+                        const bool cand = occ && (r > T(0));
+                        const T ratio = cand ? lam * fast_rcp(r) : INF;
+                        const int l = argmin_row0<T>(ratio, cand, lane);
+                        const T t1 = (l < 64) ? bcast(ratio, l) : INF;
+                        const bool can_move = (nq < n) && (d2 * ip * ip > Cst<T>::dep()) && (d2 > T(0));
+                        const T sp = bcast(s, p);
+                        const T inv = can_move ? fast_rcp(d2) : T(0);
+                        const T t2 = can_move ? -sp * inv : INF;
+                        t = t1 < t2 ? t1 : t2;
+                        if (!(t < INF)) {
+                            status = MPCQP_INFEASIBLE;
+                            fail = true;
+                            break;
+                        }
+                        full = (t2 <= t1);
+                        sl = __builtin_ctz(~mask);  // lowest free slot
+                        ldrop = l;
+                        // on a full step T gets its rank-1 update T_a += (r_a/d2) z, T_sl = -z/d2
+                        c = full ? ((lane == sl) ? -inv : r * inv) : T(0);
+                        vec = zv;
+                    } else {
+                        // slot ldrop leaves (its row T_l was copied to kAv). With W = T T' implicit,
+                        // T_a -= (T_a . T_l / T_l . T_l) T_l ; row l becomes exactly zero (f = 1).
+                        const T tl = dot_reg_lds(R, kAv);
+                        const T f = tl * fast_rcp(bcast(tl, ldrop));
+                        c = (lane == ldrop) ? T(-1) : (occ ? -f : T(0));
+                        vec = kAv;
+                    }
+                    wsync();
+                    // the single pass over vec: m_i = R_i . vec (before the update), R += c vec
+                    T mz0 = T(0), mz1 = T(0);
+#pragma unroll
+                    for (int h = 0; h < NV; h += HV) {
+                        T zz[HV];
+                        ld8(zz, vec + h);
+#pragma unroll
+                        for (int k = 0; k < HV; k += 2) {
+                            mz0 += R[h + k] * zz[k];
+                            mz1 += R[h + k + 1] * zz[k + 1];
+                        }
+#pragma unroll
+                        for (int k = 0; k < HV; ++k) {
+                            R[h + k] += c * zz[k];
+                            pin(R[h + k]);
+                        }
+                        half_fence();
+                    }
+                    if (!dropping) {
+                        // the implied primal point moved by t z: s_i -= t M_i . z
+                        if (isc) s = (pos >= 0) ? T(0) : s - t * (mz0 + mz1);
+                        lam -= t * r;
+                        lam = (occ && lam < T(0)) ? T(0) : lam;
+                        up += t;
+                        if (full) {
+                            // p takes slot sl
+                            MAl[(low ? sl : NV) * NV + l15] = mprow[l15];
+                            if (lane == sl) {
+                                lam = up;
+                                myact = p;
+                                occ = true;
+                            }
+                            if (lane == p) {
+                                pos = sl;
+                                s = T(0);
+                            }
+                            mask |= 1u << sl;
+                            ++nq;
+                            added = true;
+                        } else {
+                            // partial step: the next trip removes slot ldrop from T
+                            const int cl = bcast(myact, ldrop);
+                            wsync();
+                            if (lane == ldrop) st16(kAv, R);
+                            if (lane == cl) pos = -1;
+                            dropping = true;
+                        }
+                    } else {
+                        if (lane == ldrop) {
                             lam = T(0);
                             occ = false;
                         }
-                        if (lane == cl) pos = -1;
-                        mask &= ~(1u << l);
+                        mask &= ~(1u << ldrop);
                         --nq;
+                        dropping = false;
                     }
                     wsync();
                 }
@@ -776,8 +819,8 @@ __global__ void __launch_bounds__(64, 4)
             y = -y0v[l15] - y;  // y0 = -L^-1 q
             zv[vofs] = y;
             wsync();
-            T fresh = hv[lane] - dot_reg_lds(Mr, zv);
-            fresh = (lane < m) ? fresh : INF;
+            T fresh = hv[lane] - dot_reg_lds(R, zv);
+            fresh = isc ? fresh : INF;
             if (nq > 0) {
                 // active residuals rho_a = h_a - M_a y should vanish:
                 // dlam = -W rho_A = -T (T' rho_A)
@@ -785,11 +828,12 @@ __global__ void __launch_bounds__(64, 4)
                 rho = occ ? rho : T(0);
                 wsync();
                 kAv[vofs] = rho;
+                if (low) st16(Timg + lane * NV, R);  // T by columns is only needed here
                 wsync();
-                const T uk = dot_vec_col<LDW>(kAv, Tl + l15, T(0));  // (T' rho)_k, lane k < 16
+                const T uk = dot_vec_col<NV>(kAv, Timg + l15, T(0));  // (T' rho)_k, lane k < 16
                 rv[vofs] = low ? uk : T(0);
                 wsync();
-                T dl = -dot_lds_lds(Tl + wrow * LDW, rv);
+                T dl = -dot_reg_lds(R, rv);
                 dl = occ ? dl : T(0);
                 lam += dl;
                 lam = (occ && lam < T(0)) ? T(0) : lam;
@@ -800,25 +844,13 @@ __global__ void __launch_bounds__(64, 4)
                 wsync();
                 zv[vofs] = y;
                 wsync();
-                fresh = hv[lane] - dot_reg_lds(Mr, zv);
-                fresh = (lane < m) ? fresh : INF;
+                fresh = hv[lane] - dot_reg_lds(R, zv);
+                fresh = isc ? fresh : INF;
             }
             // accept when no inactive row is violated at the re-evaluated point
             const bool clean = __ballot(selectable && pos < 0 && fresh < -T(4) * tolh) == 0ull;
             if (clean || round == 3) {
-                if (m + 1 + NV <= 64) {
-                    // u = L^-T y: lane m+1+k holds row k of L^-T (zv holds y)
-                    xsol = dot_reg_lds(Mr, zv);
-                } else {
-                    // column sweep from the last row (lane k < 16 holds y_k)
-                    T yy = low ? y : T(0);
-#pragma unroll
-                    for (int i = NV - 1; i >= 0; --i) {
-                        const T xi = bcast(yy, i) * invv[i];
-                        if (lane == i) xsol = xi;
-                        if (lane < i) yy -= Ll[i * NV + lane] * xi;
-                    }
-                }
+                xsol = dot_reg_lds(R, zv);  // u = L^-T y in lanes 48..63 (zv holds y)
                 status = clean ? MPCQP_SOLVED : MPCQP_MAX_ITER;
                 break;
             }
@@ -836,10 +868,10 @@ __global__ void __launch_bounds__(64, 4)
     tick(6);
     const bool ok = (status == MPCQP_SOLVED);
     {
-        const int k = (m + 1 + NV <= 64) ? lane - (m + 1) : lane;  // which u_k this lane holds
+        const int k = lane - LB;  // lanes 48.. hold u_k
         if (k >= 0 && k < n) oU[prob * (int64_t)n + k] = ok ? xsol : T(0);
     }
-    if (olam && lane < m) olam[prob * (int64_t)m + lane] = ok ? lam_out : T(0);
+    if (olam && isc) olam[prob * (int64_t)m + cid] = ok ? lam_out : T(0);
     if (lane == 0) {
         if (ostatus) ostatus[prob] = status;
         if (oiters) oiters[prob] = iters;
@@ -850,39 +882,39 @@ __global__ void __launch_bounds__(64, 4)
 template <typename T> static Lay make_lay(const KernelArgs &ka)
 {
     Lay L{};
-    int o = 0;
-    auto take = [&](int cnt) {
-        const int at = o;
-        o += (cnt + 3) & ~3;  // keep 16-byte alignment for float and double
-        return at;
-    };
-    const int wma = (NV + 1) * Vec<T>::LDW + (NV + 1) * NV;  // W followed by M_A (+ shadow rows)
-    const int gimg = (ka.m + 1) * NV;            // build-time image of G (+ q row)
-    L.off_W = take(wma > gimg ? wma : gimg);
-    L.off_MA = L.off_W + (((NV + 1) * Vec<T>::LDW + 3) & ~3);
-    int scratch = 4 * 32 + 64;  // ex (4 x 32), hp
-    if (ka.A.ptr) {  // fused mode: room for the staged operands behind the exchange buffers
-        auto al = [](int c) { return (c + 3) & ~3; };
+    auto al = [](int c) { return (c + 3) & ~3; };  // 16-byte alignment for float and double
+    const int gimg = (ka.m + 1) * NV, main_x = (NV + 1) * NV + NV * NV;
+    L.off_X = 0;
+    int o = al(gimg > main_x ? gimg : main_x);
+    L.off_Y = o;
+    int y_build = 4 * 32 + 64;  // ex (4 x 32), hp
+    L.off_stage = L.off_Y + y_build;
+    if (ka.A.ptr) {  // fused mode: the staged operands sit behind the exchange buffers
         L.nA = (ka.A.step_stride ? ka.N : 1) * ka.nx * ka.nx;
         L.nB = (ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
         L.nC = ka.C.ptr ? (ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx : 0;
         L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
-        scratch += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
+        y_build += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
     }
-    L.off_L = take(NV * NV + 64 > scratch ? NV * NV + 64 : scratch);  // L, then hv[64]
-    L.off_stage = L.off_L + 4 * 32 + 64;
-    L.off_v = take(2 * NVEC * NV);
+    int y_main = ka.m * NV;  // the M image; the L image (16 x 16) fits inside
+    if (y_main < NV * NV) y_main = NV * NV;
+    const int y_sz = al(y_build > y_main ? y_build : y_main);
+    L.off_hv = L.off_Y + y_sz;
+    o = L.off_hv + 64;
+    L.off_v = o;
+    o += 8 * NV;  // kAv rv zv | shadows | y0v invv
     L.total = o;
     return L;
 }
 
-// float64 only: in single precision the explicit inverse Gram matrix W loses too
-// much on ill-conditioned active sets (cond up to 2e8 in the humanoid sweep);
-// float32 problems go to the Q-based kernel of mpcqp_lds.hip instead.
+// float64 only: in single precision the explicit operator T loses too much on
+// ill-conditioned active sets (cond up to 2e8 in the humanoid sweep); float32
+// problems go to the Q-based kernel of mpcqp_lds.hip instead. m <= 32 and n <= 16
+// are what the lane map holds.
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype)
 {
     if (dtype != MPCQP_F64) return false;
-    if (ka.n > NV || ka.m > 63) return false;
+    if (ka.n > NV || ka.m > MMAX) return false;
     if (mode == MODE_FUSED && ka.nx != 3 && ka.nx != 4) return false;
     return mode == MODE_FUSED || mode == MODE_SOLVE;
 }
