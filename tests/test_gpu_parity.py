@@ -287,3 +287,52 @@ def test_c_abi_argument_errors():
     assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == -1  # w_input must be > 0
     d = _capi.Dims(12, 4, 64, 16, 0, 15, 10.0, 1.0, 1e-2)
     assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == -2  # does not fit LDS
+
+
+def test_config3_closed_loop_matches_cpu_oracle_loop():
+    """Receding horizon on the device (examples/wheeled_inverted_pendulum.py:99-118 for
+    a batch) vs the same loop on the CPU with the oracle as the solver."""
+    from qpmpc_amd.closed_loop import NB_SUBSTEPS, WIPClosedLoop
+
+    rng = np.random.default_rng(1)
+    x0 = rng.standard_normal((12, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    x0[0] = [0.0, 0.3, 0.0, 1.0]  # saturates the input box on the first steps
+    loop = WIPClosedLoop(x0, nb_timesteps=50, sampling_period=0.024, target_vel=0.5)
+    pend = loop.pendulum
+    # CPU loop: reference semantics, one problem at a time
+    states = x0.copy()
+    prob = pend.build_mpc_problem(terminal_cost_weight=10.0, stage_state_cost_weight=1.0, stage_input_cost_weight=1e-3)
+    steps = 4
+    sat = 0.0
+    for _ in range(steps):
+        loop.step()
+        for b in range(len(states)):
+            ts = pend.target_states(states[b], 0.5)
+            prob.update_initial_state(states[b])
+            prob.update_goal_state(ts[-4:])
+            prob.update_target_states(ts[:-4])
+            U, st, _ = oracle.solve_mpc_like_reference(prob)
+            assert st == 0
+            sat = max(sat, abs(U[0, 0]))
+            for _ in range(NB_SUBSTEPS):
+                states[b] = pend.integrate(states[b], U[0], pend.sampling_period / NB_SUBSTEPS)
+        got = loop.states.cpu().numpy()
+        assert np.abs(got - states).max() <= 1e-7, np.abs(got - states).max()
+    assert sat >= 10.0 - 1e-9  # the box was active at least once
+    st = loop.stats()
+    assert st["failed"] == 0 and st["builds_and_solves"] == steps * 12
+
+
+def test_config3_closed_loop_regulates_the_pendulum():
+    """Property check at scale: 256 loops, 60 MPC steps; every loop stays upright and
+    approaches the target ground velocity."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(7)
+    x0 = rng.standard_normal((256, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    loop = WIPClosedLoop(x0, target_vel=0.5)
+    loop.step(60)
+    x = loop.states.cpu().numpy()
+    assert loop.stats()["failed"] == 0
+    assert np.isfinite(x).all() and np.abs(x[:, 1]).max() < 0.2  # pitch stays small
+    assert np.abs(x[:, 2] - 0.5).max() < 0.1  # ground velocity near the target
