@@ -11,7 +11,9 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the
- *    caller (the library never allocates or frees device memory);
+ *    caller (the library never allocates or frees device memory); problems that do
+ *    not fit the on-chip path need a caller-provided scratch `workspace` whose size
+ *    the *_workspace_bytes functions report (0 for the on-chip path; NULL is then fine);
  *  - every call is asynchronous on the caller's hipStream_t (passed as void*;
  *    NULL = the null stream), re-entrant, no global state;
  *  - return value: 0 ok, <0 bad argument (MPCQP_E*), >0 a hipError_t;
@@ -30,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 1
+#define MPCQP_ABI_VERSION 2
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -56,6 +58,7 @@ extern "C" {
 #define MPCQP_ETOOLARGE (-2) /* problem does not fit the on-chip (LDS) path   */
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
 #define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
+#define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */
 
 /* Problem dimensions and cost weights (mpc_problem.py:88-139).
  * n = N*nu decision variables, m = N*mk inequality rows. Problems whose
@@ -111,8 +114,17 @@ int mpcqp_abi_version(void);
 const char *mpcqp_error_string(int code);
 
 /* Dynamic LDS bytes one problem of these dimensions needs on the fused path;
- * MPCQP_ETOOLARGE when it exceeds the 160 KiB of a gfx950 CU. */
+ * MPCQP_ETOOLARGE when it exceeds the 160 KiB of a gfx950 CU (such problems take the
+ * HBM-resident path and need a workspace). */
 int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes);
+
+/* Device scratch bytes that mpcqp_condense_batch (for_solve == 0) or
+ * mpcqp_build_solve_batch (for_solve != 0) need for `batch` problems of these
+ * dimensions: 0 when the problem fits the on-chip path. */
+int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solve, size_t *bytes);
+
+/* Same for mpcqp_solve_batch (n variables, m rows). */
+int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t batch, size_t *bytes);
 
 /* Replaces MPCQP.__init__ (mpc_qp.py:39-122) for a batch: Phi/Psi propagation
  * (:53-54,:88-90), G_k/h_k (:62-78), P (:99-105), q (:129-149).
@@ -121,7 +133,8 @@ int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes);
  * Psi[(N+1)*nx*n]  (blocks Psi_0..Psi_N; the last one is psi_last) may be NULL. */
 int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                          int64_t batch, void *P, void *q, void *G, void *h,
-                         void *Phi, void *Psi, void *stream);
+                         void *Phi, void *Psi, void *workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* Replaces MPCQP.update_cost_vector (mpc_qp.py:129-149) and
  * MPCQP.update_constraint_vector (mpc_qp.py:151-163) for a batch, from the
@@ -141,7 +154,8 @@ int mpcqp_update_vectors_batch(const MpcqpDims *dims, const MpcqpProblem *proble
 int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P,
                       const void *q, const void *G, const void *h, int64_t batch,
                       const MpcqpSolveOpts *opts, void *x, void *lam,
-                      int32_t *status, int32_t *iters, void *stream);
+                      int32_t *status, int32_t *iters, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* Replaces the whole of solve_mpc (qpmpc/solve_mpc.py:42-44) for a batch, fused:
  * P, G and their factors never leave the CU. U[batch*n] is the stacked input
@@ -149,7 +163,7 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P,
 int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                             int64_t batch, const MpcqpSolveOpts *opts, void *U,
                             void *lam, int32_t *status, int32_t *iters,
-                            void *stream);
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* Replaces MPCProblem.integrate (mpc_problem.py:316-335) as used by Plan.states
  * (plan.py:81-109) for a batch: X[batch*(N+1)*nx], X_0 = x0,

@@ -13,7 +13,7 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -22,6 +22,8 @@ EXPORTS = (
     "mpcqp_abi_version",
     "mpcqp_error_string",
     "mpcqp_lds_bytes",
+    "mpcqp_workspace_bytes",
+    "mpcqp_solve_workspace_bytes",
     "mpcqp_condense_batch",
     "mpcqp_update_vectors_batch",
     "mpcqp_solve_batch",
@@ -79,16 +81,21 @@ def load():
     lib.mpcqp_error_string.argtypes = [C.c_int]
     lib.mpcqp_lds_bytes.restype = C.c_int
     lib.mpcqp_lds_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
+    lib.mpcqp_workspace_bytes.restype = C.c_int
+    lib.mpcqp_workspace_bytes.argtypes = [C.POINTER(Dims), i64, C.c_int32, C.POINTER(C.c_size_t)]
+    lib.mpcqp_solve_workspace_bytes.restype = C.c_int
+    lib.mpcqp_solve_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, i64, C.POINTER(C.c_size_t)]
     lib.mpcqp_condense_batch.restype = C.c_int
-    lib.mpcqp_condense_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpcqp_condense_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, vp, vp, vp, vp, vp, vp, vp,
+                                         C.c_size_t, vp]
     lib.mpcqp_update_vectors_batch.restype = C.c_int
     lib.mpcqp_update_vectors_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), vp, i64, vp, i64, i64, vp, vp, vp]
     lib.mpcqp_solve_batch.restype = C.c_int
     lib.mpcqp_solve_batch.argtypes = [C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, i64,
-                                      C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
+                                      C.POINTER(SolveOpts), vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.mpcqp_build_solve_batch.restype = C.c_int
     lib.mpcqp_build_solve_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts),
-                                            vp, vp, vp, vp, vp]
+                                            vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.mpcqp_rollout_batch.restype = C.c_int
     lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
                                         C.POINTER(Operand), vp, i64, vp, vp]

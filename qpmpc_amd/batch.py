@@ -309,6 +309,24 @@ def _require_on_gpu(*tensors) -> None:
             raise BackendError(f"operand on {t.device}: the HIP path needs device-resident tensors (no CPU fallback)")
 
 
+def _workspace(problem: "BatchMPCProblem", for_solve: bool):
+    """Caller-owned scratch for problems that do not fit the on-chip path (None when
+    they do): a uint8 tensor of exactly ``mpcqp_workspace_bytes`` bytes."""
+    torch = _torch()
+    lib = _capi.load()
+    dims = problem.dims()
+    nbytes = C.c_size_t(0)
+    rc = lib.mpcqp_workspace_bytes(C.byref(dims), problem.batch_size, 1 if for_solve else 0, C.byref(nbytes))
+    _capi.check(rc, "mpcqp_workspace_bytes")
+    if nbytes.value == 0:
+        return None
+    return torch.empty((nbytes.value,), dtype=torch.uint8, device=problem.device)
+
+
+def _ws_args(ws):
+    return (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
+
+
 def _opts(max_iter=None, feas_tol=None):
     return _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))
 
@@ -365,11 +383,14 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol)
+    ws = _workspace(problem, True)
     rc = lib.mpcqp_build_solve_batch(
         C.byref(dims), C.byref(cp), Bn, C.byref(opts), U.data_ptr(),
-        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), _stream_ptr())
+        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), *_ws_args(ws), _stream_ptr())
     _capi.check(rc, "mpcqp_build_solve_batch")
-    return BatchPlan(problem, U, status, iters, lam)
+    plan = BatchPlan(problem, U, status, iters, lam)
+    plan._workspace = ws  # keep the scratch alive until the stream has consumed it
+    return plan
 
 
 class PreparedSolve:
@@ -393,6 +414,7 @@ class PreparedSolve:
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self._opts = _opts(max_iter, feas_tol)
+        self._ws = _workspace(problem, True)
         self.rebind()
 
     def rebind(self) -> None:
@@ -400,7 +422,7 @@ class PreparedSolve:
         self._args = (
             C.byref(self._dims), C.byref(self._cp), self.problem.batch_size, C.byref(self._opts),
             self.U.data_ptr(), None if self.lam is None else self.lam.data_ptr(),
-            self.status.data_ptr(), self.iters.data_ptr(),
+            self.status.data_ptr(), self.iters.data_ptr(), *_ws_args(self._ws),
         )
 
     def launch(self, stream=None) -> None:
@@ -430,10 +452,11 @@ class BatchMPCQP:
         self.Phi_all = mk(Bn, (N + 1) * nx, nx) if keep_propagators else None
         self.Psi_all = mk(Bn, (N + 1) * nx, n) if keep_propagators else None
         dims, cp = problem.dims(), problem.c_problem()
+        self._ws = _workspace(problem, False)
         rc = lib.mpcqp_condense_batch(
             C.byref(dims), C.byref(cp), Bn, self.P.data_ptr(), self.q.data_ptr(), self.G.data_ptr(),
             self.h.data_ptr(), None if self.Phi_all is None else self.Phi_all.data_ptr(),
-            None if self.Psi_all is None else self.Psi_all.data_ptr(), _stream_ptr())
+            None if self.Psi_all is None else self.Psi_all.data_ptr(), *_ws_args(self._ws), _stream_ptr())
         _capi.check(rc, "mpcqp_condense_batch")
         self.nb_timesteps, self.state_dim = N, nx
 
@@ -477,10 +500,14 @@ def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, 
     status = torch.empty((Bn,), dtype=torch.int32, device=P.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=P.device)
     opts = _opts(max_iter, feas_tol)
+    nbytes = C.c_size_t(0)
+    _capi.check(lib.mpcqp_solve_workspace_bytes(n, m, _dtype_code(P.dtype), Bn, C.byref(nbytes)),
+                "mpcqp_solve_workspace_bytes")
+    ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=P.device) if nbytes.value else None
     rc = lib.mpcqp_solve_batch(
         n, m, _dtype_code(P.dtype), P.data_ptr(), q.data_ptr(), None if m == 0 else G.data_ptr(),
         None if m == 0 else h.data_ptr(), Bn, C.byref(opts), x.data_ptr(),
-        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), _stream_ptr())
+        None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), *_ws_args(ws), _stream_ptr())
     _capi.check(rc, "mpcqp_solve_batch")
     return x, lam, status, iters
 

@@ -1,0 +1,289 @@
+// mpcqp_big.hip -- gfx950 kernels for problems too large for one CU's LDS
+// (BASELINE config 5: nx=12, nu=4, N=64 -> n=256 variables, m=1024 rows, f32).
+// Psi, G and P live in HBM (per-problem slices of a caller-owned workspace);
+// the condensing is split into
+//   mpcqp_propagate_kernel : Phi/Psi propagation, G_k, h_k, tracking residuals
+//                            (qpmpc/mpc_qp.py:53-98)        -- HBM-bound streaming
+//   mpcqp_gram_mfma_f32    : P = w_u I + Psi' W Psi, q = Psi' W resid
+//                            (qpmpc/mpc_qp.py:99-105,129-149) -- MFMA-bound SYRK
+// The Gram contraction is the only GEMM-shaped step of the path (1.0e8 of the
+// 1.15e8 flops of a config-5 build) and the only one that goes to
+// the matrix cores: v_mfma_f32_32x32x2_f32, exact f32 (bitwise an fmaf chain).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace big {
+constexpr int NXMAX = 16;  // state dimension held in registers by the propagation
+constexpr int KC = 16;     // rows of Psi staged per Gram step
+}  // namespace big
+using namespace big;
+
+// ------------------------------------------------------------------ propagate
+// One workgroup per problem, thread c < n owns column c of Psi, thread n the free
+// response Phi_k x0. A_k, B_k, C_k, D_k of the current step are staged in LDS and read
+// as broadcast. Outputs (per problem): Psi_all [(N+1)*nx, n] (block 0 is zero),
+// resid [(N+1)*nx] = Phi_k x0 - ref_k, G [m, n], h [m].
+template <typename T>
+__global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
+                                                              T *__restrict__ res_ws, T *__restrict__ oG,
+                                                              T *__restrict__ oh)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sm = (T *)smem_raw;
+    const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, n = ka.n, m = ka.m;
+    const int tid = threadIdx.x;
+    const int64_t prob = blockIdx.x;
+    T *As = sm, *Bs = As + nx * nx, *Cs = Bs + nx * nu, *Ds = Cs + mk * nx, *es = Ds + mk * nu;
+    const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
+    const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
+    const T *gC = ka.C.ptr ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
+    const T *gD = ka.D.ptr ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+    const T *ge = (const T *)ka.e.ptr + prob * ka.e.batch_stride;
+    const T *gx0 = (const T *)ka.x0.ptr + prob * ka.x0.batch_stride;
+    const T *ggoal = ka.goal.ptr ? (const T *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+    const T *gtgt = ka.targets.ptr ? (const T *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+    T *Psi = Psi_ws + prob * (int64_t)(N + 1) * nx * n;
+    T *res = res_ws + prob * (int64_t)(N + 1) * nx;
+    T *G = oG + prob * (int64_t)m * n;
+    T *h = oh + prob * (int64_t)m;
+    const bool isx = (tid == n), col = (tid < n);
+    const int j = col ? tid / nu : -1, ii = col ? tid - j * nu : 0;
+    const bool qs = (ka.flags & MPCQP_Q_STAGE) && gtgt, qt = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+
+    T v[NXMAX];
+#pragma unroll
+    for (int s = 0; s < NXMAX; ++s) v[s] = (isx && s < nx) ? gx0[s] : T(0);
+    for (int k = 0; k <= N; ++k) {
+        __syncthreads();
+        if (k < N) {  // stage the operands of step k (coalesced)
+            for (int i = tid; i < nx * nx; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
+            for (int i = tid; i < nx * nu; i += blockDim.x) Bs[i] = gB[k * ka.B.step_stride + i];
+            if (gC)
+                for (int i = tid; i < mk * nx; i += blockDim.x) Cs[i] = gC[k * ka.C.step_stride + i];
+            if (gD)
+                for (int i = tid; i < mk * nu; i += blockDim.x) Ds[i] = gD[k * ka.D.step_stride + i];
+            for (int i = tid; i < mk; i += blockDim.x) es[i] = ge[k * ka.e.step_stride + i];
+        }
+        __syncthreads();
+        // v = Psi_k[:, c] (thread n: Phi_k x0)
+        if (col) {
+#pragma unroll
+            for (int s = 0; s < NXMAX; ++s)
+                if (s < nx) Psi[((int64_t)k * nx + s) * n + tid] = v[s];
+        } else if (isx) {
+#pragma unroll
+            for (int s = 0; s < NXMAX; ++s)
+                if (s < nx) {
+                    T ref = T(0);
+                    if (k < N) {
+                        if (qs) ref = gtgt[k * nx + s];
+                    } else if (qt) {
+                        ref = ggoal[s];
+                    }
+                    res[k * nx + s] = v[s] - ref;
+                }
+        }
+        if (k == N) break;
+        if (col || isx) {
+            // rows of G / h for step k (mpc_qp.py:62-78)
+            for (int i2 = 0; i2 < mk; ++i2) {
+                T acc = T(0);
+                if (gC) {
+#pragma unroll
+                    for (int s = 0; s < NXMAX; ++s)
+                        if (s < nx) acc += Cs[i2 * nx + s] * v[s];
+                }
+                if (col) {
+                    if (gD && j == k) acc += Ds[i2 * nu + ii];
+                    G[((int64_t)k * mk + i2) * n + tid] = acc;
+                } else {
+                    h[k * mk + i2] = es[i2] - acc;
+                }
+            }
+            // advance (mpc_qp.py:88-90)
+            T w[NXMAX];
+#pragma unroll
+            for (int r = 0; r < NXMAX; ++r) {
+                T acc = T(0);
+                if (r < nx) {
+#pragma unroll
+                    for (int s = 0; s < NXMAX; ++s)
+                        if (s < nx) acc += As[r * nx + s] * v[s];
+                }
+                w[r] = acc;
+            }
+            if (col && j == k) {
+#pragma unroll
+                for (int r = 0; r < NXMAX; ++r)
+                    if (r < nx) w[r] = Bs[r * nu + ii];
+            }
+#pragma unroll
+            for (int r = 0; r < NXMAX; ++r) v[r] = w[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Gram, MFMA f32
+// P = w_u I + sum_rows w_row Psi[row,:]' Psi[row,:]  (n x n, n a multiple of 32, <= 256)
+// One workgroup of 8 wavefronts per problem. Wavefront w owns tile row w: the 32 x n
+// strip P[32w : 32w+32, :] as n/32 accumulators of v_mfma_f32_32x32x2_f32. Psi is
+// streamed through LDS KC rows at a time; the A operand (this wavefront's 32 columns,
+// scaled by the row weight) is loaded once per k-step and reused for every tile of
+// the strip. q = Psi' W resid is accumulated by the first n threads from the same tile.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+template <int NT>  // NT = n / 32 tiles per strip
+__global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelArgs ka, const float *__restrict__ Psi_ws,
+                                                                   const float *__restrict__ res_ws,
+                                                                   float *__restrict__ oP, float *__restrict__ oq)
+{
+    __shared__ __attribute__((aligned(16))) float tile[KC * 256];
+    __shared__ float wrow[KC], rrow[KC];
+    const int nx = ka.nx, N = ka.N, n = ka.n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t prob = blockIdx.x;
+    const int K = (N + 1) * nx;
+    const float *Psi = Psi_ws + prob * (int64_t)K * n;
+    const float *res = res_ws + prob * (int64_t)K;
+    const float wxp = (ka.flags & MPCQP_P_STAGE) ? (float)ka.wx : 0.0f;
+    const float wtp = (ka.flags & MPCQP_P_TERMINAL) ? (float)ka.wt : 0.0f;
+    const float wxq = (ka.flags & MPCQP_Q_STAGE) ? (float)ka.wx : 0.0f;
+    const float wtq = (ka.flags & MPCQP_Q_TERMINAL) ? (float)ka.wt : 0.0f;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float qacc = 0.0f;
+    const bool strip = wv < NT;  // wavefronts beyond n/32 only help with the staging
+    // block 0 of Psi is zero: start at row nx
+    for (int row0 = nx; row0 < K; row0 += KC) {
+        __syncthreads();
+        // stage KC rows (coalesced float4 loads; rows past K are zero-weighted)
+        for (int i = tid * 4; i < KC * n; i += 512 * 4) {
+            const int r = i / n, c = i - r * n;
+            const int row = row0 + r;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < K) val = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + c);
+            *reinterpret_cast<float4 *>(tile + r * 256 + c) = val;
+        }
+        if (tid < KC) {
+            const int row = row0 + tid;
+            const bool term = row >= N * nx;
+            wrow[tid] = (row < K) ? (term ? wtp : wxp) : 0.0f;
+            rrow[tid] = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
+        }
+        __syncthreads();
+        if (strip) {
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 2) {
+                const int kr = kk + (lane >> 5);
+                // A[i][k] = w_k Psi[k][32 wv + i],  B[k][j] = Psi[k][32 t + j]
+                const float a = wrow[kr] * tile[kr * 256 + 32 * wv + (lane & 31)];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float b = tile[kr * 256 + 32 * t + (lane & 31)];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (tid < n) {
+#pragma unroll
+            for (int r = 0; r < KC; ++r) qacc += rrow[r] * tile[r * 256 + tid];
+        }
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *P = oP + prob * (int64_t)n * n;
+    if (strip) {
+        const float wu = (float)ka.wu;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int jj = 32 * t + (lane & 31);
+                P[(int64_t)i * n + jj] = acc[t][r] + ((i == jj) ? wu : 0.0f);
+            }
+    }
+    if (tid < n) oq[prob * (int64_t)n + tid] = qacc;
+}
+
+// Generic Gram (any n, any dtype): one thread per entry of the lower triangle is not
+// worth an MFMA path for float64 here; plain LDS-tiled VALU version, used for f64 or
+// when n is not a multiple of 32.
+template <typename T>
+__global__ void __launch_bounds__(256) mpcqp_gram_valu_kernel(const KernelArgs ka, const T *__restrict__ Psi_ws,
+                                                              const T *__restrict__ res_ws, T *__restrict__ oP,
+                                                              T *__restrict__ oq)
+{
+    const int nx = ka.nx, N = ka.N, n = ka.n;
+    const int64_t prob = blockIdx.x;
+    const int K = (N + 1) * nx;
+    const T *Psi = Psi_ws + prob * (int64_t)K * n;
+    const T *res = res_ws + prob * (int64_t)K;
+    const T wxp = (ka.flags & MPCQP_P_STAGE) ? (T)ka.wx : T(0), wtp = (ka.flags & MPCQP_P_TERMINAL) ? (T)ka.wt : T(0);
+    const T wxq = (ka.flags & MPCQP_Q_STAGE) ? (T)ka.wx : T(0), wtq = (ka.flags & MPCQP_Q_TERMINAL) ? (T)ka.wt : T(0);
+    T *P = oP + prob * (int64_t)n * n;
+    for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+        const int a = idx / n, b = idx - a * n;
+        T acc = (a == b) ? (T)ka.wu : T(0), st = T(0), tt = T(0);
+        for (int row = nx; row < N * nx; ++row) st += Psi[(int64_t)row * n + a] * Psi[(int64_t)row * n + b];
+        for (int row = N * nx; row < K; ++row) tt += Psi[(int64_t)row * n + a] * Psi[(int64_t)row * n + b];
+        P[idx] = acc + wtp * tt + wxp * st;
+    }
+    for (int a = threadIdx.x; a < n; a += blockDim.x) {
+        T st = T(0), tt = T(0);
+        for (int row = nx; row < N * nx; ++row) st += res[row] * Psi[(int64_t)row * n + a];
+        for (int row = N * nx; row < K; ++row) tt += res[row] * Psi[(int64_t)row * n + a];
+        oq[prob * (int64_t)n + a] = wtq * tt + wxq * st;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+// Workspace (elements of T) the large path needs per problem for the condensing:
+// Psi_all and the residual vector.
+size_t big_condense_ws_elems(const KernelArgs &ka) { return (size_t)(ka.N + 1) * ka.nx * (ka.n + 1); }
+
+bool big_supported(const KernelArgs &ka) { return ka.nx <= NXMAX && ka.n + 1 <= 320; }
+
+int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
+                        void *G, void *h, hipStream_t st)
+{
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    const size_t lds = (size_t)(ka.nx * ka.nx + ka.nx * ka.nu + ka.mk * ka.nx + ka.mk * ka.nu + ka.mk) * esz;
+    if (dtype == MPCQP_F64)
+        hipLaunchKernelGGL(mpcqp_propagate_kernel<double>, dim3((unsigned)batch), dim3(320), lds, st, ka,
+                           (double *)Psi_ws, (double *)res_ws, (double *)G, (double *)h);
+    else
+        hipLaunchKernelGGL(mpcqp_propagate_kernel<float>, dim3((unsigned)batch), dim3(320), lds, st, ka,
+                           (float *)Psi_ws, (float *)res_ws, (float *)G, (float *)h);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    const bool mfma = (dtype == MPCQP_F32) && (ka.n % 32 == 0) && (ka.n <= 256);
+    if (mfma) {
+        const float *ps = (const float *)Psi_ws, *rs = (const float *)res_ws;
+        switch (ka.n / 32) {
+#define GRAM_CASE(NTV)                                                                                              \
+    case NTV:                                                                                                       \
+        hipLaunchKernelGGL(mpcqp_gram_mfma_f32_kernel<NTV>, dim3((unsigned)batch), dim3(512), 0, st, ka, ps, rs,   \
+                           (float *)P, (float *)q);                                                                 \
+        break;
+            GRAM_CASE(1) GRAM_CASE(2) GRAM_CASE(3) GRAM_CASE(4) GRAM_CASE(5) GRAM_CASE(6) GRAM_CASE(7) GRAM_CASE(8)
+#undef GRAM_CASE
+        }
+    } else if (dtype == MPCQP_F64) {
+        hipLaunchKernelGGL(mpcqp_gram_valu_kernel<double>, dim3((unsigned)batch), dim3(256), 0, st, ka,
+                           (const double *)Psi_ws, (const double *)res_ws, (double *)P, (double *)q);
+    } else {
+        hipLaunchKernelGGL(mpcqp_gram_valu_kernel<float>, dim3((unsigned)batch), dim3(256), 0, st, ka,
+                           (const float *)Psi_ws, (const float *)res_ws, (float *)P, (float *)q);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpcqp

@@ -91,6 +91,44 @@ bool force_lds()
     return v && v[0] == '1';
 }
 
+// Sizes (in elements) of the pieces of the large-path workspace, per problem.
+struct BigPlan {
+    size_t psi, P, q, G, h, solver;  // psi includes the residual vector
+    size_t total(bool with_qp) const { return psi + (with_qp ? P + q + G + h : 0) + solver; }
+};
+
+BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
+{
+    BigPlan b{};
+    if (condense) b.psi = big_condense_ws_elems(ka);
+    if (solve) {
+        b.P = (size_t)ka.n * ka.n;
+        b.q = ka.n;
+        b.G = (size_t)ka.m * ka.n;
+        b.h = ka.m;
+        const Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, false, false, MODE_SOLVE, elem_size(dtype));
+        b.solver = (size_t)L.total;
+    }
+    return b;
+}
+
+bool fits_on_chip(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype)
+{
+    if (!force_lds() && w64_eligible(ka, mode, dtype)) return true;
+    Layout L;
+    return layout_for(ka, stepA, stepB, mode, dtype, L) == 0;
+}
+
+// Solve QPs given in HBM (ka.P/q/G/h) with the solver arrays in the workspace.
+int run_gws_solve(KernelArgs ka, int dtype, int64_t batch, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    if (ka.n > 256) return MPCQP_ETOOLARGE;
+    const Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, false, false, MODE_SOLVE, elem_size(dtype));
+    if (!ws || ws_bytes < (size_t)L.total * elem_size(dtype) * (size_t)batch) return MPCQP_EWORKSPACE;
+    ka.ws = ws;
+    return dispatch_gws_solve(ka, L, dtype, batch, st);
+}
+
 template <int MODE>
 int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t batch, hipStream_t st)
 {
@@ -115,6 +153,7 @@ const char *mpcqp_error_string(int code)
     case MPCQP_ETOOLARGE: return "problem does not fit the on-chip (LDS) path";
     case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
     case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
+    case MPCQP_EWORKSPACE: return "workspace missing or too small (see mpcqp_workspace_bytes)";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -133,8 +172,43 @@ int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes)
     return (*bytes > kLdsBytesPerCU || ka.n > 256) ? MPCQP_ETOOLARGE : 0;
 }
 
+int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solve, size_t *bytes)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!bytes || batch < 0) return MPCQP_EINVAL;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    *bytes = 0;
+    const int mode = for_solve ? MODE_FUSED : MODE_CONDENSE;
+    if (fits_on_chip(ka, true, true, mode, dims->dtype)) return 0;
+    if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
+    const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
+    *bytes = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
+    return 0;
+}
+
+int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t batch, size_t *bytes)
+{
+    if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
+    if (n <= 0 || m < 0 || batch < 0 || !bytes) return MPCQP_EINVAL;
+    KernelArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    ka.n = n;
+    ka.m = m;
+    ka.nx = ka.nu = 1;
+    ka.N = n;
+    *bytes = 0;
+    if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype)) return 0;
+    if (n > 256) return MPCQP_ETOOLARGE;
+    const Layout L = make_layout(1, 1, n, n, m, false, false, MODE_SOLVE, elem_size(dtype));
+    *bytes = (size_t)L.total * elem_size(dtype) * (size_t)batch;
+    return 0;
+}
+
 int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, void *P,
-                         void *q, void *G, void *h, void *Phi, void *Psi, void *stream)
+                         void *q, void *G, void *h, void *Phi, void *Psi, void *workspace,
+                         size_t workspace_bytes, void *stream)
 {
     int rc = check_dims(dims);
     if (rc) return rc;
@@ -149,11 +223,24 @@ int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int
     ka.h = h;
     ka.Phi = Phi;
     ka.Psi = Psi;
-    Layout L;
-    if ((rc = layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_CONDENSE, dims->dtype, L)))
-        return rc;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = dispatch_lds<MODE_CONDENSE>(ka, L, dims->dtype, batch, st))) return rc;
+    Layout L;
+    rc = layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_CONDENSE, dims->dtype, L);
+    if (rc == 0) {
+        if ((rc = dispatch_lds<MODE_CONDENSE>(ka, L, dims->dtype, batch, st))) return rc;
+    } else if (rc == MPCQP_ETOOLARGE && big_supported(ka)) {
+        // HBM-resident path: Psi goes to the caller's Psi buffer when given, else to the workspace
+        const size_t esz = elem_size(dims->dtype);
+        const size_t psi_el = (size_t)(ka.N + 1) * ka.nx * ka.n * (size_t)batch;
+        const size_t res_el = (size_t)(ka.N + 1) * ka.nx * (size_t)batch;
+        const size_t need = (Psi ? res_el : psi_el + res_el) * esz;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        void *psi_ws = Psi ? Psi : workspace;
+        void *res_ws = Psi ? workspace : (void *)((char *)workspace + psi_el * esz);
+        if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, P, q, G, h, st))) return rc;
+    } else {
+        return rc;
+    }
     if (Phi) rc = launch_phi(ka, dims->dtype, batch, st);
     return rc;
 }
@@ -181,7 +268,7 @@ int mpcqp_update_vectors_batch(const MpcqpDims *dims, const MpcqpProblem *proble
 
 int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const void *q, const void *G,
                       const void *h, int64_t batch, const MpcqpSolveOpts *opts, void *x, void *lam,
-                      int32_t *status, int32_t *iters, void *stream)
+                      int32_t *status, int32_t *iters, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
     if (n <= 0 || m < 0 || batch < 0 || !P || !q || !x || (m > 0 && (!G || !h))) return MPCQP_EINVAL;
@@ -202,12 +289,14 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const 
     ka.status = status;
     ka.iters = iters;
     fill_opts(ka, opts, dtype);
-    return run_solver<MODE_SOLVE>(ka, false, false, dtype, batch, (hipStream_t)stream);
+    if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype))
+        return run_solver<MODE_SOLVE>(ka, false, false, dtype, batch, (hipStream_t)stream);
+    return run_gws_solve(ka, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
                             const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status,
-                            int32_t *iters, void *stream)
+                            int32_t *iters, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = check_dims(dims);
     if (rc) return rc;
@@ -222,8 +311,34 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     ka.iters = iters;
     fill_opts(ka, opts, dims->dtype);
     if (const char *dbg = getenv("MPCQP_STAMP_PTR")) ka.X = (void *)strtoull(dbg, nullptr, 0);  // dev probe only
-    return run_solver<MODE_FUSED>(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, dims->dtype, batch,
-                                  (hipStream_t)stream);
+    const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
+        return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
+    // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the
+    // general solver with its arrays in the workspace as well
+    if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
+    const size_t esz = elem_size(dims->dtype), nb = (size_t)batch;
+    const BigPlan b = big_plan(ka, dims->dtype, true, true);
+    if (!workspace || workspace_bytes < b.total(true) * esz * nb) return MPCQP_EWORKSPACE;
+    char *w = (char *)workspace;
+    void *psi_ws = w;
+    void *res_ws = w + (size_t)(ka.N + 1) * ka.nx * ka.n * nb * esz;
+    w += b.psi * nb * esz;
+    void *Pw = w;
+    w += b.P * nb * esz;
+    void *qw = w;
+    w += b.q * nb * esz;
+    void *Gw = w;
+    w += b.G * nb * esz;
+    void *hw = w;
+    w += b.h * nb * esz;
+    if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, Pw, qw, Gw, hw, st))) return rc;
+    ka.P = Pw;
+    ka.q = qw;
+    ka.G = Gw;
+    ka.h = hw;
+    return run_gws_solve(ka, dims->dtype, batch, w, b.solver * nb * esz, st);
 }
 
 int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const MpcqpOperand *B,

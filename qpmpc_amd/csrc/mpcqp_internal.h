@@ -25,6 +25,8 @@ struct KernelArgs {
     int32_t *status, *iters;
     // rollout
     void *X;
+    // per-problem solver arrays in HBM (large problems): batch * Layout.total elements
+    void *ws;
 };
 
 // LDS carve, in elements of T. Matrices are row-major with odd row stride ld.
@@ -83,6 +85,13 @@ inline Layout make_layout(int nx, int nu, int N, int n, int m, bool stepA, bool 
 
 template <int MODE>
 int dispatch_lds(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st);
+// same solver with its arrays in a global workspace (ka.ws) instead of LDS
+int dispatch_gws_solve(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st);
+// large-problem condensing (mpcqp_big.hip)
+size_t big_condense_ws_elems(const KernelArgs &ka);
+bool big_supported(const KernelArgs &ka);
+int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
+                        void *G, void *h, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

@@ -486,11 +486,13 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
 }
 
 // ------------------------------------------------------------------ kernels
-template <typename T, int WAVES, int MODE>
+// GWS: the carve lives in a per-problem slice of a global workspace (ka.ws) instead of
+// LDS -- the same code path for problems too large for one CU (n = 256, m = 1024).
+template <typename T, int WAVES, int MODE, bool GWS = false>
 __global__ void __launch_bounds__(64 * WAVES) mpcqp_lds_kernel(const KernelArgs ka, const Layout L)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T *sm = (T *)smem_raw;
+    T *sm = GWS ? (T *)ka.ws + (int64_t)blockIdx.x * L.total : (T *)smem_raw;
     constexpr int BS = 64 * WAVES;
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
@@ -684,6 +686,15 @@ int dispatch_lds(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch
     if (dtype == MPCQP_F64)
         return small ? launch_lds<double, 1, MODE>(ka, L, batch, st) : launch_lds<double, 4, MODE>(ka, L, batch, st);
     return small ? launch_lds<float, 1, MODE>(ka, L, batch, st) : launch_lds<float, 4, MODE>(ka, L, batch, st);
+}
+
+int dispatch_gws_solve(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st)
+{
+    if (dtype == MPCQP_F64)
+        hipLaunchKernelGGL((mpcqp_lds_kernel<double, 4, MODE_SOLVE, true>), dim3((unsigned)batch), dim3(256), 0, st, ka, L);
+    else
+        hipLaunchKernelGGL((mpcqp_lds_kernel<float, 4, MODE_SOLVE, true>), dim3((unsigned)batch), dim3(256), 0, st, ka, L);
+    return (int)hipGetLastError();
 }
 
 template int dispatch_lds<MODE_FUSED>(const KernelArgs &, const Layout &, int, int64_t, hipStream_t);

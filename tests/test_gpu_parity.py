@@ -336,3 +336,87 @@ def test_config3_closed_loop_regulates_the_pendulum():
     assert loop.stats()["failed"] == 0
     assert np.isfinite(x).all() and np.abs(x[:, 1]).max() < 0.2  # pitch stays small
     assert np.abs(x[:, 2] - 0.5).max() < 0.1  # ground velocity near the target
+
+
+# ---------------------------------------------------------------- large problems (config 5)
+def _oracle_condense_workload(w, b):
+    from qpmpc_amd import MPCProblem
+
+    N = w["N"]
+    p = MPCProblem([w["A"][b, k] for k in range(N)], [w["B"][b, k] for k in range(N)], w["C"], w["D"], w["e"],
+                   N, w["wt"], w["wx"], w["wu"], initial_state=w["x0"][b], goal_state=np.asarray(w["goal"]))
+    p.update_target_states(np.asarray(w["targets"]))
+    return oracle.condense(p)
+
+
+def test_config5_condense_mfma_gram_full_size():
+    """n = 256, m = 1024, f32: HBM-resident propagation + MFMA Gram vs the f64 oracle.
+    Tolerance: 2e-5 relative to the largest entry (f32 accumulation over K = 780 rows)."""
+    from qpmpc_amd import BatchMPCQP
+    from qpmpc_amd.workloads import synthetic_ltv_batch, to_batch_problem
+
+    w = synthetic_ltv_batch(3)
+    qp = BatchMPCQP(to_batch_problem(w, dtype=torch.float32), keep_propagators=True)
+    torch.cuda.synchronize()
+    for b in (0, 2):
+        cq = _oracle_condense_workload(w, b)
+        for name, got, want in (("P", qp.P[b], cq.P), ("q", qp.q[b], cq.q), ("G", qp.G[b], cq.G), ("h", qp.h[b], cq.h),
+                                ("Psi", qp.Psi_all[b, : 64 * 12], cq.Psi), ("psi_last", qp.Psi_all[b, 64 * 12:], cq.psi_last),
+                                ("Phi", qp.Phi_all[b, : 64 * 12], cq.Phi)):
+            g = got.double().cpu().numpy()
+            assert g.shape == want.shape, name
+            assert _rel(g, want) <= 2e-5, (name, _rel(g, want))
+        P = qp.P[b].cpu().numpy()
+        assert np.abs(P - P.T).max() <= 1e-5 * np.abs(P).max()
+
+
+def test_config5_condense_f64_large_path():
+    """Same path in float64 (VALU Gram) at a size that does not fit LDS: parity 1e-12."""
+    from qpmpc_amd import BatchMPCQP
+    from qpmpc_amd.workloads import synthetic_ltv_batch, to_batch_problem
+
+    w = synthetic_ltv_batch(2, N=40)  # n = 160, m = 640
+    qp = BatchMPCQP(to_batch_problem(w), keep_propagators=False)
+    cq = _oracle_condense_workload(w, 1)
+    for name, got, want in (("P", qp.P[1], cq.P), ("q", qp.q[1], cq.q), ("G", qp.G[1], cq.G), ("h", qp.h[1], cq.h)):
+        assert _rel(got.cpu().numpy(), want) <= 1e-12, name
+
+
+def test_config5_build_solve_f32_vs_oracle():
+    """Whole path at full size (n = 256, m = 1024), f32, a few problems: HBM workspace,
+    MFMA Gram, general solver with its arrays in the workspace. f32 tolerance of SURVEY 8d:
+    |u - u_ref64| <= 1e-3 max(1, |u|)."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import synthetic_ltv_batch, to_batch_problem
+
+    w = synthetic_ltv_batch(4)
+    plan = solve_mpc_batch(to_batch_problem(w, dtype=torch.float32))
+    torch.cuda.synchronize()
+    st = plan.status.cpu().numpy()
+    U = plan.U.double().cpu().numpy()
+    Uo, _, sto, ito = oracle.solve_workload(w)
+    assert (sto == 0).all() and (st == 0).all(), (st, sto)
+    err = np.abs(U - Uo).max(axis=1) / np.maximum(1.0, np.abs(Uo).max(axis=1))
+    assert err.max() <= 1e-3, err
+    assert np.abs(Uo).max() >= 1.0 - 1e-9  # the input box is active somewhere
+
+
+def test_large_solve_f64_general_qp_in_workspace():
+    """mpcqp_solve_batch with a workspace: dense QPs with n = 120, m = 200 (too big for LDS in f64)."""
+    from qpmpc_amd import solve_qp_batch
+
+    rng = np.random.default_rng(5)
+    Bn, n, m = 3, 120, 200
+    Ps, qs, Gs, hs = [], [], [], []
+    for _ in range(Bn):
+        M = rng.standard_normal((n, n))
+        Ps.append(M @ M.T / n + 0.1 * np.eye(n))
+        qs.append(rng.standard_normal(n))
+        Gs.append(rng.standard_normal((m, n)))
+        hs.append(np.abs(rng.standard_normal(m)) * 0.2 + 0.05)
+    P, q, G, h = (torch.tensor(np.stack(a), device="cuda") for a in (Ps, qs, Gs, hs))
+    x, lam, status, iters = solve_qp_batch(P, q, G, h, return_multipliers=True)
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(Bn):
+        xo, lo, so, _ = oracle.gi_solve(Ps[b], qs[b], Gs[b], hs[b])
+        assert so == 0 and _rel(x[b].cpu().numpy(), xo) <= 1e-7

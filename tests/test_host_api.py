@@ -135,8 +135,14 @@ def test_c_abi_library_exports_every_declared_symbol():
     d = _capi.Dims(4, 1, 50, 2, _capi.F64, 15, 10.0, 1.0, 1e-3)
     assert lib.mpcqp_lds_bytes(C.byref(d), C.byref(b)) == 0 and b.value <= 160 * 1024
     # bad arguments are refused on the host, before any launch
-    assert lib.mpcqp_solve_batch(0, 0, 0, None, None, None, None, 1, None, None, None, None, None, None) == -1
-    assert lib.mpcqp_build_solve_batch(None, None, 1, None, None, None, None, None, None) == -1
+    assert lib.mpcqp_solve_batch(0, 0, 0, None, None, None, None, 1, None, None, None, None, None, None, 0, None) == -1
+    assert lib.mpcqp_build_solve_batch(None, None, 1, None, None, None, None, None, None, 0, None) == -1
+    # workspace queries are host-only: config 2 needs none, config 5 (n=256, m=1024, f32) does
+    d = _capi.Dims(3, 1, 16, 2, _capi.F64, 5, 1.0, 0.0, 1e-6)
+    assert lib.mpcqp_workspace_bytes(C.byref(d), 4096, 1, C.byref(b)) == 0 and b.value == 0
+    d = _capi.Dims(12, 4, 64, 16, _capi.F32, 15, 10.0, 1.0, 1e-2)
+    assert lib.mpcqp_workspace_bytes(C.byref(d), 2, 1, C.byref(b)) == 0 and b.value > 2 * 3_000_000
+    assert lib.mpcqp_workspace_bytes(C.byref(d), 2, 0, C.byref(b)) == 0 and b.value == 2 * 780 * 257 * 4
 
 
 def test_batch_container_layout_and_flags():
