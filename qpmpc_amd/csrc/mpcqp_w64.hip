@@ -335,6 +335,7 @@ template <> struct Cst<float> {
 constexpr int CB = 16;    // first constraint lane
 constexpr int LB = 48;    // first L^-T lane
 constexpr int MMAX = 32;  // constraints this kernel can hold
+constexpr int LDM = 18;   // row stride of the L and M images: 144 B, lanes writing rows hit distinct 16-B slots
 struct Lay {    // LDS carve in elements of T (host-computed, passed by value)
     int off_X;  // build: G image (m+1) x 16 | main: M_A 17 x 16, then the T image 16 x 16 (refinement)
     int off_Y;  // build: exchange + staged operands | L 16 x 16 | main: M image m x 16
@@ -371,8 +372,13 @@ __global__ void __launch_bounds__(64, 4)
     const bool isc = (lane >= CB) && (cid < m);  // this lane owns a constraint
     const T INF = Cst<T>::inf();
     T *Gimg = sm + L.off_X, *MAl = sm + L.off_X, *Timg = sm + L.off_X + (NV + 1) * NV;
+    const int GS = (m + 1) | 1;  // G image is stored by COLUMN with an odd stride: Gimg[c * GS + row],
+                                 // conflict-free both for the column-wise writes and the row-wise fetch
     T *Ll = sm + L.off_Y, *Ml = sm + L.off_Y, *hv = sm + L.off_hv;
-    T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV, *y0v = zv + 4 * NV, *invv = y0v + NV;
+    T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV;
+    // hv[lane] is only meaningful for the constraint lanes 16..47: its first and last 16
+    // entries double as the 1/L_jj vector and as y0 (both written after hv is filled)
+    T *invv = hv, *y0v = hv + LB;
 
     T R[NV];   // this lane's row: T_a (slots) | M_i (constraints) | row of L^-T
     T Pr[NV];  // lane a < 16: row a of P, then of L
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(64, 4)
         // so that P's rows and G's rows are never live in registers together
         for (int i = lane; i < (m + 1) * NV; i += 64) {
             const int row = i / NV, b = i - row * NV;
-            Gimg[i] = (b < n) ? (row < m ? G[row * n + b] : q[b]) : T(0);
+            Gimg[b * GS + row] = (b < n) ? (row < m ? G[row * n + b] : q[b]) : T(0);
         }
         wsync();
     } else {
@@ -473,8 +479,8 @@ __global__ void __launch_bounds__(64, 4)
 
         // G rows of step k from v = Psi_k[:, lane] (lane 16: Phi_k x0); lanes 0..15 fill
         // column `lane` of the G image, lane 16 the C_k Phi_k x0 part of h (mpc_qp.py:62-78)
-        T *gd = low ? (Gimg + lane) : hp;
-        const int gs = low ? NV : 1;
+        T *gd = low ? (Gimg + lane * GS) : hp;
+        constexpr int gs = 1;
         auto g_rows = [&](int k) {
             const bool here = (j == k);
             for (int i2 = 0; i2 < mk; ++i2) {
@@ -569,7 +575,7 @@ __global__ void __launch_bounds__(64, 4)
         }
         gram((T)ka.wt, termP, termQ, gref);  // v = Psi_N
         wsync();
-        if (low) Gimg[m * NV + lane] = col ? qa : T(0);  // the q row
+        if (low) Gimg[lane * GS + m] = col ? qa : T(0);  // the q row
         wsync();
         // h_i = e_i - C_k Phi_k x0 goes to LDS; the rows of G stay in the LDS image for now
         hv[lane] = (isc && L.nC) ? eval - hp[cid] : eval;
@@ -613,14 +619,15 @@ __global__ void __launch_bounds__(64, 4)
     if (notpd) {
         status = MPCQP_NOT_PD;
     } else {
-        if (low) st16(Ll + lane * NV, Pr);  // L image (upper part is don't-care)
+        if (low) st16(Ll + lane * LDM, Pr);  // L image (upper part is don't-care)
         // Rows fetched only now (register pressure): lane 0 takes q, constraint lanes
         // their row of G, lanes 48.. the identity (-> rows of L^-T), all others zero.
         {
             const bool fetch = isc || lane == 0;
             const int row = isc ? cid : m;
             if (fetch) {
-                ld16(R, Gimg + row * NV);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) R[k] = Gimg[k * GS + row];
             } else {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) R[k] = (lane == LB + k) ? T(1) : T(0);
@@ -634,7 +641,7 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
             for (int h = 0; h < j; h += HV) {
                 T lrow[HV];
-                ld8(lrow, Ll + j * NV + h);  // broadcast row j of L
+                ld8(lrow, Ll + j * LDM + h);  // broadcast row j of L
 #pragma unroll
                 for (int k = 0; k < HV; ++k)
                     if (h + k < j) acc -= R[h + k] * lrow[k];
@@ -646,7 +653,7 @@ __global__ void __launch_bounds__(64, 4)
         tick(3);
         wsync();  // every lane is done with the L image: the M image takes its place
         if (lane == 0) st16(y0v, R);           // w = L^-1 q ; y0 = -w
-        if (isc) st16(Ml + cid * NV, R);       // image of M for the row-p broadcasts
+        if (isc) st16(Ml + cid * LDM, R);      // image of M for the row-p broadcasts
         for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
         if (low) {
 #pragma unroll
@@ -687,7 +694,7 @@ __global__ void __launch_bounds__(64, 4)
                     status = MPCQP_SOLVED;
                     break;
                 }
-                const T *mprow = Ml + (p - CB) * NV;  // row p of M, read as broadcast
+                const T *mprow = Ml + (p - CB) * LDM;  // row p of M, read as broadcast
                 const T ip = bcast(invn, p);          // 1 / |M_p|
                 T up = T(0);
                 bool added = false;
@@ -883,7 +890,7 @@ template <typename T> static Lay make_lay(const KernelArgs &ka)
 {
     Lay L{};
     auto al = [](int c) { return (c + 3) & ~3; };  // 16-byte alignment for float and double
-    const int gimg = (ka.m + 1) * NV, main_x = (NV + 1) * NV + NV * NV;
+    const int gimg = NV * ((ka.m + 1) | 1), main_x = (NV + 1) * NV + NV * NV;
     L.off_X = 0;
     int o = al(gimg > main_x ? gimg : main_x);
     L.off_Y = o;
@@ -896,13 +903,13 @@ template <typename T> static Lay make_lay(const KernelArgs &ka)
         L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
         y_build += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
     }
-    int y_main = ka.m * NV;  // the M image; the L image (16 x 16) fits inside
-    if (y_main < NV * NV) y_main = NV * NV;
+    int y_main = ka.m * LDM;  // the M image; the L image (16 x LDM) fits inside
+    if (y_main < NV * LDM) y_main = NV * LDM;
     const int y_sz = al(y_build > y_main ? y_build : y_main);
     L.off_hv = L.off_Y + y_sz;
     o = L.off_hv + 64;
     L.off_v = o;
-    o += 8 * NV;  // kAv rv zv | shadows | y0v invv
+    o += 6 * NV;  // kAv rv zv | their shadows
     L.total = o;
     return L;
 }
