@@ -376,9 +376,9 @@ __global__ void __launch_bounds__(64, 4)
                                  // conflict-free both for the column-wise writes and the row-wise fetch
     T *Ll = sm + L.off_Y, *Ml = sm + L.off_Y, *hv = sm + L.off_hv;
     T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV;
-    // hv[lane] is only meaningful for the constraint lanes 16..47: its first and last 16
-    // entries double as the 1/L_jj vector and as y0 (both written after hv is filled)
-    T *invv = hv, *y0v = hv + LB;
+    // hv[lane] is only meaningful for the constraint lanes 16..47: its last 16 entries
+    // double as y0 (written after hv is filled)
+    T *y0v = hv + LB;
 
     T R[NV];   // this lane's row: T_a (slots) | M_i (constraints) | row of L^-T
     T Pr[NV];  // lane a < 16: row a of P, then of L
@@ -584,34 +584,25 @@ __global__ void __launch_bounds__(64, 4)
 
     tick(1);
     // ------------------------------------------------------------ factorise
-    // Right-looking Cholesky on the rows held by lanes 0..15. Column j is exchanged
-    // through LDS once and read back as broadcast; the trailing update needs no sqrt:
-    // P[i][k] -= P[i][j] P[k][j] / piv.
-    bool notpd = false;  // 1 / L_jj goes to the LDS vector invv
+    // Right-looking Cholesky on the rows held by lanes 0..15. Everything is broadcast
+    // with v_readlane (the LDS pipe is this kernel's bottleneck, the VALU is not); the
+    // trailing update needs no sqrt: P[i][k] -= P[i][j] P[k][j] / piv.
+    bool notpd = false;
+    T myinv = T(1);  // lane j keeps 1 / L_jj
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        zv[vofs] = Pr[j];
-        wsync();
-        const T piv = zv[j];
+        const T piv = bcast(Pr[j], j);
         if (!(piv > T(0))) notpd = true;
         const T rinv = Cst<T>::rs(piv);
-        const T lij = Pr[j] * rinv;  // L[i][j] (lane j: sqrt(piv))
-        const T t2 = lij * rinv;     // P[i][j] / piv
-        Pr[j] = lij;
-        invv[j] = rinv;  // wave-uniform value, every lane stores the same
+        const T pij = Pr[j];         // P[i][j] of this lane's row, before scaling
+        const T t2 = pij * rinv * rinv;  // P[i][j] / piv
 #pragma unroll
-        for (int h = (j + 1) / HV * HV; h < NV; h += HV) {
-            T c[HV];
-            ld8(c, zv + h);
-#pragma unroll
-            for (int k = 0; k < HV; ++k)
-                if (h + k > j) {
-                    Pr[h + k] -= t2 * c[k];
-                    pin(Pr[h + k]);
-                }
-            half_fence();
+        for (int k = j + 1; k < NV; ++k) {
+            Pr[k] -= t2 * bcast(pij, k);  // lane k holds P[k][j]
+            pin(Pr[k]);
         }
-        wsync();
+        Pr[j] = pij * rinv;  // L[i][j] (lane j: sqrt(piv))
+        if (lane == j) myinv = rinv;
     }
     tick(2);
     int status = MPCQP_MAX_ITER, iters = 0;
@@ -619,7 +610,6 @@ __global__ void __launch_bounds__(64, 4)
     if (notpd) {
         status = MPCQP_NOT_PD;
     } else {
-        if (low) st16(Ll + lane * LDM, Pr);  // L image (upper part is don't-care)
         // Rows fetched only now (register pressure): lane 0 takes q, constraint lanes
         // their row of G, lanes 48.. the identity (-> rows of L^-T), all others zero.
         {
@@ -633,25 +623,16 @@ __global__ void __launch_bounds__(64, 4)
                 for (int k = 0; k < NV; ++k) R[k] = (lane == LB + k) ? T(1) : T(0);
             }
         }
-        wsync();
-        // R <- R L^-T, one row per lane
+        // R <- R L^-T, one row per lane; L[j][k] lives in lane j's Pr[k]
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             T acc = R[j];
 #pragma unroll
-            for (int h = 0; h < j; h += HV) {
-                T lrow[HV];
-                ld8(lrow, Ll + j * LDM + h);  // broadcast row j of L
-#pragma unroll
-                for (int k = 0; k < HV; ++k)
-                    if (h + k < j) acc -= R[h + k] * lrow[k];
-                half_fence();
-            }
-            R[j] = acc * invv[j];
+            for (int k = 0; k < j; ++k) acc -= R[k] * bcast(Pr[k], j);
+            R[j] = acc * bcast(myinv, j);
             pin(R[j]);
         }
         tick(3);
-        wsync();  // every lane is done with the L image: the M image takes its place
         if (lane == 0) st16(y0v, R);           // w = L^-1 q ; y0 = -w
         if (isc) st16(Ml + cid * LDM, R);      // image of M for the row-p broadcasts
         for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
