@@ -424,11 +424,15 @@ __global__ void __launch_bounds__(64, 4)
         T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries)
         // One coalesced pass stages the problem's operands in LDS: a single HBM
         // latency instead of one per horizon step (a problem's steps are packed).
+        // (The pipelined chain, MK > 0, reads A_k, C_k and its B column straight from HBM
+        // one step ahead instead: fewer LDS operations, which is what this kernel is short of.)
         T *As = sm + L.off_stage, *Bs = As + L.nA, *Cs = Bs + L.nB, *Ds = Cs + L.nC;
-        for (int i = lane; i < L.nA; i += 64) As[i] = A[i];
-        for (int i = lane; i < L.nB; i += 64) Bs[i] = B[i];
-        for (int i = lane; i < L.nC; i += 64) Cs[i] = Cm[i];
-        for (int i = lane; i < L.nD; i += 64) Ds[i] = Dm[i];
+        if constexpr (MK == 0) {
+            for (int i = lane; i < L.nA; i += 64) As[i] = A[i];
+            for (int i = lane; i < L.nB; i += 64) Bs[i] = B[i];
+            for (int i = lane; i < L.nC; i += 64) Cs[i] = Cm[i];
+            for (int i = lane; i < L.nD; i += 64) Ds[i] = Dm[i];
+        }
         const bool isx = (lane == NV), col = (lane < n);
         const int j = col ? lane / nu : -1, ii = col ? lane - j * nu : 0;
         const T eval = isc ? ge[prob * ka.e.batch_stride + (cid / mk) * ka.e.step_stride + (cid % mk)] : INF;
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(64, 4)
         wsync();
         T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
 #pragma unroll
-        for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
+        for (int r = 0; r < NX; ++r) bcol[r] = col ? ((MK > 0) ? B[j * sB + r * nu + ii] : Bs[j * sB + r * nu + ii]) : T(0);
 
         // Gram accumulation of one block: Pr[b] += w v_a . v_b, qa += w resid . v_a;
         // ref[] is this lane's reference (non-zero only in lane 16).
@@ -519,16 +523,16 @@ __global__ void __launch_bounds__(64, 4)
             if (lane <= NV) {
                 T a0[NX * NX], c0[MK * NX];
 #pragma unroll
-                for (int e = 0; e < NX * NX; ++e) a0[e] = As[e];
+                for (int e = 0; e < NX * NX; ++e) a0[e] = A[e];
 #pragma unroll
-                for (int e = 0; e < MK * NX; ++e) c0[e] = Cs[e];
+                for (int e = 0; e < MK * NX; ++e) c0[e] = Cm[e];
                 for (int k = 0; k < N; ++k) {
                     const int kn = (k + 1 < N) ? k + 1 : k;
                     T a1[NX * NX], c1[MK * NX];
 #pragma unroll
-                    for (int e = 0; e < NX * NX; ++e) a1[e] = As[kn * sA + e];
+                    for (int e = 0; e < NX * NX; ++e) a1[e] = A[kn * sA + e];
 #pragma unroll
-                    for (int e = 0; e < MK * NX; ++e) c1[e] = Cs[kn * sC + e];
+                    for (int e = 0; e < MK * NX; ++e) c1[e] = Cm[kn * sC + e];
 #pragma unroll
                     for (int i2 = 0; i2 < MK; ++i2) {
                         T acc = T(0);
