@@ -420,3 +420,54 @@ def test_large_solve_f64_general_qp_in_workspace():
     for b in range(Bn):
         xo, lo, so, _ = oracle.gi_solve(Ps[b], qs[b], Gs[b], hs[b])
         assert so == 0 and _rel(x[b].cpu().numpy(), xo) <= 1e-7
+
+
+def _random_ltv_workload(rng, B, nx, nu, N, mk, with_c=True, with_d=True, wt=2.0, wx=0.5):
+    A = np.eye(nx) + 0.3 * rng.standard_normal((B, N, nx, nx))
+    Bm = rng.standard_normal((B, N, nx, nu))
+    Cm = rng.standard_normal((B, N, mk, nx)) if with_c else None
+    D = rng.standard_normal((B, N, mk, nu)) if with_d else None
+    x0 = 0.1 * rng.standard_normal((B, nx))
+    e = np.zeros((B, N, mk))
+    for b in range(B):
+        x = x0[b].copy()
+        for k in range(N):
+            base = Cm[b, k] @ x if with_c else 0.0
+            e[b, k] = base + 0.05 + 0.5 * np.abs(rng.standard_normal(mk))
+            x = A[b, k] @ x
+    return dict(A=A, B=Bm, C=Cm, D=D, e=e, N=N, wt=wt, wx=wx, wu=1e-2, x0=x0,
+                goal=rng.standard_normal((B, nx)), targets=None if wx is None else rng.standard_normal((B, N * nx)))
+
+
+@pytest.mark.parametrize("nx,nu,N,mk,with_c,with_d,wx", [
+    (4, 2, 6, 3, True, True, 0.5),     # generic chain, NX=4, nu>1, C and D, stage + terminal cost
+    (3, 4, 4, 8, True, True, 0.5),     # n = 16, m = 32 exactly, NX=3
+    (3, 1, 16, 2, False, True, None),  # input constraints only (D), terminal cost only
+    (4, 1, 12, 2, True, False, 1.0),   # WIP-like sizes with state constraints
+    (3, 2, 8, 2, True, False, None),   # pipelined chain with nu = 2
+])
+def test_wavefront_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx):
+    """Small LTV problems that the one-problem-per-wavefront kernel takes (n <= 16, m <= 32,
+    nx in {3, 4}), against the oracle; the same batch through the general LDS kernel must agree."""
+    rng = np.random.default_rng(100 * nx + 10 * nu + N)
+    w = _random_ltv_workload(rng, 96, nx, nu, N, mk, with_c, with_d, wx=wx)
+    plan, U, status, Uo, sto, err = _check_batch(w)
+    assert (status == 0).sum() >= 90
+
+
+def test_wavefront_and_workgroup_kernels_agree(monkeypatch):
+    """The two solver formulations (explicit N* in registers vs Q/R^-1 in LDS) on the same batch."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
+
+    w = humanoid_batch(2048)
+    bp = to_batch_problem(w)
+    a = solve_mpc_batch(bp)
+    monkeypatch.setenv("MPCQP_FORCE_LDS", "1")
+    b = solve_mpc_batch(bp)
+    torch.cuda.synchronize()
+    sa, sb = a.status.cpu().numpy(), b.status.cpu().numpy()
+    assert np.array_equal(sa == 0, sb == 0)
+    ok = sa == 0
+    Ua, Ub = a.U.cpu().numpy()[ok], b.U.cpu().numpy()[ok]
+    assert np.abs(Ua - Ub).max() <= 1e-7 * max(1.0, np.abs(Ub).max())
