@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 2
+#define MPCQP_ABI_VERSION 3
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -164,6 +164,36 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                             int64_t batch, const MpcqpSolveOpts *opts, void *U,
                             void *lam, int32_t *status, int32_t *iters,
                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- shared-model path: build once, re-solve for new states ----------------------
+ * The reference's own fast path (doc/src/developer-notes.rst:10, CHANGELOG.md:12,44):
+ * build MPCQP once, then only update_cost_vector / update_constraint_vector
+ * (mpc_qp.py:129-163) and re-solve. When A, B, C, D, e and the weights are the same for
+ * every problem of a batch (an initial-state sweep, or successive steps of
+ * time-invariant receding-horizon loops), everything that does not depend on
+ * x0/goal/targets is computed ONCE into a "model": L = chol(P), M = G L^-T, L^-T and
+ * the linear maps  h = e - Hx x0,  L^-1 q = Wx x0 - Wg goal - Wt targets.
+ *
+ * The model is filled from condensed data of 1 + 2 nx + N nx PSEUDO-problems sharing the
+ * operands (mpcqp_condense_batch on them): pseudo-problem 0 has x0 = goal = targets = 0,
+ * then x0 = e_c (c < nx), then goal = e_c, then targets = e_j (j < N nx):
+ *   P, G        [n*n], [m*n]        of pseudo-problem 0
+ *   q_basis     [(1+2nx+N nx) * n]  their q vectors, in that order
+ *   h_basis     [(1+2nx+N nx) * m]  their h vectors                                      */
+int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes);
+int mpcqp_factor_model(const MpcqpDims *dims, const void *P, const void *G,
+                       const void *q_basis, const void *h_basis, void *model,
+                       size_t model_bytes, void *stream);
+
+/* Solve `batch` problems that share `model`: only x0 [nx], goal [nx] and targets [N nx]
+ * differ (batch_stride 0 = shared; goal/targets may be NULL when their cost term is
+ * not flagged). Replaces update_cost_vector + update_constraint_vector + the solver
+ * call for every problem. Outputs as mpcqp_build_solve_batch. */
+int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model,
+                            const MpcqpOperand *x0, const MpcqpOperand *goal,
+                            const MpcqpOperand *targets, int64_t batch,
+                            const MpcqpSolveOpts *opts, void *U, void *lam,
+                            int32_t *status, int32_t *iters, void *stream);
 
 /* Replaces MPCProblem.integrate (mpc_problem.py:316-335) as used by Plan.states
  * (plan.py:81-109) for a batch: X[batch*(N+1)*nx], X_0 = x0,

@@ -13,7 +13,9 @@ from .batch import (  # noqa: F401
     BatchMPCProblem,
     BatchMPCQP,
     BatchPlan,
+    PreparedModelSolve,
     PreparedSolve,
+    SharedModel,
     rollout_batch,
     solve_mpc_batch,
     solve_qp_batch,
@@ -39,6 +41,8 @@ __all__ = [
     "BatchMPCQP",
     "BatchPlan",
     "PreparedSolve",
+    "SharedModel",
+    "PreparedModelSolve",
     "solve_mpc_batch",
     "solve_qp_batch",
     "rollout_batch",

@@ -13,7 +13,7 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -29,6 +29,9 @@ EXPORTS = (
     "mpcqp_solve_batch",
     "mpcqp_build_solve_batch",
     "mpcqp_rollout_batch",
+    "mpcqp_model_bytes",
+    "mpcqp_factor_model",
+    "mpcqp_solve_model_batch",
 )
 
 
@@ -96,6 +99,13 @@ def load():
     lib.mpcqp_build_solve_batch.restype = C.c_int
     lib.mpcqp_build_solve_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts),
                                             vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.mpcqp_model_bytes.restype = C.c_int
+    lib.mpcqp_model_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
+    lib.mpcqp_factor_model.restype = C.c_int
+    lib.mpcqp_factor_model.argtypes = [C.POINTER(Dims), vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.mpcqp_solve_model_batch.restype = C.c_int
+    lib.mpcqp_solve_model_batch.argtypes = [C.POINTER(Dims), vp, C.POINTER(Operand), C.POINTER(Operand),
+                                            C.POINTER(Operand), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
     lib.mpcqp_rollout_batch.restype = C.c_int
     lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
                                         C.POINTER(Operand), vp, i64, vp, vp]

@@ -438,6 +438,112 @@ class PreparedSolve:
         return BatchPlan(self.problem, self.U, self.status, self.iters, self.lam)
 
 
+class SharedModel:
+    """Everything of a batch that does NOT depend on x0 / goal / targets, factored once.
+
+    For problems that share A, B, C, D, e and the weights (an initial-state sweep such as
+    BASELINE config 4, or the successive steps of time-invariant receding-horizon loops)
+    this is the reference's own fast path -- build ``MPCQP`` once, then only
+    ``update_cost_vector`` / ``update_constraint_vector`` (mpc_qp.py:129-163) and re-solve --
+    taken to its end: L = chol(P), M = G L^-T, L^-T and the linear maps from the states to
+    h and L^-1 q are kept in HBM (``mpcqp_factor_model``); every solve then starts at the
+    active-set loop (``mpcqp_solve_model_batch``).
+    """
+
+    def __init__(self, template: BatchMPCProblem):
+        torch = _torch()
+        lib = _capi.load()
+        _require_on_gpu(template.initial_state)
+        for name in ("A", "B", "C", "D", "e"):
+            op = getattr(template, name)
+            if op is not None and op.shape[0] != 1:
+                raise ProblemDefinitionError(f"SharedModel: operand {name} differs across the batch")
+        self.template = template
+        nx, N = template.state_dim, template.nb_timesteps
+        n, m = template.nb_variables, template.nb_constraints
+        nb = 1 + 2 * nx + N * nx
+        dev, dt = template.device, template.dtype
+        x0 = torch.zeros((nb, nx), dtype=dt, device=dev)
+        goal = torch.zeros((nb, nx), dtype=dt, device=dev)
+        tgt = torch.zeros((nb, N * nx), dtype=dt, device=dev)
+        x0[1: 1 + nx] = torch.eye(nx, dtype=dt, device=dev)
+        goal[1 + nx: 1 + 2 * nx] = torch.eye(nx, dtype=dt, device=dev)
+        tgt[1 + 2 * nx:] = torch.eye(N * nx, dtype=dt, device=dev)
+        pseudo = BatchMPCProblem(
+            template.A, template.B, template.C, template.D, template.e, N, template.terminal_cost_weight,
+            template.stage_state_cost_weight, template.stage_input_cost_weight, x0, goal_state=goal,
+            target_states=tgt, dtype=dt, device=dev)
+        self.dims = pseudo.dims()  # cost flags from the weights (goal and targets are defined here)
+        qp = BatchMPCQP(pseudo, keep_propagators=False)
+        nbytes = C.c_size_t(0)
+        _capi.check(lib.mpcqp_model_bytes(C.byref(self.dims), C.byref(nbytes)), "mpcqp_model_bytes")
+        self.model = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+        rc = lib.mpcqp_factor_model(C.byref(self.dims), qp.P[0].data_ptr(), qp.G[0].data_ptr() if m else None,
+                                    qp.q.data_ptr(), qp.h.data_ptr() if m else None, self.model.data_ptr(),
+                                    nbytes.value, _stream_ptr())
+        _capi.check(rc, "mpcqp_factor_model")
+        self._keep = qp  # inputs of the asynchronous factorisation
+
+    def problem_for(self, x0, goal=None, targets=None) -> BatchMPCProblem:
+        """A batch sharing this model's operands with the given states."""
+        t = self.template
+        return BatchMPCProblem(t.A, t.B, t.C, t.D, t.e, t.nb_timesteps, t.terminal_cost_weight,
+                               t.stage_state_cost_weight, t.stage_input_cost_weight, x0, goal_state=goal,
+                               target_states=targets, dtype=t.dtype, device=t.device)
+
+    def prepare(self, problem: BatchMPCProblem, return_multipliers: bool = False,
+                max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> "PreparedModelSolve":
+        return PreparedModelSolve(self, problem, return_multipliers, max_iter, feas_tol)
+
+    def solve(self, x0, goal=None, targets=None, return_multipliers: bool = False,
+              max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> BatchPlan:
+        run = self.prepare(self.problem_for(x0, goal, targets), return_multipliers, max_iter, feas_tol)
+        run.launch()
+        return run.plan
+
+
+class PreparedModelSolve:
+    """``PreparedSolve`` for a ``SharedModel``: one C call per launch; update the problem's
+    states IN PLACE between launches."""
+
+    def __init__(self, model: SharedModel, problem: BatchMPCProblem, return_multipliers: bool = False,
+                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None):
+        torch = _torch()
+        self._lib = _capi.load()
+        self.model, self.problem = model, problem
+        flags = model.dims.flags
+        if (flags & _capi.Q_TERMINAL) and problem.goal_state is None:
+            raise ProblemDefinitionError("MPC problem has terminal cost but the goal state is undefined")
+        if (flags & _capi.Q_STAGE) and problem.target_states is None:
+            raise ProblemDefinitionError("MPC problem has a stage state cost but the reference trajectory is undefined")
+        Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
+        self.U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
+        self.lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
+        self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+        self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+        self._opts = _opts(max_iter, feas_tol)
+        self.rebind()
+
+    def rebind(self) -> None:
+        p = self.problem
+        self._ops = (p._operand(p.initial_state), p._operand(p.goal_state), p._operand(p.target_states))
+        self._args = (
+            C.byref(self.model.dims), self.model.model.data_ptr(), C.byref(self._ops[0]), C.byref(self._ops[1]),
+            C.byref(self._ops[2]), p.batch_size, C.byref(self._opts), self.U.data_ptr(),
+            None if self.lam is None else self.lam.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
+        )
+
+    def launch(self, stream=None) -> None:
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        rc = self._lib.mpcqp_solve_model_batch(*self._args, sp)
+        if rc != 0:
+            _capi.check(rc, "mpcqp_solve_model_batch")
+
+    @property
+    def plan(self) -> BatchPlan:
+        return BatchPlan(self.problem, self.U, self.status, self.iters, self.lam)
+
+
 class BatchMPCQP:
     """Condensed QPs of a batch, kept in HBM (batched ``MPCQP``, mpc_qp.py:21-163)."""
 

@@ -15,7 +15,7 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .batch import BatchMPCProblem, PreparedSolve
+from .batch import BatchMPCProblem, PreparedSolve, SharedModel
 from .systems import WheeledInvertedPendulum
 
 NB_SUBSTEPS = 15  # examples/wheeled_inverted_pendulum.py:31
@@ -40,13 +40,20 @@ class WIPClosedLoop:
     """``B`` independent wheeled-inverted-pendulum control loops advancing in lock step."""
 
     def __init__(self, x0, nb_timesteps: int = 50, sampling_period: float = 0.024, target_vel: float = 0.5,
-                 ltv: bool = True, max_iter: Optional[int] = None):
+                 ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False):
         import torch
 
         self.pendulum = WheeledInvertedPendulum(nb_timesteps=nb_timesteps, sampling_period=sampling_period)
         self.problem = wip_problem(self.pendulum, x0, ltv=ltv)
         self.target_vel = float(target_vel)
-        self.solver = PreparedSolve(self.problem, max_iter=max_iter)
+        # shared_model=True: the dynamics, constraints and weights never change along the
+        # loop, so P, its factor and M are computed ONCE (SharedModel) instead of at every
+        # step; False reproduces the reference, which rebuilds everything per step
+        # (solve_mpc.py:42, SURVEY quirk 8).
+        if shared_model:
+            self.solver = SharedModel(self.problem).prepare(self.problem, max_iter=max_iter)
+        else:
+            self.solver = PreparedSolve(self.problem, max_iter=max_iter)
         self.states = self.problem.initial_state.clone()
         N, T = nb_timesteps, sampling_period
         dev, dt = self.states.device, self.states.dtype

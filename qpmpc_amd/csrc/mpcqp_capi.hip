@@ -341,6 +341,59 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     return run_gws_solve(ka, dims->dtype, batch, w, b.solver * nb * esz, st);
 }
 
+int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!bytes) return MPCQP_EINVAL;
+    const ModelLayout ml = make_model_layout(dims->nx, dims->N, dims->N * dims->nu, dims->N * dims->mk);
+    *bytes = (ml.total + 4) * elem_size(dims->dtype);
+    return 0;
+}
+
+int mpcqp_factor_model(const MpcqpDims *dims, const void *P, const void *G, const void *q_basis,
+                       const void *h_basis, void *model, size_t model_bytes, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!P || !q_basis || !model || (dims->mk > 0 && (!G || !h_basis))) return MPCQP_EINVAL;
+    size_t need = 0;
+    mpcqp_model_bytes(dims, &need);
+    if (model_bytes < need) return MPCQP_EWORKSPACE;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    return launch_factor_model(ka, dims->dtype, P, G, q_basis, h_basis, model, (hipStream_t)stream);
+}
+
+int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const MpcqpOperand *x0,
+                            const MpcqpOperand *goal, const MpcqpOperand *targets, int64_t batch,
+                            const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status, int32_t *iters,
+                            void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!model || !x0 || !x0->ptr || !U || batch < 0) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_TERMINAL) && !(goal && goal->ptr)) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_STAGE) && !(targets && targets->ptr)) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    ka.x0 = *x0;
+    if (goal) ka.goal = *goal;
+    if (targets) ka.targets = *targets;
+    ka.model = model;
+    ka.U = U;
+    ka.lam = lam;
+    ka.status = status;
+    ka.iters = iters;
+    fill_opts(ka, opts, dims->dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (!force_lds() && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
+    Layout L;
+    if ((rc = layout_for(ka, false, false, MODE_SOLVE, dims->dtype, L))) return rc;
+    return dispatch_lds<MODE_MODEL>(ka, L, dims->dtype, batch, st);
+}
+
 int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const MpcqpOperand *B,
                         const MpcqpOperand *x0, const void *U, int64_t batch, void *X, void *stream)
 {

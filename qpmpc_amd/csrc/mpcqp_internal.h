@@ -9,7 +9,7 @@
 
 namespace mpcqp {
 
-enum { MODE_FUSED = 0, MODE_CONDENSE = 1, MODE_SOLVE = 2 };
+enum { MODE_FUSED = 0, MODE_CONDENSE = 1, MODE_SOLVE = 2, MODE_MODEL = 3 };
 
 constexpr size_t kLdsBytesPerCU = 160 * 1024;  // gfx950: 160 KiB per CU
 
@@ -27,6 +27,8 @@ struct KernelArgs {
     void *X;
     // per-problem solver arrays in HBM (large problems): batch * Layout.total elements
     void *ws;
+    // shared-model path: the factored model (ModelLayout) 
+    const void *model;
 };
 
 // LDS carve, in elements of T. Matrices are row-major with odd row stride ld.
@@ -82,6 +84,36 @@ inline Layout make_layout(int nx, int nu, int N, int n, int m, bool stepA, bool 
     L.total = o;
     return L;
 }
+
+// Layout of a factored shared model, in elements of T. nc = max(n, 16) columns: models
+// with n < 16 are padded with unit variables so that the wavefront kernel can use them.
+struct ModelLayout {
+    int nc, nb;  // padded variable count; number of pseudo-problems 1 + 2 nx + N nx
+    size_t off_M, off_LinvT, off_invn, off_e, off_Hx, off_Wx, off_Wg, off_Wt, total;
+};
+__host__ __device__ inline ModelLayout make_model_layout(int nx, int N, int n, int m)
+{
+    ModelLayout ml{};
+    ml.nc = n < 16 ? 16 : n;
+    ml.nb = 1 + 2 * nx + N * nx;
+    size_t o = 0;
+#define MPCQP_TAKE(field, cnt) \
+    ml.field = o;              \
+    o += ((size_t)(cnt) + 3) & ~(size_t)3;
+    MPCQP_TAKE(off_M, (size_t)m * ml.nc)
+    MPCQP_TAKE(off_LinvT, (size_t)ml.nc * ml.nc)
+    MPCQP_TAKE(off_invn, m)
+    MPCQP_TAKE(off_e, m)
+    MPCQP_TAKE(off_Hx, (size_t)m * nx)
+    MPCQP_TAKE(off_Wx, (size_t)ml.nc * nx)
+    MPCQP_TAKE(off_Wg, (size_t)ml.nc * nx)
+    MPCQP_TAKE(off_Wt, (size_t)ml.nc * N * nx)
+#undef MPCQP_TAKE
+    ml.total = o;  // one more element follows: the "P not positive definite" flag
+    return ml;
+}
+int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
+                        void *model, hipStream_t st);
 
 template <int MODE>
 int dispatch_lds(const KernelArgs &ka, const Layout &L, int dtype, int64_t batch, hipStream_t st);

@@ -241,9 +241,12 @@ __device__ __forceinline__ void build_phase(const KernelArgs &ka, const Layout &
 // ------------------------------------------------------------------ solve
 // In: Pm lower triangle of P (n x ld), Mm rows 0..m-1 = G, row m = q, hv = h.
 // Out: xs[n] (solution in original coordinates), u/act/where (multipliers).
-template <typename T, int WAVES>
+// PREFAC (shared-model path): Mm already holds M = G L^-T, y the start point y0, hs the
+// 1/|M_i|; nothing is factorised here and u = L^-T y comes from the model's L^-T rows.
+template <typename T, int WAVES, bool PREFAC = false>
 __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m, int max_iter,
-                                            T tol, int tid, int &status, int &iters)
+                                            T tol, int tid, int &status, int &iters,
+                                            const T *linvT = nullptr, int nc = 0)
 {
     constexpr int BS = 64 * WAVES;
     const int ld = L.ld;
@@ -258,6 +261,7 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
     status = MPCQP_MAX_ITER;
     iters = 0;
 
+    if constexpr (!PREFAC) {
     // Cholesky P = L L' in place (strict lower part + inv[] = 1/L_jj), left-looking.
     // Every lane recomputes the pivot of column j so one barrier per column suffices.
     for (int j = 0; j < n; ++j) {
@@ -285,6 +289,7 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
             row[j] = v * inv[j];
         }
     }
+    }
     for (int i = tid; i < n * ld; i += BS) {
         const int a = i / ld, b = i - a * ld;
         Qm[i] = (a == b) ? T(1) : T(0);
@@ -294,14 +299,18 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
     // P^-1 metric (classic Goldfarb-Idnani rule: fewest iterations, hardly any drop)
     for (int i = tid; i < m; i += BS) {
         where[i] = -1;
-        const T *row = Mm + i * ld;
-        T nn = T(0);
-        for (int k = 0; k < n; ++k) nn += row[k] * row[k];
-        hs[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+        if constexpr (!PREFAC) {
+            const T *row = Mm + i * ld;
+            T nn = T(0);
+            for (int k = 0; k < n; ++k) nn += row[k] * row[k];
+            hs[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+        }
     }
     for (int i = tid; i <= n; i += BS) u[i] = T(0);
     bsync();
-    for (int k = tid; k < n; k += BS) y[k] = -Mm[m * ld + k];
+    if constexpr (!PREFAC) {
+        for (int k = tid; k < n; k += BS) y[k] = -Mm[m * ld + k];
+    }
     bsync();
 
     int nq = 0;
@@ -476,12 +485,23 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
             }
         }
     }
-    // u = L^-T y (column-oriented back substitution, one barrier per column)
-    for (int i = n - 1; i >= 0; --i) {
-        const T xi = y[i] * inv[i];
-        if (tid == 0) xs[i] = xi;
-        for (int k = tid; k < i; k += BS) y[k] -= Pm[i * ld + k] * xi;
+    if constexpr (PREFAC) {
+        // u = L^-T y with the rows of L^-T taken from the shared model
+        for (int k = tid; k < n; k += BS) {
+            const T *row = linvT + (size_t)k * nc;
+            T acc = T(0);
+            for (int jj = 0; jj < n; ++jj) acc += row[jj] * y[jj];
+            xs[k] = acc;
+        }
         bsync();
+    } else {
+        // u = L^-T y (column-oriented back substitution, one barrier per column)
+        for (int i = n - 1; i >= 0; --i) {
+            const T xi = y[i] * inv[i];
+            if (tid == 0) xs[i] = xi;
+            for (int k = tid; k < i; k += BS) y[k] -= Pm[i * ld + k] * xi;
+            bsync();
+        }
     }
 }
 
@@ -499,7 +519,33 @@ __global__ void __launch_bounds__(64 * WAVES) mpcqp_lds_kernel(const KernelArgs 
     const int n = ka.n, m = ka.m, ld = L.ld;
     T *Pm = sm + L.off_P, *Mm = sm + L.off_M, *hv = sm + L.off_h;
 
-    if constexpr (MODE == MODE_SOLVE) {
+    if constexpr (MODE == MODE_MODEL) {
+        // shared model: M rows and 1/|M_i| from the model, h and y0 from this problem's states
+        const ModelLayout ml = make_model_layout(ka.nx, ka.N, n, m);
+        const T *model = (const T *)ka.model;
+        const int nx = ka.nx, nT = ka.N * ka.nx, nc = ml.nc;
+        const T *x0 = (const T *)ka.x0.ptr + prob * ka.x0.batch_stride;
+        const T *goal = ka.goal.ptr ? (const T *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = ka.targets.ptr ? (const T *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+        T *hs = sm + L.off_hs, *y = sm + L.off_y;
+        for (int i = tid; i < m * n; i += BS) Mm[(i / n) * ld + (i % n)] = model[ml.off_M + (size_t)(i / n) * nc + (i % n)];
+        for (int i = tid; i < m; i += BS) {
+            T hh = model[ml.off_e + i];
+            for (int c = 0; c < nx; ++c) hh -= model[ml.off_Hx + (size_t)i * nx + c] * x0[c];
+            hv[i] = hh;
+            hs[i] = model[ml.off_invn + i];
+        }
+        for (int k = tid; k < n; k += BS) {
+            T wk = T(0);
+            for (int c = 0; c < nx; ++c) wk += model[ml.off_Wx + (size_t)k * nx + c] * x0[c];
+            if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
+                for (int c = 0; c < nx; ++c) wk -= model[ml.off_Wg + (size_t)k * nx + c] * goal[c];
+            if ((ka.flags & MPCQP_Q_STAGE) && tgt)
+                for (int j2 = 0; j2 < nT; ++j2) wk -= model[ml.off_Wt + (size_t)k * nT + j2] * tgt[j2];
+            y[k] = -wk;  // y0 = -L^-1 q
+        }
+        bsync();
+    } else if constexpr (MODE == MODE_SOLVE) {
         const T *gP = (const T *)ka.P + prob * (int64_t)n * n;
         const T *gG = (const T *)ka.G + prob * (int64_t)m * n;
         const T *gq = (const T *)ka.q + prob * (int64_t)n;
@@ -537,7 +583,19 @@ __global__ void __launch_bounds__(64 * WAVES) mpcqp_lds_kernel(const KernelArgs 
         return;
     } else {
         int status, iters;
-        solve_phase<T, WAVES>(L, sm, n, m, ka.max_iter, (T)ka.tol, tid, status, iters);
+        if constexpr (MODE == MODE_MODEL) {
+            const ModelLayout ml = make_model_layout(ka.nx, ka.N, n, m);
+            const T *model = (const T *)ka.model;
+            if (model[ml.total] != T(0)) {
+                status = MPCQP_NOT_PD;
+                iters = 0;
+            } else {
+                solve_phase<T, WAVES, true>(L, sm, n, m, ka.max_iter, (T)ka.tol, tid, status, iters,
+                                            model + ml.off_LinvT, ml.nc);
+            }
+        } else {
+            solve_phase<T, WAVES>(L, sm, n, m, ka.max_iter, (T)ka.tol, tid, status, iters);
+        }
         const T *xs = sm + L.off_xs, *u = sm + L.off_u;
         const int *act = (const int *)(sm + L.off_int), *where = act + (n + 2);
         T *oU = (T *)ka.U + prob * (int64_t)n;
@@ -700,6 +758,7 @@ int dispatch_gws_solve(const KernelArgs &ka, const Layout &L, int dtype, int64_t
 template int dispatch_lds<MODE_FUSED>(const KernelArgs &, const Layout &, int, int64_t, hipStream_t);
 template int dispatch_lds<MODE_CONDENSE>(const KernelArgs &, const Layout &, int, int64_t, hipStream_t);
 template int dispatch_lds<MODE_SOLVE>(const KernelArgs &, const Layout &, int, int64_t, hipStream_t);
+template int dispatch_lds<MODE_MODEL>(const KernelArgs &, const Layout &, int, int64_t, hipStream_t);
 
 int launch_phi(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st)
 {

@@ -1,0 +1,135 @@
+// mpcqp_model.hip -- the shared-model path: factor once, re-solve for new states.
+//
+// Replaces, for batches whose problems differ only by x0 / goal / targets, the
+// reference's build-once usage: MPCQP(problem) once (qpmpc/mpc_qp.py:39-122), then
+// update_cost_vector / update_constraint_vector (mpc_qp.py:129-163) per problem.
+//
+// mpcqp_model_kernel (one workgroup, one-time work): Cholesky P = L L' in LDS, then the
+// forward substitution  row <- row L^-T  for every row of
+//     [ G ; Qx' ; Qg' ; Qt' ; I ]
+// giving M = G L^-T, the maps Wx, Wg, Wt (L^-1 q = Wx x0 - Wg goal - Wt targets) and
+// the rows of L^-T; plus e and Hx (h = e - Hx x0) and 1/|M_i|. The Q* columns are the q
+// vectors of pseudo-problems with unit states (include/mpcqp.h).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+template <typename T>
+__global__ void __launch_bounds__(256) mpcqp_model_kernel(const KernelArgs ka, const ModelLayout ml,
+                                                          const T *__restrict__ P, const T *__restrict__ G,
+                                                          const T *__restrict__ qb, const T *__restrict__ hb,
+                                                          T *__restrict__ model)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *Lm = (T *)smem_raw;
+    const int n = ka.n, m = ka.m, nx = ka.nx, N = ka.N, nc = ml.nc, tid = threadIdx.x;
+    const int ld = n | 1;
+    T *inv = Lm + n * ld;
+    T *flag = model + ml.total;  // 0 = ok, 1 = P not positive definite
+    for (int i = tid; i < n * n; i += 256) Lm[(i / n) * ld + (i % n)] = P[i];
+    __syncthreads();
+    // left-looking Cholesky, every thread recomputes the pivot (one barrier per column)
+    bool notpd = false;
+    for (int j = 0; j < n; ++j) {
+        T piv = Lm[j * ld + j];
+        for (int k = 0; k < j; ++k) piv -= Lm[j * ld + k] * Lm[j * ld + k];
+        if (!(piv > T(0))) {
+            notpd = true;
+            break;
+        }
+        const T rinv = T(1) / sqrt(piv);
+        for (int i = j + 1 + tid; i < n; i += 256) {
+            T v = Lm[i * ld + j];
+            for (int k = 0; k < j; ++k) v -= Lm[i * ld + k] * Lm[j * ld + k];
+            Lm[i * ld + j] = v * rinv;
+        }
+        if (tid == 0) inv[j] = rinv;
+        __syncthreads();
+    }
+    if (tid == 0) *flag = notpd ? T(1) : T(0);
+    if (notpd) return;
+    // rows through L^-T; results are written (and re-read) in place in the model
+    const int nT = N * nx;
+    const int rows = m + 2 * nx + nT + nc;
+    T *Mo = model + ml.off_M, *Lt = model + ml.off_LinvT;
+    T *Wx = model + ml.off_Wx, *Wg = model + ml.off_Wg, *Wt = model + ml.off_Wt;
+    for (int row = tid; row < rows; row += 256) {
+        const T *src = nullptr;
+        T sign = T(1);
+        T *dst;
+        int dstride, unit = -1;
+        if (row < m) {
+            src = G + (size_t)row * n;
+            dst = Mo + (size_t)row * nc;
+            dstride = 1;
+        } else if (row < m + nx) {
+            const int c = row - m;
+            src = qb + (size_t)(1 + c) * n;
+            dst = Wx + c;
+            dstride = nx;
+        } else if (row < m + 2 * nx) {
+            const int c = row - m - nx;
+            src = qb + (size_t)(1 + nx + c) * n;
+            sign = T(-1);
+            dst = Wg + c;
+            dstride = nx;
+        } else if (row < m + 2 * nx + nT) {
+            const int c = row - m - 2 * nx;
+            src = qb + (size_t)(1 + 2 * nx + c) * n;
+            sign = T(-1);
+            dst = Wt + c;
+            dstride = nT;
+        } else {
+            unit = row - (m + 2 * nx + nT);
+            dst = Lt + (size_t)unit * nc;
+            dstride = 1;
+        }
+        T nn = T(0);
+        for (int j = 0; j < nc; ++j) {
+            T v;
+            if (j < n) {
+                v = src ? sign * src[j] : ((unit == j) ? T(1) : T(0));
+                for (int k = 0; k < j; ++k) v -= dst[(size_t)k * dstride] * Lm[j * ld + k];
+                v *= inv[j];
+            } else {
+                v = (unit == j) ? T(1) : T(0);  // padded unit variables
+            }
+            dst[(size_t)j * dstride] = v;
+            nn += v * v;
+        }
+        if (row < m) model[ml.off_invn + row] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+    }
+    for (int i = tid; i < m; i += 256) {
+        const T e = hb[i];
+        model[ml.off_e + i] = e;
+        for (int c = 0; c < nx; ++c) model[ml.off_Hx + (size_t)i * nx + c] = e - hb[(size_t)(1 + c) * m + i];
+    }
+}
+
+int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
+                        void *model, hipStream_t st)
+{
+    const ModelLayout ml = make_model_layout(ka.nx, ka.N, ka.n, ka.m);
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    const size_t lds = ((size_t)ka.n * (ka.n | 1) + ka.n) * esz;
+    if (lds > kLdsBytesPerCU) return MPCQP_ETOOLARGE;
+    if (dtype == MPCQP_F64) {
+        auto kern = mpcqp_model_kernel<double>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, st, ka, ml, (const double *)P, (const double *)G,
+                           (const double *)qb, (const double *)hb, (double *)model);
+    } else {
+        auto kern = mpcqp_model_kernel<float>;
+        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, st, ka, ml, (const float *)P, (const float *)G,
+                           (const float *)qb, (const float *)hb, (float *)model);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpcqp

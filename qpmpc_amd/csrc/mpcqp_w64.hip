@@ -343,6 +343,8 @@ struct Lay {    // LDS carve in elements of T (host-computed, passed by value)
     int off_v;  // kAv, rv, zv, their shadows, y0v, invv
     int off_stage, nA, nB, nC, nD;
     int total;
+    // MODE_MODEL: element offsets inside the shared model (ModelLayout)
+    int mo_M, mo_LinvT, mo_invn, mo_e, mo_Hx, mo_Wx, mo_Wg, mo_Wt, mo_flag;
 };
 
 }  // namespace w64
@@ -389,7 +391,45 @@ __global__ void __launch_bounds__(64, 4)
     };
     tick(0);
 
-    if constexpr (MODE == MODE_SOLVE) {
+    T invn_model = T(1);
+    bool notpd = false;
+    if constexpr (MODE == MODE_MODEL) {
+        // Shared model (gA): M, L^-T and the maps from the states are already factored;
+        // this problem only differs by x0 / goal / targets.
+        const T *model = gA;
+        const int nx = ka.nx, nT = ka.N * ka.nx;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = gtgt ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        notpd = model[L.mo_flag] != T(0);
+        const T *rowsrc = isc ? model + L.mo_M + cid * NV : model + L.mo_LinvT + (lane >= LB ? lane - LB : 0) * NV;
+        const bool has_row = isc || lane >= LB;
+        if (has_row) {
+            ld16(R, rowsrc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) R[k] = T(0);
+        }
+        T hh = INF;
+        if (isc) {
+            hh = model[L.mo_e + cid];
+            for (int c = 0; c < nx; ++c) hh -= model[L.mo_Hx + cid * nx + c] * x0[c];
+            invn_model = model[L.mo_invn + cid];
+        }
+        hv[lane] = hh;
+        wsync();
+        if (low) {  // w = L^-1 q = Wx x0 - Wg goal - Wt targets (lane k: component k)
+            T wk = T(0);
+            for (int c = 0; c < nx; ++c) wk += model[L.mo_Wx + lane * nx + c] * x0[c];
+            if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
+                for (int c = 0; c < nx; ++c) wk -= model[L.mo_Wg + lane * nx + c] * goal[c];
+            if ((ka.flags & MPCQP_Q_STAGE) && tgt)
+                for (int j2 = 0; j2 < nT; ++j2) wk -= model[L.mo_Wt + lane * nT + j2] * tgt[j2];
+            y0v[lane] = wk;
+        }
+        for (int i = lane; i < (NV + 1) * NV; i += 64) MAl[i] = T(0);
+        wsync();
+    } else if constexpr (MODE == MODE_SOLVE) {
         const T *P = gA + prob * (int64_t)n * n;
         const T *G = gC + prob * (int64_t)m * n;
         const T *q = gB + prob * (int64_t)n;
@@ -591,8 +631,8 @@ __global__ void __launch_bounds__(64, 4)
     // Right-looking Cholesky on the rows held by lanes 0..15. Everything is broadcast
     // with v_readlane (the LDS pipe is this kernel's bottleneck, the VALU is not); the
     // trailing update needs no sqrt: P[i][k] -= P[i][j] P[k][j] / piv.
-    bool notpd = false;
     T myinv = T(1);  // lane j keeps 1 / L_jj
+    if constexpr (MODE != MODE_MODEL) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const T piv = bcast(Pr[j], j);
@@ -608,6 +648,7 @@ __global__ void __launch_bounds__(64, 4)
         Pr[j] = pij * rinv;  // L[i][j] (lane j: sqrt(piv))
         if (lane == j) myinv = rinv;
     }
+    }
     tick(2);
     int status = MPCQP_MAX_ITER, iters = 0;
     T xsol = T(0), lam_out = T(0);
@@ -616,7 +657,7 @@ __global__ void __launch_bounds__(64, 4)
     } else {
         // Rows fetched only now (register pressure): lane 0 takes q, constraint lanes
         // their row of G, lanes 48.. the identity (-> rows of L^-T), all others zero.
-        {
+        if constexpr (MODE != MODE_MODEL) {
             const bool fetch = isc || lane == 0;
             const int row = isc ? cid : m;
             if (fetch) {
@@ -626,7 +667,6 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
                 for (int k = 0; k < NV; ++k) R[k] = (lane == LB + k) ? T(1) : T(0);
             }
-        }
         // R <- R L^-T, one row per lane; L[j][k] lives in lane j's Pr[k]
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -645,6 +685,11 @@ __global__ void __launch_bounds__(64, 4)
             for (int k = 0; k < NV; ++k) R[k] = T(0);  // T = N* starts empty
         }
         wsync();
+        }
+        // rows of M for the row-p broadcasts: the LDS image, or the shared model itself
+        // (4 KB read by every wavefront of the launch: it stays in L1/L2)
+        const T *Mbase = (MODE == MODE_MODEL) ? gA + L.mo_M : Ml;
+        const int mstride = (MODE == MODE_MODEL) ? NV : LDM;
         const T hval = hv[lane];
         T s = hval + dot_reg_lds(R, y0v);  // h - M y0  (y0 = -L^-1 q)
         s = isc ? s : INF;
@@ -653,8 +698,8 @@ __global__ void __launch_bounds__(64, 4)
         // P^-1 metric, s_i / |M_i|. On the triple-integrator family this needs
         // 10.8 iterations on average and 16 at most, against 12.3 / 26 when the
         // slack is only scaled by 1 + |h_i|, and it practically removes the drops.
-        T invn;
-        {
+        T invn = invn_model;
+        if constexpr (MODE != MODE_MODEL) {
             T nn = T(0);
 #pragma unroll
             for (int k = 0; k < NV; ++k) nn += R[k] * R[k];
@@ -679,7 +724,7 @@ __global__ void __launch_bounds__(64, 4)
                     status = MPCQP_SOLVED;
                     break;
                 }
-                const T *mprow = Ml + (p - CB) * LDM;  // row p of M, read as broadcast
+                const T *mprow = Mbase + (p - CB) * mstride;  // row p of M, read as broadcast
                 const T ip = bcast(invn, p);          // 1 / |M_p|
                 T up = T(0);
                 bool added = false;
@@ -896,6 +941,18 @@ template <typename T> static Lay make_lay(const KernelArgs &ka)
     L.off_v = o;
     o += 6 * NV;  // kAv rv zv | their shadows
     L.total = o;
+    if (ka.model) {
+        const ModelLayout ml = make_model_layout(ka.nx, ka.N, ka.n, ka.m);
+        L.mo_M = (int)ml.off_M;
+        L.mo_LinvT = (int)ml.off_LinvT;
+        L.mo_invn = (int)ml.off_invn;
+        L.mo_e = (int)ml.off_e;
+        L.mo_Hx = (int)ml.off_Hx;
+        L.mo_Wx = (int)ml.off_Wx;
+        L.mo_Wg = (int)ml.off_Wg;
+        L.mo_Wt = (int)ml.off_Wt;
+        L.mo_flag = (int)ml.total;
+    }
     return L;
 }
 
@@ -908,7 +965,8 @@ bool w64_eligible(const KernelArgs &ka, int mode, int dtype)
     if (dtype != MPCQP_F64) return false;
     if (ka.n > NV || ka.m > MMAX) return false;
     if (mode == MODE_FUSED && ka.nx != 3 && ka.nx != 4) return false;
-    return mode == MODE_FUSED || mode == MODE_SOLVE;
+    if (mode == MODE_MODEL && ka.n > NV) return false;
+    return mode == MODE_FUSED || mode == MODE_SOLVE || mode == MODE_MODEL;
 }
 
 template <typename T, int MODE, int NX, int MK>
@@ -916,7 +974,12 @@ static int launch_w64_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     const Lay L = make_lay<T>(ka);
     const size_t bytes = (size_t)L.total * sizeof(T);
-    if constexpr (MODE == MODE_FUSED) {
+    if constexpr (MODE == MODE_MODEL) {
+        hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE, MK>), dim3((unsigned)batch), dim3(64), bytes, st,
+                           (const T *)ka.model, (const T *)nullptr, (const T *)nullptr, (const T *)nullptr,
+                           (const T *)nullptr, (const T *)ka.x0.ptr, (const T *)ka.goal.ptr,
+                           (const T *)ka.targets.ptr, (T *)ka.U, (T *)ka.lam, ka.status, ka.iters, ka, L);
+    } else if constexpr (MODE == MODE_FUSED) {
         hipLaunchKernelGGL((mpcqp_w64_kernel<T, NX, MODE, MK>), dim3((unsigned)batch), dim3(64), bytes, st,
                            (const T *)ka.A.ptr, (const T *)ka.B.ptr, (const T *)ka.C.ptr, (const T *)ka.D.ptr,
                            (const T *)ka.e.ptr, (const T *)ka.x0.ptr, (const T *)ka.goal.ptr,
@@ -942,6 +1005,7 @@ int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStre
         return lean ? launch_w64_t<double, MODE_FUSED, 4, 2>(ka, batch, st)
                     : launch_w64_t<double, MODE_FUSED, 4, 0>(ka, batch, st);
     }
+    if (mode == MODE_MODEL) return launch_w64_t<double, MODE_MODEL, 4, 0>(ka, batch, st);
     return launch_w64_t<double, MODE_SOLVE, 4, 0>(ka, batch, st);
 }
 

@@ -471,3 +471,59 @@ def test_wavefront_and_workgroup_kernels_agree(monkeypatch):
     ok = sa == 0
     Ua, Ub = a.U.cpu().numpy()[ok], b.U.cpu().numpy()[ok]
     assert np.abs(Ua - Ub).max() <= 1e-7 * max(1.0, np.abs(Ub).max())
+
+
+# ---------------------------------------------------------------- shared model (build once)
+@pytest.mark.parametrize("family", ["humanoid", "triple_shared", "wip12", "wip50"])
+def test_shared_model_equals_fused_path(family):
+    """Factor once + solve per state (mpc_qp.py:129-163 taken to its end) vs the fused
+    per-problem build on the same batch: same statuses, |dU| <= 1e-8 max(1, |U|)."""
+    from qpmpc_amd import SharedModel, solve_mpc_batch
+    from qpmpc_amd.workloads import humanoid_batch, to_batch_problem, triple_integrator_batch, wip_batch
+
+    if family == "humanoid":
+        w = humanoid_batch(4096)
+    elif family == "triple_shared":
+        w = triple_integrator_batch(2048, heterogeneous=False)
+    elif family == "wip12":
+        w = wip_batch(512, N=12, sampling_period=0.1)
+        w["x0"][:64, 1] += 0.25  # some loops hit the input box
+        pend = w["pendulum"]
+        ts = np.stack([pend.target_states(x, 0.5) for x in w["x0"]])
+        w["goal"], w["targets"] = ts[:, -4:], ts[:, :-4]
+    else:
+        w = wip_batch(96)
+        w["x0"][:16, 1] += 0.3
+        w["x0"][:16, 3] += 1.0
+        pend = w["pendulum"]
+        ts = np.stack([pend.target_states(x, 0.5) for x in w["x0"]])
+        w["goal"], w["targets"] = ts[:, -4:], ts[:, :-4]
+    bp = to_batch_problem(w)
+    ref = solve_mpc_batch(bp, return_multipliers=True)
+    model = SharedModel(bp)
+    got = model.solve(bp.initial_state, bp.goal_state, bp.target_states, return_multipliers=True)
+    torch.cuda.synchronize()
+    sr, sg = ref.status.cpu().numpy(), got.status.cpu().numpy()
+    assert np.array_equal(sr, sg), (np.sum(sr != 0), np.sum(sg != 0))
+    ok = sr == 0
+    Ur, Ug = ref.U.cpu().numpy()[ok], got.U.cpu().numpy()[ok]
+    assert np.abs(Ur - Ug).max() <= 1e-8 * max(1.0, np.abs(Ur).max()), np.abs(Ur - Ug).max()
+    Uo, _, sto, _ = oracle.solve_workload(w, count=64)
+    okc = sto == 0
+    scale = np.maximum(1.0, np.abs(Uo[okc]).max(axis=1, keepdims=True))
+    assert (np.abs(got.U.cpu().numpy()[:64][okc] - Uo[okc]) / scale).max() <= 1e-6
+
+
+def test_closed_loop_with_shared_model_matches_rebuild_every_step():
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(3)
+    x0 = rng.standard_normal((64, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    x0[0] = [0.0, 0.3, 0.0, 1.0]
+    a = WIPClosedLoop(x0.copy())
+    b = WIPClosedLoop(x0.copy(), shared_model=True)
+    a.step(10)
+    b.step(10)
+    xa, xb = a.states.cpu().numpy(), b.states.cpu().numpy()
+    assert np.abs(xa - xb).max() <= 1e-8
+    assert a.stats()["failed"] == 0 and b.stats()["failed"] == 0
