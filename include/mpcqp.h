@@ -202,6 +202,19 @@ int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A,
                         const MpcqpOperand *B, const MpcqpOperand *x0,
                         const void *U, int64_t batch, void *X, void *stream);
 
+/* One period of `batch` wheeled-inverted-pendulum control loops, fused: apply the first
+ * input of each plan (U[b*u_stride]) to the nonlinear plant for `nsub` Taylor sub-steps of
+ * sampling_period/nsub (WheeledInvertedPendulum.integrate,
+ * qpmpc/systems/wheeled_inverted_pendulum.py:127-160, called from
+ * examples/wheeled_inverted_pendulum.py:110-111), then write the next MPC problem's
+ * x0 [4], goal [4] and targets [N*4] reference ramp (get_target_states, same example
+ * :65-83,:101-108). states [batch*4] is updated in place; a loop whose plan was not
+ * found (status[b] != 0, may be NULL) applies a zero input. */
+int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride,
+                            const int32_t *status, int32_t N, double sampling_period,
+                            double target_vel, double length, double gravity, int32_t nsub,
+                            void *x0, void *goal, void *targets, int64_t batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ EXPORTS = (
     "mpcqp_model_bytes",
     "mpcqp_factor_model",
     "mpcqp_solve_model_batch",
+    "mpcqp_wip_advance_batch",
 )
 
 
@@ -106,6 +107,9 @@ def load():
     lib.mpcqp_solve_model_batch.restype = C.c_int
     lib.mpcqp_solve_model_batch.argtypes = [C.POINTER(Dims), vp, C.POINTER(Operand), C.POINTER(Operand),
                                             C.POINTER(Operand), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
+    lib.mpcqp_wip_advance_batch.restype = C.c_int
+    lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                            C.c_double, C.c_int32, vp, vp, vp, i64, vp]
     lib.mpcqp_rollout_batch.restype = C.c_int
     lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
                                         C.POINTER(Operand), vp, i64, vp, vp]

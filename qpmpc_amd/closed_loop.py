@@ -15,7 +15,10 @@ from typing import Dict, Optional
 
 import numpy as np
 
-from .batch import BatchMPCProblem, PreparedSolve, SharedModel
+import ctypes as C
+
+from . import _capi
+from .batch import BatchMPCProblem, PreparedSolve, SharedModel, _dtype_code, _stream_ptr
 from .systems import WheeledInvertedPendulum
 
 NB_SUBSTEPS = 15  # examples/wheeled_inverted_pendulum.py:31
@@ -77,14 +80,20 @@ class WIPClosedLoop:
         p.initial_state.copy_(self.states)
 
     def step(self, nb_mpc_steps: int = 1):
-        """Advance every loop by ``nb_mpc_steps`` MPC periods. Asynchronous."""
-        dt = self.pendulum.sampling_period / NB_SUBSTEPS
-        for _ in range(nb_mpc_steps):
+        """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
+        and one fused plant + reference launch (``mpcqp_wip_advance_batch``). Asynchronous."""
+        lib = _capi.load()
+        p, pend = self.problem, self.pendulum
+        if self.mpc_steps == 0:
             self._write_references()
+        for _ in range(nb_mpc_steps):
             self.solver.launch()
-            u0 = self.solver.U[:, 0]  # first input (nu = 1); zero where no plan was found
-            for _ in range(NB_SUBSTEPS):
-                self.states = self.pendulum.integrate_batch(self.states, u0, dt)
+            rc = lib.mpcqp_wip_advance_batch(
+                _dtype_code(p.dtype), self.states.data_ptr(), self.solver.U.data_ptr(), p.nb_variables,
+                self.solver.status.data_ptr(), pend.nb_timesteps, pend.sampling_period, self.target_vel,
+                pend.length, pend.GRAVITY, NB_SUBSTEPS, p.initial_state.data_ptr(), p.goal_state.data_ptr(),
+                p.target_states.data_ptr(), p.batch_size, _stream_ptr())
+            _capi.check(rc, "mpcqp_wip_advance_batch")
             self.failed += (self.solver.status != 0).sum()
             self.iters_total += self.solver.iters.sum()
             self.mpc_steps += 1

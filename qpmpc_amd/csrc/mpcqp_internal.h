@@ -112,6 +112,9 @@ __host__ __device__ inline ModelLayout make_model_layout(int nx, int N, int n, i
     ml.total = o;  // one more element follows: the "P not positive definite" flag
     return ml;
 }
+int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
+                       double Tp, double vel, double length, double gravity, int nsub, void *x0, void *goal,
+                       void *targets, int64_t batch, hipStream_t st);
 int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
                         void *model, hipStream_t st);
 

@@ -111,6 +111,67 @@ __global__ void __launch_bounds__(256) mpcqp_model_kernel(const KernelArgs ka, c
     }
 }
 
+// Plant + reference update of one control period (include/mpcqp.h: mpcqp_wip_advance_batch).
+// State = [r, theta, r', theta']; one thread per loop.
+template <typename T>
+__global__ void __launch_bounds__(256) mpcqp_wip_advance_kernel(T *__restrict__ states, const T *__restrict__ U,
+                                                                int64_t u_stride, const int32_t *__restrict__ status,
+                                                                int N, T Tp, T vel, T omega2, T g, int nsub,
+                                                                T *__restrict__ x0, T *__restrict__ goal,
+                                                                T *__restrict__ targets, int64_t batch)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    T r = states[b * 4 + 0], th = states[b * 4 + 1], rd = states[b * 4 + 2], thd = states[b * 4 + 3];
+    const T a = (status && status[b] != 0) ? T(0) : U[b * u_stride];
+    const T dt = Tp / (T)nsub;
+    for (int i = 0; i < nsub; ++i) {
+        const T thdd = omega2 * (sin(th) - (a / g) * cos(th));
+        const T r2 = r + dt * (rd + dt * (a / 2));
+        const T th2 = th + dt * (thd + dt * (thdd / 2));
+        rd = rd + dt * a;
+        thd = thd + dt * thdd;
+        r = r2;
+        th = th2;
+    }
+    states[b * 4 + 0] = r;
+    states[b * 4 + 1] = th;
+    states[b * 4 + 2] = rd;
+    states[b * 4 + 3] = thd;
+    x0[b * 4 + 0] = r;
+    x0[b * 4 + 1] = th;
+    x0[b * 4 + 2] = rd;
+    x0[b * 4 + 3] = thd;
+    T *tg = targets + b * (int64_t)N * 4;
+    for (int k = 0; k < N; ++k) {
+        tg[k * 4 + 0] = r + ((T)k * Tp) * vel;
+        tg[k * 4 + 1] = T(0);
+        tg[k * 4 + 2] = vel;
+        tg[k * 4 + 3] = T(0);
+    }
+    goal[b * 4 + 0] = r + ((T)N * Tp) * vel;
+    goal[b * 4 + 1] = T(0);
+    goal[b * 4 + 2] = vel;
+    goal[b * 4 + 3] = T(0);
+}
+
+int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
+                       double Tp, double vel, double length, double gravity, int nsub, void *x0, void *goal,
+                       void *targets, int64_t batch, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((batch + 255) / 256);
+    const double omega2 = gravity / length;
+    if (dtype == MPCQP_F64)
+        hipLaunchKernelGGL(mpcqp_wip_advance_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)states,
+                           (const double *)U, u_stride, status, N, Tp, vel, omega2, gravity, nsub, (double *)x0,
+                           (double *)goal, (double *)targets, batch);
+    else
+        hipLaunchKernelGGL(mpcqp_wip_advance_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)states,
+                           (const float *)U, u_stride, status, N, (float)Tp, (float)vel, (float)omega2, (float)gravity,
+                           nsub, (float *)x0, (float *)goal, (float *)targets, batch);
+    return (int)hipGetLastError();
+}
+
 int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
                         void *model, hipStream_t st)
 {
