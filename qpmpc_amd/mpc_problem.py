@@ -25,6 +25,16 @@ OptMatrixOrList = Union[None, np.ndarray, List[np.ndarray]]
 
 _COST_EPS = 1e-10  # weights at or below this do not enter q (mpc_problem.py:146,159)
 
+# Error texts are part of the boundary (callers and tests match on them): identical to
+# the reference's (mpc_problem.py:104-111,146-165,256-294), pinned by tests/golden.
+_MSG = {
+    "weight": "stage non-negative control weight needed for regularization",
+    "no_cost": "either terminal or stage state cost should be set",
+    "goal": "MPC problem has terminal cost but the goal state is undefined",
+    "targets": "MPC problem has a stage state cost but the reference trajectory is undefined",
+}
+_DIM_TAIL = "does not match state dimension ({nx})"
+
 
 def _at(field, k: int):
     """Per-step view of a field: lists are indexed, anything else is shared."""
@@ -42,46 +52,18 @@ class MPCProblem:
     Cost: ``w_t |x_N - goal|^2 + w_x sum_k |x_k - target_k|^2 + w_u sum_k |u_k|^2``.
     """
 
-    goal_state: Optional[np.ndarray]
-    ineq_input_matrix: OptMatrixOrList
-    ineq_state_matrix: OptMatrixOrList
-    ineq_vector: MatrixOrList
-    initial_state: Optional[np.ndarray]
-    input_dim: int
-    nb_timesteps: int
-    stage_input_cost_weight: float
-    stage_state_cost_weight: Optional[float]
-    state_dim: int
-    target_states: Optional[np.ndarray]
-    terminal_cost_weight: Optional[float]
-    transition_input_matrix: MatrixOrList
-    transition_state_matrix: MatrixOrList
-
-    def __init__(
-        self,
-        transition_state_matrix: MatrixOrList,
-        transition_input_matrix: MatrixOrList,
-        ineq_state_matrix: OptMatrixOrList,
-        ineq_input_matrix: OptMatrixOrList,
-        ineq_vector: MatrixOrList,
-        nb_timesteps: int,
-        terminal_cost_weight: Optional[float],
-        stage_state_cost_weight: Optional[float],
-        stage_input_cost_weight: float,
-        initial_state: Optional[np.ndarray] = None,
-        goal_state: Optional[np.ndarray] = None,
-        target_states: Optional[np.ndarray] = None,
-    ) -> None:
+    def __init__(self, transition_state_matrix: MatrixOrList, transition_input_matrix: MatrixOrList,
+                 ineq_state_matrix: OptMatrixOrList, ineq_input_matrix: OptMatrixOrList,
+                 ineq_vector: MatrixOrList, nb_timesteps: int, terminal_cost_weight: Optional[float],
+                 stage_state_cost_weight: Optional[float], stage_input_cost_weight: float,
+                 initial_state: Optional[np.ndarray] = None, goal_state: Optional[np.ndarray] = None,
+                 target_states: Optional[np.ndarray] = None) -> None:
         # w_u > 0 makes P >= w_u I positive definite: the QP has ONE minimiser,
         # which is what solver-independent parity rests on (mpc_problem.py:104-107).
         if stage_input_cost_weight <= 0.0:
-            raise ProblemDefinitionError(
-                "stage non-negative control weight needed for regularization"
-            )
+            raise ProblemDefinitionError(_MSG["weight"])
         if terminal_cost_weight is None and stage_state_cost_weight is None:
-            raise ProblemDefinitionError(
-                "either terminal or stage state cost should be set"
-            )
+            raise ProblemDefinitionError(_MSG["no_cost"])
         self.transition_state_matrix = transition_state_matrix
         self.transition_input_matrix = transition_input_matrix
         self.ineq_state_matrix = ineq_state_matrix
@@ -109,9 +91,7 @@ class MPCProblem:
         w = self.terminal_cost_weight
         active = w is not None and w > _COST_EPS
         if active and self.goal_state is None:
-            raise ProblemDefinitionError(
-                "MPC problem has terminal cost but the goal state is undefined"
-            )
+            raise ProblemDefinitionError(_MSG["goal"])
         return active
 
     @property
@@ -120,10 +100,7 @@ class MPCProblem:
         w = self.stage_state_cost_weight
         active = w is not None and w > _COST_EPS
         if active and self.target_states is None:
-            raise ProblemDefinitionError(
-                "MPC problem has a stage state cost "
-                "but the reference trajectory is undefined"
-            )
+            raise ProblemDefinitionError(_MSG["targets"])
         return active
 
     # -------------------------------------------------------------- accessors
@@ -148,35 +125,26 @@ class MPCProblem:
         return _at(self.ineq_vector, k)
 
     # ---------------------------------------------------------------- setters
+    def _checked(self, value: np.ndarray, size: int, template: str) -> np.ndarray:
+        """Flattened copy of a state-like array, or ``StateError`` if its size is wrong."""
+        if value.size != size:
+            raise StateError(template.format(shape=value.shape, nx=self.state_dim, N=self.nb_timesteps, size=size))
+        return value.flatten()
+
     def update_goal_state(self, goal_state: np.ndarray) -> None:
         """Set x_goal; ``StateError`` unless it has ``state_dim`` entries."""
-        if goal_state.size != self.state_dim:
-            raise StateError(
-                f"goal state of shape {goal_state.shape} "
-                f"does not match state dimension ({self.state_dim})"
-            )
-        self.goal_state = goal_state.flatten()
+        self.goal_state = self._checked(goal_state, self.state_dim, "goal state of shape {shape} " + _DIM_TAIL)
 
     def update_initial_state(self, initial_state: np.ndarray) -> None:
         """Set x_0; ``StateError`` unless it has ``state_dim`` entries."""
-        if initial_state.size != self.state_dim:
-            raise StateError(
-                f"Initial state of shape {initial_state.shape} "
-                f"does not match state dimension ({self.state_dim})"
-            )
-        self.initial_state = initial_state.flatten()
+        self.initial_state = self._checked(initial_state, self.state_dim, "Initial state of shape {shape} " + _DIM_TAIL)
 
     def update_target_states(self, target_states: np.ndarray) -> None:
         """Set the N stacked stage targets; ``StateError`` on a size mismatch."""
-        expected = self.state_dim * self.nb_timesteps
-        if target_states.size != expected:
-            raise StateError(
-                f"Reference state trajectory of shape {target_states.shape} "
-                "does not match nb_timesteps * state dimension = "
-                f"{self.nb_timesteps} * {self.state_dim} = "
-                f"{expected}"
-            )
-        self.target_states = target_states.flatten()
+        self.target_states = self._checked(
+            target_states, self.state_dim * self.nb_timesteps,
+            "Reference state trajectory of shape {shape} does not match nb_timesteps * state dimension = "
+            "{N} * {nx} = {size}")
 
     def __repr__(self) -> str:
         names = (
