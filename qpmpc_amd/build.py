@@ -7,7 +7,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_big.hip", "mpcqp_model.hip", "mpcqp_capi.hip")]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip", "mpcqp_model.hip", "mpcqp_capi.hip")]
 HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h"), os.path.join(_PKG, "csrc", "mpcqp_internal.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libmpcqp_hip.so")
 

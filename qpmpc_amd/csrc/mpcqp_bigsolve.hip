@@ -1,0 +1,763 @@
+// mpcqp_bigsolve.hip -- dual active-set solver for LARGE dense QPs (config 5:
+// n = 256, m = 1024, f32), one problem per workgroup of 256 threads.
+//
+// Replaces qpsolvers.solve_problem(...) at qpmpc/solve_mpc.py:43 for problems whose
+// matrices do not fit one CU's LDS. What does fit is the packed lower triangle of ONE
+// n x n matrix (131 KB in f32), and the method is arranged around that:
+//   * P is factorised in LDS (packed Cholesky) and the factor is INVERTED in place, so
+//     that everything needed later is a mat-vec with L^-1 (parallel, no dependent sweep):
+//         M_p = L^-1 G_p'  (the row of M = G L^-T of a selected constraint, computed lazily:
+//                           only the handful of rows that ever get selected, not all m),
+//         z_x = L^-T z     (primal direction back in the original coordinates);
+//   * the Goldfarb-Idnani operator N* (rows T_a) and the active rows M_a live in an HBM
+//     workspace (nq x n each, read column-wise by thread k: coalesced);
+//   * the slack update s -= t G z_x reads G through its TRANSPOSE (written by the
+//     propagation kernel), thread i owning rows i, i+256, ...: coalesced, no reductions.
+// Same algorithm and selection rule as mpcqp_w64.hip (explicit N*, rows ranked by their
+// distance to the hyperplane -- here in the Euclidean metric of the original rows, whose
+// norms are cheap, since the rows of M are not formed).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace bigs {
+constexpr int BS = 256;
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <typename T> __device__ __forceinline__ T block_sum(T v, T *red, int tid)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+// arg-min of (v, i) over the block; ties -> lowest index
+template <typename T> __device__ __forceinline__ void block_argmin(T &v, int &i, T *redv, int *redi, int tid)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        if (ov < v || (ov == v && oi < i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        redv[tid >> 6] = v;
+        redi[tid >> 6] = i;
+    }
+    __syncthreads();
+    v = redv[0];
+    i = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (redv[w] < v || (redv[w] == v && redi[w] < i)) {
+            v = redv[w];
+            i = redi[w];
+        }
+}
+}  // namespace bigs
+using namespace bigs;
+
+// Packed Cholesky followed by the in-place inverse of the factor, scalar version (any n <= 256,
+// any dtype): thread i owns row i. Returns false when a pivot is not positive.
+template <typename T> __device__ bool factor_invert_scalar(T *Li, int n, int tid, T *red)
+{
+    // ---- Cholesky, left-looking by columns: thread i owns row i
+    bool notpd = false;
+    {
+        const int i = tid;  // n <= BS
+        const T *ri = Li + tri(i < n ? i : 0, 0);
+        int rowj = 0;  // tri(j, 0)
+        for (int j = 0; j < n; rowj += ++j) {
+            // column j below the diagonal (and the pivot by thread j)
+            T v = T(0);
+            if (i >= j && i < n) {
+                T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+                const T *rj = Li + rowj;
+                int k = 0;
+                for (; k + 8 <= j; k += 8) {
+                    a0 += ri[k] * rj[k];
+                    a1 += ri[k + 1] * rj[k + 1];
+                    a2 += ri[k + 2] * rj[k + 2];
+                    a3 += ri[k + 3] * rj[k + 3];
+                    a0 += ri[k + 4] * rj[k + 4];
+                    a1 += ri[k + 5] * rj[k + 5];
+                    a2 += ri[k + 6] * rj[k + 6];
+                    a3 += ri[k + 7] * rj[k + 7];
+                }
+                for (; k < j; ++k) a0 += ri[k] * rj[k];
+                v = ri[j] - ((a0 + a1) + (a2 + a3));
+            }
+            if (i == j) red[0] = v;  // pivot
+            __syncthreads();
+            const T piv = red[0];
+            if (!(piv > T(0))) {
+                notpd = true;
+                break;
+            }
+            const T rinv = T(1) / sqrt(piv);
+            if (i >= j && i < n) Li[tri(i, 0) + j] = (i == j) ? piv * rinv : v * rinv;
+            __syncthreads();
+        }
+    }
+    if (notpd) return false;
+    {
+        // ---- invert L in place, row by row: X[i][j] = -(sum_{k=j}^{i-1} L[i][k] X[k][j]) / L[i][i]
+        // k runs uniformly over the wavefront (from its first column), so L[i][k] is a broadcast
+        // read, X[k][j] a conflict-free one, and the row bases stay in scalar registers.
+        {
+            const int j = tid, wbase = tid & ~63;
+            int rowi = 0;
+            for (int i = 0; i < n; rowi += ++i) {
+                const T *ri = Li + rowi;
+                const T dinv = T(1) / ri[i];
+                T x = T(0);
+                if (wbase < i) {
+                    T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
+                    int k = wbase, rowk = tri(wbase, 0);
+                    for (; k + 4 <= i; k += 4) {
+                        const int r1 = rowk + k + 1, r2 = r1 + k + 2, r3 = r2 + k + 3;
+                        const T x0 = (k >= j) ? Li[rowk + j] : T(0);
+                        const T x1 = (k + 1 >= j) ? Li[r1 + j] : T(0);
+                        const T x2 = (k + 2 >= j) ? Li[r2 + j] : T(0);
+                        const T x3 = (k + 3 >= j) ? Li[r3 + j] : T(0);
+                        a0 += ri[k] * x0;
+                        a1 += ri[k + 1] * x1;
+                        a2 += ri[k + 2] * x2;
+                        a3 += ri[k + 3] * x3;
+                        rowk = r3 + k + 4;
+                    }
+                    for (; k < i; ++k) {
+                        a0 += ri[k] * ((k >= j) ? Li[rowk + j] : T(0));
+                        rowk += k + 1;
+                    }
+                    x = -((a0 + a1) + (a2 + a3)) * dinv;
+                }
+                __syncthreads();
+                if (j < i) Li[rowi + j] = x;
+                if (j == i) Li[rowi + i] = dinv;
+                __syncthreads();
+            }
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ blocked factor + inverse on the matrix cores (f32)
+// The packed matrix is cut into 32 x 32 blocks. Per block column J: (1) the diagonal block is
+// factorised and inverted by one wavefront in registers (lanes = rows, v_readlane broadcasts) and
+// REPLACED by its inverse W_J; (2) the panel below becomes L[I,J] = A[I,J] W_J' and (3) the trailing
+// blocks A[I,I2] -= L[I,J] L[I2,J]', both as v_mfma_f32_32x32x2_f32 tiles shared out over the four
+// wavefronts. The inverse X = L^-1 then follows block row by block row:
+//     X[I,J] = - sum_{K=J}^{I-1} (W_I L[I,K]) X[K,J],   X[J,J] = W_J,
+// again as MFMA tiles, in place. f32 MFMA is an exact fmaf chain, so this is the same arithmetic as
+// the scalar version in another summation order. ~3600 MFMAs per 256 x 256 problem.
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ float rlane(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// row inside a 32 x 32 accumulator tile held by register t of this lane (column = lane & 31)
+__device__ __forceinline__ int crow(int t, int lane) { return (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5); }
+
+// One wavefront: diagonal block J -> its Cholesky factor -> the inverse of that factor, in place.
+__device__ bool diag_block_invert(float *Li, int J, int lane)
+{
+    const int r = lane & 31, c0 = 32 * J;
+    float *row = Li + tri(c0 + r, 0) + c0;
+    float d[32], w[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) d[c] = (c <= r) ? row[c] : 0.0f;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float piv = rlane(d[c], c);
+        ok = ok && (piv > 0.0f);
+        const float rinv = 1.0f / sqrtf(piv);
+        d[c] *= rinv;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 32; ++c2) d[c2] -= d[c] * rlane(d[c], c2);  // entries above the diagonal: unused
+    }
+    // lane r = column r of W = L^-1: forward substitution with the rows of L broadcast
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        float acc = (i == r) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= rlane(d[k], i) * w[k];
+        w[i] = acc / rlane(d[i], i);
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i >= r) Li[tri(c0 + i, 0) + c0 + r] = w[i];
+    }
+    return ok;
+}
+
+__device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
+{
+    const int nb = n >> 5, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    float *flag = red + 7;
+    if (tid == 0) flag[0] = 1.0f;
+    __syncthreads();
+    for (int J = 0; J < nb; ++J) {
+        const int c0 = 32 * J;
+        if (wv == 0) {
+            const bool ok = diag_block_invert(Li, J, lane);
+            if (!ok && lane == 0) flag[0] = 0.0f;
+        }
+        __syncthreads();
+        // panel: L[I,J] = A[I,J] W_J'   (B operand B[k][c] = W_J[c][k], zero above the diagonal)
+        for (int I = J + 1 + wv; I < nb; I += 4) {
+            const float *arow = Li + tri(32 * I + l31, 0) + c0;
+            const float *brow = Li + tri(c0 + l31, 0) + c0;
+            float a[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) a[s2] = arow[2 * s2 + kh];
+            f32x16 acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = 2 * s2 + kh;
+                const float bv = (k <= l31) ? brow[k] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Li[tri(32 * I + crow(t, lane), 0) + c0 + l31] = acc[t];
+        }
+        __syncthreads();
+        // trailing update: A[I,I2] -= L[I,J] L[I2,J]'
+        int cnt = 0;
+        for (int I = J + 1; I < nb; ++I)
+            for (int I2 = J + 1; I2 <= I; ++I2, ++cnt) {
+                if ((cnt & 3) != wv) continue;
+                const float *arow = Li + tri(32 * I + l31, 0) + c0;
+                const float *brow = Li + tri(32 * I2 + l31, 0) + c0;
+                const bool dg = (I2 == I);
+                f32x16 acc;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int rr = crow(t, lane);
+                    acc[t] = (!dg || l31 <= rr) ? Li[tri(32 * I + rr, 0) + 32 * I2 + l31] : 0.0f;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int k = 2 * s2 + kh;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-arow[k], brow[k], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int rr = crow(t, lane);
+                    if (!dg || l31 <= rr) Li[tri(32 * I + rr, 0) + 32 * I2 + l31] = acc[t];
+                }
+            }
+        __syncthreads();
+    }
+    // inverse, block row by block row
+    for (int I = 1; I < nb; ++I) {
+        const int r0 = 32 * I;
+        // L'[I,K] = W_I L[I,K]   (A operand W_I[r][k], zero above the diagonal)
+        for (int K = wv; K < I; K += 4) {
+            const float *wrow = Li + tri(r0 + l31, 0) + r0;
+            float bv[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) bv[s2] = Li[tri(r0 + 2 * s2 + kh, 0) + 32 * K + l31];
+            f32x16 acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = 2 * s2 + kh;
+                const float av = (k <= l31) ? wrow[k] : 0.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s2], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Li[tri(r0 + crow(t, lane), 0) + 32 * K + l31] = acc[t];
+        }
+        __syncthreads();
+        // X[I,Jt] = - sum_K L'[I,K] X[K,Jt] : kept in registers until every wavefront has read row block I
+        f32x16 acc2[2];
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            const int Jt = wv + 4 * qd;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc2[qd][t] = 0.0f;
+            if (Jt < I) {
+                for (int K = Jt; K < I; ++K) {
+                    const float *arow = Li + tri(r0 + l31, 0) + 32 * K;
+                    const bool dg = (K == Jt);
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) {
+                        const int k = 2 * s2 + kh;
+                        const float bv = (!dg || l31 <= k) ? Li[tri(32 * K + k, 0) + 32 * Jt + l31] : 0.0f;
+                        acc2[qd] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], bv, acc2[qd], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            const int Jt = wv + 4 * qd;
+            if (Jt < I) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) Li[tri(r0 + crow(t, lane), 0) + 32 * Jt + l31] = -acc2[qd][t];
+            }
+        }
+        __syncthreads();
+    }
+    return flag[0] != 0.0f;
+}
+
+// Workspace per problem (elements of T): MA [n][n], Tm [n][n].
+template <typename T>
+__global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
+                                                            const T *__restrict__ qall, const T *__restrict__ Gall,
+                                                            const T *__restrict__ GTall, const T *__restrict__ hall,
+                                                            T *__restrict__ wsall)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = ka.n, m = ka.m, tid = threadIdx.x;
+    const int64_t prob = blockIdx.x;
+    const T INF = (T)HUGE_VALF;
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    // LDS carve
+    T *Li = (T *)smem_raw;              // packed lower triangle: P -> L -> L^-1
+    T *sv = Li + n * (n + 1) / 2;       // slacks            [m]
+    T *gin = sv + m;                    // 1 / |G_i|          [m]
+    T *tolv = gin + m;                  // tol (1 + |h_i|)    [m]
+    T *y0 = tolv + m;                   // -L^-1 q            [n]
+    T *mp = y0 + n;                     // M_p                [n]
+    T *zv = mp + n;                     // z (y coordinates)  [n]
+    T *zx = zv + n;                     // L^-T z             [n]
+    T *rv = zx + n;                     // r by slot          [n]
+    T *lam = rv + n;                    // multipliers by slot[n]
+    T *tmp = lam + n;                   // scratch            [n]
+    T *red = tmp + n;                   // reductions         [8]
+    int *act = (int *)(red + 8);        // constraint of slot [n]
+    int *pos = act + n;                 // slot of constraint, -1 [m]
+    int *redi = pos + m;                // [4]
+
+    const T *P = Pall + prob * (int64_t)n * n;
+    const T *q = qall + prob * (int64_t)n;
+    const T *G = Gall + prob * (int64_t)m * n;
+    const T *GT = GTall + prob * (int64_t)m * n;
+    const T *h = hall + prob * (int64_t)m;
+    T *MA = wsall + prob * (int64_t)2 * n * n;
+    T *Tm = MA + (int64_t)n * n;
+    T *oU = (T *)ka.U + prob * (int64_t)n;
+    const T tol = (T)ka.tol;
+    int status = MPCQP_MAX_ITER, iters = 0;
+    // optional phase timestamps (tools/probe_big_phases.py): ka.X -> long long[8] per problem
+    long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
+    auto mark = [&](int slot) {
+        if (stamp && tid == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
+    };
+    mark(0);
+
+    // dst = L^-1 src : thread j takes row j of the packed inverse (k uniform across the wavefront)
+    auto lower_matvec = [&](const T *src) -> T {
+        T a0 = T(0), a1 = T(0);
+        if (tid < n) {
+            const T *rj = Li + tri(tid, 0);
+            const int kend = min(n, (tid | 63) + 1);  // the wavefront's longest row
+            int k = 0;
+#pragma unroll 4
+            for (; k + 1 < kend; k += 2) {
+                a0 += (k <= tid) ? rj[k] * src[k] : T(0);
+                a1 += (k + 1 <= tid) ? rj[k + 1] * src[k + 1] : T(0);
+            }
+            if (k < kend && k <= tid) a0 += rj[k] * src[k];
+        }
+        return a0 + a1;
+    };
+    // dst = L^-T src : thread j takes column j (row index uniform, row base in scalar registers)
+    auto upper_matvec = [&](const T *src) -> T {
+        T a0 = T(0), a1 = T(0);
+        if (tid < n) {
+            int i = tid & ~63;
+            int rowi = tri(i, 0);
+#pragma unroll 4
+            for (; i + 1 < n; i += 2) {
+                a0 += (i >= tid) ? Li[rowi + tid] * src[i] : T(0);
+                rowi += i + 1;
+                a1 += (i + 1 >= tid) ? Li[rowi + tid] * src[i + 1] : T(0);
+                rowi += i + 2;
+            }
+            if (i < n && i >= tid) a0 += Li[rowi + tid] * src[i];
+        }
+        return a0 + a1;
+    };
+
+    // ---- packed lower triangle of P
+    if ((n & 3) == 0) {
+        // whole rows as 16-byte loads, sixteen in flight per thread; the upper part is dropped
+        const int nv = n * n / 4;
+#pragma unroll 16
+        for (int v4 = tid; v4 < nv; v4 += BS) {
+            const int idx = 4 * v4, i = idx / n, j = idx - i * n;
+            if (j <= i) {
+                const V4 pv = *reinterpret_cast<const V4 *>(P + idx);
+                T *d = Li + tri(i, j);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (j + c <= i) d[c] = pv[c];
+            }
+        }
+    } else {
+#pragma unroll 8
+        for (int i = 0; i < n; ++i)
+            if (tid <= i) Li[tri(i, tid)] = P[(int64_t)i * n + tid];
+    }
+    __syncthreads();
+    mark(1);
+    // ---- L = chol(P), then L^-1 in place
+    bool pd;
+    if constexpr (sizeof(T) == 4) {
+        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red) : factor_invert_scalar<T>(Li, n, tid, red);
+    } else {
+        pd = factor_invert_scalar<T>(Li, n, tid, red);
+    }
+    if (!pd) {
+        status = MPCQP_NOT_PD;
+    } else {
+        mark(3);
+        // ---- y0 = -L^-1 q ; slacks at the unconstrained minimiser need x0 = L^-T y0
+        if (tid < n) tmp[tid] = q[tid];
+        __syncthreads();
+        {
+            const T a = lower_matvec(tmp);
+            if (tid < n) y0[tid] = -a;
+        }
+        __syncthreads();
+        {
+            const T a = upper_matvec(y0);
+            if (tid < n) zx[tid] = a;  // unconstrained minimiser in x coordinates
+        }
+        __syncthreads();
+        if ((m & 3) == 0) {
+            // four consecutive rows per thread, 16-byte loads of G', eight k in flight
+            for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
+                V4 a = {T(0), T(0), T(0), T(0)}, nn = {T(0), T(0), T(0), T(0)};
+#pragma unroll 8
+                for (int k = 0; k < n; ++k) {
+                    const V4 g = *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4);
+                    a += g * zx[k];
+                    nn += g * g;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int i = 4 * i4 + c;
+                    const T hi = h[i];
+                    sv[i] = hi - a[c];
+                    gin[i] = (nn[c] > T(0)) ? T(1) / sqrt(nn[c]) : T(1);
+                    tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;  // padded rows are never selected
+                    pos[i] = -1;
+                }
+            }
+        } else {
+            for (int i = tid; i < m; i += BS) {
+                T a = T(0), nn = T(0);
+                for (int k = 0; k < n; ++k) {
+                    const T g = GT[(int64_t)k * m + i];
+                    a += g * zx[k];
+                    nn += g * g;
+                }
+                const T hi = h[i];
+                sv[i] = hi - a;
+                gin[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+                tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
+                pos[i] = -1;
+            }
+        }
+        if (tid < n) lam[tid] = T(0);
+        __syncthreads();
+
+        mark(4);
+        int nq = 0;       // number of occupied slots (slots are compact here: 0..nq-1)
+        const int max_iter = ka.max_iter;
+        bool fail = false;
+        for (;;) {
+            // ---- select the violated row farthest from its hyperplane
+            T best = INF;
+            int bi = 0x7fffffff;
+            for (int i = tid; i < m; i += BS) {
+                const T s = sv[i];
+                if (pos[i] < 0 && s < -tolv[i]) {
+                    const T key = s * gin[i];
+                    if (key < best) {
+                        best = key;
+                        bi = i;
+                    }
+                }
+            }
+            block_argmin(best, bi, red, redi, tid);
+            if (!(best < INF)) {
+                status = MPCQP_SOLVED;
+                break;
+            }
+            const int p = bi;
+            // ---- M_p = L^-1 G_p'   (thread j: row j of L^-1 against G_p)
+            __syncthreads();
+            if (tid < n) tmp[tid] = G[(int64_t)p * n + tid];
+            __syncthreads();
+            {
+                const T a = lower_matvec(tmp);
+                if (tid < n) mp[tid] = a;
+            }
+            __syncthreads();
+            T kpp;
+            {
+                const T v = (tid < n) ? mp[tid] * mp[tid] : T(0);
+                kpp = block_sum(v, red, tid);
+            }
+            T up = T(0);
+            bool added = false;
+            while (!added) {
+                if (iters >= max_iter) {
+                    fail = true;
+                    break;
+                }
+                ++iters;
+                // r_a = T_a . M_p : one wavefront per row, lanes across columns
+                __syncthreads();
+                for (int a = tid >> 6; a < nq; a += 4) {
+                    T acc = T(0);
+                    for (int k = tid & 63; k < n; k += 64) acc += Tm[(int64_t)a * n + k] * mp[k];
+                    acc = wave_sum(acc);
+                    if ((tid & 63) == 0) rv[a] = acc;
+                }
+                __syncthreads();
+                // z = -M_p + sum_a r_a M_a   (thread k: column k, coalesced)
+                T zk = T(0);
+                if (tid < n) {
+                    zk = -mp[tid];
+#pragma unroll 4
+                    for (int a = 0; a < nq; ++a) zk += rv[a] * MA[(int64_t)a * n + tid];
+                    zv[tid] = zk;
+                }
+                const T d2 = block_sum(zk * zk, red, tid);
+                // ratio test
+                T t1 = INF;
+                int l = 0x7fffffff;
+                if (tid < nq && rv[tid] > T(0)) {
+                    t1 = lam[tid] / rv[tid];
+                    l = tid;
+                }
+                block_argmin(t1, l, red, redi, tid);
+                const bool can_move = (nq < n) && (d2 > (T)1e-10 * kpp) && (d2 > T(0));
+                const T sp = sv[p];
+                const T t2 = can_move ? -sp / d2 : INF;
+                const T t = t1 < t2 ? t1 : t2;
+                if (!(t < INF)) {
+                    status = MPCQP_INFEASIBLE;
+                    fail = true;
+                    break;
+                }
+                const bool full = (t2 <= t1);
+                // z_x = L^-T z, then s_i -= t G_i . z_x through the transposed G
+                __syncthreads();
+                {
+                    const T a = upper_matvec(zv);
+                    if (tid < n) zx[tid] = a;
+                }
+                __syncthreads();
+                if ((m & 3) == 0) {
+                    for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
+                        V4 a = {T(0), T(0), T(0), T(0)};
+#pragma unroll 8
+                        for (int k = 0; k < n; ++k)
+                            a += *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4) * zx[k];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int i = 4 * i4 + c;
+                            sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * a[c];
+                        }
+                    }
+                } else {
+                    for (int i = tid; i < m; i += BS) {
+                        T a0 = T(0), a1 = T(0);
+                        for (int k = 0; k < n; k += 2) {
+                            a0 += GT[(int64_t)k * m + i] * zx[k];
+                            a1 += GT[(int64_t)(k + 1) * m + i] * zx[k + 1];
+                        }
+                        sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * (a0 + a1);
+                    }
+                }
+                if (tid < nq) {
+                    T lv = lam[tid] - t * rv[tid];
+                    lam[tid] = lv < T(0) ? T(0) : lv;
+                }
+                up += t;
+                __syncthreads();
+                if (full) {
+                    // T_a += (r_a / d2) z ; new row T_nq = -z / d2 ; M_nq = M_p
+                    const T inv = T(1) / d2;
+                    if (tid < n) {
+                        const T zt = zv[tid];
+#pragma unroll 4
+                        for (int a = 0; a < nq; ++a) Tm[(int64_t)a * n + tid] += (rv[a] * inv) * zt;
+                        Tm[(int64_t)nq * n + tid] = -zt * inv;
+                        MA[(int64_t)nq * n + tid] = mp[tid];
+                    }
+                    if (tid == 0) {
+                        lam[nq] = up;
+                        act[nq] = p;
+                        pos[p] = nq;
+                        sv[p] = T(0);
+                    }
+                    ++nq;
+                    added = true;
+                } else {
+                    // drop slot l: T_a -= (T_a . T_l / T_l . T_l) T_l, then compact (last slot moves to l)
+                    __syncthreads();
+                    if (tid < n) tmp[tid] = Tm[(int64_t)l * n + tid];
+                    __syncthreads();
+                    for (int a = tid >> 6; a < nq; a += 4) {
+                        T acc = T(0);
+                        for (int k = tid & 63; k < n; k += 64) acc += Tm[(int64_t)a * n + k] * tmp[k];
+                        acc = wave_sum(acc);
+                        if ((tid & 63) == 0) rv[a] = acc;  // rv reused: T_a . T_l
+                    }
+                    __syncthreads();
+                    const T tll = rv[l];
+                    const int last = nq - 1;
+                    if (tid < n) {
+                        const T tl = tmp[tid];
+                        for (int a = 0; a < nq; ++a)
+                            if (a != l) Tm[(int64_t)a * n + tid] -= (rv[a] / tll) * tl;
+                        if (l != last) {
+                            Tm[(int64_t)l * n + tid] = Tm[(int64_t)last * n + tid];
+                            MA[(int64_t)l * n + tid] = MA[(int64_t)last * n + tid];
+                        }
+                    }
+                    __syncthreads();
+                    if (tid == 0) {
+                        pos[act[l]] = -1;
+                        if (l != last) {
+                            act[l] = act[last];
+                            lam[l] = lam[last];
+                            pos[act[l]] = l;
+                        }
+                        lam[last] = T(0);
+                    }
+                    --nq;
+                }
+                __syncthreads();
+            }
+            if (fail) break;
+        }
+        mark(5);
+        if (!fail || status == MPCQP_SOLVED) {
+            // y = y0 - M_A' lam ; u = L^-T y
+            __syncthreads();
+            if (tid < n) {
+                T yk = y0[tid];
+                for (int a = 0; a < nq; ++a) yk -= lam[a] * MA[(int64_t)a * n + tid];
+                zv[tid] = yk;
+            }
+            __syncthreads();
+            {
+                const T a = upper_matvec(zv);
+                if (tid < n) zx[tid] = a;
+            }
+            __syncthreads();
+        }
+        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+    }
+    mark(6);
+    const bool ok = (status == MPCQP_SOLVED);
+    if (tid < n) oU[tid] = ok ? zx[tid] : T(0);
+    if (ka.lam) {
+        T *ol = (T *)ka.lam + prob * (int64_t)m;
+        for (int i = tid; i < m; i += BS) ol[i] = (ok && pos[i] >= 0) ? lam[pos[i]] : T(0);
+    }
+    if (tid == 0) {
+        if (ka.status) ka.status[prob] = status;
+        if (ka.iters) ka.iters[prob] = iters;
+    }
+}
+
+// G [m][n] -> G' [n][m] per problem, 64 x 64 tiles through LDS (both sides coalesced).
+template <typename T>
+__global__ void __launch_bounds__(256) mpcqp_transpose_kernel(const T *__restrict__ Gall, T *__restrict__ GTall, int m, int n)
+{
+    __shared__ T tile[64][65];
+    const int tiles_c = (n + 63) / 64;
+    const int tr = blockIdx.x / tiles_c, tc = blockIdx.x - tr * tiles_c;
+    const T *G = Gall + (int64_t)blockIdx.y * m * n;
+    T *GT = GTall + (int64_t)blockIdx.y * m * n;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int r = ly; r < 64; r += 4) {
+        const int row = tr * 64 + r, c = tc * 64 + lx;
+        tile[r][lx] = (row < m && c < n) ? G[(int64_t)row * n + c] : T(0);
+    }
+    __syncthreads();
+    for (int r = ly; r < 64; r += 4) {
+        const int c = tc * 64 + r, row = tr * 64 + lx;
+        if (row < m && c < n) GT[(int64_t)c * m + row] = tile[lx][r];
+    }
+}
+
+// ------------------------------------------------------------------ host side
+int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st)
+{
+    const dim3 grid((unsigned)(((m + 63) / 64) * ((n + 63) / 64)), (unsigned)batch);
+    if (dtype == MPCQP_F64)
+        hipLaunchKernelGGL(mpcqp_transpose_kernel<double>, grid, dim3(256), 0, st, (const double *)G, (double *)GT, m, n);
+    else
+        hipLaunchKernelGGL(mpcqp_transpose_kernel<float>, grid, dim3(256), 0, st, (const float *)G, (float *)GT, m, n);
+    return (int)hipGetLastError();
+}
+
+size_t bigsolve_lds_bytes(int n, int m, size_t esz)
+{
+    const size_t el = (size_t)n * (n + 1) / 2 + 3 * (size_t)m + 7 * (size_t)n + 8;
+    return el * esz + ((size_t)n + m + 4) * 4 + 16;
+}
+bool bigsolve_supported(int n, int m, int dtype)
+{
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    return n <= bigs::BS && (n % 2 == 0) && bigsolve_lds_bytes(n, m, esz) <= kLdsBytesPerCU;
+}
+size_t bigsolve_ws_elems(int n) { return (size_t)2 * n * n; }
+
+int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
+                    const void *GT, const void *h, void *ws, hipStream_t st)
+{
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, esz);
+    if (dtype == MPCQP_F64) {
+        auto kern = mpcqp_bigsolve_kernel<double>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const double *)P, (const double *)q,
+                           (const double *)G, (const double *)GT, (const double *)h, (double *)ws);
+    } else {
+        auto kern = mpcqp_bigsolve_kernel<float>;
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const float *)P, (const float *)q,
+                           (const float *)G, (const float *)GT, (const float *)h, (float *)ws);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpcqp

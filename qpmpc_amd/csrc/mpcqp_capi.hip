@@ -91,6 +91,24 @@ bool force_lds()
     return v && v[0] == '1';
 }
 
+// MPCQP_FORCE_GWS=1 keeps large QPs on the general kernel with its arrays in the workspace
+// (cross-checking the two large-problem solvers).
+bool force_gws()
+{
+    const char *v = getenv("MPCQP_FORCE_GWS");
+    return v && v[0] == '1';
+}
+
+bool use_bigsolve(int n, int m, int dtype) { return !force_gws() && m > 0 && bigsolve_supported(n, m, dtype); }
+
+// Per-problem solver scratch (elements) for QPs that do not fit the on-chip kernels.
+size_t solver_ws_elems(int n, int m, int dtype)
+{
+    if (use_bigsolve(n, m, dtype)) return (size_t)m * n + bigsolve_ws_elems(n);  // G' + M_A + N*
+    const Layout L = make_layout(1, 1, n, n, m, false, false, MODE_SOLVE, elem_size(dtype));
+    return (size_t)L.total;
+}
+
 // Sizes (in elements) of the pieces of the large-path workspace, per problem.
 struct BigPlan {
     size_t psi, P, q, G, h, solver;  // psi includes the residual vector
@@ -106,8 +124,7 @@ BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
         b.q = ka.n;
         b.G = (size_t)ka.m * ka.n;
         b.h = ka.m;
-        const Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, false, false, MODE_SOLVE, elem_size(dtype));
-        b.solver = (size_t)L.total;
+        b.solver = solver_ws_elems(ka.n, ka.m, dtype);
     }
     return b;
 }
@@ -123,8 +140,17 @@ bool fits_on_chip(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dt
 int run_gws_solve(KernelArgs ka, int dtype, int64_t batch, void *ws, size_t ws_bytes, hipStream_t st)
 {
     if (ka.n > 256) return MPCQP_ETOOLARGE;
-    const Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, false, false, MODE_SOLVE, elem_size(dtype));
-    if (!ws || ws_bytes < (size_t)L.total * elem_size(dtype) * (size_t)batch) return MPCQP_EWORKSPACE;
+    const size_t esz = elem_size(dtype);
+    if (!ws || ws_bytes < solver_ws_elems(ka.n, ka.m, dtype) * esz * (size_t)batch) return MPCQP_EWORKSPACE;
+    if (use_bigsolve(ka.n, ka.m, dtype)) {
+        // L^-1 packed in LDS, lazy rows of M; needs G transposed (coalesced slack updates)
+        void *GT = ws;
+        void *rest = (char *)ws + (size_t)ka.m * ka.n * esz * (size_t)batch;
+        int rc = launch_transpose(ka.G, GT, ka.m, ka.n, dtype, batch, st);
+        if (rc) return rc;
+        return launch_bigsolve(ka, dtype, batch, ka.P, ka.q, ka.G, GT, ka.h, rest, st);
+    }
+    const Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, false, false, MODE_SOLVE, esz);
     ka.ws = ws;
     return dispatch_gws_solve(ka, L, dtype, batch, st);
 }
@@ -201,8 +227,7 @@ int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t bat
     *bytes = 0;
     if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype)) return 0;
     if (n > 256) return MPCQP_ETOOLARGE;
-    const Layout L = make_layout(1, 1, n, n, m, false, false, MODE_SOLVE, elem_size(dtype));
-    *bytes = (size_t)L.total * elem_size(dtype) * (size_t)batch;
+    *bytes = solver_ws_elems(n, m, dtype) * elem_size(dtype) * (size_t)batch;
     return 0;
 }
 

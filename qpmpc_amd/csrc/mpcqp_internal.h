@@ -127,6 +127,12 @@ size_t big_condense_ws_elems(const KernelArgs &ka);
 bool big_supported(const KernelArgs &ka);
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
                         void *G, void *h, hipStream_t st);
+// large-problem solver (mpcqp_bigsolve.hip): one problem per workgroup, L^-1 packed in LDS
+bool bigsolve_supported(int n, int m, int dtype);
+size_t bigsolve_ws_elems(int n);
+int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st);
+int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
+                    const void *GT, const void *h, void *ws, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

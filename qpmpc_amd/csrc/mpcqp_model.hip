@@ -181,12 +181,12 @@ int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const vo
     if (lds > kLdsBytesPerCU) return MPCQP_ETOOLARGE;
     if (dtype == MPCQP_F64) {
         auto kern = mpcqp_model_kernel<double>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, st, ka, ml, (const double *)P, (const double *)G,
                            (const double *)qb, (const double *)hb, (double *)model);
     } else {
         auto kern = mpcqp_model_kernel<float>;
-        if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, st, ka, ml, (const float *)P, (const float *)G,
                            (const float *)qb, (const float *)hb, (float *)model);
     }

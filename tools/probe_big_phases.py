@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Dev probe: per-phase shader-clock timestamps of the large-problem solver (config 5)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from qpmpc_amd import PreparedSolve, workloads as W
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+w = W.synthetic_ltv_batch(batch); bp = W.to_batch_problem(w, dtype=torch.float32)
+buf = torch.zeros(batch * 8, dtype=torch.int64, device="cuda")
+os.environ["MPCQP_STAMP_PTR"] = str(buf.data_ptr())
+run = PreparedSolve(bp)
+for _ in range(2): run.launch()
+torch.cuda.synchronize()
+t = buf.view(batch, 8).cpu().double()
+it = run.iters.cpu().double()
+names = ["load P", "factor+invert", "init slacks", "active-set", "solution"]
+t = t[:, [0, 1, 3, 4, 5, 6]]
+d = (t[:, 1:6] - t[:, 0:5])
+print("batch", batch, "mean iters", it.mean().item(), "max", it.max().item())
+for i, nme in enumerate(names):
+    print(f"  {nme:12s} mean {d[:, i].mean().item():10.0f} cyc   max {d[:, i].max().item():10.0f}")
+print(f"  total        mean {(t[:,5]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,5]-t[:,0]).max().item():10.0f}")
+print(f"  per-iteration (active-set / iters): {(d[:,3].sum()/it.sum()).item():.0f} cyc")
+print(f"  kernel span: {(t[:,5].max()-t[:,0].min()).item():.0f} cyc  (readcyclecounter ticks at 100 MHz if s_memrealtime, else shader clock)")
