@@ -26,19 +26,24 @@ using namespace big;
 // ------------------------------------------------------------------ propagate
 // One workgroup per problem, thread c < n owns column c of Psi, thread n the free
 // response Phi_k x0. A_k, B_k, C_k, D_k of the current step are staged in LDS and read
-// as broadcast. Outputs (per problem): Psi_all [(N+1)*nx, n] (block 0 is zero),
-// resid [(N+1)*nx] = Phi_k x0 - ref_k, G [m, n], h [m].
-template <typename T>
-__global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
+// as broadcast.
+// Outputs (per problem): Psi_all [(N+1)*nx, n] (block 0 is zero), resid [(N+1)*nx] =
+// Phi_k x0 - ref_k, h [m], and optionally G [m, n] and the inverse row norms 1/|G_i| [m].
+// The norms come from the nx x nx recursion S_{k+1} = A_k S_k A_k' + B_k B_k' (S_k = Psi_k Psi_k',
+// |G_i|^2 = C_i S_k C_i' + |D_i|^2 because Psi_k is zero in the columns of u_k).
+template <typename T, bool NRM>
+__global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
                                                               T *__restrict__ res_ws, T *__restrict__ oG,
-                                                              T *__restrict__ oh)
+                                                              T *__restrict__ oh, T *__restrict__ onrm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sm = (T *)smem_raw;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, n = ka.n, m = ka.m;
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
-    T *As = sm, *Bs = As + nx * nx, *Cs = Bs + nx * nu, *Ds = Cs + mk * nx, *es = Ds + mk * nu;
+    const int nA = nx * nx, nB = nx * nu, nC = mk * nx, nD = mk * nu;
+    T *As = sm, *Bs = As + nA, *Cs = Bs + nB, *Ds = Cs + nC, *es = Ds + nD;
+    T *Ss = es + mk, *T1s = Ss + nA, *Ys = T1s + nA;
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
     const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
     const T *gC = ka.C.ptr ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
@@ -49,11 +54,15 @@ __global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs k
     const T *gtgt = ka.targets.ptr ? (const T *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
     T *Psi = Psi_ws + prob * (int64_t)(N + 1) * nx * n;
     T *res = res_ws + prob * (int64_t)(N + 1) * nx;
-    T *G = oG + prob * (int64_t)m * n;
+    T *G = oG ? oG + prob * (int64_t)m * n : nullptr;
     T *h = oh + prob * (int64_t)m;
+    T *nrm = NRM ? onrm + prob * (int64_t)m : nullptr;
     const bool isx = (tid == n), col = (tid < n);
     const int j = col ? tid / nu : -1, ii = col ? tid - j * nu : 0;
     const bool qs = (ka.flags & MPCQP_Q_STAGE) && gtgt, qt = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+
+    if constexpr (NRM)
+        for (int e2 = tid; e2 < nA; e2 += 320) Ss[e2] = T(0);
 
     T v[NXMAX];
 #pragma unroll
@@ -61,12 +70,12 @@ __global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs k
     for (int k = 0; k <= N; ++k) {
         __syncthreads();
         if (k < N) {  // stage the operands of step k (coalesced)
-            for (int i = tid; i < nx * nx; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
-            for (int i = tid; i < nx * nu; i += blockDim.x) Bs[i] = gB[k * ka.B.step_stride + i];
+            for (int i = tid; i < nA; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
+            for (int i = tid; i < nB; i += blockDim.x) Bs[i] = gB[k * ka.B.step_stride + i];
             if (gC)
-                for (int i = tid; i < mk * nx; i += blockDim.x) Cs[i] = gC[k * ka.C.step_stride + i];
+                for (int i = tid; i < nC; i += blockDim.x) Cs[i] = gC[k * ka.C.step_stride + i];
             if (gD)
-                for (int i = tid; i < mk * nu; i += blockDim.x) Ds[i] = gD[k * ka.D.step_stride + i];
+                for (int i = tid; i < nD; i += blockDim.x) Ds[i] = gD[k * ka.D.step_stride + i];
             for (int i = tid; i < mk; i += blockDim.x) es[i] = ge[k * ka.e.step_stride + i];
         }
         __syncthreads();
@@ -91,18 +100,20 @@ __global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs k
         if (k == N) break;
         if (col || isx) {
             // rows of G / h for step k (mpc_qp.py:62-78)
-            for (int i2 = 0; i2 < mk; ++i2) {
-                T acc = T(0);
-                if (gC) {
+            if (isx || G) {
+                for (int i2 = 0; i2 < mk; ++i2) {
+                    T acc = T(0);
+                    if (gC) {
 #pragma unroll
-                    for (int s = 0; s < NXMAX; ++s)
-                        if (s < nx) acc += Cs[i2 * nx + s] * v[s];
-                }
-                if (col) {
-                    if (gD && j == k) acc += Ds[i2 * nu + ii];
-                    G[((int64_t)k * mk + i2) * n + tid] = acc;
-                } else {
-                    h[k * mk + i2] = es[i2] - acc;
+                        for (int s = 0; s < NXMAX; ++s)
+                            if (s < nx) acc += Cs[i2 * nx + s] * v[s];
+                    }
+                    if (col) {
+                        if (gD && j == k) acc += Ds[i2 * nu + ii];
+                        G[((int64_t)k * mk + i2) * n + tid] = acc;
+                    } else {
+                        h[k * mk + i2] = es[i2] - acc;
+                    }
                 }
             }
             // advance (mpc_qp.py:88-90)
@@ -124,6 +135,40 @@ __global__ void __launch_bounds__(320) mpcqp_propagate_kernel(const KernelArgs k
             }
 #pragma unroll
             for (int r = 0; r < NXMAX; ++r) v[r] = w[r];
+        }
+        if constexpr (NRM) {
+            // inverse row norms of step k: Y = C S_k and T1 = A S_k now, the row-wise dots and
+            // S_{k+1} = T1 A' + B B' after a barrier -- a few dozen FMAs per thread, shared by all
+            if (gC)
+                for (int e2 = tid; e2 < nC; e2 += 320) {
+                    const int i2 = e2 / nx, s = e2 - i2 * nx;
+                    T acc = T(0);
+                    for (int u = 0; u < nx; ++u) acc += Cs[i2 * nx + u] * Ss[u * nx + s];
+                    Ys[e2] = acc;
+                }
+            for (int e2 = tid; e2 < nA; e2 += 320) {
+                const int r = e2 / nx, s = e2 - r * nx;
+                T acc = T(0);
+                for (int u = 0; u < nx; ++u) acc += As[r * nx + u] * Ss[u * nx + s];
+                T1s[e2] = acc;
+            }
+            __syncthreads();
+            // the last wavefront takes the norms, the others S_{k+1}
+            for (int i2 = 319 - tid; i2 < mk; i2 += 320) {
+                T acc = T(0);
+                if (gC)
+                    for (int u = 0; u < nx; ++u) acc += Ys[i2 * nx + u] * Cs[i2 * nx + u];
+                if (gD)
+                    for (int u = 0; u < nu; ++u) acc += Ds[i2 * nu + u] * Ds[i2 * nu + u];
+                nrm[k * mk + i2] = (acc > T(0)) ? T(1) / sqrt(acc) : T(1);
+            }
+            for (int e2 = tid; e2 < nA; e2 += 320) {
+                const int r = e2 / nx, s = e2 - r * nx;
+                T acc = T(0);
+                for (int u = 0; u < nx; ++u) acc += T1s[r * nx + u] * As[s * nx + u];
+                for (int u = 0; u < nu; ++u) acc += Bs[r * nu + u] * Bs[s * nu + u];
+                Ss[e2] = acc;
+            }
         }
     }
 }
@@ -252,16 +297,20 @@ size_t big_condense_ws_elems(const KernelArgs &ka) { return (size_t)(ka.N + 1) *
 bool big_supported(const KernelArgs &ka) { return ka.nx <= NXMAX && ka.n + 1 <= 320; }
 
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
-                        void *G, void *h, hipStream_t st)
+                        void *G, void *h, void *rownorm_inv, hipStream_t st)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    const size_t lds = (size_t)(ka.nx * ka.nx + ka.nx * ka.nu + ka.mk * ka.nx + ka.mk * ka.nu + ka.mk) * esz;
-    if (dtype == MPCQP_F64)
-        hipLaunchKernelGGL(mpcqp_propagate_kernel<double>, dim3((unsigned)batch), dim3(320), lds, st, ka,
-                           (double *)Psi_ws, (double *)res_ws, (double *)G, (double *)h);
-    else
-        hipLaunchKernelGGL(mpcqp_propagate_kernel<float>, dim3((unsigned)batch), dim3(320), lds, st, ka,
-                           (float *)Psi_ws, (float *)res_ws, (float *)G, (float *)h);
+    const size_t lds =
+        (size_t)(3 * ka.nx * ka.nx + ka.nx * ka.nu + 2 * ka.mk * ka.nx + ka.mk * ka.nu + ka.mk) * esz;
+#define PROPAGATE(TY, NRMV)                                                                                     \
+    hipLaunchKernelGGL((mpcqp_propagate_kernel<TY, NRMV>), dim3((unsigned)batch), dim3(320), lds, st, ka,       \
+                       (TY *)Psi_ws, (TY *)res_ws, (TY *)G, (TY *)h, (TY *)rownorm_inv)
+    if (dtype == MPCQP_F64) {
+        if (rownorm_inv) PROPAGATE(double, true); else PROPAGATE(double, false);
+    } else {
+        if (rownorm_inv) PROPAGATE(float, true); else PROPAGATE(float, false);
+    }
+#undef PROPAGATE
     int rc = (int)hipGetLastError();
     if (rc) return rc;
     const bool mfma = (dtype == MPCQP_F32) && (ka.n % 32 == 0) && (ka.n <= 256);

@@ -75,7 +75,7 @@ using namespace bigs;
 
 // Packed Cholesky followed by the in-place inverse of the factor, scalar version (any n <= 256,
 // any dtype): thread i owns row i. Returns false when a pivot is not positive.
-template <typename T> __device__ bool factor_invert_scalar(T *Li, int n, int tid, T *red)
+template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li, int n, int tid, T *red)
 {
     // ---- Cholesky, left-looking by columns: thread i owns row i
     bool notpd = false;
@@ -121,7 +121,7 @@ template <typename T> __device__ bool factor_invert_scalar(T *Li, int n, int tid
         // k runs uniformly over the wavefront (from its first column), so L[i][k] is a broadcast
         // read, X[k][j] a conflict-free one, and the row bases stay in scalar registers.
         {
-            const int j = tid, wbase = tid & ~63;
+            const int j = tid, wbase = __builtin_amdgcn_readfirstlane(tid & ~63);
             int rowi = 0;
             for (int i = 0; i < n; rowi += ++i) {
                 const T *ri = Li + rowi;
@@ -132,10 +132,12 @@ template <typename T> __device__ bool factor_invert_scalar(T *Li, int n, int tid
                     int k = wbase, rowk = tri(wbase, 0);
                     for (; k + 4 <= i; k += 4) {
                         const int r1 = rowk + k + 1, r2 = r1 + k + 2, r3 = r2 + k + 3;
-                        const T x0 = (k >= j) ? Li[rowk + j] : T(0);
-                        const T x1 = (k + 1 >= j) ? Li[r1 + j] : T(0);
-                        const T x2 = (k + 2 >= j) ? Li[r2 + j] : T(0);
-                        const T x3 = (k + 3 >= j) ? Li[r3 + j] : T(0);
+                        const int jc = j < n ? j : 0;  // unconditional, in-bounds loads; selected below
+                        const T y0 = Li[rowk + jc], y1 = Li[r1 + jc], y2 = Li[r2 + jc], y3 = Li[r3 + jc];
+                        const T x0 = (k >= j) ? y0 : T(0);
+                        const T x1 = (k + 1 >= j) ? y1 : T(0);
+                        const T x2 = (k + 2 >= j) ? y2 : T(0);
+                        const T x3 = (k + 3 >= j) ? y3 : T(0);
                         a0 += ri[k] * x0;
                         a1 += ri[k + 1] * x1;
                         a2 += ri[k + 2] * x2;
@@ -177,13 +179,16 @@ __device__ __forceinline__ float rlane(float v, int lane)
 __device__ __forceinline__ int crow(int t, int lane) { return (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5); }
 
 // One wavefront: diagonal block J -> its Cholesky factor -> the inverse of that factor, in place.
-__device__ bool diag_block_invert(float *Li, int J, int lane)
+__device__ __forceinline__ bool diag_block_invert(float *Li, int J, int lane)
 {
     const int r = lane & 31, c0 = 32 * J;
     float *row = Li + tri(c0 + r, 0) + c0;
     float d[32], w[32];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) d[c] = (c <= r) ? row[c] : 0.0f;
+    for (int c = 0; c < 32; ++c) {
+        const float dl = row[c];
+        d[c] = (c <= r) ? dl : 0.0f;
+    }
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
@@ -210,8 +215,17 @@ __device__ bool diag_block_invert(float *Li, int J, int lane)
     return ok;
 }
 
-__device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
+__device__ __forceinline__ bool factor_invert_mfma(float *Li, int n, int tid, float *red, long long *st)
 {
+    long long t_last = 0, t_acc[5] = {0, 0, 0, 0, 0};
+    auto lapf = [&](int idx) {
+        if (st && tid == 0) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (idx >= 0) t_acc[idx] += now - t_last;
+            t_last = now;
+        }
+    };
+    lapf(-1);
     const int nb = n >> 5, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     float *flag = red + 7;
     if (tid == 0) flag[0] = 1.0f;
@@ -223,6 +237,7 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
             if (!ok && lane == 0) flag[0] = 0.0f;
         }
         __syncthreads();
+        lapf(0);
         // panel: L[I,J] = A[I,J] W_J'   (B operand B[k][c] = W_J[c][k], zero above the diagonal)
         for (int I = J + 1 + wv; I < nb; I += 4) {
             const float *arow = Li + tri(32 * I + l31, 0) + c0;
@@ -236,13 +251,15 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int k = 2 * s2 + kh;
-                const float bv = (k <= l31) ? brow[k] : 0.0f;
+                const float bl = brow[k];  // unconditional load, selected (see lower_matvec)
+                const float bv = (k <= l31) ? bl : 0.0f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], bv, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) Li[tri(32 * I + crow(t, lane), 0) + c0 + l31] = acc[t];
         }
         __syncthreads();
+        lapf(1);
         // trailing update: A[I,I2] -= L[I,J] L[I2,J]'
         int cnt = 0;
         for (int I = J + 1; I < nb; ++I)
@@ -255,7 +272,8 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     const int rr = crow(t, lane);
-                    acc[t] = (!dg || l31 <= rr) ? Li[tri(32 * I + rr, 0) + 32 * I2 + l31] : 0.0f;
+                    const float cl = Li[tri(32 * I + rr, 0) + 32 * I2 + l31];
+                    acc[t] = (!dg || l31 <= rr) ? cl : 0.0f;
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) {
@@ -269,6 +287,7 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
                 }
             }
         __syncthreads();
+        lapf(2);
     }
     // inverse, block row by block row
     for (int I = 1; I < nb; ++I) {
@@ -285,13 +304,15 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
 #pragma unroll
             for (int s2 = 0; s2 < 16; ++s2) {
                 const int k = 2 * s2 + kh;
-                const float av = (k <= l31) ? wrow[k] : 0.0f;
+                const float al = wrow[k];
+                const float av = (k <= l31) ? al : 0.0f;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s2], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) Li[tri(r0 + crow(t, lane), 0) + 32 * K + l31] = acc[t];
         }
         __syncthreads();
+        lapf(3);
         // X[I,Jt] = - sum_K L'[I,K] X[K,Jt] : kept in registers until every wavefront has read row block I
         f32x16 acc2[2];
 #pragma unroll
@@ -306,7 +327,8 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
 #pragma unroll
                     for (int s2 = 0; s2 < 16; ++s2) {
                         const int k = 2 * s2 + kh;
-                        const float bv = (!dg || l31 <= k) ? Li[tri(32 * K + k, 0) + 32 * Jt + l31] : 0.0f;
+                        const float bl = Li[tri(32 * K + k, 0) + 32 * Jt + l31];
+                        const float bv = (!dg || l31 <= k) ? bl : 0.0f;
                         acc2[qd] = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[k], bv, acc2[qd], 0, 0, 0);
                     }
                 }
@@ -322,16 +344,43 @@ __device__ bool factor_invert_mfma(float *Li, int n, int tid, float *red)
             }
         }
         __syncthreads();
+        lapf(4);
     }
+    if (st && tid == 0)
+        for (int u = 0; u < 5; ++u) st[u] = t_acc[u];
     return flag[0] != 0.0f;
 }
 
+// quad-local sums (lanes 4q .. 4q+3) on the DPP path
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ double quad_sum(double v)
+{
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
+
 // Workspace per problem (elements of T): MA [n][n], Tm [n][n].
-template <typename T>
+//
+// STRUCT = true: G is never formed. The constraint matrix of a condensed MPC problem is
+// G = blockrows(C_k Psi_k + D_k E_k) (qpmpc/mpc_qp.py:62-78), so
+//   * G v (slack updates) is one roll-out  dx_{k+1} = A_k dx_k + B_k v_k  (one wavefront, operands
+//     prefetched eight steps ahead) followed by  (G v)_{k,r} = C_k[r] dx_k + D_k[r] v_k : ~0.1 MB of
+//     operands per product instead of streaming 1 MB of G;
+//   * a row G_p (only for the selected constraint) is C_k[r] Psi_k + D_k[r] E_k from the Psi blocks
+//     the Gram kernel needed anyway;
+//   * 1/|G_i| comes from the propagation kernel (aux2).
+// aux = G' (dense mode) or Psi_all (structured mode).
+template <typename T, bool STRUCT>
 __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
                                                             const T *__restrict__ qall, const T *__restrict__ Gall,
-                                                            const T *__restrict__ GTall, const T *__restrict__ hall,
-                                                            T *__restrict__ wsall)
+                                                            const T *__restrict__ aux, const T *__restrict__ hall,
+                                                            const T *__restrict__ aux2, T *__restrict__ wsall)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = ka.n, m = ka.m, tid = threadIdx.x;
@@ -351,57 +400,157 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     T *lam = rv + n;                    // multipliers by slot[n]
     T *tmp = lam + n;                   // scratch            [n]
     T *red = tmp + n;                   // reductions         [8]
-    int *act = (int *)(red + 8);        // constraint of slot [n]
+    T *dxs = red + 8;                   // roll-out states [N][nx] (structured mode only)
+    int *act = (int *)(dxs + (STRUCT ? ka.N * ka.nx : 0));  // constraint of slot [n]
     int *pos = act + n;                 // slot of constraint, -1 [m]
     int *redi = pos + m;                // [4]
 
     const T *P = Pall + prob * (int64_t)n * n;
     const T *q = qall + prob * (int64_t)n;
-    const T *G = Gall + prob * (int64_t)m * n;
-    const T *GT = GTall + prob * (int64_t)m * n;
+    const T *G = STRUCT ? nullptr : Gall + prob * (int64_t)m * n;
+    const T *GT = STRUCT ? nullptr : aux + prob * (int64_t)m * n;
     const T *h = hall + prob * (int64_t)m;
+    // structured mode: the problem's own operands
+    const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk;
+    const T *gA = STRUCT ? (const T *)ka.A.ptr + prob * ka.A.batch_stride : nullptr;
+    const T *gB = STRUCT ? (const T *)ka.B.ptr + prob * ka.B.batch_stride : nullptr;
+    const T *gC = (STRUCT && ka.C.ptr) ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
+    const T *gD = (STRUCT && ka.D.ptr) ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+    const T *Psi = STRUCT ? aux + prob * (int64_t)(N + 1) * nx * n : nullptr;
+    const T *nrm = STRUCT ? aux2 + prob * (int64_t)m : nullptr;
+
+    // Structured mode keeps the problem's operands in REGISTERS for the whole solve (they are
+    // read once): wavefront w holds A_k, B_k for its 16 steps k = 16 w + d, lane (r, c) =
+    // (lane / 4, lane % 4) taking row r and every fourth column from c; thread t holds the rows
+    // C_k[r], D_k[r] of its four constraints i = t + 256 j.
+    constexpr int SPW = 16, RS = 4;
+    T ra[SPW][4], rb[SPW][2], rc[RS][16], rd[RS][8];
+    int krow[RS];
+    if constexpr (STRUCT) {
+        const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
+#pragma unroll
+        for (int d = 0; d < SPW; ++d) {
+            const int k = wv * SPW + d;
+            const bool live = (k < N - 1) && (r < nx);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int sc = c + 4 * jj;
+                ra[d][jj] = (live && sc < nx) ? gA[(int64_t)k * ka.A.step_stride + r * nx + sc] : T(0);
+                if (jj < 2) rb[d][jj] = (live && sc < nu) ? gB[(int64_t)k * ka.B.step_stride + r * nu + sc] : T(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            const int i = tid + BS * j;
+            const bool live = i < m;
+            const int k = live ? i / mk : 0, r = live ? i - k * mk : 0;
+            krow[j] = k;
+#pragma unroll
+            for (int sc = 0; sc < 16; ++sc)
+                rc[j][sc] = (live && gC && sc < nx) ? gC[(int64_t)k * ka.C.step_stride + r * nx + sc] : T(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                rd[j][u] = (live && gD && u < nu) ? gD[(int64_t)k * ka.D.step_stride + r * nu + u] : T(0);
+        }
+    }
+    // dxs[k] = Psi_k zx for k < N: dx_{k+1} = A_k dx_k + B_k zx_k, the wavefronts taking turns
+    auto rollout = [&]() __attribute__((always_inline)) {
+        const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
+        if (tid < nx) dxs[tid] = T(0);
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wv == w) {
+#pragma unroll
+                for (int d = 0; d < SPW; ++d) {
+                    const int k = w * SPW + d;
+                    if (k < N - 1) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int sc = c + 4 * jj;  // operands past nx / nu are zero: clamp the index
+                            acc += ra[d][jj] * dxs[k * nx + min(sc, nx - 1)];
+                            if (jj < 2) acc += rb[d][jj] * zx[k * nu + min(sc, nu - 1)];
+                        }
+                        acc = quad_sum(acc);
+                        if (c == 0 && r < nx) dxs[(k + 1) * nx + r] = acc;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    // (G zx)_i for the thread's j-th constraint, from the roll-out states
+    auto struct_row = [&](int j) __attribute__((always_inline)) -> T {
+        const int k = krow[j];
+        T acc = T(0);
+#pragma unroll
+        for (int sc = 0; sc < 16; ++sc) acc += rc[j][sc] * dxs[k * nx + min(sc, nx - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += rd[j][u] * zx[k * nu + min(u, nu - 1)];
+        return acc;
+    };
     T *MA = wsall + prob * (int64_t)2 * n * n;
     T *Tm = MA + (int64_t)n * n;
     T *oU = (T *)ka.U + prob * (int64_t)n;
     const T tol = (T)ka.tol;
     int status = MPCQP_MAX_ITER, iters = 0;
     // optional phase timestamps (tools/probe_big_phases.py): ka.X -> long long[8] per problem
-    long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
+    long long *stamp = ka.X ? (long long *)ka.X + prob * 32 : nullptr;
     auto mark = [&](int slot) {
         if (stamp && tid == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
+    };
+    long long lap_t = 0, lap_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // per-phase totals inside the loop
+    auto lap = [&](int idx) {
+        if (stamp && tid == 0) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (idx >= 0) lap_acc[idx] += now - lap_t;
+            lap_t = now;
+        }
     };
     mark(0);
 
     // dst = L^-1 src : thread j takes row j of the packed inverse (k uniform across the wavefront)
-    auto lower_matvec = [&](const T *src) -> T {
+    auto lower_matvec = [&](const T *src) __attribute__((always_inline)) -> T {
         T a0 = T(0), a1 = T(0);
         if (tid < n) {
             const T *rj = Li + tri(tid, 0);
-            const int kend = min(n, (tid | 63) + 1);  // the wavefront's longest row
+            const int kend = __builtin_amdgcn_readfirstlane(min(n, (tid | 63) + 1));  // the wavefront's longest row (uniform)
             int k = 0;
 #pragma unroll 4
+            // loads are unconditional (past the diagonal they land in later rows: finite values,
+            // selected away) so that the compiler can batch them instead of branching per element
             for (; k + 1 < kend; k += 2) {
-                a0 += (k <= tid) ? rj[k] * src[k] : T(0);
-                a1 += (k + 1 <= tid) ? rj[k + 1] * src[k + 1] : T(0);
+                const T l0 = rj[k], l1 = rj[k + 1];
+                a0 += ((k <= tid) ? l0 : T(0)) * src[k];
+                a1 += ((k + 1 <= tid) ? l1 : T(0)) * src[k + 1];
             }
-            if (k < kend && k <= tid) a0 += rj[k] * src[k];
+            if (k < kend) {
+                const T l0 = rj[k];
+                a0 += ((k <= tid) ? l0 : T(0)) * src[k];
+            }
         }
         return a0 + a1;
     };
     // dst = L^-T src : thread j takes column j (row index uniform, row base in scalar registers)
-    auto upper_matvec = [&](const T *src) -> T {
+    auto upper_matvec = [&](const T *src) __attribute__((always_inline)) -> T {
         T a0 = T(0), a1 = T(0);
         if (tid < n) {
-            int i = tid & ~63;
+            int i = __builtin_amdgcn_readfirstlane(tid & ~63);  // uniform: keeps the loop scalar
             int rowi = tri(i, 0);
 #pragma unroll 4
             for (; i + 1 < n; i += 2) {
-                a0 += (i >= tid) ? Li[rowi + tid] * src[i] : T(0);
+                const T l0 = Li[rowi + tid];
                 rowi += i + 1;
-                a1 += (i + 1 >= tid) ? Li[rowi + tid] * src[i + 1] : T(0);
+                const T l1 = Li[rowi + tid];
                 rowi += i + 2;
+                a0 += ((i >= tid) ? l0 : T(0)) * src[i];
+                a1 += ((i + 1 >= tid) ? l1 : T(0)) * src[i + 1];
             }
-            if (i < n && i >= tid) a0 += Li[rowi + tid] * src[i];
+            if (i < n) {
+                const T l0 = Li[rowi + tid];
+                a0 += ((i >= tid) ? l0 : T(0)) * src[i];
+            }
         }
         return a0 + a1;
     };
@@ -431,7 +580,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     // ---- L = chol(P), then L^-1 in place
     bool pd;
     if constexpr (sizeof(T) == 4) {
-        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red) : factor_invert_scalar<T>(Li, n, tid, red);
+        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
     } else {
         pd = factor_invert_scalar<T>(Li, n, tid, red);
     }
@@ -452,39 +601,54 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             if (tid < n) zx[tid] = a;  // unconstrained minimiser in x coordinates
         }
         __syncthreads();
-        if ((m & 3) == 0) {
-            // four consecutive rows per thread, 16-byte loads of G', eight k in flight
-            for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
-                V4 a = {T(0), T(0), T(0), T(0)}, nn = {T(0), T(0), T(0), T(0)};
-#pragma unroll 8
-                for (int k = 0; k < n; ++k) {
-                    const V4 g = *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4);
-                    a += g * zx[k];
-                    nn += g * g;
-                }
+        if constexpr (STRUCT) {
+            rollout();
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int i = 4 * i4 + c;
+            for (int j = 0; j < RS; ++j) {
+                const int i = tid + BS * j;
+                if (i < m) {
                     const T hi = h[i];
-                    sv[i] = hi - a[c];
-                    gin[i] = (nn[c] > T(0)) ? T(1) / sqrt(nn[c]) : T(1);
-                    tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;  // padded rows are never selected
+                    sv[i] = hi - struct_row(j);
+                    gin[i] = nrm[i];
+                    tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
                     pos[i] = -1;
                 }
             }
         } else {
-            for (int i = tid; i < m; i += BS) {
-                T a = T(0), nn = T(0);
-                for (int k = 0; k < n; ++k) {
-                    const T g = GT[(int64_t)k * m + i];
-                    a += g * zx[k];
-                    nn += g * g;
+            if ((m & 3) == 0) {
+                // four consecutive rows per thread, 16-byte loads of G', eight k in flight
+                for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
+                    V4 a = {T(0), T(0), T(0), T(0)}, nn = {T(0), T(0), T(0), T(0)};
+    #pragma unroll 8
+                    for (int k = 0; k < n; ++k) {
+                        const V4 g = *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4);
+                        a += g * zx[k];
+                        nn += g * g;
+                    }
+    #pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int i = 4 * i4 + c;
+                        const T hi = h[i];
+                        sv[i] = hi - a[c];
+                        gin[i] = (nn[c] > T(0)) ? T(1) / sqrt(nn[c]) : T(1);
+                        tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;  // padded rows are never selected
+                        pos[i] = -1;
+                    }
                 }
-                const T hi = h[i];
-                sv[i] = hi - a;
-                gin[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
-                tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
-                pos[i] = -1;
+            } else {
+                for (int i = tid; i < m; i += BS) {
+                    T a = T(0), nn = T(0);
+                    for (int k = 0; k < n; ++k) {
+                        const T g = GT[(int64_t)k * m + i];
+                        a += g * zx[k];
+                        nn += g * g;
+                    }
+                    const T hi = h[i];
+                    sv[i] = hi - a;
+                    gin[i] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+                    tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
+                    pos[i] = -1;
+                }
             }
         }
         if (tid < n) lam[tid] = T(0);
@@ -495,6 +659,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         const int max_iter = ka.max_iter;
         bool fail = false;
         for (;;) {
+            lap(-1);
             // ---- select the violated row farthest from its hyperplane
             T best = INF;
             int bi = 0x7fffffff;
@@ -514,10 +679,32 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                 break;
             }
             const int p = bi;
+            lap(0);
             // ---- M_p = L^-1 G_p'   (thread j: row j of L^-1 against G_p)
             __syncthreads();
-            if (tid < n) tmp[tid] = G[(int64_t)p * n + tid];
+            if constexpr (STRUCT) {
+                if (tid < n) {
+                    const int k = p / mk, r = p - k * mk;
+                    T g = T(0);
+                    if (gC) {
+                        const T *cr = gC + (int64_t)k * ka.C.step_stride + r * nx;
+                        const T *pk = Psi + (int64_t)k * nx * n + tid;
+#pragma unroll
+                        for (int sc = 0; sc < 16; ++sc) {
+                            const int sl = min(sc, nx - 1);
+                            const T cv = cr[sl];
+                            g += ((sc < nx) ? cv : T(0)) * pk[(int64_t)sl * n];
+                        }
+                    }
+                    const int jb = tid / nu;
+                    if (gD && jb == k) g += gD[(int64_t)k * ka.D.step_stride + r * nu + (tid - jb * nu)];
+                    tmp[tid] = g;
+                }
+            } else {
+                if (tid < n) tmp[tid] = G[(int64_t)p * n + tid];
+            }
             __syncthreads();
+            lap(1);
             {
                 const T a = lower_matvec(tmp);
                 if (tid < n) mp[tid] = a;
@@ -530,6 +717,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             }
             T up = T(0);
             bool added = false;
+            lap(2);
             while (!added) {
                 if (iters >= max_iter) {
                     fail = true;
@@ -545,6 +733,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     if ((tid & 63) == 0) rv[a] = acc;
                 }
                 __syncthreads();
+                lap(3);
                 // z = -M_p + sum_a r_a M_a   (thread k: column k, coalesced)
                 T zk = T(0);
                 if (tid < n) {
@@ -574,31 +763,42 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                 const bool full = (t2 <= t1);
                 // z_x = L^-T z, then s_i -= t G_i . z_x through the transposed G
                 __syncthreads();
+                lap(4);
                 {
                     const T a = upper_matvec(zv);
                     if (tid < n) zx[tid] = a;
                 }
                 __syncthreads();
-                if ((m & 3) == 0) {
-                    for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
-                        V4 a = {T(0), T(0), T(0), T(0)};
-#pragma unroll 8
-                        for (int k = 0; k < n; ++k)
-                            a += *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4) * zx[k];
+                lap(5);
+                if constexpr (STRUCT) {
+                    rollout();
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int i = 4 * i4 + c;
-                            sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * a[c];
-                        }
+                    for (int j = 0; j < RS; ++j) {
+                        const int i = tid + BS * j;
+                        if (i < m) sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * struct_row(j);
                     }
                 } else {
-                    for (int i = tid; i < m; i += BS) {
-                        T a0 = T(0), a1 = T(0);
-                        for (int k = 0; k < n; k += 2) {
-                            a0 += GT[(int64_t)k * m + i] * zx[k];
-                            a1 += GT[(int64_t)(k + 1) * m + i] * zx[k + 1];
+                    if ((m & 3) == 0) {
+                        for (int i4 = tid; i4 < (m >> 2); i4 += BS) {
+                            V4 a = {T(0), T(0), T(0), T(0)};
+    #pragma unroll 8
+                            for (int k = 0; k < n; ++k)
+                                a += *reinterpret_cast<const V4 *>(GT + (int64_t)k * m + 4 * i4) * zx[k];
+    #pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const int i = 4 * i4 + c;
+                                sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * a[c];
+                            }
                         }
-                        sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * (a0 + a1);
+                    } else {
+                        for (int i = tid; i < m; i += BS) {
+                            T a0 = T(0), a1 = T(0);
+                            for (int k = 0; k < n; k += 2) {
+                                a0 += GT[(int64_t)k * m + i] * zx[k];
+                                a1 += GT[(int64_t)(k + 1) * m + i] * zx[k + 1];
+                            }
+                            sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * (a0 + a1);
+                        }
                     }
                 }
                 if (tid < nq) {
@@ -607,6 +807,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                 }
                 up += t;
                 __syncthreads();
+                lap(6);
                 if (full) {
                     // T_a += (r_a / d2) z ; new row T_nq = -z / d2 ; M_nq = M_p
                     const T inv = T(1) / d2;
@@ -661,6 +862,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     --nq;
                 }
                 __syncthreads();
+                lap(7);
             }
             if (fail) break;
         }
@@ -683,6 +885,8 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
     }
     mark(6);
+    if (stamp && tid == 0)
+        for (int u = 0; u < 8; ++u) stamp[8 + u] = lap_acc[u];
     const bool ok = (status == MPCQP_SOLVED);
     if (tid < n) oU[tid] = ok ? zx[tid] : T(0);
     if (ka.lam) {
@@ -727,37 +931,52 @@ int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t b
     return (int)hipGetLastError();
 }
 
-size_t bigsolve_lds_bytes(int n, int m, size_t esz)
+size_t bigsolve_lds_bytes(int n, int m, size_t esz, int rollout_elems)
 {
-    const size_t el = (size_t)n * (n + 1) / 2 + 3 * (size_t)m + 7 * (size_t)n + 8;
+    const size_t el = (size_t)n * (n + 1) / 2 + 3 * (size_t)m + 7 * (size_t)n + 8 + (size_t)rollout_elems;
     return el * esz + ((size_t)n + m + 4) * 4 + 16;
 }
 bool bigsolve_supported(int n, int m, int dtype)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    return n <= bigs::BS && (n % 2 == 0) && bigsolve_lds_bytes(n, m, esz) <= kLdsBytesPerCU;
+    return n <= bigs::BS && (n % 2 == 0) && bigsolve_lds_bytes(n, m, esz, 0) <= kLdsBytesPerCU;
+}
+// structured (matrix-free G) mode: needs the roll-out table in LDS too, nx and nu within the lane map
+bool bigsolve_struct_supported(const KernelArgs &ka, int dtype)
+{
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    return ka.m > 0 && ka.m <= 4 * bigs::BS && ka.mk > 0 && ka.nx <= 16 && ka.nu <= 8 && ka.N <= 65 &&
+           ka.n <= bigs::BS && (ka.n % 2 == 0) &&
+           bigsolve_lds_bytes(ka.n, ka.m, esz, ka.N * ka.nx) <= kLdsBytesPerCU;
 }
 size_t bigsolve_ws_elems(int n) { return (size_t)2 * n * n; }
+
+template <typename T, bool STRUCT>
+static int launch_bigsolve_t(const KernelArgs &ka, int64_t batch, const void *P, const void *q, const void *G,
+                             const void *aux, const void *h, const void *aux2, void *ws, hipStream_t st)
+{
+    const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, sizeof(T), STRUCT ? ka.N * ka.nx : 0);
+    auto kern = mpcqp_bigsolve_kernel<T, STRUCT>;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const T *)P, (const T *)q,
+                       (const T *)G, (const T *)aux, (const T *)h, (const T *)aux2, (T *)ws);
+    return (int)hipGetLastError();
+}
 
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st)
 {
-    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, esz);
-    if (dtype == MPCQP_F64) {
-        auto kern = mpcqp_bigsolve_kernel<double>;
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const double *)P, (const double *)q,
-                           (const double *)G, (const double *)GT, (const double *)h, (double *)ws);
-    } else {
-        auto kern = mpcqp_bigsolve_kernel<float>;
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const float *)P, (const float *)q,
-                           (const float *)G, (const float *)GT, (const float *)h, (float *)ws);
-    }
-    return (int)hipGetLastError();
+    if (dtype == MPCQP_F64) return launch_bigsolve_t<double, false>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
+    return launch_bigsolve_t<float, false>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
+}
+
+int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q,
+                           const void *Psi_all, const void *h, const void *rownorm_inv, void *ws, hipStream_t st)
+{
+    if (dtype == MPCQP_F64)
+        return launch_bigsolve_t<double, true>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
+    return launch_bigsolve_t<float, true>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
 }
 
 }  // namespace mpcqp

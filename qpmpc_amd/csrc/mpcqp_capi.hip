@@ -109,10 +109,24 @@ size_t solver_ws_elems(int n, int m, int dtype)
     return (size_t)L.total;
 }
 
+// MPCQP_FORCE_DENSE_G=1 makes the fused large path form G (and its transpose) instead of applying
+// it through the roll-out (cross-checking the two).
+bool force_dense_g()
+{
+    const char *v = getenv("MPCQP_FORCE_DENSE_G");
+    return v && v[0] == '1';
+}
+
+bool use_struct(const KernelArgs &ka, int dtype)
+{
+    return !force_gws() && !force_dense_g() && bigsolve_struct_supported(ka, dtype);
+}
+
 // Sizes (in elements) of the pieces of the large-path workspace, per problem.
 struct BigPlan {
-    size_t psi, P, q, G, h, solver;  // psi includes the residual vector
-    size_t total(bool with_qp) const { return psi + (with_qp ? P + q + G + h : 0) + solver; }
+    size_t psi, P, q, G, h, nrm, solver;  // psi includes the residual vector
+    bool matrix_free;                     // G applied through the roll-out, never formed
+    size_t total(bool with_qp) const { return psi + (with_qp ? P + q + G + h + nrm : 0) + solver; }
 };
 
 BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
@@ -120,11 +134,17 @@ BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
     BigPlan b{};
     if (condense) b.psi = big_condense_ws_elems(ka);
     if (solve) {
+        b.matrix_free = use_struct(ka, dtype);
         b.P = (size_t)ka.n * ka.n;
         b.q = ka.n;
-        b.G = (size_t)ka.m * ka.n;
         b.h = ka.m;
-        b.solver = solver_ws_elems(ka.n, ka.m, dtype);
+        if (b.matrix_free) {
+            b.nrm = ka.m;
+            b.solver = bigsolve_ws_elems(ka.n);
+        } else {
+            b.G = (size_t)ka.m * ka.n;
+            b.solver = solver_ws_elems(ka.n, ka.m, dtype);
+        }
     }
     return b;
 }
@@ -262,7 +282,7 @@ int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
         void *psi_ws = Psi ? Psi : workspace;
         void *res_ws = Psi ? workspace : (void *)((char *)workspace + psi_el * esz);
-        if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, P, q, G, h, st))) return rc;
+        if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, P, q, G, h, nullptr, st))) return rc;
     } else {
         return rc;
     }
@@ -358,7 +378,13 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     w += b.G * nb * esz;
     void *hw = w;
     w += b.h * nb * esz;
-    if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, Pw, qw, Gw, hw, st))) return rc;
+    if (b.matrix_free) {
+        void *nw = w;
+        w += b.nrm * nb * esz;
+        if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, Pw, qw, nullptr, hw, nw, st))) return rc;
+        return launch_bigsolve_struct(ka, dims->dtype, batch, Pw, qw, psi_ws, hw, nw, w, st);
+    }
+    if ((rc = launch_big_condense(ka, dims->dtype, batch, psi_ws, res_ws, Pw, qw, Gw, hw, nullptr, st))) return rc;
     ka.P = Pw;
     ka.q = qw;
     ka.G = Gw;

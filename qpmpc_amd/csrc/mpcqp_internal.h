@@ -125,11 +125,15 @@ int dispatch_gws_solve(const KernelArgs &ka, const Layout &L, int dtype, int64_t
 // large-problem condensing (mpcqp_big.hip)
 size_t big_condense_ws_elems(const KernelArgs &ka);
 bool big_supported(const KernelArgs &ka);
+// G may be null (not formed); rownorm_inv (1/|G_i|, [batch, m]) is optional
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
-                        void *G, void *h, hipStream_t st);
+                        void *G, void *h, void *rownorm_inv, hipStream_t st);
 // large-problem solver (mpcqp_bigsolve.hip): one problem per workgroup, L^-1 packed in LDS
 bool bigsolve_supported(int n, int m, int dtype);
 size_t bigsolve_ws_elems(int n);
+bool bigsolve_struct_supported(const KernelArgs &ka, int dtype);
+int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q,
+                           const void *Psi_all, const void *h, const void *rownorm_inv, void *ws, hipStream_t st);
 int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st);
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st);
