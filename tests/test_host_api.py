@@ -141,7 +141,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     d = _capi.Dims(3, 1, 16, 2, _capi.F64, 5, 1.0, 0.0, 1e-6)
     assert lib.mpcqp_workspace_bytes(C.byref(d), 4096, 1, C.byref(b)) == 0 and b.value == 0
     d = _capi.Dims(12, 4, 64, 16, _capi.F32, 15, 10.0, 1.0, 1e-2)
-    assert lib.mpcqp_workspace_bytes(C.byref(d), 2, 1, C.byref(b)) == 0 and b.value > 2 * 3_000_000
+    assert lib.mpcqp_workspace_bytes(C.byref(d), 2, 1, C.byref(b)) == 0 and b.value > 2 * 1_000_000
     assert lib.mpcqp_workspace_bytes(C.byref(d), 2, 0, C.byref(b)) == 0 and b.value == 2 * 780 * 257 * 4
 
 
