@@ -527,3 +527,100 @@ def test_closed_loop_with_shared_model_matches_rebuild_every_step():
     xa, xb = a.states.cpu().numpy(), b.states.cpu().numpy()
     assert np.abs(xa - xb).max() <= 1e-8
     assert a.stats()["failed"] == 0 and b.stats()["failed"] == 0
+
+
+# ---------------------------------------------------------------- large-problem solver (one QP per workgroup)
+def _random_dense_qps(rng, Bn, n, m, tight=0.2):
+    Ps, qs, Gs, hs = [], [], [], []
+    for _ in range(Bn):
+        M = rng.standard_normal((n, n))
+        Ps.append(M @ M.T / n + 0.1 * np.eye(n))
+        qs.append(rng.standard_normal(n))
+        Gs.append(rng.standard_normal((m, n)))
+        hs.append(np.abs(rng.standard_normal(m)) * tight + 0.05)
+    return Ps, qs, Gs, hs
+
+
+@pytest.mark.parametrize("n,m,dtype,tol", [
+    (256, 1024, "f32", 2e-3),  # MFMA blocked factor + inverse, 16-byte loads of G'
+    (96, 203, "f32", 2e-3),    # MFMA factor, m not a multiple of 4 (scalar G' loop)
+    (100, 300, "f32", 2e-3),   # n not a multiple of 32: scalar packed Cholesky + inverse
+    (160, 512, "f64", 1e-8),   # float64: scalar factorisation, packed L^-1 = 103 KB
+])
+def test_large_solver_dense_qps_vs_oracle(n, m, dtype, tol):
+    """mpcqp_solve_batch on dense QPs too large for the on-chip kernels (mpcqp_bigsolve.hip:
+    L^-1 packed in LDS, lazy rows of M, N* in the workspace) against the float64 oracle.
+    Random dense constraints make the active set add AND drop."""
+    from qpmpc_amd import solve_qp_batch
+
+    rng = np.random.default_rng(n + m)
+    Bn = 3
+    Ps, qs, Gs, hs = _random_dense_qps(rng, Bn, n, m)
+    td = torch.float32 if dtype == "f32" else torch.float64
+    P, q, G, h = (torch.tensor(np.stack(a), device="cuda", dtype=td) for a in (Ps, qs, Gs, hs))
+    x, lam, status, iters = solve_qp_batch(P, q, G, h, return_multipliers=True)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all(), status
+    for b in range(Bn):
+        xo, lo, so, _ = oracle.gi_solve(Ps[b], qs[b], Gs[b], hs[b])
+        assert so == 0
+        xb = x[b].double().cpu().numpy()
+        assert np.abs(xb - xo).max() <= tol * max(1.0, np.abs(xo).max()), np.abs(xb - xo).max()
+        lb = lam[b].double().cpu().numpy()
+        assert (lb >= 0).all()
+        # KKT in the kernel's own precision: stationarity and primal feasibility
+        r = Ps[b] @ xb + qs[b] + Gs[b].T @ lb
+        assert np.abs(r).max() <= 50 * tol, np.abs(r).max()
+        assert (Gs[b] @ xb - hs[b]).max() <= 50 * tol
+
+
+def test_large_solver_statuses():
+    """Infeasible constraints -> status 2, indefinite P -> status 3, and U is zeroed (large solver)."""
+    from qpmpc_amd import solve_qp_batch
+
+    rng = np.random.default_rng(77)
+    n, m = 128, 400
+    Ps, qs, Gs, hs = _random_dense_qps(rng, 3, n, m)
+    Gs[1][0] = rng.standard_normal(n)
+    Gs[1][1] = -Gs[1][0]
+    hs[1][0], hs[1][1] = -1.0, -1.0  # g x <= -1 and -g x <= -1
+    Ps[2] = Ps[2] - 0.5 * np.eye(n)  # smallest eigenvalue of M M'/n + 0.1 I is close to 0.1
+    P, q, G, h = (torch.tensor(np.stack(a), device="cuda", dtype=torch.float32) for a in (Ps, qs, Gs, hs))
+    x, _, status, _ = solve_qp_batch(P, q, G, h)
+    st = status.cpu().numpy()
+    assert st[0] == 0 and st[1] == 2 and st[2] == 3, st
+    assert np.abs(x[1].cpu().numpy()).max() == 0.0 and np.abs(x[2].cpu().numpy()).max() == 0.0
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("f64", 1e-8)])
+def test_large_path_structured_ltv_with_state_and_input_constraints(dtype, tol, monkeypatch):
+    """Fused large path on a random LTV family (nx=6, nu=3, N=64, mk=5 -> n=192, m=320) with C and D
+    rows, stage and terminal costs: matrix-free G (roll-out operator) vs the oracle, and the same batch
+    with G formed densely (MPCQP_FORCE_DENSE_G) and through the general workspace kernel
+    (MPCQP_FORCE_GWS) must give the same plans."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(2025)
+    w = _random_ltv_workload(rng, 4, 6, 3, 64, 5)
+    w["A"] = np.eye(6) + 0.05 * (w["A"] - np.eye(6))  # keep the 64-step propagation well scaled
+    td = torch.float32 if dtype == "f32" else torch.float64
+    bp = to_batch_problem(w, dtype=td)
+    ref = solve_mpc_batch(bp)
+    torch.cuda.synchronize()
+    Uo, _, sto, _ = oracle_batch(w)
+    U = ref.U.double().cpu().numpy()
+    st = ref.status.cpu().numpy()
+    assert np.array_equal(st == 0, sto == 0), (st, sto)
+    ok = sto == 0
+    assert ok.sum() >= 3
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= tol
+    for env in ("MPCQP_FORCE_DENSE_G", "MPCQP_FORCE_GWS"):
+        monkeypatch.setenv(env, "1")
+        other = solve_mpc_batch(bp)
+        torch.cuda.synchronize()
+        monkeypatch.delenv(env)
+        assert np.array_equal(other.status.cpu().numpy(), st), env
+        Ub = other.U.double().cpu().numpy()
+        assert (np.abs(Ub[ok] - U[ok]) / scale).max() <= 2 * tol, env
