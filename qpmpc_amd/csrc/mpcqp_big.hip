@@ -175,11 +175,16 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
 
 // ------------------------------------------------------------------ Gram, MFMA f32
 // P = w_u I + sum_rows w_row Psi[row,:]' Psi[row,:]  (n x n, n a multiple of 32, <= 256)
-// One workgroup of 8 wavefronts per problem. Wavefront w owns tile row w: the 32 x n
-// strip P[32w : 32w+32, :] as n/32 accumulators of v_mfma_f32_32x32x2_f32. Psi is
-// streamed through LDS KC rows at a time; the A operand (this wavefront's 32 columns,
-// scaled by the row weight) is loaded once per k-step and reused for every tile of
-// the strip. q = Psi' W resid is accumulated by the first n threads from the same tile.
+// One workgroup of 8 wavefronts per problem. Wavefront w owns tile row w of the LOWER triangle:
+// the tiles P[32w : 32w+32, 32t : 32t+32], t <= w, as accumulators of v_mfma_f32_32x32x2_f32
+// (the upper triangle is mirrored in the epilogue through LDS). Psi is streamed through LDS
+// KC rows at a time; the A operand (this wavefront's 32 columns, scaled by the row weight) is
+// loaded once per k-step and reused for every tile of the strip.
+// Causality is used twice: row block k of Psi is zero from column k nu on (u_j with j >= k does
+// not reach x_k, qpmpc/mpc_qp.py:80-90), so a chunk of rows is only staged up to that column and
+// only the strips that start below it do any MFMA. With the symmetry this is 120 of the
+// 512 tile-rows of the dense product for N = 64 (the wavefront with most work does 20 of 64).
+// q = Psi' W resid is accumulated by the first n threads from the same tile.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 template <int NT>  // NT = n / 32 tiles per strip
@@ -188,9 +193,10 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
                                                                    float *__restrict__ oP, float *__restrict__ oq)
 {
     __shared__ __attribute__((aligned(16))) float tile[KC * 256];
+    __shared__ float tr[8][32 * 33];
     __shared__ float wrow[KC], rrow[KC];
-    const int nx = ka.nx, N = ka.N, n = ka.n;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nx = ka.nx, nu = ka.nu, N = ka.N, n = ka.n;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31;
     const int64_t prob = blockIdx.x;
     const int K = (N + 1) * nx;
     const float *Psi = Psi_ws + prob * (int64_t)K * n;
@@ -208,10 +214,13 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
     const bool strip = wv < NT;  // wavefronts beyond n/32 only help with the staging
     // block 0 of Psi is zero: start at row nx
     for (int row0 = nx; row0 < K; row0 += KC) {
+        // columns that can be non-zero in this chunk: below k_last nu, rounded up to a tile
+        const int klast = min(row0 + KC - 1, K - 1) / nx;
+        const int cnz = min(n, klast * nu), cmax = min(n, (cnz + 31) & ~31);
         __syncthreads();
         // stage KC rows (coalesced float4 loads; rows past K are zero-weighted)
-        for (int i = tid * 4; i < KC * n; i += 512 * 4) {
-            const int r = i / n, c = i - r * n;
+        for (int i = tid * 4; i < KC * cmax; i += 512 * 4) {
+            const int r = i / cmax, c = i - r * cmax;
             const int row = row0 + r;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < K) val = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + c);
@@ -224,20 +233,22 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
             rrow[tid] = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
         }
         __syncthreads();
-        if (strip) {
+        if (strip && 32 * wv < cnz) {
 #pragma unroll
             for (int kk = 0; kk < KC; kk += 2) {
                 const int kr = kk + (lane >> 5);
                 // A[i][k] = w_k Psi[k][32 wv + i],  B[k][j] = Psi[k][32 t + j]
-                const float a = wrow[kr] * tile[kr * 256 + 32 * wv + (lane & 31)];
+                const float a = wrow[kr] * tile[kr * 256 + 32 * wv + l31];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float b = tile[kr * 256 + 32 * t + (lane & 31)];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    if (t <= wv) {
+                        const float b = tile[kr * 256 + 32 * t + l31];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                    }
                 }
             }
         }
-        if (tid < n) {
+        if (tid < cmax) {
 #pragma unroll
             for (int r = 0; r < KC; ++r) qacc += rrow[r] * tile[r * 256 + tid];
         }
@@ -247,13 +258,27 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
     if (strip) {
         const float wu = (float)ka.wu;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            if (t > wv) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int jj = 32 * t + (lane & 31);
-                P[(int64_t)i * n + jj] = acc[t][r] + ((i == jj) ? wu : 0.0f);
+                const int il = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int i = 32 * wv + il, jj = 32 * t + l31;
+                const float v = acc[t][r] + ((i == jj) ? wu : 0.0f);
+                P[(int64_t)i * n + jj] = v;
+                if (t < wv) tr[wv][il * 33 + l31] = v;
             }
+            if (t < wv) {
+                // mirrored tile P[32t + j][32wv + i], written with i across the lanes (coalesced)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    P[(int64_t)(32 * t + jl) * n + 32 * wv + l31] = tr[wv][l31 * 33 + jl];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+        }
     }
     if (tid < n) oq[prob * (int64_t)n + tid] = qacc;
 }

@@ -179,11 +179,19 @@ __device__ __forceinline__ float rlane(float v, int lane)
 __device__ __forceinline__ int crow(int t, int lane) { return (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5); }
 
 // One wavefront: diagonal block J -> its Cholesky factor -> the inverse of that factor, in place.
-__device__ __forceinline__ bool diag_block_invert(float *Li, int J, int lane)
+// Lane r keeps row r in registers. Column c is broadcast through a 32-float LDS buffer (one write,
+// eight 16-byte broadcast reads) rather than lane by lane; the inverse W = L^-1 is then one forward
+// substitution per lane (lane r = column r) against the rows of L read back as broadcasts.
+__device__ __forceinline__ bool diag_block_invert(float *Li, int J, int lane, float *colbuf)
 {
-    const int r = lane & 31, c0 = 32 * J;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int r = lane & 31;
+    // opaque to the optimiser: otherwise the 100+ lane predicates below are hoisted out of the
+    // caller's loop over J and kept alive through the MFMA phases (hundreds of spills)
+    asm volatile("" : "+v"(r));
+    const int c0 = 32 * J;
     float *row = Li + tri(c0 + r, 0) + c0;
-    float d[32], w[32];
+    float d[32], w[32], rinvs[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
         const float dl = row[c];
@@ -192,21 +200,51 @@ __device__ __forceinline__ bool diag_block_invert(float *Li, int J, int lane)
     bool ok = true;
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-        const float piv = rlane(d[c], c);
+        if (lane < 32) colbuf[r] = d[c];  // column c before scaling
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float cv[32];
+#pragma unroll
+        for (int g = c / 4; g < 8; ++g) {
+            const f4 v = *reinterpret_cast<const f4 *>(colbuf + 4 * g);
+            cv[4 * g] = v[0];
+            cv[4 * g + 1] = v[1];
+            cv[4 * g + 2] = v[2];
+            cv[4 * g + 3] = v[3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float piv = cv[c];
         ok = ok && (piv > 0.0f);
-        const float rinv = 1.0f / sqrtf(piv);
+        float rinv = __builtin_amdgcn_rsqf(piv);  // v_rsq_f32 + one Newton step
+        rinv = rinv * (1.5f - 0.5f * piv * rinv * rinv);
+        rinvs[c] = rinv;
+        // L[r][c] = a[r][c] rinv ; a[r][c2] -= L[r][c] L[c2][c] = (a[r][c] rinv^2) a[c2][c]
+        const float f = (r >= c) ? d[c] * (rinv * rinv) : 0.0f;
         d[c] *= rinv;
 #pragma unroll
-        for (int c2 = c + 1; c2 < 32; ++c2) d[c2] -= d[c] * rlane(d[c], c2);  // entries above the diagonal: unused
+        for (int c2 = c + 1; c2 < 32; ++c2) {
+            d[c2] -= f * cv[c2];
+            asm volatile("" : "+v"(d[c2]));  // right-looking on purpose: do not defer the updates
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // lane r = column r of W = L^-1: forward substitution with the rows of L broadcast
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c <= r) row[c] = d[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane r = column r of W = L^-1
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
+        const float *ri = Li + tri(c0 + i, 0) + c0;  // uniform address: broadcast reads
         float acc = (i == r) ? 1.0f : 0.0f;
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc -= rlane(d[k], i) * w[k];
-        w[i] = acc / rlane(d[i], i);
+        for (int k = 0; k < i; ++k) acc -= ri[k] * w[k];
+        w[i] = acc * rinvs[i];
+        asm volatile("" : "+v"(w[i]));  // computed here, not sunk into the predicated stores below
+        __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < 32) {
 #pragma unroll
         for (int i = 0; i < 32; ++i)
@@ -215,7 +253,7 @@ __device__ __forceinline__ bool diag_block_invert(float *Li, int J, int lane)
     return ok;
 }
 
-__device__ __forceinline__ bool factor_invert_mfma(float *Li, int n, int tid, float *red, long long *st)
+__device__ __forceinline__ bool factor_invert_mfma(float *Li, int n, int tid, float *red, float *scratch, long long *st)
 {
     long long t_last = 0, t_acc[5] = {0, 0, 0, 0, 0};
     auto lapf = [&](int idx) {
@@ -233,7 +271,7 @@ __device__ __forceinline__ bool factor_invert_mfma(float *Li, int n, int tid, fl
     for (int J = 0; J < nb; ++J) {
         const int c0 = 32 * J;
         if (wv == 0) {
-            const bool ok = diag_block_invert(Li, J, lane);
+            const bool ok = diag_block_invert(Li, J, lane, scratch);
             if (!ok && lane == 0) flag[0] = 0.0f;
         }
         __syncthreads();
@@ -426,7 +464,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     constexpr int SPW = 16, RS = 4;
     T ra[SPW][4], rb[SPW][2], rc[RS][16], rd[RS][8];
     int krow[RS];
-    if constexpr (STRUCT) {
+    auto load_operands = [&]() __attribute__((always_inline)) {
         const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
 #pragma unroll
         for (int d = 0; d < SPW; ++d) {
@@ -452,7 +490,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             for (int u = 0; u < 8; ++u)
                 rd[j][u] = (live && gD && u < nu) ? gD[(int64_t)k * ka.D.step_stride + r * nu + u] : T(0);
         }
-    }
+    };
     // dxs[k] = Psi_k zx for k < N: dx_{k+1} = A_k dx_k + B_k zx_k, the wavefronts taking turns
     auto rollout = [&]() __attribute__((always_inline)) {
         const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
@@ -557,18 +595,19 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
 
     // ---- packed lower triangle of P
     if ((n & 3) == 0) {
-        // whole rows as 16-byte loads, sixteen in flight per thread; the upper part is dropped
+        // whole rows as 16-byte loads, sixteen in flight per thread. Branch-free so that the loads
+        // batch: groups above the diagonal re-read their row's diagonal group and store to a dump
+        // slot (the vectors after y0 are not in use yet; n >= 64 here, see bigsolve_supported).
         const int nv = n * n / 4;
+        T *dump = y0 + tid;
 #pragma unroll 16
         for (int v4 = tid; v4 < nv; v4 += BS) {
             const int idx = 4 * v4, i = idx / n, j = idx - i * n;
-            if (j <= i) {
-                const V4 pv = *reinterpret_cast<const V4 *>(P + idx);
-                T *d = Li + tri(i, j);
+            const bool need = j <= i;
+            const V4 pv = *reinterpret_cast<const V4 *>(P + (need ? idx : i * n + (i & ~3)));
+            T *d = Li + tri(i, j);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (j + c <= i) d[c] = pv[c];
-            }
+            for (int c = 0; c < 4; ++c) *((need && j + c <= i) ? d + c : dump) = pv[c];
         }
     } else {
 #pragma unroll 8
@@ -580,7 +619,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     // ---- L = chol(P), then L^-1 in place
     bool pd;
     if constexpr (sizeof(T) == 4) {
-        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
+        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, sv, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
     } else {
         pd = factor_invert_scalar<T>(Li, n, tid, red);
     }
@@ -588,6 +627,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         status = MPCQP_NOT_PD;
     } else {
         mark(3);
+        if constexpr (STRUCT) load_operands();  // after the factorisation: 190 registers it should not have to carry
         // ---- y0 = -L^-1 q ; slacks at the unconstrained minimiser need x0 = L^-T y0
         if (tid < n) tmp[tid] = q[tid];
         __syncthreads();
@@ -939,14 +979,14 @@ size_t bigsolve_lds_bytes(int n, int m, size_t esz, int rollout_elems)
 bool bigsolve_supported(int n, int m, int dtype)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    return n <= bigs::BS && (n % 2 == 0) && bigsolve_lds_bytes(n, m, esz, 0) <= kLdsBytesPerCU;
+    return n >= 64 && n <= bigs::BS && (n % 2 == 0) && bigsolve_lds_bytes(n, m, esz, 0) <= kLdsBytesPerCU;
 }
 // structured (matrix-free G) mode: needs the roll-out table in LDS too, nx and nu within the lane map
 bool bigsolve_struct_supported(const KernelArgs &ka, int dtype)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
     return ka.m > 0 && ka.m <= 4 * bigs::BS && ka.mk > 0 && ka.nx <= 16 && ka.nu <= 8 && ka.N <= 65 &&
-           ka.n <= bigs::BS && (ka.n % 2 == 0) &&
+           ka.n >= 64 && ka.n <= bigs::BS && (ka.n % 2 == 0) &&
            bigsolve_lds_bytes(ka.n, ka.m, esz, ka.N * ka.nx) <= kLdsBytesPerCU;
 }
 size_t bigsolve_ws_elems(int n) { return (size_t)2 * n * n; }
