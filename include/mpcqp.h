@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 3
+#define MPCQP_ABI_VERSION 4
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -214,6 +214,22 @@ int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t 
                             const int32_t *status, int32_t N, double sampling_period,
                             double target_vel, double length, double gravity, int32_t nsub,
                             void *x0, void *goal, void *targets, int64_t batch, void *stream);
+
+/* One period of `batch` LIPM walking controllers, fused (examples/lipm_walking_controller.py:304-333):
+ * if U is not NULL, apply the first jerk of each plan (U[b*u_stride], zero when status[b] != 0) to
+ * the constant-jerk plant for `nsub` exact sub-steps (integrate, :216-236) and advance the footstep
+ * phase (PhaseStepper.advance / advance_stride :125-132, main loop :329-332); then write the NEXT MPC
+ * problem of every walker: x0 [3], goal [3] and the per-step ZMP bounds e [N, 2] of its receding
+ * horizon (PhaseStepper.get_nb_steps :134-165, update_goal_and_constraints :179-213; rows without a
+ * bound hold max_zmp_dist). U == NULL only writes the problem of the current phase (first period).
+ * Per walker, updated in place: states [3], index, stride_index (int64), support; read: strides [2],
+ * foot_size. Refuses (EINVAL) horizons spanning more than two steps, like the reference (:107-110). */
+int mpcqp_lipm_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride,
+                             const int32_t *status, int32_t N, double sampling_period, int32_t nsub,
+                             int32_t nb_dsp, int32_t nb_ssp, double max_zmp_dist, int64_t *index,
+                             int64_t *stride_index, void *support, const void *strides,
+                             const void *foot_size, void *x0, void *goal, void *e, int64_t batch,
+                             void *stream);
 
 #ifdef __cplusplus
 }

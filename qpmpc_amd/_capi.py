@@ -13,7 +13,7 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -33,6 +33,7 @@ EXPORTS = (
     "mpcqp_factor_model",
     "mpcqp_solve_model_batch",
     "mpcqp_wip_advance_batch",
+    "mpcqp_lipm_advance_batch",
 )
 
 
@@ -110,6 +111,9 @@ def load():
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]
+    lib.mpcqp_lipm_advance_batch.restype = C.c_int
+    lib.mpcqp_lipm_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpcqp_rollout_batch.restype = C.c_int
     lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
                                         C.POINTER(Operand), vp, i64, vp, vp]

@@ -109,3 +109,186 @@ class WIPClosedLoop:
             "failed": int(self.failed.item()),
             "mean_iters": float(self.iters_total.item()) / solves,
         }
+
+
+# ---------------------------------------------------------------------------
+# LIPM walking controller
+# ---------------------------------------------------------------------------
+MAX_ZMP_DIST = 100.0  # examples/lipm_walking_controller.py:29
+
+
+class LIPMWalkingLoop:
+    """``B`` walkers running the model-predictive part of the LIPM walking controller in lock step.
+
+    Batched counterpart of examples/lipm_walking_controller.py:304-333. Per MPC period every walker
+    (1) rebuilds the ZMP bounds ``e_k`` of its receding horizon from its footstep phase and its goal
+    state (``PhaseStepper.get_nb_steps`` + ``update_goal_and_constraints``, :134-213) -- a per-step
+    *list* of inequality vectors in the reference, a ``[B, N, 2]`` operand here --, (2) solves its MPC
+    problem (triple integrator, nx=3, nu=1, N=16, ZMP rows ``C``; one fused launch for the batch,
+    replacing ``solve_mpc`` at :309), (3) integrates the first jerk exactly for ``substeps``
+    sub-steps (:216-236, :311-312) and (4) advances its phase (:329-332). Walkers differ by initial
+    phase, support foot, stride lengths and foot size; the model (A, B, C) is shared (stride 0).
+    Everything stays on the device; the host only enqueues work.
+    """
+
+    def __init__(self, batch: int, strides=None, foot_size=None, index=None, stride_index=None, support=None,
+                 state=None, com_height: float = 0.84, dsp_duration: float = 0.1, ssp_duration: float = 0.7,
+                 gravity: float = 9.81, init_support_foot_pos: float = 0.09, nb_timesteps: int = 16,
+                 sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None):
+        import torch
+
+        _capi.require_gpu()
+        dev, f64 = torch.device("cuda", torch.cuda.current_device()), torch.float64
+        T, N = float(sampling_period), int(nb_timesteps)
+        self.nb_timesteps, self.sampling_period, self.substeps = N, T, int(substeps)
+        self.nb_dsp, self.nb_ssp = int(round(dsp_duration / T)), int(round(ssp_duration / T))
+        if 2 * (self.nb_dsp + self.nb_ssp) < N:  # PhaseStepper.__init__, :107-110
+            from .exceptions import ProblemDefinitionError
+
+            raise ProblemDefinitionError("there are more than two steps in the receding horizon")
+        self.omega = float(np.sqrt(gravity / com_height))
+
+        def dev_t(v, default, dtype, shape):
+            a = np.broadcast_to(np.asarray(default if v is None else v), shape)
+            return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+
+        self.strides = dev_t(strides, (-0.18, 0.18), f64, (batch, 2))
+        self.foot_size = dev_t(foot_size, 0.065, f64, (batch,))
+        self.index = dev_t(index, 5, torch.int64, (batch,))  # initial index of the reference, :117
+        self.stride_index = dev_t(stride_index, 0, torch.int64, (batch,))
+        self.support = dev_t(support, init_support_foot_pos, f64, (batch,))
+        if state is None:  # ZMP at the centre of the first foothold, DCM halfway (:300-302)
+            s0 = self.support
+            state = torch.stack([torch.zeros_like(s0), 0.5 * self.omega * s0, -self.omega**2 * s0], dim=1)
+        self.states = dev_t(state.cpu().numpy() if hasattr(state, "cpu") else state, None, f64, (batch, 3))
+        # build_mpc_problem (:59-101): shared LTI model, per-walker e / x0 / goal
+        A = np.array([[1.0, T, T**2 / 2.0], [0.0, 1.0, T], [0.0, 0.0, 1.0]])
+        Bm = np.array([T**3 / 6.0, T**2 / 2.0, T]).reshape((3, 1))
+        zmp = np.array([1.0, 0.0, -1.0 / self.omega**2])
+        self.zmp_from_state = torch.tensor(zmp, dtype=f64, device=dev)
+        Cm = np.array([+zmp, -zmp])
+        e0 = np.full((batch, N, 2), MAX_ZMP_DIST)
+        self.problem = BatchMPCProblem(A, Bm, Cm, None, e0, N, 1.0, None, 1e-3, np.zeros((batch, 3)),
+                                       goal_state=np.zeros((batch, 3)))
+        self.solver = PreparedSolve(self.problem, max_iter=max_iter)
+        self._k = torch.arange(N, device=dev)
+        self._problem_written = False  # e / goal / x0 of the CURRENT phase are in the problem buffers
+        self.mpc_steps = 0
+        self.failed = torch.zeros((), dtype=torch.int64, device=dev)
+        self.iters_total = torch.zeros((), dtype=torch.int64, device=dev)
+
+    # -- PhaseStepper.get_nb_steps (:134-165), vectorised over the batch ---------------------------
+    def _segment_counts(self):
+        import torch
+
+        nb_dsp, nb_ssp, N = self.nb_dsp, self.nb_ssp, self.nb_timesteps
+        zero = torch.zeros_like(self.index)
+        offset = self.index
+        init_dsp = torch.clamp(nb_dsp - offset, min=0)
+        offset = torch.clamp(offset - nb_dsp, min=0)
+        init_ssp = torch.clamp(nb_ssp - offset, min=0)
+        remaining = N - init_dsp - init_ssp
+        next_dsp = torch.clamp(remaining, max=nb_dsp)
+        remaining = torch.maximum(zero, remaining - nb_dsp)
+        next_ssp = torch.clamp(remaining, max=nb_ssp)
+        remaining = torch.maximum(zero, remaining - nb_ssp)
+        last_dsp = torch.clamp(remaining, max=nb_dsp)
+        remaining = torch.maximum(zero, remaining - nb_dsp)
+        last_ssp = torch.clamp(remaining, max=nb_ssp)
+        return torch.stack([init_dsp, init_ssp, next_dsp, next_ssp, last_dsp, last_ssp], dim=1)
+
+    def _foot_positions(self):
+        nxt = self.support + self.strides.gather(1, self.stride_index[:, None])[:, 0]  # get_next_foot_pos
+        last = nxt + self.strides.gather(1, ((self.stride_index + 1) % 2)[:, None])[:, 0]  # get_last_foot_pos
+        return nxt, last
+
+    def _write_goal_and_constraints(self) -> None:
+        """update_goal_and_constraints (:179-213) for every walker, in place."""
+        import torch
+
+        counts = self._segment_counts()  # [B, 6]
+        nxt, last = self._foot_positions()
+        half = 0.5 * self.foot_size
+        free = torch.full_like(self.support, MAX_ZMP_DIST)
+        upper = torch.stack([free, self.support + half, free, nxt + half, free, last + half], dim=1)
+        lower = torch.stack([free, -(self.support - half), free, -(nxt - half), free, -(last - half)], dim=1)
+        ends = torch.cumsum(counts, dim=1)  # step k lies in segment #(ends <= k)
+        seg = (self._k[None, :, None] >= ends[:, None, :]).sum(dim=2).clamp(max=5)  # [B, N]
+        e = self.problem.e.view(-1, self.nb_timesteps, 2)
+        e[:, :, 0] = upper.gather(1, seg)
+        e[:, :, 1] = lower.gather(1, seg)
+        goal = self.problem.goal_state
+        goal.zero_()
+        goal[:, 0] = torch.where(counts[:, 4] > 0, last, nxt)
+        self.problem.initial_state.copy_(self.states)
+
+    def _integrate(self, jerk):
+        """Constant-jerk plant (:216-236), ``substeps`` exact sub-steps like the example (:311-312)."""
+        import torch
+
+        dt = self.sampling_period / self.substeps
+        p, v, a = self.states[:, 0], self.states[:, 1], self.states[:, 2]
+        for _ in range(self.substeps):
+            p, v, a = (p + dt * (v + dt * (a / 2 + dt * jerk / 6)), v + dt * (a + dt * (jerk / 2)), a + dt * jerk)
+        self.states = torch.stack([p, v, a], dim=1)
+
+    def _advance_phase(self) -> None:
+        """phase.advance(); on wrap-around the swing foot becomes the support foot (:329-332)."""
+        import torch
+
+        nxt, _ = self._foot_positions()
+        index = self.index + 1
+        index = torch.where(index >= self.nb_dsp + self.nb_ssp, torch.zeros_like(index), index)
+        wrapped = index == 0
+        self.support = torch.where(wrapped, nxt, self.support)
+        self.stride_index = torch.where(wrapped, (self.stride_index + 1) % 2, self.stride_index)
+        self.index = index
+
+    def _advance_fused(self, first: bool) -> None:
+        """One launch of ``mpcqp_lipm_advance_batch``: plant + phase + next problem (or, for the very
+        first period, only the problem of the current phase)."""
+        p = self.problem
+        rc = _capi.load().mpcqp_lipm_advance_batch(
+            _dtype_code(p.dtype), self.states.data_ptr(), None if first else self.solver.U.data_ptr(), p.nb_variables,
+            None if first else self.solver.status.data_ptr(), self.nb_timesteps, self.sampling_period, self.substeps,
+            self.nb_dsp, self.nb_ssp, MAX_ZMP_DIST, self.index.data_ptr(), self.stride_index.data_ptr(),
+            self.support.data_ptr(), self.strides.data_ptr(), self.foot_size.data_ptr(), p.initial_state.data_ptr(),
+            p.goal_state.data_ptr(), p.e.data_ptr(), p.batch_size, _stream_ptr())
+        _capi.check(rc, "mpcqp_lipm_advance_batch")
+
+    def step(self, nb_mpc_steps: int = 1, fused: bool = True):
+        """Advance every walker by ``nb_mpc_steps`` MPC periods: per period one solver launch and one
+        fused plant + phase + next-problem launch. ``fused=False`` does the same bookkeeping with torch
+        ops (dozens of small launches; kept as a cross-check of the kernel). Asynchronous."""
+        import torch
+
+        for _ in range(nb_mpc_steps):
+            if fused:
+                if not self._problem_written:
+                    self._advance_fused(first=True)
+                self.solver.launch()
+                self._advance_fused(first=False)
+                self._problem_written = True
+                self.failed += (self.solver.status != 0).sum()
+            else:
+                self._problem_written = False
+                self._write_goal_and_constraints()
+                self.solver.launch()
+                ok = self.solver.status == 0
+                jerk = torch.where(ok, self.solver.U[:, 0], torch.zeros_like(self.solver.U[:, 0]))
+                self._integrate(jerk)
+                self._advance_phase()
+                self.failed += (~ok).sum()
+            self.iters_total += self.solver.iters.sum()
+            self.mpc_steps += 1
+        return self.states
+
+    def zmp(self):
+        """Current ZMP of every walker (``zmp_from_state``, :53-55)."""
+        return self.states @ self.zmp_from_state
+
+    def stats(self) -> Dict[str, float]:
+        B = self.problem.batch_size
+        solves = max(self.mpc_steps * B, 1)
+        return {"loops": B, "mpc_steps": self.mpc_steps, "builds_and_solves": self.mpc_steps * B,
+                "failed": int(self.failed.item()), "mean_iters": float(self.iters_total.item()) / solves}

@@ -115,6 +115,10 @@ __host__ __device__ inline ModelLayout make_model_layout(int nx, int N, int n, i
 int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
                        double Tp, double vel, double length, double gravity, int nsub, void *x0, void *goal,
                        void *targets, int64_t batch, hipStream_t st);
+int launch_lipm_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
+                        double Tp, int nsub, int nb_dsp, int nb_ssp, double max_zmp, int64_t *index,
+                        int64_t *stride_index, void *support, const void *strides, const void *foot_size, void *x0,
+                        void *goal, void *e, int64_t batch, hipStream_t st);
 int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
                         void *model, hipStream_t st);
 

@@ -172,6 +172,105 @@ int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride,
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- LIPM walking loop, one period
+// examples/lipm_walking_controller.py:304-333 for `batch` walkers, one thread each: integrate the first
+// jerk of the plan exactly for nsub sub-steps (:216-236), advance the footstep phase (:125-132, :329-332),
+// then write the next problem: x0, goal and the per-step ZMP bounds e [N, 2] of the receding horizon
+// (PhaseStepper.get_nb_steps :134-165 + update_goal_and_constraints :179-213).
+template <typename T>
+__global__ void __launch_bounds__(256) mpcqp_lipm_advance_kernel(
+    T *__restrict__ states, const T *__restrict__ U, int64_t u_stride, const int32_t *__restrict__ status, int N, T Tp,
+    int nsub, int nb_dsp, int nb_ssp, T max_zmp, int64_t *__restrict__ index, int64_t *__restrict__ stride_index,
+    T *__restrict__ support, const T *__restrict__ strides, const T *__restrict__ foot_size, T *__restrict__ x0,
+    T *__restrict__ goal, T *__restrict__ e, int64_t batch)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    T p = states[b * 3 + 0], v = states[b * 3 + 1], a = states[b * 3 + 2];
+    int idx = (int)index[b], sidx = (int)stride_index[b];
+    T cur = support[b];
+    const T s0 = strides[b * 2 + 0], s1 = strides[b * 2 + 1];
+    if (U) {
+        const T jerk = (status && status[b] != 0) ? T(0) : U[b * u_stride];
+        const T dt = Tp / (T)nsub;
+        for (int i = 0; i < nsub; ++i) {
+            const T p2 = p + dt * (v + dt * (a / 2 + dt * jerk / 6));
+            const T v2 = v + dt * (a + dt * (jerk / 2));
+            a = a + dt * jerk;
+            p = p2;
+            v = v2;
+        }
+        idx += 1;
+        if (idx >= nb_dsp + nb_ssp) idx = 0;
+        if (idx == 0) {  // the swing foot lands: it becomes the support foot
+            cur = cur + (sidx == 0 ? s0 : s1);
+            sidx = (sidx + 1) % 2;
+        }
+        states[b * 3 + 0] = p;
+        states[b * 3 + 1] = v;
+        states[b * 3 + 2] = a;
+        index[b] = idx;
+        stride_index[b] = sidx;
+        support[b] = cur;
+    }
+    x0[b * 3 + 0] = p;
+    x0[b * 3 + 1] = v;
+    x0[b * 3 + 2] = a;
+    // segments of the horizon
+    int offset = idx;
+    const int init_dsp = max(0, nb_dsp - offset);
+    offset = max(0, offset - nb_dsp);
+    const int init_ssp = max(0, nb_ssp - offset);
+    int remaining = N - init_dsp - init_ssp;
+    const int next_dsp = min(nb_dsp, remaining);
+    remaining = max(0, remaining - nb_dsp);
+    const int next_ssp = min(nb_ssp, remaining);
+    remaining = max(0, remaining - nb_ssp);
+    const int last_dsp = min(nb_dsp, remaining);
+    const T nxt = cur + (sidx == 0 ? s0 : s1);
+    const T last = nxt + (sidx == 0 ? s1 : s0);
+    const T half = T(0.5) * foot_size[b];
+    const int e1 = init_dsp, e2 = e1 + init_ssp, e3 = e2 + next_dsp, e4 = e3 + next_ssp, e5 = e4 + last_dsp;
+    T *eb = e + b * (int64_t)N * 2;
+    for (int k = 0; k < N; ++k) {
+        T hi = max_zmp, lo = max_zmp;
+        if (k >= e1 && k < e2) {
+            hi = cur + half;
+            lo = -(cur - half);
+        } else if (k >= e3 && k < e4) {
+            hi = nxt + half;
+            lo = -(nxt - half);
+        } else if (k >= e5) {
+            hi = last + half;
+            lo = -(last - half);
+        }
+        eb[2 * k] = hi;
+        eb[2 * k + 1] = lo;
+    }
+    goal[b * 3 + 0] = last_dsp > 0 ? last : nxt;
+    goal[b * 3 + 1] = T(0);
+    goal[b * 3 + 2] = T(0);
+}
+
+int launch_lipm_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
+                        double Tp, int nsub, int nb_dsp, int nb_ssp, double max_zmp, int64_t *index,
+                        int64_t *stride_index, void *support, const void *strides, const void *foot_size, void *x0,
+                        void *goal, void *e, int64_t batch, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((batch + 255) / 256);
+    if (dtype == MPCQP_F64)
+        hipLaunchKernelGGL(mpcqp_lipm_advance_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)states,
+                           (const double *)U, u_stride, status, N, Tp, nsub, nb_dsp, nb_ssp, max_zmp, index,
+                           stride_index, (double *)support, (const double *)strides, (const double *)foot_size,
+                           (double *)x0, (double *)goal, (double *)e, batch);
+    else
+        hipLaunchKernelGGL(mpcqp_lipm_advance_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)states,
+                           (const float *)U, u_stride, status, N, (float)Tp, nsub, nb_dsp, nb_ssp, (float)max_zmp,
+                           index, stride_index, (float *)support, (const float *)strides, (const float *)foot_size,
+                           (float *)x0, (float *)goal, (float *)e, batch);
+    return (int)hipGetLastError();
+}
+
 int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
                         void *model, hipStream_t st)
 {

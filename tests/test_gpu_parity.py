@@ -624,3 +624,56 @@ def test_large_path_structured_ltv_with_state_and_input_constraints(dtype, tol, 
         assert np.array_equal(other.status.cpu().numpy(), st), env
         Ub = other.U.double().cpu().numpy()
         assert (np.abs(Ub[ok] - U[ok]) / scale).max() <= 2 * tol, env
+
+
+# ---------------------------------------------------------------- LIPM walking loop
+def test_lipm_walking_loop_matches_cpu_oracle_loop():
+    """Batched device loop (per-step e_k lists rebuilt from each walker's footstep phase, goal updates,
+    exact jerk plant) against the restated reference loop on the CPU with the oracle solver. Walker 0
+    has the reference example's parameters; the others vary strides, foot size, phase and support."""
+    from oracle import lipm_np as L
+
+    from qpmpc_amd.closed_loop import LIPMWalkingLoop
+
+    rng = np.random.default_rng(9)
+    B, steps = 40, 30
+    strides = np.stack([-rng.uniform(0.12, 0.2, B), rng.uniform(0.12, 0.2, B)], axis=1)
+    foot = rng.uniform(0.05, 0.08, B)
+    index = rng.integers(0, 8, B)
+    sidx = rng.integers(0, 2, B)
+    support = np.where(sidx == 0, 1.0, -1.0) * rng.uniform(0.07, 0.11, B)  # next stride moves to the other side
+    strides[0], foot[0], index[0], sidx[0], support[0] = (-0.18, 0.18), 0.065, 5, 0, 0.09
+    loop = LIPMWalkingLoop(B, strides=strides, foot_size=foot, index=index, stride_index=sidx, support=support)
+    # step 0 of walker 0 is the first row of the reference fixture
+    loop._write_goal_and_constraints()
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "lipm_schedule.npz"))
+    assert np.array_equal(loop.problem.e[0].cpu().numpy(), d["e"][0])
+    assert np.array_equal(loop.problem.goal_state[0].cpu().numpy(), d["goal"][0])
+    X = [loop.states.cpu().numpy().copy()]
+    for _ in range(steps):
+        loop.step()  # fused: one solver launch + one mpcqp_lipm_advance_batch launch per period
+        X.append(loop.states.cpu().numpy().copy())
+    X = np.stack(X, axis=1)  # [B, steps+1, 3]
+    st = loop.stats()
+    assert st["failed"] == 0 and st["builds_and_solves"] == B * steps
+    # the same bookkeeping done with torch ops instead of the fused kernel
+    ref = LIPMWalkingLoop(B, strides=strides, foot_size=foot, index=index, stride_index=sidx, support=support)
+    ref.step(steps, fused=False)
+    assert np.abs(ref.states.cpu().numpy() - X[:, -1]).max() <= 1e-12
+    assert torch.equal(ref.index, loop.index) and torch.equal(ref.stride_index, loop.stride_index)
+    assert torch.equal(ref.support, loop.support)
+
+    def solve(problem):
+        U, s, _ = oracle.solve_mpc_like_reference(problem)
+        return None if s != 0 else U[:, 0]
+
+    for b in range(B):
+        p = L.parameters(strides=tuple(strides[b]), foot_size=float(foot[b]))
+        w = L.new_walker(p, index=int(index[b]), stride_index=int(sidx[b]), support=float(support[b]))
+        x0 = np.array([0.0, 0.5 * p["omega"] * support[b], -p["omega"] ** 2 * support[b]])
+        Xo, _, So = L.closed_loop(p, w, x0, steps, solve=solve)
+        assert (So == 0).all()
+        assert np.abs(X[b] - Xo).max() <= 1e-7, (b, np.abs(X[b] - Xo).max())
+    # phase bookkeeping of walker 0 after 30 periods equals the reference's
+    assert int(loop.index[0]) == int(d["index"][steps]) and int(loop.stride_index[0]) == int(d["stride_index"][steps])
+    assert float(loop.support[0]) == float(d["support_pos"][steps])

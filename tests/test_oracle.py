@@ -114,3 +114,46 @@ def test_infeasible_and_not_pd_statuses():
     assert st == 2
     x, lam, st, _ = oracle.gi_solve(np.array([[1.0, 2.0], [2.0, 1.0]]), np.zeros(2), np.zeros((0, 2)), np.zeros(0))
     assert st == 3
+
+
+# ---------------------------------------------------------------- LIPM walking loop
+def test_lipm_schedule_restatement_matches_reference_fixture_bitwise():
+    """oracle/lipm_np.py against the schedule captured from the reference example's own PhaseStepper /
+    update_goal_and_constraints / integrate (tools/gen_golden_lipm.py): 80 consecutive MPC steps."""
+    import os
+
+    from oracle import lipm_np as L
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "lipm_schedule.npz"))
+    p = L.parameters()
+    assert p["omega"] == float(d["omega"])
+    assert np.array_equal(p["zmp_from_state"], d["zmp_from_state"]) and np.array_equal(p["dcm_from_state"], d["dcm_from_state"])
+    A, B, C = L.model(p)
+    assert np.array_equal(A, d["A"]) and np.array_equal(B, d["B"]) and np.array_equal(C, d["C"])
+    assert np.array_equal(L.initial_state(p), d["init_state"])
+    w = L.new_walker(p, index=int(d["initial_index"]))
+    for s in range(d["e"].shape[0]):
+        e, goal = L.goal_and_constraints(p, w)
+        assert np.array_equal(e, d["e"][s]) and np.array_equal(goal, d["goal"][s]), s
+        assert (w["index"], w["stride_index"], w["support"]) == (d["index"][s], d["stride_index"][s], d["support_pos"][s])
+        L.advance(p, w)
+    nxt = np.stack([L.integrate(d["plant_state"][i], d["plant_jerk"][i], d["plant_dt"][i]) for i in range(32)])
+    assert np.array_equal(nxt, d["plant_next"])
+
+
+def test_lipm_oracle_loop_walks():
+    """The restated loop with the CPU oracle solver: every QP solvable, the CoM follows the footsteps
+    and the ZMP stays inside the support foot during single support."""
+    from oracle import lipm_np as L
+
+    p = L.parameters()
+    w = L.new_walker(p)
+
+    def solve(problem):
+        U, st, _ = oracle.solve_mpc_like_reference(problem)
+        return None if st != 0 else U[:, 0]
+
+    X, U0, S = L.closed_loop(p, w, L.initial_state(p), 40, solve=solve)
+    assert (S == 0).all()
+    assert np.abs(X[:, 0]).max() < 0.2  # the CoM sways between footholds at +-0.09
+    assert np.ptp(X[:, 0]) > 0.05
