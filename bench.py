@@ -171,6 +171,30 @@ def main() -> None:
         Uo, _, sto, _ = oracle.solve_workload(w)
         ok = sto == 0
         err = np.abs(U[ok] - Uo[ok])
+        # KKT residuals of the kernel's own (u, lambda) on a sample, against the oracle-built QP
+        from qpmpc_amd import MPCProblem
+
+        chk = PreparedSolve(bp, return_multipliers=True)
+        chk.launch()
+        torch.cuda.synchronize()
+        lam = chk.lam.cpu().numpy()
+        kkt = {"stationarity": 0.0, "primal": 0.0, "complementarity": 0.0, "dual": 0.0}
+        for b in range(0, args.batch, max(1, args.batch // 128)):
+            if not ok[b]:
+                continue
+            p = MPCProblem(
+                [w["A"][b, k] for k in range(w["N"])] if not args.shared_lti else w["A"],
+                [w["B"][b, k] for k in range(w["N"])] if not args.shared_lti else w["B"],
+                [w["C"][b, k] for k in range(w["N"])] if not args.shared_lti else w["C"], None,
+                [w["e"][b, k] for k in range(w["N"])] if not args.shared_lti else w["e"],
+                w["N"], w["wt"], w["wx"], w["wu"], initial_state=w["x0"][b], goal_state=w["goal"][b])
+            cq = oracle.condense(p)
+            ub, lb = U[b], lam[b]
+            slack = cq.h - cq.G @ ub
+            kkt["stationarity"] = max(kkt["stationarity"], float(np.abs(cq.P @ ub + cq.q + cq.G.T @ lb).max()))
+            kkt["primal"] = max(kkt["primal"], float(np.maximum(-slack, 0.0).max()))
+            kkt["dual"] = max(kkt["dual"], float(np.maximum(-lb, 0.0).max()))
+            kkt["complementarity"] = max(kkt["complementarity"], float(np.abs(lb * slack).max()))
         nx, nu, N, mk = 3, 1, 16, 2
         n, m = N * nu, N * mk
         bytes_per_problem = W.algorithmic_bytes_per_problem(w)
@@ -220,6 +244,8 @@ def main() -> None:
             },
             "accuracy": {
                 "max_abs_err_vs_oracle": float(err.max()),
+                "p99_abs_err_vs_oracle": float(np.quantile(err.max(axis=1), 0.99)),
+                "max_kkt_residuals_sample": kkt,
                 "max_rel_err_vs_oracle": float((err / np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))).max()),
                 "solved_frac": float(solved.item()) / (args.batch * world),
                 "mean_iters": mean_iters,
