@@ -24,8 +24,8 @@ constexpr int KC = 16;     // rows of Psi staged per Gram step
 using namespace big;
 
 // ------------------------------------------------------------------ propagate
-// One workgroup per problem, thread c < n owns column c of Psi, thread n the free
-// response Phi_k x0. A_k, B_k, C_k, D_k of the current step are staged in LDS and read
+// One workgroup per problem, thread c < n <= 256 owns column c of Psi; the last wavefront carries the
+// free response Phi_k x0 (in LDS), h and the tracking residuals. A_k, B_k, C_k, D_k of the current step are staged in LDS and read
 // as broadcast.
 // Outputs (per problem): Psi_all [(N+1)*nx, n] (block 0 is zero), resid [(N+1)*nx] =
 // Phi_k x0 - ref_k, h [m], and optionally G [m, n] and the inverse row norms 1/|G_i| [m].
@@ -57,17 +57,27 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
     T *G = oG ? oG + prob * (int64_t)m * n : nullptr;
     T *h = oh + prob * (int64_t)m;
     T *nrm = NRM ? onrm + prob * (int64_t)m : nullptr;
-    const bool isx = (tid == n), col = (tid < n);
+    const bool col = (tid < n);
     const int j = col ? tid / nu : -1, ii = col ? tid - j * nu : 0;
     const bool qs = (ka.flags & MPCQP_Q_STAGE) && gtgt, qt = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+    // first step at which some column of this wavefront is non-zero (uniform): before it the
+    // wavefront only stores zeros (causality, mpc_qp.py:80-90)
+    const int jfirst = __builtin_amdgcn_readfirstlane(min((tid & ~63) / nu, N));
+    // the free response Phi_k x0 lives in LDS (double-buffered) and is advanced by the last wavefront,
+    // one lane per row, so that no single lane carries a serial chain of mk + nx dot products
+    T *xs = Ys + nC;
+    const int l4 = tid - 256;  // lane of the last wavefront (threads 256..319)
 
     if constexpr (NRM)
         for (int e2 = tid; e2 < nA; e2 += 320) Ss[e2] = T(0);
+    if (l4 >= 0 && l4 < nx) xs[l4] = gx0[l4];
 
     T v[NXMAX];
 #pragma unroll
-    for (int s = 0; s < NXMAX; ++s) v[s] = (isx && s < nx) ? gx0[s] : T(0);
+    for (int s = 0; s < NXMAX; ++s) v[s] = T(0);
     for (int k = 0; k <= N; ++k) {
+        const T *xc = xs + (k & 1) * nx;
+        T *xn = xs + ((k + 1) & 1) * nx;
         __syncthreads();
         if (k < N) {  // stage the operands of step k (coalesced)
             for (int i = tid; i < nA; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
@@ -79,62 +89,69 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
             for (int i = tid; i < mk; i += blockDim.x) es[i] = ge[k * ka.e.step_stride + i];
         }
         __syncthreads();
-        // v = Psi_k[:, c] (thread n: Phi_k x0)
+        // v = Psi_k[:, c]
         if (col) {
 #pragma unroll
             for (int s = 0; s < NXMAX; ++s)
                 if (s < nx) Psi[((int64_t)k * nx + s) * n + tid] = v[s];
-        } else if (isx) {
-#pragma unroll
-            for (int s = 0; s < NXMAX; ++s)
-                if (s < nx) {
-                    T ref = T(0);
-                    if (k < N) {
-                        if (qs) ref = gtgt[k * nx + s];
-                    } else if (qt) {
-                        ref = ggoal[s];
-                    }
-                    res[k * nx + s] = v[s] - ref;
-                }
+        } else if (l4 >= 0 && l4 < nx) {
+            T ref = T(0);
+            if (k < N) {
+                if (qs) ref = gtgt[k * nx + l4];
+            } else if (qt) {
+                ref = ggoal[l4];
+            }
+            res[k * nx + l4] = xc[l4] - ref;
         }
         if (k == N) break;
-        if (col || isx) {
-            // rows of G / h for step k (mpc_qp.py:62-78)
-            if (isx || G) {
+        if (col) {
+            // rows of G for step k (mpc_qp.py:62-78)
+            if (G) {
                 for (int i2 = 0; i2 < mk; ++i2) {
                     T acc = T(0);
-                    if (gC) {
+                    if (gC && k > jfirst) {
 #pragma unroll
                         for (int s = 0; s < NXMAX; ++s)
                             if (s < nx) acc += Cs[i2 * nx + s] * v[s];
                     }
-                    if (col) {
-                        if (gD && j == k) acc += Ds[i2 * nu + ii];
-                        G[((int64_t)k * mk + i2) * n + tid] = acc;
-                    } else {
-                        h[k * mk + i2] = es[i2] - acc;
+                    if (gD && j == k) acc += Ds[i2 * nu + ii];
+                    G[((int64_t)k * mk + i2) * n + tid] = acc;
+                }
+            }
+            if (k >= jfirst) {
+                // advance (mpc_qp.py:88-90)
+                T w[NXMAX];
+#pragma unroll
+                for (int r = 0; r < NXMAX; ++r) {
+                    T acc = T(0);
+                    if (r < nx) {
+#pragma unroll
+                        for (int s = 0; s < NXMAX; ++s)
+                            if (s < nx) acc += As[r * nx + s] * v[s];
                     }
+                    w[r] = acc;
                 }
-            }
-            // advance (mpc_qp.py:88-90)
-            T w[NXMAX];
+                if (j == k) {
 #pragma unroll
-            for (int r = 0; r < NXMAX; ++r) {
+                    for (int r = 0; r < NXMAX; ++r)
+                        if (r < nx) w[r] = Bs[r * nu + ii];
+                }
+#pragma unroll
+                for (int r = 0; r < NXMAX; ++r) v[r] = w[r];
+            }
+        } else if (l4 >= 0) {
+            // h rows (mpc_qp.py:74-78) and the free response, one lane per row
+            for (int i2 = l4; i2 < mk; i2 += 64) {
                 T acc = T(0);
-                if (r < nx) {
-#pragma unroll
-                    for (int s = 0; s < NXMAX; ++s)
-                        if (s < nx) acc += As[r * nx + s] * v[s];
-                }
-                w[r] = acc;
+                if (gC)
+                    for (int s = 0; s < nx; ++s) acc += Cs[i2 * nx + s] * xc[s];
+                h[k * mk + i2] = es[i2] - acc;
             }
-            if (col && j == k) {
-#pragma unroll
-                for (int r = 0; r < NXMAX; ++r)
-                    if (r < nx) w[r] = Bs[r * nu + ii];
+            if (l4 < nx) {
+                T acc = T(0);
+                for (int s = 0; s < nx; ++s) acc += As[l4 * nx + s] * xc[s];
+                xn[l4] = acc;
             }
-#pragma unroll
-            for (int r = 0; r < NXMAX; ++r) v[r] = w[r];
         }
         if constexpr (NRM) {
             // inverse row norms of step k: Y = C S_k and T1 = A S_k now, the row-wise dots and
@@ -319,14 +336,14 @@ __global__ void __launch_bounds__(256) mpcqp_gram_valu_kernel(const KernelArgs k
 // Psi_all and the residual vector.
 size_t big_condense_ws_elems(const KernelArgs &ka) { return (size_t)(ka.N + 1) * ka.nx * (ka.n + 1); }
 
-bool big_supported(const KernelArgs &ka) { return ka.nx <= NXMAX && ka.n + 1 <= 320; }
+bool big_supported(const KernelArgs &ka) { return ka.nx <= NXMAX && ka.n <= 256; }
 
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
                         void *G, void *h, void *rownorm_inv, hipStream_t st)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
     const size_t lds =
-        (size_t)(3 * ka.nx * ka.nx + ka.nx * ka.nu + 2 * ka.mk * ka.nx + ka.mk * ka.nu + ka.mk) * esz;
+        (size_t)(3 * ka.nx * ka.nx + ka.nx * ka.nu + 2 * ka.mk * ka.nx + ka.mk * ka.nu + ka.mk + 2 * ka.nx) * esz;
 #define PROPAGATE(TY, NRMV)                                                                                     \
     hipLaunchKernelGGL((mpcqp_propagate_kernel<TY, NRMV>), dim3((unsigned)batch), dim3(320), lds, st, ka,       \
                        (TY *)Psi_ws, (TY *)res_ws, (TY *)G, (TY *)h, (TY *)rownorm_inv)
