@@ -677,3 +677,32 @@ def test_lipm_walking_loop_matches_cpu_oracle_loop():
     # phase bookkeeping of walker 0 after 30 periods equals the reference's
     assert int(loop.index[0]) == int(d["index"][steps]) and int(loop.stride_index[0]) == int(d["stride_index"][steps])
     assert float(loop.support[0]) == float(d["support_pos"][steps])
+
+
+@pytest.mark.parametrize("batch", [1, 3, 63, 65, 4097])
+def test_batch_size_edges_wavefront_kernel(batch):
+    """Batch sizes around the launch granularities (one wavefront per problem, 64-thread blocks)."""
+    from qpmpc_amd.workloads import triple_integrator_batch
+
+    w = triple_integrator_batch(batch, seed=batch)
+    plan, U, status, Uo, sto, err = _check_batch(w)
+    assert (status == 0).all() and err <= 1e-8
+
+
+def test_large_batch_sweep_shared_operands():
+    """262,144 problems in one launch (config-4 family, stride-0 operands): every item equals the
+    item of a 4096-batch with the same state (no cross-talk, no grid-size limit)."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
+
+    small = humanoid_batch(4096)
+    big = dict(small)
+    reps = 64
+    big["x0"] = np.tile(small["x0"], (reps, 1))
+    a = solve_mpc_batch(to_batch_problem(small))
+    b = solve_mpc_batch(to_batch_problem(big))
+    torch.cuda.synchronize()
+    Ua, Ub = a.U.cpu().numpy(), b.U.cpu().numpy().reshape(reps, 4096, -1)
+    sa, sb = a.status.cpu().numpy(), b.status.cpu().numpy().reshape(reps, 4096)
+    assert (sb == sa[None]).all()
+    assert np.array_equal(Ub, np.broadcast_to(Ua[None], Ub.shape))  # same kernel, same data -> bitwise
