@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
@@ -70,6 +71,33 @@ template <typename T> __device__ __forceinline__ void block_argmin(T &v, int &i,
             i = redi[w];
         }
 }
+// 1/sqrt(x) and 1/x from the hardware estimates plus Newton steps (full precision of T; the IEEE
+// sqrt + divide sequences are ~100 instructions each in float64 and sit on the factorisation's
+// critical path once per column)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+__device__ __forceinline__ float fast_rsqrt(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    return y * (1.5f - 0.5f * x * y * y);
+}
+__device__ __forceinline__ double fast_recip(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+__device__ __forceinline__ float fast_recip(float x)
+{
+    const float y = __builtin_amdgcn_rcpf(x);
+    return fmaf(y, fmaf(-x, y, 1.0f), y);
+}
 }  // namespace bigs
 using namespace bigs;
 
@@ -110,7 +138,7 @@ template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li
                 notpd = true;
                 break;
             }
-            const T rinv = T(1) / sqrt(piv);
+            const T rinv = fast_rsqrt(piv);
             if (i >= j && i < n) Li[tri(i, 0) + j] = (i == j) ? piv * rinv : v * rinv;
             __syncthreads();
         }
@@ -125,7 +153,7 @@ template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li
             int rowi = 0;
             for (int i = 0; i < n; rowi += ++i) {
                 const T *ri = Li + rowi;
-                const T dinv = T(1) / ri[i];
+                const T dinv = fast_recip(ri[i]);
                 T x = T(0);
                 if (wbase < i) {
                     T a0 = T(0), a1 = T(0), a2 = T(0), a3 = T(0);
@@ -414,7 +442,18 @@ __device__ __forceinline__ double quad_sum(double v)
 //     the Gram kernel needed anyway;
 //   * 1/|G_i| comes from the propagation kernel (aux2).
 // aux = G' (dense mode) or Psi_all (structured mode).
-template <typename T, bool STRUCT>
+//
+// KIND = K_MID: mid-size problems (n up to ~128, BASELINE config 3: n = 50, m = 100, N = 50), fused
+// build + solve in ONE launch with a small LDS footprint (several problems per CU):
+//   * the problem's operands A, B, C, D are staged into LDS once (a few KB);
+//   * front end: Psi_k (nx x n, two LDS buffers) is propagated step by step and CONSUMED on the fly --
+//     P += w_k Psi_k' Psi_k straight into the packed triangle, q += w_k Psi_k' resid_k, h_k, and the row
+//     norms from S_k = Psi_k Psi_k' -- so neither Psi (N nx n) nor G (m n) nor M = G L^-T ever exists;
+//   * the same solver as above, G applied through the roll-out (operands from LDS), a selected row
+//     G_p = C_k[r] Psi_k + D_k[r] E_k rebuilt by the adjoint recursion mu' <- mu' A_j, g_j = B_j' mu.
+enum { K_DENSE = 0, K_STRUCT = 1, K_MID = 2 };
+
+template <typename T, int KIND>
 __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
                                                             const T *__restrict__ qall, const T *__restrict__ Gall,
                                                             const T *__restrict__ aux, const T *__restrict__ hall,
@@ -425,6 +464,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     const int64_t prob = blockIdx.x;
     const T INF = (T)HUGE_VALF;
     typedef T V4 __attribute__((ext_vector_type(4)));
+    constexpr bool STRUCT = (KIND == K_STRUCT), MID = (KIND == K_MID), MFREE = (KIND != K_DENSE);
     // LDS carve
     T *Li = (T *)smem_raw;              // packed lower triangle: P -> L -> L^-1
     T *sv = Li + n * (n + 1) / 2;       // slacks            [m]
@@ -439,21 +479,31 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     T *tmp = lam + n;                   // scratch            [n]
     T *red = tmp + n;                   // reductions         [8]
     T *dxs = red + 8;                   // roll-out states [N][nx] (structured mode only)
-    int *act = (int *)(dxs + (STRUCT ? ka.N * ka.nx : 0));  // constraint of slot [n]
+    // mid-size kind: the operands of every step, two Psi_k buffers, small front-end vectors
+    const int sAk = MID ? (ka.A.step_stride ? ka.nx * ka.nx : 0) : 0, sBk = MID ? (ka.B.step_stride ? ka.nx * ka.nu : 0) : 0;
+    const int sCk = MID ? (ka.C.step_stride ? ka.mk * ka.nx : 0) : 0, sDk = MID ? (ka.D.step_stride ? ka.mk * ka.nu : 0) : 0;
+    T *opA = dxs + (MFREE ? ka.N * ka.nx : 0);
+    T *opB = opA + (MID ? (sAk ? ka.N : 1) * ka.nx * ka.nx : 0);
+    T *opC = opB + (MID ? (sBk ? ka.N : 1) * ka.nx * ka.nu : 0);
+    T *opD = opC + ((MID && ka.C.ptr) ? (sCk ? ka.N : 1) * ka.mk * ka.nx : 0);
+    T *psiA = opD + ((MID && ka.D.ptr) ? (sDk ? ka.N : 1) * ka.mk * ka.nu : 0);
+    T *psiB = psiA + (MID ? ka.nx * n : 0);
+    T *fe = psiB + (MID ? ka.nx * n : 0);  // phi [2 nx], resid [2 nx], S [2 nx nx], T1 [nx nx], mu [2 nx]
+    int *act = (int *)(fe + (MID ? 6 * ka.nx + 3 * ka.nx * ka.nx : 0));  // constraint of slot [n]
     int *pos = act + n;                 // slot of constraint, -1 [m]
     int *redi = pos + m;                // [4]
 
     const T *P = Pall + prob * (int64_t)n * n;
     const T *q = qall + prob * (int64_t)n;
-    const T *G = STRUCT ? nullptr : Gall + prob * (int64_t)m * n;
-    const T *GT = STRUCT ? nullptr : aux + prob * (int64_t)m * n;
-    const T *h = hall + prob * (int64_t)m;
+    const T *G = MFREE ? nullptr : Gall + prob * (int64_t)m * n;
+    const T *GT = MFREE ? nullptr : aux + prob * (int64_t)m * n;
+    const T *h = MID ? nullptr : hall + prob * (int64_t)m;
     // structured mode: the problem's own operands
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk;
-    const T *gA = STRUCT ? (const T *)ka.A.ptr + prob * ka.A.batch_stride : nullptr;
-    const T *gB = STRUCT ? (const T *)ka.B.ptr + prob * ka.B.batch_stride : nullptr;
-    const T *gC = (STRUCT && ka.C.ptr) ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
-    const T *gD = (STRUCT && ka.D.ptr) ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+    const T *gA = MFREE ? (const T *)ka.A.ptr + prob * ka.A.batch_stride : nullptr;
+    const T *gB = MFREE ? (const T *)ka.B.ptr + prob * ka.B.batch_stride : nullptr;
+    const T *gC = (MFREE && ka.C.ptr) ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
+    const T *gD = (MFREE && ka.D.ptr) ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
     const T *Psi = STRUCT ? aux + prob * (int64_t)(N + 1) * nx * n : nullptr;
     const T *nrm = STRUCT ? aux2 + prob * (int64_t)m : nullptr;
 
@@ -493,6 +543,24 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     };
     // dxs[k] = Psi_k zx for k < N: dx_{k+1} = A_k dx_k + B_k zx_k, the wavefronts taking turns
     auto rollout = [&]() __attribute__((always_inline)) {
+        if constexpr (MID) {
+            // operands in LDS: the first wavefront walks the horizon, lane r = row r of the state
+            if (tid < 64) {
+                if (tid < nx) dxs[tid] = T(0);
+                for (int k = 0; k < N - 1; ++k) {
+                    T acc = T(0);
+                    if (tid < nx) {
+                        const T *ar = opA + k * sAk + tid * nx, *br = opB + k * sBk + tid * nu;
+                        for (int sc = 0; sc < nx; ++sc) acc += ar[sc] * dxs[k * nx + sc];
+                        for (int u = 0; u < nu; ++u) acc += br[u] * zx[k * nu + u];
+                        dxs[(k + 1) * nx + tid] = acc;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+            __syncthreads();
+            return;
+        }
         const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
         if (tid < nx) dxs[tid] = T(0);
         for (int w = 0; w < 4; ++w) {
@@ -526,6 +594,20 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         for (int sc = 0; sc < 16; ++sc) acc += rc[j][sc] * dxs[k * nx + min(sc, nx - 1)];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += rd[j][u] * zx[k * nu + min(u, nu - 1)];
+        return acc;
+    };
+    // (G zx)_i with the operands in LDS (mid-size kind)
+    auto mid_row = [&](int i) __attribute__((always_inline)) -> T {
+        const int k = i / mk, r = i - k * mk;
+        T acc = T(0);
+        if (gC) {
+            const T *cr = opC + k * sCk + r * nx;
+            for (int sc = 0; sc < nx; ++sc) acc += cr[sc] * dxs[k * nx + sc];
+        }
+        if (gD) {
+            const T *dr = opD + k * sDk + r * nu;
+            for (int u = 0; u < nu; ++u) acc += dr[u] * zx[k * nu + u];
+        }
         return acc;
     };
     T *MA = wsall + prob * (int64_t)2 * n * n;
@@ -593,26 +675,225 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         return a0 + a1;
     };
 
-    // ---- packed lower triangle of P
-    if ((n & 3) == 0) {
-        // whole rows as 16-byte loads, sixteen in flight per thread. Branch-free so that the loads
-        // batch: groups above the diagonal re-read their row's diagonal group and store to a dump
-        // slot (the vectors after y0 are not in use yet; n >= 64 here, see bigsolve_supported).
-        const int nv = n * n / 4;
-        T *dump = y0 + tid;
-#pragma unroll 16
-        for (int v4 = tid; v4 < nv; v4 += BS) {
-            const int idx = 4 * v4, i = idx / n, j = idx - i * n;
-            const bool need = j <= i;
-            const V4 pv = *reinterpret_cast<const V4 *>(P + (need ? idx : i * n + (i & ~3)));
-            T *d = Li + tri(i, j);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) *((need && j + c <= i) ? d + c : dump) = pv[c];
+    if constexpr (MID) {
+        // ---------------------------------------------------------------- on-chip front end
+        const T wxp = (ka.flags & MPCQP_P_STAGE) ? (T)ka.wx : T(0), wtp = (ka.flags & MPCQP_P_TERMINAL) ? (T)ka.wt : T(0);
+        const T *gx0 = (const T *)ka.x0.ptr + prob * ka.x0.batch_stride;
+        const T *ggoal = ka.goal.ptr ? (const T *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+        const T *gtgt = ka.targets.ptr ? (const T *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+        const T *ge = (const T *)ka.e.ptr + prob * ka.e.batch_stride;
+        const bool qs = (ka.flags & MPCQP_Q_STAGE) && gtgt, qt = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+        const T wxq = qs ? (T)ka.wx : T(0), wtq = qt ? (T)ka.wt : T(0);
+        T *phi = fe, *resid = fe + 2 * nx, *Sm = resid + 2 * nx, *T1 = Sm + 2 * nx * nx;
+        // stage the operands (LTI operands once)
+        for (int i = tid; i < (sAk ? N : 1) * nx * nx; i += BS) opA[i] = gA[i];
+        for (int i = tid; i < (sBk ? N : 1) * nx * nu; i += BS) opB[i] = gB[i];
+        if (gC)
+            for (int i = tid; i < (sCk ? N : 1) * mk * nx; i += BS) opC[i] = gC[i];
+        if (gD)
+            for (int i = tid; i < (sDk ? N : 1) * mk * nu; i += BS) opD[i] = gD[i];
+        for (int i = tid; i < n * (n + 1) / 2; i += BS) Li[i] = T(0);
+        for (int i = tid; i < nx * n; i += BS) psiA[i] = T(0);
+        for (int i = tid; i < nx * nx; i += BS) Sm[i] = T(0);
+        // e and the reference trajectory go to LDS as well (no global load inside the step loop):
+        // e into tolv (turned into h in place), the targets into the roll-out table (free until the solve)
+        for (int i = tid; i < m; i += BS) tolv[i] = ge[(int64_t)(i / mk) * ka.e.step_stride + (i % mk)];
+        if (qs)
+            for (int i = tid; i < N * nx; i += BS) dxs[i] = gtgt[i];
+        T goal_l = T(0);  // goal entry of lane l of the last wavefront
+        if (qt && tid >= BS - 64 && tid - (BS - 64) < nx) goal_l = ggoal[tid - (BS - 64)];
+        if (tid < nx) {
+            const T x = gx0[tid];
+            phi[tid] = x;
+            resid[tid] = x - (qs ? gtgt[tid] : T(0));  // resid_0 (multiplies Psi_0 = 0)
         }
+        // entries of the packed triangle are shared out as (row i, every NC-th column from c)
+        const int NC = max(1, BS / n), pi = tid % n, pc = tid / n;
+        // ... or, when the lower triangle has at most BS tiles of 4 x 4 (n <= 88), as one register tile each
+        const int T4 = (n + 3) / 4;
+        const bool tiled = T4 * (T4 + 1) / 2 <= BS;
+        int ti = 0, tj = 0;
+        {
+            int rem = tid;
+            while (rem > ti) {  // tile number tid -> (ti, tj), tj <= ti
+                rem -= ti + 1;
+                ++ti;
+            }
+            tj = rem;
+        }
+        const bool tlive = tiled && ti < T4;
+        T pacc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v2 = 0; v2 < 4; ++v2) pacc[u][v2] = T(0);
+        T qacc = T(0);
+        const int tq = (2 * n <= BS) ? tid - BS / 2 : tid;          // column of q this thread accumulates
+        const int th = (mk <= 64 && BS >= 192) ? tid - 128 : tid;   // first h row of this thread
+        __syncthreads();
+        // ONE barrier per step: everything step k reads (Psi_k, Phi_k x0, resid_k, S_k = Psi_k Psi_k') was
+        // written by step k-1 into the other half of a double buffer
+        long long wv_busy = 0;  // dev probe: cycles this wavefront works per step (excluding the barrier)
+        for (int k = 0; k <= N; ++k) {
+            const long long t_in = stamp ? (long long)__builtin_readcyclecounter() : 0;
+            T *cur = (k & 1) ? psiB : psiA, *nxt = (k & 1) ? psiA : psiB;
+            const T *ph = phi + (k & 1) * nx, *rc = resid + (k & 1) * nx, *Sc = Sm + (k & 1) * nx * nx;
+            T *phn = phi + ((k + 1) & 1) * nx, *rn = resid + ((k + 1) & 1) * nx, *Sn = Sm + ((k + 1) & 1) * nx * nx;
+            const int ncol = min(n, k * nu);  // Psi_k is zero from column k nu on
+            const bool last = (k == N);
+            // P += w_k Psi_k' Psi_k (lower triangle, packed) ; q += w_k Psi_k' resid_k
+            const T wp = last ? wtp : wxp, wq = last ? wtq : wxq;
+            if (tiled) {
+                // 4 x 4 register tile of P per thread: per state row 8 LDS reads feed 16 FMAs, and the
+                // accumulators never leave the registers until the triangle is complete
+                if (wp != T(0) && tlive && 4 * tj < ncol) {
+                    for (int sc = 0; sc < nx; ++sc) {
+                        const T *pr = cur + sc * n;
+                        T a4[4], b4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a4[u] = wp * pr[min(4 * ti + u, n - 1)];
+                            b4[u] = pr[min(4 * tj + u, n - 1)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v2 = 0; v2 < 4; ++v2) pacc[u][v2] += a4[u] * b4[v2];
+                    }
+                }
+            } else if (wp != T(0) && pc < NC && pi < ncol) {
+                // padded to 4, 8 or 16 state rows so that the coefficients stay in registers
+                auto accumulate = [&](auto nxc_tag) __attribute__((always_inline)) {
+                    constexpr int NXC = decltype(nxc_tag)::value;
+                    T ci[NXC];
+#pragma unroll
+                    for (int sc = 0; sc < NXC; ++sc) ci[sc] = (sc < nx) ? wp * cur[min(sc, nx - 1) * n + pi] : T(0);
+                    T *row = Li + tri(pi, 0);
+                    for (int j = pc; j <= pi; j += NC) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int sc = 0; sc < NXC; ++sc) acc += ci[sc] * cur[min(sc, nx - 1) * n + j];
+                        row[j] += acc;
+                    }
+                };
+                if (nx <= 4)
+                    accumulate(std::integral_constant<int, 4>{});
+                else if (nx <= 8)
+                    accumulate(std::integral_constant<int, 8>{});
+                else
+                    accumulate(std::integral_constant<int, 16>{});
+            }
+            // (the per-step jobs are spread over the wavefronts -- tiles from thread 0 up, q and the Psi update
+            //  from the top down, h / norms in the third wavefront, the small recursions in the last -- so that no
+            //  wavefront runs all of them back to back)
+            if (tq >= 0 && tq < ncol && wq != T(0)) {
+                T acc = T(0);
+                for (int sc = 0; sc < nx; ++sc) acc += cur[sc * n + tq] * rc[sc];
+                qacc += wq * acc;
+            }
+            if (!last) {
+                const T *Ak = opA + k * sAk, *Bk = opB + k * sBk;
+                // h_k = e_k - C_k Phi_k x0 (kept in tolv until the tolerances are formed) ; 1/|G_i| with
+                // |G_i|^2 = C_i S_k C_i' + |D_i|^2
+                for (int r = th; r >= 0 && r < mk; r += BS) {
+                    T acc = T(0), nn = T(0);
+                    if (gC) {
+                        const T *cr = opC + k * sCk + r * nx;
+                        for (int a = 0; a < nx; ++a) {
+                            acc += cr[a] * ph[a];
+                            T t1 = T(0);
+                            for (int b = 0; b < nx; ++b) t1 += Sc[a * nx + b] * cr[b];
+                            nn += cr[a] * t1;
+                        }
+                    }
+                    if (gD) {
+                        const T *dr = opD + k * sDk + r * nu;
+                        for (int u = 0; u < nu; ++u) nn += dr[u] * dr[u];
+                    }
+                    tolv[k * mk + r] -= acc;
+                    gin[k * mk + r] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+                }
+                // Psi_{k+1} = A_k Psi_k, block k <- B_k
+                for (int e2 = BS - 1 - tid; e2 < nx * n; e2 += BS) {
+                    const int a = e2 / n, c = e2 - a * n;
+                    T acc = T(0);
+                    const int jb = c / nu;
+                    if (jb == k) {
+                        acc = Bk[a * nu + (c - jb * nu)];
+                    } else if (c < ncol) {
+                        for (int b = 0; b < nx; ++b) acc += Ak[a * nx + b] * cur[b * n + c];
+                    }
+                    nxt[e2] = acc;
+                }
+                // the last wavefront: Phi_{k+1} x0, resid_{k+1}, S_{k+1} = A_k S_k A_k' + B_k B_k'
+                if (tid >= BS - 64) {
+                    const int l = tid - (BS - 64);
+                    if (l < nx) {
+                        T acc = T(0);
+                        for (int b = 0; b < nx; ++b) acc += Ak[l * nx + b] * ph[b];
+                        phn[l] = acc;
+                        T ref = T(0);
+                        if (k + 1 < N) {
+                            if (qs) ref = dxs[(k + 1) * nx + l];
+                        } else {
+                            ref = goal_l;
+                        }
+                        rn[l] = acc - ref;
+                    }
+                    for (int e2 = l; e2 < nx * nx; e2 += 64) {
+                        const int a = e2 / nx, b = e2 - a * nx;
+                        T acc = T(0);
+                        for (int u = 0; u < nx; ++u) acc += Ak[a * nx + u] * Sc[u * nx + b];
+                        T1[e2] = acc;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (int e2 = l; e2 < nx * nx; e2 += 64) {
+                        const int a = e2 / nx, b = e2 - a * nx;
+                        T acc = T(0);
+                        for (int u = 0; u < nx; ++u) acc += T1[a * nx + u] * Ak[b * nx + u];
+                        for (int u = 0; u < nu; ++u) acc += Bk[a * nu + u] * Bk[b * nu + u];
+                        Sn[e2] = acc;
+                    }
+                }
+            }
+            if (stamp) wv_busy += (long long)__builtin_readcyclecounter() - t_in;
+            __syncthreads();
+        }
+        if (stamp && (tid & 63) == 0) stamp[24 + (tid >> 6)] = wv_busy;
+        if (tlive) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v2 = 0; v2 < 4; ++v2) {
+                    const int i = 4 * ti + u, j = 4 * tj + v2;
+                    if (i < n && j <= i) Li[tri(i, j)] = pacc[u][v2];
+                }
+        }
+        __syncthreads();
+        if (tq >= 0 && tq < n) tmp[tq] = qacc;  // q, consumed below
+        if (tid < n) Li[tri(tid, tid)] += (T)ka.wu;
     } else {
-#pragma unroll 8
-        for (int i = 0; i < n; ++i)
-            if (tid <= i) Li[tri(i, tid)] = P[(int64_t)i * n + tid];
+        // ---- packed lower triangle of P
+        if ((n & 3) == 0) {
+            // whole rows as 16-byte loads, sixteen in flight per thread. Branch-free so that the loads
+            // batch: groups above the diagonal re-read their row's diagonal group and store to a dump
+            // slot (the vectors after y0 are not in use yet; n >= 64 here, see bigsolve_supported).
+            const int nv = n * n / 4;
+            T *dump = y0 + tid;
+    #pragma unroll 16
+            for (int v4 = tid; v4 < nv; v4 += BS) {
+                const int idx = 4 * v4, i = idx / n, j = idx - i * n;
+                const bool need = j <= i;
+                const V4 pv = *reinterpret_cast<const V4 *>(P + (need ? idx : i * n + (i & ~3)));
+                T *d = Li + tri(i, j);
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) *((need && j + c <= i) ? d + c : dump) = pv[c];
+            }
+        } else {
+    #pragma unroll 8
+            for (int i = 0; i < n; ++i)
+                if (tid <= i) Li[tri(i, tid)] = P[(int64_t)i * n + tid];
+        }
     }
     __syncthreads();
     mark(1);
@@ -629,7 +910,9 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         mark(3);
         if constexpr (STRUCT) load_operands();  // after the factorisation: 190 registers it should not have to carry
         // ---- y0 = -L^-1 q ; slacks at the unconstrained minimiser need x0 = L^-T y0
-        if (tid < n) tmp[tid] = q[tid];
+        if constexpr (!MID) {
+            if (tid < n) tmp[tid] = q[tid];
+        }
         __syncthreads();
         {
             const T a = lower_matvec(tmp);
@@ -641,7 +924,15 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             if (tid < n) zx[tid] = a;  // unconstrained minimiser in x coordinates
         }
         __syncthreads();
-        if constexpr (STRUCT) {
+        if constexpr (MID) {
+            rollout();
+            for (int i = tid; i < m; i += BS) {
+                const T hi = tolv[i];  // h was parked here by the front end
+                sv[i] = hi - mid_row(i);
+                tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
+                pos[i] = -1;
+            }
+        } else if constexpr (STRUCT) {
             rollout();
 #pragma unroll
             for (int j = 0; j < RS; ++j) {
@@ -722,7 +1013,37 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             lap(0);
             // ---- M_p = L^-1 G_p'   (thread j: row j of L^-1 against G_p)
             __syncthreads();
-            if constexpr (STRUCT) {
+            if constexpr (MID) {
+                // G_p = C_k[r] Psi_k + D_k[r] E_k by the adjoint recursion (first wavefront):
+                // mu = C_k[r]' ; for j = k-1 .. 0 : G_p[block j] = B_j' mu, mu <- A_j' mu
+                const int k = p / mk, r = p - k * mk;
+                if (tid < n) {
+                    const int jb = tid / nu;
+                    tmp[tid] = (gD && jb == k) ? opD[k * sDk + r * nu + (tid - jb * nu)] : T(0);
+                }
+                if (gC) __syncthreads();  // the recursion below overwrites blocks j < k of tmp
+                if (gC && tid < 64) {
+                    T *mu = fe + 4 * nx + 3 * nx * nx;  // two buffers of nx
+                    if (tid < nx) mu[tid] = opC[k * sCk + r * nx + tid];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (int j = k - 1; j >= 0; --j) {
+                        const T *mc = mu + ((k - 1 - j) & 1) * nx;
+                        T *mn = mu + ((k - j) & 1) * nx;
+                        const T *Aj = opA + j * sAk, *Bj = opB + j * sBk;
+                        if (tid < nu) {
+                            T acc = T(0);
+                            for (int a = 0; a < nx; ++a) acc += Bj[a * nu + tid] * mc[a];
+                            tmp[j * nu + tid] = acc;
+                        } else if (tid >= 32 && tid < 32 + nx) {
+                            const int b = tid - 32;
+                            T acc = T(0);
+                            for (int a = 0; a < nx; ++a) acc += Aj[a * nx + b] * mc[a];
+                            mn[b] = acc;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    }
+                }
+            } else if constexpr (STRUCT) {
                 if (tid < n) {
                     const int k = p / mk, r = p - k * mk;
                     T g = T(0);
@@ -810,7 +1131,10 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                 }
                 __syncthreads();
                 lap(5);
-                if constexpr (STRUCT) {
+                if constexpr (MID) {
+                    rollout();
+                    for (int i = tid; i < m; i += BS) sv[i] = (pos[i] >= 0) ? T(0) : sv[i] - t * mid_row(i);
+                } else if constexpr (STRUCT) {
                     rollout();
 #pragma unroll
                     for (int j = 0; j < RS; ++j) {
@@ -991,12 +1315,31 @@ bool bigsolve_struct_supported(const KernelArgs &ka, int dtype)
 }
 size_t bigsolve_ws_elems(int n) { return (size_t)2 * n * n; }
 
-template <typename T, bool STRUCT>
+// extra LDS elements of the mid-size kind: roll-out table, operands, two Psi_k buffers, front-end vectors
+static size_t mid_extra_elems(const KernelArgs &ka)
+{
+    size_t el = (size_t)ka.N * ka.nx;
+    el += (size_t)(ka.A.step_stride ? ka.N : 1) * ka.nx * ka.nx + (size_t)(ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
+    if (ka.C.ptr) el += (size_t)(ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx;
+    if (ka.D.ptr) el += (size_t)(ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu;
+    el += 2 * (size_t)ka.nx * ka.n + 6 * (size_t)ka.nx + 3 * (size_t)ka.nx * ka.nx;
+    return el;
+}
+// Fused build+solve of mid-size problems in one launch; LDS capped so that at least two problems share a CU.
+bool mid_supported(const KernelArgs &ka, int dtype)
+{
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    return ka.m > 0 && ka.mk > 0 && ka.nx <= 16 && ka.nu <= 32 && ka.n >= 32 && ka.n <= 160 &&
+           bigsolve_lds_bytes(ka.n, ka.m, esz, (int)mid_extra_elems(ka)) <= 72 * 1024;
+}
+
+template <typename T, int KIND>
 static int launch_bigsolve_t(const KernelArgs &ka, int64_t batch, const void *P, const void *q, const void *G,
                              const void *aux, const void *h, const void *aux2, void *ws, hipStream_t st)
 {
-    const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, sizeof(T), STRUCT ? ka.N * ka.nx : 0);
-    auto kern = mpcqp_bigsolve_kernel<T, STRUCT>;
+    const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, sizeof(T),
+                                          KIND == K_MID ? (int)mid_extra_elems(ka) : (KIND == K_STRUCT ? ka.N * ka.nx : 0));
+    auto kern = mpcqp_bigsolve_kernel<T, KIND>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const T *)P, (const T *)q,
@@ -1007,16 +1350,23 @@ static int launch_bigsolve_t(const KernelArgs &ka, int64_t batch, const void *P,
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st)
 {
-    if (dtype == MPCQP_F64) return launch_bigsolve_t<double, false>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
-    return launch_bigsolve_t<float, false>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
+    if (dtype == MPCQP_F64) return launch_bigsolve_t<double, K_DENSE>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
+    return launch_bigsolve_t<float, K_DENSE>(ka, batch, P, q, G, GT, h, nullptr, ws, st);
 }
 
 int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q,
                            const void *Psi_all, const void *h, const void *rownorm_inv, void *ws, hipStream_t st)
 {
     if (dtype == MPCQP_F64)
-        return launch_bigsolve_t<double, true>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
-    return launch_bigsolve_t<float, true>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
+        return launch_bigsolve_t<double, K_STRUCT>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
+    return launch_bigsolve_t<float, K_STRUCT>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
+}
+
+int launch_mid(const KernelArgs &ka, int dtype, int64_t batch, void *ws, hipStream_t st)
+{
+    if (dtype == MPCQP_F64)
+        return launch_bigsolve_t<double, K_MID>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
+    return launch_bigsolve_t<float, K_MID>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
 }
 
 }  // namespace mpcqp

@@ -149,6 +149,23 @@ BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
     return b;
 }
 
+// Mid-size fused problems (config 3) go to the lean one-launch kernel unless the small-problem kernel
+// takes them or MPCQP_FORCE_LDS=1 asks for the all-in-LDS kernel (cross-checks).
+bool use_mid(const KernelArgs &ka, int dtype)
+{
+    return !force_lds() && !w64_eligible(ka, MODE_FUSED, dtype) && mid_supported(ka, dtype);
+}
+
+// mpcqp_workspace_bytes sees the dimensions only, not the operand strides: it reports the mid-size
+// kernel's workspace whenever the most compact operand layout (LTI, no C/D) would be taken. A launch with
+// bulkier operands may still fall back to the all-in-LDS kernel, which simply ignores the workspace.
+bool problem_strides_unknown_mid(KernelArgs ka, int dtype)
+{
+    ka.A.step_stride = ka.B.step_stride = ka.C.step_stride = ka.D.step_stride = 0;
+    ka.C.ptr = ka.D.ptr = nullptr;
+    return use_mid(ka, dtype);
+}
+
 bool fits_on_chip(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype)
 {
     if (!force_lds() && w64_eligible(ka, mode, dtype)) return true;
@@ -227,6 +244,10 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
     fill_args(ka, dims, nullptr);
     *bytes = 0;
     const int mode = for_solve ? MODE_FUSED : MODE_CONDENSE;
+    if (for_solve && problem_strides_unknown_mid(ka, dims->dtype)) {
+        *bytes = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
+        return 0;
+    }
     if (fits_on_chip(ka, true, true, mode, dims->dtype)) return 0;
     if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
     const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
@@ -358,6 +379,11 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     if (const char *dbg = getenv("MPCQP_STAMP_PTR")) ka.X = (void *)strtoull(dbg, nullptr, 0);  // dev probe only
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (use_mid(ka, dims->dtype)) {
+        const size_t need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_mid(ka, dims->dtype, batch, workspace, st);
+    }
     if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
         return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
     // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the

@@ -138,6 +138,9 @@ size_t bigsolve_ws_elems(int n);
 bool bigsolve_struct_supported(const KernelArgs &ka, int dtype);
 int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q,
                            const void *Psi_all, const void *h, const void *rownorm_inv, void *ws, hipStream_t st);
+// mid-size fused build+solve (mpcqp_bigsolve.hip, KIND = K_MID): ws = 2 n^2 elements per problem
+bool mid_supported(const KernelArgs &ka, int dtype);
+int launch_mid(const KernelArgs &ka, int dtype, int64_t batch, void *ws, hipStream_t st);
 int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st);
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st);

@@ -5,7 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from qpmpc_amd import PreparedSolve, workloads as W
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-w = W.synthetic_ltv_batch(batch); bp = W.to_batch_problem(w, dtype=torch.float32)
+kind = sys.argv[2] if len(sys.argv) > 2 else "config5"
+if kind == "wip":  # config 3 through the mid-size kind of the same kernel (f64)
+    w = W.wip_batch(batch); bp = W.to_batch_problem(w)
+else:
+    w = W.synthetic_ltv_batch(batch); bp = W.to_batch_problem(w, dtype=torch.float32)
 buf = torch.zeros(batch * 32, dtype=torch.int64, device="cuda")
 os.environ["MPCQP_STAMP_PTR"] = str(buf.data_ptr())
 run = PreparedSolve(bp)
@@ -32,3 +36,5 @@ fl = full[:, 16:21]
 print("  inside factor+invert (cycles per problem):")
 for i, nme in enumerate(["diag blocks", "panels", "trailing", "W_I L[I,K]", "X rows"]):
     print(f"    {nme:16s} {fl[:, i].mean().item():9.0f}")
+if kind == "wip":
+    print("  front end, busy cycles per wavefront (sum over the steps):", [int(full[:, 24 + w].mean().item()) for w in range(4)])
