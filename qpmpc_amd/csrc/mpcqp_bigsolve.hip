@@ -36,16 +36,19 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
-template <typename T> __device__ __forceinline__ T block_sum(T v, T *red, int tid)
+template <int NWV, typename T> __device__ __forceinline__ T block_sum(T v, T *red, int tid)
 {
     v = wave_sum(v);
     __syncthreads();
     if ((tid & 63) == 0) red[tid >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    T s = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) s += red[w];
+    return s;
 }
 // arg-min of (v, i) over the block; ties -> lowest index
-template <typename T> __device__ __forceinline__ void block_argmin(T &v, int &i, T *redv, int *redi, int tid)
+template <int NWV, typename T> __device__ __forceinline__ void block_argmin(T &v, int &i, T *redv, int *redi, int tid)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -65,7 +68,7 @@ template <typename T> __device__ __forceinline__ void block_argmin(T &v, int &i,
     v = redv[0];
     i = redi[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < NWV; ++w)
         if (redv[w] < v || (redv[w] == v && redi[w] < i)) {
             v = redv[w];
             i = redi[w];
@@ -453,8 +456,8 @@ __device__ __forceinline__ double quad_sum(double v)
 //     G_p = C_k[r] Psi_k + D_k[r] E_k rebuilt by the adjoint recursion mu' <- mu' A_j, g_j = B_j' mu.
 enum { K_DENSE = 0, K_STRUCT = 1, K_MID = 2 };
 
-template <typename T, int KIND>
-__global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
+template <typename T, int KIND, int NWV>
+__global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
                                                             const T *__restrict__ qall, const T *__restrict__ Gall,
                                                             const T *__restrict__ aux, const T *__restrict__ hall,
                                                             const T *__restrict__ aux2, T *__restrict__ wsall)
@@ -465,6 +468,8 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     const T INF = (T)HUGE_VALF;
     typedef T V4 __attribute__((ext_vector_type(4)));
     constexpr bool STRUCT = (KIND == K_STRUCT), MID = (KIND == K_MID), MFREE = (KIND != K_DENSE);
+    constexpr int BS = 64 * NWV;  // threads per problem: 256, or 128 for mid-size problems with n <= 128
+    static_assert(NWV == 4 || KIND == K_MID, "the large-problem kinds are laid out for four wavefronts");
     // LDS carve
     T *Li = (T *)smem_raw;              // packed lower triangle: P -> L -> L^-1
     T *sv = Li + n * (n + 1) / 2;       // slacks            [m]
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
         }
         const int lane = tid & 63, wv = tid >> 6, r = lane >> 2, c = lane & 3;
         if (tid < nx) dxs[tid] = T(0);
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NWV; ++w) {
             __syncthreads();
             if (wv == w) {
 #pragma unroll
@@ -900,7 +905,10 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
     // ---- L = chol(P), then L^-1 in place
     bool pd;
     if constexpr (sizeof(T) == 4) {
-        pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, sv, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
+        if constexpr (NWV == 4)
+            pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, sv, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
+        else
+            pd = factor_invert_scalar<T>(Li, n, tid, red);
     } else {
         pd = factor_invert_scalar<T>(Li, n, tid, red);
     }
@@ -1004,7 +1012,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     }
                 }
             }
-            block_argmin(best, bi, red, redi, tid);
+            block_argmin<NWV>(best, bi, red, redi, tid);
             if (!(best < INF)) {
                 status = MPCQP_SOLVED;
                 break;
@@ -1074,7 +1082,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
             T kpp;
             {
                 const T v = (tid < n) ? mp[tid] * mp[tid] : T(0);
-                kpp = block_sum(v, red, tid);
+                kpp = block_sum<NWV>(v, red, tid);
             }
             T up = T(0);
             bool added = false;
@@ -1087,7 +1095,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                 ++iters;
                 // r_a = T_a . M_p : one wavefront per row, lanes across columns
                 __syncthreads();
-                for (int a = tid >> 6; a < nq; a += 4) {
+                for (int a = tid >> 6; a < nq; a += NWV) {
                     T acc = T(0);
                     for (int k = tid & 63; k < n; k += 64) acc += Tm[(int64_t)a * n + k] * mp[k];
                     acc = wave_sum(acc);
@@ -1103,7 +1111,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     for (int a = 0; a < nq; ++a) zk += rv[a] * MA[(int64_t)a * n + tid];
                     zv[tid] = zk;
                 }
-                const T d2 = block_sum(zk * zk, red, tid);
+                const T d2 = block_sum<NWV>(zk * zk, red, tid);
                 // ratio test
                 T t1 = INF;
                 int l = 0x7fffffff;
@@ -1111,7 +1119,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     t1 = lam[tid] / rv[tid];
                     l = tid;
                 }
-                block_argmin(t1, l, red, redi, tid);
+                block_argmin<NWV>(t1, l, red, redi, tid);
                 const bool can_move = (nq < n) && (d2 > (T)1e-10 * kpp) && (d2 > T(0));
                 const T sp = sv[p];
                 const T t2 = can_move ? -sp / d2 : INF;
@@ -1195,7 +1203,7 @@ __global__ void __launch_bounds__(BS) mpcqp_bigsolve_kernel(const KernelArgs ka,
                     __syncthreads();
                     if (tid < n) tmp[tid] = Tm[(int64_t)l * n + tid];
                     __syncthreads();
-                    for (int a = tid >> 6; a < nq; a += 4) {
+                    for (int a = tid >> 6; a < nq; a += NWV) {
                         T acc = T(0);
                         for (int k = tid & 63; k < n; k += 64) acc += Tm[(int64_t)a * n + k] * tmp[k];
                         acc = wave_sum(acc);
@@ -1333,16 +1341,16 @@ bool mid_supported(const KernelArgs &ka, int dtype)
            bigsolve_lds_bytes(ka.n, ka.m, esz, (int)mid_extra_elems(ka)) <= 72 * 1024;
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, int NWV = 4>
 static int launch_bigsolve_t(const KernelArgs &ka, int64_t batch, const void *P, const void *q, const void *G,
                              const void *aux, const void *h, const void *aux2, void *ws, hipStream_t st)
 {
     const size_t lds = bigsolve_lds_bytes(ka.n, ka.m, sizeof(T),
                                           KIND == K_MID ? (int)mid_extra_elems(ka) : (KIND == K_STRUCT ? ka.N * ka.nx : 0));
-    auto kern = mpcqp_bigsolve_kernel<T, KIND>;
+    auto kern = mpcqp_bigsolve_kernel<T, KIND, NWV>;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(bigs::BS), lds, st, ka, (const T *)P, (const T *)q,
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64 * NWV), lds, st, ka, (const T *)P, (const T *)q,
                        (const T *)G, (const T *)aux, (const T *)h, (const T *)aux2, (T *)ws);
     return (int)hipGetLastError();
 }
@@ -1364,9 +1372,15 @@ int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const
 
 int launch_mid(const KernelArgs &ka, int dtype, int64_t batch, void *ws, hipStream_t st)
 {
+    // two wavefronts per problem pay only when the smaller block really doubles the problems resident on a
+    // CU, i.e. when LDS (not the 16 wavefront slots) allows eight of them; config 3 (30 KB) stays at four
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    const bool two = ka.n <= 128 && bigsolve_lds_bytes(ka.n, ka.m, esz, (int)mid_extra_elems(ka)) <= 20 * 1024;
     if (dtype == MPCQP_F64)
-        return launch_bigsolve_t<double, K_MID>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
-    return launch_bigsolve_t<float, K_MID>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
+        return two ? launch_bigsolve_t<double, K_MID, 2>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st)
+                   : launch_bigsolve_t<double, K_MID, 4>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
+    return two ? launch_bigsolve_t<float, K_MID, 2>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st)
+               : launch_bigsolve_t<float, K_MID, 4>(ka, batch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, st);
 }
 
 }  // namespace mpcqp
