@@ -244,14 +244,21 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
     fill_args(ka, dims, nullptr);
     *bytes = 0;
     const int mode = for_solve ? MODE_FUSED : MODE_CONDENSE;
-    if (for_solve && problem_strides_unknown_mid(ka, dims->dtype)) {
-        *bytes = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
-        return 0;
+    // The query sees dimensions, not operand strides, while the launch picks its kernel with the strides
+    // (bulkier operands need more LDS): report the LARGEST workspace any path the launch may take needs.
+    size_t need = 0;
+    const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
+    if (maybe_mid) need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
+    if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
+        if (big_supported(ka) && ka.n <= 256) {
+            const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
+            const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
+            if (big > need) need = big;
+        } else if (!maybe_mid) {
+            return MPCQP_ETOOLARGE;
+        }
     }
-    if (fits_on_chip(ka, true, true, mode, dims->dtype)) return 0;
-    if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
-    const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
-    *bytes = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
+    *bytes = need;
     return 0;
 }
 

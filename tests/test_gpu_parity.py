@@ -706,3 +706,43 @@ def test_large_batch_sweep_shared_operands():
     sa, sb = a.status.cpu().numpy(), b.status.cpu().numpy().reshape(reps, 4096)
     assert (sb == sa[None]).all()
     assert np.array_equal(Ub, np.broadcast_to(Ua[None], Ub.shape))  # same kernel, same data -> bitwise
+
+
+# ---------------------------------------------------------------- mid-size fused kernel (K_MID)
+@pytest.mark.parametrize("nx,nu,N,mk,with_c,with_d,wx,lti", [
+    (5, 2, 20, 3, True, True, 0.5, False),    # n = 40, m = 60: C and D rows, stage + terminal cost, per-step operands
+    (4, 1, 50, 2, False, True, 1.0, False),   # config-3 shape (input box only)
+    (6, 3, 16, 4, True, False, None, False),  # n = 48, state constraints only (adjoint row fetch), terminal cost only
+    (3, 2, 30, 2, True, True, 0.5, True),     # n = 60, LTI operands (stride 0, staged once)
+    (12, 2, 16, 4, True, True, 0.5, False),   # n = 32, nx = 12: the paths padded to 16 state rows
+    (12, 4, 24, 6, True, True, 0.5, False),   # n = 96 with bulky per-step operands: falls through to the large path
+])
+def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, lti, monkeypatch):
+    """Fused build+solve of mid-size problems (on-chip streaming front end, matrix-free G) against the
+    oracle, and against the all-in-LDS workgroup kernel on the same batch (MPCQP_FORCE_LDS)."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(1000 * nx + 10 * N + mk)
+    w = _random_ltv_workload(rng, 24, nx, nu, N, mk, with_c, with_d, wx=wx)
+    w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
+    if lti:  # one model for the whole batch and horizon
+        for key in ("A", "B", "C", "D"):
+            if w[key] is not None:
+                w[key] = w[key][0, 0]
+        w["e"] = np.abs(w["e"]).max(axis=(0, 1)) + 1.0
+    bp = to_batch_problem(w)
+    plan = solve_mpc_batch(bp, return_multipliers=True)
+    torch.cuda.synchronize()
+    U, st = plan.U.cpu().numpy(), plan.status.cpu().numpy()
+    Uo, _, sto, _ = oracle_batch(w)
+    assert np.array_equal(st == 0, sto == 0), (st, sto)
+    ok = sto == 0
+    assert ok.sum() >= 20
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-7
+    monkeypatch.setenv("MPCQP_FORCE_LDS", "1")
+    other = solve_mpc_batch(bp)
+    torch.cuda.synchronize()
+    assert np.array_equal(other.status.cpu().numpy(), st)
+    assert (np.abs(other.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-7
