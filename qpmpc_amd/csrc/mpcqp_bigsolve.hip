@@ -106,8 +106,19 @@ using namespace bigs;
 
 // Packed Cholesky followed by the in-place inverse of the factor, scalar version (any n <= 256,
 // any dtype): thread i owns row i. Returns false when a pivot is not positive.
-template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li, int n, int tid, T *red)
+// WAVE = true: n <= 64, called by the first wavefront only -- every participant is in one wavefront, so
+// the ~4 n workgroup barriers become wavefront-level fences (LDS is in order within a wavefront).
+template <typename T, bool WAVE = false>
+__device__ __forceinline__ bool factor_invert_scalar(T *Li, int n, int tid, T *red)
 {
+    auto sync = [&]() __attribute__((always_inline)) {
+        if constexpr (WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
     // ---- Cholesky, left-looking by columns: thread i owns row i
     bool notpd = false;
     {
@@ -135,7 +146,7 @@ template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li
                 v = ri[j] - ((a0 + a1) + (a2 + a3));
             }
             if (i == j) red[0] = v;  // pivot
-            __syncthreads();
+            sync();
             const T piv = red[0];
             if (!(piv > T(0))) {
                 notpd = true;
@@ -143,7 +154,7 @@ template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li
             }
             const T rinv = fast_rsqrt(piv);
             if (i >= j && i < n) Li[tri(i, 0) + j] = (i == j) ? piv * rinv : v * rinv;
-            __syncthreads();
+            sync();
         }
     }
     if (notpd) return false;
@@ -181,10 +192,10 @@ template <typename T> __device__ __forceinline__ bool factor_invert_scalar(T *Li
                     }
                     x = -((a0 + a1) + (a2 + a3)) * dinv;
                 }
-                __syncthreads();
+                sync();
                 if (j < i) Li[rowi + j] = x;
                 if (j == i) Li[rowi + i] = dinv;
-                __syncthreads();
+                sync();
             }
         }
     }
@@ -903,14 +914,28 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
     __syncthreads();
     mark(1);
     // ---- L = chol(P), then L^-1 in place
+    auto factor_small_or_scalar = [&](T *A, int nn, int t, T *rd) __attribute__((always_inline)) -> bool {
+        if (nn > 64) return factor_invert_scalar<T, false>(A, nn, t, rd);
+        // one wavefront owns every row: no workgroup barrier inside the factorisation
+        if (t < 64) {
+            const bool ok = factor_invert_scalar<T, true>(A, nn, t, rd);
+            if (t == 0) rd[7] = ok ? T(1) : T(0);
+        }
+        __syncthreads();
+        return rd[7] != T(0);
+    };
     bool pd;
     if constexpr (sizeof(T) == 4) {
-        if constexpr (NWV == 4)
-            pd = ((n & 31) == 0) ? factor_invert_mfma(Li, n, tid, red, sv, stamp ? stamp + 16 : nullptr) : factor_invert_scalar<T>(Li, n, tid, red);
-        else
-            pd = factor_invert_scalar<T>(Li, n, tid, red);
+        if constexpr (NWV == 4) {
+            if ((n & 31) == 0)
+                pd = factor_invert_mfma(Li, n, tid, red, sv, stamp ? stamp + 16 : nullptr);
+            else
+                pd = factor_small_or_scalar(Li, n, tid, red);
+        } else {
+            pd = factor_small_or_scalar(Li, n, tid, red);
+        }
     } else {
-        pd = factor_invert_scalar<T>(Li, n, tid, red);
+        pd = factor_small_or_scalar(Li, n, tid, red);
     }
     if (!pd) {
         status = MPCQP_NOT_PD;
