@@ -726,6 +726,11 @@ def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, 
     rng = np.random.default_rng(1000 * nx + 10 * N + mk)
     w = _random_ltv_workload(rng, 24, nx, nu, N, mk, with_c, with_d, wx=wx)
     w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
+    if (nx, nu) == (5, 2):  # ragged horizons: some rows are padding (zero rows, bound 1e30) and must never be selected
+        pad = rng.random((24, N, mk)) < 0.25
+        w["C"][pad] = 0.0
+        w["D"][pad] = 0.0
+        w["e"][pad] = 1e30
     if lti:  # one model for the whole batch and horizon
         for key in ("A", "B", "C", "D"):
             if w[key] is not None:
