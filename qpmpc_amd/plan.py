@@ -72,5 +72,9 @@ class Plan:
             if x_init is None:
                 logging.warning("Problem has undefined initial state")
                 return None
-            self._states = self.problem.integrate(x_init, self._inputs)
+            pre = getattr(self, "_precomputed_rollout", None)  # (x0, X) from the fused single-problem path
+            if pre is not None and np.array_equal(pre[0], np.asarray(x_init, dtype=float).ravel()):
+                self._states = pre[1]
+            else:
+                self._states = self.problem.integrate(x_init, self._inputs)
         return self._states

@@ -36,6 +36,15 @@ def solve_mpc(problem: MPCProblem, solver: str = "hip_gi", sparse: bool = False,
     if problem.initial_state is None:
         raise ProblemDefinitionError("initial state is undefined")
     if solver in HIP_SOLVERS:
+        from .single import solve_single
+
+        fast = solve_single(problem, kwargs.get("max_iter"), kwargs.get("feas_tol"))
+        if fast is not None:  # one upload, one fused launch + roll-out, one download
+            x, z, X, status, iters = fast
+            plan = Plan(problem, Solution(None, x=x, z=z, found=(status == 0), extras={"status": status, "iters": iters}))
+            if X is not None:  # already rolled out on the device; used if the initial state is still the same
+                plan._precomputed_rollout = (np.asarray(problem.initial_state, dtype=float).ravel().copy(), X)
+            return plan
         bp = BatchMPCProblem.from_problems([problem])
         bplan = solve_mpc_batch(bp, solver=solver, return_multipliers=True,
                                 max_iter=kwargs.get("max_iter"), feas_tol=kwargs.get("feas_tol"))

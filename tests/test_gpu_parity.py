@@ -751,3 +751,33 @@ def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, 
     torch.cuda.synchronize()
     assert np.array_equal(other.status.cpu().numpy(), st)
     assert (np.abs(other.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-7
+
+
+def test_single_problem_fast_path_equals_general_path_and_keeps_plan_semantics():
+    """solve_mpc packs one problem into one upload / one fused launch + roll-out / one download
+    (qpmpc_amd/single.py); the result must equal the batch-container path, and ``Plan.states`` must still
+    follow the reference's lazy rule (plan.py:102-105): rolled out from the problem's CURRENT initial state."""
+    from qpmpc_amd import BatchMPCProblem, MPCProblem, solve_mpc, solve_mpc_batch
+    from qpmpc_amd.single import solve_single
+
+    for name in ("triple_integrator_x0a", "wip_n50_ltv_lists", "humanoid_x0a", "lipm_step_07"):
+        problem, z = load_case(name)
+        plan = solve_mpc(problem, solver="hip_gi")
+        assert solve_single(problem) is not None  # this fixture takes the fast path
+        ref = solve_mpc_batch(BatchMPCProblem.from_problems([problem]))
+        torch.cuda.synchronize()
+        assert np.array_equal(plan.inputs.ravel(), ref.U[0].cpu().numpy())  # same kernel, same data
+        assert np.abs(plan.states - ref.states[0].cpu().numpy()).max() <= 1e-12
+        assert np.abs(plan.inputs.ravel() - z["U_star"].ravel()).max() <= 1e-6 * max(1.0, np.abs(z["U_star"]).max())
+    # ragged per-step rows go through the general path
+    problem, _ = load_case("random_ltv_ragged")
+    assert solve_single(problem) is None
+    assert not solve_mpc(problem, solver="hip_gi").is_empty
+    # lazy states: changing the initial state before the first access changes the roll-out
+    problem, _ = load_case("triple_integrator")
+    plan = solve_mpc(problem, solver="hip_gi")
+    x_new = np.array([0.2, -0.1, 0.05])
+    problem.update_initial_state(x_new)
+    X = plan.states
+    assert np.array_equal(X[0], x_new)
+    assert np.abs(X - oracle.integrate(problem, x_new, plan.inputs)).max() <= 1e-12
