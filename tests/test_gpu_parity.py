@@ -781,3 +781,85 @@ def test_single_problem_fast_path_equals_general_path_and_keeps_plan_semantics()
     X = plan.states
     assert np.array_equal(X[0], x_new)
     assert np.abs(X - oracle.integrate(problem, x_new, plan.inputs)).max() <= 1e-12
+
+
+def test_fuzz_dimensions_across_all_kernels():
+    """Random (nx, nu, N, mk, operand layout, cost terms) so that every dispatch target is hit -- the wavefront
+    kernel, the workgroup kernel, the mid-size kind and the large path -- each batch against the oracle."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(31337)
+    seen = 0
+    for trial in range(36):
+        nx = int(rng.integers(2, 7))
+        nu = int(rng.integers(1, 4))
+        N = int(rng.choice([3, 5, 8, 12, 16, 24, 33, 40]))
+        mk = int(rng.integers(1, 5))
+        with_c, with_d = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        if not (with_c or with_d):
+            with_d = True
+        wx = None if rng.integers(0, 3) == 0 else float(rng.uniform(0.1, 2.0))
+        wt = None if (wx is not None and rng.integers(0, 3) == 0) else float(rng.uniform(0.5, 5.0))
+        B = 6
+        w = _random_ltv_workload(rng, B, nx, nu, N, mk, with_c, with_d, wt=wt, wx=wx)
+        w["A"] = np.eye(nx) + (0.3 if N <= 16 else 0.08) * (w["A"] - np.eye(nx))  # keep long horizons well scaled
+        layout = int(rng.integers(0, 3))
+        if layout == 1:  # shared model, per-step operands
+            for key in ("A", "B", "C", "D"):
+                if w[key] is not None:
+                    w[key] = w[key][0]
+            w["e"] = np.abs(w["e"]).max(axis=0) + 0.5
+        elif layout == 2:  # LTI
+            for key in ("A", "B", "C", "D"):
+                if w[key] is not None:
+                    w[key] = w[key][0, 0]
+            w["e"] = np.abs(w["e"]).max(axis=(0, 1)) + 0.5
+        if wt is None:
+            w["goal"] = None
+        plan = solve_mpc_batch(to_batch_problem(w))
+        torch.cuda.synchronize()
+        U, st = plan.U.cpu().numpy(), plan.status.cpu().numpy()
+        Uo, _, sto, _ = oracle_batch(w)
+        tag = (trial, nx, nu, N, mk, with_c, with_d, wt, wx, layout)
+        assert np.array_equal(st == 0, sto == 0), (tag, st, sto)
+        ok = sto == 0
+        if ok.any():
+            scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+            err = (np.abs(U[ok] - Uo[ok]) / scale).max()
+            assert err <= 1e-6, (tag, err)
+            seen += int(ok.sum())
+    assert seen >= 150
+
+
+def test_fuzz_dimensions_float32():
+    """The float32 instantiations of the same dispatch space (workgroup kernel, mid-size kind incl. its MFMA
+    factorisation when n is a multiple of 32, large path): |u - u_ref64| <= 2e-3 max(1, |u|) where both
+    precisions solve the problem."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(4242)
+    agree = total = 0
+    for trial, (nx, nu, N, mk) in enumerate([(3, 1, 16, 2), (4, 2, 16, 3), (5, 2, 20, 3), (4, 1, 50, 2), (6, 3, 16, 4),
+                                             (4, 2, 32, 2), (3, 4, 16, 2), (12, 4, 64, 16), (6, 2, 48, 3), (2, 1, 8, 1)]):
+        B = 6
+        if (nx, N) == (12, 64):
+            from qpmpc_amd.workloads import synthetic_ltv_batch
+
+            w = synthetic_ltv_batch(B)
+        else:
+            w = _random_ltv_workload(rng, B, nx, nu, N, mk, True, True)
+            w["A"] = np.eye(nx) + (0.3 if N <= 16 else 0.05) * (w["A"] - np.eye(nx))
+        plan = solve_mpc_batch(to_batch_problem(w, dtype=torch.float32))
+        torch.cuda.synchronize()
+        U, st = plan.U.double().cpu().numpy(), plan.status.cpu().numpy()
+        Uo, _, sto, _ = oracle_batch(w)
+        both = (st == 0) & (sto == 0)
+        total += B
+        agree += int((st == 0).sum() == (sto == 0).sum())
+        if both.any():
+            scale = np.maximum(1.0, np.abs(Uo[both]).max(axis=1, keepdims=True))
+            err = (np.abs(U[both] - Uo[both]) / scale).max()
+            assert err <= 2e-3, ((nx, nu, N, mk), err)
+        assert both.sum() >= (sto == 0).sum() - 1, ((nx, nu, N, mk), st, sto)
