@@ -73,19 +73,27 @@ class MPCQP:
         self._rows = bp.valid_rows
         self._sparse = sparse
         N, nx = mpc_problem.nb_timesteps, mpc_problem.state_dim
-        Phi_all = self._dev.Phi_all[0].cpu().numpy()
-        Psi_all = self._dev.Psi_all[0].cpu().numpy()
+        # ONE device-to-host copy for everything the reference exposes as NumPy attributes
+        import torch
+
+        d = self._dev
+        parts = [d.Phi_all[0], d.Psi_all[0], d.P[0], d.G[0], d.q[0], d.h[0]]
+        flat = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy()
+        views, o = [], 0
+        for t in parts:
+            views.append(flat[o: o + t.numel()].reshape(tuple(t.shape)))
+            o += t.numel()
+        Phi_all, Psi_all, P, G, q, h = views
         self.Phi, self.phi_last = Phi_all[: N * nx], Phi_all[N * nx:]
         self.Psi, self.psi_last = Psi_all[: N * nx], Psi_all[N * nx:]
-        P = self._dev.P[0].cpu().numpy()
-        G = self._dev.G[0].cpu().numpy()[self._rows]
+        G = G[self._rows]
         if sparse:  # mpc_qp.py:108-109
             from scipy.sparse import csc_matrix
 
             P, G = csc_matrix(P), csc_matrix(G)
         self.P, self.G = P, G
-        self.q = self._dev.q[0].cpu().numpy()
-        self.h = self._dev.h[0].cpu().numpy()[self._rows]
+        self.q = q.copy()
+        self.h = h[self._rows].copy()
         self.e = np.hstack(
             [np.asarray(mpc_problem.get_ineq_vector(k), dtype=float).ravel() for k in range(N)]
         )

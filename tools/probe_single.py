@@ -21,3 +21,13 @@ t0 = time.perf_counter()
 for i in range(reps):
     plan = solve_mpc(problem, solver="hip_gi"); X = plan.states
 print(f"  ... including plan.states: {(time.perf_counter()-t0)/reps*1e6:.0f} us per call")
+from qpmpc_amd import MPCQP
+for _ in range(3): qp = MPCQP(problem)
+t0 = time.perf_counter()
+for i in range(100):
+    qp = MPCQP(problem); P = qp.P
+print(f"MPCQP(problem) + .P on the host: {(time.perf_counter()-t0)/100*1e6:.0f} us per call")
+t0 = time.perf_counter()
+for i in range(100):
+    problem.update_initial_state(np.array([0.001 * i, 0.0, 0.0])); qp.update_cost_vector(problem); qp.update_constraint_vector(problem); q = qp.q
+print(f"update_cost_vector + update_constraint_vector + .q: {(time.perf_counter()-t0)/100*1e6:.0f} us per call")
