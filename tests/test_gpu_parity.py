@@ -842,7 +842,8 @@ def test_fuzz_dimensions_float32():
     rng = np.random.default_rng(4242)
     agree = total = 0
     for trial, (nx, nu, N, mk) in enumerate([(3, 1, 16, 2), (4, 2, 16, 3), (5, 2, 20, 3), (4, 1, 50, 2), (6, 3, 16, 4),
-                                             (4, 2, 32, 2), (3, 4, 16, 2), (12, 4, 64, 16), (6, 2, 48, 3), (2, 1, 8, 1)]):
+                                             (4, 2, 32, 2), (3, 4, 16, 2), (12, 4, 64, 16), (6, 2, 48, 3), (2, 1, 8, 1),
+                                             (4, 2, 70, 2)]):  # n = 140: mid-size kind with four wavefronts, scalar factor
         B = 6
         if (nx, N) == (12, 64):
             from qpmpc_amd.workloads import synthetic_ltv_batch
