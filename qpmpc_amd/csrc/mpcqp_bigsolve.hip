@@ -582,6 +582,13 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
         for (int w = 0; w < NWV; ++w) {
             __syncthreads();
             if (wv == w) {
+                // The state travels from step to step in REGISTERS: after the quad sum every lane of quad r
+                // holds dx_{k+1}[r]; lane (r, c) fetches the entries c, c+4, c+8, c+12 it multiplies next from
+                // quads c + 4 jj with ds_bpermute (no LDS round trip on the critical path). dxs is still
+                // written -- the constraint rows and the next wavefront read it -- but nobody waits for it here.
+                T xc[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) xc[jj] = dxs[(w * SPW) * nx + min(c + 4 * jj, nx - 1)];
 #pragma unroll
                 for (int d = 0; d < SPW; ++d) {
                     const int k = w * SPW + d;
@@ -590,12 +597,13 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
                             const int sc = c + 4 * jj;  // operands past nx / nu are zero: clamp the index
-                            acc += ra[d][jj] * dxs[k * nx + min(sc, nx - 1)];
+                            acc += ra[d][jj] * xc[jj];
                             if (jj < 2) acc += rb[d][jj] * zx[k * nu + min(sc, nu - 1)];
                         }
                         acc = quad_sum(acc);
                         if (c == 0 && r < nx) dxs[(k + 1) * nx + r] = acc;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) xc[jj] = __shfl(acc, 4 * min(c + 4 * jj, 15));
                     }
                 }
             }
