@@ -667,15 +667,39 @@ __global__ void __launch_bounds__(64, 4)
 #pragma unroll
                 for (int k = 0; k < NV; ++k) R[k] = (lane == LB + k) ? T(1) : T(0);
             }
-        // R <- R L^-T, one row per lane; L[j][k] lives in lane j's Pr[k]
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            T acc = R[j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) acc -= R[k] * bcast(Pr[k], j);
-            R[j] = acc * bcast(myinv, j);
-            pin(R[j]);
+        // R <- R L^-T, one row per lane. L[j][k] lives in lane j's Pr[k]; it is broadcast through an LDS
+        // image (16-byte reads at a wavefront-uniform address: 80 LDS reads) instead of 272 v_readlane --
+        // in this phase every wavefront of the CU is VALU-bound at the same time and the LDS pipe is idle.
+        if (low) {
+            st16(Ll + lane * LDM, Pr);
+            Ll[lane * LDM + NV] = myinv;
         }
+        wsync();
+        {
+            using V = typename Vec<T>::type;
+            constexpr int W = Vec<T>::W;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const V *Lr = reinterpret_cast<const V *>(Ll + j * LDM);
+                T acc = R[j];
+#pragma unroll
+                for (int kk = 0; kk * W < j; ++kk) {
+                    const V t = Lr[kk];
+                    if constexpr (W == 2) {
+                        acc -= R[2 * kk] * t.x;
+                        if (2 * kk + 1 < j) acc -= R[2 * kk + 1] * t.y;
+                    } else {
+                        acc -= R[4 * kk] * t.x;
+                        if (4 * kk + 1 < j) acc -= R[4 * kk + 1] * t.y;
+                        if (4 * kk + 2 < j) acc -= R[4 * kk + 2] * t.z;
+                        if (4 * kk + 3 < j) acc -= R[4 * kk + 3] * t.w;
+                    }
+                }
+                R[j] = acc * Lr[NV / W].x;
+                pin(R[j]);
+            }
+        }
+        wsync();  // the M image below reuses the L image
         tick(3);
         if (lane == 0) st16(y0v, R);           // w = L^-1 q ; y0 = -w
         if (isc) st16(Ml + cid * LDM, R);      // image of M for the row-p broadcasts
