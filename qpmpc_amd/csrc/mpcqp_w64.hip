@@ -633,20 +633,50 @@ __global__ void __launch_bounds__(64, 4)
     // trailing update needs no sqrt: P[i][k] -= P[i][j] P[k][j] / piv.
     T myinv = T(1);  // lane j keeps 1 / L_jj
     if constexpr (MODE != MODE_MODEL) {
+    // Column j (one entry per lane) is broadcast through a double-buffered 16-entry LDS vector: column j+1
+    // is brought up to date and written FIRST in step j, so its round trip overlaps the rest of step j's
+    // updates. One write and <= 8 wavefront-uniform 16-byte reads per column replace 2 (15 - j) v_readlane.
+    {
+        using V = typename Vec<T>::type;
+        constexpr int W = Vec<T>::W;
+        T *cb = Ll + NV * LDM;  // two buffers of NV (+ a shadow entry for lanes >= 16), behind the L image
+        const int cw = low ? lane : NV;
+        cb[cw] = Pr[0];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const T piv = bcast(Pr[j], j);
-        if (!(piv > T(0))) notpd = true;
-        const T rinv = Cst<T>::rs(piv);
-        const T pij = Pr[j];         // P[i][j] of this lane's row, before scaling
-        const T t2 = pij * rinv * rinv;  // P[i][j] / piv
+        for (int j = 0; j < NV; ++j) {
+            const T *cbj = cb + (j & 1) * (NV + W);
+            T cv[NV];
 #pragma unroll
-        for (int k = j + 1; k < NV; ++k) {
-            Pr[k] -= t2 * bcast(pij, k);  // lane k holds P[k][j]
-            pin(Pr[k]);
+            for (int g = j / W; g < NV / W; ++g) {
+                const V t = reinterpret_cast<const V *>(cbj)[g];
+                if constexpr (W == 2) {
+                    cv[2 * g] = t.x;
+                    cv[2 * g + 1] = t.y;
+                } else {
+                    cv[4 * g] = t.x;
+                    cv[4 * g + 1] = t.y;
+                    cv[4 * g + 2] = t.z;
+                    cv[4 * g + 3] = t.w;
+                }
+            }
+            const T piv = cv[j];
+            if (!(piv > T(0))) notpd = true;
+            const T rinv = Cst<T>::rs(piv);
+            const T pij = Pr[j];             // P[i][j] of this lane's row, before scaling
+            const T t2 = pij * rinv * rinv;  // P[i][j] / piv
+            if (j + 1 < NV) {
+                Pr[j + 1] -= t2 * cv[j + 1];
+                pin(Pr[j + 1]);
+                (cb + ((j + 1) & 1) * (NV + W))[cw] = Pr[j + 1];
+            }
+#pragma unroll
+            for (int k = j + 2; k < NV; ++k) {
+                Pr[k] -= t2 * cv[k];  // cv[k] = P[k][j]
+                pin(Pr[k]);
+            }
+            Pr[j] = pij * rinv;  // L[i][j] (lane j: sqrt(piv))
+            if (lane == j) myinv = rinv;
         }
-        Pr[j] = pij * rinv;  // L[i][j] (lane j: sqrt(piv))
-        if (lane == j) myinv = rinv;
     }
     }
     tick(2);
@@ -958,7 +988,7 @@ template <typename T> static Lay make_lay(const KernelArgs &ka)
         y_build += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD);
     }
     int y_main = ka.m * LDM;  // the M image; the L image (16 x LDM) fits inside
-    if (y_main < NV * LDM) y_main = NV * LDM;
+    if (y_main < NV * LDM + 2 * (NV + 4)) y_main = NV * LDM + 2 * (NV + 4);  // L image + the two column buffers of the factorisation
     const int y_sz = al(y_build > y_main ? y_build : y_main);
     L.off_hv = L.off_Y + y_sz;
     o = L.off_hv + 64;
