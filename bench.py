@@ -74,8 +74,9 @@ def cpu_baseline(w, seconds: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000,
+                    help="timed steps (one step = 58 us: short runs end before the GPU reaches its sustained clocks)")
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU (configs[1]: 4096)")
     ap.add_argument("--shared-lti", action="store_true", help="stride-0 operands (not the headline mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -12,7 +12,7 @@ lines = []
 # ---- kernel stats (rocprofv3 --kernel-trace --stats)
 for f in glob.glob(src + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
-    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline")
+    lines.append("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2000 --warmup 200 --no-cpu-baseline")
     lines.append("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs")
     for r in rows[:8]:
         lines.append(",".join([r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]]))
