@@ -81,6 +81,7 @@ def main() -> None:
     ap.add_argument("--shared-lti", action="store_true", help="stride-0 operands (not the headline mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--spinup", type=float, default=0.25, help="seconds of untimed launches before the warm-up (clock ramp)")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-streams-in-flight measurement")
     args = ap.parse_args()
 
@@ -114,6 +115,13 @@ def main() -> None:
         if dist is not None:
             dist.barrier()
 
+    # Untimed device spin-up before the W warm-up steps: one step is ~55 us, so a short (W, K) would be over
+    # before the GPU has left its idle clocks (57 us/step measured that way against 54 us sustained).
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        for _ in range(100):
+            run.launch()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         run.launch()
     torch.cuda.synchronize()
@@ -215,6 +223,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "spinup_s": args.spinup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
