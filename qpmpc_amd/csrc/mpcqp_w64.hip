@@ -315,7 +315,15 @@ __device__ __forceinline__ float fast_rcp(float x)
     return fmaf(y, e, y);
 }
 // wavefront-level ordering of LDS traffic (a 64-thread workgroup needs no s_barrier)
-__device__ __forceinline__ void wsync() { __syncthreads(); }
+__device__ __forceinline__ void wsync()
+{
+    // One wavefront per workgroup: LDS operations of a wavefront complete in order, so what one lane
+    // wrote is what another lane reads next without any wait. Only the COMPILER has to keep the order
+    // (wavefront-scope fence); __syncthreads() would also drain the LDS queue (s_waitcnt lgkmcnt(0)) at
+    // every exchange, six times per active-set iteration.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <typename T> struct Cst;
 template <> struct Cst<double> {
