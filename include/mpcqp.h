@@ -120,7 +120,10 @@ int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes);
 
 /* Device scratch bytes that mpcqp_condense_batch (for_solve == 0) or
  * mpcqp_build_solve_batch (for_solve != 0) need for `batch` problems of these
- * dimensions: 0 when the problem fits the on-chip path. */
+ * dimensions: 0 for small problems solved entirely on chip; 2 n^2 elements per problem
+ * (rows of the active-set operator) for the mid-size fused kernel; the propagators, P
+ * and the same rows for large problems. The query sees dimensions only, so it reports the
+ * largest amount any kernel the launch may pick (it depends on the operand strides) needs. */
 int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solve, size_t *bytes);
 
 /* Same for mpcqp_solve_batch (n variables, m rows). */
