@@ -431,6 +431,191 @@ __device__ __forceinline__ bool factor_invert_mfma(float *Li, int n, int tid, fl
     return flag[0] != 0.0f;
 }
 
+// ------------------------------------------------------------------ blocked factor + inverse, float64 (mid-size kind)
+// Same scheme as factor_invert_mfma with 16 x 16 blocks on v_mfma_f64_16x16x4_f64. The matrix is padded to a
+// multiple of 16 with an identity block (chol(diag(P, I)) = diag(L, I)), which the caller provides: packed
+// triangle of npad = 16 ceil(n / 16) rows. Operand maps: A lane l -> A[l & 15][l >> 4], B lane l ->
+// B[l >> 4][l & 15]; C/D register t of lane l -> row (l >> 4) + 4 t, column l & 15 (NOT the f32 map).
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+__device__ __forceinline__ bool diag_block_invert64(double *Li, int J, int lane, double *colbuf)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    int r = lane & 15;
+    asm volatile("" : "+v"(r));  // see diag_block_invert: keeps the lane predicates out of the caller's loops
+    const int c0 = 16 * J;
+    double *row = Li + tri(c0 + r, 0) + c0;
+    double d[16], w[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double dl = row[c];
+        d[c] = (c <= r) ? dl : 0.0;
+    }
+    bool ok = true;
+    double *rinvs = colbuf + 16;  // 1 / L_cc, read back as broadcasts by the inverse
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (lane < 16) colbuf[r] = d[c];  // column c before scaling
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double cv[16];
+#pragma unroll
+        for (int g = c / 2; g < 8; ++g) {
+            const d2 v = *reinterpret_cast<const d2 *>(colbuf + 2 * g);
+            cv[2 * g] = v[0];
+            cv[2 * g + 1] = v[1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const double piv = cv[c];
+        ok = ok && (piv > 0.0);
+        const double rinv = fast_rsqrt(piv);
+        if (lane == 0) rinvs[c] = rinv;
+        const double f = (r >= c) ? d[c] * (rinv * rinv) : 0.0;
+        d[c] *= rinv;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+            d[c2] -= f * cv[c2];
+            asm volatile("" : "+v"(d[c2]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c <= r) row[c] = d[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // lane r = column r of W = L^-1
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const double *ri = Li + tri(c0 + i, 0) + c0;  // uniform address: broadcast reads
+        double acc = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) acc -= ri[k] * w[k];
+        w[i] = acc * rinvs[i];
+        asm volatile("" : "+v"(w[i]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i >= r) Li[tri(c0 + i, 0) + c0 + r] = w[i];
+    }
+    return ok;
+}
+
+// npad: multiple of 16 (rows n..npad-1 of the packed triangle hold the identity); four wavefronts.
+__device__ __forceinline__ bool factor_invert_mfma64(double *Li, int npad, int tid, double *red, double *scratch)
+{
+    const int nb = npad >> 4, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    double *flag = red + 7;
+    if (tid == 0) flag[0] = 1.0;
+    __syncthreads();
+    for (int J = 0; J < nb; ++J) {
+        const int c0 = 16 * J;
+        if (wv == 0) {
+            const bool ok = diag_block_invert64(Li, J, lane, scratch);
+            if (!ok && lane == 0) flag[0] = 0.0;
+        }
+        __syncthreads();
+        // panel: L[I,J] = A[I,J] W_J'
+        for (int I = J + 1 + wv; I < nb; I += 4) {
+            const double *arow = Li + tri(16 * I + l15, 0) + c0;
+            const double *brow = Li + tri(c0 + l15, 0) + c0;
+            double a[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) a[s2] = arow[4 * s2 + kq];
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int k = 4 * s2 + kq;
+                const double bl = brow[k];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s2], (k <= l15) ? bl : 0.0, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Li[tri(16 * I + kq + 4 * t, 0) + c0 + l15] = acc[t];
+        }
+        __syncthreads();
+        // trailing update: A[I,I2] -= L[I,J] L[I2,J]'
+        int cnt = 0;
+        for (int I = J + 1; I < nb; ++I)
+            for (int I2 = J + 1; I2 <= I; ++I2, ++cnt) {
+                if ((cnt & 3) != wv) continue;
+                const double *arow = Li + tri(16 * I + l15, 0) + c0;
+                const double *brow = Li + tri(16 * I2 + l15, 0) + c0;
+                const bool dg = (I2 == I);
+                f64x4 acc;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = kq + 4 * t;
+                    const double cl = Li[tri(16 * I + rr, 0) + 16 * I2 + l15];
+                    acc[t] = (!dg || l15 <= rr) ? cl : 0.0;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const int k = 4 * s2 + kq;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[k], brow[k], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = kq + 4 * t;
+                    if (!dg || l15 <= rr) Li[tri(16 * I + rr, 0) + 16 * I2 + l15] = acc[t];
+                }
+            }
+        __syncthreads();
+    }
+    // inverse, block row by block row
+    for (int I = 1; I < nb; ++I) {
+        const int r0 = 16 * I;
+        for (int K = wv; K < I; K += 4) {  // L'[I,K] = W_I L[I,K]
+            const double *wrow = Li + tri(r0 + l15, 0) + r0;
+            double bv[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) bv[s2] = Li[tri(r0 + 4 * s2 + kq, 0) + 16 * K + l15];
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int k = 4 * s2 + kq;
+                const double al = wrow[k];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((k <= l15) ? al : 0.0, bv[s2], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Li[tri(r0 + kq + 4 * t, 0) + 16 * K + l15] = acc[t];
+        }
+        __syncthreads();
+        // X[I,Jt] = - sum_K L'[I,K] X[K,Jt]: in registers until every wavefront has read row block I
+        f64x4 acc2[3];
+#pragma unroll
+        for (int qd = 0; qd < 3; ++qd) {
+            const int Jt = wv + 4 * qd;
+            acc2[qd] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (Jt < I) {
+                for (int K = Jt; K < I; ++K) {
+                    const double *arow = Li + tri(r0 + l15, 0) + 16 * K;
+                    const bool dg = (K == Jt);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) {
+                        const int k = 4 * s2 + kq;
+                        const double bl = Li[tri(16 * K + k, 0) + 16 * Jt + l15];
+                        acc2[qd] = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[k], (!dg || l15 <= k) ? bl : 0.0, acc2[qd], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qd = 0; qd < 3; ++qd) {
+            const int Jt = wv + 4 * qd;
+            if (Jt < I) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Li[tri(r0 + kq + 4 * t, 0) + 16 * Jt + l15] = -acc2[qd][t];
+            }
+        }
+        __syncthreads();
+    }
+    return flag[0] != 0.0;
+}
+
 // quad-local sums (lanes 4q .. 4q+3) on the DPP path
 __device__ __forceinline__ float quad_sum(float v)
 {
@@ -468,7 +653,7 @@ __device__ __forceinline__ double quad_sum(double v)
 enum { K_DENSE = 0, K_STRUCT = 1, K_MID = 2 };
 
 template <typename T, int KIND, int NWV>
-__global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
+__global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) == 8) ? 4 : 1) mpcqp_bigsolve_kernel(const KernelArgs ka, const T *__restrict__ Pall,
                                                             const T *__restrict__ qall, const T *__restrict__ Gall,
                                                             const T *__restrict__ aux, const T *__restrict__ hall,
                                                             const T *__restrict__ aux2, T *__restrict__ wsall)
@@ -483,7 +668,8 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
     static_assert(NWV == 4 || KIND == K_MID, "the large-problem kinds are laid out for four wavefronts");
     // LDS carve
     T *Li = (T *)smem_raw;              // packed lower triangle: P -> L -> L^-1
-    T *sv = Li + n * (n + 1) / 2;       // slacks            [m]
+    const int npad = MID ? ((n + 15) & ~15) : n;  // mid-size kind: triangle padded to 16-row blocks (identity rows)
+    T *sv = Li + npad * (npad + 1) / 2;  // slacks            [m]
     T *gin = sv + m;                    // 1 / |G_i|          [m]
     T *tolv = gin + m;                  // tol (1 + |h_i|)    [m]
     T *y0 = tolv + m;                   // -L^-1 q            [n]
@@ -716,7 +902,7 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
             for (int i = tid; i < (sCk ? N : 1) * mk * nx; i += BS) opC[i] = gC[i];
         if (gD)
             for (int i = tid; i < (sDk ? N : 1) * mk * nu; i += BS) opD[i] = gD[i];
-        for (int i = tid; i < n * (n + 1) / 2; i += BS) Li[i] = T(0);
+        for (int i = tid; i < npad * (npad + 1) / 2; i += BS) Li[i] = T(0);
         for (int i = tid; i < nx * n; i += BS) psiA[i] = T(0);
         for (int i = tid; i < nx * nx; i += BS) Sm[i] = T(0);
         // e and the reference trajectory go to LDS as well (no global load inside the step loop):
@@ -896,6 +1082,7 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
         __syncthreads();
         if (tq >= 0 && tq < n) tmp[tq] = qacc;  // q, consumed below
         if (tid < n) Li[tri(tid, tid)] += (T)ka.wu;
+        for (int i = n + tid; i < npad; i += BS) Li[tri(i, i)] = T(1);
     } else {
         // ---- packed lower triangle of P
         if ((n & 3) == 0) {
@@ -943,7 +1130,10 @@ __global__ void __launch_bounds__(64 * NWV) mpcqp_bigsolve_kernel(const KernelAr
             pd = factor_small_or_scalar(Li, n, tid, red);
         }
     } else {
-        pd = factor_small_or_scalar(Li, n, tid, red);
+        if constexpr (MID && NWV == 4)
+            pd = factor_invert_mfma64(Li, npad, tid, red, mp);  // mp (n >= 32 entries) is free until the first iteration
+        else
+            pd = factor_small_or_scalar(Li, n, tid, red);
     }
     if (!pd) {
         status = MPCQP_NOT_PD;
@@ -1364,6 +1554,8 @@ static size_t mid_extra_elems(const KernelArgs &ka)
     if (ka.C.ptr) el += (size_t)(ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx;
     if (ka.D.ptr) el += (size_t)(ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu;
     el += 2 * (size_t)ka.nx * ka.n + 6 * (size_t)ka.nx + 3 * (size_t)ka.nx * ka.nx;
+    const size_t np = ((size_t)ka.n + 15) & ~(size_t)15;
+    el += np * (np + 1) / 2 - (size_t)ka.n * (ka.n + 1) / 2;  // triangle padded to 16-row blocks
     return el;
 }
 // Fused build+solve of mid-size problems in one launch; LDS capped so that at least two problems share a CU.
