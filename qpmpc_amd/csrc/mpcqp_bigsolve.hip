@@ -1021,7 +1021,7 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
                         for (int u = 0; u < nu; ++u) nn += dr[u] * dr[u];
                     }
                     tolv[k * mk + r] -= acc;
-                    gin[k * mk + r] = (nn > T(0)) ? T(1) / sqrt(nn) : T(1);
+                    gin[k * mk + r] = (nn > T(0)) ? fast_rsqrt(nn) : T(1);
                 }
                 // Psi_{k+1} = A_k Psi_k, block k <- B_k
                 for (int e2 = BS - 1 - tid; e2 < nx * n; e2 += BS) {
@@ -1050,14 +1050,15 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
                         }
                         rn[l] = acc - ref;
                     }
-                    for (int e2 = l; e2 < nx * nx; e2 += 64) {
+                    // S is only needed for the norms of rows with a state part: skipped without C (config 3)
+                    for (int e2 = l; gC && e2 < nx * nx; e2 += 64) {
                         const int a = e2 / nx, b = e2 - a * nx;
                         T acc = T(0);
                         for (int u = 0; u < nx; ++u) acc += Ak[a * nx + u] * Sc[u * nx + b];
                         T1[e2] = acc;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    for (int e2 = l; e2 < nx * nx; e2 += 64) {
+                    for (int e2 = l; gC && e2 < nx * nx; e2 += 64) {
                         const int a = e2 / nx, b = e2 - a * nx;
                         T acc = T(0);
                         for (int u = 0; u < nx; ++u) acc += T1[a * nx + u] * Ak[b * nx + u];
