@@ -1133,6 +1133,8 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
     } else {
         if constexpr (MID && NWV == 4)
             pd = factor_invert_mfma64(Li, npad, tid, red, mp);  // mp (n >= 32 entries) is free until the first iteration
+        else if constexpr (NWV == 4)
+            pd = ((n & 15) == 0 && n <= 192) ? factor_invert_mfma64(Li, n, tid, red, mp) : factor_small_or_scalar(Li, n, tid, red);
         else
             pd = factor_small_or_scalar(Li, n, tid, red);
     }
