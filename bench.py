@@ -71,6 +71,46 @@ def cpu_baseline(w, seconds: float = 12.0):
     }
 
 
+def other_workloads():
+    """Rates of the other BASELINE.json configurations on this GPU (rank 0, one GPU only; never `value`):
+    a few launches each, HIP events on the launch stream. Parity for these is in tests/ (-m gpu)."""
+    import numpy as np
+    import torch
+
+    from qpmpc_amd import PreparedSolve, SharedModel
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.closed_loop import LIPMWalkingLoop, WIPClosedLoop
+
+    def rate(run, batch, reps):
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return batch * reps / (e0.elapsed_time(e1) * 1e-3)
+
+    out = {}
+    w = W.wip_batch(1024)
+    out["config3_wip_n50_fused_batch1024"] = rate(PreparedSolve(W.to_batch_problem(w)).launch, 1024, 20)
+    rng = np.random.default_rng(1)
+    loop = WIPClosedLoop(rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1]))
+    out["config3_closed_loop_rebuild_every_step"] = rate(loop.step, 1024, 50)
+    w = W.humanoid_batch(65536)
+    bp = W.to_batch_problem(w)
+    out["config4_humanoid_sweep_65536_fused"] = rate(PreparedSolve(bp).launch, 65536, 10)
+    out["config4_humanoid_sweep_65536_shared_model"] = rate(SharedModel(bp).prepare(bp).launch, 65536, 10)
+    w = W.synthetic_ltv_batch(1024)
+    out["config5_synthetic_ltv_n256_m1024_f32_batch1024"] = rate(
+        PreparedSolve(W.to_batch_problem(w, dtype=torch.float32)).launch, 1024, 5)
+    walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
+    out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
+    return {k: float(v) for k, v in out.items()} | {"unit": "problems/s (builds+solves/s for the loops)"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +122,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spinup", type=float, default=0.25, help="seconds of untimed launches before the warm-up (clock ramp)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations")
     ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-streams-in-flight measurement")
     args = ap.parse_args()
 
@@ -263,6 +304,11 @@ def main() -> None:
         }
         if overlap is not None:
             out["overlap_2_streams"] = overlap
+        if not args.no_extras and world == 1:
+            try:
+                out["other_workloads"] = other_workloads()
+            except Exception as exc:  # never at the expense of the headline line
+                out["other_workloads"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
