@@ -15,7 +15,8 @@
  *    not fit the on-chip path need a caller-provided scratch `workspace` whose size
  *    the *_workspace_bytes functions report (0 for the on-chip path; NULL is then fine);
  *  - every call is asynchronous on the caller's hipStream_t (passed as void*;
- *    NULL = the null stream), re-entrant, no global state;
+ *    NULL = the null stream), re-entrant, no global state (nothing is read from the
+ *    process environment; dispatch overrides are explicit MpcqpSolveOpts.flags);
  *  - return value: 0 ok, <0 bad argument (MPCQP_E*), >0 a hipError_t;
  *    per-problem outcome is reported in status[b], never by the return value;
  *  - matrices are row-major and densely packed; one batch item after another
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 4
+#define MPCQP_ABI_VERSION 5
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -100,11 +101,35 @@ typedef struct MpcqpProblem {
     MpcqpOperand targets; /* N*nx          target_states   (nullable)           */
 } MpcqpProblem;
 
+/* MpcqpSolveOpts.flags -- explicit kernel-dispatch overrides. 0 in production: the library picks the
+ * kernel from the dimensions. Tests set them to cross-check two formulations of the same solver on the
+ * same batch (they replace the MPCQP_FORCE_* environment switches of ABI 4: no hidden process state). */
+#define MPCQP_OPT_FORCE_LDS 1      /* everything that fits one CU's LDS goes to the workgroup kernel      */
+#define MPCQP_OPT_FORCE_GWS 2      /* large QPs: general kernel with its arrays in the workspace          */
+#define MPCQP_OPT_FORCE_DENSE_G 4  /* large fused path: form G (and its transpose) instead of applying it */
+#define MPCQP_OPT_ONE_PER_WAVE 8   /* small problems: one problem per wavefront instead of two            */
+
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
-    int32_t reserved;
+    int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */
     double feas_tol;  /* a row is violated when (h_i-G_i u)/(1+|h_i|) < -tol;
                          <=0 -> 1e-12 (f64) / 1e-5 (f32)                         */
+    /* Warm start (the reference reaches it through **kwargs -> qpsolvers' initvals,
+     * qpmpc/solve_mpc.py:20,43): warm_active[b*warm_stride + a], a < warm_count, lists constraint
+     * rows (0 <= row < m, or -1 = none) expected to be active at the solution of problem b, e.g. the
+     * previous period's active set shifted by one step. The solver adds them first, in that order,
+     * and then continues as usual, so a wrong guess costs iterations, never correctness. NULL = cold. */
+    const int32_t *warm_active;
+    int32_t warm_count;
+    int32_t warm_stride;
+    /* Final active set, nullable: active_out[b*active_stride + a] = constraint row held by slot a,
+     * -1 padded (a < active_stride, at most n rows are ever active). Feeds the next warm start. */
+    int32_t *active_out;
+    int32_t active_stride;
+    int32_t reserved;
+    /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (8 for the small-problem
+     * kernels, 32 for the mid-size / large ones) that receives shader-clock stamps at phase boundaries. */
+    void *probe;
 } MpcqpSolveOpts;
 
 /* ABI version of the loaded library (== MPCQP_ABI_VERSION of its build). */

@@ -13,7 +13,8 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
+OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE = 1, 2, 4, 8
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -54,7 +55,12 @@ class Problem(C.Structure):
 
 
 class SolveOpts(C.Structure):
-    _fields_ = [("max_iter", C.c_int32), ("reserved", C.c_int32), ("feas_tol", C.c_double)]
+    _fields_ = [
+        ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
+        ("warm_active", C.c_void_p), ("warm_count", C.c_int32), ("warm_stride", C.c_int32),
+        ("active_out", C.c_void_p), ("active_stride", C.c_int32), ("reserved", C.c_int32),
+        ("probe", C.c_void_p),
+    ]
 
 
 _lib = None

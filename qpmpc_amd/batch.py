@@ -327,8 +327,18 @@ def _ws_args(ws):
     return (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
 
 
-def _opts(max_iter=None, feas_tol=None):
-    return _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))
+def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_active=None, active_out=None, probe=None):
+    """``MpcqpSolveOpts``. ``warm_active`` / ``active_out`` are int32 device tensors [B, k] (row ids, -1 = none);
+    ``flags`` are the explicit dispatch overrides ``_capi.OPT_*`` (tests); ``probe`` an int64 device tensor."""
+    o = _capi.SolveOpts()
+    o.max_iter, o.flags, o.feas_tol = int(max_iter or 0), int(flags), float(feas_tol or 0.0)
+    if warm_active is not None:
+        o.warm_active, o.warm_count, o.warm_stride = warm_active.data_ptr(), int(warm_active.shape[1]), int(warm_active.stride(0))
+    if active_out is not None:
+        o.active_out, o.active_stride = active_out.data_ptr(), int(active_out.stride(0))
+    if probe is not None:
+        o.probe = probe.data_ptr()
+    return o
 
 
 class BatchPlan:
@@ -369,9 +379,13 @@ class BatchPlan:
 
 
 def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_multipliers: bool = False,
-                    max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> BatchPlan:
+                    max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw) -> BatchPlan:
     """Build and solve every problem of the batch in ONE fused launch
-    (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem)."""
+    (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem).
+
+    ``opt_kw``: ``warm_active`` (int32 [B, k] device tensor: rows expected active, -1 = none),
+    ``active_out`` (int32 [B, >= n] device tensor receiving the final active set), ``flags``
+    (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
     if solver not in HIP_SOLVERS:
         raise BackendError(f"solver '{solver}' is not a batched backend; available: {HIP_SOLVERS}")
     torch = _torch()
@@ -382,14 +396,14 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
-    dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol)
+    dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol, **opt_kw)
     ws = _workspace(problem, True)
     rc = lib.mpcqp_build_solve_batch(
         C.byref(dims), C.byref(cp), Bn, C.byref(opts), U.data_ptr(),
         None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), *_ws_args(ws), _stream_ptr())
     _capi.check(rc, "mpcqp_build_solve_batch")
     plan = BatchPlan(problem, U, status, iters, lam)
-    plan._workspace = ws  # keep the scratch alive until the stream has consumed it
+    plan._workspace = (ws, opt_kw)  # keep the scratch (and the opts' tensors) alive until the stream has consumed them
     return plan
 
 
@@ -403,17 +417,18 @@ class PreparedSolve:
     """
 
     def __init__(self, problem: BatchMPCProblem, return_multipliers: bool = False,
-                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None):
+                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw):
         torch = _torch()
         self._lib = _capi.load()
         _require_on_gpu(problem.initial_state)
         self.problem = problem
+        self._opt_kw = opt_kw  # tensors referenced by the opts struct stay alive with the object
         Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
         self.U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
         self.lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
-        self._opts = _opts(max_iter, feas_tol)
+        self._opts = _opts(max_iter, feas_tol, **opt_kw)
         self._ws = _workspace(problem, True)
         self.rebind()
 
@@ -492,8 +507,8 @@ class SharedModel:
                                target_states=targets, dtype=t.dtype, device=t.device)
 
     def prepare(self, problem: BatchMPCProblem, return_multipliers: bool = False,
-                max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> "PreparedModelSolve":
-        return PreparedModelSolve(self, problem, return_multipliers, max_iter, feas_tol)
+                max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw) -> "PreparedModelSolve":
+        return PreparedModelSolve(self, problem, return_multipliers, max_iter, feas_tol, **opt_kw)
 
     def solve(self, x0, goal=None, targets=None, return_multipliers: bool = False,
               max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> BatchPlan:
@@ -507,10 +522,11 @@ class PreparedModelSolve:
     states IN PLACE between launches."""
 
     def __init__(self, model: SharedModel, problem: BatchMPCProblem, return_multipliers: bool = False,
-                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None):
+                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw):
         torch = _torch()
         self._lib = _capi.load()
         self.model, self.problem = model, problem
+        self._opt_kw = opt_kw
         flags = model.dims.flags
         if (flags & _capi.Q_TERMINAL) and problem.goal_state is None:
             raise ProblemDefinitionError("MPC problem has terminal cost but the goal state is undefined")
@@ -521,7 +537,7 @@ class PreparedModelSolve:
         self.lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
-        self._opts = _opts(max_iter, feas_tol)
+        self._opts = _opts(max_iter, feas_tol, **opt_kw)
         self.rebind()
 
     def rebind(self) -> None:
@@ -585,11 +601,11 @@ class BatchMPCQP:
         """h = e - C Phi x0 for a new x0 (mpc_qp.py:151-163)."""
         self._update(problem, False, True)
 
-    def solve(self, return_multipliers: bool = False, max_iter=None, feas_tol=None):
-        return solve_qp_batch(self.P, self.q, self.G, self.h, return_multipliers, max_iter, feas_tol)
+    def solve(self, return_multipliers: bool = False, max_iter=None, feas_tol=None, **opt_kw):
+        return solve_qp_batch(self.P, self.q, self.G, self.h, return_multipliers, max_iter, feas_tol, **opt_kw)
 
 
-def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, feas_tol=None):
+def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, feas_tol=None, **opt_kw):
     """Batched dense QP solve, ``min 1/2 x'Px + q'x s.t. Gx <= h`` per item
     (replaces ``qpsolvers.solve_problem`` at solve_mpc.py:43).
     Returns (x [B,n], lam [B,m] | None, status [B], iters [B])."""
@@ -605,7 +621,7 @@ def solve_qp_batch(P, q, G, h, return_multipliers: bool = False, max_iter=None, 
     lam = torch.empty((Bn, m), dtype=P.dtype, device=P.device) if return_multipliers else None
     status = torch.empty((Bn,), dtype=torch.int32, device=P.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=P.device)
-    opts = _opts(max_iter, feas_tol)
+    opts = _opts(max_iter, feas_tol, **opt_kw)
     nbytes = C.c_size_t(0)
     _capi.check(lib.mpcqp_solve_workspace_bytes(n, m, _dtype_code(P.dtype), Bn, C.byref(nbytes)),
                 "mpcqp_solve_workspace_bytes")

@@ -1,15 +1,26 @@
-"""Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+Every translation unit is compiled to its own object (in parallel, only when its
+source or a header is newer) and the objects are linked into
+``qpmpc_amd/lib/libmpcqp_hip.so``. Objects and the library are git-ignored; the
+library travels to the GPU box with the tree.
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip", "mpcqp_model.hip", "mpcqp_capi.hip")]
+_UNITS = ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_pair.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip",
+          "mpcqp_model.hip", "mpcqp_stage.hip", "mpcqp_capi.hip")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in _UNITS]
 HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h"), os.path.join(_PKG, "csrc", "mpcqp_internal.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libmpcqp_hip.so")
+OBJ_DIR = os.path.join(_PKG, "lib", "obj")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _hipcc() -> str:
@@ -19,29 +30,50 @@ def _hipcc() -> str:
     raise FileNotFoundError("hipcc not found (set HIPCC=...)")
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(s)]
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in SOURCES + HEADERS)
+    return any(os.path.getmtime(s) > t for s in _sources() + HEADERS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def _obj_for(src: str) -> str:
+    return os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+
+
+def _compile(src: str, force: bool, verbose: bool, extra) -> str:
+    obj = _obj_for(src)
+    deps = [src] + HEADERS
+    if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+        return obj
+    cmd = [_hipcc(), *FLAGS, *extra, "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_PKG, "csrc"),
+           "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     """hipcc --offload-arch=gfx950 -> qpmpc_amd/lib/libmpcqp_hip.so"""
     if not force and not is_stale():
         return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(s)]
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_PKG, "csrc"),
-        *srcs, "-o", LIB_PATH,
-    ]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force, verbose, list(extra_flags)), srcs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -825,8 +825,8 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
     T *oU = (T *)ka.U + prob * (int64_t)n;
     const T tol = (T)ka.tol;
     int status = MPCQP_MAX_ITER, iters = 0;
-    // optional phase timestamps (tools/probe_big_phases.py): ka.X -> long long[8] per problem
-    long long *stamp = ka.X ? (long long *)ka.X + prob * 32 : nullptr;
+    // optional phase timestamps (tools/probe_big_phases.py): MpcqpSolveOpts.probe -> long long[8] per problem
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 32 : nullptr;
     auto mark = [&](int slot) {
         if (stamp && tid == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };

@@ -69,10 +69,25 @@ void fill_args(KernelArgs &ka, const MpcqpDims *d, const MpcqpProblem *p)
     }
 }
 
-void fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
+int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
 {
     ka.max_iter = (o && o->max_iter > 0) ? o->max_iter : 10 * (ka.n + ka.m) + 10;
     ka.tol = (o && o->feas_tol > 0.0) ? o->feas_tol : (dtype == MPCQP_F64 ? 1e-12 : 1e-5);
+    if (!o) return 0;
+    ka.opt_flags = o->flags;
+    ka.probe = o->probe;
+    if (o->warm_active) {
+        if (o->warm_count < 0 || o->warm_stride < o->warm_count) return MPCQP_EINVAL;
+        ka.warm_active = o->warm_count > 0 ? o->warm_active : nullptr;
+        ka.warm_count = o->warm_count;
+        ka.warm_stride = o->warm_stride;
+    }
+    if (o->active_out) {
+        if (o->active_stride <= 0) return MPCQP_EINVAL;
+        ka.active_out = o->active_out;
+        ka.active_stride = o->active_stride;
+    }
+    return 0;
 }
 
 int layout_for(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype, Layout &L)
@@ -83,43 +98,30 @@ int layout_for(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype
     return 0;
 }
 
-// MPCQP_FORCE_LDS=1 routes small problems through the general LDS kernel too
-// (A/B measurements and cross-checking the two solver formulations).
-bool force_lds()
-{
-    const char *v = getenv("MPCQP_FORCE_LDS");
-    return v && v[0] == '1';
-}
+// Dispatch overrides are explicit bits of MpcqpSolveOpts.flags (no process-wide state):
+// MPCQP_OPT_FORCE_LDS routes small problems through the general LDS kernel too, MPCQP_OPT_FORCE_GWS keeps
+// large QPs on the general kernel with its arrays in the workspace, MPCQP_OPT_FORCE_DENSE_G makes the fused
+// large path form G instead of applying it through the roll-out (cross-checks of two formulations).
+bool force_lds(int fl) { return fl & MPCQP_OPT_FORCE_LDS; }
+bool force_gws(int fl) { return fl & MPCQP_OPT_FORCE_GWS; }
+bool force_dense_g(int fl) { return fl & MPCQP_OPT_FORCE_DENSE_G; }
+// every combination of overrides a launch may carry: the workspace queries, which see no opts, report the
+// largest amount any of them needs
+const int kFlagVariants[] = {0, MPCQP_OPT_FORCE_LDS, MPCQP_OPT_FORCE_GWS, MPCQP_OPT_FORCE_DENSE_G};
 
-// MPCQP_FORCE_GWS=1 keeps large QPs on the general kernel with its arrays in the workspace
-// (cross-checking the two large-problem solvers).
-bool force_gws()
-{
-    const char *v = getenv("MPCQP_FORCE_GWS");
-    return v && v[0] == '1';
-}
-
-bool use_bigsolve(int n, int m, int dtype) { return !force_gws() && m > 0 && bigsolve_supported(n, m, dtype); }
+bool use_bigsolve(int n, int m, int dtype, int fl) { return !force_gws(fl) && m > 0 && bigsolve_supported(n, m, dtype); }
 
 // Per-problem solver scratch (elements) for QPs that do not fit the on-chip kernels.
-size_t solver_ws_elems(int n, int m, int dtype)
+size_t solver_ws_elems(int n, int m, int dtype, int fl)
 {
-    if (use_bigsolve(n, m, dtype)) return (size_t)m * n + bigsolve_ws_elems(n);  // G' + M_A + N*
+    if (use_bigsolve(n, m, dtype, fl)) return (size_t)m * n + bigsolve_ws_elems(n);  // G' + M_A + N*
     const Layout L = make_layout(1, 1, n, n, m, false, false, MODE_SOLVE, elem_size(dtype));
     return (size_t)L.total;
 }
 
-// MPCQP_FORCE_DENSE_G=1 makes the fused large path form G (and its transpose) instead of applying
-// it through the roll-out (cross-checking the two).
-bool force_dense_g()
-{
-    const char *v = getenv("MPCQP_FORCE_DENSE_G");
-    return v && v[0] == '1';
-}
-
 bool use_struct(const KernelArgs &ka, int dtype)
 {
-    return !force_gws() && !force_dense_g() && bigsolve_struct_supported(ka, dtype);
+    return !force_gws(ka.opt_flags) && !force_dense_g(ka.opt_flags) && bigsolve_struct_supported(ka, dtype);
 }
 
 // Sizes (in elements) of the pieces of the large-path workspace, per problem.
@@ -143,17 +145,17 @@ BigPlan big_plan(const KernelArgs &ka, int dtype, bool condense, bool solve)
             b.solver = bigsolve_ws_elems(ka.n);
         } else {
             b.G = (size_t)ka.m * ka.n;
-            b.solver = solver_ws_elems(ka.n, ka.m, dtype);
+            b.solver = solver_ws_elems(ka.n, ka.m, dtype, ka.opt_flags);
         }
     }
     return b;
 }
 
 // Mid-size fused problems (config 3) go to the lean one-launch kernel unless the small-problem kernel
-// takes them or MPCQP_FORCE_LDS=1 asks for the all-in-LDS kernel (cross-checks).
+// takes them or MPCQP_OPT_FORCE_LDS asks for the all-in-LDS kernel (cross-checks).
 bool use_mid(const KernelArgs &ka, int dtype)
 {
-    return !force_lds() && !w64_eligible(ka, MODE_FUSED, dtype) && mid_supported(ka, dtype);
+    return !force_lds(ka.opt_flags) && !w64_eligible(ka, MODE_FUSED, dtype) && mid_supported(ka, dtype);
 }
 
 // mpcqp_workspace_bytes sees the dimensions only, not the operand strides: it reports the mid-size
@@ -168,7 +170,7 @@ bool problem_strides_unknown_mid(KernelArgs ka, int dtype)
 
 bool fits_on_chip(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype)
 {
-    if (!force_lds() && w64_eligible(ka, mode, dtype)) return true;
+    if (!force_lds(ka.opt_flags) && w64_eligible(ka, mode, dtype)) return true;
     Layout L;
     return layout_for(ka, stepA, stepB, mode, dtype, L) == 0;
 }
@@ -178,8 +180,8 @@ int run_gws_solve(KernelArgs ka, int dtype, int64_t batch, void *ws, size_t ws_b
 {
     if (ka.n > 256) return MPCQP_ETOOLARGE;
     const size_t esz = elem_size(dtype);
-    if (!ws || ws_bytes < solver_ws_elems(ka.n, ka.m, dtype) * esz * (size_t)batch) return MPCQP_EWORKSPACE;
-    if (use_bigsolve(ka.n, ka.m, dtype)) {
+    if (!ws || ws_bytes < solver_ws_elems(ka.n, ka.m, dtype, ka.opt_flags) * esz * (size_t)batch) return MPCQP_EWORKSPACE;
+    if (use_bigsolve(ka.n, ka.m, dtype, ka.opt_flags)) {
         // L^-1 packed in LDS, lazy rows of M; needs G transposed (coalesced slack updates)
         void *GT = ws;
         void *rest = (char *)ws + (size_t)ka.m * ka.n * esz * (size_t)batch;
@@ -195,7 +197,10 @@ int run_gws_solve(KernelArgs ka, int dtype, int64_t batch, void *ws, size_t ws_b
 template <int MODE>
 int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t batch, hipStream_t st)
 {
-    if (!force_lds() && w64_eligible(ka, MODE, dtype)) return launch_w64(ka, MODE, dtype, batch, st);
+    if (!force_lds(ka.opt_flags)) {
+        if (!(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE, dtype)) return launch_pair(ka, batch, st);
+        if (w64_eligible(ka, MODE, dtype)) return launch_w64(ka, MODE, dtype, batch, st);
+    }
     Layout L;
     int rc = layout_for(ka, stepA, stepB, MODE, dtype, L);
     if (rc) return rc;
@@ -244,19 +249,24 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
     fill_args(ka, dims, nullptr);
     *bytes = 0;
     const int mode = for_solve ? MODE_FUSED : MODE_CONDENSE;
-    // The query sees dimensions, not operand strides, while the launch picks its kernel with the strides
-    // (bulkier operands need more LDS): report the LARGEST workspace any path the launch may take needs.
+    // The query sees dimensions, not operand strides or MpcqpSolveOpts.flags, while the launch picks its kernel
+    // with both (bulkier operands need more LDS): report the LARGEST workspace any path the launch may take needs.
     size_t need = 0;
-    const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
-    if (maybe_mid) need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
-    if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
-        if (big_supported(ka) && ka.n <= 256) {
-            const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
-            const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
-            if (big > need) need = big;
-        } else if (!maybe_mid) {
-            return MPCQP_ETOOLARGE;
+    for (int fl : kFlagVariants) {
+        ka.opt_flags = fl;
+        const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
+        size_t v = 0;
+        if (maybe_mid) v = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
+        if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
+            if (big_supported(ka) && ka.n <= 256) {
+                const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
+                const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
+                if (big > v) v = big;
+            } else if (!maybe_mid) {
+                return MPCQP_ETOOLARGE;
+            }
         }
+        if (v > need) need = v;
     }
     *bytes = need;
     return 0;
@@ -275,7 +285,12 @@ int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t bat
     *bytes = 0;
     if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype)) return 0;
     if (n > 256) return MPCQP_ETOOLARGE;
-    *bytes = solver_ws_elems(n, m, dtype) * elem_size(dtype) * (size_t)batch;
+    size_t need = 0;
+    for (int fl : kFlagVariants) {
+        const size_t v = solver_ws_elems(n, m, dtype, fl) * elem_size(dtype) * (size_t)batch;
+        if (v > need) need = v;
+    }
+    *bytes = need;
     return 0;
 }
 
@@ -361,7 +376,7 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const 
     ka.lam = lam;
     ka.status = status;
     ka.iters = iters;
-    fill_opts(ka, opts, dtype);
+    if (int rc = fill_opts(ka, opts, dtype)) return rc;
     if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype))
         return run_solver<MODE_SOLVE>(ka, false, false, dtype, batch, (hipStream_t)stream);
     return run_gws_solve(ka, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream);
@@ -382,8 +397,7 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     ka.lam = lam;
     ka.status = status;
     ka.iters = iters;
-    fill_opts(ka, opts, dims->dtype);
-    if (const char *dbg = getenv("MPCQP_STAMP_PTR")) ka.X = (void *)strtoull(dbg, nullptr, 0);  // dev probe only
+    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (use_mid(ka, dims->dtype)) {
@@ -470,9 +484,9 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const Mpcq
     ka.lam = lam;
     ka.status = status;
     ka.iters = iters;
-    fill_opts(ka, opts, dims->dtype);
+    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (!force_lds() && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
+    if (!force_lds(ka.opt_flags) && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
     Layout L;
     if ((rc = layout_for(ka, false, false, MODE_SOLVE, dims->dtype, L))) return rc;
     return dispatch_lds<MODE_MODEL>(ka, L, dims->dtype, batch, st);

@@ -29,6 +29,13 @@ struct KernelArgs {
     void *ws;
     // shared-model path: the factored model (ModelLayout) 
     const void *model;
+    // MpcqpSolveOpts beyond max_iter / feas_tol
+    int opt_flags;                // MPCQP_OPT_*
+    const int32_t *warm_active;   // [batch, warm_stride] initial active-set guess, or null
+    int warm_count, warm_stride;
+    int32_t *active_out;          // [batch, active_stride] final active set, or null
+    int active_stride;
+    void *probe;                  // developer probe: int64 stamps per problem, or null
 };
 
 // LDS carve, in elements of T. Matrices are row-major with odd row stride ld.
@@ -144,6 +151,9 @@ int launch_mid(const KernelArgs &ka, int dtype, int64_t batch, void *ws, hipStre
 int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st);
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st);
+// small-problem kernel (mpcqp_pair.hip): two problems per wavefront, fused build+solve
+bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
+int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

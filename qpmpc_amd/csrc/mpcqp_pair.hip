@@ -1,0 +1,858 @@
+// mpcqp_pair.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32
+// inequality rows, nx in {3, 4}, float64): TWO PROBLEMS PER WAVEFRONT.
+//
+// Replaces the same reference code as mpcqp_w64.hip (qpmpc/mpc_qp.py:53-149 for the
+// build, qpsolvers.solve_problem at qpmpc/solve_mpc.py:43 for the solve) for the fused
+// build+solve of BASELINE configs 1, 2 and 4 (nx=3, nu=1, N=16 -> n=16, m=32).
+//
+// Why two per wavefront (round-2 counters, profiles/r02_*): with one problem per
+// wavefront and four wavefronts per SIMD the launch is bound by VALU ISSUE -- about
+// 4.1 k vector instructions per problem of which 1.5 k are f64 FMAs -- and every role
+// of the 64 lanes executed the whole stream although each instruction was useful for
+// one role only. Here a problem owns 32 lanes and each lane owns TWO 16-register rows,
+// so one instruction stream serves two problems:
+//   lane l of a half (l = 0..31):
+//     RM  row M_l of M = G L^-T (constraint l), slack s_l                (all 32 lanes)
+//     RT  l < 16: row l of T = N* (active-set slot l, multiplier, constraint id)
+//         l >= 16: row l-16 of L^-T (identity pushed through the forward substitution),
+//                  so that u = L^-T y is one dot product at the end
+//   during the build lanes 0..15 own a column of Psi and row l of P -> L, lane 16 the
+//   free response Phi_k x0.
+// The two halves take their own branches of the active-set iteration through
+// predication: every per-problem scalar (selected row, slot, step length, status) is a
+// per-lane value that is uniform inside a half. Half-wide reductions are four DPP row
+// rotations plus one v_permlane16_swap; a value of one lane is fetched with ds_bpermute.
+// 2048 wavefronts for the 4096 problems of config 2 -> two wavefronts per SIMD, a
+// 256-register budget (no scratch), 19.6 KB of LDS per wavefront.
+//
+// Solver: the same dual active-set method (Goldfarb-Idnani 1983) with the explicit
+// operator T = N* as mpcqp_w64.hip; see that file for the derivation. Per step, for
+// the selected row p:  r = T M_p ; z = -M_p + M_A' r ; d2 = |z|^2 ;
+//   t = min(t1 = min lam_a/r_a, t2 = -s_p/d2) ; s_i -= t M_i.z ;
+//   full step: T_a += (r_a/d2) z, T_new = -z/d2 ; partial step: slot l leaves,
+//   T_a -= (T_a.T_l / T_l.T_l) T_l.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace pair {
+
+constexpr int NV = 16;    // padded number of variables / slots
+constexpr int HL = 32;    // lanes per problem
+constexpr int MMAX = 32;  // constraints a half can hold
+constexpr int LDM = 18;   // row stride of the L and M images (144 B: rows start in distinct 16-B slots)
+
+// ------------------------------------------------------------ lane primitives
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+constexpr int ROR8 = 0x128, ROR4 = 0x124, ROR2 = 0x122, ROR1 = 0x121;  // rotate within a row of 16
+
+// all-reduce (min) over the 32 lanes of each half
+__device__ __forceinline__ unsigned half_min(unsigned v)
+{
+    v = min(v, dpp_u<ROR8>(v));
+    v = min(v, dpp_u<ROR4>(v));
+    v = min(v, dpp_u<ROR2>(v));
+    v = min(v, dpp_u<ROR1>(v));
+    // rows 1 and 3 of the first operand are exchanged with rows 0 and 2 of the second
+    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return min((unsigned)sw[0], (unsigned)sw[1]);
+}
+// value of lane `idx` (0..31, uniform inside a half) of the caller's own half
+__device__ __forceinline__ int half_get(int x, int hb, int idx)
+{
+    return __builtin_amdgcn_ds_bpermute((hb + idx) << 2, x);
+}
+__device__ __forceinline__ double half_get(double x, int hb, int idx)
+{
+    const int a = (hb + idx) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+// true in every lane of a half iff `pred` holds in one of its lanes
+__device__ __forceinline__ bool half_any(bool pred, int hb)
+{
+    const unsigned long long b = __ballot(pred);
+    return ((unsigned)(b >> hb)) != 0u;
+}
+
+// order-preserving map of a double onto two unsigned words
+__device__ __forceinline__ void ordered(double x, unsigned &hi, unsigned &lo)
+{
+    const unsigned h = (unsigned)__double2hiint(x), l = (unsigned)__double2loint(x);
+    const bool neg = h & 0x80000000u;
+    hi = neg ? ~h : (h | 0x80000000u);
+    lo = neg ? ~l : l;
+}
+
+// ------------------------------------------------------------ 16-vectors in LDS
+__device__ __forceinline__ void ld16(double (&d)[NV], const double *src)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        const double2 t = p[i];
+        d[2 * i] = t.x;
+        d[2 * i + 1] = t.y;
+    }
+}
+__device__ __forceinline__ void st16(double *dst, const double (&s)[NV])
+{
+    double2 *p = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        double2 t;
+        t.x = s[2 * i];
+        t.y = s[2 * i + 1];
+        p[i] = t;
+    }
+}
+__device__ __forceinline__ double dot16(const double (&a)[NV], const double (&b)[NV])
+{
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) {
+        acc0 += a[k] * b[k];
+        acc1 += a[k + 1] * b[k + 1];
+        acc2 += a[k + 2] * b[k + 2];
+        acc3 += a[k + 3] * b[k + 3];
+    }
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
+// 1/x from the hardware estimate plus two Newton steps (operands are never subnormal
+// or zero when the result is used)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+// One wavefront per workgroup: its LDS operations complete in order, so only the
+// COMPILER has to keep the order of an exchange (no s_barrier, no queue drain).
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct Lay {     // LDS carve of ONE problem in doubles (host-computed, passed by value)
+    int off_X;   // build: G image 16 x GS | main: M_A 17 x 16, then the T image 16 x 16 (refinement)
+    int off_Y;   // build: exchange + staged operands | L 16 x LDM + column buffers | main: M image m x LDM
+    int off_hv;  // h_i by lane (32), then y0 (16)
+    int off_v;   // kAv, rv, zv and their shadows (6 x 16)
+    int off_stage, nA, nB, nC, nD;
+    int per;     // doubles per problem (the second half's carve starts here)
+};
+
+constexpr double DEP = 1e-14;  // |z|^2 / |M_p|^2 below this: M_p depends on the active rows
+
+}  // namespace pair
+
+using namespace pair;
+
+// MK > 0: compile-time number of inequality rows per step for the register-pipelined
+// chain (terminal cost only, state constraints only); MK == 0: generic chain.
+template <int NX, int MK>
+__global__ void __launch_bounds__(64, 2)
+    mpcqp_pair_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
+                      const double *__restrict__ gD, const double *__restrict__ ge, const double *__restrict__ gx0,
+                      const double *__restrict__ ggoal, const double *__restrict__ gtgt, double *__restrict__ oU,
+                      double *__restrict__ olam, int32_t *__restrict__ ostatus, int32_t *__restrict__ oiters,
+                      const KernelArgs ka, const Lay L, const int64_t batch)
+{
+    using T = double;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x;
+    const int hb = lane & 32;   // first lane of this half
+    const int hl = lane & 31;   // lane inside the half
+    const int l15 = lane & 15;
+    const bool low = hl < NV;
+    int64_t prob = 2 * (int64_t)blockIdx.x + (hb >> 5);
+    const bool valid = prob < batch;  // an odd batch leaves the last half idle: it repeats the last problem, stores nothing
+    prob = valid ? prob : batch - 1;
+    T *sm = (T *)smem_raw + (hb ? L.per : 0);
+    const int vofs = low ? hl : 3 * NV + l15;  // element of an exchange vector (shadow copy for lanes >= 16)
+    const int n = ka.n, m = ka.m;
+    const bool isc = hl < m;  // this lane owns a constraint
+    const T INF = HUGE_VAL;
+    T *Gimg = sm + L.off_X, *MAl = sm + L.off_X, *Timg = sm + L.off_X + (NV + 1) * NV;
+    const int GS = (m + 1) | 1;  // the G image is stored by COLUMN with an odd stride
+    T *Ll = sm + L.off_Y, *Ml = sm + L.off_Y, *hv = sm + L.off_hv;
+    T *y0v = hv + HL;
+    T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV;
+
+    // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[8] per problem
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 8 : nullptr;
+    auto tick = [&](int slot) {
+        if (stamp && hl == 0 && valid) stamp[slot] = (long long)__builtin_readcyclecounter();
+    };
+    tick(0);
+
+    T Pr[NV];  // lane a < 16: row a of P, then of L
+    // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
+    {
+        constexpr int nx = NX;
+        const int nu = ka.nu, N = ka.N, mk = ka.mk;
+        const T *A = gA + prob * ka.A.batch_stride;
+        const T *B = gB + prob * ka.B.batch_stride;
+        const T *Cm = gC ? gC + prob * ka.C.batch_stride : nullptr;
+        const T *Dm = gD ? gD + prob * ka.D.batch_stride : nullptr;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = gtgt ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0;
+        const int sC = ka.C.step_stride ? mk * nx : 0, sD = ka.D.step_stride ? mk * nu : 0;
+        const bool stageP = ka.flags & MPCQP_P_STAGE, stageQ = (ka.flags & MPCQP_Q_STAGE) && tgt;
+        const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
+        T *ex = sm + L.off_Y;           // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
+        T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries)
+        T *As = sm + L.off_stage, *Bs = As + L.nA, *Cs = Bs + L.nB, *Ds = Cs + L.nC;
+        // The problem's operands are staged in LDS by the 32 lanes of its half: every load of the
+        // four arrays is issued before the first store, so the whole stage costs ONE HBM latency.
+        {
+            constexpr int CA = 8, CB2 = 2, CC = 4, CD = 4;  // 32-element chunks held in registers per array
+            T ta[CA], tb[CB2], tc[CC], td[CD];
+#pragma unroll
+            for (int u = 0; u < CA; ++u) ta[u] = (u * HL + hl < L.nA) ? A[u * HL + hl] : T(0);
+#pragma unroll
+            for (int u = 0; u < CB2; ++u) tb[u] = (u * HL + hl < L.nB) ? B[u * HL + hl] : T(0);
+#pragma unroll
+            for (int u = 0; u < CC; ++u) tc[u] = (u * HL + hl < L.nC) ? Cm[u * HL + hl] : T(0);
+#pragma unroll
+            for (int u = 0; u < CD; ++u) td[u] = (u * HL + hl < L.nD) ? Dm[u * HL + hl] : T(0);
+#pragma unroll
+            for (int u = 0; u < CA; ++u)
+                if (u * HL + hl < L.nA) As[u * HL + hl] = ta[u];
+#pragma unroll
+            for (int u = 0; u < CB2; ++u)
+                if (u * HL + hl < L.nB) Bs[u * HL + hl] = tb[u];
+#pragma unroll
+            for (int u = 0; u < CC; ++u)
+                if (u * HL + hl < L.nC) Cs[u * HL + hl] = tc[u];
+#pragma unroll
+            for (int u = 0; u < CD; ++u)
+                if (u * HL + hl < L.nD) Ds[u * HL + hl] = td[u];
+            // anything beyond the register chunks (long horizons of tiny systems never get here; kept for safety)
+            for (int i = CA * HL + hl; i < L.nA; i += HL) As[i] = A[i];
+            for (int i = CB2 * HL + hl; i < L.nB; i += HL) Bs[i] = B[i];
+            for (int i = CC * HL + hl; i < L.nC; i += HL) Cs[i] = Cm[i];
+            for (int i = CD * HL + hl; i < L.nD; i += HL) Ds[i] = Dm[i];
+        }
+        const bool isx = (hl == NV), col = (hl < n);
+        const int j = col ? hl / nu : -1, ii = col ? hl - j * nu : 0;
+        const T eval = isc ? ge[prob * ka.e.batch_stride + (hl / mk) * ka.e.step_stride + (hl % mk)] : INF;
+        T v[NX], gref[NX];
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            v[s] = isx ? x0[s] : T(0);
+            gref[s] = (isx && termQ) ? goal[s] : T(0);
+        }
+        const T wu = (T)ka.wu;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) Pr[b] = (hl == b) ? (col ? wu : T(1)) : T(0);
+        T qa = T(0);
+        wsync();
+        T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
+#pragma unroll
+        for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
+
+        // Gram accumulation of one block: Pr[b] += w v_a . v_b, qa += w resid . v_a;
+        // ref[] is this lane's reference (non-zero only in lane 16).
+        auto gram = [&](T w, bool useP, bool useQ, const T (&ref)[NX]) {
+            if (!useP && !useQ) return;
+            wsync();
+#pragma unroll
+            for (int s = 0; s < NX; ++s) ex[s * 32 + hl] = v[s] - ref[s];
+            wsync();
+#pragma unroll
+            for (int s = 0; s < NX; ++s) {
+                const T t = w * v[s];
+                if (useP) {
+                    T vb[NV];
+                    ld16(vb, ex + s * 32);
+#pragma unroll
+                    for (int b = 0; b < NV; ++b) {
+                        Pr[b] += t * vb[b];
+                        pin(Pr[b]);
+                    }
+                }
+                if (useQ) qa += t * ex[s * 32 + NV];
+            }
+        };
+        // G rows of step k from v = Psi_k[:, lane] (lane 16: Phi_k x0); lanes 0..15 fill
+        // column `lane` of the G image, lane 16 the C_k Phi_k x0 part of h (mpc_qp.py:62-78)
+        T *gd = low ? (Gimg + hl * GS) : hp;
+        auto g_rows = [&](int k) {
+            const bool here = (j == k);
+            for (int i2 = 0; i2 < mk; ++i2) {
+                T acc = T(0);
+                if (L.nC) {
+                    const T *Ci = Cs + k * sC + i2 * nx;  // broadcast LDS reads
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) acc += Ci[s] * v[s];
+                }
+                if (L.nD) {
+                    const T dv = Ds[k * sD + i2 * nu + ii];
+                    acc += here ? dv : T(0);
+                }
+                gd[k * mk + i2] = acc;
+            }
+        };
+        // Psi_{k+1} = A_k Psi_k, then column block k <- B_k (mpc_qp.py:88-90)
+        auto advance = [&](int k) {
+            const T *Ak = As + k * sA;
+            const bool here = (j == k);
+            T w[NX];
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                T acc = T(0);
+#pragma unroll
+                for (int s = 0; s < NX; ++s) acc += Ak[r * nx + s] * v[s];
+                w[r] = acc;
+            }
+#pragma unroll
+            for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
+        };
+        if constexpr (MK > 0) {
+            // Terminal cost only, C only, mk == MK (configs 1, 2, 4; the host checks). Register-pipelined
+            // chain on 17 lanes per half: the broadcast LDS reads of A_{k+1}, C_{k+1} are in flight while
+            // step k computes [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k.
+            if (hl <= NV) {
+                T a0[NX * NX], c0[MK * NX];
+#pragma unroll
+                for (int e = 0; e < NX * NX; ++e) a0[e] = As[e];
+#pragma unroll
+                for (int e = 0; e < MK * NX; ++e) c0[e] = Cs[e];
+                for (int k = 0; k < N; ++k) {
+                    const int kn = (k + 1 < N) ? k + 1 : k;
+                    T a1[NX * NX], c1[MK * NX];
+#pragma unroll
+                    for (int e = 0; e < NX * NX; ++e) a1[e] = As[kn * sA + e];
+#pragma unroll
+                    for (int e = 0; e < MK * NX; ++e) c1[e] = Cs[kn * sC + e];
+#pragma unroll
+                    for (int i2 = 0; i2 < MK; ++i2) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int s2 = 0; s2 < NX; ++s2) acc += c0[i2 * NX + s2] * v[s2];
+                        gd[k * MK + i2] = acc;
+                    }
+                    const bool here = (j == k);
+                    T w[NX];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) {
+                        T acc = T(0);
+#pragma unroll
+                        for (int s2 = 0; s2 < NX; ++s2) acc += a0[r * NX + s2] * v[s2];
+                        w[r] = acc;
+                    }
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
+#pragma unroll
+                    for (int e = 0; e < NX * NX; ++e) a0[e] = a1[e];
+#pragma unroll
+                    for (int e = 0; e < MK * NX; ++e) c0[e] = c1[e];
+                }
+            }
+        } else if (!stageP && !stageQ) {
+            if (hl <= NV) {
+                for (int k = 0; k < N; ++k) {
+                    g_rows(k);
+                    advance(k);
+                }
+            }
+        } else {
+            for (int k = 0; k < N; ++k) {
+                if (hl <= NV) g_rows(k);
+                if (k >= 1) {
+                    T tref[NX];
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) tref[s] = (isx && stageQ) ? tgt[k * nx + s] : T(0);
+                    gram((T)ka.wx, stageP, stageQ, tref);
+                }
+                if (hl <= NV) advance(k);
+            }
+        }
+        gram((T)ka.wt, termP, termQ, gref);  // v = Psi_N
+        wsync();
+        if (low) Gimg[hl * GS + m] = col ? qa : T(0);  // the q row
+        wsync();
+        hv[hl] = (isc && L.nC) ? eval - hp[hl] : eval;  // h_i = e_i - C_k Phi_k x0
+        wsync();
+    }
+
+    tick(1);
+    // ------------------------------------------------------------ factorise
+    // Right-looking Cholesky on the rows held by lanes 0..15 of each half. Column j (one entry per
+    // lane) is broadcast through a double-buffered 16-entry LDS vector: column j+1 is brought up to
+    // date and written FIRST in step j, so its round trip overlaps the rest of step j's updates.
+    bool notpd = false;
+    T myinv = T(1);  // lane j keeps 1 / L_jj
+    {
+        T *cb = Ll + NV * LDM;  // two buffers of NV + 2 (shadow entry for lanes >= 16)
+        const int cw = low ? hl : NV;
+        cb[cw] = Pr[0];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const T *cbj = cb + (j & 1) * (NV + 2);
+            T cv[NV];
+#pragma unroll
+            for (int g = j / 2; g < NV / 2; ++g) {
+                const double2 t = reinterpret_cast<const double2 *>(cbj)[g];
+                cv[2 * g] = t.x;
+                cv[2 * g + 1] = t.y;
+            }
+            const T piv = cv[j];
+            if (!(piv > T(0))) notpd = true;
+            const T rinv = rsqrt(piv);
+            const T pij = Pr[j];             // P[i][j] of this lane's row, before scaling
+            const T t2 = pij * rinv * rinv;  // P[i][j] / piv
+            if (j + 1 < NV) {
+                Pr[j + 1] -= t2 * cv[j + 1];
+                pin(Pr[j + 1]);
+                (cb + ((j + 1) & 1) * (NV + 2))[cw] = Pr[j + 1];
+            }
+#pragma unroll
+            for (int k = j + 2; k < NV; ++k) {
+                Pr[k] -= t2 * cv[k];  // cv[k] = P[k][j]
+                pin(Pr[k]);
+            }
+            Pr[j] = pij * rinv;                                    // L[i][j] (lane j: sqrt(piv))
+            if (hl == j) myinv = rinv;
+        }
+    }
+    tick(2);
+
+    // ------------------------------------------------------------ rows, forward substitution
+    T RM[NV], RT[NV];
+    {
+        // Rows fetched only now: constraint lanes their row of G; lane 0 takes q in RT, lanes 16..31
+        // the identity (-> rows of L^-T), the other slot lanes zero.
+#pragma unroll
+        for (int k = 0; k < NV; ++k) RM[k] = isc ? Gimg[k * GS + hl] : T(0);
+        if (hl == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) RT[k] = Gimg[k * GS + m];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) RT[k] = (hl == NV + k) ? T(1) : T(0);
+        }
+        // [RM; RT] <- [RM; RT] L^-T, rows of L broadcast from an LDS image (16-byte reads at
+        // half-uniform addresses)
+        if (low) {
+            st16(Ll + hl * LDM, Pr);
+            Ll[hl * LDM + NV] = myinv;
+        }
+        wsync();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const double2 *Lr = reinterpret_cast<const double2 *>(Ll + j * LDM);
+            T am = RM[j], at = RT[j];
+#pragma unroll
+            for (int kk = 0; 2 * kk < j; ++kk) {
+                const double2 t = Lr[kk];
+                am -= RM[2 * kk] * t.x;
+                at -= RT[2 * kk] * t.x;
+                if (2 * kk + 1 < j) {
+                    am -= RM[2 * kk + 1] * t.y;
+                    at -= RT[2 * kk + 1] * t.y;
+                }
+            }
+            const T li = Lr[NV / 2].x;
+            RM[j] = am * li;
+            RT[j] = at * li;
+            pin(RM[j]);  // keeps step j+1's broadcast reads behind step j (register pressure)
+            pin(RT[j]);
+        }
+        wsync();  // the M image below reuses the L image
+    }
+    tick(3);
+    int status = MPCQP_MAX_ITER, iters = 0;
+    T xsol = T(0), lam_out = T(0);
+    bool done = notpd;  // this half has left the active-set loop
+    bool finished = notpd;  // ... and needs no refinement any more (failed, or accepted)
+    if (notpd) status = MPCQP_NOT_PD;
+
+    if (hl == 0) st16(y0v, RT);        // w = L^-1 q ; y0 = -w
+    if (isc) st16(Ml + hl * LDM, RM);  // image of M for the row-p broadcasts
+    for (int i = hl; i < (NV + 1) * NV; i += HL) MAl[i] = T(0);
+    if (low) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) RT[k] = T(0);  // T = N* starts empty
+    }
+    wsync();
+    const T hval = hv[hl];
+    T s;
+    {
+        T y0[NV];
+        ld16(y0, y0v);
+        s = hval + dot16(RM, y0);  // h - M y0  (y0 = -L^-1 q)
+    }
+    s = isc ? s : INF;
+    // Selection rule (the classic Goldfarb-Idnani one): among the rows violated beyond the
+    // tolerance, the one FARTHEST from its hyperplane in the P^-1 metric, s_i / |M_i|.
+    T invn;
+    {
+        const T nn = dot16(RM, RM);
+        invn = (nn > T(0)) ? rsqrt(nn) : T(1);
+    }
+    const bool selectable = isc && (hval < T(1e29));
+    const T tol = (T)ka.tol;
+    const T tolh = tol + tol * fabs(hval);  // row i is violated when s_i < -tol (1 + |h_i|)
+    const int max_iter = ka.max_iter;
+
+    T lam = T(0);      // slot lanes: multiplier of the slot
+    int myact = 0;     // slot lanes: constraint held by the slot
+    bool occ = false;  // slot lanes: slot occupied
+    int pos = -1;      // constraint lanes: slot of this constraint, or -1
+    // half-uniform state
+    int nq = 0, p = 0, ldrop = 0;
+    unsigned mask = 0;  // occupied slots
+    bool needp = true, dropping = false;
+    T up = T(0);
+    tick(4);
+    for (int round = 0; round < 4; ++round) {
+        // ===================================================== active-set loop
+        for (;;) {
+            // ---- selection, for the halves that start a new constraint
+            {
+                unsigned hi, lo;
+                ordered(s * invn, hi, lo);
+                const bool want = needp && !done;
+                const unsigned key = (want && selectable && pos < 0 && s < -tolh) ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
+                const unsigned mkey = half_min(key);
+                if (want) {
+                    if (mkey == 0xffffffffu) {
+                        done = true;
+                        status = MPCQP_SOLVED;
+                    } else {
+                        p = (int)(mkey & 31u);
+                        up = T(0);
+                        needp = false;
+                    }
+                }
+            }
+            if (__ballot(!done) == 0ull) break;
+            bool stepping = !done && !dropping;
+            if (stepping && iters >= max_iter) {
+                done = true;
+                finished = true;
+                status = MPCQP_MAX_ITER;
+                stepping = false;
+            }
+            const bool drp = !done && dropping;
+            iters += stepping ? 1 : 0;
+            // ---- r = T M_p ; z = -M_p + M_A' r   (stepping halves; the others compute and ignore)
+            const T *mprow = Ml + p * LDM;  // row p of M, read as a broadcast inside the half
+            T r;
+            {
+                T mp[NV];
+                ld16(mp, mprow);
+                r = dot16(RT, mp);
+            }
+            r = (occ && stepping) ? r : T(0);
+            rv[vofs] = r;
+            const T mpl = mprow[l15];
+            wsync();
+            T z;
+            {
+                T rr[NV];
+                ld16(rr, rv);
+                const T *colp = MAl + l15;
+                T a0 = -mpl, a1 = T(0), a2 = T(0), a3 = T(0);
+#pragma unroll
+                for (int a = 0; a < NV; a += 4) {
+                    a0 += rr[a] * colp[a * NV];
+                    a1 += rr[a + 1] * colp[(a + 1) * NV];
+                    a2 += rr[a + 2] * colp[(a + 2) * NV];
+                    a3 += rr[a + 3] * colp[(a + 3) * NV];
+                }
+                z = (a0 + a1) + (a2 + a3);
+            }
+            z = (low && stepping) ? z : T(0);
+            zv[vofs] = z;
+            wsync();
+            // ---- the vector of this trip's single pass over the rows: z (step) or T_l (drop)
+            T vv[NV];
+            ld16(vv, drp ? kAv : zv);
+            const T mz = dot16(RM, vv);
+            // ---- step length
+            const T d2 = dot16(vv, vv);  // |z|^2, every lane from its own copy
+            const T sp = half_get(s, hb, p);
+            const T ip = half_get(invn, hb, p);
+            const bool can_move = (nq < n) && (d2 * ip * ip > DEP) && (d2 > T(0));
+            const T inv = can_move ? fast_rcp(d2) : T(0);
+            const T t2 = can_move ? -sp * inv : INF;
+            const bool cand = occ && (r > T(0));
+            // a blocking multiplier exists iff lam_a / r_a < t2 for some slot
+            const bool blocked = half_any(stepping && cand && (lam < t2 * r), hb);
+            T t1 = INF;
+            int l = 0;
+            if (__ballot(blocked) != 0ull) {  // rare: ratio test on the multipliers
+                const T ratio = cand ? lam * fast_rcp(r) : INF;
+                unsigned hi, lo;
+                ordered(ratio, hi, lo);
+                hi = cand ? hi : 0xffffffffu;
+                const unsigned mhi = half_min(hi);
+                const unsigned k2 = (cand && hi == mhi) ? ((lo & ~31u) | (unsigned)hl) : 0xffffffffu;
+                const unsigned ml = half_min(k2);
+                l = (int)(ml & 31u);
+                const T tl1 = half_get(ratio, hb, l);
+                t1 = (mhi != 0xffffffffu) ? tl1 : INF;
+            }
+            T t = t1 < t2 ? t1 : t2;
+            if (stepping && !(t < INF)) {  // no step possible: the constraints are inconsistent
+                done = true;
+                finished = true;
+                status = MPCQP_INFEASIBLE;
+                stepping = false;
+            }
+            t = stepping ? t : T(0);
+            const bool full = stepping && (t2 <= t1);
+            const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
+            // ---- coefficient of the pass  RT += c * vv
+            T c = full ? ((hl == sl) ? -inv : r * inv) : T(0);
+            if (__ballot(drp) != 0ull) {
+                // slot ldrop leaves (its row T_l is in kAv). With W = T T' implicit,
+                // T_a -= (T_a . T_l / T_l . T_l) T_l ; row l becomes exactly zero.
+                const T tl = dot16(RT, vv);
+                const T tld = half_get(tl, hb, ldrop);
+                const T f = tl * fast_rcp(tld);
+                const T cd = (hl == ldrop) ? T(-1) : (occ ? -f : T(0));
+                c = drp ? cd : c;
+            }
+            c = low ? c : T(0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) RT[k] += c * vv[k];
+            // ---- bookkeeping
+            if (stepping) {
+                // the implied primal point moved by t z: s_i -= t M_i . z
+                if (isc) s = (pos >= 0) ? T(0) : s - t * mz;
+                lam -= t * r;
+                lam = (occ && lam < T(0)) ? T(0) : lam;
+                up += t;
+            }
+            // p takes slot sl (full step); other lanes write the junk row
+            MAl[((low && full) ? sl : NV) * NV + l15] = mpl;
+            if (full) {
+                if (hl == sl) {
+                    lam = up;
+                    myact = p;
+                    occ = true;
+                }
+                if (hl == p) {
+                    pos = sl;
+                    s = T(0);
+                }
+                mask |= 1u << sl;
+                ++nq;
+                needp = true;
+            }
+            const bool partial = stepping && !full;
+            if (drp) {
+                if (hl == ldrop) {
+                    lam = T(0);
+                    occ = false;
+                }
+                mask &= ~(1u << ldrop);
+                --nq;
+                dropping = false;
+            }
+            if (__ballot(partial) != 0ull) {
+                // partial step: the next trip removes slot l from T
+                const int cl = half_get(myact, hb, l);
+                wsync();
+                if (partial && hl == l) st16(kAv, RT);
+                if (partial) {
+                    if (hl == cl) pos = -1;
+                    dropping = true;
+                    ldrop = l;
+                }
+            }
+            wsync();
+        }
+        tick(5);
+        if (__ballot(!finished) == 0ull) break;
+        // ================================== refine multipliers, verify slacks
+        // (halves that are already finished compute along and change nothing)
+        wsync();
+        rv[vofs] = lam;
+        wsync();
+        T y;
+        {
+            T rr[NV];
+            ld16(rr, rv);
+            const T *colp = MAl + l15;
+            T a0 = T(0), a1 = T(0);
+#pragma unroll
+            for (int a = 0; a < NV; a += 2) {
+                a0 += rr[a] * colp[a * NV];
+                a1 += rr[a + 1] * colp[(a + 1) * NV];
+            }
+            y = -y0v[l15] - (a0 + a1);  // y = y0 - M_A' lam, y0 = -L^-1 q
+        }
+        zv[vofs] = y;
+        wsync();
+        T yy[NV];
+        ld16(yy, zv);
+        T fresh = hv[hl] - dot16(RM, yy);
+        fresh = isc ? fresh : INF;
+        if (__ballot(nq > 0 && !finished) != 0ull) {
+            // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A = -T (T' rho_A)
+            T rho = half_get(fresh, hb, myact);
+            rho = occ ? rho : T(0);
+            wsync();
+            kAv[vofs] = rho;
+            if (low) st16(Timg + hl * NV, RT);  // T by columns is only needed here
+            wsync();
+            T uk;
+            {
+                T rr[NV];
+                ld16(rr, kAv);
+                const T *colp = Timg + l15;
+                T a0 = T(0), a1 = T(0);
+#pragma unroll
+                for (int a = 0; a < NV; a += 2) {
+                    a0 += rr[a] * colp[a * NV];
+                    a1 += rr[a + 1] * colp[(a + 1) * NV];
+                }
+                uk = a0 + a1;  // (T' rho)_k, lane k < 16
+            }
+            rv[vofs] = low ? uk : T(0);
+            wsync();
+            T dl;
+            {
+                T rr[NV];
+                ld16(rr, rv);
+                dl = -dot16(RT, rr);
+            }
+            dl = occ ? dl : T(0);
+            lam += dl;
+            lam = (occ && lam < T(0)) ? T(0) : lam;
+            wsync();
+            rv[vofs] = dl;
+            wsync();
+            {
+                T rr[NV];
+                ld16(rr, rv);
+                const T *colp = MAl + l15;
+                T a0 = T(0), a1 = T(0);
+#pragma unroll
+                for (int a = 0; a < NV; a += 2) {
+                    a0 += rr[a] * colp[a * NV];
+                    a1 += rr[a + 1] * colp[(a + 1) * NV];
+                }
+                y -= a0 + a1;
+            }
+            wsync();
+            zv[vofs] = y;
+            wsync();
+            ld16(yy, zv);
+            fresh = hv[hl] - dot16(RM, yy);
+            fresh = isc ? fresh : INF;
+        }
+        // accept when no inactive row is violated at the re-evaluated point
+        const bool dirty = half_any(selectable && pos < 0 && fresh < -T(4) * tolh, hb);
+        if (!finished) {
+            if (!dirty || round == 3) {
+                xsol = dot16(RT, yy);  // u = L^-T y in lanes 16..31 (yy holds y)
+                status = dirty ? MPCQP_MAX_ITER : MPCQP_SOLVED;
+                finished = true;
+            } else {
+                // continue the active-set loop from the re-evaluated slacks
+                s = (pos >= 0) ? T(0) : fresh;
+                status = MPCQP_MAX_ITER;
+                done = false;
+                needp = true;
+            }
+        }
+        if (__ballot(!finished) == 0ull) break;
+    }
+    if (status == MPCQP_SOLVED && olam) {
+        const T lv = half_get(lam, hb, pos < 0 ? 0 : pos);
+        lam_out = (pos >= 0) ? lv : T(0);
+    }
+
+    tick(6);
+    const bool ok = (status == MPCQP_SOLVED);
+    if (valid) {
+        const int k = hl - NV;  // lanes 16..31 hold u_k
+        if (k >= 0 && k < n) oU[prob * (int64_t)n + k] = ok ? xsol : T(0);
+        if (olam && isc) olam[prob * (int64_t)m + hl] = ok ? lam_out : T(0);
+        if (hl == 0) {
+            if (ostatus) ostatus[prob] = status;
+            if (oiters) oiters[prob] = iters;
+        }
+    }
+}
+
+// ------------------------------------------------------------ host side
+static Lay make_lay(const KernelArgs &ka)
+{
+    Lay L{};
+    auto al = [](int c) { return (c + 3) & ~3; };  // 32-byte granules keep every region 16-byte aligned
+    const int gimg = NV * ((ka.m + 1) | 1), main_x = (NV + 1) * NV + NV * NV;
+    L.off_X = 0;
+    int o = al(gimg > main_x ? gimg : main_x);
+    L.off_Y = o;
+    int y_build = 4 * 32 + 32;  // ex (4 x 32), hp
+    L.off_stage = L.off_Y + y_build;
+    L.nA = (ka.A.step_stride ? ka.N : 1) * ka.nx * ka.nx;
+    L.nB = (ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
+    L.nC = ka.C.ptr ? (ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx : 0;
+    L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
+    y_build += L.nA + L.nB + L.nC + L.nD;
+    int y_main = ka.m * LDM;                                                 // the M image
+    if (y_main < NV * LDM + 2 * (NV + 2)) y_main = NV * LDM + 2 * (NV + 2);  // L image + the factorisation's column buffers
+    const int y_sz = al(y_build > y_main ? y_build : y_main);
+    L.off_hv = L.off_Y + y_sz;
+    o = L.off_hv + HL + NV;
+    L.off_v = o;
+    o += 6 * NV;  // kAv rv zv | their shadows
+    L.per = al(o);
+    return L;
+}
+
+bool pair_eligible(const KernelArgs &ka, int mode, int dtype)
+{
+    if (dtype != MPCQP_F64 || mode != MODE_FUSED) return false;
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1) return false;
+    if (ka.nx != 3 && ka.nx != 4) return false;
+    const Lay L = make_lay(ka);
+    return (size_t)L.per * 2 * sizeof(double) <= 64 * 1024;
+}
+
+template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    const Lay L = make_lay(ka);
+    const size_t bytes = (size_t)L.per * 2 * sizeof(double);
+    const unsigned grid = (unsigned)((batch + 1) / 2);
+    hipLaunchKernelGGL((mpcqp_pair_kernel<NX, MK>), dim3(grid), dim3(64), bytes, st, (const double *)ka.A.ptr,
+                       (const double *)ka.B.ptr, (const double *)ka.C.ptr, (const double *)ka.D.ptr,
+                       (const double *)ka.e.ptr, (const double *)ka.x0.ptr, (const double *)ka.goal.ptr,
+                       (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L,
+                       batch);
+    return (int)hipGetLastError();
+}
+
+int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    // the register-pipelined chain: terminal cost only, state constraints only, two rows per step
+    const bool lean = ka.mk == 2 && ka.C.ptr && !ka.D.ptr && !(ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
+    if (ka.nx == 3) return lean ? launch_pair_t<3, 2>(ka, batch, st) : launch_pair_t<3, 0>(ka, batch, st);
+    return lean ? launch_pair_t<4, 2>(ka, batch, st) : launch_pair_t<4, 0>(ka, batch, st);
+}
+
+}  // namespace mpcqp

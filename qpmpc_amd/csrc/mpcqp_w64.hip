@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(64, 4)
 
     T R[NV];   // this lane's row: T_a (slots) | M_i (constraints) | row of L^-T
     T Pr[NV];  // lane a < 16: row a of P, then of L
-    // optional phase timestamps (tools/probe_phases.py): ka.X -> long long[8] per problem
-    long long *stamp = ka.X ? (long long *)ka.X + prob * 8 : nullptr;
+    // optional phase timestamps (tools/probe_phases.py): MpcqpSolveOpts.probe -> long long[8] per problem
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 8 : nullptr;
     auto tick = [&](int slot) {
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };

@@ -123,7 +123,7 @@ def solve_single(problem, max_iter=None, feas_tol=None):
             flags |= _capi.Q_STAGE
     dims = _capi.Dims(nx, nu, N, mk, _capi.F64, flags, 0.0 if wt is None else float(wt), 0.0 if wx is None else float(wx),
                       float(problem.stage_input_cost_weight))
-    opts = _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))
+    opts = _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))  # remaining fields: NULL / 0
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     r.d_in.copy_(r.h_in, non_blocking=True)

@@ -455,22 +455,26 @@ def test_wavefront_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx)
     assert (status == 0).sum() >= 90
 
 
-def test_wavefront_and_workgroup_kernels_agree(monkeypatch):
-    """The two solver formulations (explicit N* in registers vs Q/R^-1 in LDS) on the same batch."""
-    from qpmpc_amd import solve_mpc_batch
+def test_wavefront_and_workgroup_kernels_agree():
+    """The solver formulations on the same batch: explicit N* in registers, two problems per wavefront
+    (default) and one per wavefront (OPT_ONE_PER_WAVE), vs Q/R^-1 in LDS (OPT_FORCE_LDS). 2047 problems:
+    the odd batch leaves the second half of the last wavefront idle."""
+    from qpmpc_amd import _capi, solve_mpc_batch
     from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
 
-    w = humanoid_batch(2048)
+    w = humanoid_batch(2047)
     bp = to_batch_problem(w)
     a = solve_mpc_batch(bp)
-    monkeypatch.setenv("MPCQP_FORCE_LDS", "1")
-    b = solve_mpc_batch(bp)
+    b = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
+    c = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
     torch.cuda.synchronize()
-    sa, sb = a.status.cpu().numpy(), b.status.cpu().numpy()
-    assert np.array_equal(sa == 0, sb == 0)
+    sa, sb, sc = a.status.cpu().numpy(), b.status.cpu().numpy(), c.status.cpu().numpy()
+    assert np.array_equal(sa == 0, sb == 0) and np.array_equal(sa, sc)
     ok = sa == 0
-    Ua, Ub = a.U.cpu().numpy()[ok], b.U.cpu().numpy()[ok]
+    Ua, Ub, Uc = a.U.cpu().numpy()[ok], b.U.cpu().numpy()[ok], c.U.cpu().numpy()[ok]
     assert np.abs(Ua - Ub).max() <= 1e-7 * max(1.0, np.abs(Ub).max())
+    assert np.abs(Ua - Uc).max() <= 1e-9 * max(1.0, np.abs(Uc).max())
+    assert np.array_equal(a.iters.cpu().numpy(), c.iters.cpu().numpy())  # same algorithm, same pivots
 
 
 # ---------------------------------------------------------------- shared model (build once)
@@ -593,12 +597,12 @@ def test_large_solver_statuses():
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-3), ("f64", 1e-8)])
-def test_large_path_structured_ltv_with_state_and_input_constraints(dtype, tol, monkeypatch):
+def test_large_path_structured_ltv_with_state_and_input_constraints(dtype, tol):
     """Fused large path on a random LTV family (nx=6, nu=3, N=64, mk=5 -> n=192, m=320) with C and D
     rows, stage and terminal costs: matrix-free G (roll-out operator) vs the oracle, and the same batch
-    with G formed densely (MPCQP_FORCE_DENSE_G) and through the general workspace kernel
-    (MPCQP_FORCE_GWS) must give the same plans."""
-    from qpmpc_amd import solve_mpc_batch
+    with G formed densely (OPT_FORCE_DENSE_G) and through the general workspace kernel
+    (OPT_FORCE_GWS) must give the same plans."""
+    from qpmpc_amd import _capi, solve_mpc_batch
     from qpmpc_amd.workloads import to_batch_problem
 
     rng = np.random.default_rng(2025)
@@ -616,11 +620,9 @@ def test_large_path_structured_ltv_with_state_and_input_constraints(dtype, tol, 
     assert ok.sum() >= 3
     scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
     assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= tol
-    for env in ("MPCQP_FORCE_DENSE_G", "MPCQP_FORCE_GWS"):
-        monkeypatch.setenv(env, "1")
-        other = solve_mpc_batch(bp)
+    for env, flag in (("dense G", _capi.OPT_FORCE_DENSE_G), ("workspace kernel", _capi.OPT_FORCE_GWS)):
+        other = solve_mpc_batch(bp, flags=flag)
         torch.cuda.synchronize()
-        monkeypatch.delenv(env)
         assert np.array_equal(other.status.cpu().numpy(), st), env
         Ub = other.U.double().cpu().numpy()
         assert (np.abs(Ub[ok] - U[ok]) / scale).max() <= 2 * tol, env
@@ -717,10 +719,10 @@ def test_large_batch_sweep_shared_operands():
     (12, 2, 16, 4, True, True, 0.5, False),   # n = 32, nx = 12: the paths padded to 16 state rows
     (12, 4, 24, 6, True, True, 0.5, False),   # n = 96 with bulky per-step operands: falls through to the large path
 ])
-def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, lti, monkeypatch):
+def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, lti):
     """Fused build+solve of mid-size problems (on-chip streaming front end, matrix-free G) against the
-    oracle, and against the all-in-LDS workgroup kernel on the same batch (MPCQP_FORCE_LDS)."""
-    from qpmpc_amd import solve_mpc_batch
+    oracle, and against the all-in-LDS workgroup kernel on the same batch (OPT_FORCE_LDS)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
     from qpmpc_amd.workloads import to_batch_problem
 
     rng = np.random.default_rng(1000 * nx + 10 * N + mk)
@@ -746,8 +748,7 @@ def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, 
     assert ok.sum() >= 20
     scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
     assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-7
-    monkeypatch.setenv("MPCQP_FORCE_LDS", "1")
-    other = solve_mpc_batch(bp)
+    other = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
     torch.cuda.synchronize()
     assert np.array_equal(other.status.cpu().numpy(), st)
     assert (np.abs(other.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-7

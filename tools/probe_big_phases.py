@@ -11,8 +11,7 @@ if kind == "wip":  # config 3 through the mid-size kind of the same kernel (f64)
 else:
     w = W.synthetic_ltv_batch(batch); bp = W.to_batch_problem(w, dtype=torch.float32)
 buf = torch.zeros(batch * 32, dtype=torch.int64, device="cuda")
-os.environ["MPCQP_STAMP_PTR"] = str(buf.data_ptr())
-run = PreparedSolve(bp)
+run = PreparedSolve(bp, probe=buf)
 for _ in range(2): run.launch()
 torch.cuda.synchronize()
 full = buf.view(batch, 32).cpu().double()

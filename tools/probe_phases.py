@@ -7,8 +7,9 @@ from qpmpc_amd import PreparedSolve, workloads as W
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 w = W.triple_integrator_batch(batch); bp = W.to_batch_problem(w)
 buf = torch.zeros(batch * 8, dtype=torch.int64, device="cuda")
-os.environ["MPCQP_STAMP_PTR"] = str(buf.data_ptr())
-run = PreparedSolve(bp)
+from qpmpc_amd import _capi
+flags = _capi.OPT_ONE_PER_WAVE if (len(sys.argv) > 2 and sys.argv[2] == "w64") else 0
+run = PreparedSolve(bp, probe=buf, flags=flags)
 for _ in range(3): run.launch()
 torch.cuda.synchronize()
 t = buf.view(batch, 8).cpu().double()
