@@ -127,7 +127,7 @@ typedef struct MpcqpSolveOpts {
     int32_t *active_out;
     int32_t active_stride;
     int32_t reserved;
-    /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (8 for the small-problem
+    /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (16 for the small-problem
      * kernels, 32 for the mid-size / large ones) that receives shader-clock stamps at phase boundaries. */
     void *probe;
 } MpcqpSolveOpts;

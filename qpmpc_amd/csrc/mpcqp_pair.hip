@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(64, 2)
     T *y0v = hv + HL;
     T *kAv = sm + L.off_v, *rv = kAv + NV, *zv = rv + NV;
 
-    // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[8] per problem
-    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 8 : nullptr;
+    // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[16] per problem
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     auto tick = [&](int slot) {
         if (stamp && hl == 0 && valid) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(64, 2)
         const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
         T *ex = sm + L.off_Y;           // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
         T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries)
-        T *As = sm + L.off_stage, *Bs = As + L.nA, *Cs = Bs + L.nB, *Ds = Cs + L.nC;
+        auto al4 = [](int c) { return (c + 3) & ~3; };  // as make_lay: every staged array starts 16-byte aligned
+        T *As = sm + L.off_stage, *Bs = As + al4(L.nA), *Cs = Bs + al4(L.nB), *Ds = Cs + al4(L.nC);
         // The problem's operands are staged in LDS by the 32 lanes of its half: every load of the
         // four arrays is issued before the first store, so the whole stage costs ONE HBM latency.
         {
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(64, 2)
             for (int i = CC * HL + hl; i < L.nC; i += HL) Cs[i] = Cm[i];
             for (int i = CD * HL + hl; i < L.nD; i += HL) Ds[i] = Dm[i];
         }
+        tick(8);
         const bool isx = (hl == NV), col = (hl < n);
         const int j = col ? hl / nu : -1, ii = col ? hl - j * nu : 0;
         const T eval = isc ? ge[prob * ka.e.batch_stride + (hl / mk) * ka.e.step_stride + (hl % mk)] : INF;
@@ -264,6 +266,7 @@ __global__ void __launch_bounds__(64, 2)
         for (int b = 0; b < NV; ++b) Pr[b] = (hl == b) ? (col ? wu : T(1)) : T(0);
         T qa = T(0);
         wsync();
+        tick(9);
         T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
 #pragma unroll
         for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
@@ -330,23 +333,14 @@ __global__ void __launch_bounds__(64, 2)
             // chain on 17 lanes per half: the broadcast LDS reads of A_{k+1}, C_{k+1} are in flight while
             // step k computes [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k.
             if (hl <= NV) {
-                T a0[NX * NX], c0[MK * NX];
-#pragma unroll
-                for (int e = 0; e < NX * NX; ++e) a0[e] = As[e];
-#pragma unroll
-                for (int e = 0; e < MK * NX; ++e) c0[e] = Cs[e];
-                for (int k = 0; k < N; ++k) {
-                    const int kn = (k + 1 < N) ? k + 1 : k;
-                    T a1[NX * NX], c1[MK * NX];
-#pragma unroll
-                    for (int e = 0; e < NX * NX; ++e) a1[e] = As[kn * sA + e];
-#pragma unroll
-                    for (int e = 0; e < MK * NX; ++e) c1[e] = Cs[kn * sC + e];
+                constexpr int NA = NX * NX, NC = MK * NX;
+                // one step from register copies of A_k, C_k
+                auto step = [&](int k, const T *a, const T *c) {
 #pragma unroll
                     for (int i2 = 0; i2 < MK; ++i2) {
                         T acc = T(0);
 #pragma unroll
-                        for (int s2 = 0; s2 < NX; ++s2) acc += c0[i2 * NX + s2] * v[s2];
+                        for (int s2 = 0; s2 < NX; ++s2) acc += c[i2 * NX + s2] * v[s2];
                         gd[k * MK + i2] = acc;
                     }
                     const bool here = (j == k);
@@ -355,15 +349,73 @@ __global__ void __launch_bounds__(64, 2)
                     for (int r = 0; r < NX; ++r) {
                         T acc = T(0);
 #pragma unroll
-                        for (int s2 = 0; s2 < NX; ++s2) acc += a0[r * NX + s2] * v[s2];
+                        for (int s2 = 0; s2 < NX; ++s2) acc += a[r * NX + s2] * v[s2];
                         w[r] = acc;
                     }
 #pragma unroll
                     for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
+                };
+                if (sA && sC) {
+                    // Time-varying A and C: the blocks of steps (k, k+1), k even, are contiguous and 16-byte
+                    // aligned in the staged image, so a PAIR of steps is fetched with 16-byte broadcast reads
+                    // into one of two register sets while the other set's two steps compute.
+                    T pa[2 * NA], pc[2 * NC], qa2[2 * NA], qc[2 * NC];
+                    auto fetch = [&](int k, T(&a)[2 * NA], T(&c)[2 * NC]) {
+                        const double2 *sa = reinterpret_cast<const double2 *>(As + k * NA);
+                        const double2 *sc = reinterpret_cast<const double2 *>(Cs + k * NC);
 #pragma unroll
-                    for (int e = 0; e < NX * NX; ++e) a0[e] = a1[e];
+                        for (int e = 0; e < NA; ++e) {
+                            const double2 t = sa[e];
+                            a[2 * e] = t.x;
+                            a[2 * e + 1] = t.y;
+                        }
 #pragma unroll
-                    for (int e = 0; e < MK * NX; ++e) c0[e] = c1[e];
+                        for (int e = 0; e < NC; ++e) {
+                            const double2 t = sc[e];
+                            c[2 * e] = t.x;
+                            c[2 * e + 1] = t.y;
+                        }
+                    };
+                    fetch(0, pa, pc);
+                    for (int k = 0;;) {
+                        fetch((k + 2 < N) ? k + 2 : k, qa2, qc);
+                        step(k, pa, pc);
+                        if (k + 1 < N) step(k + 1, pa + NA, pc + NC);
+                        k += 2;
+                        if (k >= N) break;
+                        fetch((k + 2 < N) ? k + 2 : k, pa, pc);
+                        step(k, qa2, qc);
+                        if (k + 1 < N) step(k + 1, qa2 + NA, qc + NC);
+                        k += 2;
+                        if (k >= N) break;
+                    }
+                } else if (!sA && !sC) {
+                    // time-invariant A and C: fetched once
+                    T a0[NA], c0[NC];
+#pragma unroll
+                    for (int e = 0; e < NA; ++e) a0[e] = As[e];
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) c0[e] = Cs[e];
+                    for (int k = 0; k < N; ++k) step(k, a0, c0);
+                } else {
+                    T a0[NA], c0[NC];
+#pragma unroll
+                    for (int e = 0; e < NA; ++e) a0[e] = As[e];
+#pragma unroll
+                    for (int e = 0; e < NC; ++e) c0[e] = Cs[e];
+                    for (int k = 0; k < N; ++k) {
+                        const int kn = (k + 1 < N) ? k + 1 : k;
+                        T a1[NA], c1[NC];
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) a1[e] = As[kn * sA + e];
+#pragma unroll
+                        for (int e = 0; e < NC; ++e) c1[e] = Cs[kn * sC + e];
+                        step(k, a0, c0);
+#pragma unroll
+                        for (int e = 0; e < NA; ++e) a0[e] = a1[e];
+#pragma unroll
+                        for (int e = 0; e < NC; ++e) c0[e] = c1[e];
+                    }
                 }
             }
         } else if (!stageP && !stageQ) {
@@ -385,8 +437,10 @@ __global__ void __launch_bounds__(64, 2)
                 if (hl <= NV) advance(k);
             }
         }
+        tick(10);
         gram((T)ka.wt, termP, termQ, gref);  // v = Psi_N
         wsync();
+        tick(11);
         if (low) Gimg[hl * GS + m] = col ? qa : T(0);  // the q row
         wsync();
         hv[hl] = (isc && L.nC) ? eval - hp[hl] : eval;  // h_i = e_i - C_k Phi_k x0
@@ -813,7 +867,7 @@ static Lay make_lay(const KernelArgs &ka)
     L.nB = (ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
     L.nC = ka.C.ptr ? (ka.C.step_stride ? ka.N : 1) * ka.mk * ka.nx : 0;
     L.nD = ka.D.ptr ? (ka.D.step_stride ? ka.N : 1) * ka.mk * ka.nu : 0;
-    y_build += L.nA + L.nB + L.nC + L.nD;
+    y_build += al(L.nA) + al(L.nB) + al(L.nC) + al(L.nD) + 2 * 16;  // + slack for the pair fetch past an odd horizon's last step
     int y_main = ka.m * LDM;                                                 // the M image
     if (y_main < NV * LDM + 2 * (NV + 2)) y_main = NV * LDM + 2 * (NV + 2);  // L image + the factorisation's column buffers
     const int y_sz = al(y_build > y_main ? y_build : y_main);

@@ -6,13 +6,15 @@ import torch
 from qpmpc_amd import PreparedSolve, workloads as W
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 w = W.triple_integrator_batch(batch); bp = W.to_batch_problem(w)
-buf = torch.zeros(batch * 8, dtype=torch.int64, device="cuda")
+one = len(sys.argv) > 2 and sys.argv[2] == "w64"
+SL = 8 if one else 16
+buf = torch.zeros(batch * SL, dtype=torch.int64, device="cuda")
 from qpmpc_amd import _capi
 flags = _capi.OPT_ONE_PER_WAVE if (len(sys.argv) > 2 and sys.argv[2] == "w64") else 0
 run = PreparedSolve(bp, probe=buf, flags=flags)
 for _ in range(3): run.launch()
 torch.cuda.synchronize()
-t = buf.view(batch, 8).cpu().double()
+t = buf.view(batch, SL).cpu().double()
 it = run.iters.cpu().double()
 names = ["build", "cholesky", "fwd-subst", "init", "active-set", "refine+x"]
 d = (t[:, 1:7] - t[:, 0:6])
@@ -22,3 +24,7 @@ for i, nme in enumerate(names):
 print(f"  total        mean {(t[:,6]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,6]-t[:,0]).max().item():10.0f}")
 print(f"  per-iteration (active-set / iters): {(d[:,4].sum()/it.sum()).item():.0f} cyc")
 print(f"  kernel span: {(t[:,6].max()-t[:,0].min()).item():.0f} cyc")
+if not one:
+    sub = t[:, [0, 8, 9, 10, 11, 1]]
+    for nme, a in zip(["stage operands", "x0/e loads, wsync", "chain", "gram", "q row, h"], range(5)):
+        print(f"    build/{nme:18s} mean {(sub[:, a+1]-sub[:, a]).mean().item():8.0f} cyc")
