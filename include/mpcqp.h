@@ -60,6 +60,7 @@ extern "C" {
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
 #define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
 #define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */
+#define MPCQP_EUNSUPPORTED (-6) /* option not available for these dimensions / this dtype    */
 
 /* Problem dimensions and cost weights (mpc_problem.py:88-139).
  * n = N*nu decision variables, m = N*mk inequality rows. Problems whose
@@ -114,18 +115,25 @@ typedef struct MpcqpSolveOpts {
     int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */
     double feas_tol;  /* a row is violated when (h_i-G_i u)/(1+|h_i|) < -tol;
                          <=0 -> 1e-12 (f64) / 1e-5 (f32)                         */
-    /* Warm start (the reference reaches it through **kwargs -> qpsolvers' initvals,
-     * qpmpc/solve_mpc.py:20,43): warm_active[b*warm_stride + a], a < warm_count, lists constraint
-     * rows (0 <= row < m, or -1 = none) expected to be active at the solution of problem b, e.g. the
-     * previous period's active set shifted by one step. The solver adds them first, in that order,
-     * and then continues as usual, so a wrong guess costs iterations, never correctness. NULL = cold. */
-    const int32_t *warm_active;
-    int32_t warm_count;
-    int32_t warm_stride;
-    /* Final active set, nullable: active_out[b*active_stride + a] = constraint row held by slot a,
-     * -1 padded (a < active_stride, at most n rows are ever active). Feeds the next warm start. */
-    int32_t *active_out;
-    int32_t active_stride;
+    /* Warm start for receding-horizon loops (the reference reaches its backends' warm start through
+     * **kwargs -> qpsolvers' initvals, qpmpc/solve_mpc.py:20,43; loops at
+     * examples/wheeled_inverted_pendulum.py:99-118, examples/lipm_walking_controller.py:307-335).
+     * warm_state: caller-owned DEVICE buffer of mpcqp_warm_state_bytes() per problem, packed by problem.
+     *   When non-NULL every solve ENDS by storing its final active set and the active-set operator
+     *   N* = (M_A M_A')^-1 M_A there (M = G L^-T); problems that were not solved store an empty set.
+     * warm_start != 0: the solve BEGINS from the stored state instead of the empty set: multipliers are
+     *   recomputed for the new q and h, rows whose multiplier turned negative leave, violated rows enter
+     *   through the usual iterations -- a period whose active set moved by two rows costs about two
+     *   iterations instead of one per active row.
+     * Contract: N* depends on the matrices only, so the state is meaningful while A, B, C, D and the
+     *   weights are those of the solve that stored it; e, x0, goal and targets may change freely. The
+     *   contract is not trusted: with a warm start a solution is accepted only after its KKT conditions
+     *   were re-checked from scratch (stationarity holds by construction, multipliers >= 0, active rows
+     *   on their bounds, inactive rows feasible); a stale state costs a cold restart, never a wrong plan.
+     * Supported by the small-problem fused kernel (n <= 16, m <= 32, float64); other dimensions return
+     * MPCQP_EUNSUPPORTED when warm_state is given. */
+    void *warm_state;
+    int32_t warm_start;
     int32_t reserved;
     /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (16 for the small-problem
      * kernels, 32 for the mid-size / large ones) that receives shader-clock stamps at phase boundaries. */
@@ -153,6 +161,9 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
 
 /* Same for mpcqp_solve_batch (n variables, m rows). */
 int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t batch, size_t *bytes);
+
+/* Bytes per problem of MpcqpSolveOpts.warm_state for these dimensions (0: no warm start for them). */
+int mpcqp_warm_state_bytes(const MpcqpDims *dims, size_t *bytes);
 
 /* Replaces MPCQP.__init__ (mpc_qp.py:39-122) for a batch: Phi/Psi propagation
  * (:53-54,:88-90), G_k/h_k (:62-78), P (:99-105), q (:129-149).

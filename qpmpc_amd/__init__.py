@@ -15,6 +15,7 @@ from .batch import (  # noqa: F401
     BatchPlan,
     PreparedModelSolve,
     PreparedSolve,
+    WarmState,
     SharedModel,
     rollout_batch,
     solve_mpc_batch,
@@ -41,6 +42,7 @@ __all__ = [
     "BatchMPCQP",
     "BatchPlan",
     "PreparedSolve",
+    "WarmState",
     "SharedModel",
     "PreparedModelSolve",
     "solve_mpc_batch",

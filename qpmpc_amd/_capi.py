@@ -13,6 +13,7 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
+EUNSUPPORTED = -6
 ABI_VERSION = 5
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE = 1, 2, 4, 8
 
@@ -24,6 +25,7 @@ EXPORTS = (
     "mpcqp_error_string",
     "mpcqp_lds_bytes",
     "mpcqp_workspace_bytes",
+    "mpcqp_warm_state_bytes",
     "mpcqp_solve_workspace_bytes",
     "mpcqp_condense_batch",
     "mpcqp_update_vectors_batch",
@@ -57,8 +59,7 @@ class Problem(C.Structure):
 class SolveOpts(C.Structure):
     _fields_ = [
         ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
-        ("warm_active", C.c_void_p), ("warm_count", C.c_int32), ("warm_stride", C.c_int32),
-        ("active_out", C.c_void_p), ("active_stride", C.c_int32), ("reserved", C.c_int32),
+        ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("reserved", C.c_int32),
         ("probe", C.c_void_p),
     ]
 
@@ -94,6 +95,8 @@ def load():
     lib.mpcqp_lds_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
     lib.mpcqp_workspace_bytes.restype = C.c_int
     lib.mpcqp_workspace_bytes.argtypes = [C.POINTER(Dims), i64, C.c_int32, C.POINTER(C.c_size_t)]
+    lib.mpcqp_warm_state_bytes.restype = C.c_int
+    lib.mpcqp_warm_state_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
     lib.mpcqp_solve_workspace_bytes.restype = C.c_int
     lib.mpcqp_solve_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, i64, C.POINTER(C.c_size_t)]
     lib.mpcqp_condense_batch.restype = C.c_int

@@ -327,18 +327,46 @@ def _ws_args(ws):
     return (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
 
 
-def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_active=None, active_out=None, probe=None):
-    """``MpcqpSolveOpts``. ``warm_active`` / ``active_out`` are int32 device tensors [B, k] (row ids, -1 = none);
-    ``flags`` are the explicit dispatch overrides ``_capi.OPT_*`` (tests); ``probe`` an int64 device tensor."""
+def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_state=None, warm_start: bool = False, probe=None):
+    """``MpcqpSolveOpts``. ``warm_state``: a :class:`WarmState` (or a uint8 device tensor) that every solve
+    updates and, with ``warm_start=True``, starts from; ``flags``: the explicit dispatch overrides
+    ``_capi.OPT_*`` (tests); ``probe``: an int64 device tensor for the developer stamps."""
     o = _capi.SolveOpts()
     o.max_iter, o.flags, o.feas_tol = int(max_iter or 0), int(flags), float(feas_tol or 0.0)
-    if warm_active is not None:
-        o.warm_active, o.warm_count, o.warm_stride = warm_active.data_ptr(), int(warm_active.shape[1]), int(warm_active.stride(0))
-    if active_out is not None:
-        o.active_out, o.active_stride = active_out.data_ptr(), int(active_out.stride(0))
+    if warm_state is not None:
+        buf = warm_state.buffer if isinstance(warm_state, WarmState) else warm_state
+        o.warm_state, o.warm_start = buf.data_ptr(), 1 if warm_start else 0
     if probe is not None:
         o.probe = probe.data_ptr()
     return o
+
+
+class WarmState:
+    """Per-problem active set and active-set operator kept in HBM between the periods of
+    receding-horizon loops (``MpcqpSolveOpts.warm_state``). Valid while the problems' matrices and
+    weights stay the same; states, goals, targets and bounds may change. A stale state only costs a
+    cold restart (the kernel re-checks the KKT conditions of what it returns)."""
+
+    def __init__(self, problem: "BatchMPCProblem"):
+        torch = _torch()
+        lib = _capi.load()
+        dims = problem.dims()
+        nbytes = C.c_size_t(0)
+        _capi.check(lib.mpcqp_warm_state_bytes(C.byref(dims), C.byref(nbytes)), "mpcqp_warm_state_bytes")
+        if nbytes.value == 0:
+            raise BackendError(
+                "warm start is available for n = N*nu <= 16 variables, m <= 32 rows, float64 "
+                f"(got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype})")
+        self.bytes_per_problem = int(nbytes.value)
+        self.batch_size = problem.batch_size
+        self.buffer = torch.zeros((problem.batch_size, self.bytes_per_problem), dtype=torch.uint8, device=problem.device)
+        self.buffer[:, 16 * 16 * 8:] = 0xFF  # constraint ids -1: empty set
+
+    @property
+    def active_set(self):
+        """int32 [B, 16]: constraint row held by each slot after the last solve, -1 = empty."""
+        torch = _torch()
+        return self.buffer[:, 16 * 16 * 8:].contiguous().view(torch.int32)
 
 
 class BatchPlan:
@@ -383,9 +411,8 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     """Build and solve every problem of the batch in ONE fused launch
     (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem).
 
-    ``opt_kw``: ``warm_active`` (int32 [B, k] device tensor: rows expected active, -1 = none),
-    ``active_out`` (int32 [B, >= n] device tensor receiving the final active set), ``flags``
-    (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
+    ``opt_kw``: ``warm_state`` (a :class:`WarmState`, updated by every solve) with ``warm_start=True``
+    to begin from it, ``flags`` (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
     if solver not in HIP_SOLVERS:
         raise BackendError(f"solver '{solver}' is not a batched backend; available: {HIP_SOLVERS}")
     torch = _torch()
@@ -439,6 +466,12 @@ class PreparedSolve:
             self.U.data_ptr(), None if self.lam is None else self.lam.data_ptr(),
             self.status.data_ptr(), self.iters.data_ptr(), *_ws_args(self._ws),
         )
+
+    def set_warm_start(self, on: bool) -> None:
+        """Begin the next launches from the ``warm_state`` given at construction (or from the empty set)."""
+        if "warm_state" not in self._opt_kw:
+            raise BackendError("PreparedSolve was built without warm_state=WarmState(problem)")
+        self._opts.warm_start = 1 if on else 0
 
     def launch(self, stream=None) -> None:
         """Enqueue one fused build+solve of the whole batch on ``stream``

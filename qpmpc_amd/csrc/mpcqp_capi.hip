@@ -76,17 +76,8 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
     if (!o) return 0;
     ka.opt_flags = o->flags;
     ka.probe = o->probe;
-    if (o->warm_active) {
-        if (o->warm_count < 0 || o->warm_stride < o->warm_count) return MPCQP_EINVAL;
-        ka.warm_active = o->warm_count > 0 ? o->warm_active : nullptr;
-        ka.warm_count = o->warm_count;
-        ka.warm_stride = o->warm_stride;
-    }
-    if (o->active_out) {
-        if (o->active_stride <= 0) return MPCQP_EINVAL;
-        ka.active_out = o->active_out;
-        ka.active_stride = o->active_stride;
-    }
+    ka.warm_state = o->warm_state;
+    ka.warm_start = o->warm_state ? o->warm_start : 0;
     return 0;
 }
 
@@ -199,8 +190,10 @@ int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t 
 {
     if (!force_lds(ka.opt_flags)) {
         if (!(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE, dtype)) return launch_pair(ka, batch, st);
+        if (ka.warm_state) return MPCQP_EUNSUPPORTED;
         if (w64_eligible(ka, MODE, dtype)) return launch_w64(ka, MODE, dtype, batch, st);
     }
+    if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     Layout L;
     int rc = layout_for(ka, stepA, stepB, MODE, dtype, L);
     if (rc) return rc;
@@ -222,6 +215,7 @@ const char *mpcqp_error_string(int code)
     case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
     case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
     case MPCQP_EWORKSPACE: return "workspace missing or too small (see mpcqp_workspace_bytes)";
+    case MPCQP_EUNSUPPORTED: return "option not available for these dimensions / this dtype (warm start: n <= 16, m <= 32, float64)";
     default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -238,6 +232,17 @@ int mpcqp_lds_bytes(const MpcqpDims *dims, size_t *bytes)
     Layout L = make_layout(ka.nx, ka.nu, ka.N, ka.n, ka.m, true, true, MODE_FUSED, elem_size(dims->dtype));
     *bytes = (size_t)L.total * elem_size(dims->dtype);
     return (*bytes > kLdsBytesPerCU || ka.n > 256) ? MPCQP_ETOOLARGE : 0;
+}
+
+int mpcqp_warm_state_bytes(const MpcqpDims *dims, size_t *bytes)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!bytes) return MPCQP_EINVAL;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    *bytes = pair_eligible(ka, MODE_FUSED, dims->dtype) ? kPairWarmDoubles * sizeof(double) : 0;
+    return 0;
 }
 
 int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solve, size_t *bytes)
@@ -377,6 +382,7 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const 
     ka.status = status;
     ka.iters = iters;
     if (int rc = fill_opts(ka, opts, dtype)) return rc;
+    if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     if (fits_on_chip(ka, false, false, MODE_SOLVE, dtype))
         return run_solver<MODE_SOLVE>(ka, false, false, dtype, batch, (hipStream_t)stream);
     return run_gws_solve(ka, dtype, batch, workspace, workspace_bytes, (hipStream_t)stream);
@@ -400,6 +406,7 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
+    if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
     if (use_mid(ka, dims->dtype)) {
         const size_t need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
@@ -485,6 +492,7 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const Mpcq
     ka.status = status;
     ka.iters = iters;
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+    if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (!force_lds(ka.opt_flags) && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
     Layout L;

@@ -31,10 +31,8 @@ struct KernelArgs {
     const void *model;
     // MpcqpSolveOpts beyond max_iter / feas_tol
     int opt_flags;                // MPCQP_OPT_*
-    const int32_t *warm_active;   // [batch, warm_stride] initial active-set guess, or null
-    int warm_count, warm_stride;
-    int32_t *active_out;          // [batch, active_stride] final active set, or null
-    int active_stride;
+    void *warm_state;             // per-problem active set + operator (read if warm_start, written at the end), or null
+    int warm_start;
     void *probe;                  // developer probe: int64 stamps per problem, or null
 };
 
@@ -153,6 +151,7 @@ int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *
                     const void *GT, const void *h, void *ws, hipStream_t st);
 // small-problem kernel (mpcqp_pair.hip): two problems per wavefront, fused build+solve
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
+constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids
 int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);

@@ -576,8 +576,90 @@ __global__ void __launch_bounds__(64, 2)
     unsigned mask = 0;  // occupied slots
     bool needp = true, dropping = false;
     T up = T(0);
+    const T s0 = s;      // slacks at the unconstrained minimiser (cold restart)
+    bool warm = false;   // this half started from a stored active set
+    bool wfix = false;   // ... and is still repairing it (multipliers that turned negative leave one by one)
+    bool wdrop = false;  // the drop in flight belongs to that repair: back to the multiplier solve afterwards
+    int fails = 0;       // verifications that found a violated row (per half)
+    bool recold = false; // a warm-started half failed inside the loop: restart it from the empty set
+    // back to the empty active set (after a warm start that did not lead to a certified point)
+    auto cold_reset = [&]() {
+        warm = wfix = wdrop = recold = false;
+        fails = 0;
+        iters = 0;
+        if (low) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) RT[k] = T(0);
+        }
+        lam = T(0);
+        occ = false;
+        pos = -1;
+        mask = 0;
+        nq = 0;
+        s = s0;
+        status = MPCQP_MAX_ITER;
+        done = false;
+        needp = true;
+        dropping = false;
+    };
+
+    // ------------------------------------------------------------ warm start (MpcqpSolveOpts.warm_state)
+    // The stored operator T = N* depends on M only (not on q, h), so the previous period's T and
+    // active set are a valid operator for this period as long as the matrices did not change. The
+    // multipliers are recomputed from scratch (lam = -T T' s0_A); while one is negative its row
+    // leaves and they are recomputed; then (y, A) is an S-pair in Goldfarb-Idnani's sense and the
+    // usual iterations go on from it.
+    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
+    if (wstate && ka.warm_start && !notpd) {
+        int *slotof = reinterpret_cast<int *>(kAv);  // 32 ints: slot claiming each constraint
+        int a = -1;
+        if (low) a = reinterpret_cast<const int *>(wstate + NV * NV)[hl];
+        const bool okrow = low && a >= 0 && a < m && hv[(a >= 0 && a < m) ? a : 0] < T(1e29);
+        slotof[hl] = -1;
+        wsync();
+        if (okrow) slotof[a] = hl;  // two slots naming one row: one of them wins
+        wsync();
+        const bool win = okrow && slotof[a] == hl;
+        const int mypos = slotof[hl];
+        const unsigned wmask = (unsigned)(__ballot(win) >> hb) & 0xffffu;
+        const int cnt = __builtin_popcount(wmask);
+        wsync();
+        T wrow[NV];
+        bool finite = true;
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(wstate + (low ? hl : 0) * NV);
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) {
+                const double2 t = win ? src[i] : double2{0.0, 0.0};
+                wrow[2 * i] = t.x;
+                wrow[2 * i + 1] = t.y;
+                finite = finite && (fabs(t.x) < T(1e150)) && (fabs(t.y) < T(1e150));  // false for NaN / inf too
+            }
+        }
+        const bool sane = !half_any(!finite, hb);
+        if (cnt > 0 && cnt <= n && sane) {  // (half-uniform)
+            if (low) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) RT[k] = wrow[k];
+            }
+            if (win) {  // M_A by slot (the refinement and z = -M_p + M_A' r read it)
+                T row[NV];
+                ld16(row, Ml + a * LDM);
+                st16(MAl + hl * NV, row);
+            }
+            occ = win;
+            myact = win ? a : 0;
+            pos = isc ? mypos : -1;
+            mask = wmask;
+            nq = cnt;
+            warm = wfix = true;
+            done = true;  // straight to the multiplier solve
+            needp = false;
+        }
+        wsync();
+    }
     tick(4);
-    for (int round = 0; round < 4; ++round) {
+    for (;;) {
         // ===================================================== active-set loop
         for (;;) {
             // ---- selection, for the halves that start a new constraint
@@ -602,7 +684,8 @@ __global__ void __launch_bounds__(64, 2)
             bool stepping = !done && !dropping;
             if (stepping && iters >= max_iter) {
                 done = true;
-                finished = true;
+                finished = !warm;
+                recold = warm;
                 status = MPCQP_MAX_ITER;
                 stepping = false;
             }
@@ -669,7 +752,8 @@ __global__ void __launch_bounds__(64, 2)
             T t = t1 < t2 ? t1 : t2;
             if (stepping && !(t < INF)) {  // no step possible: the constraints are inconsistent
                 done = true;
-                finished = true;
+                finished = !warm;  // after a warm start the verdict is only trusted from a cold operator
+                recold = warm;
                 status = MPCQP_INFEASIBLE;
                 stepping = false;
             }
@@ -723,6 +807,10 @@ __global__ void __launch_bounds__(64, 2)
                 mask &= ~(1u << ldrop);
                 --nq;
                 dropping = false;
+                if (wdrop) {  // a warm-start repair: the multipliers are solved again before anything else
+                    wdrop = false;
+                    done = true;
+                }
             }
             if (__ballot(partial) != 0ull) {
                 // partial step: the next trip removes slot l from T
@@ -738,9 +826,19 @@ __global__ void __launch_bounds__(64, 2)
             wsync();
         }
         tick(5);
+        if (__ballot(recold) != 0ull) {
+            // rows of empty slots must read as zero in M_A
+            wsync();
+            if (recold)
+                for (int i = hl; i < NV * NV; i += HL) MAl[i] = T(0);
+            if (recold) cold_reset();
+            wsync();
+            if (__ballot(!finished && done) == 0ull) continue;
+        }
         if (__ballot(!finished) == 0ull) break;
-        // ================================== refine multipliers, verify slacks
+        // ================================== multipliers by refinement, slacks re-evaluated
         // (halves that are already finished compute along and change nothing)
+        if (wfix) lam = T(0);  // repair phase: lam = -T T' s0_A from scratch
         wsync();
         rv[vofs] = lam;
         wsync();
@@ -763,6 +861,7 @@ __global__ void __launch_bounds__(64, 2)
         ld16(yy, zv);
         T fresh = hv[hl] - dot16(RM, yy);
         fresh = isc ? fresh : INF;
+        T lraw = lam;  // multipliers before the clamp at zero (repair phase)
         if (__ballot(nq > 0 && !finished) != 0ull) {
             // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A = -T (T' rho_A)
             T rho = half_get(fresh, hb, myact);
@@ -793,8 +892,11 @@ __global__ void __launch_bounds__(64, 2)
                 dl = -dot16(RT, rr);
             }
             dl = occ ? dl : T(0);
-            lam += dl;
-            lam = (occ && lam < T(0)) ? T(0) : lam;
+            if (!finished) {
+                lraw = lam + dl;
+                lam = (occ && lraw < T(0)) ? T(0) : lraw;
+            }
+            // with dl as it is (not clamped) y moves exactly onto the active hyperplanes
             wsync();
             rv[vofs] = dl;
             wsync();
@@ -817,20 +919,73 @@ __global__ void __launch_bounds__(64, 2)
             fresh = hv[hl] - dot16(RM, yy);
             fresh = isc ? fresh : INF;
         }
-        // accept when no inactive row is violated at the re-evaluated point
-        const bool dirty = half_any(selectable && pos < 0 && fresh < -T(4) * tolh, hb);
-        if (!finished) {
-            if (!dirty || round == 3) {
+        // ---- warm-start repair: the most negative multiplier's row leaves, then everything is solved again
+        if (__ballot(wfix && !finished) != 0ull) {
+            unsigned hi, lo;
+            ordered(lraw, hi, lo);
+            const bool negl = wfix && occ && lraw < T(0);
+            const unsigned key = negl ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
+            const unsigned mkey = half_min(key);
+            const bool rep = wfix && !finished;
+            if (rep && mkey != 0xffffffffu) {
+                const int l = (int)(mkey & 31u);
+                ldrop = l;
+                dropping = true;
+                wdrop = true;
+                done = false;
+                needp = false;
+            }
+            const int cl = half_get(myact, hb, ldrop);
+            wsync();
+            if (rep && dropping && hl == ldrop) st16(kAv, RT);
+            if (rep && dropping && hl == cl) pos = -1;
+            wsync();
+            if (rep && !dropping) {
+                // every multiplier is >= 0: (y, A) is an S-pair, the usual iterations take over
+                wfix = false;
+                s = (pos >= 0) ? T(0) : fresh;
+                done = false;
+                needp = true;
+            }
+            if (__ballot(!finished && (wfix || !done)) != 0ull && __ballot(!finished && done) == 0ull) continue;
+        }
+        // ---- acceptance: no inactive row violated, and (after a warm start, whose operator is not trusted)
+        //      every active row on its bound -- with stationarity by construction and lam >= 0 these are
+        //      the KKT conditions of the strictly convex QP
+        bool dirty = half_any(selectable && pos < 0 && !(fresh >= -T(4) * tolh), hb);  // (NaN counts as violated)
+        if (__ballot(warm && !finished) != 0ull) {
+            const T ra = half_get(fresh, hb, myact);
+            const T ta = half_get(tolh, hb, myact);
+            const bool off = half_any(occ && !(fabs(ra) <= T(1e3) * ta), hb);
+            const bool neg = half_any(occ && !(lam >= T(0)), hb);
+            dirty = dirty || (warm && (off || neg));
+        }
+        bool coldnow = false;
+        if (!finished && done && !wfix) {
+            if (!dirty) {
                 xsol = dot16(RT, yy);  // u = L^-T y in lanes 16..31 (yy holds y)
-                status = dirty ? MPCQP_MAX_ITER : MPCQP_SOLVED;
+                status = MPCQP_SOLVED;
                 finished = true;
-            } else {
+            } else if (++fails < 4) {
                 // continue the active-set loop from the re-evaluated slacks
                 s = (pos >= 0) ? T(0) : fresh;
                 status = MPCQP_MAX_ITER;
                 done = false;
                 needp = true;
+            } else if (warm) {
+                coldnow = true;  // the stored state did not lead to a certified point
+            } else {
+                xsol = dot16(RT, yy);
+                status = MPCQP_MAX_ITER;
+                finished = true;
             }
+        }
+        if (__ballot(coldnow) != 0ull) {
+            wsync();
+            if (coldnow)
+                for (int i = hl; i < NV * NV; i += HL) MAl[i] = T(0);
+            if (coldnow) cold_reset();
+            wsync();
         }
         if (__ballot(!finished) == 0ull) break;
     }
@@ -848,6 +1003,12 @@ __global__ void __launch_bounds__(64, 2)
         if (hl == 0) {
             if (ostatus) ostatus[prob] = status;
             if (oiters) oiters[prob] = iters;
+        }
+        if (wstate && low) {  // the operator and the active set for the next period's warm start
+            double2 *dst = reinterpret_cast<double2 *>(wstate + hl * NV);
+#pragma unroll
+            for (int i = 0; i < NV / 2; ++i) dst[i] = double2{RT[2 * i], RT[2 * i + 1]};
+            reinterpret_cast<int *>(wstate + NV * NV)[hl] = (ok && occ) ? myact : -1;
         }
     }
 }

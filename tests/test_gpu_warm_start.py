@@ -1,0 +1,134 @@
+"""GPU tests (-m gpu) of the solver warm start (MpcqpSolveOpts.warm_state):
+the previous solve's active set and active-set operator seed the next one. The reference reaches
+its backends' warm start through **kwargs (qpmpc/solve_mpc.py:20,43) inside receding-horizon loops
+(examples/wheeled_inverted_pendulum.py:99-118). Whatever the stored state, results must equal the
+cold solve / the CPU oracle: the kernel re-checks the KKT conditions of what it returns.
+"""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _solve(bp, **kw):
+    from qpmpc_amd import solve_mpc_batch
+
+    plan = solve_mpc_batch(bp, return_multipliers=True, **kw)
+    torch.cuda.synchronize()
+    return plan.U.cpu().numpy(), plan.status.cpu().numpy(), plan.iters.cpu().numpy(), plan.multipliers.cpu().numpy()
+
+
+def _scale(U):
+    return np.maximum(1.0, np.abs(U).max(axis=1, keepdims=True))
+
+
+@pytest.mark.parametrize("family", ["triple", "humanoid"])
+def test_warm_start_from_own_solution_needs_no_iteration(family):
+    from qpmpc_amd import WarmState
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(1023) if family == "triple" else W.humanoid_batch(1023)
+    bp = W.to_batch_problem(w)
+    ws = WarmState(bp)
+    U0, st0, it0, lam0 = _solve(bp, warm_state=ws)  # cold, stores the state
+    act = ws.active_set.cpu().numpy()
+    ok = st0 == 0
+    assert ok.sum() >= 900
+    # the stored set is the set of rows with a positive multiplier (up to weakly active rows)
+    for b in np.flatnonzero(ok)[:64]:
+        stored = set(int(a) for a in act[b] if a >= 0)
+        assert set(np.flatnonzero(lam0[b] > 1e-9)) <= stored
+    assert (act[~ok] == -1).all()
+    U1, st1, it1, lam1 = _solve(bp, warm_state=ws, warm_start=True)
+    assert np.array_equal(st0, st1)
+    assert (it1[ok] == 0).all(), it1[ok].max()
+    assert (np.abs(U1[ok] - U0[ok]) / _scale(U0[ok])).max() <= 1e-9
+    assert np.abs(lam1[ok] - lam0[ok]).max() <= 1e-6 * max(1.0, np.abs(lam0[ok]).max())
+    # infeasible / failed items restart cold and report the same status
+    assert np.array_equal(it1[~ok], it0[~ok])
+
+
+def test_warm_start_receding_horizon_saves_iterations_same_plans():
+    """A 2048-problem triple-integrator receding horizon: every period the state advances by the first
+    input and the goal moves; warm-started periods must give the cold plans with fewer iterations."""
+    from qpmpc_amd import PreparedSolve, WarmState
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(2048, heterogeneous=False)
+    bp_c, bp_w = W.to_batch_problem(w), W.to_batch_problem(w)
+    ws = WarmState(bp_w)
+    cold, warm = PreparedSolve(bp_c), PreparedSolve(bp_w, warm_state=ws)
+    A = torch.as_tensor(w["A"], device="cuda")
+    Bm = torch.as_tensor(w["B"], device="cuda").reshape(3)
+    it_c = it_w = 0
+    for period in range(12):
+        cold.launch()
+        warm.launch()
+        torch.cuda.synchronize()
+        sc, sw = cold.status.cpu().numpy(), warm.status.cpu().numpy()
+        assert np.array_equal(sc, sw), period
+        ok = sc == 0
+        Uc, Uw = cold.U.cpu().numpy(), warm.U.cpu().numpy()
+        assert (np.abs(Uw[ok] - Uc[ok]) / _scale(Uc[ok])).max() <= 1e-8, period
+        if period >= 1:
+            it_c += int(cold.iters.sum().item())
+            it_w += int(warm.iters.sum().item())
+        # plant: x+ = A x + B u0 (both copies get the cold plan so the two sequences stay identical)
+        x = bp_c.initial_state
+        xn = x @ A.T + cold.U[:, :1] * Bm
+        bp_c.initial_state.copy_(xn)
+        bp_w.initial_state.copy_(xn)
+        warm.set_warm_start(True)
+    assert it_w < 0.6 * it_c, (it_w, it_c)
+
+
+def test_warm_start_with_a_foreign_or_garbage_state_is_still_correct():
+    """The state is not trusted: seeded with another batch's solution, with random bytes, and with a
+    state stored for different matrices, the plans must still match the oracle."""
+    from qpmpc_amd import WarmState
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(512, seed=7)
+    bp = W.to_batch_problem(w)
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    ok = sto == 0
+    # (a) another batch's active sets
+    other = W.to_batch_problem(W.triple_integrator_batch(512, seed=8))
+    ws = WarmState(other)
+    _solve(other, warm_state=ws)
+    U, st, _, _ = _solve(bp, warm_state=ws, warm_start=True)
+    assert np.array_equal(st == 0, ok)
+    assert (np.abs(U[ok] - Uo[ok]) / _scale(Uo[ok])).max() <= 1e-8
+    # (b) random bytes (NaNs, huge values, out-of-range and duplicate row ids)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ws.buffer.copy_(torch.randint(0, 256, ws.buffer.shape, dtype=torch.uint8, device="cuda", generator=g))
+    ids = ws.active_set
+    ids.copy_(torch.randint(-3, 40, ids.shape, dtype=torch.int32, device="cuda", generator=g))
+    ws.buffer[:, 16 * 16 * 8:] = ids.view(torch.uint8)
+    U, st, _, _ = _solve(bp, warm_state=ws, warm_start=True)
+    assert np.array_equal(st == 0, ok)
+    assert (np.abs(U[ok] - Uo[ok]) / _scale(Uo[ok])).max() <= 1e-8
+    # (c) a state stored for different matrices (humanoid sweep), same dimensions
+    hb = W.to_batch_problem(W.humanoid_batch(512))
+    ws2 = WarmState(hb)
+    _solve(hb, warm_state=ws2)
+    U, st, _, _ = _solve(bp, warm_state=ws2, warm_start=True)
+    assert np.array_equal(st == 0, ok)
+    assert (np.abs(U[ok] - Uo[ok]) / _scale(Uo[ok])).max() <= 1e-8
+
+
+def test_warm_start_is_refused_where_it_is_not_implemented():
+    from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(W.wip_batch(4))  # n = 50: mid-size kernel
+    with pytest.raises(BackendError, match="warm start is available"):
+        WarmState(bp)
+    small = W.to_batch_problem(W.triple_integrator_batch(4))
+    ws = WarmState(small)
+    with pytest.raises(BackendError, match="-6"):  # MPCQP_EUNSUPPORTED through the C ABI
+        solve_mpc_batch(small, warm_state=ws, flags=_capi.OPT_FORCE_LDS)
