@@ -18,7 +18,7 @@ import numpy as np
 import ctypes as C
 
 from . import _capi
-from .batch import BatchMPCProblem, PreparedSolve, SharedModel, _dtype_code, _stream_ptr
+from .batch import BatchMPCProblem, PreparedSolve, SharedModel, WarmState, _dtype_code, _stream_ptr
 from .systems import WheeledInvertedPendulum
 
 NB_SUBSTEPS = 15  # examples/wheeled_inverted_pendulum.py:31
@@ -134,7 +134,8 @@ class LIPMWalkingLoop:
     def __init__(self, batch: int, strides=None, foot_size=None, index=None, stride_index=None, support=None,
                  state=None, com_height: float = 0.84, dsp_duration: float = 0.1, ssp_duration: float = 0.7,
                  gravity: float = 9.81, init_support_foot_pos: float = 0.09, nb_timesteps: int = 16,
-                 sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None):
+                 sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None,
+                 warm_start: bool = False):
         import torch
 
         _capi.require_gpu()
@@ -170,7 +171,11 @@ class LIPMWalkingLoop:
         e0 = np.full((batch, N, 2), MAX_ZMP_DIST)
         self.problem = BatchMPCProblem(A, Bm, Cm, None, e0, N, 1.0, None, 1e-3, np.zeros((batch, 3)),
                                        goal_state=np.zeros((batch, 3)))
-        self.solver = PreparedSolve(self.problem, max_iter=max_iter)
+        # warm_start: every period begins from the previous period's active set and operator (the model
+        # A, B, C is time-invariant here, only the bounds e, x0 and the goal move; MpcqpSolveOpts.warm_state)
+        self.warm_state = WarmState(self.problem) if warm_start else None
+        self.solver = (PreparedSolve(self.problem, max_iter=max_iter, warm_state=self.warm_state) if warm_start
+                       else PreparedSolve(self.problem, max_iter=max_iter))
         self._k = torch.arange(N, device=dev)
         self._problem_written = False  # e / goal / x0 of the CURRENT phase are in the problem buffers
         self.mpc_steps = 0
@@ -267,6 +272,8 @@ class LIPMWalkingLoop:
                 if not self._problem_written:
                     self._advance_fused(first=True)
                 self.solver.launch()
+                if self.warm_state is not None and self.mpc_steps == 0:
+                    self.solver.set_warm_start(True)  # from the second period on
                 self._advance_fused(first=False)
                 self._problem_written = True
                 self.failed += (self.solver.status != 0).sum()
@@ -274,6 +281,8 @@ class LIPMWalkingLoop:
                 self._problem_written = False
                 self._write_goal_and_constraints()
                 self.solver.launch()
+                if self.warm_state is not None and self.mpc_steps == 0:
+                    self.solver.set_warm_start(True)
                 ok = self.solver.status == 0
                 jerk = torch.where(ok, self.solver.U[:, 0], torch.zeros_like(self.solver.U[:, 0]))
                 self._integrate(jerk)

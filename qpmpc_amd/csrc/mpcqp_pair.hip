@@ -489,6 +489,23 @@ __global__ void __launch_bounds__(64, 2)
     }
     tick(2);
 
+    // the stored warm-start state is requested now and consumed after the forward substitution
+    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
+    const bool wload = wstate && ka.warm_start && !notpd;
+    int wid = -1;
+    T wrow[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) wrow[k] = T(0);
+    if (wload && low) {
+        wid = reinterpret_cast<const int *>(wstate + NV * NV)[hl];
+        const double2 *src = reinterpret_cast<const double2 *>(wstate + hl * NV);
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i) {
+            const double2 t = src[i];
+            wrow[2 * i] = t.x;
+            wrow[2 * i + 1] = t.y;
+        }
+    }
     // ------------------------------------------------------------ rows, forward substitution
     T RM[NV], RT[NV];
     {
@@ -580,11 +597,12 @@ __global__ void __launch_bounds__(64, 2)
     bool warm = false;   // this half started from a stored active set
     bool wfix = false;   // ... and is still repairing it (multipliers that turned negative leave one by one)
     bool wdrop = false;  // the drop in flight belongs to that repair: back to the multiplier solve afterwards
+    bool negl = false;   // slot lanes: this slot's multiplier came out negative, the slot leaves during the repair
     int fails = 0;       // verifications that found a violated row (per half)
     bool recold = false; // a warm-started half failed inside the loop: restart it from the empty set
     // back to the empty active set (after a warm start that did not lead to a certified point)
     auto cold_reset = [&]() {
-        warm = wfix = wdrop = recold = false;
+        warm = wfix = wdrop = recold = negl = false;
         fails = 0;
         iters = 0;
         if (low) {
@@ -609,11 +627,9 @@ __global__ void __launch_bounds__(64, 2)
     // multipliers are recomputed from scratch (lam = -T T' s0_A); while one is negative its row
     // leaves and they are recomputed; then (y, A) is an S-pair in Goldfarb-Idnani's sense and the
     // usual iterations go on from it.
-    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
-    if (wstate && ka.warm_start && !notpd) {
+    if (wload) {
         int *slotof = reinterpret_cast<int *>(kAv);  // 32 ints: slot claiming each constraint
-        int a = -1;
-        if (low) a = reinterpret_cast<const int *>(wstate + NV * NV)[hl];
+        const int a = wid;
         const bool okrow = low && a >= 0 && a < m && hv[(a >= 0 && a < m) ? a : 0] < T(1e29);
         slotof[hl] = -1;
         wsync();
@@ -624,23 +640,14 @@ __global__ void __launch_bounds__(64, 2)
         const unsigned wmask = (unsigned)(__ballot(win) >> hb) & 0xffffu;
         const int cnt = __builtin_popcount(wmask);
         wsync();
-        T wrow[NV];
         bool finite = true;
-        {
-            const double2 *src = reinterpret_cast<const double2 *>(wstate + (low ? hl : 0) * NV);
 #pragma unroll
-            for (int i = 0; i < NV / 2; ++i) {
-                const double2 t = win ? src[i] : double2{0.0, 0.0};
-                wrow[2 * i] = t.x;
-                wrow[2 * i + 1] = t.y;
-                finite = finite && (fabs(t.x) < T(1e150)) && (fabs(t.y) < T(1e150));  // false for NaN / inf too
-            }
-        }
-        const bool sane = !half_any(!finite, hb);
+        for (int k = 0; k < NV; ++k) finite = finite && (fabs(wrow[k]) < T(1e150));  // false for NaN / inf too
+        const bool sane = !half_any(win && !finite, hb);
         if (cnt > 0 && cnt <= n && sane) {  // (half-uniform)
             if (low) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k) RT[k] = wrow[k];
+                for (int k = 0; k < NV; ++k) RT[k] = win ? wrow[k] : T(0);
             }
             if (win) {  // M_A by slot (the refinement and z = -M_p + M_A' r read it)
                 T row[NV];
@@ -807,7 +814,23 @@ __global__ void __launch_bounds__(64, 2)
                 mask &= ~(1u << ldrop);
                 --nq;
                 dropping = false;
-                if (wdrop) {  // a warm-start repair: the multipliers are solved again before anything else
+            }
+            if (__ballot(drp && wdrop) != 0ull) {
+                // warm-start repair: every slot whose multiplier was negative leaves, one pass each, then the
+                // multipliers are solved again (rows dropped in excess come back through the usual iterations)
+                const bool mine = drp && wdrop;
+                if (hl == ldrop) negl = false;
+                const unsigned nk = half_min((mine && negl && occ) ? (unsigned)hl : 0xffffffffu);
+                const bool more = mine && nk != 0xffffffffu;
+                const int nl = more ? (int)nk : 0;
+                const int cl = half_get(myact, hb, nl);
+                wsync();
+                if (more && hl == nl) st16(kAv, RT);  // its row AFTER this pass
+                if (more && hl == cl) pos = -1;
+                if (more) {
+                    ldrop = nl;
+                    dropping = true;
+                } else if (mine) {
                     wdrop = false;
                     done = true;
                 }
@@ -839,28 +862,35 @@ __global__ void __launch_bounds__(64, 2)
         // ================================== multipliers by refinement, slacks re-evaluated
         // (halves that are already finished compute along and change nothing)
         if (wfix) lam = T(0);  // repair phase: lam = -T T' s0_A from scratch
-        wsync();
-        rv[vofs] = lam;
-        wsync();
-        T y;
-        {
-            T rr[NV];
-            ld16(rr, rv);
-            const T *colp = MAl + l15;
-            T a0 = T(0), a1 = T(0);
-#pragma unroll
-            for (int a = 0; a < NV; a += 2) {
-                a0 += rr[a] * colp[a * NV];
-                a1 += rr[a + 1] * colp[(a + 1) * NV];
-            }
-            y = -y0v[l15] - (a0 + a1);  // y = y0 - M_A' lam, y0 = -L^-1 q
-        }
-        zv[vofs] = y;
-        wsync();
+        T y = -y0v[l15];       // y0 = -L^-1 q
         T yy[NV];
-        ld16(yy, zv);
-        T fresh = hv[hl] - dot16(RM, yy);
-        fresh = isc ? fresh : INF;
+        T fresh = s0;          // slacks at y0
+        if (__ballot(!wfix && !finished) != 0ull) {
+            wsync();
+            rv[vofs] = lam;
+            wsync();
+            {
+                T rr[NV];
+                ld16(rr, rv);
+                const T *colp = MAl + l15;
+                T a0 = T(0), a1 = T(0);
+#pragma unroll
+                for (int a = 0; a < NV; a += 2) {
+                    a0 += rr[a] * colp[a * NV];
+                    a1 += rr[a + 1] * colp[(a + 1) * NV];
+                }
+                y -= a0 + a1;  // y = y0 - M_A' lam
+            }
+            zv[vofs] = y;
+            wsync();
+            ld16(yy, zv);
+            fresh = hv[hl] - dot16(RM, yy);
+            fresh = isc ? fresh : INF;
+        } else {
+            zv[vofs] = y;
+            wsync();
+            ld16(yy, zv);
+        }
         T lraw = lam;  // multipliers before the clamp at zero (repair phase)
         if (__ballot(nq > 0 && !finished) != 0ull) {
             // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A = -T (T' rho_A)
@@ -923,7 +953,7 @@ __global__ void __launch_bounds__(64, 2)
         if (__ballot(wfix && !finished) != 0ull) {
             unsigned hi, lo;
             ordered(lraw, hi, lo);
-            const bool negl = wfix && occ && lraw < T(0);
+            negl = wfix && !finished && occ && lraw < T(0);
             const unsigned key = negl ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
             const unsigned mkey = half_min(key);
             const bool rep = wfix && !finished;
@@ -941,13 +971,13 @@ __global__ void __launch_bounds__(64, 2)
             if (rep && dropping && hl == cl) pos = -1;
             wsync();
             if (rep && !dropping) {
-                // every multiplier is >= 0: (y, A) is an S-pair, the usual iterations take over
+                // every multiplier is >= 0: (y, A) is an S-pair. It goes through the acceptance test below
+                // (lam, y and the slacks are those of this very set); violated rows, if any, enter through the
+                // usual iterations from there.
                 wfix = false;
-                s = (pos >= 0) ? T(0) : fresh;
-                done = false;
-                needp = true;
+                fails = -1;  // this first test is not a failed verification
             }
-            if (__ballot(!finished && (wfix || !done)) != 0ull && __ballot(!finished && done) == 0ull) continue;
+            if (__ballot(!finished && done) == 0ull) continue;
         }
         // ---- acceptance: no inactive row violated, and (after a warm start, whose operator is not trusted)
         //      every active row on its bound -- with stationarity by construction and lam >= 0 these are
