@@ -137,6 +137,10 @@ def check(code: int, what: str) -> None:
     """Turn a non-zero return code of the C ABI into ``BackendError``."""
     if code != 0:
         msg = load().mpcqp_error_string(code).decode()
+        if code == -2:  # MPCQP_ETOOLARGE: name the envelope instead of leaving the caller guessing
+            msg += (". Supported by the dense condensed path: n = N*nu <= 256 variables; problems that do not fit "
+                    "160 KiB of LDS additionally need nx <= 16. Longer horizons: solve_mpc_batch(..., "
+                    "formulation='stagewise')")
         raise BackendError(f"{what} failed with code {code}: {msg}")
 
 

@@ -264,9 +264,16 @@ class BatchMPCProblem:
         anyD = any(p.get_ineq_input_matrix(k) is not None for p in problems for k in range(N))
         Cm = np.zeros((Bn, N, mk, nx)) if anyC else None
         Dm = np.zeros((Bn, N, mk, nu)) if anyD else None
+        weights = (p0.terminal_cost_weight, p0.stage_state_cost_weight, p0.stage_input_cost_weight)
         for b, p in enumerate(problems):
             if (p.nb_timesteps, p.state_dim, p.input_dim) != (N, nx, nu):
                 raise ProblemDefinitionError("problems of a batch must share (N, nx, nu)")
+            if (p.terminal_cost_weight, p.stage_state_cost_weight, p.stage_input_cost_weight) != weights:
+                raise ProblemDefinitionError(
+                    "problems of a batch must share the three cost weights "
+                    f"(problem 0: {weights}, problem {b}: "
+                    f"{(p.terminal_cost_weight, p.stage_state_cost_weight, p.stage_input_cost_weight)}); "
+                    "group the problems by weights and solve one batch per group")
             if p.initial_state is None:
                 raise ProblemDefinitionError("initial state is undefined")
             for k in range(N):

@@ -506,7 +506,6 @@ int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const Mpcq
     int rc = check_dims(dims);
     if (rc) return rc;
     if (!A || !B || !x0 || !A->ptr || !B->ptr || !x0->ptr || !U || !X || batch < 0) return MPCQP_EINVAL;
-    if (dims->nx > 64) return MPCQP_ETOOLARGE;
     if (batch == 0) return 0;
     KernelArgs ka;
     fill_args(ka, dims, nullptr);

@@ -619,20 +619,22 @@ __global__ void __launch_bounds__(64) mpcqp_phi_kernel(const KernelArgs ka)
 {
     const int nx = ka.nx, N = ka.N;
     const int64_t prob = blockIdx.x;
-    const int c = threadIdx.x;
-    if (c >= nx) return;
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
     const int64_t sA = ka.A.step_stride;
     T *oPhi = (T *)ka.Phi + prob * (int64_t)(N + 1) * nx * nx;
-    for (int s = 0; s < nx; ++s) oPhi[s * nx + c] = (s == c) ? T(1) : T(0);
-    for (int k = 0; k < N; ++k) {
-        const T *Ak = gA + k * sA;
-        const T *src = oPhi + (int64_t)k * nx * nx;
-        T *dst = oPhi + (int64_t)(k + 1) * nx * nx;
-        for (int r = 0; r < nx; ++r) {
-            T acc = T(0);
-            for (int s = 0; s < nx; ++s) acc += Ak[r * nx + s] * src[s * nx + c];
-            dst[r * nx + c] = acc;
+    // a lane owns columns c, c + 64, ... (any state dimension); a column's chain only reads what the same
+    // lane wrote one step earlier
+    for (int c = threadIdx.x; c < nx; c += 64) {
+        for (int s = 0; s < nx; ++s) oPhi[s * nx + c] = (s == c) ? T(1) : T(0);
+        for (int k = 0; k < N; ++k) {
+            const T *Ak = gA + k * sA;
+            const T *src = oPhi + (int64_t)k * nx * nx;
+            T *dst = oPhi + (int64_t)(k + 1) * nx * nx;
+            for (int r = 0; r < nx; ++r) {
+                T acc = T(0);
+                for (int s = 0; s < nx; ++s) acc += Ak[r * nx + s] * src[s * nx + c];
+                dst[r * nx + c] = acc;
+            }
         }
     }
 }
@@ -723,6 +725,37 @@ __global__ void __launch_bounds__(64) mpcqp_rollout_kernel(const KernelArgs ka, 
     }
 }
 
+// The same roll-out for state dimensions above 64: one problem per wavefront, the state in two LDS
+// buffers, lane r owns rows r, r + 64, ...
+template <typename T>
+__global__ void __launch_bounds__(64) mpcqp_rollout_wide_kernel(const KernelArgs ka)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rollout_smem[];
+    T *xa = (T *)rollout_smem, *xb = xa + ka.nx;
+    const int nx = ka.nx, nu = ka.nu, N = ka.N, lane = threadIdx.x;
+    const int64_t pb = blockIdx.x;
+    const T *gA = (const T *)ka.A.ptr + pb * ka.A.batch_stride;
+    const T *gB = (const T *)ka.B.ptr + pb * ka.B.batch_stride;
+    const T *gx0 = (const T *)ka.x0.ptr + pb * ka.x0.batch_stride;
+    const T *gU = (const T *)ka.U + pb * (int64_t)N * nu;
+    T *oX = (T *)ka.X + pb * (int64_t)(N + 1) * nx;
+    for (int r = lane; r < nx; r += 64) oX[r] = xa[r] = gx0[r];
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const T *Ak = gA + k * ka.A.step_stride, *Bk = gB + k * ka.B.step_stride;
+        for (int r = lane; r < nx; r += 64) {
+            T acc = T(0);
+            for (int s = 0; s < nx; ++s) acc += Ak[r * nx + s] * xa[s];
+            for (int c = 0; c < nu; ++c) acc += Bk[r * nu + c] * gU[k * nu + c];
+            oX[(k + 1) * nx + r] = xb[r] = acc;
+        }
+        __syncthreads();
+        T *t = xa;
+        xa = xb;
+        xb = t;
+    }
+}
+
 // ------------------------------------------------------------ host launchers
 template <typename T, int WAVES, int MODE>
 static int launch_lds(const KernelArgs &ka, const Layout &L, int64_t batch, hipStream_t st)
@@ -782,6 +815,15 @@ int launch_update(const KernelArgs &ka, int dtype, int64_t phi_bs, int64_t psi_b
 
 int launch_rollout(const KernelArgs &ka, int dtype, int64_t batch, hipStream_t st)
 {
+    if (ka.nx > 64) {
+        const size_t bytes = 2 * (size_t)ka.nx * (dtype == MPCQP_F64 ? 8 : 4);
+        if (bytes > 64 * 1024) return MPCQP_ETOOLARGE;
+        if (dtype == MPCQP_F64)
+            hipLaunchKernelGGL(mpcqp_rollout_wide_kernel<double>, dim3((unsigned)batch), dim3(64), bytes, st, ka);
+        else
+            hipLaunchKernelGGL(mpcqp_rollout_wide_kernel<float>, dim3((unsigned)batch), dim3(64), bytes, st, ka);
+        return (int)hipGetLastError();
+    }
     int gp = 1;
     while (gp < ka.nx) gp <<= 1;
     const int per = 64 / gp;

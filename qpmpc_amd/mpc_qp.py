@@ -67,23 +67,31 @@ class MPCQP:
     def __init__(self, mpc_problem: MPCProblem, sparse: bool = False) -> None:
         if mpc_problem.initial_state is None:
             raise ProblemDefinitionError("initial state is undefined")
-        bp = BatchMPCProblem.from_problems([mpc_problem])
-        self._batch_problem = bp
-        self._dev = BatchMPCQP(bp, keep_propagators=True)
-        self._rows = bp.valid_rows
-        self._sparse = sparse
         N, nx = mpc_problem.nb_timesteps, mpc_problem.state_dim
-        # ONE device-to-host copy for everything the reference exposes as NumPy attributes
-        import torch
+        self._sparse = sparse
+        self._upd = None  # staging buffers of the q / h updates, created on first use
+        from .single import condense_single
 
-        d = self._dev
-        parts = [d.Phi_all[0], d.Psi_all[0], d.P[0], d.G[0], d.q[0], d.h[0]]
-        flat = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy()
-        views, o = [], 0
-        for t in parts:
-            views.append(flat[o: o + t.numel()].reshape(tuple(t.shape)))
-            o += t.numel()
-        Phi_all, Psi_all, P, G, q, h = views
+        fast = condense_single(mpc_problem)  # one upload, one launch (+ Phi), one download
+        if fast is not None:
+            (Phi_all, Psi_all, P, G, q, h), self._ctx = fast
+            self._rows = np.arange(G.shape[0])
+        else:  # ragged per-step row counts: the batch containers pad them
+            bp = BatchMPCProblem.from_problems([mpc_problem])
+            dev = BatchMPCQP(bp, keep_propagators=True)
+            self._rows = bp.valid_rows
+            import torch
+
+            parts = [dev.Phi_all[0], dev.Psi_all[0], dev.P[0], dev.G[0], dev.q[0], dev.h[0]]
+            flat = torch.cat([t.reshape(-1) for t in parts]).cpu().numpy()
+            views, o = [], 0
+            for t in parts:
+                views.append(flat[o: o + t.numel()].reshape(tuple(t.shape)))
+                o += t.numel()
+            Phi_all, Psi_all, P, G, q, h = views
+            self._ctx = {"out": dev, "in": bp, "cp": bp.c_problem(), "dims": bp.dims(), "Phi": dev.Phi_all.data_ptr(),
+                         "Psi": dev.Psi_all.data_ptr(), "nx": nx, "N": N, "n": bp.nb_variables,
+                         "m": bp.nb_constraints, "device": bp.device}
         self.Phi, self.phi_last = Phi_all[: N * nx], Phi_all[N * nx:]
         self.Psi, self.psi_last = Psi_all[: N * nx], Psi_all[N * nx:]
         G = G[self._rows]
@@ -125,25 +133,80 @@ class MPCQP:
         except ImportError:
             return QPData(self.P, self.q, self.G, self.h)
 
-    def _refresh_states(self, mpc_problem: MPCProblem) -> None:
+    def _update_vectors(self, mpc_problem: MPCProblem):
+        """q and h for the problem's current x0 / goal / targets in ONE round trip: the three states are
+        packed into one pinned buffer (one upload), ``mpcqp_update_vectors_batch`` computes both vectors in
+        one launch from the Phi/Psi kept on the device, and ``[q | h]`` comes back in one copy. The result is
+        memoised on the states, so ``update_cost_vector`` followed by ``update_constraint_vector`` for the same
+        problem -- the reference's usage, doc/src/developer-notes.rst:10 -- costs a single launch."""
+        import ctypes as C
+
+        import torch
+
+        from . import _capi
+
         if mpc_problem.initial_state is None:
             raise ProblemDefinitionError("initial state is undefined")
-        bp = self._batch_problem
-        bp.update_initial_state(mpc_problem.initial_state)
-        bp.terminal_cost_weight = mpc_problem.terminal_cost_weight
-        bp.stage_state_cost_weight = mpc_problem.stage_state_cost_weight
-        bp.goal_state = None
-        bp.target_states = None
-        if mpc_problem.goal_state is not None:
-            bp.update_goal_state(mpc_problem.goal_state)
-        if mpc_problem.target_states is not None:
-            bp.update_target_states(mpc_problem.target_states)
+        ctx = self._ctx
+        nx, N, n, m = ctx["nx"], ctx["N"], ctx["n"], ctx["m"]
+        u = self._upd
+        if u is None:
+            u = self._upd = {}
+            # Pinned host buffers that the kernel reads and writes DIRECTLY (ROCm maps pinned host memory
+            # into the device's address space at the same address): a q / h update is one launch and one
+            # stream synchronisation, no copy commands -- 2 N nx + n + m doubles cross PCIe either way.
+            u["h_in"] = torch.empty((2 * nx + N * nx,), dtype=torch.float64).pin_memory()
+            u["h_out"] = torch.empty((n + m,), dtype=torch.float64).pin_memory()
+            u["key"] = None
+            base = u["h_in"].data_ptr()
+            cp = ctx["cp"]
+            cp.x0 = _capi.Operand(base, 0, 0)
+            u["goal_op"] = _capi.Operand(base + 8 * nx, 0, 0)
+            u["tgt_op"] = _capi.Operand(base + 16 * nx, 0, 0)
+            u["cp"] = cp
+        x0 = np.asarray(mpc_problem.initial_state, dtype=np.float64).ravel()
+        goal, tgt = mpc_problem.goal_state, mpc_problem.target_states
+        wt, wx = mpc_problem.terminal_cost_weight, mpc_problem.stage_state_cost_weight
+        key = (x0.tobytes(), None if goal is None else np.asarray(goal, dtype=np.float64).tobytes(),
+               None if tgt is None else np.asarray(tgt, dtype=np.float64).tobytes(), wt, wx)
+        if u["key"] == key:
+            return u["q"], u["h"]
+        buf = u["h_in"].numpy()
+        buf[:nx] = x0
+        if goal is not None:
+            buf[nx:2 * nx] = np.asarray(goal, dtype=np.float64).ravel()
+        if tgt is not None:
+            buf[2 * nx:] = np.asarray(tgt, dtype=np.float64).ravel()
+        # cost flags as BatchMPCProblem.cost_flags (mpc_qp.py:119-122, mpc_problem.py:141-166)
+        flags = (_capi.P_TERMINAL if wt is not None else 0) | (_capi.P_STAGE if wx is not None else 0)
+        t_on, s_on = wt is not None and wt > 1e-10, wx is not None and wx > 1e-10
+        if not (t_on and goal is None):
+            if t_on:
+                flags |= _capi.Q_TERMINAL
+            if s_on and tgt is not None:
+                flags |= _capi.Q_STAGE
+        dims = ctx["dims"]
+        dims.flags = flags
+        dims.w_terminal = 0.0 if wt is None else float(wt)
+        dims.w_stage = 0.0 if wx is None else float(wx)
+        cp = u["cp"]
+        cp.goal = u["goal_op"] if goal is not None else _capi.Operand(None, 0, 0)
+        cp.targets = u["tgt_op"] if tgt is not None else _capi.Operand(None, 0, 0)
+        stream = torch.cuda.current_stream()
+        out = u["h_out"].data_ptr()
+        rc = _capi.load().mpcqp_update_vectors_batch(
+            C.byref(dims), C.byref(cp), ctx["Phi"], 0, ctx["Psi"], 0, 1, out,
+            (out + 8 * n) if m else None, C.c_void_p(stream.cuda_stream))
+        _capi.check(rc, "mpcqp_update_vectors_batch")
+        stream.synchronize()
+        res = u["h_out"].numpy()
+        u["q"], u["h"], u["key"] = res[:n].copy(), res[n:].copy(), key
+        return u["q"], u["h"]
 
     def update_cost_vector(self, mpc_problem: MPCProblem) -> None:
         """Recompute q for new x0 / goal / targets (mpc_qp.py:129-149)."""
-        self._refresh_states(mpc_problem)
-        self._dev.update_cost_vector(self._batch_problem)
-        self.q[:] = self._dev.q[0].cpu().numpy()
+        q, _ = self._update_vectors(mpc_problem)
+        self.q[:] = q
         # the reference raises AFTER accumulating the terminal term when targets
         # are missing (mpc_qp.py:145 -> mpc_problem.py:161-165); same here
         mpc_problem.has_terminal_cost
@@ -154,6 +217,5 @@ class MPCQP:
         if mpc_problem.initial_state is None:
             raise ProblemDefinitionError("initial state is undefined")
         if self.C is not None:
-            self._refresh_states(mpc_problem)
-            self._dev.update_constraint_vector(self._batch_problem)
-            self.h = self._dev.h[0].cpu().numpy()[self._rows]
+            _, h = self._update_vectors(mpc_problem)
+            self.h = h[self._rows].copy()

@@ -13,6 +13,7 @@ Problems with ragged per-step row counts take the general path.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -58,21 +59,29 @@ class _Runner:
         self.h_out = torch.empty((self.out_f + 1,), dtype=torch.float64).pin_memory()
         self.h_out_np = self.h_out.numpy()
         self.h_out_i32 = self.h_out_np[self.out_f:].view(np.int32)
-        base = self.d_in.data_ptr()
         blocks = [nx * nx, nx * nu, mk * nx, mk * nu, mk]
 
-        def op(i, present=True):
-            if not present or sizes[i] == 0:
-                return _capi.Operand(None, 0, 0)
-            step = blocks[i] if (i < 5 and steps[i] > 1) else 0
-            return _capi.Operand(base + 8 * int(self.offsets[i]), 0, step)
+        def problem_at(base):
+            def op(i, present=True):
+                if not present or sizes[i] == 0:
+                    return _capi.Operand(None, 0, 0)
+                step = blocks[i] if (i < 5 and steps[i] > 1) else 0
+                return _capi.Operand(base + 8 * int(self.offsets[i]), 0, step)
 
-        self.cp = _capi.Problem(op(0), op(1), op(2), op(3), op(4), op(5), op(6, has_goal), op(7, has_targets))
-        ob = self.d_out.data_ptr()
+            return _capi.Problem(op(0), op(1), op(2), op(3), op(4), op(5), op(6, has_goal), op(7, has_targets))
+
+        self.cp = problem_at(self.d_in.data_ptr())
+        # Small problems skip the two copy commands: ROCm maps pinned host memory into the device's address
+        # space at the same address, so the kernels read the operands from, and write the results to, the
+        # pinned buffers directly (a few KB over PCIe either way); one call = launches + one synchronisation.
+        self.zero_copy = 8 * (total + self.out_f + 1) <= 32 * 1024
+        self.cp_host = problem_at(self.h_in.data_ptr())
+        ob = self.h_out.data_ptr() if self.zero_copy else self.d_out.data_ptr()
         self.pU, self.pLam, self.pX = ob, ob + 8 * n, ob + 8 * (n + m)
         self.pStatus, self.pIters = ob + 8 * self.out_f, ob + 8 * self.out_f + 4
         self.ws = None
         self.ws_key = None
+        self.c_host = self.c_ws = None  # condense_single's staging, created on first use
 
     def workspace(self, dims):
         key = (dims.flags,)
@@ -84,9 +93,9 @@ class _Runner:
         return (None, 0) if self.ws is None else (self.ws.data_ptr(), self.ws.numel())
 
 
-def solve_single(problem, max_iter=None, feas_tol=None):
-    """(x [n] | None, z [m] | None, X [N+1, nx] | None, status, iters) for one host ``MPCProblem``, or
-    ``None`` when the problem needs the general path (ragged per-step row counts)."""
+def _pack(problem):
+    """Runner for the problem's layout with the operands written into its pinned buffer, plus the
+    dims struct; ``None`` when the problem needs the general path (ragged per-step row counts)."""
     N, nx, nu = problem.nb_timesteps, problem.state_dim, problem.input_dim
     try:
         e, se = _field(problem.ineq_vector, N, (-1,))
@@ -100,11 +109,16 @@ def solve_single(problem, max_iter=None, feas_tol=None):
     except ValueError:  # ragged rows or None inside a list
         return None
     goal, targets = problem.goal_state, problem.target_states
-    key = (nx, nu, N, mk, sa, sb, sc, sd, se, goal is not None, targets is not None)
+    # staging buffers are per layout, per device AND per host thread (two threads solving the same layout
+    # must not share pinned / device buffers; after torch.cuda.set_device the buffers must follow)
+    import torch as _t
+
+    key = (nx, nu, N, mk, sa, sb, sc, sd, se, goal is not None, targets is not None,
+           _t.cuda.current_device() if _t.cuda.is_available() else -1, threading.get_ident())
     r = _RUNNERS.get(key)
     if r is None:
         r = _RUNNERS[key] = _Runner(nx, nu, N, mk, (sa, sb, sc, sd, se), goal is not None, targets is not None)
-    torch, lib, o, buf = r.torch, r.lib, r.offsets, r.h_in_np
+    o, buf = r.offsets, r.h_in_np
     for i, arr in enumerate((A, B, Cm, Dm, e)):
         if arr is not None:
             buf[o[i]:o[i + 1]] = arr.ravel()
@@ -123,17 +137,81 @@ def solve_single(problem, max_iter=None, feas_tol=None):
             flags |= _capi.Q_STAGE
     dims = _capi.Dims(nx, nu, N, mk, _capi.F64, flags, 0.0 if wt is None else float(wt), 0.0 if wx is None else float(wx),
                       float(problem.stage_input_cost_weight))
+    return r, dims
+
+
+def condense_single(problem):
+    """(Phi_all [(N+1) nx, nx], Psi_all [(N+1) nx, n], P, G, q, h) of one host ``MPCProblem`` as NumPy
+    arrays: one upload, ``mpcqp_condense_batch`` with a batch of one, one download (``MPCQP.__init__``,
+    qpmpc/mpc_qp.py:39-122); ``None`` when the problem needs the general path."""
+    packed = _pack(problem)
+    if packed is None:
+        return None
+    r, dims = packed
+    torch, lib = r.torch, r.lib
+    nx, N, n, m = r.nx, r.N, r.n, r.m
+    sizes = [(N + 1) * nx * nx, (N + 1) * nx * n, n * n, m * n, n, m]
+    total = sum(sizes)
+    if r.c_host is None:
+        nbytes = C.c_size_t(0)
+        rc = lib.mpcqp_workspace_bytes(C.byref(dims), 1, 0, C.byref(nbytes))
+        if rc != 0:
+            return None  # too large for the condensing kernels: the general path reports it
+        r.c_ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=r.device) if nbytes.value else None
+        r.c_host = torch.empty((total,), dtype=torch.float64).pin_memory()
+    # the outputs and a copy of the operands belong to the caller (MPCQP keeps Phi/Psi/C/e on the device for
+    # update_cost_vector / update_constraint_vector); the staging buffers are the runner's
+    c_out = torch.empty((total,), dtype=torch.float64, device=r.device)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    base = c_out.data_ptr()
+    ptr = [base + 8 * int(o) for o in offs[:-1]]
+    stream = torch.cuda.current_stream()
+    r.d_in.copy_(r.h_in, non_blocking=True)
+    rc = lib.mpcqp_condense_batch(C.byref(dims), C.byref(r.cp), 1, ptr[2], ptr[4], ptr[3] if m else None,
+                                  ptr[5] if m else None, ptr[0], ptr[1],
+                                  None if r.c_ws is None else r.c_ws.data_ptr(), 0 if r.c_ws is None else r.c_ws.numel(),
+                                  C.c_void_p(stream.cuda_stream))
+    _capi.check(rc, "mpcqp_condense_batch")
+    r.c_host.copy_(c_out, non_blocking=True)
+    own_in = r.d_in.clone()
+    stream.synchronize()
+    flat = r.c_host.numpy().copy()
+    shapes = [((N + 1) * nx, nx), ((N + 1) * nx, n), (n, n), (m, n), (n,), (m,)]
+    arrays = tuple(flat[offs[i]:offs[i + 1]].reshape(shapes[i]) for i in range(6))
+    # operands of this problem inside its own copy of the input buffer
+    shift = own_in.data_ptr() - r.d_in.data_ptr()
+    cp = _capi.Problem()
+    for name in ("A", "B", "C", "D", "e", "x0", "goal", "targets"):
+        op = getattr(r.cp, name)
+        setattr(cp, name, _capi.Operand(op.ptr + shift if op.ptr else None, op.batch_stride, op.step_stride))
+    keep = {"out": c_out, "in": own_in, "cp": cp, "dims": dims, "Phi": ptr[0], "Psi": ptr[1],
+            "nx": nx, "N": N, "n": n, "m": m, "device": r.device}
+    return arrays, keep
+
+
+def solve_single(problem, max_iter=None, feas_tol=None):
+    """(x [n] | None, z [m] | None, X [N+1, nx] | None, status, iters) for one host ``MPCProblem``, or
+    ``None`` when the problem needs the general path (ragged per-step row counts)."""
+    packed = _pack(problem)
+    if packed is None:
+        return None
+    r, dims = packed
+    torch, lib = r.torch, r.lib
+    N, nx = r.N, r.nx
     opts = _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))  # remaining fields: NULL / 0
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
-    r.d_in.copy_(r.h_in, non_blocking=True)
+    cp = r.cp_host if r.zero_copy else r.cp
+    if not r.zero_copy:
+        r.d_in.copy_(r.h_in, non_blocking=True)
     ws_ptr, ws_len = r.workspace(dims)
-    rc = lib.mpcqp_build_solve_batch(C.byref(dims), C.byref(r.cp), 1, C.byref(opts), r.pU, r.pLam, r.pStatus, r.pIters,
+    rc = lib.mpcqp_build_solve_batch(C.byref(dims), C.byref(cp), 1, C.byref(opts), r.pU, r.pLam, r.pStatus, r.pIters,
                                      ws_ptr, ws_len, sp)
     _capi.check(rc, "mpcqp_build_solve_batch")
-    rc = lib.mpcqp_rollout_batch(C.byref(dims), C.byref(r.cp.A), C.byref(r.cp.B), C.byref(r.cp.x0), r.pU, 1, r.pX, sp)
+    rc = lib.mpcqp_rollout_batch(C.byref(dims), C.byref(cp.A), C.byref(cp.B), C.byref(cp.x0), r.pU, 1, r.pX, sp)
     _capi.check(rc, "mpcqp_rollout_batch")
-    r.h_out.copy_(r.d_out, non_blocking=True)
+    if not r.zero_copy:
+        r.h_out.copy_(r.d_out, non_blocking=True)
     stream.synchronize()
     out = r.h_out_np
     status, iters = int(r.h_out_i32[0]), int(r.h_out_i32[1])

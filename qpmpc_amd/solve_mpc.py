@@ -8,6 +8,8 @@ reference literally -- condense (on the GPU) then hand ``mpc_qp.problem`` to
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 
 from .batch import HIP_SOLVERS, BatchMPCProblem, solve_mpc_batch
@@ -19,16 +21,29 @@ from .plan import Plan, Solution
 available_solvers = list(HIP_SOLVERS)
 
 
-def solve_mpc(problem: MPCProblem, solver: str = "hip_gi", sparse: bool = False, **kwargs) -> Plan:
+_HIP_KWARGS = ("max_iter", "feas_tol", "warm_state", "warm_start", "initvals", "verbose")
+
+
+def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) -> Plan:
     """Solve a linear time-variant MPC problem.
 
     Args:
         problem: problem to solve (its initial state must be set).
-        solver: ``"hip_gi"`` (aliases ``"hip"``, ``"mpcqp_hip"``) for the fused
-            MI355X path; any qpsolvers backend name if qpsolvers is installed.
+        solver: required, like upstream (qpmpc/solve_mpc.py:18). ``"hip_gi"`` (aliases ``"hip"``,
+            ``"mpcqp_hip"``) selects the fused MI355X path; any qpsolvers backend name works if
+            qpsolvers is installed (the condensing still runs on the GPU).
         sparse: only meaningful for qpsolvers backends (CSC wrappers, as upstream).
-        kwargs: ``max_iter``, ``feas_tol`` for the HIP solver; forwarded verbatim
-            to ``qpsolvers.solve_problem`` otherwise.
+        kwargs: forwarded verbatim to ``qpsolvers.solve_problem`` for qpsolvers backends. The HIP
+            solver honours ``max_iter``, ``feas_tol``, ``warm_state=WarmState(...)`` with
+            ``warm_start=True`` (solver warm start from the previous call's active set, see
+            ``qpmpc_amd.WarmState``); it accepts and ignores ``initvals`` (a primal guess is of no use
+            to a dual active-set method -- qpsolvers' quadprog wrapper ignores it the same way, with a
+            warning) and ``verbose``. Any other keyword raises ``TypeError``: nothing is dropped silently.
+
+    Supported sizes of the HIP path: ``n = N*nu <= 256`` variables when the problem does not fit one
+    CU's LDS (then ``nx <= 16``); beyond that the C ABI returns ``MPCQP_ETOOLARGE`` and a
+    ``BackendError`` naming the limit is raised (the stage-wise solver ``formulation="stagewise"`` of
+    ``solve_mpc_batch`` has no such cap on the horizon).
 
     Returns:
         A ``Plan``; empty (``is_empty``) when no solution was found.
@@ -36,9 +51,16 @@ def solve_mpc(problem: MPCProblem, solver: str = "hip_gi", sparse: bool = False,
     if problem.initial_state is None:
         raise ProblemDefinitionError("initial state is undefined")
     if solver in HIP_SOLVERS:
+        unknown = sorted(set(kwargs) - set(_HIP_KWARGS))
+        if unknown:
+            raise TypeError(f"solve_mpc(solver='{solver}') got keyword arguments it cannot honour: {unknown}; "
+                            f"supported: {list(_HIP_KWARGS)}")
+        if kwargs.get("initvals") is not None:
+            logging.warning("hip_gi: warm-start values ignored (dual active-set method); use warm_state=")
+        warm_state, warm_start = kwargs.get("warm_state"), bool(kwargs.get("warm_start", False))
         from .single import solve_single
 
-        fast = solve_single(problem, kwargs.get("max_iter"), kwargs.get("feas_tol"))
+        fast = None if warm_state is not None else solve_single(problem, kwargs.get("max_iter"), kwargs.get("feas_tol"))
         if fast is not None:  # one upload, one fused launch + roll-out, one download
             x, z, X, status, iters = fast
             plan = Plan(problem, Solution(None, x=x, z=z, found=(status == 0), extras={"status": status, "iters": iters}))
@@ -46,8 +68,9 @@ def solve_mpc(problem: MPCProblem, solver: str = "hip_gi", sparse: bool = False,
                 plan._precomputed_rollout = (np.asarray(problem.initial_state, dtype=float).ravel().copy(), X)
             return plan
         bp = BatchMPCProblem.from_problems([problem])
+        opt_kw = {} if warm_state is None else {"warm_state": warm_state, "warm_start": warm_start}
         bplan = solve_mpc_batch(bp, solver=solver, return_multipliers=True,
-                                max_iter=kwargs.get("max_iter"), feas_tol=kwargs.get("feas_tol"))
+                                max_iter=kwargs.get("max_iter"), feas_tol=kwargs.get("feas_tol"), **opt_kw)
         status = int(bplan.status[0].item())
         x = bplan.U[0].cpu().numpy()
         z = bplan.multipliers[0].cpu().numpy()[bp.valid_rows]

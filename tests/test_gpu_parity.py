@@ -45,6 +45,12 @@ def test_mpcqp_matches_reference_fixture(name):
         assert got.dtype == np.float64
         assert _rel(got, want) <= 1e-12, (name, key, _rel(got, want))
     assert np.array_equal(qp.P, qp.P.T)  # exactly symmetric like the reference
+    # C = block_diag(C_0..C_{N-1}) kept for the h updates (mpc_qp.py:97); None where the reference's C is
+    # the meaningless object array of quirk 4 (every C_k is None)
+    if bool(z["out_C_is_object"]):
+        assert qp.C is None
+    else:
+        assert qp.C.shape == z["out_C"].shape and np.array_equal(qp.C, z["out_C"]), name
 
 
 def test_humanoid_first_rows_zero_and_update_vectors():
@@ -65,6 +71,37 @@ def test_humanoid_first_rows_zero_and_update_vectors():
     qp.update_constraint_vector(p)
     assert _rel(qp.q, z["q_updated"]) <= 1e-12
     assert _rel(qp.h, z["h_updated"]) <= 1e-12
+
+
+def test_wide_state_dimension_propagators_and_rollout():
+    """nx = 70 > 64 (one wavefront): Phi columns and the roll-out beyond lane 63 (round-1 advisor finding:
+    columns 64.. of Phi were never written). Compared with the NumPy restatement of mpc_qp.py."""
+    from qpmpc_amd import MPCQP, MPCProblem
+
+    rng = np.random.default_rng(70)
+    nx, nu, N = 70, 2, 3
+    A = [np.eye(nx) + 0.05 * rng.standard_normal((nx, nx)) for _ in range(N)]
+    B = [rng.standard_normal((nx, nu)) for _ in range(N)]
+    Cm = rng.standard_normal((3, nx))
+    p = MPCProblem(A, B, Cm, None, np.full(3, 50.0), N, 1.0, 0.5, 0.1, initial_state=rng.standard_normal(nx),
+                   goal_state=rng.standard_normal(nx))
+    p.update_target_states(rng.standard_normal(N * nx))
+    qp = MPCQP(p)
+    ref = oracle.condense(p)
+    for key in ("P", "q", "G", "h", "Phi", "Psi", "phi_last", "psi_last"):
+        assert _rel(getattr(qp, key), getattr(ref, key)) <= 1e-12, key
+    p.update_initial_state(rng.standard_normal(nx))
+    qp.update_cost_vector(p)
+    qp.update_constraint_vector(p)
+    ref2 = oracle.condense(p)
+    assert _rel(qp.q, ref2.q) <= 1e-12 and _rel(qp.h, ref2.h) <= 1e-12
+    U = rng.standard_normal((N, nu))
+    X = p.integrate(p.initial_state, U)  # mpcqp_rollout_batch, wide kernel
+    x = p.initial_state.copy()
+    for k in range(N):
+        assert np.abs(X[k] - x).max() <= 1e-12
+        x = A[k] @ x + B[k] @ U[k]
+    assert np.abs(X[N] - x).max() <= 1e-12
 
 
 def test_sparse_flag_wraps_csc():

@@ -68,6 +68,23 @@ def test_exception_messages_match_reference():
         qpmpc_amd.solve_mpc(_simple(), solver="hip_gi")
 
 
+def test_solve_mpc_signature_follows_upstream():
+    """`solver` is a required argument (qpmpc/solve_mpc.py:18) and the HIP solver refuses keyword
+    arguments it cannot honour instead of dropping them."""
+    p = _simple(initial_state=np.zeros(2))
+    with pytest.raises(TypeError):
+        qpmpc_amd.solve_mpc(p)
+    with pytest.raises(TypeError, match="eps_abs"):
+        qpmpc_amd.solve_mpc(p, solver="hip_gi", eps_abs=1e-9)
+
+
+def test_batch_of_problems_with_different_weights_is_refused():
+    ps = [_simple(initial_state=np.zeros(2)) for _ in range(3)]
+    ps[2].stage_input_cost_weight = 0.5
+    with pytest.raises(ProblemDefinitionError, match="share the three cost weights"):
+        qpmpc_amd.BatchMPCProblem.from_problems(ps)
+
+
 def test_problem_container_semantics():
     A = [np.eye(2) * (k + 1) for k in range(3)]
     p = _simple(transition_state_matrix=A, target_states=np.ones(6), initial_state=np.ones((2, 1)), goal_state=np.ones(2))
