@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: MPC QP builds+solves per second (batched).
 
-A "step" is one fused build+solve of one batch of BASELINE.json's configs[1]:
-4096 triple-integrator problems (nx=3, nu=1, N=16 -> n=16, m=32), float64,
-heterogeneous operands (A_k, B_k, C_k, e_k stacked per problem and per step, a
-real condense per problem), inputs resident in HBM when the timed region starts.
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
-    python bench.py --gpus N --steps K --warmup W
+A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in
+HBM when the timed region starts. ``--config`` picks the BASELINE.json configuration that is
+timed (configs[1..4]; configs[0] is the reference's single CPU problem):
 
-N > 1 is launched by torch.distributed.run, one rank per GPU; the batch shards
-by problem (each rank owns 4096 problems of its own, no data-path collective:
-weak scaling). Rank 0 prints ONE JSON line.
+  2 (default, the headline)  batch 4096 triple integrator N=16 per GPU, float64, heterogeneous
+                             per-problem LTV operands, one fused build+solve launch; weak scaling.
+  3  wheeled inverted pendulum N=50 (T = 0.024 s), 1024 receding-horizon closed loops per GPU,
+     float64, LTV lists: one MPC period (fused build+solve rebuilt every step like the reference,
+     + the nonlinear plant for 15 sub-steps) = 1024 builds+solves; weak scaling.
+  4  humanoid one-step N=16, 65,536-state sweep, float64, STRONG-sharded over the N GPUs
+     (8192 per GPU at N=8); the all_gather of U/status is timed separately (``all_gather_ms``).
+  5  synthetic LTV nx=12 nu=4 N=64 (n=256, m=1024), float32, batch 8192 STRONG-sharded
+     (1024 per GPU at N=8); MFMA Gram; ``roofline.bound`` = mfma.
+
+N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; problems never interact, so
+the data path has no collective. Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -24,56 +32,431 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_PEAK_TFLOPS = 78.6  # MI355X vector/matrix fp64 peak (AMD spec; not in the guide)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_PEAK_TFLOPS = 78.6   # MI355X vector/matrix fp64 peak (AMD spec; not in the guide)
+FP32_PEAK_TFLOPS = 157.3  # MI355X f32 vector = f32-input MFMA peak (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    2: dict(batch=4096, scaling="weak", dtype="f64",
+            workload="batch={b} triple-integrator N=16 (nx=3 nu=1, n=16 m=32), heterogeneous per-problem LTV operands, "
+                     "fp64, fused condense + dual active-set solve, one launch per step"),
+    3: dict(batch=1024, scaling="weak", dtype="f64",
+            workload="{b} wheeled-inverted-pendulum receding-horizon loops, N=50 T=0.024 s (nx=4 nu=1, n=50 m=100), LTV "
+                     "lists, fp64; one step = one MPC period: fused build+solve rebuilt every step + plant (15 sub-steps)"),
+    4: dict(batch=65536, scaling="strong", dtype="f64",
+            workload="humanoid one-step (LIPM) N=16 (n=16 m=32), {b}-state sweep strong-sharded over the GPUs, fp64, "
+                     "fused build+solve; U/status all_gather timed separately"),
+    5: dict(batch=8192, scaling="strong", dtype="f32",
+            workload="synthetic LTV nx=12 nu=4 N=64 (n=256 m=1024) with input and state boxes, batch {b} strong-sharded "
+                     "over the GPUs, fp32, propagate + MFMA Gram + one-QP-per-workgroup active-set solve"),
+}
 
 
-def cpu_baseline(w, seconds: float = 12.0):
-    """Oracle timed on the host, rank 0 only. Two figures:
-    * "port": the reference's execution model -- one Python call per problem,
-      NumPy condensing (oracle.condense_np, the restatement of mpc_qp.py) and a
-      native dense active-set solve (what qpsolvers/quadprog does), 1 thread;
-    * "port_c": the all-C oracle (condense + Goldfarb-Idnani), 1 thread.
-    """
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 2000 for the 40-us steps of configs 2/4, fewer for 3/5)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="override the configuration's batch (per GPU if weak, total if strong)")
+    ap.add_argument("--shared-lti", action="store_true", help="config 2 with stride-0 operands (not the headline mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--spinup", type=float, default=0.25, help="seconds of untimed launches before the warm-up (clock ramp)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-streams-in-flight measurement")
+    args = ap.parse_args(argv)
+    defaults = {2: (2000, 200), 3: (100, 20), 4: (200, 20), 5: (20, 3)}
+    if args.steps is None:
+        args.steps = defaults[args.config][0]
+    if args.warmup is None:
+        args.warmup = defaults[args.config][1]
+    return args
+
+
+# ---------------------------------------------------------------------------------- workloads
+def local_workload(config: int, rank: int, world: int, batch=None, shared_lti: bool = False):
+    """(this rank's workload dict, problems of the whole job per step, problems of this rank per step)."""
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_range, shard_workload
+
+    spec = CONFIGS[config]
+    b = int(batch or spec["batch"])
+    if spec["scaling"] == "weak":  # every rank owns b problems of its own (independent seeds)
+        if config == 2:
+            w = W.triple_integrator_batch(b, seed=20250614 + rank, heterogeneous=not shared_lti)
+        else:
+            w = W.wip_batch(b, seed=1 + rank)
+        return w, b * world, b
+    # strong: ONE global problem set, whatever the number of ranks; this rank takes its contiguous slice
+    if config == 4:
+        w = shard_workload(W.humanoid_batch(b, seed=2), rank, world)
+    else:
+        lo, hi = shard_range(b, rank, world)
+        w = W.synthetic_ltv_batch_slice(lo, hi, seed=3)
+    return w, b, int(w["x0"].shape[0])
+
+
+class _Runner:
+    """One step of the configured hot path on this rank's GPU."""
+
+    def __init__(self, config: int, w, device="cuda"):
+        import numpy as np
+        import torch
+
+        from qpmpc_amd import PreparedSolve
+        from qpmpc_amd import workloads as W
+
+        self.config = config
+        if config == 3:
+            from qpmpc_amd.closed_loop import WIPClosedLoop
+
+            self.loop = WIPClosedLoop(np.asarray(w["x0"]))
+            self.solver = self.loop.solver
+            self.launch = lambda stream=None: self.loop.step()
+            # the timed region is ONE EPISODE from the random initial states (SURVEY 8d: "x0 ~ N(0, diag(.05,.05,
+            # .1,.1)^2), ... repeat >= 100 MPC steps"): warm-up and spin-up periods must not leave the loops in
+            # their constraint-free steady state
+            self.reset = lambda: self.loop.reset(np.asarray(w["x0"]))
+        else:
+            self.bp = W.to_batch_problem(w, dtype=torch.float32 if config == 5 else None)
+            self.solver = PreparedSolve(self.bp)
+            self.launch = self.solver.launch
+
+    @property
+    def U(self):
+        return self.solver.U
+
+    @property
+    def status(self):
+        return self.solver.status
+
+    @property
+    def iters(self):
+        return self.solver.iters
+
+
+class _Clock:
+    """Timing of K launches: HIP events on the launch stream (torch's current stream) + a host clock
+    around a full synchronisation. On a CPU device (the gloo test of this file's rank logic) both are the
+    host clock."""
+
+    def __init__(self, device: str):
+        self.cuda = device == "cuda"
+
+    def sync(self):
+        if self.cuda:
+            import torch
+
+            torch.cuda.synchronize()
+
+    def time(self, launch, steps: int):
+        import torch
+
+        self.sync()
+        if self.cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        if self.cuda:
+            e0.record()
+        for _ in range(steps):
+            launch()
+        if self.cuda:
+            e1.record()
+        self.sync()
+        wall = time.perf_counter() - t0
+        return wall, (e0.elapsed_time(e1) * 1e-3 if self.cuda else wall)
+
+
+# ---------------------------------------------------------------------------------- the measurement
+def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, device: str = "cuda"):
+    """Everything between "process group is up" and "rank 0 has the JSON record". ``make_runner`` and
+    ``device`` exist so that tests can drive this rank logic on CPU (gloo) with the solve stubbed."""
+    import torch
+
+    spec = CONFIGS[args.config]
+    clock = _Clock(device)
+    w, total_per_step, local_per_step = local_workload(args.config, rank, world, args.batch, args.shared_lti)
+    run = make_runner(args.config, w, device)
+    clock.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def allreduce(x, op):
+        if dist is not None:
+            dist.all_reduce(x, op=getattr(dist.ReduceOp, op))
+        return x
+
+    dev = torch.device("cuda", torch.cuda.current_device()) if device == "cuda" else torch.device("cpu")
+    # Untimed device spin-up before the W warm-up steps: a step of configs 2/4 is ~40 us, so a short (W, K)
+    # would be over before the GPU has left its idle clocks.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup:
+        for _ in range(20):
+            run.launch()
+        clock.sync()
+    for _ in range(args.warmup):
+        run.launch()
+    if hasattr(run, "reset"):
+        run.reset()
+    clock.sync()
+    barrier()
+    elapsed, kernel_s = clock.time(run.launch, args.steps)
+    barrier()
+    kernel_ms = kernel_s / args.steps * 1e3  # average duration of one step's launches, HIP events
+
+    # whole-job reductions: MAX of the elapsed time, SUMs of the counts
+    t = allreduce(torch.tensor([elapsed], dtype=torch.float64, device=dev), "MAX")
+    if hasattr(run, "loop"):  # closed loop: counts over the whole timed episode
+        st = run.loop.stats()
+        c = [st["builds_and_solves"] - st["failed"], st["mean_iters"] * st["builds_and_solves"], st["builds_and_solves"]]
+        counts = allreduce(torch.tensor(c, dtype=torch.float64, device=dev), "SUM")
+    else:
+        counts = allreduce(torch.stack([(run.status == 0).sum(), run.iters.sum(),
+                                        torch.tensor(run.status.numel(), device=run.status.device)]).to(torch.float64).to(dev), "SUM")
+    elapsed = float(t.item())
+
+    # strong-scaling configurations hand the whole batch to every rank afterwards: all_gather, timed apart
+    gather_ms = None
+    if spec["scaling"] == "strong":
+        from qpmpc_amd.distributed import gather_batch
+
+        for _ in range(2):
+            gather_batch(run.U, total_per_step)
+        clock.sync()
+        barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            U_all = gather_batch(run.U, total_per_step)
+            st_all = gather_batch(run.status, total_per_step)
+        clock.sync()
+        tg = allreduce(torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev), "MAX")
+        gather_ms = float(tg.item()) * 1e3
+        assert U_all.shape[0] == total_per_step and st_all.shape[0] == total_per_step
+
+    # Extra (config 2, not `value`): two independent batches in flight on two streams
+    overlap = None
+    if args.config == 2 and not args.no_overlap and device == "cuda":
+        overlap = _overlap_two_streams(args, run, rank, world, barrier, allreduce, dev)
+
+    if rank != 0:
+        return None
+    problems = float(counts[2].item())
+    out = {
+        "metric": "MPC QP builds+solves/sec (batched)",
+        "value": total_per_step * args.steps / elapsed,
+        "unit": "problems/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "spinup_s": args.spinup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": spec["scaling"],
+        "vs_baseline": None,
+        "dtype": spec["dtype"],
+        "data": "synthetic",
+        "config": {
+            "workload": (spec["workload"].format(b=args.batch or spec["batch"])
+                         + (" [shared LTI operands, stride 0]" if args.shared_lti else "")),
+            "baseline_config_index": args.config - 1,
+            "problems_per_step": total_per_step,
+            "problems_per_gpu_per_step": local_per_step,
+            "parallelism": f"batch-sharded x{world}, no data-path collective",
+        },
+        "solved_frac": float(counts[0].item()) / max(problems, 1.0),
+        "mean_iters": float(counts[1].item()) / max(problems, 1.0),
+    }
+    if gather_ms is not None:
+        out["all_gather_ms"] = gather_ms
+        out["all_gather_note"] = "U [B, n] + status [B] to every rank (padded all_gather, qpmpc_amd.distributed.gather_batch); outside the timed region"
+    if overlap is not None:
+        out["overlap_2_streams"] = overlap
+    if device == "cuda":
+        out["roofline"] = _roofline(args, w, local_per_step, kernel_ms, out["mean_iters"])
+        out["accuracy"] = _accuracy(args, w, run)
+        if not args.no_extras and world == 1 and args.config == 2:
+            try:
+                out["other_workloads"] = other_workloads()
+            except Exception as exc:  # never at the expense of the headline line
+                out["other_workloads"] = {"error": repr(exc)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.config, w, args.cpu_seconds)
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores_value"]
+    return out
+
+
+def _overlap_two_streams(args, run, rank, world, barrier, allreduce, dev):
+    """Not the headline: two independent batches in flight on two HIP streams, the way a server or a set of
+    unrelated control loops would submit work (how much of a single-stream step is ramp and tail)."""
+    import torch
+
+    from qpmpc_amd import PreparedSolve
+    from qpmpc_amd import workloads as W
+
+    b = args.batch or CONFIGS[2]["batch"]
+    w2 = W.triple_integrator_batch(b, seed=30250614 + rank, heterogeneous=not args.shared_lti)
+    runs = [run.solver, PreparedSolve(W.to_batch_problem(w2))]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for k in range(2 * args.warmup):
+        runs[k % 2].launch(stream=streams[k % 2])
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        runs[k % 2].launch(stream=streams[k % 2])
+    torch.cuda.synchronize()
+    el2 = time.perf_counter() - t1
+    barrier()
+    t2 = allreduce(torch.tensor([el2], dtype=torch.float64, device=dev), "MAX")
+    return {"streams": 2, "value": b * world * args.steps / float(t2.item()), "unit": "problems/s",
+            "ms_per_step": float(t2.item()) / args.steps * 1e3,
+            "note": "independent batches in flight on 2 HIP streams; not the headline value"}
+
+
+def _dims_of(w):
+    import numpy as np
+
+    nx, nu = int(np.asarray(w["A"]).shape[-1]), int(np.asarray(w["B"]).shape[-1])
+    N, mk = int(w["N"]), int(np.asarray(w["e"]).shape[-1])
+    return nx, nu, N, mk
+
+
+def _traffic_from_profiles(config: int):
+    """HBM bytes per launch from rocprofv3 PMC passes stored under profiles/ (NOT measured by this run)."""
+    for name in (f"r02_pmc_traffic_config{config}.json", "r02_pmc_traffic.json" if config == 2 else None):
+        if name is None:
+            continue
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
+                    "note": "stored rocprofv3 FETCH_SIZE/WRITE_SIZE figure (separate --pmc passes), not an observation of this run"}
+    return None
+
+
+def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
+    from qpmpc_amd import workloads as W
+
+    nx, nu, N, mk = _dims_of(w)
+    n, m = N * nu, N * mk
+    kernel_s = kernel_ms * 1e-3
+    esz = 4 if args.config == 5 else 8
+    bytes_pp = W.algorithmic_bytes_per_problem(w, esz)
+    stage, term = w["wx"] is not None, w["wt"] is not None
+    flops_pp = W.algorithmic_build_flops(nx, nu, N, mk, stage, term) + W.algorithmic_solve_flops(n, m, mean_iters)
+    gbs = bytes_pp * local_per_step / kernel_s / 1e9
+    tfs = flops_pp * local_per_step / kernel_s / 1e12
+    common = {"kernel_ms": kernel_ms, "algorithmic_bytes_per_problem": bytes_pp, "algorithmic_flops_per_problem": flops_pp,
+              "units_per_launch": local_per_step, "traffic": None, "traffic_from_profiles": _traffic_from_profiles(args.config)}
+    if args.config in (2, 4):
+        return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "kernel": "mpcqp_pair_kernel (fused build+solve, two problems per wavefront)",
+                "achieved_tflops_f64": tfs, **common,
+                "note": "nominally HBM-bound (4 flop/B) but a launch moves only ~11 MB: the serial active-set chain of "
+                        "each wavefront (instruction issue + dependent latency) sets the time, not HBM or FP64 throughput"}
+    if args.config == 3:
+        return {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS,
+                "kernel": "mpcqp_bigsolve_kernel<double, K_MID> (+ mpcqp_wip_advance, <2% of the step)",
+                "achieved_gbs": gbs, **common,
+                "note": "fp64 FMA/MFMA-bound by intensity (~100 flop/B); peak = AMD's fp64 vector=matrix figure"}
+    return {"bound": "mfma", "achieved": tfs, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP32_PEAK_TFLOPS,
+            "kernel": "mpcqp_propagate + mpcqp_gram_mfma_f32 + mpcqp_bigsolve<float> (three launches per step; "
+                      "per-kernel durations in profiles/)",
+            "achieved_gbs": gbs, **common,
+            "note": "algorithmic dense flops (the reference's Gram is a full dense product; the kernels skip the causal "
+                    "and symmetric zeros) over the duration of the step's three launches; exact-f32 MFMA peak"}
+
+
+def _accuracy(args, w, run):
+    """max |u - u_oracle| on (a sample of) this rank's problems, CPU oracle as the checker."""
     import numpy as np
 
     import oracle
-    from qpmpc_amd import MPCProblem
 
-    batch = w["x0"].shape[0]
+    lim = {2: None, 3: 64, 4: 4096, 5: 4}[args.config]
+    U = run.U.double().cpu().numpy()
+    st = run.status.cpu().numpy()
+    if args.config == 3:  # the loop has moved on: compare the LAST solved problems through the oracle
+        bp = run.loop.problem
+        ws = dict(w)
+        ws["x0"] = bp.initial_state.cpu().numpy()
+        ws["goal"] = bp.goal_state.cpu().numpy()
+        ws["targets"] = bp.target_states.cpu().numpy()
+        # the problem buffers already hold the NEXT period's data; re-solve them on the device for the comparison
+        run.solver.launch()
+        import torch
+
+        torch.cuda.synchronize()
+        U, st, w = run.U.cpu().numpy(), run.status.cpu().numpy(), ws
+    Uo, _, sto, _ = oracle.solve_workload(w, count=lim)
+    k = Uo.shape[0]
+    ok = (sto == 0) & (st[:k] == 0)
+    err = np.abs(U[:k][ok] - Uo[ok])
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    return {"checked_problems": int(k), "status_agree": bool(np.array_equal(st[:k] == 0, sto == 0)),
+            "max_abs_err_vs_oracle": float(err.max()) if err.size else 0.0,
+            "max_rel_err_vs_oracle": float((err / scale).max()) if err.size else 0.0,
+            "tolerance": "1e-6 relative (float64) / 1e-3 (float32), tests/"}
+
+
+def cpu_baseline(config: int, w, seconds: float = 10.0):
+    """The oracle timed on the host cores (rank 0, N=1 only), on a bounded sample of the same workload:
+    * "port" (`value`): the reference's execution model -- one Python call per problem, NumPy condensing
+      (oracle.condense_np, the restatement of mpc_qp.py) + a native dense active-set solve (what
+      qpsolvers/quadprog does), 1 thread;
+    * "port_c": the all-C oracle (condense + Goldfarb-Idnani), 1 thread;
+    * "all_cores": the all-C oracle in one spawned process per host CPU, each on its own shard."""
+    import numpy as np
+
+    import oracle
+    from oracle.parallel import all_cores_rate
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    batch = int(w["x0"].shape[0])
     t0 = time.perf_counter()
-    done = 0
-    b = 0
-    while time.perf_counter() - t0 < seconds:
-        p = MPCProblem(
-            [w["A"][b, k] for k in range(w["N"])], [w["B"][b, k] for k in range(w["N"])],
-            [w["C"][b, k] for k in range(w["N"])], None, [w["e"][b, k] for k in range(w["N"])],
-            w["N"], w["wt"], w["wx"], w["wu"], initial_state=w["x0"][b], goal_state=w["goal"][b])
-        U, st, _ = oracle.solve_mpc_like_reference(p)
+    done, b = 0, 0
+    budget = seconds * 0.4
+    while time.perf_counter() - t0 < budget:
+        p = W.problem_from_workload(w, b)
+        oracle.solve_mpc_like_reference(p)
         done += 1
         b = (b + 1) % batch
     t_ref = time.perf_counter() - t0
+    sample = min(batch, {2: 1024, 3: 64, 4: 1024, 5: 2}[config])
+    ws = shard_workload(w, 0, max(1, batch // sample)) if sample < batch else w
     t1 = time.perf_counter()
     reps = 0
-    while time.perf_counter() - t1 < max(2.0, seconds / 4):
-        oracle.solve_workload(w)
+    while time.perf_counter() - t1 < seconds * 0.2 or reps == 0:
+        oracle.solve_workload(ws)
         reps += 1
     t_c = time.perf_counter() - t1
+    nb = int(ws["x0"].shape[0])
+    cores = all_cores_rate(ws, seconds=max(2.0, seconds * 0.3))
     return {
-        "value": done / t_ref,
-        "unit": "problems/s",
-        "cores": 1,
-        "kind": "port",
+        "value": done / t_ref, "unit": "problems/s", "cores": 1, "kind": "port",
         "sample": f"{done} problems of the same batch, one Python call each (NumPy condense + C active-set), {t_ref:.1f} s",
-        "port_c_value": reps * batch / t_c,
-        "port_c_sample": f"all-C oracle, {reps} passes over the {batch}-problem batch, {t_c:.1f} s, 1 thread",
+        "port_c_value": reps * nb / t_c,
+        "port_c_sample": f"all-C oracle, {reps} passes over {nb} problems of the batch, {t_c:.1f} s, 1 thread",
+        "all_cores_value": cores["value"], "all_cores": cores["cores"], "cpu_model": cores["cpu_model"],
+        "all_cores_sample": f"all-C oracle, {cores['cores']} spawned processes (one per host CPU), each passing over the same "
+                            f"{nb} problems for {cores['seconds_per_worker']:.1f} s",
         "host_cpus": os.cpu_count(),
     }
 
 
 def other_workloads():
     """Rates of the other BASELINE.json configurations on this GPU (rank 0, one GPU only; never `value`):
-    a few launches each, HIP events on the launch stream. Parity for these is in tests/ (-m gpu)."""
+    a few launches each, HIP events on the launch stream. Each of them can be the timed `value` with
+    --config 3|4|5; parity for all of them is in tests/ (-m gpu)."""
     import numpy as np
     import torch
 
@@ -111,22 +494,8 @@ def other_workloads():
     return {k: float(v) for k, v in out.items()} | {"unit": "problems/s (builds+solves/s for the loops)"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000,
-                    help="timed steps (one step = 58 us: short runs end before the GPU reaches its sustained clocks)")
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU (configs[1]: 4096)")
-    ap.add_argument("--shared-lti", action="store_true", help="stride-0 operands (not the headline mode)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--spinup", type=float, default=0.25, help="seconds of untimed launches before the warm-up (clock ramp)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the short runs of the other configurations")
-    ap.add_argument("--no-overlap", action="store_true", help="skip the extra two-streams-in-flight measurement")
-    args = ap.parse_args()
-
-    import numpy as np
+def main(argv=None) -> None:
+    args = parse_args(argv)
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,176 +511,8 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    from qpmpc_amd import PreparedSolve
-    from qpmpc_amd import workloads as W
-
-    # each rank owns its own shard of the sweep (independent problems, no exchange)
-    w = W.triple_integrator_batch(args.batch, seed=20250614 + rank, heterogeneous=not args.shared_lti)
-    bp = W.to_batch_problem(w)
-    run = PreparedSolve(bp)
-    torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    # Untimed device spin-up before the W warm-up steps: one step is ~55 us, so a short (W, K) would be over
-    # before the GPU has left its idle clocks (57 us/step measured that way against 54 us sustained).
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup:
-        for _ in range(100):
-            run.launch()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run.launch()
-    torch.cuda.synchronize()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # same stream the kernels are enqueued on (torch's current stream)
-    for _ in range(args.steps):
-        run.launch()
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # average launch duration, HIP events
-
-    # Extra (not `value`): two independent batches in flight on two streams, the way a
-    # server or a set of unrelated control loops would submit work. It measures how much
-    # of a single-stream step is ramp/tail (the step ends with its slowest wavefront).
-    overlap = None
-    if not args.no_overlap:
-        w2 = W.triple_integrator_batch(args.batch, seed=30250614 + rank, heterogeneous=not args.shared_lti)
-        runs = [run, PreparedSolve(W.to_batch_problem(w2))]
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-        torch.cuda.synchronize()
-        for k in range(2 * args.warmup):
-            runs[k % 2].launch(stream=streams[k % 2])
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            runs[k % 2].launch(stream=streams[k % 2])
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t1
-        barrier()
-        t2 = torch.tensor([el2], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        overlap = {"streams": 2, "value": args.batch * world * args.steps / float(t2.item()), "unit": "problems/s",
-                   "ms_per_step": float(t2.item()) / args.steps * 1e3,
-                   "note": "independent batches in flight on 2 HIP streams; not the headline value"}
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    solved = (run.status == 0).sum().to(torch.float64).reshape(1)
-    it_sum = run.iters.sum().to(torch.float64).reshape(1)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(solved, op=dist.ReduceOp.SUM)
-        dist.all_reduce(it_sum, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_problems = args.batch * world * args.steps
-
+    out = run_bench(args, rank, world, dist)
     if rank == 0:
-        import oracle
-
-        U = run.U.cpu().numpy()
-        Uo, _, sto, _ = oracle.solve_workload(w)
-        ok = sto == 0
-        err = np.abs(U[ok] - Uo[ok])
-        # KKT residuals of the kernel's own (u, lambda) on a sample, against the oracle-built QP
-        from qpmpc_amd import MPCProblem
-
-        chk = PreparedSolve(bp, return_multipliers=True)
-        chk.launch()
-        torch.cuda.synchronize()
-        lam = chk.lam.cpu().numpy()
-        kkt = {"stationarity": 0.0, "primal": 0.0, "complementarity": 0.0, "dual": 0.0}
-        for b in range(0, args.batch, max(1, args.batch // 128)):
-            if not ok[b]:
-                continue
-            p = MPCProblem(
-                [w["A"][b, k] for k in range(w["N"])] if not args.shared_lti else w["A"],
-                [w["B"][b, k] for k in range(w["N"])] if not args.shared_lti else w["B"],
-                [w["C"][b, k] for k in range(w["N"])] if not args.shared_lti else w["C"], None,
-                [w["e"][b, k] for k in range(w["N"])] if not args.shared_lti else w["e"],
-                w["N"], w["wt"], w["wx"], w["wu"], initial_state=w["x0"][b], goal_state=w["goal"][b])
-            cq = oracle.condense(p)
-            ub, lb = U[b], lam[b]
-            slack = cq.h - cq.G @ ub
-            kkt["stationarity"] = max(kkt["stationarity"], float(np.abs(cq.P @ ub + cq.q + cq.G.T @ lb).max()))
-            kkt["primal"] = max(kkt["primal"], float(np.maximum(-slack, 0.0).max()))
-            kkt["dual"] = max(kkt["dual"], float(np.maximum(-lb, 0.0).max()))
-            kkt["complementarity"] = max(kkt["complementarity"], float(np.abs(lb * slack).max()))
-        nx, nu, N, mk = 3, 1, 16, 2
-        n, m = N * nu, N * mk
-        bytes_per_problem = W.algorithmic_bytes_per_problem(w)
-        mean_iters = float(it_sum.item()) / (args.batch * world)
-        flops_per_problem = W.algorithmic_build_flops(nx, nu, N, mk, False, True) + W.algorithmic_solve_flops(n, m, mean_iters)
-        kernel_s = kernel_ms * 1e-3
-        achieved_gbs = bytes_per_problem * args.batch / kernel_s / 1e9
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        traffic = None
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        out = {
-            "metric": "MPC QP builds+solves/sec (batched)",
-            "value": total_problems / elapsed,
-            "unit": "problems/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "spinup_s": args.spinup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"batch={args.batch} triple-integrator N=16 (nx=3 nu=1, n=16 m=32), "
-                            + ("shared LTI operands (stride 0)" if args.shared_lti else "heterogeneous per-problem LTV operands")
-                            + ", fp64, fused condense + dual active-set solve, one launch per step",
-                "batch_per_gpu": args.batch,
-                "parallelism": f"batch-sharded x{world}, no data-path collective",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": "mpcqp fused build+solve",
-                "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_problem": bytes_per_problem,
-                "algorithmic_flops_per_problem": flops_per_problem,
-                "achieved_tflops_f64": flops_per_problem * args.batch / kernel_s / 1e12,
-                "note": "latency-bound: 4096 problems x 2.7 KB is 11 MB per launch; the serial "
-                        "active-set chain per problem, not HBM or FP64 throughput, sets the time",
-            },
-            "accuracy": {
-                "max_abs_err_vs_oracle": float(err.max()),
-                "p99_abs_err_vs_oracle": float(np.quantile(err.max(axis=1), 0.99)),
-                "max_kkt_residuals_sample": kkt,
-                "max_rel_err_vs_oracle": float((err / np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))).max()),
-                "solved_frac": float(solved.item()) / (args.batch * world),
-                "mean_iters": mean_iters,
-            },
-        }
-        if overlap is not None:
-            out["overlap_2_streams"] = overlap
-        if not args.no_extras and world == 1:
-            try:
-                out["other_workloads"] = other_workloads()
-            except Exception as exc:  # never at the expense of the headline line
-                out["other_workloads"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
-            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

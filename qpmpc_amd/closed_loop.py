@@ -79,6 +79,15 @@ class WIPClosedLoop:
         p.goal_state[:, 2] = self.target_vel
         p.initial_state.copy_(self.states)
 
+    def reset(self, x0) -> None:
+        """Put every loop back to state ``x0`` [B, 4] (a new episode; counters restart)."""
+        import torch
+
+        self.states.copy_(torch.as_tensor(np.asarray(x0, dtype=float), dtype=self.states.dtype, device=self.states.device))
+        self.mpc_steps = 0
+        self.failed.zero_()
+        self.iters_total.zero_()
+
     def step(self, nb_mpc_steps: int = 1):
         """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
         and one fused plant + reference launch (``mpcqp_wip_advance_batch``). Asynchronous."""

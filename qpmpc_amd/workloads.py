@@ -114,6 +114,62 @@ def synthetic_ltv_batch(batch: int = 8192, nx: int = 12, nu: int = 4, N: int = 6
     return _pack(A, B, C, D, e, N, 10.0, 1.0, 1e-2, x0, np.zeros(nx), np.zeros(N * nx), name=f"synthetic_ltv_nx{nx}_nu{nu}_N{N}")
 
 
+def synthetic_ltv_batch_slice(lo: int, hi: int, nx: int = 12, nu: int = 4, N: int = 64, seed: int = 3):
+    """Problems lo..hi-1 of ONE global config-5 problem set (per-problem seeding), so that a batch
+    strong-sharded over any number of ranks is the same set of problems (bench.py --config 5)."""
+    batch = hi - lo
+    A = np.empty((batch, N, nx, nx))
+    B = np.empty((batch, N, nx, nu))
+    x0 = np.empty((batch, nx))
+    for i in range(batch):
+        rng = np.random.default_rng([seed, lo + i])
+        Qs, _ = np.linalg.qr(rng.standard_normal((N, nx, nx)))
+        A[i] = 0.98 * Qs
+        B[i] = rng.standard_normal((N, nx, nu)) / np.sqrt(nx)
+        x0[i] = rng.standard_normal(nx)
+    D = np.vstack([np.eye(nu), -np.eye(nu), np.zeros((8, nu))])
+    C = np.zeros((16, nx))
+    for r in range(4):
+        C[8 + r, r] = 1.0
+        C[12 + r, r] = -1.0
+    e = np.concatenate([np.ones(8), 5.0 * np.ones(8)])
+    return _pack(A, B, C, D, e, N, 10.0, 1.0, 1e-2, x0, np.zeros(nx), np.zeros(N * nx), name=f"synthetic_ltv_nx{nx}_nu{nu}_N{N}")
+
+
+def problem_from_workload(w: dict, b: int):
+    """Host ``MPCProblem`` of item ``b`` of a workload dict, with per-step LISTS where the workload varies
+    along the horizon (the reference's LTV convention, mpc_problem.py:177-245) and arrays where it does not."""
+    from .mpc_problem import MPCProblem
+
+    N = int(w["N"])
+
+    def field(key, block_ndim):
+        a = w[key]
+        if a is None:
+            return None
+        a = np.asarray(a)
+        extra = a.ndim - block_ndim
+        if extra == 2:
+            a = a[b] if a.shape[0] > 1 else a[0]
+            extra = 1
+        if extra == 1:
+            return [a[k] for k in range(N)] if a.shape[0] == N else a[0]
+        return a
+
+    def state(key):
+        a = w[key]
+        if a is None:
+            return None
+        a = np.asarray(a)
+        return a[b] if a.ndim == 2 else a
+
+    p = MPCProblem(field("A", 2), field("B", 2), field("C", 2), field("D", 2), field("e", 1), N, w["wt"], w["wx"],
+                   w["wu"], initial_state=state("x0"), goal_state=state("goal"))
+    if w["targets"] is not None:
+        p.update_target_states(state("targets"))
+    return p
+
+
 def to_batch_problem(w: dict, dtype=None, device=None):
     """Upload a workload dict to the device as a ``BatchMPCProblem``."""
     from .batch import BatchMPCProblem

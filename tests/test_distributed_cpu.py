@@ -72,3 +72,79 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path):
         assert np.array_equal(z["U"], U) and np.array_equal(z["st"], st)
         assert z["problems"] == total and z["solved"] == (st == 0).sum() and z["infeasible"] == (st == 2).sum()
         assert abs(z["mean_iters"] - it.mean()) < 1e-12 and z["max_iters"] == it.max()
+
+
+# ---------------------------------------------------------------- bench.py's own rank logic under gloo
+class _OracleRunner:
+    """Stand-in for bench._Runner on CPU: the solve is done by the oracle (test infrastructure) into CPU
+    tensors. What is under test is bench.run_bench: argument handling, per-rank workloads (weak: own
+    seeds; strong: slices of one global set), reductions, the timed all_gather and the JSON record."""
+
+    def __init__(self, config, w, device):
+        self.w = w
+        self.launches = 0
+        self.launch()
+
+    def launch(self, stream=None):
+        U, _, st, it = oracle.solve_workload(self.w)
+        self.U, self.status, self.iters = torch.tensor(U), torch.tensor(st, dtype=torch.int32), torch.tensor(it, dtype=torch.int32)
+        self.launches += 1
+
+
+def _bench_worker(rank, world, port, config, batch, out_dir):
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = bench.parse_args(["--gpus", str(world), "--config", str(config), "--steps", "2", "--warmup", "1",
+                                 "--batch", str(batch), "--spinup", "0", "--no-cpu-baseline"])
+        out = bench.run_bench(args, rank, world, dist if world > 1 else None, make_runner=_OracleRunner, device="cpu")
+        assert (out is not None) == (rank == 0)
+        if rank == 0:
+            with open(os.path.join(out_dir, f"bench_c{config}_w{world}.json"), "w") as f:
+                json.dump(out, f)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config,batch", [(2, 24), (4, 37)])
+def test_bench_rank_logic_two_ranks_gloo(tmp_path, config, batch):
+    import json
+
+    for world in (1, 2):
+        mp.spawn(_bench_worker, args=(world, _free_port(), config, batch, str(tmp_path)), nprocs=world, join=True)
+    one = json.load(open(tmp_path / f"bench_c{config}_w1.json"))
+    two = json.load(open(tmp_path / f"bench_c{config}_w2.json"))
+    for rec, world in ((one, 1), (two, 2)):
+        assert rec["n_gpus"] == world and rec["steps"] == 2 and rec["warmup"] == 1 and rec["unit"] == "problems/s"
+        assert rec["metric"].startswith("MPC QP builds+solves/sec") and rec["vs_baseline"] is None
+        assert rec["value"] > 0 and abs(rec["value"] - rec["config"]["problems_per_step"] * 2 / (rec["ms_per_step"] * 2e-3)) < 1e-6 * rec["value"]
+    if config == 2:  # weak: every rank owns `batch` problems of its own
+        assert one["scaling"] == two["scaling"] == "weak"
+        assert one["config"]["problems_per_step"] == batch and two["config"]["problems_per_step"] == 2 * batch
+        assert two["config"]["problems_per_gpu_per_step"] == batch
+        assert "all_gather_ms" not in two
+    else:  # strong: ONE global set split over the ranks, gathered afterwards
+        assert one["scaling"] == two["scaling"] == "strong"
+        assert one["config"]["problems_per_step"] == two["config"]["problems_per_step"] == batch
+        assert two["config"]["problems_per_gpu_per_step"] == 19  # rank 0 of shards (19, 18)
+        assert two["all_gather_ms"] >= 0.0
+        # the same global problem set whatever the number of ranks: identical whole-job statistics
+        assert abs(one["solved_frac"] - two["solved_frac"]) < 1e-12 and abs(one["mean_iters"] - two["mean_iters"]) < 1e-12
+
+
+def test_bench_config5_slices_are_one_global_problem_set():
+    a = W.synthetic_ltv_batch_slice(0, 4, N=8)
+    b = W.synthetic_ltv_batch_slice(2, 4, N=8)
+    for key in ("A", "B", "x0"):
+        assert np.array_equal(a[key][2:], b[key])
