@@ -58,3 +58,27 @@ def all_cores_rate(w: Dict, seconds: float = 4.0, workers: int = 0) -> Dict:
     rate = sum(d / t for d, t in res)
     return {"value": rate, "cores": workers, "cpu_model": cpu_model(), "seconds_per_worker": seconds,
             "wall_s_including_spawn": wall}
+
+
+def _solve_shard(w):
+    from oracle.capi import solve_workload
+
+    return solve_workload(w)
+
+
+def solve_workload_parallel(w: Dict, shard, workers: int = 0):
+    """``oracle.solve_workload`` over contiguous shards in spawned processes (tests that check the GPU
+    against the oracle at sizes one core would need minutes for). Returns (U, lam, status, iters)."""
+    import numpy as np
+
+    if workers <= 0:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except AttributeError:
+            workers = os.cpu_count() or 1
+    batch = int(w["x0"].shape[0])
+    workers = max(1, min(workers, batch, 64))
+    parts = [shard(w, r, workers) for r in range(workers)]
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_solve_shard, parts, chunksize=1)
+    return tuple(np.concatenate([r[i] for r in res], axis=0) for i in range(4))

@@ -227,10 +227,10 @@ def test_config4_humanoid_sweep_with_infeasible_items():
 def test_config3_wip_n50_batch():
     from qpmpc_amd.workloads import wip_batch
 
-    w = wip_batch(64)
+    w = wip_batch(1024)  # BASELINE configs[2] at its full batch (the C oracle needs 0.3 s for it)
     _check_batch(w)
     # a saturating state so that the input box is active
-    w2 = wip_batch(32, seed=9)
+    w2 = wip_batch(256, seed=9)
     w2["x0"][:, 1] += 0.3
     w2["x0"][:, 3] += 1.0
     pend = w2["pendulum"]
@@ -297,6 +297,9 @@ def test_status_codes_not_pd_and_unconstrained():
     np.testing.assert_allclose(x[1].cpu().numpy(), [1.0, -2.0], atol=1e-14)
 
 
+F32_HUMANOID_MISSES = 1  # round 2 on MI355X: 256 of 256 solved in float32 (0 misses); one item of slack
+
+
 def test_float32_path_tolerance():
     """fp32 instantiation: tolerance 1e-3 * max(1, |u|) vs the f64 oracle."""
     from qpmpc_amd import solve_mpc_batch
@@ -308,7 +311,10 @@ def test_float32_path_tolerance():
     st = plan.status.cpu().numpy()
     Uo, _, sto, _ = oracle_batch(w)
     ok = (st == 0) & (sto == 0)
-    assert ok.sum() >= 0.9 * (sto == 0).sum()
+    print("f32 humanoid sweep: oracle solved", int((sto == 0).sum()), "f32 solved", int((st == 0).sum()), "both", int(ok.sum()),
+          "f32-only failures", int(((st != 0) & (sto == 0)).sum()), "statuses", np.unique(st[(st != 0) & (sto == 0)]))
+    assert ok.sum() >= (sto == 0).sum() - F32_HUMANOID_MISSES  # observed on MI355X, see the constant
+    assert not ((st == 0) & (sto != 0)).any()  # never "solved" where float64 proves infeasibility
     scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
     assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-3
 
@@ -334,12 +340,13 @@ def test_config3_closed_loop_matches_cpu_oracle_loop():
     rng = np.random.default_rng(1)
     x0 = rng.standard_normal((12, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
     x0[0] = [0.0, 0.3, 0.0, 1.0]  # saturates the input box on the first steps
+    x0[1] = [0.0, -0.25, 0.0, -0.8]
     loop = WIPClosedLoop(x0, nb_timesteps=50, sampling_period=0.024, target_vel=0.5)
     pend = loop.pendulum
     # CPU loop: reference semantics, one problem at a time
     states = x0.copy()
     prob = pend.build_mpc_problem(terminal_cost_weight=10.0, stage_state_cost_weight=1.0, stage_input_cost_weight=1e-3)
-    steps = 4
+    steps = 100  # the length of a BASELINE configs[2] episode (">= 100 MPC steps")
     sat = 0.0
     for _ in range(steps):
         loop.step()
@@ -354,7 +361,7 @@ def test_config3_closed_loop_matches_cpu_oracle_loop():
             for _ in range(NB_SUBSTEPS):
                 states[b] = pend.integrate(states[b], U[0], pend.sampling_period / NB_SUBSTEPS)
         got = loop.states.cpu().numpy()
-        assert np.abs(got - states).max() <= 1e-7, np.abs(got - states).max()
+        assert np.abs(got - states).max() <= 1e-7 * max(1.0, np.abs(states).max()), np.abs(got - states).max()
     assert sat >= 10.0 - 1e-9  # the box was active at least once
     st = loop.stats()
     assert st["failed"] == 0 and st["builds_and_solves"] == steps * 12
@@ -426,12 +433,15 @@ def test_config5_build_solve_f32_vs_oracle():
     from qpmpc_amd import solve_mpc_batch
     from qpmpc_amd.workloads import synthetic_ltv_batch, to_batch_problem
 
-    w = synthetic_ltv_batch(4)
+    from oracle.parallel import solve_workload_parallel
+    from qpmpc_amd.distributed import shard_workload
+
+    w = synthetic_ltv_batch(256)  # a quarter of one GPU's share of configs[4]; the oracle runs on the host's cores
     plan = solve_mpc_batch(to_batch_problem(w, dtype=torch.float32))
     torch.cuda.synchronize()
     st = plan.status.cpu().numpy()
     U = plan.U.double().cpu().numpy()
-    Uo, _, sto, ito = oracle.solve_workload(w)
+    Uo, _, sto, ito = solve_workload_parallel(w, shard_workload)
     assert (sto == 0).all() and (st == 0).all(), (st, sto)
     err = np.abs(U - Uo).max(axis=1) / np.maximum(1.0, np.abs(Uo).max(axis=1))
     assert err.max() <= 1e-3, err
@@ -870,6 +880,9 @@ def test_fuzz_dimensions_across_all_kernels():
     assert seen >= 150
 
 
+F32_FUZZ_AGREE = 10  # round 2 on MI355X: 10 of the 11 families have the same solved count as float64
+
+
 def test_fuzz_dimensions_float32():
     """The float32 instantiations of the same dispatch space (workgroup kernel, mid-size kind incl. its MFMA
     factorisation when n is a multiple of 32, large path): |u - u_ref64| <= 2e-3 max(1, |u|) where both
@@ -902,3 +915,5 @@ def test_fuzz_dimensions_float32():
             err = (np.abs(U[both] - Uo[both]) / scale).max()
             assert err <= 2e-3, ((nx, nu, N, mk), err)
         assert both.sum() >= (sto == 0).sum() - 1, ((nx, nu, N, mk), st, sto)
+    print("f32 fuzz: families whose solved counts agree with float64:", agree, "of", total // 6)
+    assert agree >= F32_FUZZ_AGREE, (agree, total)
