@@ -2,11 +2,13 @@
 
 CPU-only (no GPU): covers oracle/condense_np.py, oracle/mpc_oracle.c.
 """
+import os
+
 import numpy as np
 import pytest
 
 import oracle
-from golden_util import all_cases, kkt_residuals, load_case
+from golden_util import GOLDEN, all_cases, kkt_residuals, load_case
 
 BUILD_KEYS = ("P", "q", "G", "h", "Phi", "Psi", "phi_last", "psi_last", "e")
 
@@ -157,3 +159,50 @@ def test_lipm_oracle_loop_walks():
     assert (S == 0).all()
     assert np.abs(X[:, 0]).max() < 0.2  # the CoM sways between footholds at +-0.09
     assert np.ptp(X[:, 0]) > 0.05
+
+
+# ---------------------------------------------------------------- stage-wise restatement
+def _load_stagewise(name):
+    from qpmpc_amd import MPCProblem
+
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    p = MPCProblem(z["A"], z["B"], z["C"], None, z["e"], int(z["nb_timesteps"]), float(z["terminal_cost_weight"]),
+                   float(z["stage_state_cost_weight"]), float(z["stage_input_cost_weight"]), initial_state=z["initial_state"],
+                   goal_state=z["goal_state"])
+    p.update_target_states(z["target_states"])
+    return p, z
+
+
+@pytest.mark.parametrize("name", ["stagewise_triple_n64", "stagewise_triple_n256", "stagewise_triple_n1024",
+                                  "stagewise_triple_n1024_b"])
+def test_stagewise_oracle_matches_reference_built_dense_minimiser(name):
+    """The Riccati-based matrix-free active set (oracle/stagewise_np.py) against the minimiser of the QP that
+    the REFERENCE condensed (tools/gen_golden_stagewise.py): same inputs, same U*, same active rows; its KKT
+    residuals are evaluated without any condensed matrix (adjoint recursion)."""
+    from oracle import stagewise_np as S
+
+    p, z = _load_stagewise(name)
+    sp = S.from_mpc_problem(p)
+    U, lam, st, it = S.solve_stagewise(sp)
+    assert st == 0
+    Us = z["U_star"]
+    assert np.abs(U - Us).max() <= 1e-7 * max(1.0, np.abs(Us).max())  # cond(P) up to 1e9 on the dense side
+    assert set(np.flatnonzero(lam > 1e-9)) <= set(z["active_set"].tolist())
+    kk = S.kkt_residuals_stagewise(sp, U, lam)
+    assert kk["stationarity"] <= 1e-9 and kk["primal"] <= 1e-12 and kk["dual"] == 0.0 and kk["complementarity"] <= 1e-12
+    # the fixture's own solution passes the same matrix-free KKT check (pins kkt_residuals_stagewise itself)
+    lam_s = np.zeros(lam.shape)
+    lam_s[z["active_set"]] = z["lambda_active"]
+    kf = S.kkt_residuals_stagewise(sp, Us, lam_s)
+    assert kf["stationarity"] <= 1e-8 and kf["primal"] <= 1e-12 and kf["complementarity"] <= 1e-10
+
+
+def test_stagewise_oracle_equals_dense_oracle_on_the_reference_fixtures():
+    """Every certified fixture of the dense path, through the stage-wise restatement: <= 1e-9."""
+    from oracle import stagewise_np as S
+
+    for name in all_cases(solved_only=True):
+        p, z = load_case(name)
+        U, lam, st, it = S.solve_stagewise(S.from_mpc_problem(p))
+        assert st == 0, name
+        assert np.abs(U - z["U_star"]).max() <= 1e-9 * max(1.0, np.abs(z["U_star"]).max()), name
