@@ -204,6 +204,21 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                             void *lam, int32_t *status, int32_t *iters,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- stage-wise (uncondensed) formulation: long horizons -------------------------------------
+ * The reference has no sparse formulation: sparse=True only wraps the dense condensed matrices in CSC
+ * (qpmpc/mpc_qp.py:39,108-109; qpmpc/solve_mpc.py:31-32), so its build is O(N^2) memory, O(N^3) time.
+ * This entry point solves the same QP as mpcqp_build_solve_batch -- same operands, same outputs, same
+ * minimiser -- without forming P or G: Riccati gains once per problem, then per active-set iteration
+ * one LQR solve (two sweeps over the horizon) and O(|A| N) vector work; O(N) memory. No cap on
+ * N; float64, 2 <= nx <= 4, 1 <= nu <= 2 (MPCQP_EUNSUPPORTED otherwise). `max_active` bounds the number
+ * of simultaneously active rows (<= 0: min(n, m, 128)); a problem that needs more returns
+ * status MPCQP_MAX_ITER. The workspace is caller-owned (mpcqp_stagewise_workspace_bytes). */
+int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes);
+int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
+                                const MpcqpSolveOpts *opts, int32_t max_active, void *U, void *lam,
+                                int32_t *status, int32_t *iters, void *workspace, size_t workspace_bytes,
+                                void *stream);
+
 /* ---- shared-model path: build once, re-solve for new states ----------------------
  * The reference's own fast path (doc/src/developer-notes.rst:10, CHANGELOG.md:12,44):
  * build MPCQP once, then only update_cost_vector / update_constraint_vector

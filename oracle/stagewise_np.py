@@ -127,9 +127,8 @@ def solve_stagewise(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-12)
     U0, X0 = ric.solve(qlin, np.zeros((N, nu)), x0=sp.x0, pN=pN)
     # when a tracking term is off in q but on in P (weight set, state undefined) the cost still pulls to 0
     s = sp.e - np.einsum("kri,ki->kr", sp.C, X0[:N]) - np.einsum("kri,ki->kr", sp.D, U0)  # [N, mk]
-    hval = sp.e - np.einsum("kri,ki->kr", sp.C, _free_response(sp))
-    selectable = hval < 1e29
-    tolh = tol * (1.0 + np.abs(hval))
+    selectable = sp.e < 1e29  # padded rows (C = D = 0, e = 1e30) can never be active
+    tolh = tol * (1.0 + np.abs(sp.e))  # a row is violated when its slack is below -tol (1 + |e_i|)
 
     act: List[Tuple[int, int]] = []   # (k, r) of every active row, in slot order
     V: List[np.ndarray] = []          # V_a = P^-1 g_a'   [N, nu]
@@ -137,8 +136,7 @@ def solve_stagewise(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-12)
     lam: List[float] = []
     W = np.zeros((0, 0))
     gdot = lambda k, r, Uv, Xv: float(sp.C[k, r] @ Xv[k] + sp.D[k, r] @ Uv[k])  # noqa: E731
-    # row norms in the P^-1 metric for the selection rule (farthest violated hyperplane)
-    invn = _row_inv_norms(sp, ric)
+    invn = _row_inv_norms(sp)
     iters = 0
     status = 1
     n = N * nu
@@ -212,34 +210,12 @@ def solve_stagewise(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-12)
     return _finish(sp, U0, V, lam, act, status, iters)
 
 
-def _free_response(sp: StageProblem) -> np.ndarray:
-    X = np.zeros((sp.N, sp.nx))
-    x = sp.x0.copy()
-    for k in range(sp.N):
-        X[k] = x
-        x = sp.A[k] @ x
-    return X
-
-
-def _row_inv_norms(sp: StageProblem, ric: Riccati) -> np.ndarray:
-    """1 / sqrt(g_i P^-1 g_i') for every row (the selection metric). O(N) LQR solves would be O(N^2):
-    the diagonal is obtained instead from the controllability-type recursion of the closed loop,
-    Sigma_{k+1} = Acl_k Sigma_k Acl_k' + B_k Sinv_k B_k'  (Sigma_k = Psi_k P^-1 Psi_k' restricted to stage k),
-    g_i P^-1 g_i' = [C D_eff] blocks of it; see mpcqp_stage.hip. Here (oracle) the plain definition is used
-    for short horizons and the recursion for long ones; both agree (tests)."""
-    N, nx, nu, mk = sp.N, sp.nx, sp.nu, sp.mk
-    out = np.ones((N, mk))
-    Sig = np.zeros((nx, nx))  # cov-like: x_k = Psi_k U, Sigma_k = Psi_k P^-1 Psi_k'
-    for k in range(N):
-        Kk, Si = ric.K[k], ric.Sinv[k]
-        # u_k = -K_k x_k + noise with "covariance" Sinv_k in the P^-1 metric
-        for r in range(mk):
-            c_eff = sp.C[k, r] - Kk.T @ sp.D[k, r]
-            val = float(c_eff @ Sig @ c_eff + sp.D[k, r] @ Si @ sp.D[k, r])
-            out[k, r] = 1.0 / np.sqrt(val) if val > 0 else 1.0
-        Acl = ric.Acl[k]
-        Sig = Acl @ Sig @ Acl.T + sp.B[k] @ Si @ sp.B[k].T
-    return out
+def _row_inv_norms(sp: StageProblem) -> np.ndarray:
+    """Selection metric: the violated row farthest from its hyperplane in the Euclidean norm of its own
+    stage block [C_k[r] D_k[r]] (the dense kernels use the P^-1 metric, which costs one more O(N) recursion
+    here and only changes the iteration count, never the minimiser)."""
+    nn = np.sqrt((sp.C ** 2).sum(axis=2) + (sp.D ** 2).sum(axis=2))
+    return np.where(nn > 0.0, 1.0 / np.where(nn > 0.0, nn, 1.0), 1.0)
 
 
 def _finish(sp, U0, V, lam, act, status, iters):

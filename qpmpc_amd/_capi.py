@@ -31,6 +31,8 @@ EXPORTS = (
     "mpcqp_update_vectors_batch",
     "mpcqp_solve_batch",
     "mpcqp_build_solve_batch",
+    "mpcqp_stagewise_workspace_bytes",
+    "mpcqp_stagewise_solve_batch",
     "mpcqp_rollout_batch",
     "mpcqp_model_bytes",
     "mpcqp_factor_model",
@@ -110,6 +112,11 @@ def load():
     lib.mpcqp_build_solve_batch.restype = C.c_int
     lib.mpcqp_build_solve_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts),
                                             vp, vp, vp, vp, vp, C.c_size_t, vp]
+    lib.mpcqp_stagewise_workspace_bytes.restype = C.c_int
+    lib.mpcqp_stagewise_workspace_bytes.argtypes = [C.POINTER(Dims), i64, C.c_int32, C.POINTER(C.c_size_t)]
+    lib.mpcqp_stagewise_solve_batch.restype = C.c_int
+    lib.mpcqp_stagewise_solve_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts), C.c_int32,
+                                                vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.mpcqp_model_bytes.restype = C.c_int
     lib.mpcqp_model_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
     lib.mpcqp_factor_model.restype = C.c_int

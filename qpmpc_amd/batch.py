@@ -414,9 +414,14 @@ class BatchPlan:
 
 
 def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_multipliers: bool = False,
-                    max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw) -> BatchPlan:
+                    max_iter: Optional[int] = None, feas_tol: Optional[float] = None, formulation: str = "condensed",
+                    max_active: Optional[int] = None, **opt_kw) -> BatchPlan:
     """Build and solve every problem of the batch in ONE fused launch
     (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem).
+
+    ``formulation="stagewise"`` solves the same QP without condensing it (``mpcqp_stagewise_solve_batch``:
+    Riccati-based dual active set, O(N) memory and O(N) work per iteration, no cap on the horizon;
+    float64, nx <= 4, nu <= 2); ``max_active`` bounds the active rows it can hold (default min(n, m, 128)).
 
     ``opt_kw``: ``warm_state`` (a :class:`WarmState`, updated by every solve) with ``warm_start=True``
     to begin from it, ``flags`` (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
@@ -431,6 +436,21 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol, **opt_kw)
+    if formulation == "stagewise":
+        nbytes = C.c_size_t(0)
+        _capi.check(lib.mpcqp_stagewise_workspace_bytes(C.byref(dims), Bn, int(max_active or 0), C.byref(nbytes)),
+                    "mpcqp_stagewise_workspace_bytes")
+        ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=problem.device)
+        rc = lib.mpcqp_stagewise_solve_batch(
+            C.byref(dims), C.byref(cp), Bn, C.byref(opts), int(max_active or 0), U.data_ptr(),
+            None if lam is None else lam.data_ptr(), status.data_ptr(), iters.data_ptr(), ws.data_ptr(), ws.numel(),
+            _stream_ptr())
+        _capi.check(rc, "mpcqp_stagewise_solve_batch")
+        plan = BatchPlan(problem, U, status, iters, lam)
+        plan._workspace = (ws, opt_kw)
+        return plan
+    if formulation != "condensed":
+        raise ProblemDefinitionError(f"formulation must be 'condensed' or 'stagewise', not {formulation!r}")
     ws = _workspace(problem, True)
     rc = lib.mpcqp_build_solve_batch(
         C.byref(dims), C.byref(cp), Bn, C.byref(opts), U.data_ptr(),

@@ -446,6 +446,43 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     return run_gws_solve(ka, dims->dtype, batch, w, b.solver * nb * esz, st);
 }
 
+int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!bytes || batch < 0) return MPCQP_EINVAL;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    if (!stage_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
+    *bytes = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    return 0;
+}
+
+int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
+                                const MpcqpSolveOpts *opts, int32_t max_active, void *U, void *lam, int32_t *status,
+                                int32_t *iters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_problem(dims, problem))) return rc;
+    if (batch < 0 || !U) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    if (!stage_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    ka.U = U;
+    ka.lam = lam;
+    ka.status = status;
+    ka.iters = iters;
+    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+    if (ka.warm_state) return MPCQP_EUNSUPPORTED;
+    const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
+    const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+    return launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream);
+}
+
 int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes)
 {
     int rc = check_dims(dims);

@@ -149,6 +149,11 @@ int launch_mid(const KernelArgs &ka, int dtype, int64_t batch, void *ws, hipStre
 int launch_transpose(const void *G, void *GT, int m, int n, int dtype, int64_t batch, hipStream_t st);
 int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q, const void *G,
                     const void *GT, const void *h, void *ws, hipStream_t st);
+// stage-wise formulation (mpcqp_stage.hip): one problem per wavefront, O(N) per iteration
+bool stage_supported(const KernelArgs &ka, int dtype);
+int stage_default_maxq(const KernelArgs &ka);
+size_t stage_ws_doubles(const KernelArgs &ka, int maxq);
+int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st);
 // small-problem kernel (mpcqp_pair.hip): two problems per wavefront, fused build+solve
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
 constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids

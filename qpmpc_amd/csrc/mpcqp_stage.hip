@@ -1,0 +1,772 @@
+// mpcqp_stage.hip -- gfx950 kernel for the STAGE-WISE (uncondensed) formulation: long horizons.
+//
+// The reference has no sparse formulation (sparse=True only wraps the dense condensed matrices in CSC,
+// qpmpc/mpc_qp.py:39,108-109; qpmpc/solve_mpc.py:31-32): its build is O(N^2) memory and O(N^3) time and the
+// dense kernels of this library stop at n = N nu = 256. This kernel solves the same QP
+//
+//   min 1/2 sum w_u |u_k|^2 + 1/2 sum_{1<=k<N} w_x |x_k - xref_k|^2 + 1/2 w_t |x_N - x_goal|^2
+//   s.t. x_{k+1} = A_k x_k + B_k u_k,  C_k x_k + D_k u_k <= e_k
+//
+// without ever forming P or G: O(N) memory, O(N) work per active-set iteration. Restated on the CPU in
+// oracle/stagewise_np.py; same minimiser as the dense path (tests/golden/stagewise_*.npz come from the
+// reference-built dense QP).
+//
+// Method -- Goldfarb-Idnani's dual active set in the metric of the condensed Hessian P:
+//   * v -> P^-1 v is ONE LQR SOLVE: Riccati gains (Acl_k = A_k - B_k K_k, K_k, S_k^-1) computed once per
+//     problem, then a backward sweep (costate p_k, feed-forward ff_k) and a forward sweep (u_k, x_k);
+//   * a row of G applied to a vector is a read of that vector's state trajectory:
+//     g_i . v = C_k[r] x_k(v) + D_k[r] v_k;
+//   * per active row a the slot keeps V_a = P^-1 g_a' and its trajectory X_a, and W = (G_A P^-1 G_A')^-1
+//     (|A| x |A|) is bordered / deflated by rank-one updates. Step along z = -(V_p - sum_a r_a V_a),
+//     r = W c, c_a = g_a . V_p, d2 = g_p . V_p - c . r; full step t2 = -s_p / d2, partial step
+//     t1 = min lam_a / r_a; the primal point is implied: u = u0 - sum_a lam_a V_a.
+//
+// Mapping -- ONE PROBLEM PER WAVEFRONT, the horizon cut into 64 CHUNKS of L = ceil(N/64) steps, lane j
+// owning chunk j for everything (slacks, slot vectors, trajectories): the O(|A| N) work of an iteration is
+// spread over the 64 lanes, and the two sweeps of the LQR solve -- affine recurrences, serial in k -- are
+// chunked scans: every lane runs its chunk from a zero inflow, the 64 chunk boundaries are chained through
+// the chunks' transition matrices (readlane, 63 small mat-vecs), then every lane re-runs its chunk from
+// its true inflow: depth 2 L + 63 instead of N. All per-problem arrays live in a caller-owned HBM
+// workspace (they are re-read by the same CU: L1/L2-resident for the horizons this is meant for); the
+// small vectors shared by the lanes (c, r, multipliers, the active list) live in LDS.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace stage {
+
+struct Ws {  // per-problem workspace carve, in doubles (host-computed, passed by value)
+    int64_t Acl, Kg, Sinv, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
+    int maxq;
+};
+
+__host__ __device__ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
+{
+    Ws w{};
+    int64_t o = 0;
+    auto take = [&](int64_t cnt) {
+        const int64_t at = o;
+        o += (cnt + 1) & ~(int64_t)1;
+        return at;
+    };
+    const int64_t m = (int64_t)N * mk;
+    w.Acl = take((int64_t)N * nx * nx);
+    w.Kg = take((int64_t)N * nu * nx);
+    w.Sinv = take((int64_t)N * nu * nu);
+    w.ff = take((int64_t)N * nu);
+    w.U0 = take((int64_t)N * nu);
+    w.X0 = take((int64_t)N * nx);
+    w.s = take(m);
+    w.invn = take(m);
+    w.rowslot = take((m + 1) / 2);  // int32 per row
+    w.V = take((int64_t)(maxq + 1) * N * nu);   // slot maxq: the candidate row of the current iteration
+    w.XV = take((int64_t)(maxq + 1) * N * nx);
+    w.W = take((int64_t)maxq * maxq);
+    w.total = o;
+    w.maxq = maxq;
+    return w;
+}
+
+__device__ __forceinline__ double rl(double x, int lane)  // lane must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// (value, index) arg-min over the wavefront; ties -> lowest index; every lane gets the result
+__device__ __forceinline__ void wave_argmin(double &v, int &idx)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(idx, o);
+        const bool take = (ov < v) || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+}
+// stores of one lane become visible to the other lanes of the wavefront (same CU, same L1)
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace stage
+
+using namespace stage;
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64)
+    mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
+    const int lane = threadIdx.x;
+    const int64_t prob = blockIdx.x;
+    const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
+    const int L = (N + 63) / 64;                    // steps per chunk
+    const int k0 = lane * L < N ? lane * L : N;     // this lane's chunk [k0, k1)
+    const int k1 = (k0 + L < N) ? k0 + L : N;
+    const int nch = (N + L - 1) / L;                // chunks that hold steps
+    const double INF = HUGE_VAL;
+    // ---- LDS: vectors shared by the lanes
+    double *cv = (double *)stage_smem, *rv = cv + maxq, *lamv = rv + maxq;
+    int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
+    // ---- workspace
+    double *ws = wsbase + prob * wl.total;
+    double *Acl = ws + wl.Acl, *Kg = ws + wl.Kg, *Sinv = ws + wl.Sinv, *ffv = ws + wl.ff, *U0 = ws + wl.U0, *X0 = ws + wl.X0;
+    double *sl = ws + wl.s, *invn = ws + wl.invn, *Vs = ws + wl.V, *XVs = ws + wl.XV, *Wm = ws + wl.W;
+    int *rowslot = (int *)(ws + wl.rowslot);
+    // ---- operands
+    const double *gA = (const double *)ka.A.ptr + prob * ka.A.batch_stride;
+    const double *gB = (const double *)ka.B.ptr + prob * ka.B.batch_stride;
+    const double *gC = ka.C.ptr ? (const double *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
+    const double *gD = ka.D.ptr ? (const double *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+    const double *ge = (const double *)ka.e.ptr + prob * ka.e.batch_stride;
+    const double *gx0 = (const double *)ka.x0.ptr + prob * ka.x0.batch_stride;
+    const double *ggoal = ka.goal.ptr ? (const double *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+    const double *gtgt = ka.targets.ptr ? (const double *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+    const int64_t sA = ka.A.step_stride, sB = ka.B.step_stride, sC = ka.C.step_stride, sD = ka.D.step_stride, sE = ka.e.step_stride;
+    const bool stageP = ka.flags & MPCQP_P_STAGE, termP = ka.flags & MPCQP_P_TERMINAL;
+    const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+    const double wu = ka.wu, wx = stageP ? ka.wx : 0.0, wt = termP ? ka.wt : 0.0;
+
+    // ================================================================= factor: Riccati recursion
+    // (serial in k and nonlinear: every lane computes it, the operands arrive through scalar loads)
+    {
+        double P[NX * NX];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) P[i] = (i / NX == i % NX) ? wt : 0.0;
+        for (int k = N - 1; k >= 0; --k) {
+            const double *A = gA + k * sA, *B = gB + k * sB;
+            double PA[NX * NX], PB[NX * NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a += P[i * NX + l] * A[l * NX + j];
+                    PA[i * NX + j] = a;
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a += P[i * NX + l] * B[l * NU + j];
+                    PB[i * NU + j] = a;
+                }
+            }
+            double S[NU * NU], Si[NU * NU], BPA[NU * NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    double a = (i == j) ? wu : 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a += B[l * NU + i] * PB[l * NU + j];
+                    S[i * NU + j] = a;
+                }
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a += B[l * NU + i] * PA[l * NX + j];
+                    BPA[i * NX + j] = a;
+                }
+            }
+            if constexpr (NU == 1) {
+                Si[0] = 1.0 / S[0];
+            } else {
+                const double det = S[0] * S[3] - S[1] * S[2], id = 1.0 / det;
+                Si[0] = S[3] * id;
+                Si[1] = -S[1] * id;
+                Si[2] = -S[2] * id;
+                Si[3] = S[0] * id;
+            }
+            double Kk[NU * NX], Ac[NX * NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) a += Si[i * NU + l] * BPA[l * NX + j];
+                    Kk[i * NX + j] = a;
+                }
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double a = A[i * NX + j];
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) a -= B[i * NU + l] * Kk[l * NX + j];
+                    Ac[i * NX + j] = a;
+                }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX * NX; ++i) Acl[(int64_t)k * NX * NX + i] = Ac[i];
+#pragma unroll
+                for (int i = 0; i < NU * NX; ++i) Kg[(int64_t)k * NU * NX + i] = Kk[i];
+#pragma unroll
+                for (int i = 0; i < NU * NU; ++i) Sinv[(int64_t)k * NU * NU + i] = Si[i];
+            }
+            // P_k = Q_k + A' P_{k+1} Acl, symmetrised (x_0 is data: Q_0 = 0)
+            const double qk = (k >= 1) ? wx : 0.0;
+            double Pn[NX * NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    double a = (i == j) ? qk : 0.0;
+#pragma unroll
+                    for (int l = 0; l < NX; ++l) a += PA[l * NX + i] * Ac[l * NX + j];  // (P A)' Acl = A' P Acl
+                    Pn[i * NX + j] = a;
+                }
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) P[i * NX + j] = 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
+        }
+    }
+    wsync();
+    // chunk transition matrix Phi_j = Acl_{k1-1} ... Acl_{k0} of this lane's chunk (identity if empty)
+    double Phi[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) Phi[i] = (i / NX == i % NX) ? 1.0 : 0.0;
+    for (int k = k0; k < k1; ++k) {
+        const double *Ac = Acl + (int64_t)k * NX * NX;
+        double T[NX * NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += Ac[i * NX + l] * Phi[l * NX + j];
+                T[i * NX + j] = a;
+            }
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) Phi[i] = T[i];
+    }
+
+    // ================================================================= the LQR solve as two chunked scans
+    // linear costs: state cost q_k = qs * (row vector qrow) at k == kq plus the dense tracking term when
+    // `track`; input cost r_k = rrow at k == kq.   (kq < 0: none)
+    // backward: p_k = g_k + Acl_k' p_{k+1},  g_k = q_k - K_k' r_k ;  ff_k = -Sinv_k (B_k' p_{k+1} + r_k)
+    auto lin_q = [&](int k, int kq, const double *qrow, bool track, double (&q)[NX]) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) q[i] = 0.0;
+        if (track && stageQ && k >= 1) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) q[i] = -ka.wx * gtgt[(int64_t)k * NX + i];
+        }
+        if (k == kq) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) q[i] -= qrow[i];
+        }
+    };
+    auto backward = [&](int kq, const double *qrow, const double *rrow, bool track) {
+        // pass 1: chunk offset gamma_j (outflow at the chunk's bottom for a zero inflow at its top)
+        double p[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) p[i] = 0.0;
+        for (int k = k1 - 1; k >= k0; --k) {
+            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX;
+            double q[NX], np_[NX];
+            lin_q(k, kq, qrow, track, q);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = q[i];
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += Ac[l * NX + i] * p[l];
+                if (k == kq) {
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) a += Kk[l * NX + i] * rrow[l];  // - K' r with r = -rrow
+                }
+                np_[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) p[i] = np_[i];
+        }
+        // pass 2: inflow at the top of every chunk, chained from the terminal costate downwards
+        double pin[NX], cur[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            cur[i] = (track && termQ) ? -ka.wt * ggoal[i] : 0.0;  // p_N
+            pin[i] = cur[i];
+        }
+        for (int j = nch - 1; j >= 1; --j) {
+            // inflow of chunk j-1 = Phi_j' cur + gamma_j
+            double nxt[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = rl(p[i], j);
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += rl(Phi[l * NX + i], j) * cur[l];
+                nxt[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                cur[i] = nxt[i];
+                pin[i] = (lane == j - 1) ? cur[i] : pin[i];
+            }
+        }
+        if (lane >= nch) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pin[i] = 0.0;
+        }
+        // pass 3: the chunk again from its true inflow; feed-forward terms written out
+#pragma unroll
+        for (int i = 0; i < NX; ++i) p[i] = pin[i];
+        for (int k = k1 - 1; k >= k0; --k) {
+            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX, *Si = Sinv + (int64_t)k * NU * NU;
+            const double *B = gB + k * sB;
+            double t[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = (k == kq) ? -rrow[i] : 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += B[l * NU + i] * p[l];
+                t[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NU; ++l) a -= Si[i * NU + l] * t[l];
+                ffv[(int64_t)k * NU + i] = a;
+            }
+            double q[NX], np_[NX];
+            lin_q(k, kq, qrow, track, q);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = q[i];
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += Ac[l * NX + i] * p[l];
+                if (k == kq) {
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) a += Kk[l * NX + i] * rrow[l];
+                }
+                np_[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) p[i] = np_[i];
+        }
+    };
+    // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs; writes Uo [N, NU], Xo [N, NX]
+    auto forward = [&](const double *xs, double *Uo, double *Xo) {
+        double y[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            const double *Ac = Acl + (int64_t)k * NX * NX, *B = gB + k * sB, *f = ffv + (int64_t)k * NU;
+            double ny[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += Ac[i * NX + l] * y[l];
+#pragma unroll
+                for (int l = 0; l < NU; ++l) a += B[i * NU + l] * f[l];
+                ny[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) y[i] = ny[i];
+        }
+        double xin[NX], cur[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            cur[i] = xs ? xs[i] : 0.0;
+            xin[i] = cur[i];
+        }
+        for (int j = 0; j + 1 < nch; ++j) {
+            double nxt[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = rl(y[i], j);
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += rl(Phi[i * NX + l], j) * cur[l];
+                nxt[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                cur[i] = nxt[i];
+                xin[i] = (lane == j + 1) ? cur[i] : xin[i];
+            }
+        }
+        double x[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xin[i];
+        for (int k = k0; k < k1; ++k) {
+            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX, *B = gB + k * sB;
+            const double *f = ffv + (int64_t)k * NU;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Xo[(int64_t)k * NX + i] = x[i];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = f[i];
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a -= Kk[i * NX + l] * x[l];
+                Uo[(int64_t)k * NU + i] = a;
+            }
+            double nx_[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; ++l) a += Ac[i * NX + l] * x[l];
+#pragma unroll
+                for (int l = 0; l < NU; ++l) a += B[i * NU + l] * f[l];
+                nx_[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = nx_[i];
+        }
+    };
+    // g_(k,r) . (U, X) = C_k[r] x_k + D_k[r] u_k
+    auto gdot = [&](int k, int r, const double *Uv, const double *Xv) {
+        double a = 0.0;
+        if (gC) {
+            const double *c = gC + k * sC + r * NX;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) a += c[i] * Xv[(int64_t)k * NX + i];
+        }
+        if (gD) {
+            const double *d = gD + k * sD + r * NU;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) a += d[i] * Uv[(int64_t)k * NU + i];
+        }
+        return a;
+    };
+
+    // ================================================================= unconstrained minimiser, slacks
+    double zero_row[NX > NU ? NX : NU];
+#pragma unroll
+    for (int i = 0; i < (NX > NU ? NX : NU); ++i) zero_row[i] = 0.0;
+    backward(-1, zero_row, zero_row, true);
+    wsync();
+    forward(gx0, U0, X0);
+    wsync();
+    const double tol = ka.tol;
+    for (int k = k0; k < k1; ++k)
+        for (int r = 0; r < mk; ++r) {
+            const int64_t i = (int64_t)k * mk + r;
+            const double ev = ge[k * sE + r];
+            sl[i] = ev - gdot(k, r, U0, X0);
+            double nn = 0.0;
+            if (gC)
+                for (int c = 0; c < NX; ++c) nn += gC[k * sC + r * NX + c] * gC[k * sC + r * NX + c];
+            if (gD)
+                for (int c = 0; c < NU; ++c) nn += gD[k * sD + r * NU + c] * gD[k * sD + r * NU + c];
+            invn[i] = nn > 0.0 ? rsqrt(nn) : 1.0;
+            rowslot[i] = -1;
+        }
+    wsync();
+
+    // ================================================================= active-set loop
+    int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
+    const int max_iter = ka.max_iter;
+    const int nvar = N * NU;
+    double *Vp = Vs + (int64_t)maxq * N * NU, *Xp = XVs + (int64_t)maxq * N * NX;  // the candidate's slot
+    bool fail = false;
+    for (int round = 0; round < 4 && !fail; ++round) {
+        for (;;) {
+            // ---- selection: the violated row farthest from its hyperplane
+            double best = INF;
+            int bi = 0x7fffffff;
+            for (int k = k0; k < k1; ++k)
+                for (int r = 0; r < mk; ++r) {
+                    const int64_t i = (int64_t)k * mk + r;
+                    const double ev = ge[k * sE + r], sv = sl[i];
+                    const bool viol = ev < 1e29 && rowslot[i] < 0 && sv < -(tol + tol * fabs(ev));
+                    const double sc = sv * invn[i];
+                    if (viol && sc < best) {
+                        best = sc;
+                        bi = (int)i;
+                    }
+                }
+            wave_argmin(best, bi);
+            if (!(best < INF)) {
+                status = MPCQP_SOLVED;
+                break;
+            }
+            const int kp = bi / mk, rp = bi - kp * mk;
+            double qrow[NX], rrow[NU];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) qrow[i] = gC ? gC[kp * sC + rp * NX + i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) rrow[i] = gD ? gD[kp * sD + rp * NU + i] : 0.0;
+            double up = 0.0;
+            bool added = false;
+            // V_p = P^-1 g_p' and its trajectory do not change while p waits for room: solved once
+            backward(kp, qrow, rrow, false);
+            wsync();
+            forward(nullptr, Vp, Xp);
+            wsync();
+            const double dpp = gdot(kp, rp, Vp, Xp);
+            while (!added) {
+                if (iters >= max_iter || nq >= maxq) {
+                    fail = true;
+                    break;
+                }
+                ++iters;
+                // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
+                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], actr[a], Vp, Xp);
+                wsync();
+                double cr = 0.0;
+                for (int a = lane; a < nq; a += 64) {
+                    double acc = 0.0;
+                    for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
+                    rv[a] = acc;
+                    cr += acc * cv[a];
+                }
+                cr = wave_sum(cr);
+                wsync();
+                const double d2 = dpp - cr;
+                const bool can_move = (nq < nvar) && (d2 > 1e-13 * dpp) && (d2 > 0.0);
+                // ---- ratio test on the multipliers
+                double t1 = INF;
+                int l = 0x7fffffff;
+                for (int a = lane; a < nq; a += 64) {
+                    const double ra = rv[a];
+                    if (ra > 0.0) {
+                        const double q = lamv[a] / ra;
+                        if (q < t1) {
+                            t1 = q;
+                            l = a;
+                        }
+                    }
+                }
+                wave_argmin(t1, l);
+                const double sp = sl[bi];
+                const double t2 = can_move ? -sp / d2 : INF;
+                const double t = t1 < t2 ? t1 : t2;
+                if (!(t < INF)) {
+                    status = MPCQP_INFEASIBLE;
+                    fail = true;
+                    break;
+                }
+                const bool full = (t2 <= t1);
+                // ---- slacks: s_i -= t g_i . z ,  z = -(V_p - sum_a r_a V_a)  (this lane's chunk)
+                for (int k = k0; k < k1; ++k) {
+                    double zu[NU], zx[NX];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) zu[i] = -Vp[(int64_t)k * NU + i];
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) zx[i] = -Xp[(int64_t)k * NX + i];
+                    for (int a = 0; a < nq; ++a) {
+                        const double ra = rv[a];
+                        const double *va = Vs + ((int64_t)a * N + k) * NU, *xa = XVs + ((int64_t)a * N + k) * NX;
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) zu[i] += ra * va[i];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) zx[i] += ra * xa[i];
+                    }
+                    for (int r = 0; r < mk; ++r) {
+                        double gz = 0.0;
+                        if (gC)
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) gz += gC[k * sC + r * NX + i] * zx[i];
+                        if (gD)
+#pragma unroll
+                            for (int i = 0; i < NU; ++i) gz += gD[k * sD + r * NU + i] * zu[i];
+                        const int64_t i = (int64_t)k * mk + r;
+                        sl[i] = (rowslot[i] >= 0) ? 0.0 : sl[i] - t * gz;
+                    }
+                }
+                // ---- multipliers
+                for (int a = lane; a < nq; a += 64) {
+                    const double v = lamv[a] - t * rv[a];
+                    lamv[a] = v < 0.0 ? 0.0 : v;
+                }
+                up += t;
+                wsync();
+                if (full) {
+                    // p becomes active in slot nq: W is bordered, the candidate's vectors move into the slot
+                    const double id2 = 1.0 / d2;
+                    for (int a = lane; a < nq; a += 64) {
+                        const double ra = rv[a];
+                        for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] += rv[b] * ra * id2;
+                        Wm[(int64_t)nq * maxq + a] = -ra * id2;
+                        Wm[(int64_t)a * maxq + nq] = -ra * id2;
+                    }
+                    if (lane == 0) {
+                        Wm[(int64_t)nq * maxq + nq] = id2;
+                        lamv[nq] = up;
+                        actk[nq] = kp;
+                        actr[nq] = rp;
+                        rowslot[bi] = nq;
+                        sl[bi] = 0.0;
+                    }
+                    double *vd = Vs + (int64_t)nq * N * NU, *xd = XVs + (int64_t)nq * N * NX;
+                    for (int k = k0; k < k1; ++k) {
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) vd[(int64_t)k * NU + i] = Vp[(int64_t)k * NU + i];
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) xd[(int64_t)k * NX + i] = Xp[(int64_t)k * NX + i];
+                    }
+                    ++nq;
+                    added = true;
+                } else {
+                    // partial step: slot l leaves; W is deflated and the last slot moves into the hole
+                    const double wll = Wm[(int64_t)l * maxq + l];
+                    const double iw = 1.0 / wll;
+                    for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
+                    wsync();
+                    for (int a = lane; a < nq; a += 64) {
+                        const double wa = cv[a];
+                        for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
+                    }
+                    wsync();
+                    const int last = nq - 1;
+                    const int drow = actk[l] * mk + actr[l];
+                    if (l != last) {
+                        for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
+                        wsync();
+                        for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
+                        wsync();
+                        const double *vs = Vs + (int64_t)last * N * NU, *xs = XVs + (int64_t)last * N * NX;
+                        double *vd = Vs + (int64_t)l * N * NU, *xd = XVs + (int64_t)l * N * NX;
+                        for (int k = k0; k < k1; ++k) {
+#pragma unroll
+                            for (int i = 0; i < NU; ++i) vd[(int64_t)k * NU + i] = vs[(int64_t)k * NU + i];
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) xd[(int64_t)k * NX + i] = xs[(int64_t)k * NX + i];
+                        }
+                    }
+                    if (lane == 0) {
+                        rowslot[drow] = -1;
+                        if (l != last) {
+                            lamv[l] = lamv[last];
+                            actk[l] = actk[last];
+                            actr[l] = actr[last];
+                            rowslot[actk[last] * mk + actr[last]] = l;
+                        }
+                    }
+                    --nq;
+                }
+                wsync();
+            }
+            if (fail) break;
+        }
+        if (fail) break;
+        // ================================================================= primal point, verification
+        // u = u0 - sum_a lam_a V_a ; slacks from scratch through x = x0 - sum_a lam_a X_a
+        bool dirty = false;
+        for (int k = k0; k < k1; ++k) {
+            double u[NU], x[NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u[i] = U0[(int64_t)k * NU + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X0[(int64_t)k * NX + i];
+            for (int a = 0; a < nq; ++a) {
+                const double la = lamv[a];
+                const double *va = Vs + ((int64_t)a * N + k) * NU, *xa = XVs + ((int64_t)a * N + k) * NX;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) u[i] -= la * va[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] -= la * xa[i];
+            }
+            double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ou[i] = u[i];
+            for (int r = 0; r < mk; ++r) {
+                const int64_t i = (int64_t)k * mk + r;
+                const double ev = ge[k * sE + r];
+                double g = 0.0;
+                if (gC)
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) g += gC[k * sC + r * NX + c] * x[c];
+                if (gD)
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) g += gD[k * sD + r * NU + c] * u[c];
+                const double fresh = ev - g;
+                const bool act = rowslot[i] >= 0;
+                if (ev < 1e29 && !act && !(fresh >= -4.0 * (tol + tol * fabs(ev)))) dirty = true;
+                sl[i] = act ? 0.0 : fresh;
+            }
+        }
+        dirty = __ballot(dirty) != 0ull;
+        wsync();
+        if (!dirty) {
+            status = MPCQP_SOLVED;
+            break;
+        }
+        status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
+    }
+    if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+    const bool ok = status == MPCQP_SOLVED;
+    if (!ok) {
+        double *ou = (double *)ka.U + prob * (int64_t)nvar;
+        for (int k = k0; k < k1; ++k)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ou[(int64_t)k * NU + i] = 0.0;
+    }
+    if (ka.lam) {
+        double *ol = (double *)ka.lam + prob * (int64_t)N * mk;
+        for (int k = k0; k < k1; ++k)
+            for (int r = 0; r < mk; ++r) {
+                const int64_t i = (int64_t)k * mk + r;
+                const int sidx = rowslot[i];
+                ol[i] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
+            }
+    }
+    if (lane == 0) {
+        if (ka.status) ka.status[prob] = status;
+        if (ka.iters) ka.iters[prob] = iters;
+    }
+}
+
+// ------------------------------------------------------------ host side
+bool stage_supported(const KernelArgs &ka, int dtype)
+{
+    return dtype == MPCQP_F64 && ka.nx >= 2 && ka.nx <= 4 && ka.nu >= 1 && ka.nu <= 2 && ka.mk >= 1;
+}
+
+int stage_default_maxq(const KernelArgs &ka)
+{
+    int q = ka.n < ka.m ? ka.n : ka.m;
+    return q < 128 ? q : 128;
+}
+
+size_t stage_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
+
+template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
+    const size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int));
+    auto kern = mpcqp_stage_kernel<NX, NU>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64), lds, st, ka, wl, (double *)ws, batch);
+    return (int)hipGetLastError();
+}
+
+int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    switch (ka.nx * 10 + ka.nu) {
+    case 21: return launch_stage_t<2, 1>(ka, maxq, batch, ws, st);
+    case 22: return launch_stage_t<2, 2>(ka, maxq, batch, ws, st);
+    case 31: return launch_stage_t<3, 1>(ka, maxq, batch, ws, st);
+    case 32: return launch_stage_t<3, 2>(ka, maxq, batch, ws, st);
+    case 41: return launch_stage_t<4, 1>(ka, maxq, batch, ws, st);
+    case 42: return launch_stage_t<4, 2>(ka, maxq, batch, ws, st);
+    default: return MPCQP_EUNSUPPORTED;
+    }
+}
+
+}  // namespace mpcqp
