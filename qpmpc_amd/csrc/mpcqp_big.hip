@@ -31,19 +31,22 @@ using namespace big;
 // Phi_k x0 - ref_k, h [m], and optionally G [m, n] and the inverse row norms 1/|G_i| [m].
 // The norms come from the nx x nx recursion S_{k+1} = A_k S_k A_k' + B_k B_k' (S_k = Psi_k Psi_k',
 // |G_i|^2 = C_i S_k C_i' + |D_i|^2 because Psi_k is zero in the columns of u_k).
-template <typename T, bool NRM>
+// NXC > 0: the state dimension at compile time (straight-line 16-byte broadcast reads of A_k, C_k); 0: any nx <= NXMAX.
+template <typename T, bool NRM, int NXC>
 __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
                                                               T *__restrict__ res_ws, T *__restrict__ oG,
                                                               T *__restrict__ oh, T *__restrict__ onrm)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *sm = (T *)smem_raw;
-    const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, n = ka.n, m = ka.m;
+    const int nx = NXC > 0 ? NXC : ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, n = ka.n, m = ka.m;
+    constexpr int NXU = NXC > 0 ? NXC : NXMAX;  // unroll bound of the per-column loops
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
     const int nA = nx * nx, nB = nx * nu, nC = mk * nx, nD = mk * nu;
-    T *As = sm, *Bs = As + nA, *Cs = Bs + nB, *Ds = Cs + nC, *es = Ds + nD;
-    T *Ss = es + mk, *T1s = Ss + nA, *Ys = T1s + nA;
+    auto al4 = [](int c) { return (c + 3) & ~3; };  // every staged array starts 16-byte aligned
+    T *As = sm, *Bs = As + al4(nA), *Cs = Bs + al4(nB), *Ds = Cs + al4(nC), *es = Ds + al4(nD);
+    T *Ss = es + al4(mk), *T1s = Ss + al4(nA), *Ys = T1s + al4(nA);
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
     const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
     const T *gC = ka.C.ptr ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
@@ -65,34 +68,67 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
     const int jfirst = __builtin_amdgcn_readfirstlane(min((tid & ~63) / nu, N));
     // the free response Phi_k x0 lives in LDS (double-buffered) and is advanced by the last wavefront,
     // one lane per row, so that no single lane carries a serial chain of mk + nx dot products
-    T *xs = Ys + nC;
+    T *xs = Ys + al4(nC);
     const int l4 = tid - 256;  // lane of the last wavefront (threads 256..319)
 
     if constexpr (NRM)
         for (int e2 = tid; e2 < nA; e2 += 320) Ss[e2] = T(0);
     if (l4 >= 0 && l4 < nx) xs[l4] = gx0[l4];
 
-    T v[NXMAX];
+    T v[NXU];
 #pragma unroll
-    for (int s = 0; s < NXMAX; ++s) v[s] = T(0);
+    for (int s = 0; s < NXU; ++s) v[s] = T(0);
+    // The operands of step k+1 are requested into registers while step k computes and land in LDS at the next
+    // barrier: the HBM latency of the staging is paid once, not once per step. (Two elements per thread and array
+    // cover 640 entries; larger blocks -- mk nx > 640 -- are staged the plain way.)
+    const bool pfok = nA <= 640 && nB <= 640 && nC <= 640 && nD <= 640 && mk <= 640;
+    T pa[2], pb[2], pc[2], pd[2], pe[2];
+    auto request = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 320;
+            pa[u] = (i < nA) ? gA[k * ka.A.step_stride + i] : T(0);
+            pb[u] = (i < nB) ? gB[k * ka.B.step_stride + i] : T(0);
+            pc[u] = (gC && i < nC) ? gC[k * ka.C.step_stride + i] : T(0);
+            pd[u] = (gD && i < nD) ? gD[k * ka.D.step_stride + i] : T(0);
+            pe[u] = (i < mk) ? ge[k * ka.e.step_stride + i] : T(0);
+        }
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 320;
+            if (i < nA) As[i] = pa[u];
+            if (i < nB) Bs[i] = pb[u];
+            if (gC && i < nC) Cs[i] = pc[u];
+            if (gD && i < nD) Ds[i] = pd[u];
+            if (i < mk) es[i] = pe[u];
+        }
+    };
+    if (pfok) request(0);
     for (int k = 0; k <= N; ++k) {
         const T *xc = xs + (k & 1) * nx;
         T *xn = xs + ((k + 1) & 1) * nx;
         __syncthreads();
         if (k < N) {  // stage the operands of step k (coalesced)
-            for (int i = tid; i < nA; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
-            for (int i = tid; i < nB; i += blockDim.x) Bs[i] = gB[k * ka.B.step_stride + i];
-            if (gC)
-                for (int i = tid; i < nC; i += blockDim.x) Cs[i] = gC[k * ka.C.step_stride + i];
-            if (gD)
-                for (int i = tid; i < nD; i += blockDim.x) Ds[i] = gD[k * ka.D.step_stride + i];
-            for (int i = tid; i < mk; i += blockDim.x) es[i] = ge[k * ka.e.step_stride + i];
+            if (pfok) {
+                land();
+            } else {
+                for (int i = tid; i < nA; i += blockDim.x) As[i] = gA[k * ka.A.step_stride + i];
+                for (int i = tid; i < nB; i += blockDim.x) Bs[i] = gB[k * ka.B.step_stride + i];
+                if (gC)
+                    for (int i = tid; i < nC; i += blockDim.x) Cs[i] = gC[k * ka.C.step_stride + i];
+                if (gD)
+                    for (int i = tid; i < nD; i += blockDim.x) Ds[i] = gD[k * ka.D.step_stride + i];
+                for (int i = tid; i < mk; i += blockDim.x) es[i] = ge[k * ka.e.step_stride + i];
+            }
         }
         __syncthreads();
+        if (pfok && k + 1 < N) request(k + 1);
         // v = Psi_k[:, c]
         if (col) {
 #pragma unroll
-            for (int s = 0; s < NXMAX; ++s)
+            for (int s = 0; s < NXU; ++s)
                 if (s < nx) Psi[((int64_t)k * nx + s) * n + tid] = v[s];
         } else if (l4 >= 0 && l4 < nx) {
             T ref = T(0);
@@ -111,7 +147,7 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
                     T acc = T(0);
                     if (gC && k > jfirst) {
 #pragma unroll
-                        for (int s = 0; s < NXMAX; ++s)
+                        for (int s = 0; s < NXU; ++s)
                             if (s < nx) acc += Cs[i2 * nx + s] * v[s];
                     }
                     if (gD && j == k) acc += Ds[i2 * nu + ii];
@@ -120,24 +156,24 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
             }
             if (k >= jfirst) {
                 // advance (mpc_qp.py:88-90)
-                T w[NXMAX];
+                T w[NXU];
 #pragma unroll
-                for (int r = 0; r < NXMAX; ++r) {
+                for (int r = 0; r < NXU; ++r) {
                     T acc = T(0);
                     if (r < nx) {
 #pragma unroll
-                        for (int s = 0; s < NXMAX; ++s)
+                        for (int s = 0; s < NXU; ++s)
                             if (s < nx) acc += As[r * nx + s] * v[s];
                     }
                     w[r] = acc;
                 }
                 if (j == k) {
 #pragma unroll
-                    for (int r = 0; r < NXMAX; ++r)
+                    for (int r = 0; r < NXU; ++r)
                         if (r < nx) w[r] = Bs[r * nu + ii];
                 }
 #pragma unroll
-                for (int r = 0; r < NXMAX; ++r) v[r] = w[r];
+                for (int r = 0; r < NXU; ++r) v[r] = w[r];
             }
         } else if (l4 >= 0) {
             // h rows (mpc_qp.py:74-78) and the free response, one lane per row
@@ -229,27 +265,54 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     float qacc = 0.0f;
     const bool strip = wv < NT;  // wavefronts beyond n/32 only help with the staging
-    // block 0 of Psi is zero: start at row nx
-    for (int row0 = nx; row0 < K; row0 += KC) {
-        // columns that can be non-zero in this chunk: below k_last nu, rounded up to a tile
-        const int klast = min(row0 + KC - 1, K - 1) / nx;
-        const int cnz = min(n, klast * nu), cmax = min(n, (cnz + 31) & ~31);
-        __syncthreads();
-        // stage KC rows (coalesced float4 loads; rows past K are zero-weighted)
-        for (int i = tid * 4; i < KC * cmax; i += 512 * 4) {
-            const int r = i / cmax, c = i - r * cmax;
-            const int row = row0 + r;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < K) val = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + c);
-            *reinterpret_cast<float4 *>(tile + r * 256 + c) = val;
+    // block 0 of Psi is zero: start at row nx. The NEXT chunk's rows are requested into registers before this
+    // chunk's MFMAs and land in LDS after them, so the HBM latency of the staging overlaps the matrix work.
+    auto chunk_cols = [&](int row0, int &cnz, int &cmax) {
+        const int klast = min(row0 + KC - 1, K - 1) / nx;  // columns that can be non-zero: below k_last nu
+        cnz = min(n, klast * nu);
+        cmax = min(n, (cnz + 31) & ~31);
+    };
+    float4 pf[2];
+    float pw = 0.0f, pr = 0.0f;
+    auto request = [&](int row0) {
+        int cnz, cmax;
+        chunk_cols(row0, cnz, cmax);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid * 4 + u * 2048;
+            pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < KC * cmax) {
+                const int r = i / cmax, c = i - r * cmax;
+                const int row = row0 + r;
+                if (row < K) pf[u] = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + c);
+            }
         }
         if (tid < KC) {
             const int row = row0 + tid;
             const bool term = row >= N * nx;
-            wrow[tid] = (row < K) ? (term ? wtp : wxp) : 0.0f;
-            rrow[tid] = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
+            pw = (row < K) ? (term ? wtp : wxp) : 0.0f;
+            pr = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
+        }
+    };
+    request(nx);
+    for (int row0 = nx; row0 < K; row0 += KC) {
+        int cnz, cmax;
+        chunk_cols(row0, cnz, cmax);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid * 4 + u * 2048;
+            if (i < KC * cmax) {
+                const int r = i / cmax, c = i - r * cmax;
+                *reinterpret_cast<float4 *>(tile + r * 256 + c) = pf[u];
+            }
+        }
+        if (tid < KC) {
+            wrow[tid] = pw;
+            rrow[tid] = pr;
         }
         __syncthreads();
+        if (row0 + KC < K) request(row0 + KC);
         if (strip && 32 * wv < cnz) {
 #pragma unroll
             for (int kk = 0; kk < KC; kk += 2) {
@@ -342,15 +405,18 @@ int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Ps
                         void *G, void *h, void *rownorm_inv, hipStream_t st)
 {
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    const size_t lds =
-        (size_t)(3 * ka.nx * ka.nx + ka.nx * ka.nu + 2 * ka.mk * ka.nx + ka.mk * ka.nu + ka.mk + 2 * ka.nx) * esz;
-#define PROPAGATE(TY, NRMV)                                                                                     \
-    hipLaunchKernelGGL((mpcqp_propagate_kernel<TY, NRMV>), dim3((unsigned)batch), dim3(320), lds, st, ka,       \
+    auto al4 = [](size_t c) { return (c + 3) & ~(size_t)3; };
+    const size_t lds = (3 * al4((size_t)ka.nx * ka.nx) + al4((size_t)ka.nx * ka.nu) + 2 * al4((size_t)ka.mk * ka.nx) +
+                        al4((size_t)ka.mk * ka.nu) + al4((size_t)ka.mk) + 2 * (size_t)ka.nx + 8) * esz;
+#define PROPAGATE(TY, NRMV, NXV)                                                                                \
+    hipLaunchKernelGGL((mpcqp_propagate_kernel<TY, NRMV, NXV>), dim3((unsigned)batch), dim3(320), lds, st, ka,  \
                        (TY *)Psi_ws, (TY *)res_ws, (TY *)G, (TY *)h, (TY *)rownorm_inv)
     if (dtype == MPCQP_F64) {
-        if (rownorm_inv) PROPAGATE(double, true); else PROPAGATE(double, false);
+        if (rownorm_inv) PROPAGATE(double, true, 0); else PROPAGATE(double, false, 0);
+    } else if (ka.nx == 12) {  // config 5's state dimension at compile time
+        if (rownorm_inv) PROPAGATE(float, true, 12); else PROPAGATE(float, false, 12);
     } else {
-        if (rownorm_inv) PROPAGATE(float, true); else PROPAGATE(float, false);
+        if (rownorm_inv) PROPAGATE(float, true, 0); else PROPAGATE(float, false, 0);
     }
 #undef PROPAGATE
     int rc = (int)hipGetLastError();
