@@ -109,6 +109,9 @@ typedef struct MpcqpProblem {
 #define MPCQP_OPT_FORCE_GWS 2      /* large QPs: general kernel with its arrays in the workspace          */
 #define MPCQP_OPT_FORCE_DENSE_G 4  /* large fused path: form G (and its transpose) instead of applying it */
 #define MPCQP_OPT_ONE_PER_WAVE 8   /* small problems: one problem per wavefront instead of two            */
+#define MPCQP_OPT_FORCE_CONDENSED 16 /* mid-size problems: keep the condensed kernels (mpcqp_build_solve_batch
+                                        otherwise hands 16 < n <= 128, nx <= 4, nu <= 2, float64 to the stage-wise
+                                        kernel, which is faster there and returns the same minimiser)          */
 
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */

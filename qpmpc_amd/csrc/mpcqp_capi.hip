@@ -98,7 +98,18 @@ bool force_gws(int fl) { return fl & MPCQP_OPT_FORCE_GWS; }
 bool force_dense_g(int fl) { return fl & MPCQP_OPT_FORCE_DENSE_G; }
 // every combination of overrides a launch may carry: the workspace queries, which see no opts, report the
 // largest amount any of them needs
-const int kFlagVariants[] = {0, MPCQP_OPT_FORCE_LDS, MPCQP_OPT_FORCE_GWS, MPCQP_OPT_FORCE_DENSE_G};
+const int kFlagVariants[] = {0, MPCQP_OPT_FORCE_LDS, MPCQP_OPT_FORCE_GWS, MPCQP_OPT_FORCE_DENSE_G, MPCQP_OPT_FORCE_CONDENSED};
+
+// Fused build+solve of mid-size problems of small systems goes to the stage-wise kernel (mpcqp_stage.hip): same
+// minimiser (tests), 1.5-1.9x the mid-size condensed kernel on config 3. Its slots hold min(n, m) <= 128 active rows, i.e.
+// every row that can be active at once, so nothing is lost against the condensed kernels.
+bool use_stage_auto(const KernelArgs &ka, int dtype)
+{
+    const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
+                              MPCQP_OPT_ONE_PER_WAVE;
+    return !(ka.opt_flags & override_bits) && !ka.warm_state && stage_supported(ka, dtype) && ka.n > 16 && ka.n <= 128 &&
+           ka.m >= 1;
+}
 
 bool use_bigsolve(int n, int m, int dtype, int fl) { return !force_gws(fl) && m > 0 && bigsolve_supported(n, m, dtype); }
 
@@ -262,6 +273,10 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
         const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
         size_t v = 0;
         if (maybe_mid) v = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;  // N* and M_A rows
+        if (for_solve && use_stage_auto(ka, dims->dtype)) {
+            const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+            if (sw > v) v = sw;
+        }
         if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
             if (big_supported(ka) && ka.n <= 256) {
                 const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
@@ -407,6 +422,12 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (use_stage_auto(ka, dims->dtype)) {
+        const int maxq = stage_default_maxq(ka);
+        const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_stage(ka, maxq, batch, workspace, st);
+    }
     if (use_mid(ka, dims->dtype)) {
         const size_t need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;

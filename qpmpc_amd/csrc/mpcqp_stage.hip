@@ -142,14 +142,35 @@ __global__ void __launch_bounds__(64)
     const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
     const double wu = ka.wu, wx = stageP ? ka.wx : 0.0, wt = termP ? ka.wt : 0.0;
 
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;  // developer probe (MpcqpSolveOpts.probe)
+    auto tick = [&](int slot) {
+        if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
+    };
+    tick(0);
     // ================================================================= factor: Riccati recursion
     // (serial in k and nonlinear: every lane computes it, the operands arrive through scalar loads)
     {
         double P[NX * NX];
 #pragma unroll
         for (int i = 0; i < NX * NX; ++i) P[i] = (i / NX == i % NX) ? wt : 0.0;
+        // operands of step k-1 are requested while step k computes (the recursion is a ~12-stage dependent chain
+        // per step: without this every step also waits for its own loads)
+        double An[NX * NX], Bn[NX * NU];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) An[i] = gA[(N - 1) * sA + i];
+#pragma unroll
+        for (int i = 0; i < NX * NU; ++i) Bn[i] = gB[(N - 1) * sB + i];
         for (int k = N - 1; k >= 0; --k) {
-            const double *A = gA + k * sA, *B = gB + k * sB;
+            double A[NX * NX], B[NX * NU];
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) A[i] = An[i];
+#pragma unroll
+            for (int i = 0; i < NX * NU; ++i) B[i] = Bn[i];
+            const int kn = k > 0 ? k - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) An[i] = gA[kn * sA + i];
+#pragma unroll
+            for (int i = 0; i < NX * NU; ++i) Bn[i] = gB[kn * sB + i];
             double PA[NX * NX], PB[NX * NU];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -241,6 +262,7 @@ __global__ void __launch_bounds__(64)
         }
     }
     wsync();
+    tick(1);
     // chunk transition matrix Phi_j = Acl_{k1-1} ... Acl_{k0} of this lane's chunk (identity if empty)
     double Phi[NX * NX];
 #pragma unroll
@@ -260,6 +282,151 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int i = 0; i < NX * NX; ++i) Phi[i] = T[i];
     }
+
+    // ---- boundary scans in two levels. The 64 chunk boundaries obey x_{j+1} = Phi_j x_j + beta_j (forward) and
+    // p_{j-1} = Phi_j' p_j + gamma_j (backward). The lanes form 8 groups of 8: (a) inside every group the offsets
+    // are chained lane to lane (7 steps, all groups at once), (b) the 8 group inflows are chained through the
+    // groups' total transition matrices (7 steps, readlane), (c) every lane gets its inflow from its group's inflow
+    // and its neighbour's prefix. The prefix products Qf_j = Phi_j ... Phi_{8g}, Qb_j = Phi_j' ... Phi_{8g+7}' depend
+    // on the problem only and stay in registers: 21 dependent small mat-vecs per scan instead of 63, no memory.
+    double Qf[NX * NX], Qb[NX * NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            Qf[i * NX + j] = Phi[i * NX + j];
+            Qb[i * NX + j] = Phi[j * NX + i];
+        }
+#pragma unroll 1
+    for (int sdx = 1; sdx < 8; ++sdx) {
+        double Pf[NX * NX], Pb[NX * NX];
+#pragma unroll
+        for (int e = 0; e < NX * NX; ++e) {
+            Pf[e] = __shfl_up(Qf[e], 1);
+            Pb[e] = __shfl_down(Qb[e], 1);
+        }
+        const bool hf = (lane & 7) == sdx, hb = (lane & 7) == 7 - sdx;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double tf[NX], tb[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double a = 0.0, c = 0.0;
+#pragma unroll
+                for (int q = 0; q < NX; ++q) {
+                    a += Phi[i * NX + q] * Pf[q * NX + j];  // Phi_j Qf_{j-1}
+                    c += Phi[q * NX + i] * Pb[q * NX + j];  // Phi_j' Qb_{j+1}
+                }
+                tf[j] = a;
+                tb[j] = c;
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                Qf[i * NX + j] = hf ? tf[j] : Qf[i * NX + j];
+                Qb[i * NX + j] = hb ? tb[j] : Qb[i * NX + j];
+            }
+        }
+    }
+    // inflow of every chunk for the forward recurrence, from the chunk offsets beta_j (in `off`) and x_s
+    auto inflow_fwd = [&](double (&off)[NX], const double *xs, double (&xin)[NX]) {
+#pragma unroll 1
+        for (int sdx = 1; sdx < 8; ++sdx) {  // (a) off_j <- Phi_j off_{j-1} + beta_j inside the groups
+            double o[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) o[i] = __shfl_up(off[i], 1);
+            const bool h = (lane & 7) == sdx;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = off[i];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a += Phi[i * NX + q] * o[q];
+                off[i] = h ? a : off[i];
+            }
+        }
+        double xg[NX], cur[NX];  // (b) inflow of this lane's group
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xg[i] = cur[i] = xs ? xs[i] : 0.0;
+#pragma unroll 1
+        for (int g = 0; g < 7; ++g) {
+            const int src = 8 * g + 7;
+            double nxt[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = rl(off[i], src);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a += rl(Qf[i * NX + q], src) * cur[q];
+                nxt[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                cur[i] = nxt[i];
+                xg[i] = ((lane >> 3) == g + 1) ? cur[i] : xg[i];
+            }
+        }
+        double xo[NX];  // (c) outflow of this lane's chunk, handed to the next lane
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = off[i];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) a += Qf[i * NX + q] * xg[q];
+            xo[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double up = __shfl_up(xo[i], 1);
+            xin[i] = ((lane & 7) == 0) ? xg[i] : up;
+        }
+    };
+    // the same for the backward recurrence (gamma_j in `off`, terminal costate pN at the top of chunk 63)
+    auto inflow_bwd = [&](double (&off)[NX], const double (&pN)[NX], double (&pin)[NX]) {
+#pragma unroll 1
+        for (int sdx = 1; sdx < 8; ++sdx) {
+            double o[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) o[i] = __shfl_down(off[i], 1);
+            const bool h = (lane & 7) == 7 - sdx;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = off[i];
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a += Phi[q * NX + i] * o[q];
+                off[i] = h ? a : off[i];
+            }
+        }
+        double pg[NX], cur[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) pg[i] = cur[i] = pN[i];
+#pragma unroll 1
+        for (int g = 7; g >= 1; --g) {
+            const int src = 8 * g;
+            double nxt[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = rl(off[i], src);
+#pragma unroll
+                for (int q = 0; q < NX; ++q) a += rl(Qb[i * NX + q], src) * cur[q];
+                nxt[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                cur[i] = nxt[i];
+                pg[i] = ((lane >> 3) == g - 1) ? cur[i] : pg[i];
+            }
+        }
+        double po[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            double a = off[i];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) a += Qb[i * NX + q] * pg[q];
+            po[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const double dn = __shfl_down(po[i], 1);
+            pin[i] = ((lane & 7) == 7) ? pg[i] : dn;
+        }
+    };
 
     // ================================================================= the LQR solve as two chunked scans
     // linear costs: state cost q_k = qs * (row vector qrow) at k == kq plus the dense tracking term when
@@ -300,32 +467,13 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
             for (int i = 0; i < NX; ++i) p[i] = np_[i];
         }
-        // pass 2: inflow at the top of every chunk, chained from the terminal costate downwards
-        double pin[NX], cur[NX];
+        // pass 2: inflow at the top of every chunk (empty chunks are identities)
+        double pin[NX];
+        {
+            double pN[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            cur[i] = (track && termQ) ? -ka.wt * ggoal[i] : 0.0;  // p_N
-            pin[i] = cur[i];
-        }
-        for (int j = nch - 1; j >= 1; --j) {
-            // inflow of chunk j-1 = Phi_j' cur + gamma_j
-            double nxt[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = rl(p[i], j);
-#pragma unroll
-                for (int l = 0; l < NX; ++l) a += rl(Phi[l * NX + i], j) * cur[l];
-                nxt[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                cur[i] = nxt[i];
-                pin[i] = (lane == j - 1) ? cur[i] : pin[i];
-            }
-        }
-        if (lane >= nch) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pin[i] = 0.0;
+            for (int i = 0; i < NX; ++i) pN[i] = (track && termQ) ? -ka.wt * ggoal[i] : 0.0;
+            inflow_bwd(p, pN, pin);
         }
         // pass 3: the chunk again from its true inflow; feed-forward terms written out
 #pragma unroll
@@ -385,27 +533,8 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
             for (int i = 0; i < NX; ++i) y[i] = ny[i];
         }
-        double xin[NX], cur[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            cur[i] = xs ? xs[i] : 0.0;
-            xin[i] = cur[i];
-        }
-        for (int j = 0; j + 1 < nch; ++j) {
-            double nxt[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                double a = rl(y[i], j);
-#pragma unroll
-                for (int l = 0; l < NX; ++l) a += rl(Phi[i * NX + l], j) * cur[l];
-                nxt[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                cur[i] = nxt[i];
-                xin[i] = (lane == j + 1) ? cur[i] : xin[i];
-            }
-        }
+        double xin[NX];
+        inflow_fwd(y, xs, xin);
         double x[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xin[i];
@@ -455,10 +584,13 @@ __global__ void __launch_bounds__(64)
     double zero_row[NX > NU ? NX : NU];
 #pragma unroll
     for (int i = 0; i < (NX > NU ? NX : NU); ++i) zero_row[i] = 0.0;
+    tick(2);
     backward(-1, zero_row, zero_row, true);
     wsync();
+    tick(3);
     forward(gx0, U0, X0);
     wsync();
+    tick(4);
     const double tol = ka.tol;
     for (int k = k0; k < k1; ++k)
         for (int r = 0; r < mk; ++r) {
@@ -475,6 +607,7 @@ __global__ void __launch_bounds__(64)
         }
     wsync();
 
+    tick(5);
     // ================================================================= active-set loop
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
@@ -662,6 +795,7 @@ __global__ void __launch_bounds__(64)
             if (fail) break;
         }
         if (fail) break;
+        tick(6);
         // ================================================================= primal point, verification
         // u = u0 - sum_a lam_a V_a ; slacks from scratch through x = x0 - sum_a lam_a X_a
         bool dirty = false;
@@ -706,6 +840,7 @@ __global__ void __launch_bounds__(64)
         }
         status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
     }
+    tick(7);
     if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
     const bool ok = status == MPCQP_SOLVED;
     if (!ok) {

@@ -795,10 +795,13 @@ def test_mid_size_kernel_random_ltv_families(nx, nu, N, mk, with_c, with_d, wx, 
     assert ok.sum() >= 20
     scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
     assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-7
-    other = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
-    torch.cuda.synchronize()
-    assert np.array_equal(other.status.cpu().numpy(), st)
-    assert (np.abs(other.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-7
+    # the default dispatch hands small systems (nx <= 4, nu <= 2) to the stage-wise kernel; the condensed mid-size
+    # kernel and the all-in-LDS workgroup kernel must give the same plans on the same batch
+    for flag in (_capi.OPT_FORCE_CONDENSED, _capi.OPT_FORCE_LDS):
+        other = solve_mpc_batch(bp, flags=flag)
+        torch.cuda.synchronize()
+        assert np.array_equal(other.status.cpu().numpy(), st), flag
+        assert (np.abs(other.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-7, flag
 
 
 def test_single_problem_fast_path_equals_general_path_and_keeps_plan_semantics():

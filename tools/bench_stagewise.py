@@ -23,16 +23,17 @@ def timeit(fn, reps=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps, out
 
-for B, N, dt in ((4096, 16, 1 / 16), (4096, 64, 1 / 16), (4096, 256, 1 / 32), (4096, 1024, 1 / 64), (512, 4096, 1 / 128)):
-    bp = long_batch(B, N, dt)
-    ts, plan = timeit(lambda: solve_mpc_batch(bp, formulation="stagewise"))
-    st = plan.status.cpu().numpy(); it = plan.iters.float().mean().item()
-    line = f"N={N:5d} batch {B}: stage-wise {ts*1e3:9.2f} ms = {B/ts/1e3:9.1f} k problems/s  (solved {np.mean(st==0):.3f}, mean iters {it:.1f}, max {plan.iters.max().item()})"
-    if N * 1 <= 256:
-        td, pd = timeit(lambda: solve_mpc_batch(bp))
-        err = float(((pd.U - plan.U).abs().max(dim=1).values / pd.U.abs().max(dim=1).values.clamp(min=1.0)).max())
-        line += f" | condensed {td*1e3:8.2f} ms = {B/td/1e3:9.1f} k/s, max rel diff {err:.1e}"
-    print(line, flush=True)
-w = W.triple_integrator_batch(4096); bp = W.to_batch_problem(w)
-ts, plan = timeit(lambda: solve_mpc_batch(bp, formulation="stagewise")); td, pd = timeit(lambda: solve_mpc_batch(bp))
-print(f"config 2 (N=16, 4096): stage-wise {ts*1e3:.3f} ms vs condensed {td*1e3:.3f} ms")
+if __name__ == "__main__":
+    for B, N, dt in ((4096, 16, 1 / 16), (4096, 64, 1 / 16), (4096, 256, 1 / 32), (4096, 1024, 1 / 64), (512, 4096, 1 / 128)):
+        bp = long_batch(B, N, dt)
+        ts, plan = timeit(lambda: solve_mpc_batch(bp, formulation="stagewise"))
+        st = plan.status.cpu().numpy(); it = plan.iters.float().mean().item()
+        line = f"N={N:5d} batch {B}: stage-wise {ts*1e3:9.2f} ms = {B/ts/1e3:9.1f} k problems/s  (solved {np.mean(st==0):.3f}, mean iters {it:.1f}, max {plan.iters.max().item()})"
+        if N * 1 <= 256:
+            td, pd = timeit(lambda: solve_mpc_batch(bp))
+            err = float(((pd.U - plan.U).abs().max(dim=1).values / pd.U.abs().max(dim=1).values.clamp(min=1.0)).max())
+            line += f" | condensed {td*1e3:8.2f} ms = {B/td/1e3:9.1f} k/s, max rel diff {err:.1e}"
+        print(line, flush=True)
+    w = W.triple_integrator_batch(4096); bp = W.to_batch_problem(w)
+    ts, plan = timeit(lambda: solve_mpc_batch(bp, formulation="stagewise")); td, pd = timeit(lambda: solve_mpc_batch(bp))
+    print(f"config 2 (N=16, 4096): stage-wise {ts*1e3:.3f} ms vs condensed {td*1e3:.3f} ms")

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Dev probe: per-phase shader-clock stamps of the stage-wise kernel. usage: probe_stage_phases.py [wip|long] [batch] [N]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from qpmpc_amd import solve_mpc_batch, workloads as W
+kind = sys.argv[1] if len(sys.argv) > 1 else "wip"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+if kind == "wip":
+    bp = W.to_batch_problem(W.wip_batch(batch))
+else:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_stagewise import long_batch  # noqa
+    N = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    bp = long_batch(batch, N, 1.0 / max(16, N // 16))
+buf = torch.zeros(batch * 16, dtype=torch.int64, device="cuda")
+for _ in range(2): plan = solve_mpc_batch(bp, formulation="stagewise", probe=buf)
+torch.cuda.synchronize()
+t = buf.view(batch, 16).cpu().double()
+names = ["riccati", "chunk matrices", "u0 backward", "u0 forward", "slacks", "active set", "verification"]
+print(kind, "batch", batch, "N", bp.nb_timesteps, "mean iters", plan.iters.float().mean().item())
+for i, nme in enumerate(names):
+    d = t[:, i + 1] - t[:, i]
+    print(f"  {nme:16s} mean {d.mean().item():10.0f} cyc   max {d.max().item():10.0f}")
+print(f"  total            mean {(t[:,7]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,7]-t[:,0]).max().item():10.0f}")
