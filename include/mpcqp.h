@@ -272,6 +272,10 @@ int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t 
                             double target_vel, double length, double gravity, int32_t nsub,
                             void *x0, void *goal, void *targets, int64_t batch, void *stream);
 
+/* Bookkeeping of closed loops (the reference's loops count nothing; ours report failures and iterations):
+ * stats[0] += number of problems with status != 0, stats[1] += sum of iters. stats: two int64 in DEVICE memory. */
+int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream);
+
 /* One period of `batch` LIPM walking controllers, fused (examples/lipm_walking_controller.py:304-333):
  * if U is not NULL, apply the first jerk of each plan (U[b*u_stride], zero when status[b] != 0) to
  * the constant-jerk plant for `nsub` exact sub-steps (integrate, :216-236) and advance the footstep

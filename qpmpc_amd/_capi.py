@@ -37,6 +37,7 @@ EXPORTS = (
     "mpcqp_model_bytes",
     "mpcqp_factor_model",
     "mpcqp_solve_model_batch",
+    "mpcqp_accumulate_stats",
     "mpcqp_wip_advance_batch",
     "mpcqp_lipm_advance_batch",
 )
@@ -124,6 +125,8 @@ def load():
     lib.mpcqp_solve_model_batch.restype = C.c_int
     lib.mpcqp_solve_model_batch.argtypes = [C.POINTER(Dims), vp, C.POINTER(Operand), C.POINTER(Operand),
                                             C.POINTER(Operand), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
+    lib.mpcqp_accumulate_stats.restype = C.c_int
+    lib.mpcqp_accumulate_stats.argtypes = [vp, vp, i64, vp, vp]
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]

@@ -63,8 +63,8 @@ class WIPClosedLoop:
         # ramp[k] = k*T*target_vel for k = 0..N (reference position offsets)
         self._ramp = torch.arange(N + 1, device=dev, dtype=dt) * (T * self.target_vel)
         self.mpc_steps = 0
-        self.failed = torch.zeros((), dtype=torch.int64, device=dev)
-        self.iters_total = torch.zeros((), dtype=torch.int64, device=dev)
+        self._stats = torch.zeros((2,), dtype=torch.int64, device=dev)  # [failed, sum of iterations], mpcqp_accumulate_stats
+        self.failed, self.iters_total = self._stats[0], self._stats[1]
 
     def _write_references(self) -> None:
         """target_states / goal_state of every loop, in place (so the bound pointers stay valid)."""
@@ -103,8 +103,8 @@ class WIPClosedLoop:
                 pend.length, pend.GRAVITY, NB_SUBSTEPS, p.initial_state.data_ptr(), p.goal_state.data_ptr(),
                 p.target_states.data_ptr(), p.batch_size, _stream_ptr())
             _capi.check(rc, "mpcqp_wip_advance_batch")
-            self.failed += (self.solver.status != 0).sum()
-            self.iters_total += self.solver.iters.sum()
+            lib.mpcqp_accumulate_stats(self.solver.status.data_ptr(), self.solver.iters.data_ptr(), p.batch_size,
+                                       self._stats.data_ptr(), _stream_ptr())
             self.mpc_steps += 1
         return self.states
 
@@ -188,8 +188,8 @@ class LIPMWalkingLoop:
         self._k = torch.arange(N, device=dev)
         self._problem_written = False  # e / goal / x0 of the CURRENT phase are in the problem buffers
         self.mpc_steps = 0
-        self.failed = torch.zeros((), dtype=torch.int64, device=dev)
-        self.iters_total = torch.zeros((), dtype=torch.int64, device=dev)
+        self._stats = torch.zeros((2,), dtype=torch.int64, device=dev)  # [failed, sum of iterations], mpcqp_accumulate_stats
+        self.failed, self.iters_total = self._stats[0], self._stats[1]
 
     # -- PhaseStepper.get_nb_steps (:134-165), vectorised over the batch ---------------------------
     def _segment_counts(self):
@@ -285,7 +285,6 @@ class LIPMWalkingLoop:
                     self.solver.set_warm_start(True)  # from the second period on
                 self._advance_fused(first=False)
                 self._problem_written = True
-                self.failed += (self.solver.status != 0).sum()
             else:
                 self._problem_written = False
                 self._write_goal_and_constraints()
@@ -296,8 +295,8 @@ class LIPMWalkingLoop:
                 jerk = torch.where(ok, self.solver.U[:, 0], torch.zeros_like(self.solver.U[:, 0]))
                 self._integrate(jerk)
                 self._advance_phase()
-                self.failed += (~ok).sum()
-            self.iters_total += self.solver.iters.sum()
+            _capi.load().mpcqp_accumulate_stats(self.solver.status.data_ptr(), self.solver.iters.data_ptr(),
+                                                self.problem.batch_size, self._stats.data_ptr(), _stream_ptr())
             self.mpc_steps += 1
         return self.states
 

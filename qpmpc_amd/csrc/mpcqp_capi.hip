@@ -587,6 +587,13 @@ int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t 
                               nsub, x0, goal, targets, batch, (hipStream_t)stream);
 }
 
+int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream)
+{
+    if (!status || !iters || !stats || batch < 0) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    return launch_stats(status, iters, batch, stats, (hipStream_t)stream);
+}
+
 int mpcqp_lipm_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
                              int32_t N, double sampling_period, int32_t nsub, int32_t nb_dsp, int32_t nb_ssp,
                              double max_zmp_dist, int64_t *index, int64_t *stride_index, void *support,

@@ -172,6 +172,35 @@ int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride,
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- loop statistics
+// stats[0] += #(status != 0), stats[1] += sum(iters): one launch instead of the half-dozen tiny tensor kernels the
+// closed loops used per period for the same bookkeeping.
+__global__ void __launch_bounds__(256) mpcqp_stats_kernel(const int32_t *__restrict__ status, const int32_t *__restrict__ iters,
+                                                          int64_t batch, unsigned long long *__restrict__ stats)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long f = 0, it = 0;
+    if (i < batch) {
+        f = status[i] != 0;
+        it = (unsigned long long)iters[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        f += __shfl_xor(f, o);
+        it += __shfl_xor(it, o);
+    }
+    if ((threadIdx.x & 63) == 0 && (f | it)) {
+        if (f) atomicAdd(stats, f);
+        if (it) atomicAdd(stats + 1, it);
+    }
+}
+
+int launch_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, hipStream_t st)
+{
+    hipLaunchKernelGGL(mpcqp_stats_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, status, iters, batch,
+                       (unsigned long long *)stats);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- LIPM walking loop, one period
 // examples/lipm_walking_controller.py:304-333 for `batch` walkers, one thread each: integrate the first
 // jerk of the plan exactly for nsub sub-steps (:216-236), advance the footstep phase (:125-132, :329-332),
