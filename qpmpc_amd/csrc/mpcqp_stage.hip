@@ -108,7 +108,7 @@ __device__ __forceinline__ void wsync()
 using namespace stage;
 
 template <int NX, int NU>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)
     mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
@@ -245,20 +245,17 @@ __global__ void __launch_bounds__(64)
             }
             // P_k = Q_k + A' P_{k+1} Acl, symmetrised (x_0 is data: Q_0 = 0)
             const double qk = (k >= 1) ? wx : 0.0;
-            double Pn[NX * NX];
+            // (A' P Acl is symmetric: the upper triangle is computed and mirrored)
 #pragma unroll
             for (int i = 0; i < NX; ++i)
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
+                for (int j = i; j < NX; ++j) {
                     double a = (i == j) ? qk : 0.0;
 #pragma unroll
                     for (int l = 0; l < NX; ++l) a += PA[l * NX + i] * Ac[l * NX + j];  // (P A)' Acl = A' P Acl
-                    Pn[i * NX + j] = a;
+                    P[i * NX + j] = a;
+                    P[j * NX + i] = a;
                 }
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-#pragma unroll
-                for (int j = 0; j < NX; ++j) P[i * NX + j] = 0.5 * (Pn[i * NX + j] + Pn[j * NX + i]);
         }
     }
     wsync();
