@@ -571,8 +571,8 @@ class SharedModel:
         return PreparedModelSolve(self, problem, return_multipliers, max_iter, feas_tol, **opt_kw)
 
     def solve(self, x0, goal=None, targets=None, return_multipliers: bool = False,
-              max_iter: Optional[int] = None, feas_tol: Optional[float] = None) -> BatchPlan:
-        run = self.prepare(self.problem_for(x0, goal, targets), return_multipliers, max_iter, feas_tol)
+              max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw) -> BatchPlan:
+        run = self.prepare(self.problem_for(x0, goal, targets), return_multipliers, max_iter, feas_tol, **opt_kw)
         run.launch()
         return run.plan
 

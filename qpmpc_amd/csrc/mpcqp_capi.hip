@@ -552,6 +552,8 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const Mpcq
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (!force_lds(ka.opt_flags) && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE_MODEL, dims->dtype))
+        return launch_pair_model(ka, batch, st);
     if (!force_lds(ka.opt_flags) && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
     Layout L;
     if ((rc = layout_for(ka, false, false, MODE_SOLVE, dims->dtype, L))) return rc;

@@ -159,6 +159,7 @@ int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStr
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
 constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids
 int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st);
+int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st);  // shared model (ka.model)
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

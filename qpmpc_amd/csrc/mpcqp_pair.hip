@@ -164,7 +164,9 @@ using namespace pair;
 
 // MK > 0: compile-time number of inequality rows per step for the register-pipelined
 // chain (terminal cost only, state constraints only); MK == 0: generic chain.
-template <int NX, int MK>
+// MODEL: the problems share a factored model (mpcqp_factor_model: M, L^-T and the linear maps from the states to
+// h and L^-1 q, gA = the model); build, factorisation and forward substitution are skipped (mpc_qp.py:129-163 usage).
+template <int NX, int MK, bool MODEL = false>
 __global__ void __launch_bounds__(64, 2)
     mpcqp_pair_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ gD, const double *__restrict__ ge, const double *__restrict__ gx0,
@@ -202,7 +204,7 @@ __global__ void __launch_bounds__(64, 2)
 
     T Pr[NV];  // lane a < 16: row a of P, then of L
     // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
-    {
+    if constexpr (!MODEL) {
         constexpr int nx = NX;
         const int nu = ka.nu, N = ka.N, mk = ka.mk;
         const T *A = gA + prob * ka.A.batch_stride;
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(64, 2)
     // date and written FIRST in step j, so its round trip overlaps the rest of step j's updates.
     bool notpd = false;
     T myinv = T(1);  // lane j keeps 1 / L_jj
-    {
+    if constexpr (!MODEL) {
         T *cb = Ll + NV * LDM;  // two buffers of NV + 2 (shadow entry for lanes >= 16)
         const int cw = low ? hl : NV;
         cb[cw] = Pr[0];
@@ -508,7 +510,43 @@ __global__ void __launch_bounds__(64, 2)
     }
     // ------------------------------------------------------------ rows, forward substitution
     T RM[NV], RT[NV];
-    {
+    if constexpr (MODEL) {
+        // rows of M and of L^-T straight from the model (4 KB, read by every wavefront of the launch: L1/L2),
+        // h = e - Hx x0 and w = L^-1 q = Wx x0 - Wg goal - Wt targets from the model's linear maps
+        const T *model = gA;
+        const ModelLayout ml = make_model_layout(ka.nx, ka.N, n, m);
+        const int nxr = ka.nx, nT = ka.N * ka.nx;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = gtgt ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        notpd = model[ml.total] != T(0);
+        {
+            T rm[NV], rt[NV];
+            ld16(rm, model + ml.off_M + (size_t)(isc ? hl : 0) * NV);
+            ld16(rt, model + ml.off_LinvT + (size_t)(low ? 0 : hl - NV) * NV);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                RM[k] = isc ? rm[k] : T(0);
+                RT[k] = low ? T(0) : rt[k];
+            }
+        }
+        T hh = INF;
+        if (isc) {
+            hh = model[ml.off_e + hl];
+            for (int c = 0; c < nxr; ++c) hh -= model[ml.off_Hx + (size_t)hl * nxr + c] * x0[c];
+        }
+        hv[hl] = hh;
+        if (low) {
+            T wk = T(0);
+            for (int c = 0; c < nxr; ++c) wk += model[ml.off_Wx + (size_t)hl * nxr + c] * x0[c];
+            if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
+                for (int c = 0; c < nxr; ++c) wk -= model[ml.off_Wg + (size_t)hl * nxr + c] * goal[c];
+            if ((ka.flags & MPCQP_Q_STAGE) && tgt)
+                for (int j2 = 0; j2 < nT; ++j2) wk -= model[ml.off_Wt + (size_t)hl * nT + j2] * tgt[j2];
+            y0v[hl] = wk;
+        }
+        wsync();
+    } else {
         // Rows fetched only now: constraint lanes their row of G; lane 0 takes q in RT, lanes 16..31
         // the identity (-> rows of L^-T), the other slot lanes zero.
 #pragma unroll
@@ -556,7 +594,7 @@ __global__ void __launch_bounds__(64, 2)
     bool finished = notpd;  // ... and needs no refinement any more (failed, or accepted)
     if (notpd) status = MPCQP_NOT_PD;
 
-    if (hl == 0) st16(y0v, RT);        // w = L^-1 q ; y0 = -w
+    if (!MODEL && hl == 0) st16(y0v, RT);  // w = L^-1 q ; y0 = -w
     if (isc) st16(Ml + hl * LDM, RM);  // image of M for the row-p broadcasts
     for (int i = hl; i < (NV + 1) * NV; i += HL) MAl[i] = T(0);
     if (low) {
@@ -1072,9 +1110,9 @@ static Lay make_lay(const KernelArgs &ka)
 
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype)
 {
-    if (dtype != MPCQP_F64 || mode != MODE_FUSED) return false;
+    if (dtype != MPCQP_F64 || (mode != MODE_FUSED && mode != MODE_MODEL)) return false;
     if (ka.n > NV || ka.m > MMAX || ka.m < 1) return false;
-    if (ka.nx != 3 && ka.nx != 4) return false;
+    if (mode == MODE_FUSED && ka.nx != 3 && ka.nx != 4) return false;
     const Lay L = make_lay(ka);
     return (size_t)L.per * 2 * sizeof(double) <= 64 * 1024;
 }
@@ -1089,6 +1127,18 @@ template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t
                        (const double *)ka.e.ptr, (const double *)ka.x0.ptr, (const double *)ka.goal.ptr,
                        (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L,
                        batch);
+    return (int)hipGetLastError();
+}
+
+int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    const Lay L = make_lay(ka);
+    const size_t bytes = (size_t)L.per * 2 * sizeof(double);
+    const unsigned grid = (unsigned)((batch + 1) / 2);
+    hipLaunchKernelGGL((mpcqp_pair_kernel<3, 0, true>), dim3(grid), dim3(64), bytes, st, (const double *)ka.model,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                       (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
+                       (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
     return (int)hipGetLastError();
 }
 

@@ -563,6 +563,14 @@ def test_shared_model_equals_fused_path(family):
     okc = sto == 0
     scale = np.maximum(1.0, np.abs(Uo[okc]).max(axis=1, keepdims=True))
     assert (np.abs(got.U.cpu().numpy()[:64][okc] - Uo[okc]) / scale).max() <= 1e-6
+    # small problems: the model is solved two problems per wavefront by default; one per wavefront must agree
+    from qpmpc_amd import _capi
+
+    one = model.solve(bp.initial_state, bp.goal_state, bp.target_states, return_multipliers=True, flags=_capi.OPT_ONE_PER_WAVE)
+    torch.cuda.synchronize()
+    assert np.array_equal(one.status.cpu().numpy(), sg)
+    assert np.abs(one.U.cpu().numpy()[ok] - Ug).max() <= 1e-9 * max(1.0, np.abs(Ug).max())
+    assert np.abs(one.multipliers.cpu().numpy()[ok] - got.multipliers.cpu().numpy()[ok]).max() <= 1e-6 * max(1.0, float(got.multipliers.abs().max()))
 
 
 def test_closed_loop_with_shared_model_matches_rebuild_every_step():

@@ -11,7 +11,8 @@ if kind == "wip":  # config 3 through the mid-size kind of the same kernel (f64)
 else:
     w = W.synthetic_ltv_batch(batch); bp = W.to_batch_problem(w, dtype=torch.float32)
 buf = torch.zeros(batch * 32, dtype=torch.int64, device="cuda")
-run = PreparedSolve(bp, probe=buf)
+from qpmpc_amd import _capi
+run = PreparedSolve(bp, probe=buf, flags=_capi.OPT_FORCE_CONDENSED)  # the condensed kernels (config 3 would otherwise take the stage-wise one)
 for _ in range(2): run.launch()
 torch.cuda.synchronize()
 full = buf.view(batch, 32).cpu().double()
