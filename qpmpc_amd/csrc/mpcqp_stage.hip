@@ -54,19 +54,27 @@ __host__ __device__ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
         o += (cnt + 1) & ~(int64_t)1;
         return at;
     };
-    const int64_t m = (int64_t)N * mk;
-    w.Acl = take((int64_t)N * nx * nx);
-    w.Kg = take((int64_t)N * nu * nx);
-    w.Sinv = take((int64_t)N * nu * nu);
-    w.ff = take((int64_t)N * nu);
-    w.U0 = take((int64_t)N * nu);
-    w.X0 = take((int64_t)N * nx);
+    // per-step arrays are stored TRANSPOSED by chunk: step k = lane L + kk lives at index kk 64 + lane, so that the 64
+    // lanes of a wavefront, each walking its own chunk, touch 64 consecutive entries per instruction (coalesced)
+    // instead of 64 cache lines; they are sized for the padded horizon NP = 64 ceil(N / 64)
+    const int64_t NP = 64 * (int64_t)((N + 63) / 64);
+    const int64_t m = NP * mk;
+    w.Acl = take(NP * nx * nx);
+    w.Kg = take(NP * nu * nx);
+    w.Sinv = take(NP * nu * nu);
+    w.ff = take(NP * nu);
+    w.U0 = take(NP * nu);
+    w.X0 = take(NP * nx);
     w.s = take(m);
     w.invn = take(m);
     w.rowslot = take((m + 1) / 2);  // int32 per row
-    w.V = take((int64_t)(maxq + 1) * N * nu);   // slot maxq: the candidate row of the current iteration
-    w.XV = take((int64_t)(maxq + 1) * N * nx);
+    w.V = take((int64_t)(maxq + 1) * NP * nu);   // slot maxq: the candidate row of the current iteration
+    w.XV = take((int64_t)(maxq + 1) * NP * nx);
     w.W = take((int64_t)maxq * maxq);
+    // the problems of a launch walk their workspaces in lock step: a stride that is a large power of two would put
+    // all of them on the same memory channels. Odd multiple of 512 B.
+    o = (o + 63) & ~(int64_t)63;
+    if (((o >> 6) & 1) == 0) o += 64;
     w.total = o;
     w.maxq = maxq;
     return w;
@@ -119,6 +127,12 @@ __global__ void __launch_bounds__(64, 2)
     const int k0 = lane * L < N ? lane * L : N;     // this lane's chunk [k0, k1)
     const int k1 = (k0 + L < N) ? k0 + L : N;
     const int nch = (N + L - 1) / L;                // chunks that hold steps
+    const int64_t NP = 64 * (int64_t)L;             // padded horizon (slot stride of the per-step arrays)
+    auto wq = [&](int k) { return (int64_t)(k - k0) * 64 + lane; };  // workspace index of a step of THIS lane's chunk
+    auto wg = [&](int k) {                                             // ... of any step
+        const int j = k / L;
+        return (int64_t)(k - j * L) * 64 + j;
+    };
     const double INF = HUGE_VAL;
     // ---- LDS: vectors shared by the lanes
     double *cv = (double *)stage_smem, *rv = cv + maxq, *lamv = rv + maxq;
@@ -236,12 +250,13 @@ __global__ void __launch_bounds__(64, 2)
                     Ac[i * NX + j] = a;
                 }
             if (lane == 0) {
+                const int64_t w = wg(k);
 #pragma unroll
-                for (int i = 0; i < NX * NX; ++i) Acl[(int64_t)k * NX * NX + i] = Ac[i];
+                for (int i = 0; i < NX * NX; ++i) Acl[w * NX * NX + i] = Ac[i];
 #pragma unroll
-                for (int i = 0; i < NU * NX; ++i) Kg[(int64_t)k * NU * NX + i] = Kk[i];
+                for (int i = 0; i < NU * NX; ++i) Kg[w * NU * NX + i] = Kk[i];
 #pragma unroll
-                for (int i = 0; i < NU * NU; ++i) Sinv[(int64_t)k * NU * NU + i] = Si[i];
+                for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
             }
             // P_k = Q_k + A' P_{k+1} Acl, symmetrised (x_0 is data: Q_0 = 0)
             const double qk = (k >= 1) ? wx : 0.0;
@@ -265,7 +280,7 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) Phi[i] = (i / NX == i % NX) ? 1.0 : 0.0;
     for (int k = k0; k < k1; ++k) {
-        const double *Ac = Acl + (int64_t)k * NX * NX;
+        const double *Ac = Acl + wq(k) * NX * NX;
         double T[NX * NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i)
@@ -447,7 +462,7 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int i = 0; i < NX; ++i) p[i] = 0.0;
         for (int k = k1 - 1; k >= k0; --k) {
-            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX;
+            const double *Ac = Acl + wq(k) * NX * NX, *Kk = Kg + wq(k) * NU * NX;
             double q[NX], np_[NX];
             lin_q(k, kq, qrow, track, q);
 #pragma unroll
@@ -476,7 +491,7 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int i = 0; i < NX; ++i) p[i] = pin[i];
         for (int k = k1 - 1; k >= k0; --k) {
-            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX, *Si = Sinv + (int64_t)k * NU * NU;
+            const double *Ac = Acl + wq(k) * NX * NX, *Kk = Kg + wq(k) * NU * NX, *Si = Sinv + wq(k) * NU * NU;
             const double *B = gB + k * sB;
             double t[NU];
 #pragma unroll
@@ -491,7 +506,7 @@ __global__ void __launch_bounds__(64, 2)
                 double a = 0.0;
 #pragma unroll
                 for (int l = 0; l < NU; ++l) a -= Si[i * NU + l] * t[l];
-                ffv[(int64_t)k * NU + i] = a;
+                ffv[wq(k) * NU + i] = a;
             }
             double q[NX], np_[NX];
             lin_q(k, kq, qrow, track, q);
@@ -516,7 +531,7 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int i = 0; i < NX; ++i) y[i] = 0.0;
         for (int k = k0; k < k1; ++k) {
-            const double *Ac = Acl + (int64_t)k * NX * NX, *B = gB + k * sB, *f = ffv + (int64_t)k * NU;
+            const double *Ac = Acl + wq(k) * NX * NX, *B = gB + k * sB, *f = ffv + wq(k) * NU;
             double ny[NX];
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
@@ -536,16 +551,16 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xin[i];
         for (int k = k0; k < k1; ++k) {
-            const double *Ac = Acl + (int64_t)k * NX * NX, *Kk = Kg + (int64_t)k * NU * NX, *B = gB + k * sB;
-            const double *f = ffv + (int64_t)k * NU;
+            const double *Ac = Acl + wq(k) * NX * NX, *Kk = Kg + wq(k) * NU * NX, *B = gB + k * sB;
+            const double *f = ffv + wq(k) * NU;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) Xo[(int64_t)k * NX + i] = x[i];
+            for (int i = 0; i < NX; ++i) Xo[wq(k) * NX + i] = x[i];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 double a = f[i];
 #pragma unroll
                 for (int l = 0; l < NX; ++l) a -= Kk[i * NX + l] * x[l];
-                Uo[(int64_t)k * NU + i] = a;
+                Uo[wq(k) * NU + i] = a;
             }
             double nx_[NX];
 #pragma unroll
@@ -562,17 +577,17 @@ __global__ void __launch_bounds__(64, 2)
         }
     };
     // g_(k,r) . (U, X) = C_k[r] x_k + D_k[r] u_k
-    auto gdot = [&](int k, int r, const double *Uv, const double *Xv) {
+    auto gdot = [&](int k, int64_t w, int r, const double *Uv, const double *Xv) {  // w = workspace index of step k
         double a = 0.0;
         if (gC) {
             const double *c = gC + k * sC + r * NX;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) a += c[i] * Xv[(int64_t)k * NX + i];
+            for (int i = 0; i < NX; ++i) a += c[i] * Xv[w * NX + i];
         }
         if (gD) {
             const double *d = gD + k * sD + r * NU;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) a += d[i] * Uv[(int64_t)k * NU + i];
+            for (int i = 0; i < NU; ++i) a += d[i] * Uv[w * NU + i];
         }
         return a;
     };
@@ -591,9 +606,9 @@ __global__ void __launch_bounds__(64, 2)
     const double tol = ka.tol;
     for (int k = k0; k < k1; ++k)
         for (int r = 0; r < mk; ++r) {
-            const int64_t i = (int64_t)k * mk + r;
+            const int64_t i = wq(k) * mk + r;
             const double ev = ge[k * sE + r];
-            sl[i] = ev - gdot(k, r, U0, X0);
+            sl[i] = ev - gdot(k, wq(k), r, U0, X0);
             double nn = 0.0;
             if (gC)
                 for (int c = 0; c < NX; ++c) nn += gC[k * sC + r * NX + c] * gC[k * sC + r * NX + c];
@@ -609,7 +624,7 @@ __global__ void __launch_bounds__(64, 2)
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
     const int nvar = N * NU;
-    double *Vp = Vs + (int64_t)maxq * N * NU, *Xp = XVs + (int64_t)maxq * N * NX;  // the candidate's slot
+    double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
     bool fail = false;
     for (int round = 0; round < 4 && !fail; ++round) {
         for (;;) {
@@ -618,13 +633,13 @@ __global__ void __launch_bounds__(64, 2)
             int bi = 0x7fffffff;
             for (int k = k0; k < k1; ++k)
                 for (int r = 0; r < mk; ++r) {
-                    const int64_t i = (int64_t)k * mk + r;
+                    const int64_t i = wq(k) * mk + r;
                     const double ev = ge[k * sE + r], sv = sl[i];
                     const bool viol = ev < 1e29 && rowslot[i] < 0 && sv < -(tol + tol * fabs(ev));
                     const double sc = sv * invn[i];
                     if (viol && sc < best) {
                         best = sc;
-                        bi = (int)i;
+                        bi = k * mk + r;  // natural row id: ties go to the lowest one, like the restatement
                     }
                 }
             wave_argmin(best, bi);
@@ -633,6 +648,7 @@ __global__ void __launch_bounds__(64, 2)
                 break;
             }
             const int kp = bi / mk, rp = bi - kp * mk;
+            const int64_t wp = wg(kp), bw = wp * mk + rp;  // workspace index of step kp / of row p
             double qrow[NX], rrow[NU];
 #pragma unroll
             for (int i = 0; i < NX; ++i) qrow[i] = gC ? gC[kp * sC + rp * NX + i] : 0.0;
@@ -645,7 +661,7 @@ __global__ void __launch_bounds__(64, 2)
             wsync();
             forward(nullptr, Vp, Xp);
             wsync();
-            const double dpp = gdot(kp, rp, Vp, Xp);
+            const double dpp = gdot(kp, wp, rp, Vp, Xp);
             while (!added) {
                 if (iters >= max_iter || nq >= maxq) {
                     fail = true;
@@ -653,7 +669,7 @@ __global__ void __launch_bounds__(64, 2)
                 }
                 ++iters;
                 // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], actr[a], Vp, Xp);
+                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], wg(actk[a]), actr[a], Vp, Xp);
                 wsync();
                 double cr = 0.0;
                 for (int a = lane; a < nq; a += 64) {
@@ -680,7 +696,7 @@ __global__ void __launch_bounds__(64, 2)
                     }
                 }
                 wave_argmin(t1, l);
-                const double sp = sl[bi];
+                const double sp = sl[bw];
                 const double t2 = can_move ? -sp / d2 : INF;
                 const double t = t1 < t2 ? t1 : t2;
                 if (!(t < INF)) {
@@ -693,12 +709,12 @@ __global__ void __launch_bounds__(64, 2)
                 for (int k = k0; k < k1; ++k) {
                     double zu[NU], zx[NX];
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) zu[i] = -Vp[(int64_t)k * NU + i];
+                    for (int i = 0; i < NU; ++i) zu[i] = -Vp[wq(k) * NU + i];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) zx[i] = -Xp[(int64_t)k * NX + i];
+                    for (int i = 0; i < NX; ++i) zx[i] = -Xp[wq(k) * NX + i];
                     for (int a = 0; a < nq; ++a) {
                         const double ra = rv[a];
-                        const double *va = Vs + ((int64_t)a * N + k) * NU, *xa = XVs + ((int64_t)a * N + k) * NX;
+                        const double *va = Vs + ((int64_t)a * NP + wq(k)) * NU, *xa = XVs + ((int64_t)a * NP + wq(k)) * NX;
 #pragma unroll
                         for (int i = 0; i < NU; ++i) zu[i] += ra * va[i];
 #pragma unroll
@@ -712,7 +728,7 @@ __global__ void __launch_bounds__(64, 2)
                         if (gD)
 #pragma unroll
                             for (int i = 0; i < NU; ++i) gz += gD[k * sD + r * NU + i] * zu[i];
-                        const int64_t i = (int64_t)k * mk + r;
+                        const int64_t i = wq(k) * mk + r;
                         sl[i] = (rowslot[i] >= 0) ? 0.0 : sl[i] - t * gz;
                     }
                 }
@@ -737,15 +753,15 @@ __global__ void __launch_bounds__(64, 2)
                         lamv[nq] = up;
                         actk[nq] = kp;
                         actr[nq] = rp;
-                        rowslot[bi] = nq;
-                        sl[bi] = 0.0;
+                        rowslot[bw] = nq;
+                        sl[bw] = 0.0;
                     }
-                    double *vd = Vs + (int64_t)nq * N * NU, *xd = XVs + (int64_t)nq * N * NX;
+                    double *vd = Vs + (int64_t)nq * NP * NU, *xd = XVs + (int64_t)nq * NP * NX;
                     for (int k = k0; k < k1; ++k) {
 #pragma unroll
-                        for (int i = 0; i < NU; ++i) vd[(int64_t)k * NU + i] = Vp[(int64_t)k * NU + i];
+                        for (int i = 0; i < NU; ++i) vd[wq(k) * NU + i] = Vp[wq(k) * NU + i];
 #pragma unroll
-                        for (int i = 0; i < NX; ++i) xd[(int64_t)k * NX + i] = Xp[(int64_t)k * NX + i];
+                        for (int i = 0; i < NX; ++i) xd[wq(k) * NX + i] = Xp[wq(k) * NX + i];
                     }
                     ++nq;
                     added = true;
@@ -761,19 +777,19 @@ __global__ void __launch_bounds__(64, 2)
                     }
                     wsync();
                     const int last = nq - 1;
-                    const int drow = actk[l] * mk + actr[l];
+                    const int64_t drow = wg(actk[l]) * mk + actr[l];
                     if (l != last) {
                         for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
                         wsync();
                         for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
                         wsync();
-                        const double *vs = Vs + (int64_t)last * N * NU, *xs = XVs + (int64_t)last * N * NX;
-                        double *vd = Vs + (int64_t)l * N * NU, *xd = XVs + (int64_t)l * N * NX;
+                        const double *vs = Vs + (int64_t)last * NP * NU, *xs = XVs + (int64_t)last * NP * NX;
+                        double *vd = Vs + (int64_t)l * NP * NU, *xd = XVs + (int64_t)l * NP * NX;
                         for (int k = k0; k < k1; ++k) {
 #pragma unroll
-                            for (int i = 0; i < NU; ++i) vd[(int64_t)k * NU + i] = vs[(int64_t)k * NU + i];
+                            for (int i = 0; i < NU; ++i) vd[wq(k) * NU + i] = vs[wq(k) * NU + i];
 #pragma unroll
-                            for (int i = 0; i < NX; ++i) xd[(int64_t)k * NX + i] = xs[(int64_t)k * NX + i];
+                            for (int i = 0; i < NX; ++i) xd[wq(k) * NX + i] = xs[wq(k) * NX + i];
                         }
                     }
                     if (lane == 0) {
@@ -782,7 +798,7 @@ __global__ void __launch_bounds__(64, 2)
                             lamv[l] = lamv[last];
                             actk[l] = actk[last];
                             actr[l] = actr[last];
-                            rowslot[actk[last] * mk + actr[last]] = l;
+                            rowslot[wg(actk[last]) * mk + actr[last]] = l;
                         }
                     }
                     --nq;
@@ -799,12 +815,12 @@ __global__ void __launch_bounds__(64, 2)
         for (int k = k0; k < k1; ++k) {
             double u[NU], x[NX];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) u[i] = U0[(int64_t)k * NU + i];
+            for (int i = 0; i < NU; ++i) u[i] = U0[wq(k) * NU + i];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X0[(int64_t)k * NX + i];
+            for (int i = 0; i < NX; ++i) x[i] = X0[wq(k) * NX + i];
             for (int a = 0; a < nq; ++a) {
                 const double la = lamv[a];
-                const double *va = Vs + ((int64_t)a * N + k) * NU, *xa = XVs + ((int64_t)a * N + k) * NX;
+                const double *va = Vs + ((int64_t)a * NP + wq(k)) * NU, *xa = XVs + ((int64_t)a * NP + wq(k)) * NX;
 #pragma unroll
                 for (int i = 0; i < NU; ++i) u[i] -= la * va[i];
 #pragma unroll
@@ -814,7 +830,7 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
             for (int i = 0; i < NU; ++i) ou[i] = u[i];
             for (int r = 0; r < mk; ++r) {
-                const int64_t i = (int64_t)k * mk + r;
+                const int64_t i = wq(k) * mk + r;
                 const double ev = ge[k * sE + r];
                 double g = 0.0;
                 if (gC)
@@ -850,9 +866,8 @@ __global__ void __launch_bounds__(64, 2)
         double *ol = (double *)ka.lam + prob * (int64_t)N * mk;
         for (int k = k0; k < k1; ++k)
             for (int r = 0; r < mk; ++r) {
-                const int64_t i = (int64_t)k * mk + r;
-                const int sidx = rowslot[i];
-                ol[i] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
+                const int sidx = rowslot[wq(k) * mk + r];
+                ol[(int64_t)k * mk + r] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
             }
     }
     if (lane == 0) {
