@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 _UNITS = ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_pair.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip",
-          "mpcqp_model.hip", "mpcqp_stage.hip", "mpcqp_capi.hip")
+          "mpcqp_model.hip", "mpcqp_stage.hip", "mpcqp_stagew.hip", "mpcqp_capi.hip")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in _UNITS]
 HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h"), os.path.join(_PKG, "csrc", "mpcqp_internal.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libmpcqp_hip.so")

@@ -29,6 +29,10 @@ namespace mpcqp {
 namespace bigs {
 constexpr int BS = 256;
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+// Per-problem stride of the solver's workspace rows (M_A and N*, n x n each). The problems of a launch walk their
+// slices in lock step: 2 n^2 elements is a power of two for n = 256 and would put every problem on the same memory
+// channels (measured on the stage-wise kernel: 8x). 160 extra elements break the alignment.
+__host__ __device__ inline int64_t ws_stride_elems(int n) { return (int64_t)2 * n * n + 160; }
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v)
 {
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
         }
         return acc;
     };
-    T *MA = wsall + prob * (int64_t)2 * n * n;
+    T *MA = wsall + prob * ws_stride_elems(n);
     T *Tm = MA + (int64_t)n * n;
     T *oU = (T *)ka.U + prob * (int64_t)n;
     const T tol = (T)ka.tol;
@@ -1547,7 +1551,7 @@ bool bigsolve_struct_supported(const KernelArgs &ka, int dtype)
            ka.n >= 64 && ka.n <= bigs::BS && (ka.n % 2 == 0) &&
            bigsolve_lds_bytes(ka.n, ka.m, esz, ka.N * ka.nx) <= kLdsBytesPerCU;
 }
-size_t bigsolve_ws_elems(int n) { return (size_t)2 * n * n; }
+size_t bigsolve_ws_elems(int n) { return (size_t)ws_stride_elems(n); }
 
 // extra LDS elements of the mid-size kind: roll-out table, operands, two Psi_k buffers, front-end vectors
 static size_t mid_extra_elems(const KernelArgs &ka)

@@ -474,9 +474,13 @@ int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_
     if (!bytes || batch < 0) return MPCQP_EINVAL;
     KernelArgs ka;
     fill_args(ka, dims, nullptr);
-    if (!stage_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
     const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
-    *bytes = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    if (stage_supported(ka, dims->dtype))
+        *bytes = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    else if (stagew_supported(ka, dims->dtype))
+        *bytes = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+    else
+        return MPCQP_EUNSUPPORTED;
     return 0;
 }
 
@@ -491,7 +495,8 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     if (batch == 0) return 0;
     KernelArgs ka;
     fill_args(ka, dims, problem);
-    if (!stage_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    const bool narrow = stage_supported(ka, dims->dtype);
+    if (!narrow && !stagew_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
     ka.U = U;
     ka.lam = lam;
     ka.status = status;
@@ -499,9 +504,11 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
-    const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    const size_t need = narrow ? stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch
+                               : stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
     if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
-    return launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream);
+    if (narrow) return launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream);
+    return launch_stagew(ka, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
 }
 
 int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes)

@@ -155,6 +155,10 @@ bool stage_supported(const KernelArgs &ka, int dtype);
 int stage_default_maxq(const KernelArgs &ka);
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq);
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st);
+// ... for wider systems (mpcqp_stagew.hip): nx <= 16, nu <= 4, f64 and f32; workspace in elements of the dtype
+bool stagew_supported(const KernelArgs &ka, int dtype);
+size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype);
+int launch_stagew(const KernelArgs &ka, int dtype, int maxq, int64_t batch, void *ws, hipStream_t st);
 // small-problem kernel (mpcqp_pair.hip): two problems per wavefront, fused build+solve
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
 constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids

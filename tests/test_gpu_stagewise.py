@@ -107,6 +107,79 @@ def test_stagewise_refuses_unsupported_dimensions():
     from qpmpc_amd import BackendError, solve_mpc_batch
     from qpmpc_amd import workloads as W
 
-    bp = W.to_batch_problem(W.synthetic_ltv_batch(2, N=8))  # nx = 12
+    w = W.synthetic_ltv_batch(2, N=8)
+    w["A"] = np.concatenate([np.concatenate([w["A"], np.zeros((2, 8, 12, 8))], axis=3), np.zeros((2, 8, 8, 20))], axis=2)  # nx = 20
+    w["B"] = np.concatenate([w["B"], np.zeros((2, 8, 8, 4))], axis=2)
+    w["C"] = np.concatenate([w["C"], np.zeros((16, 8))], axis=1)
+    w["x0"] = np.concatenate([w["x0"], np.zeros((2, 8))], axis=1)
+    w["goal"], w["targets"] = np.zeros(20), np.zeros(8 * 20)
+    bp = W.to_batch_problem(w)
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(bp, formulation="stagewise")
+
+
+# ---------------------------------------------------------------- wider systems (mpcqp_stagew.hip)
+def _random_ltv(rng, B, nx, nu, N, mk):
+    A = np.eye(nx) + 0.08 * rng.standard_normal((B, N, nx, nx))
+    Bm = rng.standard_normal((B, N, nx, nu))
+    Cm = rng.standard_normal((B, N, mk, nx))
+    D = rng.standard_normal((B, N, mk, nu))
+    x0 = 0.1 * rng.standard_normal((B, nx))
+    e = np.zeros((B, N, mk))
+    for b in range(B):
+        x = x0[b].copy()
+        for k in range(N):
+            e[b, k] = Cm[b, k] @ x + 0.05 + 0.5 * np.abs(rng.standard_normal(mk))
+            x = A[b, k] @ x
+    return dict(A=A, B=Bm, C=Cm, D=D, e=e, N=N, wt=2.0, wx=0.5, wu=1e-2, x0=x0,
+                goal=rng.standard_normal((B, nx)), targets=rng.standard_normal((B, N * nx)))
+
+
+@pytest.mark.parametrize("nx,nu,N,mk", [(6, 2, 20, 3), (5, 3, 33, 2), (9, 4, 16, 4), (16, 4, 12, 3), (12, 1, 70, 2)])
+def test_wide_stagewise_kernel_random_ltv_vs_oracles(nx, nu, N, mk):
+    """nx > 4 or nu > 2: the LDS-tile Riccati / serial-sweep kernel, float64, against the dense C oracle and (iteration
+    counts included) against the NumPy restatement of the stage-wise method."""
+    from oracle import stagewise_np as S
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(100 * nx + N)
+    w = _random_ltv(rng, 24, nx, nu, N, mk)
+    plan = solve_mpc_batch(W.to_batch_problem(w), formulation="stagewise", return_multipliers=True)
+    torch.cuda.synchronize()
+    U, st, lam = plan.U.cpu().numpy(), plan.status.cpu().numpy(), plan.multipliers.cpu().numpy()
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    assert np.array_equal(st == 0, sto == 0), (st, sto)
+    ok = sto == 0
+    assert ok.sum() >= 18
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-7
+    for b in np.flatnonzero(ok)[:4]:
+        sp = S.from_mpc_problem(W.problem_from_workload(w, int(b)))
+        Us, ls, sts, its = S.solve_stagewise(sp)
+        assert sts == 0 and int(plan.iters[b].item()) == its
+        assert np.abs(U[b] - Us).max() <= 1e-9 * max(1.0, np.abs(Us).max())
+        kk = S.kkt_residuals_stagewise(sp, U[b], lam[b])
+        assert kk["stationarity"] <= 1e-9 and kk["primal"] <= 1e-10 and kk["dual"] == 0.0, kk
+
+
+def test_wide_stagewise_config5_dimensions_f64_and_f32():
+    """BASELINE configs[4]'s problems (nx = 12, nu = 4, N = 64: n = 256, m = 1024) WITHOUT P, G or any factor of them:
+    float64 against the dense oracle at 1e-7, float32 at the config's 1e-3, and against the condensed float32 HIP path."""
+    from oracle.parallel import solve_workload_parallel
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    w = W.synthetic_ltv_batch(96)
+    Uo, _, sto, _ = solve_workload_parallel(w, shard_workload)
+    assert (sto == 0).all()
+    scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+    p64 = solve_mpc_batch(W.to_batch_problem(w), formulation="stagewise")
+    p32 = solve_mpc_batch(W.to_batch_problem(w, dtype=torch.float32), formulation="stagewise")
+    d32 = solve_mpc_batch(W.to_batch_problem(w, dtype=torch.float32))
+    torch.cuda.synchronize()
+    assert (p64.status == 0).all() and (p32.status == 0).all()
+    assert (np.abs(p64.U.cpu().numpy() - Uo) / scale).max() <= 1e-7
+    assert (np.abs(p32.U.double().cpu().numpy() - Uo) / scale).max() <= 1e-3
+    assert (np.abs(p32.U.double().cpu().numpy() - d32.U.double().cpu().numpy()) / scale).max() <= 2e-3
