@@ -29,10 +29,11 @@ namespace mpcqp {
 namespace stagew {
 
 constexpr int NX = 16, NU = 4;  // capacities (register arrays, LDS tiles); the true dimensions nx, nu are run-time values
-constexpr int LD = 17;          // row stride of the 16 x 16 LDS tiles (odd: column sweeps are conflict-free too)
+constexpr int LD = 17;          // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
+constexpr int REC = 12;         // per-lane record of a sweep step: 4 + 4 matrix entries + 4 small ones
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Acl, Aclt, Kt, Sinv, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
+    int64_t Rb, Rf, Kt, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
     int maxq;
 };
 
@@ -47,10 +48,9 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
     };
     const int64_t NP = 64 * (int64_t)((N + 63) / 64);  // per-step arrays transposed by chunk, see mpcqp_stage.hip
     const int64_t m = NP * mk;
-    w.Acl = take((int64_t)N * nx * nx);   // natural order: the sweeps are serial, every lane reads step k
-    w.Aclt = take((int64_t)N * nx * nx);
+    w.Rb = take((int64_t)N * 64 * REC);   // lane-ordered records of the backward / forward sweep (one 48-byte load per
+    w.Rf = take((int64_t)N * 64 * REC);   // lane and step instead of a dozen scattered ones)
     w.Kt = take((int64_t)N * nx * nu);
-    w.Sinv = take((int64_t)N * nu * nu);
     w.ff = take((int64_t)N * nu);
     w.U0 = take(NP * nu);
     w.X0 = take(NP * nx);
@@ -92,6 +92,20 @@ __device__ __forceinline__ void wsync()
 template <typename T> struct Tol;
 template <> struct Tol<double> { static constexpr double dep = 1e-13; };
 template <> struct Tol<float> { static constexpr float dep = 1e-6f; };
+// 16 x 16 (+)= 16 x 4 times 4 x 16 on the matrix cores; operands A[lane % 16][lane / 16], B[lane / 16][lane % 16];
+// result register t of a lane: column lane % 16, row 4 (lane / 16) + t in float32, (lane / 16) + 4 t in float64
+// (checked on MI355X, tools/ note in DESIGN.md).
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+    using V = __attribute__((ext_vector_type(4))) float;
+    static __device__ __forceinline__ V run(float a, float b, V c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int pg, int t) { return 4 * pg + t; }
+};
+template <> struct Mfma<double> {
+    using V = __attribute__((ext_vector_type(4))) double;
+    static __device__ __forceinline__ V run(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int pg, int t) { return pg + 4 * t; }
+};
 
 }  // namespace stagew
 
@@ -118,13 +132,13 @@ __global__ void __launch_bounds__(64)
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
     T *Pm = (T *)stagew_smem, *PAm = Pm + 16 * LD, *Mm = PAm + 16 * LD, *Am = Mm + 16 * LD, *Atm = Am + 16 * LD;
-    T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 5, *Btm = Bm + 16 * 5, *BPAm = Btm + 4 * LD;
+    T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
     T *Km = BPAm + 4 * LD, *Sm = Km + 4 * LD, *Sim = Sm + 16, *vec = Sim + 16, *tv = vec + 16;
     T *cv = tv + 8, *rv = cv + maxq, *lamv = rv + maxq;
     int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
-    T *Acl = ws + wl.Acl, *Aclt = ws + wl.Aclt, *Kt = ws + wl.Kt, *Sinv = ws + wl.Sinv, *ffv = ws + wl.ff;
+    T *Rb = ws + wl.Rb, *Rf = ws + wl.Rf, *Kt = ws + wl.Kt, *ffv = ws + wl.ff;
     T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *sl = ws + wl.s, *invn = ws + wl.invn, *Vs = ws + wl.V, *XVs = ws + wl.XV, *Wm = ws + wl.W;
     int *rowslot = (int *)(ws + wl.rowslot);
     // ---- operands
@@ -147,48 +161,58 @@ __global__ void __launch_bounds__(64)
     };
     tick(0);
 
-    // C[r][c] = sum_k A[r][k] B[k][c] (+ epilogue) for r < nr, c < nc over the wavefront: lane (pg, c16) owns rows pg + 4t
+    // C[r][c] = alpha sum_k A[r][k] B[k][c] + beta Add[r][c] (r < nr, c < nc) on the matrix cores: one MFMA per
+    // chunk of 4 along k, operands read from the LDS tiles (every tile is ZERO outside its valid part, so the last
+    // chunk may run past nk; rows / columns past nr / nc read neighbouring tiles and are not stored).
     auto mm = [&](T *C, int ldc, const T *A, int lda, const T *B, int ldb, int nr, int nc, int nk, T alpha, const T *Add,
                   int ldadd, T beta) {
-        T acc[4] = {T(0), T(0), T(0), T(0)};
-        if (c16 < nc) {
-            for (int k = 0; k < nk; ++k) {
-                const T b = B[k * ldb + c16];
+        typename Mfma<T>::V acc = {T(0), T(0), T(0), T(0)};
+        for (int k = 0; k < nk; k += 4) acc = Mfma<T>::run(A[c16 * lda + k + pg], B[(k + pg) * ldb + c16], acc);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] += A[(pg + 4 * t) * lda + k] * b;  // rows >= nr read in-tile padding: ignored
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = pg + 4 * t;
-                if (r < nr) C[r * ldc + c16] = alpha * acc[t] + (Add ? beta * Add[r * ldadd + c16] : T(0));
-            }
+        for (int t = 0; t < 4; ++t) {
+            const int r = Mfma<T>::row(pg, t);
+            if (r < nr && c16 < nc) C[r * ldc + c16] = alpha * acc[t] + (Add ? beta * Add[r * ldadd + c16] : T(0));
         }
     };
 
     // ================================================================= factor: Riccati recursion in LDS
-    for (int i = lane; i < 16 * LD; i += 64) Pm[i] = T(0);
+    for (int i = lane; i < (int)(vec - Pm) + 24; i += 64) Pm[i] = T(0);  // every tile, vec and tv
     wsync();
     if (lane < nx) Pm[lane * LD + lane] = wt;
     wsync();
+    // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step
+    T pfa[4], pfb;
+    auto request = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = lane + 64 * u;
+            pfa[u] = (i < nx * nx) ? gA[k * sA + i] : T(0);
+        }
+        pfb = (lane < nx * nu) ? gB[k * sB + lane] : T(0);
+    };
+    request(N - 1);
     for (int k = N - 1; k >= 0; --k) {
         // stage A_k, A_k', B_k, B_k'
-        for (int i = lane; i < nx * nx; i += 64) {
-            const int r = i / nx, c = i - r * nx;
-            const T a = gA[k * sA + i];
-            Am[r * LD + c] = a;
-            Atm[c * LD + r] = a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = lane + 64 * u;
+            if (i < nx * nx) {
+                const int r = i / nx, c = i - r * nx;
+                Am[r * LD + c] = pfa[u];
+                Atm[c * LD + r] = pfa[u];
+            }
         }
-        for (int i = lane; i < nx * nu; i += 64) {
-            const int r = i / nu, c = i - r * nu;
-            const T b = gB[k * sB + i];
-            Bm[r * 5 + c] = b;
-            Btm[c * LD + r] = b;
+        if (lane < nx * nu) {
+            const int r = lane / nu, c = lane - r * nu;
+            Bm[r * 4 + c] = pfb;
+            Btm[c * LD + r] = pfb;
         }
         wsync();
+        if (k > 0) request(k - 1);
         mm(PAm, LD, Pm, LD, Am, LD, nx, nx, nx, T(1), nullptr, 0, T(0));   // PA = P A
-        mm(PBm, 5, Pm, LD, Bm, 5, nx, nu, nx, T(1), nullptr, 0, T(0));     // PB = P B
+        mm(PBm, 4, Pm, LD, Bm, 4, nx, nu, nx, T(1), nullptr, 0, T(0));     // PB = P B
         wsync();
-        mm(Sm, 4, Btm, LD, PBm, 5, nu, nu, nx, T(1), nullptr, 0, T(0));    // B' P B
+        mm(Sm, 4, Btm, LD, PBm, 4, nu, nu, nx, T(1), nullptr, 0, T(0));    // B' P B
         mm(BPAm, LD, Btm, LD, PAm, LD, nu, nx, nx, T(1), nullptr, 0, T(0));  // B' P A
         wsync();
         // S^-1 (nu <= 4): Gauss-Jordan on the symmetric positive definite S = w_u I + B'PB, every lane the same
@@ -225,22 +249,29 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {  // (compile-time register indices: no scratch)
                     if (lane == i * 4 + j) Sim[lane] = Si[i][j];
-                    if (i < nu && j < nu && lane == i * nu + j) Sinv[(int64_t)k * nu * nu + lane] = Si[i][j];
                 }
         }
         wsync();
         mm(Km, LD, Sim, 4, BPAm, LD, nu, nx, nu, T(1), nullptr, 0, T(0));  // K = S^-1 B'PA
         wsync();
-        mm(Acm, LD, Bm, 5, Km, LD, nx, nx, nu, T(-1), Am, LD, T(1));       // Acl = A - B K
-        mm(Mm, LD, PBm, 5, Km, LD, nx, nx, nu, T(-1), PAm, LD, T(1));      // M = P Acl = PA - PB K
+        mm(Acm, LD, Bm, 4, Km, LD, nx, nx, nu, T(-1), Am, LD, T(1));       // Acl = A - B K
+        mm(Mm, LD, PBm, 4, Km, LD, nx, nx, nu, T(-1), PAm, LD, T(1));      // M = P Acl = PA - PB K
         wsync();
         mm(PAm, LD, Atm, LD, Mm, LD, nx, nx, nx, T(1), nullptr, 0, T(0));  // A' P Acl (into the PA tile)
-        // factors to the workspace: Acl, Acl', K'
-        for (int i = lane; i < nx * nx; i += 64) {
-            const int r = i / nx, c = i - r * nx;
-            const T a = Acm[r * LD + c];
-            Acl[(int64_t)k * nx * nx + i] = a;
-            Aclt[(int64_t)k * nx * nx + c * nx + r] = a;
+        // factors to the workspace as the sweeps' per-lane records, and K' (only read at the candidate row's step)
+        {
+            T *rb = Rb + ((int64_t)k * 64 + lane) * REC, *rf = Rf + ((int64_t)k * 64 + lane) * REC;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = pg + 4 * u;
+                rb[u] = (j < nx && c16 < nx) ? Acm[j * LD + c16] : T(0);      // Acl[j][c]   (Acl' p)
+                rb[4 + u] = (j < nx && c16 < nu) ? Bm[j * 4 + c16] : T(0);    // B[j][i]     (B' p)
+                rb[8 + u] = (lane < nu && u < nu) ? Sim[lane * 4 + u] : T(0); // S^-1[i][l]
+                rf[u] = (j < nx && c16 < nx) ? Acm[c16 * LD + j] : T(0);      // Acl[c][j]   (Acl x)
+                rf[4 + u] = (j < nx && c16 < nu) ? Km[c16 * LD + j] : T(0);   // K[i][j]     (K x)
+            }
+            rf[8] = (c16 < nx && pg < nu) ? Bm[c16 * 4 + pg] : T(0);          // B[c][pg]    (B ff, one input per row group)
+            rf[9] = rf[10] = rf[11] = T(0);
         }
         for (int i = lane; i < nx * nu; i += 64) {
             const int r = i / nu, c = i - r * nu;  // Kt[r][c] = K[c][r]
@@ -265,11 +296,10 @@ __global__ void __launch_bounds__(64)
     tick(1);
 
     // ================================================================= the LQR solve: two serial sweeps
-    // mat-vec helper: out[c] = sum_j Mat[j * ld + c] * v[j]  (c < nc, j < nj), every lane of column c gets the result
-    auto mv = [&](const T *Mat, int ld, const T *v, int nc, int nj) {
-        T a = T(0);
-        if (c16 < nc)
-            for (int j = pg; j < nj; j += 4) a += Mat[j * ld + c16] * v[j];
+    // A step of a sweep is two mat-vecs  out[c] = sum_j Mat[j][c] v[j]: the 16 lanes of a row group hold the outputs c,
+    // row group pg sums the quarter j = pg, pg + 4, ... of the inner dimension, two xor-shuffles add the quarters. The
+    // matrix entries of step k -+ 1 are requested into registers while step k computes (they sit in HBM / L2).
+    auto quarter_sum = [&](T a) {
         a += __shfl_xor(a, 16);
         a += __shfl_xor(a, 32);
         return a;
@@ -278,12 +308,41 @@ __global__ void __launch_bounds__(64)
     // Linear costs: q_k = -qrow, r_k = -rrow at k == kq (kq < 0: none); tracking terms when `track`.
     auto backward = [&](int kq, const T (&qrow)[NX], const T (&rrow)[NU], bool track) {
         if (lane < 16) vec[lane] = (track && termQ && lane < nx) ? -(T)ka.wt * ggoal[lane] : T(0);  // p_N
+        T ma[4], mb[4], si[NU], tg;
+        auto request = [&](int k) {
+            const T *rb = Rb + ((int64_t)k * 64 + lane) * REC;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ma[u] = rb[u];
+                mb[u] = rb[4 + u];
+                si[u] = rb[8 + u];
+            }
+            tg = (track && stageQ && k >= 1 && c16 < nx) ? (T)ka.wx * gtgt[(int64_t)k * nx + c16] : T(0);
+        };
+        request(N - 1);
         wsync();
         for (int k = N - 1; k >= 0; --k) {
-            const T *Ac = Acl + (int64_t)k * nx * nx, *Kk = Kt + (int64_t)k * nx * nu, *B = gB + k * sB;
-            T tb = mv(B, nu, vec, nu, nx);       // (B' p)_i in lanes c16 = i < nu
-            T pn = mv(Ac, nx, vec, nx, nx);      // (Acl' p)_c
+            T a4[4], b4[4], s4[NU];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a4[u] = ma[u];
+                b4[u] = mb[u];
+            }
+#pragma unroll
+            for (int l = 0; l < NU; ++l) s4[l] = si[l];
+            const T tgk = tg;
+            if (k > 0) request(k - 1);
+            T pn = T(0), tb = T(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T vj = vec[(pg + 4 * u) & 15];  // entries >= nx are zero
+                pn += a4[u] * vj;
+                tb += b4[u] * vj;
+            }
+            pn = quarter_sum(pn);  // (Acl' p)_c
+            tb = quarter_sum(tb);  // (B' p)_i in lanes c16 = i < nu
             if (k == kq) {
+                const T *Kk = Kt + (int64_t)k * nx * nu;
                 if (c16 < nu) tb -= rrow[c16];
                 if (c16 < nx) {
                     T g = -qrow[c16];
@@ -293,14 +352,13 @@ __global__ void __launch_bounds__(64)
                     pn += g;
                 }
             }
-            if (track && stageQ && k >= 1 && c16 < nx) pn -= (T)ka.wx * gtgt[(int64_t)k * nx + c16];
-            if (lane < nu) tv[lane] = tb;
+            pn -= tgk;
+            // ff_i = - sum_l Sinv[i][l] tb_l : the tb_l sit in lanes l of this row group
+            T ff = T(0);
+#pragma unroll
+            for (int l = 0; l < NU; ++l) ff -= s4[l] * __shfl(tb, l);
+            if (lane < nu) ffv[(int64_t)k * nu + lane] = ff;
             wsync();
-            if (lane < nu) {
-                T a = T(0);
-                for (int l = 0; l < nu; ++l) a -= Sinv[(int64_t)k * nu * nu + lane * nu + l] * tv[l];
-                ffv[(int64_t)k * nu + lane] = a;
-            }
             if (lane < 16) vec[lane] = (lane < nx) ? pn : T(0);
             wsync();
         }
@@ -308,18 +366,40 @@ __global__ void __launch_bounds__(64)
     // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs; writes Uo, Xo (chunk-transposed)
     auto forward = [&](const T *xs, T *Uo, T *Xo) {
         if (lane < 16) vec[lane] = (xs && lane < nx) ? xs[lane] : T(0);
+        T ma[4], mk4[4], bf;
+        auto request = [&](int k) {
+            const T *rf = Rf + ((int64_t)k * 64 + lane) * REC;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ma[u] = rf[u];
+                mk4[u] = rf[4 + u];
+            }
+            // (B ff)_c, row group pg adds the term of input pg
+            bf = (pg < nu) ? rf[8] * ffv[(int64_t)k * nu + pg] : T(0);
+        };
+        request(0);
         wsync();
         for (int k = 0; k < N; ++k) {
-            const T *Act = Aclt + (int64_t)k * nx * nx, *Kk = Kt + (int64_t)k * nx * nu, *B = gB + k * sB;
-            const int64_t w = wg(k);
-            const T kx = mv(Kk, nu, vec, nu, nx);   // (K x)_i
-            T xn = mv(Act, nx, vec, nx, nx);        // (Acl x)_c
-            if (lane < nx) Xo[w * nx + lane] = vec[lane];
-            if (lane < nu) {
-                Uo[w * nu + lane] = ffv[(int64_t)k * nu + lane] - kx;
+            T a4[4], k4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a4[u] = ma[u];
+                k4[u] = mk4[u];
             }
-            if (c16 < nx)
-                for (int i = 0; i < nu; ++i) xn += B[c16 * nu + i] * ffv[(int64_t)k * nu + i];
+            const T bfk = bf;
+            if (k + 1 < N) request(k + 1);
+            const int64_t w = wg(k);
+            T xn = bfk, kx = T(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T vj = vec[(pg + 4 * u) & 15];
+                xn += a4[u] * vj;
+                kx += k4[u] * vj;
+            }
+            xn = quarter_sum(xn);  // (Acl x + B ff)_c
+            kx = quarter_sum(kx);  // (K x)_i
+            if (lane < nx) Xo[w * nx + lane] = vec[lane];
+            if (lane < nu) Uo[w * nu + lane] = ffv[(int64_t)k * nu + lane] - kx;
             wsync();
             if (lane < 16) vec[lane] = (lane < nx) ? xn : T(0);
             wsync();
@@ -645,7 +725,7 @@ size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 template <typename T> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, sizeof(T));
-    const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 5 + 3 * 4 * LD + 16 + 16 + 16 + 8);
+    const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 3 * 4 * LD + 16 + 16 + 16 + 8);
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 16;
     auto kern = mpcqp_stagew_kernel<T>;
     if (lds > 48 * 1024) {

@@ -8,6 +8,8 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "wip"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 if kind == "wip":
     bp = W.to_batch_problem(W.wip_batch(batch))
+elif kind in ("c5", "c5f64"):
+    bp = W.to_batch_problem(W.synthetic_ltv_batch_slice(0, batch), dtype=torch.float32 if kind == "c5" else torch.float64)
 else:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from bench_stagewise import long_batch  # noqa
