@@ -471,11 +471,15 @@ class PreparedSolve:
     """
 
     def __init__(self, problem: BatchMPCProblem, return_multipliers: bool = False,
-                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None, **opt_kw):
+                 max_iter: Optional[int] = None, feas_tol: Optional[float] = None, formulation: str = "condensed",
+                 max_active: Optional[int] = None, **opt_kw):
         torch = _torch()
         self._lib = _capi.load()
         _require_on_gpu(problem.initial_state)
+        if formulation not in ("condensed", "stagewise"):
+            raise ProblemDefinitionError(f"formulation must be 'condensed' or 'stagewise', not {formulation!r}")
         self.problem = problem
+        self._stagewise, self._max_active = formulation == "stagewise", int(max_active or 0)
         self._opt_kw = opt_kw  # tensors referenced by the opts struct stay alive with the object
         Bn, n, m = problem.batch_size, problem.nb_variables, problem.nb_constraints
         self.U = torch.empty((Bn, n), dtype=problem.dtype, device=problem.device)
@@ -483,16 +487,25 @@ class PreparedSolve:
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self._opts = _opts(max_iter, feas_tol, **opt_kw)
-        self._ws = _workspace(problem, True)
+        if self._stagewise:
+            dims, nbytes = problem.dims(), C.c_size_t(0)
+            _capi.check(self._lib.mpcqp_stagewise_workspace_bytes(C.byref(dims), Bn, self._max_active, C.byref(nbytes)),
+                        "mpcqp_stagewise_workspace_bytes")
+            self._ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=problem.device)
+        else:
+            self._ws = _workspace(problem, True)
         self.rebind()
 
     def rebind(self) -> None:
         self._dims, self._cp = self.problem.dims(), self.problem.c_problem()
-        self._args = (
-            C.byref(self._dims), C.byref(self._cp), self.problem.batch_size, C.byref(self._opts),
+        head = (C.byref(self._dims), C.byref(self._cp), self.problem.batch_size, C.byref(self._opts))
+        if self._stagewise:
+            head = head + (self._max_active,)
+        self._args = head + (
             self.U.data_ptr(), None if self.lam is None else self.lam.data_ptr(),
             self.status.data_ptr(), self.iters.data_ptr(), *_ws_args(self._ws),
         )
+        self._entry = self._lib.mpcqp_stagewise_solve_batch if self._stagewise else self._lib.mpcqp_build_solve_batch
 
     def set_warm_start(self, on: bool) -> None:
         """Begin the next launches from the ``warm_state`` given at construction (or from the empty set)."""
@@ -504,9 +517,9 @@ class PreparedSolve:
         """Enqueue one fused build+solve of the whole batch on ``stream``
         (default: torch's current stream). Asynchronous."""
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
-        rc = self._lib.mpcqp_build_solve_batch(*self._args, sp)
+        rc = self._entry(*self._args, sp)
         if rc != 0:
-            _capi.check(rc, "mpcqp_build_solve_batch")
+            _capi.check(rc, "mpcqp_stagewise_solve_batch" if self._stagewise else "mpcqp_build_solve_batch")
 
     @property
     def plan(self) -> BatchPlan:

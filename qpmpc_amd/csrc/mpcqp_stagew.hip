@@ -5,21 +5,23 @@
 // the condensed Hessian P with P never formed; a product with P^-1 is one LQR solve; qpmpc/mpc_qp.py:39,108-109 and
 // qpmpc/solve_mpc.py:31-32 are what it replaces). What differs is how one wavefront handles nx x nx matrices that no
 // longer fit a lane's registers:
-//   * RICCATI RECURSION: the step's matrices (P, A_k, A_k', P A, A_cl, ...) live in LDS as 16 x 16 tiles; a product is
-//     spread over the 64 lanes -- lane (p, c) = (lane / 16, lane % 16) owns the outputs (p + 4 t, c), t = 0..3 -- and reads
-//     its operands from LDS (the B-side entry is shared by the lane's four outputs). Transposed operands are staged
-//     transposed (A_k', B_k') so that every read runs along a row.
-//   * SWEEPS of the LQR solve: serial over the horizon, each step a mat-vec whose 12-16 outputs sit on the 16 lanes of a
-//     row group, the four row groups summing a quarter of the inner dimension each (two xor-shuffles); the running vector
-//     (costate / state) lives in LDS. The factor stores A_cl and its transpose so that both sweeps read rows.
-//   * the O(|A| N) part of an iteration (slot vectors, slacks, selection) is spread over the lanes by chunks of the
-//     horizon exactly as in the narrow kernel, and the code is the same.
+//   * RICCATI RECURSION: the step's matrices (P, A_k, A_k', P A, A_cl, ...) live in LDS as 16 x 16 tiles and every
+//     product runs on the matrix cores (one 16x16x4 MFMA per chunk of 4 of the inner dimension).
+//   * SWEEPS of the LQR solve: serial over the horizon and latency-bound, so a step has NO LDS traffic and NO barrier:
+//     lane c < 16 holds row c of the step's matrix (A_cl' going backward, A_cl going forward), lanes 16..19 the rows
+//     of the input-sized one (B', K); the running vector sits in one register of lanes 0..nx-1 and its entries are read
+//     with v_readlane into scalar operands of the lanes' FMA chains. The rows come from per-step records the factor
+//     wrote in exactly that order (two to four 16-byte loads per lane), requested D steps ahead into a register ring.
+//   * ACTIVE SET: every active row a keeps V_a = P^-1 g_a' (inputs only) and h_a = G V_a (all m rows), so an iteration
+//     after the candidate's two sweeps is m-long AXPYs over coalesced arrays: c_a = h_p[row a], slack update
+//     s += t (h_p - sum r_a h_a). Slots are addressed through a permutation, nothing is copied when rows enter or leave.
 // One wavefront per problem and ~10 KB (f32) of LDS: 8+ problems per CU are in flight, against ONE for the dense
-// large-problem solver (its packed L^-1 fills the LDS) -- that, not the flop count, is where most of the gain at
-// config 5's size comes from.
+// large-problem solver (its packed L^-1 fills the LDS).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
@@ -28,14 +30,17 @@ namespace mpcqp {
 
 namespace stagew {
 
-constexpr int NX = 16, NU = 4;  // capacities (register arrays, LDS tiles); the true dimensions nx, nu are run-time values
-constexpr int LD = 17;          // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
-constexpr int REC = 12;         // per-lane record of a sweep step: 4 + 4 matrix entries + 4 small ones
+constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
+constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
+constexpr int D = 4;    // the sweeps request their records this many steps ahead
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Rb, Rf, Kt, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
-    int maxq;
+    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, s0, s, invn, rowslot, V, H, W, total;
+    int maxq, rbs, rfs;
 };
+
+// nxc: nx rounded up to a multiple of 4 (the kernel's compile-time row length)
+inline int nxc_of(int nx) { return (nx + 3) & ~3; }
 
 inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
 {
@@ -46,19 +51,24 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
         o += (cnt + 3) & ~(int64_t)3;
         return at;
     };
-    const int64_t NP = 64 * (int64_t)((N + 63) / 64);  // per-step arrays transposed by chunk, see mpcqp_stage.hip
-    const int64_t m = NP * mk;
-    w.Rb = take((int64_t)N * 64 * REC);   // lane-ordered records of the backward / forward sweep (one 48-byte load per
-    w.Rf = take((int64_t)N * 64 * REC);   // lane and step instead of a dozen scattered ones)
+    const int nxc = nxc_of(nx);
+    const int64_t m = (int64_t)N * mk;
+    // per-step records of the sweeps: 20 rows of nxc (lanes 0..15: A_cl' | A_cl, lanes 16..19: B' | K), then S^-1 | B
+    w.rbs = 20 * nxc + 16;
+    w.rfs = 20 * nxc + 64;
+    w.Rb = take((int64_t)N * w.rbs);
+    w.Rf = take((int64_t)N * w.rfs);
     w.Kt = take((int64_t)N * nx * nu);
-    w.ff = take((int64_t)N * nu);
-    w.U0 = take(NP * nu);
-    w.X0 = take(NP * nx);
+    w.ff = take((int64_t)N * 4);
+    w.U0 = take((int64_t)N * nu);
+    w.X0 = take((int64_t)N * nx);
+    w.Xp = take((int64_t)N * nx);
+    w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
     w.rowslot = take((m * 4 + esz - 1) / esz);  // int32 per row
-    w.V = take((int64_t)(maxq + 1) * NP * nu);
-    w.XV = take((int64_t)(maxq + 1) * NP * nx);
+    w.V = take((int64_t)(maxq + 1) * N * nu);   // slot maxq + 1: the candidate
+    w.H = take((int64_t)(maxq + 1) * m);
     w.W = take((int64_t)maxq * maxq);
     o = (o + 127) & ~(int64_t)127;  // odd multiple of 512 B / 1 KB between problems (memory channels)
     if (((o >> 7) & 1) == 0) o += 128;
@@ -107,27 +117,27 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int row(int pg, int t) { return pg + 4 * t; }
 };
 
+// lane j's value as a wave-uniform scalar (v_readlane)
+__device__ __forceinline__ float rl(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+__device__ __forceinline__ double rl(double v, int j)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), j), __builtin_amdgcn_readlane(__double2loint(v), j));
+}
+
 }  // namespace stagew
 
 using namespace stagew;
 
-template <typename T>
+template <typename T, int NXC>
 __global__ void __launch_bounds__(64)
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
+    using V4 = __attribute__((ext_vector_type(4))) T;
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
-    const int L = (N + 63) / 64;
-    const int k0 = lane * L < N ? lane * L : N;
-    const int k1 = (k0 + L < N) ? k0 + L : N;
-    const int64_t NP = 64 * (int64_t)L;
-    auto wq = [&](int k) { return (int64_t)(k - k0) * 64 + lane; };
-    auto wg = [&](int k) {
-        const int j = k / L;
-        return (int64_t)(k - j * L) * 64 + j;
-    };
+    const int M = N * mk, nvar = N * nu;
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
@@ -135,11 +145,12 @@ __global__ void __launch_bounds__(64)
     T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
     T *Km = BPAm + 4 * LD, *Sm = Km + 4 * LD, *Sim = Sm + 16, *vec = Sim + 16, *tv = vec + 16;
     T *cv = tv + 8, *rv = cv + maxq, *lamv = rv + maxq;
-    int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
+    int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
     T *Rb = ws + wl.Rb, *Rf = ws + wl.Rf, *Kt = ws + wl.Kt, *ffv = ws + wl.ff;
-    T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *sl = ws + wl.s, *invn = ws + wl.invn, *Vs = ws + wl.V, *XVs = ws + wl.XV, *Wm = ws + wl.W;
+    T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *Xp = ws + wl.Xp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
+    T *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W;
     int *rowslot = (int *)(ws + wl.rowslot);
     // ---- operands
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
@@ -258,20 +269,16 @@ __global__ void __launch_bounds__(64)
         mm(Mm, LD, PBm, 4, Km, LD, nx, nx, nu, T(-1), PAm, LD, T(1));      // M = P Acl = PA - PB K
         wsync();
         mm(PAm, LD, Atm, LD, Mm, LD, nx, nx, nx, T(1), nullptr, 0, T(0));  // A' P Acl (into the PA tile)
-        // factors to the workspace as the sweeps' per-lane records, and K' (only read at the candidate row's step)
+        // factors to the workspace: the sweeps' records (see the header), and K' (read at the candidate row's step)
         {
-            T *rb = Rb + ((int64_t)k * 64 + lane) * REC, *rf = Rf + ((int64_t)k * 64 + lane) * REC;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = pg + 4 * u;
-                rb[u] = (j < nx && c16 < nx) ? Acm[j * LD + c16] : T(0);      // Acl[j][c]   (Acl' p)
-                rb[4 + u] = (j < nx && c16 < nu) ? Bm[j * 4 + c16] : T(0);    // B[j][i]     (B' p)
-                rb[8 + u] = (lane < nu && u < nu) ? Sim[lane * 4 + u] : T(0); // S^-1[i][l]
-                rf[u] = (j < nx && c16 < nx) ? Acm[c16 * LD + j] : T(0);      // Acl[c][j]   (Acl x)
-                rf[4 + u] = (j < nx && c16 < nu) ? Km[c16 * LD + j] : T(0);   // K[i][j]     (K x)
+            T *rb = Rb + (int64_t)k * wl.rbs, *rf = Rf + (int64_t)k * wl.rfs;
+            for (int e = lane; e < 20 * NXC; e += 64) {
+                const int l2 = e / NXC, j = e - l2 * NXC;
+                rb[e] = (l2 < 16) ? Acm[j * LD + l2] : Bm[j * 4 + (l2 - 16)];     // Acl[j][c]  |  B[j][i]
+                rf[e] = (l2 < 16) ? Acm[l2 * LD + j] : Km[(l2 - 16) * LD + j];    // Acl[c][j]  |  K[i][j]
             }
-            rf[8] = (c16 < nx && pg < nu) ? Bm[c16 * 4 + pg] : T(0);          // B[c][pg]    (B ff, one input per row group)
-            rf[9] = rf[10] = rf[11] = T(0);
+            if (lane < 16) rb[20 * NXC + lane] = Sim[lane];  // S^-1[i][l]
+            rf[20 * NXC + lane] = Bm[lane];                  // B[c][i]
         }
         for (int i = lane; i < nx * nu; i += 64) {
             const int r = i / nu, c = i - r * nu;  // Kt[r][c] = K[c][r]
@@ -296,207 +303,222 @@ __global__ void __launch_bounds__(64)
     tick(1);
 
     // ================================================================= the LQR solve: two serial sweeps
-    // A step of a sweep is two mat-vecs  out[c] = sum_j Mat[j][c] v[j]: the 16 lanes of a row group hold the outputs c,
-    // row group pg sums the quarter j = pg, pg + 4, ... of the inner dimension, two xor-shuffles add the quarters. The
-    // matrix entries of step k -+ 1 are requested into registers while step k computes (they sit in HBM / L2).
-    auto quarter_sum = [&](T a) {
-        a += __shfl_xor(a, 16);
-        a += __shfl_xor(a, 32);
-        return a;
-    };
-    // backward: p_k = g_k + Acl_k' p_{k+1}, g_k = q_k - K_k' r_k ; ff_k = -S_k^-1 (B_k' p_{k+1} + r_k).
-    // Linear costs: q_k = -qrow, r_k = -rrow at k == kq (kq < 0: none); tracking terms when `track`.
-    auto backward = [&](int kq, const T (&qrow)[NX], const T (&rrow)[NU], bool track) {
-        if (lane < 16) vec[lane] = (track && termQ && lane < nx) ? -(T)ka.wt * ggoal[lane] : T(0);  // p_N
-        T ma[4], mb[4], si[NU], tg;
-        auto request = [&](int k) {
-            const T *rb = Rb + ((int64_t)k * 64 + lane) * REC;
+    const bool has = lane < 20, lo = lane < 16;
+    // backward: p_k = g_k + Acl_k' p_{k+1} ; ff_k = -S_k^-1 (B_k' p_{k+1} + r_k). Linear costs: the tracking terms when
+    // `track`, else row (kq, .) of G: `addq` holds, per lane, -C[c] + (K_kq' D)_c (lanes < nx) and -D[i] (lanes 16 + i);
+    // the costate of a single row is zero after its step, so that sweep starts at kq.
+    // (every lane issues the loads -- lanes past 19 re-read row 0 -- so that the ring carries no divergent branch and the
+    // waits stay counted per step)
+    const int rrow = has ? lane : 0, srow = lane & 3, crow = lane < nx ? lane : nx - 1;
+    auto backward = [&](auto trackc, int kq, T addq) {
+        constexpr bool track = decltype(trackc)::value;
+        const bool tgt = track && stageQ;
+        const T *tp = tgt ? gtgt : Rb;  // (a readable address when there are no targets)
+        const T wxq = (T)ka.wx;
+        T pv = (track && termQ && lane < nx) ? -(T)ka.wt * ggoal[lane] : T(0);  // p_N
+        const int kstart = track ? N - 1 : kq;
+        V4 rec[D][NXC / 4], sv[D];
+        T tg[D];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ma[u] = rb[u];
-                mb[u] = rb[4 + u];
-                si[u] = rb[8 + u];
-            }
-            tg = (track && stageQ && k >= 1 && c16 < nx) ? (T)ka.wx * gtgt[(int64_t)k * nx + c16] : T(0);
+        for (int d = 0; d < D; ++d) {
+            sv[d] = V4{T(0), T(0), T(0), T(0)};
+            tg[d] = T(0);
+#pragma unroll
+            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = V4{T(0), T(0), T(0), T(0)};
+        }
+        auto req = [&](int d, int k) {
+            const T *rb = Rb + (int64_t)k * wl.rbs;
+            const V4 *p = (const V4 *)(rb + rrow * NXC);
+#pragma unroll
+            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = p[q];
+            sv[d] = *(const V4 *)(rb + 20 * NXC + srow * 4);
+            if (track) tg[d] = tp[(int64_t)k * nx + crow];
         };
-        request(N - 1);
-        wsync();
-        for (int k = N - 1; k >= 0; --k) {
-            T a4[4], b4[4], s4[NU];
+        // (requests are unconditional -- clamped at the end of the sweep -- so that every path carries the same number
+        // of loads in flight and the compiler can wait for exactly the oldest)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a4[u] = ma[u];
-                b4[u] = mb[u];
-            }
-#pragma unroll
-            for (int l = 0; l < NU; ++l) s4[l] = si[l];
-            const T tgk = tg;
-            if (k > 0) request(k - 1);
-            T pn = T(0), tb = T(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const T vj = vec[(pg + 4 * u) & 15];  // entries >= nx are zero
-                pn += a4[u] * vj;
-                tb += b4[u] * vj;
-            }
-            pn = quarter_sum(pn);  // (Acl' p)_c
-            tb = quarter_sum(tb);  // (B' p)_i in lanes c16 = i < nu
-            if (k == kq) {
-                const T *Kk = Kt + (int64_t)k * nx * nu;
-                if (c16 < nu) tb -= rrow[c16];
-                if (c16 < nx) {
-                    T g = -qrow[c16];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i)
-                        if (i < nu) g += Kk[c16 * nu + i] * rrow[i];  // - K' r with r = -rrow
-                    pn += g;
-                }
-            }
-            pn -= tgk;
-            // ff_i = - sum_l Sinv[i][l] tb_l : the tb_l sit in lanes l of this row group
-            T ff = T(0);
-#pragma unroll
-            for (int l = 0; l < NU; ++l) ff -= s4[l] * __shfl(tb, l);
-            if (lane < nu) ffv[(int64_t)k * nu + lane] = ff;
-            wsync();
-            if (lane < 16) vec[lane] = (lane < nx) ? pn : T(0);
-            wsync();
+        for (int d = 0; d < D; ++d) {
+            req(d, kstart - d >= 0 ? kstart - d : 0);
+            __builtin_amdgcn_sched_barrier(0);  // oldest first: the loop waits for them in this order
         }
-    };
-    // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs; writes Uo, Xo (chunk-transposed)
-    auto forward = [&](const T *xs, T *Uo, T *Xo) {
-        if (lane < 16) vec[lane] = (xs && lane < nx) ? xs[lane] : T(0);
-        T ma[4], mk4[4], bf;
-        auto request = [&](int k) {
-            const T *rf = Rf + ((int64_t)k * 64 + lane) * REC;
+        auto step = [&](int d, int k, bool again) {
+            T a0 = T(0), a1 = T(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ma[u] = rf[u];
-                mk4[u] = rf[4 + u];
+            for (int j = 0; j < NXC; j += 2) {
+                a0 += rec[d][j / 4][j % 4] * rl(pv, j);
+                a1 += rec[d][(j + 1) / 4][(j + 1) % 4] * rl(pv, j + 1);
             }
-            // (B ff)_c, row group pg adds the term of input pg
-            bf = (pg < nu) ? rf[8] * ffv[(int64_t)k * nu + pg] : T(0);
+            T acc = a0 + a1;  // lanes < 16: (Acl' p)_c ; lanes 16 + i: (B' p)_i
+            if (k == kq) acc += addq;
+            if (tgt && k >= 1) acc -= (lane < nx) ? wxq * tg[d] : T(0);
+            T f = T(0);
+#pragma unroll
+            for (int l = 0; l < NU; ++l) f -= sv[d][l] * rl(acc, 16 + l);
+            if (!lo && has) ffv[(int64_t)k * 4 + (lane - 16)] = f;
+            pv = acc;
+            if (again) req(d, k - D >= 0 ? k - D : 0);
         };
-        request(0);
-        wsync();
-        for (int k = 0; k < N; ++k) {
-            T a4[4], k4[4];
+        // full groups of D steps (every step re-requests: same loads in flight on every path), then the remainder
+        int k = kstart;
+        for (int g = (kstart + 1) / D; g > 0; --g) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a4[u] = ma[u];
-                k4[u] = mk4[u];
-            }
-            const T bfk = bf;
-            if (k + 1 < N) request(k + 1);
-            const int64_t w = wg(k);
-            T xn = bfk, kx = T(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const T vj = vec[(pg + 4 * u) & 15];
-                xn += a4[u] * vj;
-                kx += k4[u] * vj;
-            }
-            xn = quarter_sum(xn);  // (Acl x + B ff)_c
-            kx = quarter_sum(kx);  // (K x)_i
-            if (lane < nx) Xo[w * nx + lane] = vec[lane];
-            if (lane < nu) Uo[w * nu + lane] = ffv[(int64_t)k * nu + lane] - kx;
-            wsync();
-            if (lane < 16) vec[lane] = (lane < nx) ? xn : T(0);
-            wsync();
+            for (int d = 0; d < D; ++d) step(d, k - d, true);
+            k -= D;
         }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (k - d >= 0) step(d, k - d, false);
     };
-    // g_(k,r) . (U, X) = C_k[r] x_k + D_k[r] u_k   (w = workspace index of step k)
-    auto gdot = [&](int k, int64_t w, int r, const T *Uv, const T *Xv) {
-        T a = T(0);
-        if (gC) {
-            const T *c = gC + k * sC + r * nx;
+    // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs (ff_k = 0 for k > kff); writes the
+    // inputs to Uo[k][i] and the states to Xo[k][c]
+    auto forward = [&](const T *xs, int kff, T *Uo, T *Xo) {
+        T xv = (xs && lane < nx) ? xs[lane] : T(0);
+        V4 rec[D][NXC / 4], b4[D];
+        T ffk[D];
 #pragma unroll
-            for (int i = 0; i < NX; ++i)
-                if (i < nx) a += c[i] * Xv[w * nx + i];
-        }
-        if (gD) {
-            const T *d = gD + k * sD + r * nu;
+        for (int d = 0; d < D; ++d) {
+            b4[d] = V4{T(0), T(0), T(0), T(0)};
+            ffk[d] = T(0);
 #pragma unroll
-            for (int i = 0; i < NU; ++i)
-                if (i < nu) a += d[i] * Uv[w * nu + i];
+            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = V4{T(0), T(0), T(0), T(0)};
         }
-        return a;
+        auto req = [&](int d, int k) {
+            const T *rf = Rf + (int64_t)k * wl.rfs;
+            const V4 *p = (const V4 *)(rf + rrow * NXC);
+#pragma unroll
+            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = p[q];
+            b4[d] = *(const V4 *)(rf + 20 * NXC + (lane & 15) * 4);
+            ffk[d] = ffv[(int64_t)k * 4 + srow];
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            req(d, d < N ? d : N - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto step = [&](int d, int k, bool again) {
+            T a0 = T(0), a1 = T(0);
+#pragma unroll
+            for (int j = 0; j < NXC; j += 2) {
+                a0 += rec[d][j / 4][j % 4] * rl(xv, j);
+                a1 += rec[d][(j + 1) / 4][(j + 1) % 4] * rl(xv, j + 1);
+            }
+            const T acc = a0 + a1;  // lanes < 16: (Acl x)_c ; lanes 16 + i: (K x)_i
+            const T ffd = (k <= kff) ? ffk[d] : T(0);
+            T bff = T(0);
+#pragma unroll
+            for (int l = 0; l < NU; ++l) bff += b4[d][l] * rl(ffd, 16 + l);
+            if (lane < nx) Xo[(int64_t)k * nx + lane] = xv;
+            if (!lo && lane < 16 + nu) Uo[(int64_t)k * nu + (lane - 16)] = ffd - acc;
+            xv = acc + bff;
+            if (again) req(d, k + D < N ? k + D : N - 1);
+        };
+        int k = 0;
+        for (int g = N / D; g > 0; --g) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) step(d, k + d, true);
+            k += D;
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (k + d < N) step(d, k + d, false);
+    };
+    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k over the rows i = k mk + r (lanes side by side: coalesced)
+    auto gmul = [&](const T *Uv, const T *Xv, T *hd) {
+        for (int i = lane; i < M; i += 64) {
+            const int k = i / mk, r = i - k * mk;
+            T a = T(0);
+            if (gC) {
+                const T *c = gC + k * sC + r * nx, *x = Xv + (int64_t)k * nx;
+#pragma unroll
+                for (int j = 0; j < NXC; ++j)
+                    if (j < nx) a += c[j] * x[j];
+            }
+            if (gD) {
+                const T *dd = gD + k * sD + r * nu, *u = Uv + (int64_t)k * nu;
+#pragma unroll
+                for (int j = 0; j < NU; ++j)
+                    if (j < nu) a += dd[j] * u[j];
+            }
+            hd[i] = a;
+        }
     };
 
     // ================================================================= unconstrained minimiser, slacks
-    {
-        T zq[NX], zr[NU];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) zq[i] = T(0);
-#pragma unroll
-        for (int i = 0; i < NU; ++i) zr[i] = T(0);
-        tick(2);
-        backward(-1, zq, zr, true);
-    }
+    tick(2);
+    backward(std::true_type{}, -1, T(0));
     wsync();
     tick(3);
-    forward(gx0, U0, X0);
+    forward(gx0, N, U0, X0);
     wsync();
     tick(4);
     const T tol = ka.tol;
-    for (int k = k0; k < k1; ++k)
-        for (int r = 0; r < mk; ++r) {
-            const int64_t i = wq(k) * mk + r;
-            const T ev = ge[k * sE + r];
-            sl[i] = ev - gdot(k, wq(k), r, U0, X0);
-            T nn = 0.0;
-            if (gC)
-                for (int c = 0; c < NX; ++c) if (c < nx) nn += gC[k * sC + r * nx + c] * gC[k * sC + r * nx + c];
-            if (gD)
-                for (int c = 0; c < NU; ++c) if (c < nu) nn += gD[k * sD + r * nu + c] * gD[k * sD + r * nu + c];
-            invn[i] = nn > 0.0 ? (T)rsqrt((double)nn) : 1.0;
-            rowslot[i] = -1;
-        }
+    gmul(U0, X0, sl);
+    for (int i = lane; i < M; i += 64) {
+        const int k = i / mk, r = i - k * mk;
+        const T sv = ge[k * sE + r] - sl[i];
+        s0[i] = sv;
+        sl[i] = sv;
+        T nn = T(0);
+        if (gC)
+            for (int c = 0; c < nx; ++c) nn += gC[k * sC + r * nx + c] * gC[k * sC + r * nx + c];
+        if (gD)
+            for (int c = 0; c < nu; ++c) nn += gD[k * sD + r * nu + c] * gD[k * sD + r * nu + c];
+        invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+        rowslot[i] = -1;
+    }
+    for (int a = lane; a <= maxq; a += 64) phys[a] = a;
     wsync();
 
     tick(5);
     // ================================================================= active-set loop
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
-    const int nvar = N * nu;
-    T *Vp = Vs + (int64_t)maxq * NP * nu, *Xp = XVs + (int64_t)maxq * NP * nx;  // the candidate's slot
     bool fail = false;
     for (int round = 0; round < 4 && !fail; ++round) {
         for (;;) {
             // ---- selection: the violated row farthest from its hyperplane
             T best = INF;
             int bi = 0x7fffffff;
-            for (int k = k0; k < k1; ++k)
-                for (int r = 0; r < mk; ++r) {
-                    const int64_t i = wq(k) * mk + r;
-                    const T ev = ge[k * sE + r], sv = sl[i];
-                    const bool viol = ev < 1e29 && rowslot[i] < 0 && sv < -(tol + tol * fabs((double)ev));
-                    const T sc = sv * invn[i];
-                    if (viol && sc < best) {
-                        best = sc;
-                        bi = k * mk + r;  // natural row id: ties go to the lowest one, like the restatement
-                    }
+            for (int i = lane; i < M; i += 64) {
+                const int k = i / mk, r = i - k * mk;
+                const T ev = ge[k * sE + r], sv = sl[i];
+                const bool viol = ev < 1e29 && rowslot[i] < 0 && sv < -(tol + tol * fabs((double)ev));
+                const T sc = sv * invn[i];
+                if (viol && sc < best) {  // ties go to the lowest row id, like the restatement
+                    best = sc;
+                    bi = i;
                 }
+            }
             wave_argmin(best, bi);
             if (!(best < INF)) {
                 status = MPCQP_SOLVED;
                 break;
             }
             const int kp = bi / mk, rp = bi - kp * mk;
-            const int64_t wp = wg(kp), bw = wp * mk + rp;  // workspace index of step kp / of row p
-            T qrow[NX], rrow[NU];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) if (i < nx) qrow[i] = gC ? gC[kp * sC + rp * nx + i] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) if (i < nu) rrow[i] = gD ? gD[kp * sD + rp * nu + i] : 0.0;
-            T up = 0.0;
+            // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room
+            const int ps = phys[nq];
+            T *Vp = Vs + (int64_t)ps * nvar, *hp = Hs + (int64_t)ps * M;
+            {
+                T addq = T(0);
+                if (lane < nx) {
+                    addq = gC ? -gC[kp * sC + rp * nx + lane] : T(0);
+                    if (gD) {
+                        const T *Kk = Kt + ((int64_t)kp * nx + lane) * nu, *dd = gD + kp * sD + rp * nu;
+                        for (int i = 0; i < nu; ++i) addq += Kk[i] * dd[i];  // - K' r with r = -D[rp]
+                    }
+                } else if (lane >= 16 && lane < 16 + nu) {
+                    addq = gD ? -gD[kp * sD + rp * nu + (lane - 16)] : T(0);
+                }
+                backward(std::false_type{}, kp, addq);
+            }
+            wsync();
+            forward(nullptr, kp, Vp, Xp);
+            wsync();
+            gmul(Vp, Xp, hp);
+            wsync();
+            const T dpp = hp[bi];
+            T up = T(0);
             bool added = false;
-            // V_p = P^-1 g_p' and its trajectory do not change while p waits for room: solved once
-            backward(kp, qrow, rrow, false);
-            wsync();
-            forward(nullptr, Vp, Xp);
-            wsync();
-            const T dpp = gdot(kp, wp, rp, Vp, Xp);
             while (!added) {
                 if (iters >= max_iter || nq >= maxq) {
                     fail = true;
@@ -504,11 +526,11 @@ __global__ void __launch_bounds__(64)
                 }
                 ++iters;
                 // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], wg(actk[a]), actr[a], Vp, Xp);
+                for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
                 wsync();
-                T cr = 0.0;
+                T cr = T(0);
                 for (int a = lane; a < nq; a += 64) {
-                    T acc = 0.0;
+                    T acc = T(0);
                     for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
                     rv[a] = acc;
                     cr += acc * cv[a];
@@ -516,13 +538,13 @@ __global__ void __launch_bounds__(64)
                 cr = wave_sum(cr);
                 wsync();
                 const T d2 = dpp - cr;
-                const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > 0.0);
+                const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
                 // ---- ratio test on the multipliers
                 T t1 = INF;
                 int l = 0x7fffffff;
                 for (int a = lane; a < nq; a += 64) {
                     const T ra = rv[a];
-                    if (ra > 0.0) {
+                    if (ra > T(0)) {
                         const T q = lamv[a] / ra;
                         if (q < t1) {
                             t1 = q;
@@ -531,7 +553,7 @@ __global__ void __launch_bounds__(64)
                     }
                 }
                 wave_argmin(t1, l);
-                const T sp = sl[bw];
+                const T sp = sl[bi];
                 const T t2 = can_move ? -sp / d2 : INF;
                 const T t = t1 < t2 ? t1 : t2;
                 if (!(t < INF)) {
@@ -540,43 +562,22 @@ __global__ void __launch_bounds__(64)
                     break;
                 }
                 const bool full = (t2 <= t1);
-                // ---- slacks: s_i -= t g_i . z ,  z = -(V_p - sum_a r_a V_a)  (this lane's chunk)
-                for (int k = k0; k < k1; ++k) {
-                    T zu[NU], zx[NX];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) if (i < nu) zu[i] = -Vp[wq(k) * nu + i];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) if (i < nx) zx[i] = -Xp[wq(k) * nx + i];
-                    for (int a = 0; a < nq; ++a) {
-                        const T ra = rv[a];
-                        const T *va = Vs + ((int64_t)a * NP + wq(k)) * nu, *xa = XVs + ((int64_t)a * NP + wq(k)) * nx;
-#pragma unroll
-                        for (int i = 0; i < NU; ++i) if (i < nu) zu[i] += ra * va[i];
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) if (i < nx) zx[i] += ra * xa[i];
-                    }
-                    for (int r = 0; r < mk; ++r) {
-                        T gz = 0.0;
-                        if (gC)
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) if (i < nx) gz += gC[k * sC + r * nx + i] * zx[i];
-                        if (gD)
-#pragma unroll
-                            for (int i = 0; i < NU; ++i) if (i < nu) gz += gD[k * sD + r * nu + i] * zu[i];
-                        const int64_t i = wq(k) * mk + r;
-                        sl[i] = (rowslot[i] >= 0) ? 0.0 : sl[i] - t * gz;
-                    }
+                // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i
+                for (int i = lane; i < M; i += 64) {
+                    T z = hp[i];
+                    for (int a = 0; a < nq; ++a) z -= rv[a] * Hs[(int64_t)phys[a] * M + i];
+                    sl[i] = (rowslot[i] >= 0) ? T(0) : sl[i] + t * z;
                 }
                 // ---- multipliers
                 for (int a = lane; a < nq; a += 64) {
                     const T v = lamv[a] - t * rv[a];
-                    lamv[a] = v < 0.0 ? 0.0 : v;
+                    lamv[a] = v < T(0) ? T(0) : v;
                 }
                 up += t;
                 wsync();
                 if (full) {
-                    // p becomes active in slot nq: W is bordered, the candidate's vectors move into the slot
-                    const T id2 = 1.0 / d2;
+                    // p becomes active at index nq (its slot is already phys[nq]): W is bordered
+                    const T id2 = T(1) / d2;
                     for (int a = lane; a < nq; a += 64) {
                         const T ra = rv[a];
                         for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] += rv[b] * ra * id2;
@@ -586,24 +587,17 @@ __global__ void __launch_bounds__(64)
                     if (lane == 0) {
                         Wm[(int64_t)nq * maxq + nq] = id2;
                         lamv[nq] = up;
-                        actk[nq] = kp;
-                        actr[nq] = rp;
-                        rowslot[bw] = nq;
-                        sl[bw] = 0.0;
-                    }
-                    T *vd = Vs + (int64_t)nq * NP * nu, *xd = XVs + (int64_t)nq * NP * nx;
-                    for (int k = k0; k < k1; ++k) {
-#pragma unroll
-                        for (int i = 0; i < NU; ++i) if (i < nu) vd[wq(k) * nu + i] = Vp[wq(k) * nu + i];
-#pragma unroll
-                        for (int i = 0; i < NX; ++i) if (i < nx) xd[wq(k) * nx + i] = Xp[wq(k) * nx + i];
+                        actrow[nq] = bi;
+                        rowslot[bi] = nq;
+                        sl[bi] = T(0);
                     }
                     ++nq;
                     added = true;
                 } else {
-                    // partial step: slot l leaves; W is deflated and the last slot moves into the hole
+                    // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
+                    // through the permutation (the candidate's stays where it is)
                     const T wll = Wm[(int64_t)l * maxq + l];
-                    const T iw = 1.0 / wll;
+                    const T iw = T(1) / wll;
                     for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
                     wsync();
                     for (int a = lane; a < nq; a += 64) {
@@ -612,29 +606,23 @@ __global__ void __launch_bounds__(64)
                     }
                     wsync();
                     const int last = nq - 1;
-                    const int64_t drow = wg(actk[l]) * mk + actr[l];
                     if (l != last) {
                         for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
                         wsync();
                         for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
                         wsync();
-                        const T *vs = Vs + (int64_t)last * NP * nu, *xs = XVs + (int64_t)last * NP * nx;
-                        T *vd = Vs + (int64_t)l * NP * nu, *xd = XVs + (int64_t)l * NP * nx;
-                        for (int k = k0; k < k1; ++k) {
-#pragma unroll
-                            for (int i = 0; i < NU; ++i) if (i < nu) vd[wq(k) * nu + i] = vs[wq(k) * nu + i];
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) if (i < nx) xd[wq(k) * nx + i] = xs[wq(k) * nx + i];
-                        }
                     }
                     if (lane == 0) {
-                        rowslot[drow] = -1;
+                        rowslot[actrow[l]] = -1;
+                        const int freed = phys[l];
                         if (l != last) {
                             lamv[l] = lamv[last];
-                            actk[l] = actk[last];
-                            actr[l] = actr[last];
-                            rowslot[wg(actk[last]) * mk + actr[last]] = l;
+                            actrow[l] = actrow[last];
+                            rowslot[actrow[last]] = l;
+                            phys[l] = phys[last];
                         }
+                        phys[last] = phys[nq];
+                        phys[nq] = freed;
                     }
                     --nq;
                 }
@@ -645,40 +633,22 @@ __global__ void __launch_bounds__(64)
         if (fail) break;
         tick(6);
         // ================================================================= primal point, verification
-        // u = u0 - sum_a lam_a V_a ; slacks from scratch through x = x0 - sum_a lam_a X_a
+        // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
+        T *ou = (T *)ka.U + prob * (int64_t)nvar;
+        for (int i = lane; i < nvar; i += 64) {
+            T u = U0[i];
+            for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nvar + i];
+            ou[i] = u;
+        }
         bool dirty = false;
-        for (int k = k0; k < k1; ++k) {
-            T u[NU], x[NX];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) if (i < nu) u[i] = U0[wq(k) * nu + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) if (i < nx) x[i] = X0[wq(k) * nx + i];
-            for (int a = 0; a < nq; ++a) {
-                const T la = lamv[a];
-                const T *va = Vs + ((int64_t)a * NP + wq(k)) * nu, *xa = XVs + ((int64_t)a * NP + wq(k)) * nx;
-#pragma unroll
-                for (int i = 0; i < NU; ++i) if (i < nu) u[i] -= la * va[i];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) if (i < nx) x[i] -= la * xa[i];
-            }
-            T *ou = (T *)ka.U + prob * (int64_t)nvar + (int64_t)k * nu;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) if (i < nu) ou[i] = u[i];
-            for (int r = 0; r < mk; ++r) {
-                const int64_t i = wq(k) * mk + r;
-                const T ev = ge[k * sE + r];
-                T g = 0.0;
-                if (gC)
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) if (c < nx) g += gC[k * sC + r * nx + c] * x[c];
-                if (gD)
-#pragma unroll
-                    for (int c = 0; c < NU; ++c) if (c < nu) g += gD[k * sD + r * nu + c] * u[c];
-                const T fresh = ev - g;
-                const bool act = rowslot[i] >= 0;
-                if (ev < 1e29 && !act && !(fresh >= -4.0 * (tol + tol * fabs((double)ev)))) dirty = true;
-                sl[i] = act ? 0.0 : fresh;
-            }
+        for (int i = lane; i < M; i += 64) {
+            const int k = i / mk, r = i - k * mk;
+            const T ev = ge[k * sE + r];
+            T fresh = s0[i];
+            for (int a = 0; a < nq; ++a) fresh += lamv[a] * Hs[(int64_t)phys[a] * M + i];
+            const bool act = rowslot[i] >= 0;
+            if (ev < 1e29 && !act && !(fresh >= -4.0 * (tol + tol * fabs((double)ev)))) dirty = true;
+            sl[i] = act ? T(0) : fresh;
         }
         dirty = __ballot(dirty) != 0ull;
         wsync();
@@ -693,17 +663,14 @@ __global__ void __launch_bounds__(64)
     const bool ok = status == MPCQP_SOLVED;
     if (!ok) {
         T *ou = (T *)ka.U + prob * (int64_t)nvar;
-        for (int k = k0; k < k1; ++k)
-#pragma unroll
-            for (int i = 0; i < NU; ++i) if (i < nu) ou[(int64_t)k * nu + i] = 0.0;
+        for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
     }
     if (ka.lam) {
-        T *ol = (T *)ka.lam + prob * (int64_t)N * mk;
-        for (int k = k0; k < k1; ++k)
-            for (int r = 0; r < mk; ++r) {
-                const int sidx = rowslot[wq(k) * mk + r];
-                ol[(int64_t)k * mk + r] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
-            }
+        T *ol = (T *)ka.lam + prob * (int64_t)M;
+        for (int i = lane; i < M; i += 64) {
+            const int sidx = rowslot[i];
+            ol[i] = (ok && sidx >= 0) ? lamv[sidx] : T(0);
+        }
     }
     if (lane == 0) {
         if (ka.status) ka.status[prob] = status;
@@ -714,7 +681,7 @@ __global__ void __launch_bounds__(64)
 // ------------------------------------------------------------ host side
 bool stagew_supported(const KernelArgs &ka, int dtype)
 {
-    return (dtype == MPCQP_F64 || dtype == MPCQP_F32) && ka.nx >= 2 && ka.nx <= NX && ka.nu >= 1 && ka.nu <= NU && ka.mk >= 1;
+    return (dtype == MPCQP_F64 || dtype == MPCQP_F32) && ka.nx >= 2 && ka.nx <= 16 && ka.nu >= 1 && ka.nu <= NU && ka.mk >= 1;
 }
 
 size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
@@ -722,12 +689,12 @@ size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
     return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, dtype == MPCQP_F64 ? 8 : 4).total;
 }
 
-template <typename T> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, sizeof(T));
     const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 3 * 4 * LD + 16 + 16 + 16 + 8);
-    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 16;
-    auto kern = mpcqp_stagew_kernel<T>;
+    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 32;
+    auto kern = mpcqp_stagew_kernel<T, NXC>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -736,9 +703,19 @@ template <typename T> static int launch_stagew_t(const KernelArgs &ka, int maxq,
     return (int)hipGetLastError();
 }
 
+template <typename T> static int launch_stagew_d(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    switch (nxc_of(ka.nx)) {
+    case 4: return launch_stagew_t<T, 4>(ka, maxq, batch, ws, st);
+    case 8: return launch_stagew_t<T, 8>(ka, maxq, batch, ws, st);
+    case 12: return launch_stagew_t<T, 12>(ka, maxq, batch, ws, st);
+    default: return launch_stagew_t<T, 16>(ka, maxq, batch, ws, st);
+    }
+}
+
 int launch_stagew(const KernelArgs &ka, int dtype, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
-    return dtype == MPCQP_F64 ? launch_stagew_t<double>(ka, maxq, batch, ws, st) : launch_stagew_t<float>(ka, maxq, batch, ws, st);
+    return dtype == MPCQP_F64 ? launch_stagew_d<double>(ka, maxq, batch, ws, st) : launch_stagew_d<float>(ka, maxq, batch, ws, st);
 }
 
 }  // namespace mpcqp

@@ -11,12 +11,15 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 res = {}
 for name, dt, form in (("stagewise f32", torch.float32, "stagewise"), ("stagewise f64", torch.float64, "stagewise"), ("condensed f32", torch.float32, "condensed")):
     bp = W.to_batch_problem(w, dtype=dt)
-    p = solve_mpc_batch(bp, formulation=form); torch.cuda.synchronize()
+    ps = PreparedSolve(bp, formulation=form)  # (one workspace, no allocation in the timed loop)
+    ps.launch(); torch.cuda.synchronize()
     e0.record()
-    for _ in range(3): p = solve_mpc_batch(bp, formulation=form)
+    for _ in range(3): ps.launch()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
+    p = ps.plan
     res[name] = p.U.double()
+    del ps
     print(f"{name}: {ms:8.2f} ms per {batch} -> {batch/ms:8.1f} k problems/s; solved {(p.status==0).float().mean().item():.4f}, iters {p.iters.float().mean().item():.2f} max {p.iters.max().item()}", flush=True)
 ref = res["stagewise f64"]
 sc = ref.abs().max(dim=1).values.clamp(min=1.0)

@@ -25,3 +25,8 @@ for i, nme in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print(f"  {nme:16s} mean {d.mean().item():10.0f} cyc   max {d.max().item():10.0f}")
 print(f"  total            mean {(t[:,7]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,7]-t[:,0]).max().item():10.0f}")
+print(f"  makespan {(t[:,7].max()-t[:,0].min()).item():.0f} cyc; start spread {(t[:,0].max()-t[:,0].min()).item():.0f}")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    e0.record(); plan = solve_mpc_batch(bp, formulation="stagewise"); e1.record(); torch.cuda.synchronize()
+    print(f"  call: {e0.elapsed_time(e1):.2f} ms")
