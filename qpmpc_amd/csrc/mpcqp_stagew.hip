@@ -35,7 +35,7 @@ constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA op
 constexpr int D = 4;    // the sweeps request their records this many steps ahead
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, s0, s, invn, rowslot, V, H, W, total;
+    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, s0, s, invn, thr, rowslot, V, H, W, total;
     int maxq, rbs, rfs;
 };
 
@@ -66,6 +66,7 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
     w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
+    w.thr = take(m);
     w.rowslot = take((m * 4 + esz - 1) / esz);  // int32 per row
     w.V = take((int64_t)(maxq + 1) * N * nu);   // slot maxq + 1: the candidate
     w.H = take((int64_t)(maxq + 1) * m);
@@ -133,6 +134,7 @@ __global__ void __launch_bounds__(64)
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
+    typedef V4 V4u __attribute__((aligned(4)));  // a row of the caller's C / D: element-aligned only
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(64)
     T *ws = wsbase + prob * wl.total;
     T *Rb = ws + wl.Rb, *Rf = ws + wl.Rf, *Kt = ws + wl.Kt, *ffv = ws + wl.ff;
     T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *Xp = ws + wl.Xp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
+    T *thr = ws + wl.thr;
     T *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W;
     int *rowslot = (int *)(ws + wl.rowslot);
     // ---- operands
@@ -171,6 +174,17 @@ __global__ void __launch_bounds__(64)
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
     tick(0);
+    // (developer probe) slots 8..15 accumulate the time spent in the parts of the active-set loop
+    long long tlast = 0;
+    auto tacc = [&](int slot) {
+        if (stamp) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0 && slot >= 0) stamp[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (stamp && lane == 0)
+        for (int i = 8; i < 16; ++i) stamp[i] = 0;
 
     // C[r][c] = alpha sum_k A[r][k] B[k][c] + beta Add[r][c] (r < nr, c < nc) on the matrix cores: one MFMA per
     // chunk of 4 along k, operands read from the LDS tiles (every tile is ZERO outside its valid part, so the last
@@ -422,25 +436,69 @@ __global__ void __launch_bounds__(64)
         for (int d = 0; d < D - 1; ++d)
             if (k + d < N) step(d, k + d, false);
     };
-    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k over the rows i = k mk + r (lanes side by side: coalesced)
-    auto gmul = [&](const T *Uv, const T *Xv, T *hd) {
-        for (int i = lane; i < M; i += 64) {
-            const int k = i / mk, r = i - k * mk;
-            T a = T(0);
-            if (gC) {
-                const T *c = gC + k * sC + r * nx, *x = Xv + (int64_t)k * nx;
+    // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
+    constexpr int GU = 4;
+    const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
+    auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
+    const bool vecC = gC && nx == NXC, vecD = gD && nu == NU;  // rows are whole 4-vectors
+    // row i of G times (U, X) -- or, with sq, times itself
+    auto rowdot = [&](int i, const T *Uv, const T *Xv, bool sq) {
+        const int k = stepof(i), r = i - k * mk;
+        T acc = T(0);
+        if (gC) {
+            const T *c = gC + k * sC + r * nx, *x = sq ? c : Xv + (int64_t)k * nx;
+            if (vecC) {
+#pragma unroll
+                for (int q = 0; q < NXC / 4; ++q) {
+                    const V4u cq = ((const V4u *)c)[q], xq = ((const V4u *)x)[q];
+                    acc += cq[0] * xq[0] + cq[1] * xq[1] + cq[2] * xq[2] + cq[3] * xq[3];
+                }
+            } else {
 #pragma unroll
                 for (int j = 0; j < NXC; ++j)
-                    if (j < nx) a += c[j] * x[j];
+                    if (j < nx) acc += c[j] * x[j];
             }
-            if (gD) {
-                const T *dd = gD + k * sD + r * nu, *u = Uv + (int64_t)k * nu;
+        }
+        if (gD) {
+            const T *dd = gD + k * sD + r * nu, *u = sq ? dd : Uv + (int64_t)k * nu;
+            if (vecD) {
+                const V4u dq = *(const V4u *)dd, uq = *(const V4u *)u;
+                acc += dq[0] * uq[0] + dq[1] * uq[1] + dq[2] * uq[2] + dq[3] * uq[3];
+            } else {
 #pragma unroll
                 for (int j = 0; j < NU; ++j)
-                    if (j < nu) a += dd[j] * u[j];
+                    if (j < nu) acc += dd[j] * u[j];
             }
-            hd[i] = a;
         }
+        return acc;
+    };
+    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k
+    auto gmul = [&](const T *Uv, const T *Xv, T *hd) {
+        for (int i0 = lane; i0 < M; i0 += 64 * GU) {
+            T a[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int i = i0 + 64 * u;
+                a[u] = rowdot(i < M ? i : M - 1, Uv, Xv, false);
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+                if (i0 + 64 * u < M) hd[i0 + 64 * u] = a[u];
+        }
+    };
+    // the violated row farthest from its hyperplane (active rows sit at s = 0 exactly, rows without a bound at ~1e30:
+    // neither can be selected); ties go to the lowest row id, like the restatement
+    auto select = [&](T &best, int &bi) {
+        best = INF;
+        bi = 0x7fffffff;
+        for (int i = lane; i < M; i += 64) {
+            const T sv = sl[i], sc = sv * invn[i];
+            if (sv < -thr[i] && sc < best) {
+                best = sc;
+                bi = i;
+            }
+        }
+        wave_argmin(best, bi);
     };
 
     // ================================================================= unconstrained minimiser, slacks
@@ -454,15 +512,12 @@ __global__ void __launch_bounds__(64)
     const T tol = ka.tol;
     gmul(U0, X0, sl);
     for (int i = lane; i < M; i += 64) {
-        const int k = i / mk, r = i - k * mk;
-        const T sv = ge[k * sE + r] - sl[i];
+        const int k = stepof(i), r = i - k * mk;
+        const T ev = ge[k * sE + r], sv = ev - sl[i];
         s0[i] = sv;
         sl[i] = sv;
-        T nn = T(0);
-        if (gC)
-            for (int c = 0; c < nx; ++c) nn += gC[k * sC + r * nx + c] * gC[k * sC + r * nx + c];
-        if (gD)
-            for (int c = 0; c < nu; ++c) nn += gD[k * sD + r * nu + c] * gD[k * sD + r * nu + c];
+        thr[i] = tol + tol * (T)fabs((double)ev);
+        const T nn = rowdot(i, nullptr, nullptr, true);
         invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
         rowslot[i] = -1;
     }
@@ -473,27 +528,22 @@ __global__ void __launch_bounds__(64)
     // ================================================================= active-set loop
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
-    bool fail = false;
+    bool fail = false, havesel = false;
+    T nbest = INF;
+    int nbi = 0x7fffffff;
     for (int round = 0; round < 4 && !fail; ++round) {
         for (;;) {
-            // ---- selection: the violated row farthest from its hyperplane
-            T best = INF;
-            int bi = 0x7fffffff;
-            for (int i = lane; i < M; i += 64) {
-                const int k = i / mk, r = i - k * mk;
-                const T ev = ge[k * sE + r], sv = sl[i];
-                const bool viol = ev < 1e29 && rowslot[i] < 0 && sv < -(tol + tol * fabs((double)ev));
-                const T sc = sv * invn[i];
-                if (viol && sc < best) {  // ties go to the lowest row id, like the restatement
-                    best = sc;
-                    bi = i;
-                }
-            }
-            wave_argmin(best, bi);
+            // ---- selection (already made by the slack pass of the step that just ended, if there was one)
+            tacc(-1);
+            T best = nbest;
+            int bi = nbi;
+            if (!havesel) select(best, bi);
+            havesel = false;
             if (!(best < INF)) {
                 status = MPCQP_SOLVED;
                 break;
             }
+            tacc(8);
             const int kp = bi / mk, rp = bi - kp * mk;
             // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room
             const int ps = phys[nq];
@@ -512,10 +562,13 @@ __global__ void __launch_bounds__(64)
                 backward(std::false_type{}, kp, addq);
             }
             wsync();
+            tacc(9);
             forward(nullptr, kp, Vp, Xp);
             wsync();
+            tacc(10);
             gmul(Vp, Xp, hp);
             wsync();
+            tacc(11);
             const T dpp = hp[bi];
             T up = T(0);
             bool added = false;
@@ -562,11 +615,38 @@ __global__ void __launch_bounds__(64)
                     break;
                 }
                 const bool full = (t2 <= t1);
-                // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i
-                for (int i = lane; i < M; i += 64) {
-                    T z = hp[i];
-                    for (int a = 0; a < nq; ++a) z -= rv[a] * Hs[(int64_t)phys[a] * M + i];
-                    sl[i] = (rowslot[i] >= 0) ? T(0) : sl[i] + t * z;
+                tacc(12);
+                // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
+                nbest = INF;
+                nbi = 0x7fffffff;
+                for (int i0 = lane; i0 < M; i0 += 64 * GU) {
+                    int idx[GU];
+                    T z[GU];
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        idx[u] = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                        z[u] = hp[idx[u]];
+                    }
+                    for (int a = 0; a < nq; ++a) {
+                        const T ra = rv[a];
+                        const T *ha = Hs + (int64_t)phys[a] * M;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) z[u] -= ra * ha[idx[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < GU; ++u) {
+                        const int i = idx[u];
+                        const T v = (rowslot[i] >= 0) ? T(0) : sl[i] + t * z[u];
+                        const T sc = v * invn[i];
+                        const bool viol = v < -thr[i] && i != bi;
+                        if (i0 + 64 * u < M) {
+                            sl[i] = v;
+                            if (viol && sc < nbest) {
+                                nbest = sc;
+                                nbi = i;
+                            }
+                        }
+                    }
                 }
                 // ---- multipliers
                 for (int a = lane; a < nq; a += 64) {
@@ -575,6 +655,7 @@ __global__ void __launch_bounds__(64)
                 }
                 up += t;
                 wsync();
+                tacc(13);
                 if (full) {
                     // p becomes active at index nq (its slot is already phys[nq]): W is bordered
                     const T id2 = T(1) / d2;
@@ -593,6 +674,8 @@ __global__ void __launch_bounds__(64)
                     }
                     ++nq;
                     added = true;
+                    wave_argmin(nbest, nbi);
+                    havesel = true;
                 } else {
                     // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
                     // through the permutation (the candidate's stays where it is)
@@ -627,6 +710,7 @@ __global__ void __launch_bounds__(64)
                     --nq;
                 }
                 wsync();
+                tacc(14);
             }
             if (fail) break;
         }
@@ -641,14 +725,27 @@ __global__ void __launch_bounds__(64)
             ou[i] = u;
         }
         bool dirty = false;
-        for (int i = lane; i < M; i += 64) {
-            const int k = i / mk, r = i - k * mk;
-            const T ev = ge[k * sE + r];
-            T fresh = s0[i];
-            for (int a = 0; a < nq; ++a) fresh += lamv[a] * Hs[(int64_t)phys[a] * M + i];
-            const bool act = rowslot[i] >= 0;
-            if (ev < 1e29 && !act && !(fresh >= -4.0 * (tol + tol * fabs((double)ev)))) dirty = true;
-            sl[i] = act ? T(0) : fresh;
+        for (int i0 = lane; i0 < M; i0 += 64 * GU) {
+            int idx[GU];
+            T fr[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                idx[u] = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                fr[u] = s0[idx[u]];
+            }
+            for (int a = 0; a < nq; ++a) {
+                const T la = lamv[a];
+                const T *ha = Hs + (int64_t)phys[a] * M;
+#pragma unroll
+                for (int u = 0; u < GU; ++u) fr[u] += la * ha[idx[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int i = idx[u];
+                const bool act = rowslot[i] >= 0;
+                if (!act && !(fr[u] >= T(-4) * thr[i])) dirty = true;
+                if (i0 + 64 * u < M) sl[i] = act ? T(0) : fr[u];
+            }
         }
         dirty = __ballot(dirty) != 0ull;
         wsync();

@@ -25,6 +25,9 @@ for i, nme in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print(f"  {nme:16s} mean {d.mean().item():10.0f} cyc   max {d.max().item():10.0f}")
 print(f"  total            mean {(t[:,7]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,7]-t[:,0]).max().item():10.0f}")
+if kind in ("c5", "c5f64"):
+    for i, nme in zip(range(8, 15), ["selection", "backward", "forward", "gmul", "step calc", "slack update", "W update"]):
+        print(f"    in loop: {nme:14s} mean {t[:, i].mean().item():10.0f} cyc")
 print(f"  makespan {(t[:,7].max()-t[:,0].min()).item():.0f} cyc; start spread {(t[:,0].max()-t[:,0].min()).item():.0f}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):
