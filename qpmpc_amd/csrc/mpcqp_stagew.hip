@@ -118,6 +118,24 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int row(int pg, int t) { return pg + 4 * t; }
 };
 
+// C[r][c] = alpha sum_k A[r][k] B[k][c] (+ beta Add[r][c]) on the matrix cores: one MFMA per chunk of 4 along k,
+// operands read from LDS tiles with compile-time strides. Tiles are 16 or 4 rows / columns (NR, NC) and ZERO outside
+// their valid part, so the products run over the full tile and the padding of the result is zero again; reads past a
+// 4-row / 4-column operand land in the neighbouring tiles and only feed results that are not stored.
+template <typename T, int LDA, int LDB, int LDC, int NR, int NC, int NK>
+__device__ __forceinline__ void mm_t(T *C, const T *A, const T *B, T alpha, const T *Add, T beta, int pg, int c16)
+{
+    typename Mfma<T>::V acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int k = 0; k < NK; k += 4) acc = Mfma<T>::run(A[c16 * LDA + k + pg], B[(k + pg) * LDB + c16], acc);
+    if (NC < 16 && c16 >= NC) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = Mfma<T>::row(pg, t);
+        if (NR == 16 || r < NR) C[r * LDC + c16] = alpha * acc[t] + (Add ? beta * Add[r * LDC + c16] : T(0));
+    }
+}
+
 // lane j's value as a wave-uniform scalar (v_readlane)
 __device__ __forceinline__ float rl(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 __device__ __forceinline__ double rl(double v, int j)
@@ -140,6 +158,7 @@ __global__ void __launch_bounds__(64)
     const int64_t prob = blockIdx.x;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int M = N * mk, nvar = N * nu;
+    const bool has = lane < 20, lo = lane < 16;  // lanes holding a row of a sweep record
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
@@ -186,20 +205,6 @@ __global__ void __launch_bounds__(64)
     if (stamp && lane == 0)
         for (int i = 8; i < 16; ++i) stamp[i] = 0;
 
-    // C[r][c] = alpha sum_k A[r][k] B[k][c] + beta Add[r][c] (r < nr, c < nc) on the matrix cores: one MFMA per
-    // chunk of 4 along k, operands read from the LDS tiles (every tile is ZERO outside its valid part, so the last
-    // chunk may run past nk; rows / columns past nr / nc read neighbouring tiles and are not stored).
-    auto mm = [&](T *C, int ldc, const T *A, int lda, const T *B, int ldb, int nr, int nc, int nk, T alpha, const T *Add,
-                  int ldadd, T beta) {
-        typename Mfma<T>::V acc = {T(0), T(0), T(0), T(0)};
-        for (int k = 0; k < nk; k += 4) acc = Mfma<T>::run(A[c16 * lda + k + pg], B[(k + pg) * ldb + c16], acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = Mfma<T>::row(pg, t);
-            if (r < nr && c16 < nc) C[r * ldc + c16] = alpha * acc[t] + (Add ? beta * Add[r * ldadd + c16] : T(0));
-        }
-    };
-
     // ================================================================= factor: Riccati recursion in LDS
     for (int i = lane; i < (int)(vec - Pm) + 24; i += 64) Pm[i] = T(0);  // every tile, vec and tv
     wsync();
@@ -207,6 +212,19 @@ __global__ void __launch_bounds__(64)
     wsync();
     // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step
     T pfa[4], pfb;
+    int offA[4], offAt[4], offB = -1, offBt = 0, offK = -1;  // LDS offsets of this lane's entries (-1: none)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = lane + 64 * u, r = i / nx, c = i - r * nx;
+        offA[u] = (i < nx * nx) ? r * LD + c : -1;
+        offAt[u] = c * LD + r;
+    }
+    if (lane < nx * nu) {
+        const int r = lane / nu, c = lane - r * nu;
+        offB = r * 4 + c;
+        offBt = c * LD + r;
+        offK = c * LD + r;  // Kt[r][c] = K[c][r]
+    }
     auto request = [&](int k) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -219,26 +237,22 @@ __global__ void __launch_bounds__(64)
     for (int k = N - 1; k >= 0; --k) {
         // stage A_k, A_k', B_k, B_k'
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = lane + 64 * u;
-            if (i < nx * nx) {
-                const int r = i / nx, c = i - r * nx;
-                Am[r * LD + c] = pfa[u];
-                Atm[c * LD + r] = pfa[u];
+        for (int u = 0; u < 4; ++u)
+            if (offA[u] >= 0) {
+                Am[offA[u]] = pfa[u];
+                Atm[offAt[u]] = pfa[u];
             }
-        }
-        if (lane < nx * nu) {
-            const int r = lane / nu, c = lane - r * nu;
-            Bm[r * 4 + c] = pfb;
-            Btm[c * LD + r] = pfb;
+        if (offB >= 0) {
+            Bm[offB] = pfb;
+            Btm[offBt] = pfb;
         }
         wsync();
         if (k > 0) request(k - 1);
-        mm(PAm, LD, Pm, LD, Am, LD, nx, nx, nx, T(1), nullptr, 0, T(0));   // PA = P A
-        mm(PBm, 4, Pm, LD, Bm, 4, nx, nu, nx, T(1), nullptr, 0, T(0));     // PB = P B
+        mm_t<T, LD, LD, LD, 16, 16, NXC>(PAm, Pm, Am, T(1), nullptr, T(0), pg, c16);    // PA = P A
+        mm_t<T, LD, 4, 4, 16, 4, NXC>(PBm, Pm, Bm, T(1), nullptr, T(0), pg, c16);      // PB = P B
         wsync();
-        mm(Sm, 4, Btm, LD, PBm, 4, nu, nu, nx, T(1), nullptr, 0, T(0));    // B' P B
-        mm(BPAm, LD, Btm, LD, PAm, LD, nu, nx, nx, T(1), nullptr, 0, T(0));  // B' P A
+        mm_t<T, LD, 4, 4, 4, 4, NXC>(Sm, Btm, PBm, T(1), nullptr, T(0), pg, c16);     // B' P B
+        mm_t<T, LD, LD, LD, 4, 16, NXC>(BPAm, Btm, PAm, T(1), nullptr, T(0), pg, c16); // B' P A
         wsync();
         // S^-1 (nu <= 4): Gauss-Jordan on the symmetric positive definite S = w_u I + B'PB, every lane the same
         {
@@ -277,26 +291,35 @@ __global__ void __launch_bounds__(64)
                 }
         }
         wsync();
-        mm(Km, LD, Sim, 4, BPAm, LD, nu, nx, nu, T(1), nullptr, 0, T(0));  // K = S^-1 B'PA
+        mm_t<T, 4, LD, LD, 4, 16, 4>(Km, Sim, BPAm, T(1), nullptr, T(0), pg, c16);     // K = S^-1 B'PA
         wsync();
-        mm(Acm, LD, Bm, 4, Km, LD, nx, nx, nu, T(-1), Am, LD, T(1));       // Acl = A - B K
-        mm(Mm, LD, PBm, 4, Km, LD, nx, nx, nu, T(-1), PAm, LD, T(1));      // M = P Acl = PA - PB K
+        mm_t<T, 4, LD, LD, 16, 16, 4>(Acm, Bm, Km, T(-1), Am, T(1), pg, c16);           // Acl = A - B K
+        mm_t<T, 4, LD, LD, 16, 16, 4>(Mm, PBm, Km, T(-1), PAm, T(1), pg, c16);          // M = P Acl = PA - PB K
         wsync();
-        mm(PAm, LD, Atm, LD, Mm, LD, nx, nx, nx, T(1), nullptr, 0, T(0));  // A' P Acl (into the PA tile)
-        // factors to the workspace: the sweeps' records (see the header), and K' (read at the candidate row's step)
+        mm_t<T, LD, LD, LD, 16, 16, NXC>(PAm, Atm, Mm, T(1), nullptr, T(0), pg, c16);   // A' P Acl (into the PA tile)
+        // factors to the workspace: the sweeps' records (see the header) -- lane l < 20 writes row l of both -- and K'
+        // (read at the candidate row's step)
         {
             T *rb = Rb + (int64_t)k * wl.rbs, *rf = Rf + (int64_t)k * wl.rfs;
-            for (int e = lane; e < 20 * NXC; e += 64) {
-                const int l2 = e / NXC, j = e - l2 * NXC;
-                rb[e] = (l2 < 16) ? Acm[j * LD + l2] : Bm[j * 4 + (l2 - 16)];     // Acl[j][c]  |  B[j][i]
-                rf[e] = (l2 < 16) ? Acm[l2 * LD + j] : Km[(l2 - 16) * LD + j];    // Acl[c][j]  |  K[i][j]
+            if (has) {
+                const T *cb = lo ? Acm + lane : Bm + (lane - 16);                 // column: Acl[.][c] | B[.][i]
+                const T *cf = lo ? Acm + lane * LD : Km + (lane - 16) * LD;       // row:    Acl[c][.] | K[i][.]
+                const int sb = lo ? LD : 4;
+#pragma unroll
+                for (int q = 0; q < NXC / 4; ++q) {
+                    V4 vb, vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vb[e] = cb[(4 * q + e) * sb];
+                        vf[e] = cf[4 * q + e];
+                    }
+                    ((V4 *)(rb + lane * NXC))[q] = vb;
+                    ((V4 *)(rf + lane * NXC))[q] = vf;
+                }
             }
-            if (lane < 16) rb[20 * NXC + lane] = Sim[lane];  // S^-1[i][l]
-            rf[20 * NXC + lane] = Bm[lane];                  // B[c][i]
-        }
-        for (int i = lane; i < nx * nu; i += 64) {
-            const int r = i / nu, c = i - r * nu;  // Kt[r][c] = K[c][r]
-            Kt[(int64_t)k * nx * nu + i] = Km[c * LD + r];
+            if (lo) rb[20 * NXC + lane] = Sim[lane];  // S^-1[i][l]
+            rf[20 * NXC + lane] = Bm[lane];           // B[c][i]
+            if (offK >= 0) Kt[(int64_t)k * nx * nu + lane] = Km[offK];
         }
         wsync();
         // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
@@ -306,7 +329,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int r = pg + 4 * t;
-                pn[t] = (r < nx && c16 < nx) ? T(0.5) * (PAm[r * LD + c16] + PAm[c16 * LD + r]) + ((r == c16) ? qk : T(0)) : T(0);
+                pn[t] = T(0.5) * (PAm[r * LD + c16] + PAm[c16 * LD + r]) + ((r == c16 && r < nx) ? qk : T(0));  // (zero padding)
             }
             wsync();
 #pragma unroll
@@ -317,7 +340,6 @@ __global__ void __launch_bounds__(64)
     tick(1);
 
     // ================================================================= the LQR solve: two serial sweeps
-    const bool has = lane < 20, lo = lane < 16;
     // backward: p_k = g_k + Acl_k' p_{k+1} ; ff_k = -S_k^-1 (B_k' p_{k+1} + r_k). Linear costs: the tracking terms when
     // `track`, else row (kq, .) of G: `addq` holds, per lane, -C[c] + (K_kq' D)_c (lanes < nx) and -D[i] (lanes 16 + i);
     // the costate of a single row is zero after its step, so that sweep starts at kq.
