@@ -35,14 +35,15 @@ constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA op
 constexpr int D = 4;    // the sweeps request their records this many steps ahead
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, s0, s, invn, thr, rowslot, V, H, W, total;
-    int maxq, rbs, rfs;
+    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
+    int maxq, rbs, rfs, mg;
 };
 
 // nxc: nx rounded up to a multiple of 4 (the kernel's compile-time row length)
 inline int nxc_of(int nx) { return (nx + 3) & ~3; }
 
-inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
+// ginv: C and D do not change along the horizon (their packed copy holds mk rows instead of N mk)
+inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz)
 {
     Ws w{};
     int64_t o = 0;
@@ -60,15 +61,17 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, size_t esz)
     w.Rf = take((int64_t)N * w.rfs);
     w.Kt = take((int64_t)N * nx * nu);
     w.ff = take((int64_t)N * 4);
-    w.U0 = take((int64_t)N * nu);
-    w.X0 = take((int64_t)N * nx);
-    w.Xp = take((int64_t)N * nx);
+    w.U0 = take((int64_t)N * 4);    // input / state trajectories in rows of 4 / nxc entries, zero-padded
+    w.X0 = take((int64_t)N * nxc);
+    w.Xp = take((int64_t)N * nxc);
+    w.mg = ginv ? mk : (int)m;
+    w.Gp = take((int64_t)(nxc + 4) * w.mg);  // [C | D] in quarter-rows: Gp[q][row] is a 4-vector, q < nxc / 4 + 1
     w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
     w.thr = take(m);
     w.rowslot = take((m * 4 + esz - 1) / esz);  // int32 per row
-    w.V = take((int64_t)(maxq + 1) * N * nu);   // slot maxq + 1: the candidate
+    w.V = take((int64_t)(maxq + 1) * N * 4);    // slot maxq + 1: the candidate
     w.H = take((int64_t)(maxq + 1) * m);
     w.W = take((int64_t)maxq * maxq);
     o = (o + 127) & ~(int64_t)127;  // odd multiple of 512 B / 1 KB between problems (memory channels)
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(64)
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
-    const int M = N * mk, nvar = N * nu;
+    const int M = N * mk, nvar = N * nu, nv4 = N * 4;
     const bool has = lane < 20, lo = lane < 16;  // lanes holding a row of a sweep record
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
@@ -172,6 +175,9 @@ __global__ void __launch_bounds__(64)
     T *Rb = ws + wl.Rb, *Rf = ws + wl.Rf, *Kt = ws + wl.Kt, *ffv = ws + wl.ff;
     T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *Xp = ws + wl.Xp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
     T *thr = ws + wl.thr;
+    V4 *Gp = (V4 *)(ws + wl.Gp);
+    const int Mg = wl.mg;
+    const bool ginv = Mg != M;
     T *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W;
     int *rowslot = (int *)(ws + wl.rowslot);
     // ---- operands
@@ -406,7 +412,7 @@ __global__ void __launch_bounds__(64)
             if (k - d >= 0) step(d, k - d, false);
     };
     // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs (ff_k = 0 for k > kff); writes the
-    // inputs to Uo[k][i] and the states to Xo[k][c]
+    // inputs to Uo[k][0..3] and the states to Xo[k][0..NXC-1]
     auto forward = [&](const T *xs, int kff, T *Uo, T *Xo) {
         T xv = (xs && lane < nx) ? xs[lane] : T(0);
         V4 rec[D][NXC / 4], b4[D];
@@ -443,8 +449,8 @@ __global__ void __launch_bounds__(64)
             T bff = T(0);
 #pragma unroll
             for (int l = 0; l < NU; ++l) bff += b4[d][l] * rl(ffd, 16 + l);
-            if (lane < nx) Xo[(int64_t)k * nx + lane] = xv;
-            if (!lo && lane < 16 + nu) Uo[(int64_t)k * nu + (lane - 16)] = ffd - acc;
+            if (lane < NXC) Xo[(int64_t)k * NXC + lane] = xv;  // (zero past nx, past nu)
+            if (!lo && has) Uo[(int64_t)k * 4 + (lane - 16)] = ffd - acc;
             xv = acc + bff;
             if (again) req(d, k + D < N ? k + D : N - 1);
         };
@@ -459,53 +465,58 @@ __global__ void __launch_bounds__(64)
             if (k + d < N) step(d, k + d, false);
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
-    constexpr int GU = 4;
+    constexpr int GU = sizeof(T) == 4 ? 4 : 2;  // rows of G per lane in flight (NQ + 1 four-vectors each)
+    constexpr int SU = 8;                       // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
-    const bool vecC = gC && nx == NXC, vecD = gD && nu == NU;  // rows are whole 4-vectors
-    // row i of G times (U, X) -- or, with sq, times itself
-    auto rowdot = [&](int i, const T *Uv, const T *Xv, bool sq) {
+    constexpr int NQ = NXC / 4;
+    // [C | D] packed once: row i (or r, when they do not change along the horizon) as NQ + 1 four-vectors, zero-padded,
+    // quarter-major so that the lanes of a pass read side by side
+    for (int i = lane; i < Mg; i += 64) {
         const int k = stepof(i), r = i - k * mk;
-        T acc = T(0);
+        V4 g[NQ + 1];
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) g[q] = V4{T(0), T(0), T(0), T(0)};
         if (gC) {
-            const T *c = gC + k * sC + r * nx, *x = sq ? c : Xv + (int64_t)k * nx;
-            if (vecC) {
+            const T *c = gC + k * sC + r * nx;
 #pragma unroll
-                for (int q = 0; q < NXC / 4; ++q) {
-                    const V4u cq = ((const V4u *)c)[q], xq = ((const V4u *)x)[q];
-                    acc += cq[0] * xq[0] + cq[1] * xq[1] + cq[2] * xq[2] + cq[3] * xq[3];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NXC; ++j)
-                    if (j < nx) acc += c[j] * x[j];
-            }
+            for (int j = 0; j < NXC; ++j)
+                if (j < nx) g[j / 4][j % 4] = c[j];
         }
         if (gD) {
-            const T *dd = gD + k * sD + r * nu, *u = sq ? dd : Uv + (int64_t)k * nu;
-            if (vecD) {
-                const V4u dq = *(const V4u *)dd, uq = *(const V4u *)u;
-                acc += dq[0] * uq[0] + dq[1] * uq[1] + dq[2] * uq[2] + dq[3] * uq[3];
-            } else {
+            const T *dd = gD + k * sD + r * nu;
 #pragma unroll
-                for (int j = 0; j < NU; ++j)
-                    if (j < nu) acc += dd[j] * u[j];
-            }
+            for (int j = 0; j < NU; ++j)
+                if (j < nu) g[NQ][j] = dd[j];
         }
-        return acc;
-    };
-    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) Gp[(int64_t)q * Mg + i] = g[q];
+    }
+    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k : the rows' quarter-vectors of GU rows are requested together
     auto gmul = [&](const T *Uv, const T *Xv, T *hd) {
         for (int i0 = lane; i0 < M; i0 += 64 * GU) {
-            T a[GU];
+            V4 g[GU][NQ + 1];
+            int kk[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
-                const int i = i0 + 64 * u;
-                a[u] = rowdot(i < M ? i : M - 1, Uv, Xv, false);
+                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                kk[u] = stepof(i);
+                const int gi = ginv ? i - kk[u] * mk : i;
+#pragma unroll
+                for (int q = 0; q <= NQ; ++q) g[u][q] = Gp[(unsigned)(q * Mg + gi)];
             }
 #pragma unroll
-            for (int u = 0; u < GU; ++u)
-                if (i0 + 64 * u < M) hd[i0 + 64 * u] = a[u];
+            for (int u = 0; u < GU; ++u) {
+                const V4 *x = (const V4 *)(Xv + (int64_t)kk[u] * NXC);
+                const V4 uq = *(const V4 *)(Uv + (int64_t)kk[u] * 4);
+                T acc = g[u][NQ][0] * uq[0] + g[u][NQ][1] * uq[1] + g[u][NQ][2] * uq[2] + g[u][NQ][3] * uq[3];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const V4 xq = x[q];
+                    acc += g[u][q][0] * xq[0] + g[u][q][1] * xq[1] + g[u][q][2] * xq[2] + g[u][q][3] * xq[3];
+                }
+                if (i0 + 64 * u < M) hd[i0 + 64 * u] = acc;
+            }
         }
     };
     // the violated row farthest from its hyperplane (active rows sit at s = 0 exactly, rows without a bound at ~1e30:
@@ -539,7 +550,13 @@ __global__ void __launch_bounds__(64)
         s0[i] = sv;
         sl[i] = sv;
         thr[i] = tol + tol * (T)fabs((double)ev);
-        const T nn = rowdot(i, nullptr, nullptr, true);
+        const int gi = ginv ? r : i;
+        T nn = T(0);
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) {
+            const V4 g = Gp[(unsigned)(q * Mg + gi)];
+            nn += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+        }
         invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
         rowslot[i] = -1;
     }
@@ -569,7 +586,7 @@ __global__ void __launch_bounds__(64)
             const int kp = bi / mk, rp = bi - kp * mk;
             // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room
             const int ps = phys[nq];
-            T *Vp = Vs + (int64_t)ps * nvar, *hp = Hs + (int64_t)ps * M;
+            T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
             {
                 T addq = T(0);
                 if (lane < nx) {
@@ -641,26 +658,31 @@ __global__ void __launch_bounds__(64)
                 // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
                 nbest = INF;
                 nbi = 0x7fffffff;
-                for (int i0 = lane; i0 < M; i0 += 64 * GU) {
-                    int idx[GU];
-                    T z[GU];
+                for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                    unsigned idx[SU];
+                    int rs[SU];
+                    T z[SU], so[SU], iv[SU], th[SU];
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        idx[u] = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                    for (int u = 0; u < SU; ++u) {
+                        idx[u] = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                         z[u] = hp[idx[u]];
+                        so[u] = sl[idx[u]];
+                        iv[u] = invn[idx[u]];
+                        th[u] = thr[idx[u]];
+                        rs[u] = rowslot[idx[u]];
                     }
                     for (int a = 0; a < nq; ++a) {
                         const T ra = rv[a];
                         const T *ha = Hs + (int64_t)phys[a] * M;
 #pragma unroll
-                        for (int u = 0; u < GU; ++u) z[u] -= ra * ha[idx[u]];
+                        for (int u = 0; u < SU; ++u) z[u] -= ra * ha[idx[u]];
                     }
 #pragma unroll
-                    for (int u = 0; u < GU; ++u) {
-                        const int i = idx[u];
-                        const T v = (rowslot[i] >= 0) ? T(0) : sl[i] + t * z[u];
-                        const T sc = v * invn[i];
-                        const bool viol = v < -thr[i] && i != bi;
+                    for (int u = 0; u < SU; ++u) {
+                        const int i = (int)idx[u];
+                        const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[u];
+                        const T sc = v * iv[u];
+                        const bool viol = v < -th[u] && i != bi;
                         if (i0 + 64 * u < M) {
                             sl[i] = v;
                             if (viol && sc < nbest) {
@@ -741,32 +763,34 @@ __global__ void __launch_bounds__(64)
         // ================================================================= primal point, verification
         // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
         T *ou = (T *)ka.U + prob * (int64_t)nvar;
-        for (int i = lane; i < nvar; i += 64) {
+        for (int i = lane; i < nv4; i += 64) {
             T u = U0[i];
-            for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nvar + i];
-            ou[i] = u;
+            for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
+            if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
         }
         bool dirty = false;
-        for (int i0 = lane; i0 < M; i0 += 64 * GU) {
-            int idx[GU];
-            T fr[GU];
+        for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+            unsigned idx[SU];
+                    int rs[SU];
+            T fr[SU], th[SU];
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                idx[u] = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+            for (int u = 0; u < SU; ++u) {
+                idx[u] = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                 fr[u] = s0[idx[u]];
+                th[u] = thr[idx[u]];
+                rs[u] = rowslot[idx[u]];
             }
             for (int a = 0; a < nq; ++a) {
                 const T la = lamv[a];
                 const T *ha = Hs + (int64_t)phys[a] * M;
 #pragma unroll
-                for (int u = 0; u < GU; ++u) fr[u] += la * ha[idx[u]];
+                for (int u = 0; u < SU; ++u) fr[u] += la * ha[idx[u]];
             }
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int i = idx[u];
-                const bool act = rowslot[i] >= 0;
-                if (!act && !(fr[u] >= T(-4) * thr[i])) dirty = true;
-                if (i0 + 64 * u < M) sl[i] = act ? T(0) : fr[u];
+            for (int u = 0; u < SU; ++u) {
+                const bool act = rs[u] >= 0;
+                if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
+                if (i0 + 64 * u < M) sl[idx[u]] = act ? T(0) : fr[u];
             }
         }
         dirty = __ballot(dirty) != 0ull;
@@ -798,6 +822,12 @@ __global__ void __launch_bounds__(64)
 }
 
 // ------------------------------------------------------------ host side
+static bool g_invariant(const KernelArgs &ka)
+{
+    // (a size query carries no operands: it gets the larger, per-step layout)
+    return (ka.C.ptr || ka.D.ptr) && (!ka.C.ptr || ka.C.step_stride == 0) && (!ka.D.ptr || ka.D.step_stride == 0);
+}
+
 bool stagew_supported(const KernelArgs &ka, int dtype)
 {
     return (dtype == MPCQP_F64 || dtype == MPCQP_F32) && ka.nx >= 2 && ka.nx <= 16 && ka.nu >= 1 && ka.nu <= NU && ka.mk >= 1;
@@ -805,12 +835,12 @@ bool stagew_supported(const KernelArgs &ka, int dtype)
 
 size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 {
-    return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, dtype == MPCQP_F64 ? 8 : 4).total;
+    return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), dtype == MPCQP_F64 ? 8 : 4).total;
 }
 
 template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
-    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, sizeof(T));
+    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T));
     const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 3 * 4 * LD + 16 + 16 + 16 + 8);
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 32;
     auto kern = mpcqp_stagew_kernel<T, NXC>;
