@@ -151,7 +151,7 @@ __device__ __forceinline__ double rl(double v, int j)
 using namespace stagew;
 
 template <typename T, int NXC>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 1)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
