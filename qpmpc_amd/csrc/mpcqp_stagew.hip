@@ -7,11 +7,13 @@
 // longer fit a lane's registers:
 //   * RICCATI RECURSION: the step's matrices (P, A_k, A_k', P A, A_cl, ...) live in LDS as 16 x 16 tiles and every
 //     product runs on the matrix cores (one 16x16x4 MFMA per chunk of 4 of the inner dimension).
-//   * SWEEPS of the LQR solve: serial over the horizon and latency-bound, so a step has NO LDS traffic and NO barrier:
-//     lane c < 16 holds row c of the step's matrix (A_cl' going backward, A_cl going forward), lanes 16..19 the rows
-//     of the input-sized one (B', K); the running vector sits in one register of lanes 0..nx-1 and its entries are read
-//     with v_readlane into scalar operands of the lanes' FMA chains. The rows come from per-step records the factor
-//     wrote in exactly that order (two to four 16-byte loads per lane), requested D steps ahead into a register ring.
+//   * SWEEPS of the LQR solve: serial over the horizon and latency-bound, so a step is nothing but a short chain of
+//     MFMAs: the costate / state is a 16-vector held the way the matrix cores take a B operand (component 4 q + g in
+//     register q of the lanes of row group g), the step's matrix comes from a per-step record the factor wrote in
+//     A-operand order (64 consecutive values per MFMA), with its rows permuted so that the product lands in B-operand
+//     order again -- no shuffles, no LDS, no barrier between the steps. The matrices are stacked so that one product
+//     gives everything a step needs: backward [A_cl' ; -S^-1 B'] p -> (p_k, ff_k); forward [[A_cl, B], [-K, I]] (x, ff)
+//     -> (x_{k+1}, u_k). Records are requested D steps ahead into a register ring.
 //   * ACTIVE SET: every active row a keeps V_a = P^-1 g_a' (inputs only) and h_a = G V_a (all m rows), so an iteration
 //     after the candidate's two sweeps is m-long AXPYs over coalesced arrays: c_a = h_p[row a], slack update
 //     s += t (h_p - sum r_a h_a). Slots are addressed through a permutation, nothing is copied when rows enter or leave.
@@ -32,11 +34,11 @@ namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
-constexpr int D = 4;    // the sweeps request their records this many steps ahead
+constexpr int D = 8;    // the sweeps request their records this many steps ahead
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Rb, Rf, Kt, ff, U0, X0, Xp, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
-    int maxq, rbs, rfs, mg;
+    int64_t Mb, Mf, KS, ff, U0, Zp, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
+    int maxq, mg;
 };
 
 // nxc: nx rounded up to a multiple of 4 (the kernel's compile-time row length)
@@ -54,18 +56,17 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     };
     const int nxc = nxc_of(nx);
     const int64_t m = (int64_t)N * mk;
-    // per-step records of the sweeps: 20 rows of nxc (lanes 0..15: A_cl' | A_cl, lanes 16..19: B' | K), then S^-1 | B
-    w.rbs = 20 * nxc + 16;
-    w.rfs = 20 * nxc + 64;
-    w.Rb = take((int64_t)N * w.rbs);
-    w.Rf = take((int64_t)N * w.rfs);
-    w.Kt = take((int64_t)N * nx * nu);
+    // per-step records of the sweeps, in MFMA A-operand order: nq (backward) and nq + 1 (forward) chunks of 64 values
+    // for each of the na row blocks of the stacked matrix (one when nxc + 4 <= 16)
+    const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
+    w.Mb = take((int64_t)N * na * nq * 64);
+    w.Mf = take((int64_t)N * na * (nq + 1) * 64);
+    w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
     w.ff = take((int64_t)N * 4);
-    w.U0 = take((int64_t)N * 4);    // input / state trajectories in rows of 4 / nxc entries, zero-padded
-    w.X0 = take((int64_t)N * nxc);
-    w.Xp = take((int64_t)N * nxc);
+    w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
+    w.Zp = take((int64_t)N * (nxc + 4));       // (x_k, u_k) of the latest forward sweep, in B-operand order
     w.mg = ginv ? mk : (int)m;
-    w.Gp = take((int64_t)(nxc + 4) * w.mg);  // [C | D] in quarter-rows: Gp[q][row] is a 4-vector, q < nxc / 4 + 1
+    w.Gp = take((int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zp's rows, as four-vectors: Gp[j][row], j <= nxc / 4
     w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
@@ -114,11 +115,14 @@ template <> struct Mfma<float> {
     using V = __attribute__((ext_vector_type(4))) float;
     static __device__ __forceinline__ V run(float a, float b, V c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int pg, int t) { return 4 * pg + t; }
+    // the row of the stacked matrix an A-operand row must hold for the product to come out in B-operand order
+    static __device__ __forceinline__ int rowmap(int i) { return 4 * (i & 3) + (i >> 2); }
 };
 template <> struct Mfma<double> {
     using V = __attribute__((ext_vector_type(4))) double;
     static __device__ __forceinline__ V run(double a, double b, V c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ int row(int pg, int t) { return pg + 4 * t; }
+    static __device__ __forceinline__ int rowmap(int i) { return i; }
 };
 
 // C[r][c] = alpha sum_k A[r][k] B[k][c] (+ beta Add[r][c]) on the matrix cores: one MFMA per chunk of 4 along k,
@@ -161,19 +165,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     const int64_t prob = blockIdx.x;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int M = N * mk, nvar = N * nu, nv4 = N * 4;
-    const bool has = lane < 20, lo = lane < 16;  // lanes holding a row of a sweep record
+    constexpr int NQ = NXC / 4;             // quarters of the state
+    constexpr bool STACK = NXC <= 12;       // the input-sized rows fit under the state-sized ones in one 16-row block
+    constexpr int NA = STACK ? 1 : 2;       // row blocks of the stacked matrices
+    constexpr int NB = NA * NQ, NF = NA * (NQ + 1);  // record values per lane and step, backward / forward
+    constexpr int ZL = NXC + 4;             // a row of Zp: position g (NQ + 1) + q holds x[4 q + g] (q < NQ), u[g] (q = NQ)
+    const bool col0 = c16 == 0;             // the lanes of right-hand side 0
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
     T *Pm = (T *)stagew_smem, *PAm = Pm + 16 * LD, *Mm = PAm + 16 * LD, *Am = Mm + 16 * LD, *Atm = Am + 16 * LD;
     T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
-    T *Km = BPAm + 4 * LD, *Sm = Km + 4 * LD, *Sim = Sm + 16, *vec = Sim + 16, *tv = vec + 16;
-    T *cv = tv + 8, *rv = cv + maxq, *lamv = rv + maxq;
+    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *Sim = Sm + 16, *cst = Sim + 16;  // cst: 0, 1
+    T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq;
     int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
-    T *Rb = ws + wl.Rb, *Rf = ws + wl.Rf, *Kt = ws + wl.Kt, *ffv = ws + wl.ff;
-    T *U0 = ws + wl.U0, *X0 = ws + wl.X0, *Xp = ws + wl.Xp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
+    T *Mb = ws + wl.Mb, *Mf = ws + wl.Mf, *KS = ws + wl.KS, *ffv = ws + wl.ff;
+    T *U0 = ws + wl.U0, *Zp = ws + wl.Zp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
     T *thr = ws + wl.thr;
     V4 *Gp = (V4 *)(ws + wl.Gp);
     const int Mg = wl.mg;
@@ -212,10 +221,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int i = 8; i < 16; ++i) stamp[i] = 0;
 
     // ================================================================= factor: Riccati recursion in LDS
-    for (int i = lane; i < (int)(vec - Pm) + 24; i += 64) Pm[i] = T(0);  // every tile, vec and tv
+    for (int i = lane; i < (int)(cst - Pm) + 8; i += 64) Pm[i] = T(0);  // every tile and the constants
     wsync();
     if (lane < nx) Pm[lane * LD + lane] = wt;
+    if (lane == 0) cst[1] = T(1);
     wsync();
+    // where this lane's record values come from (LDS offsets from Pm; fixed along the horizon): entry (blk, kk) of a
+    // record is the stacked matrix at row rowmap(lane % 16) of block blk, column 4 kk + lane / 16
+    int srcb[NB], srcf[NF];
+    T sgnf[NF];
+    {
+        const int zero = (int)(cst - Pm), one = zero + 1, mrow = Mfma<T>::rowmap(c16);
+#pragma unroll
+        for (int blk = 0; blk < NA; ++blk) {
+#pragma unroll
+            for (int kk = 0; kk <= NQ; ++kk) {
+                const int col = 4 * kk + pg;
+                // the input-sized row this (block, row) is, or -1
+                const int irow = (blk == 0) ? ((STACK && mrow >= NXC && mrow < NXC + 4) ? mrow - NXC : -1) : (mrow < 4 ? mrow : -1);
+                if (kk < NQ) {  // backward: [Acl' ; F], F = -S^-1 B'
+                    int o = zero;
+                    if (blk == 0 && mrow < NXC) o = (int)(Acm - Pm) + col * LD + mrow;
+                    if (irow >= 0) o = (int)(Fm - Pm) + irow * LD + col;
+                    srcb[blk * NQ + kk] = o;
+                }
+                {  // forward: [[Acl, B], [-K, I]]
+                    int o = zero;
+                    T sg = T(1);
+                    if (blk == 0 && mrow < NXC) o = col < NXC ? (int)(Acm - Pm) + mrow * LD + col : (int)(Bm - Pm) + mrow * 4 + (col - NXC);
+                    if (irow >= 0) {
+                        if (col < NXC) {
+                            o = (int)(Km - Pm) + irow * LD + col;
+                            sg = T(-1);
+                        } else {
+                            o = (col - NXC == irow) ? one : zero;
+                        }
+                    }
+                    srcf[blk * (NQ + 1) + kk] = o;
+                    sgnf[blk * (NQ + 1) + kk] = sg;
+                }
+            }
+        }
+    }
     // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step
     T pfa[4], pfb;
     int offA[4], offAt[4], offB = -1, offBt = 0, offK = -1;  // LDS offsets of this lane's entries (-1: none)
@@ -298,34 +345,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         }
         wsync();
         mm_t<T, 4, LD, LD, 4, 16, 4>(Km, Sim, BPAm, T(1), nullptr, T(0), pg, c16);     // K = S^-1 B'PA
+        mm_t<T, 4, LD, LD, 4, 16, 4>(Fm, Sim, Btm, T(-1), nullptr, T(0), pg, c16);     // F = -S^-1 B'
         wsync();
         mm_t<T, 4, LD, LD, 16, 16, 4>(Acm, Bm, Km, T(-1), Am, T(1), pg, c16);           // Acl = A - B K
         mm_t<T, 4, LD, LD, 16, 16, 4>(Mm, PBm, Km, T(-1), PAm, T(1), pg, c16);          // M = P Acl = PA - PB K
         wsync();
         mm_t<T, LD, LD, LD, 16, 16, NXC>(PAm, Atm, Mm, T(1), nullptr, T(0), pg, c16);   // A' P Acl (into the PA tile)
-        // factors to the workspace: the sweeps' records (see the header) -- lane l < 20 writes row l of both -- and K'
+        // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
         // (read at the candidate row's step)
         {
-            T *rb = Rb + (int64_t)k * wl.rbs, *rf = Rf + (int64_t)k * wl.rfs;
-            if (has) {
-                const T *cb = lo ? Acm + lane : Bm + (lane - 16);                 // column: Acl[.][c] | B[.][i]
-                const T *cf = lo ? Acm + lane * LD : Km + (lane - 16) * LD;       // row:    Acl[c][.] | K[i][.]
-                const int sb = lo ? LD : 4;
+            T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
 #pragma unroll
-                for (int q = 0; q < NXC / 4; ++q) {
-                    V4 vb, vf;
+            for (int e = 0; e < NB; ++e) mb[e * 64] = Pm[srcb[e]];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        vb[e] = cb[(4 * q + e) * sb];
-                        vf[e] = cf[4 * q + e];
-                    }
-                    ((V4 *)(rb + lane * NXC))[q] = vb;
-                    ((V4 *)(rf + lane * NXC))[q] = vf;
-                }
-            }
-            if (lo) rb[20 * NXC + lane] = Sim[lane];  // S^-1[i][l]
-            rf[20 * NXC + lane] = Bm[lane];           // B[c][i]
-            if (offK >= 0) Kt[(int64_t)k * nx * nu + lane] = Km[offK];
+            for (int e = 0; e < NF; ++e) mf[e * 64] = sgnf[e] * Pm[srcf[e]];
+            T *ks = KS + (int64_t)k * (nx * nu + 16);
+            if (offK >= 0) ks[lane] = Km[offK];
+            if (lane < 16) ks[nx * nu + lane] = Sim[lane];
         }
         wsync();
         // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
@@ -346,35 +382,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     tick(1);
 
     // ================================================================= the LQR solve: two serial sweeps
-    // backward: p_k = g_k + Acl_k' p_{k+1} ; ff_k = -S_k^-1 (B_k' p_{k+1} + r_k). Linear costs: the tracking terms when
-    // `track`, else row (kq, .) of G: `addq` holds, per lane, -C[c] + (K_kq' D)_c (lanes < nx) and -D[i] (lanes 16 + i);
-    // the costate of a single row is zero after its step, so that sweep starts at kq.
-    // (every lane issues the loads -- lanes past 19 re-read row 0 -- so that the ring carries no divergent branch and the
-    // waits stay counted per step)
-    const int rrow = has ? lane : 0, srow = lane & 3, crow = lane < nx ? lane : nx - 1;
-    auto backward = [&](auto trackc, int kq, T addq) {
+    // The running vector is an MFMA B operand: register q of the lanes of row group g = lane / 16 holds component
+    // 4 q + g (columns: right-hand sides; column 0 = lanes with lane % 16 == 0 is the one in use).
+    using MV = typename Mfma<T>::V;
+    const T *tp = stageQ ? gtgt : Mb;  // (a readable address when there are no targets)
+    // backward: (p_k, ff_k) = [Acl_k' ; F_k] p_{k+1} (+ the step's linear cost). With `track` the tracking costs from p_N;
+    // else the costate of one row of G, which is zero after its step kq: `start` is (p_kq, ff_kq) and the sweep runs
+    // over k < kq.
+    auto backward = [&](auto trackc, int kq, MV start, T ffstart) {
         constexpr bool track = decltype(trackc)::value;
         const bool tgt = track && stageQ;
-        const T *tp = tgt ? gtgt : Rb;  // (a readable address when there are no targets)
         const T wxq = (T)ka.wx;
-        T pv = (track && termQ && lane < nx) ? -(T)ka.wt * ggoal[lane] : T(0);  // p_N
-        const int kstart = track ? N - 1 : kq;
-        V4 rec[D][NXC / 4], sv[D];
-        T tg[D];
+        MV st = start;
+        const int kstart = track ? N - 1 : kq - 1;
+        if (!track && col0) ffv[(int64_t)kq * 4 + pg] = ffstart;
+        T rec[D][NB], tg[D][NQ];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            sv[d] = V4{T(0), T(0), T(0), T(0)};
-            tg[d] = T(0);
 #pragma unroll
-            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = V4{T(0), T(0), T(0), T(0)};
+            for (int e = 0; e < NB; ++e) rec[d][e] = T(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tg[d][q] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *rb = Rb + (int64_t)k * wl.rbs;
-            const V4 *p = (const V4 *)(rb + rrow * NXC);
+            const T *mb = Mb + (int64_t)k * (NB * 64) + lane;
 #pragma unroll
-            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = p[q];
-            sv[d] = *(const V4 *)(rb + 20 * NXC + srow * 4);
-            if (track) tg[d] = tp[(int64_t)k * nx + crow];
+            for (int e = 0; e < NB; ++e) rec[d][e] = mb[e * 64];
+            if (track) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) tg[d][q] = tp[(int64_t)k * nx + (4 * q + pg < nx ? 4 * q + pg : nx - 1)];
+            }
         };
         // (requests are unconditional -- clamped at the end of the sweep -- so that every path carries the same number
         // of loads in flight and the compiler can wait for exactly the oldest)
@@ -384,20 +421,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             __builtin_amdgcn_sched_barrier(0);  // oldest first: the loop waits for them in this order
         }
         auto step = [&](int d, int k, bool again) {
-            T a0 = T(0), a1 = T(0);
+            MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int j = 0; j < NXC; j += 2) {
-                a0 += rec[d][j / 4][j % 4] * rl(pv, j);
-                a1 += rec[d][(j + 1) / 4][(j + 1) % 4] * rl(pv, j + 1);
+            for (int kk = 0; kk < NQ; ++kk) {
+                a0 = Mfma<T>::run(rec[d][kk], st[kk], a0);
+                if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + kk], st[kk], a1);
             }
-            T acc = a0 + a1;  // lanes < 16: (Acl' p)_c ; lanes 16 + i: (B' p)_i
-            if (k == kq) acc += addq;
-            if (tgt && k >= 1) acc -= (lane < nx) ? wxq * tg[d] : T(0);
-            T f = T(0);
+            if (tgt && k >= 1 && col0) {
 #pragma unroll
-            for (int l = 0; l < NU; ++l) f -= sv[d][l] * rl(acc, 16 + l);
-            if (!lo && has) ffv[(int64_t)k * 4 + (lane - 16)] = f;
-            pv = acc;
+                for (int q = 0; q < NQ; ++q)
+                    if (4 * q + pg < nx) a0[q] -= wxq * tg[d][q];
+            }
+            if (col0) ffv[(int64_t)k * 4 + pg] = STACK ? a0[NQ] : a1[0];
+            st = a0;
             if (again) req(d, k - D >= 0 ? k - D : 0);
         };
         // full groups of D steps (every step re-requests: same loads in flight on every path), then the remainder
@@ -411,26 +447,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int d = 0; d < D - 1; ++d)
             if (k - d >= 0) step(d, k - d, false);
     };
-    // forward: u_k = -K_k x_k + ff_k, x_{k+1} = Acl_k x_k + B_k ff_k from x_0 = xs (ff_k = 0 for k > kff); writes the
-    // inputs to Uo[k][0..3] and the states to Xo[k][0..NXC-1]
-    auto forward = [&](const T *xs, int kff, T *Uo, T *Xo) {
-        T xv = (xs && lane < nx) ? xs[lane] : T(0);
-        V4 rec[D][NXC / 4], b4[D];
-        T ffk[D];
+    // forward: (x_{k+1}, u_k) = [[Acl_k, B_k], [-K_k, I]] (x_k, ff_k) from x_0 = xs (ff_k = 0 for k > kff); writes the
+    // inputs to Uo[k][0..3] and (x_k, u_k) to Zp[k]
+    auto forward = [&](const T *xs, int kff, T *Uo) {
+        T z[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) z[q] = (xs && col0 && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
+        T rec[D][NF], ffr[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            b4[d] = V4{T(0), T(0), T(0), T(0)};
-            ffk[d] = T(0);
+            ffr[d] = T(0);
 #pragma unroll
-            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = V4{T(0), T(0), T(0), T(0)};
+            for (int e = 0; e < NF; ++e) rec[d][e] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *rf = Rf + (int64_t)k * wl.rfs;
-            const V4 *p = (const V4 *)(rf + rrow * NXC);
+            const T *mf = Mf + (int64_t)k * (NF * 64) + lane;
 #pragma unroll
-            for (int q = 0; q < NXC / 4; ++q) rec[d][q] = p[q];
-            b4[d] = *(const V4 *)(rf + 20 * NXC + (lane & 15) * 4);
-            ffk[d] = ffv[(int64_t)k * 4 + srow];
+            for (int e = 0; e < NF; ++e) rec[d][e] = mf[e * 64];
+            ffr[d] = ffv[(int64_t)k * 4 + pg];
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -438,20 +472,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             __builtin_amdgcn_sched_barrier(0);
         }
         auto step = [&](int d, int k, bool again) {
-            T a0 = T(0), a1 = T(0);
+            const T ffd = (k <= kff && col0) ? ffr[d] : T(0);
+            MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-            for (int j = 0; j < NXC; j += 2) {
-                a0 += rec[d][j / 4][j % 4] * rl(xv, j);
-                a1 += rec[d][(j + 1) / 4][(j + 1) % 4] * rl(xv, j + 1);
+            for (int kk = 0; kk <= NQ; ++kk) {
+                const T b = kk < NQ ? z[kk < NQ ? kk : 0] : ffd;
+                a0 = Mfma<T>::run(rec[d][kk], b, a0);
+                if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
             }
-            const T acc = a0 + a1;  // lanes < 16: (Acl x)_c ; lanes 16 + i: (K x)_i
-            const T ffd = (k <= kff) ? ffk[d] : T(0);
-            T bff = T(0);
+            const T u = STACK ? a0[NQ] : a1[0];
+            if (col0) {
+                T *zr = Zp + (int64_t)k * ZL + pg * (NQ + 1);
 #pragma unroll
-            for (int l = 0; l < NU; ++l) bff += b4[d][l] * rl(ffd, 16 + l);
-            if (lane < NXC) Xo[(int64_t)k * NXC + lane] = xv;  // (zero past nx, past nu)
-            if (!lo && has) Uo[(int64_t)k * 4 + (lane - 16)] = ffd - acc;
-            xv = acc + bff;
+                for (int q = 0; q < NQ; ++q) zr[q] = z[q];
+                zr[NQ] = u;
+                Uo[(int64_t)k * 4 + pg] = u;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) z[q] = a0[q];
             if (again) req(d, k + D < N ? k + D : N - 1);
         };
         int k = 0;
@@ -469,31 +507,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     constexpr int SU = 8;                       // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
-    constexpr int NQ = NXC / 4;
-    // [C | D] packed once: row i (or r, when they do not change along the horizon) as NQ + 1 four-vectors, zero-padded,
-    // quarter-major so that the lanes of a pass read side by side
+    // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
+    // four-vectors, zero-padded, vector-major so that the lanes of a pass read side by side
     for (int i = lane; i < Mg; i += 64) {
         const int k = stepof(i), r = i - k * mk;
         V4 g[NQ + 1];
 #pragma unroll
-        for (int q = 0; q <= NQ; ++q) g[q] = V4{T(0), T(0), T(0), T(0)};
-        if (gC) {
-            const T *c = gC + k * sC + r * nx;
-#pragma unroll
-            for (int j = 0; j < NXC; ++j)
-                if (j < nx) g[j / 4][j % 4] = c[j];
-        }
-        if (gD) {
-            const T *dd = gD + k * sD + r * nu;
-#pragma unroll
-            for (int j = 0; j < NU; ++j)
-                if (j < nu) g[NQ][j] = dd[j];
+        for (int pos = 0; pos < ZL; ++pos) {
+            const int gq = pos / (NQ + 1), q = pos - gq * (NQ + 1);  // position g (NQ + 1) + q
+            T v = T(0);
+            if (q < NQ) {
+                if (gC && 4 * q + gq < nx) v = gC[k * sC + r * nx + 4 * q + gq];
+            } else if (gD && gq < nu) {
+                v = gD[k * sD + r * nu + gq];
+            }
+            g[pos / 4][pos % 4] = v;
         }
 #pragma unroll
         for (int q = 0; q <= NQ; ++q) Gp[(int64_t)q * Mg + i] = g[q];
     }
-    // hd[i] = g_i . (U, X) = C_k[r] x_k + D_k[r] u_k : the rows' quarter-vectors of GU rows are requested together
-    auto gmul = [&](const T *Uv, const T *Xv, T *hd) {
+    // hd[i] = g_i . (x_k, u_k) of the latest forward sweep (Zp): the four-vectors of GU rows are requested together
+    auto gmul = [&](T *hd) {
         for (int i0 = lane; i0 < M; i0 += 64 * GU) {
             V4 g[GU][NQ + 1];
             int kk[GU];
@@ -507,13 +541,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
-                const V4 *x = (const V4 *)(Xv + (int64_t)kk[u] * NXC);
-                const V4 uq = *(const V4 *)(Uv + (int64_t)kk[u] * 4);
-                T acc = g[u][NQ][0] * uq[0] + g[u][NQ][1] * uq[1] + g[u][NQ][2] * uq[2] + g[u][NQ][3] * uq[3];
+                const V4 *zr = (const V4 *)(Zp + (int64_t)kk[u] * ZL);
+                T acc = T(0);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const V4 xq = x[q];
-                    acc += g[u][q][0] * xq[0] + g[u][q][1] * xq[1] + g[u][q][2] * xq[2] + g[u][q][3] * xq[3];
+                for (int q = 0; q <= NQ; ++q) {
+                    const V4 zq = zr[q];
+                    acc += g[u][q][0] * zq[0] + g[u][q][1] * zq[1] + g[u][q][2] * zq[2] + g[u][q][3] * zq[3];
                 }
                 if (i0 + 64 * u < M) hd[i0 + 64 * u] = acc;
             }
@@ -536,14 +569,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
 
     // ================================================================= unconstrained minimiser, slacks
     tick(2);
-    backward(std::true_type{}, -1, T(0));
+    {
+        MV pN = {T(0), T(0), T(0), T(0)};
+        if (termQ && col0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (4 * q + pg < nx) pN[q] = -(T)ka.wt * ggoal[4 * q + pg];
+        }
+        backward(std::true_type{}, -1, pN, T(0));
+    }
     wsync();
     tick(3);
-    forward(gx0, N, U0, X0);
+    forward(gx0, N, U0);
     wsync();
     tick(4);
     const T tol = ka.tol;
-    gmul(U0, X0, sl);
+    gmul(sl);
     for (int i = lane; i < M; i += 64) {
         const int k = stepof(i), r = i - k * mk;
         const T ev = ge[k * sE + r], sv = ev - sl[i];
@@ -588,24 +629,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             const int ps = phys[nq];
             T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
             {
-                T addq = T(0);
-                if (lane < nx) {
-                    addq = gC ? -gC[kp * sC + rp * nx + lane] : T(0);
-                    if (gD) {
-                        const T *Kk = Kt + ((int64_t)kp * nx + lane) * nu, *dd = gD + kp * sD + rp * nu;
-                        for (int i = 0; i < nu; ++i) addq += Kk[i] * dd[i];  // - K' r with r = -D[rp]
+                // (p_kp, ff_kp) of row (kp, rp): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above kp is zero)
+                MV st = {T(0), T(0), T(0), T(0)};
+                T ffs = T(0);
+                if (col0) {
+                    const T *ks = KS + (int64_t)kp * (nx * nu + 16);
+                    const T *dd = gD ? gD + kp * sD + rp * nu : nullptr;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = 4 * q + pg;
+                        if (c < nx) {
+                            T v = gC ? -gC[kp * sC + rp * nx + c] : T(0);
+                            if (dd)
+                                for (int i = 0; i < nu; ++i) v += ks[c * nu + i] * dd[i];
+                            st[q] = v;
+                        }
                     }
-                } else if (lane >= 16 && lane < 16 + nu) {
-                    addq = gD ? -gD[kp * sD + rp * nu + (lane - 16)] : T(0);
+                    if (dd && pg < nu)
+                        for (int l = 0; l < nu; ++l) ffs += ks[nx * nu + pg * 4 + l] * dd[l];
                 }
-                backward(std::false_type{}, kp, addq);
+                backward(std::false_type{}, kp, st, ffs);
             }
             wsync();
             tacc(9);
-            forward(nullptr, kp, Vp, Xp);
+            forward(nullptr, kp, Vp);
             wsync();
             tacc(10);
-            gmul(Vp, Xp, hp);
+            gmul(hp);
             wsync();
             tacc(11);
             const T dpp = hp[bi];
@@ -841,7 +891,7 @@ size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T));
-    const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 3 * 4 * LD + 16 + 16 + 16 + 8);
+    const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16 + 8);
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 32;
     auto kern = mpcqp_stagew_kernel<T, NXC>;
     if (lds > 48 * 1024) {
