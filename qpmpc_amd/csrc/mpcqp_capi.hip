@@ -111,6 +111,24 @@ bool use_stage_auto(const KernelArgs &ka, int dtype)
            ka.m >= 1;
 }
 
+// Fused build+solve of problems that do NOT fit the on-chip condensed kernels goes to the wide stage-wise kernel
+// (mpcqp_stagew.hip) when the system fits it (nx <= 16, nu <= 4): same minimiser (tests), 7-10x the HBM-resident
+// condensed path at BASELINE config 5's size, and float32 errors ~300x smaller (nothing is squared into P). Its slots
+// hold min(n, m, 256) active rows -- every row that can be active at once where the condensed path exists (n <= 256).
+bool fits_on_chip(const KernelArgs &ka, bool stepA, bool stepB, int mode, int dtype);
+bool use_stagew_auto(const KernelArgs &ka, int dtype)
+{
+    const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
+                              MPCQP_OPT_ONE_PER_WAVE;
+    return !(ka.opt_flags & override_bits) && !ka.warm_state && stagew_supported(ka, dtype) && ka.m >= 1 &&
+           !fits_on_chip(ka, true, true, MODE_FUSED, dtype);
+}
+int stagew_auto_maxq(const KernelArgs &ka)
+{
+    const int q = ka.n < ka.m ? ka.n : ka.m;
+    return q < 256 ? q : 256;
+}
+
 bool use_bigsolve(int n, int m, int dtype, int fl) { return !force_gws(fl) && m > 0 && bigsolve_supported(n, m, dtype); }
 
 // Per-problem solver scratch (elements) for QPs that do not fit the on-chip kernels.
@@ -277,7 +295,10 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
             const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
             if (sw > v) v = sw;
         }
-        if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
+        if (for_solve && use_stagew_auto(ka, dims->dtype)) {
+            const size_t sw = stagew_ws_elems(ka, stagew_auto_maxq(ka), dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+            if (sw > v) v = sw;
+        } else if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
             if (big_supported(ka) && ka.n <= 256) {
                 const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
                 const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
@@ -435,6 +456,12 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     }
     if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
         return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
+    if (use_stagew_auto(ka, dims->dtype)) {
+        const int maxq = stagew_auto_maxq(ka);
+        const size_t need = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_stagew(ka, dims->dtype, maxq, batch, workspace, st);
+    }
     // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the
     // general solver with its arrays in the workspace as well
     if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;

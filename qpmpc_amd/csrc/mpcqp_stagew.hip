@@ -503,8 +503,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             if (k + d < N) step(d, k + d, false);
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
-    constexpr int GU = sizeof(T) == 4 ? 4 : 2;  // rows of G per lane in flight (NQ + 1 four-vectors each)
-    constexpr int SU = 8;                       // rows per lane in flight in the slack passes
+    constexpr int GU = 2;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
+    constexpr int SU = 4;                       // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
@@ -527,28 +527,53 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int q = 0; q <= NQ; ++q) Gp[(int64_t)q * Mg + i] = g[q];
     }
     // hd[i] = g_i . (x_k, u_k) of the latest forward sweep (Zp): the four-vectors of GU rows are requested together
+    // (when C, D are fixed along the horizon and mk divides 64, a lane meets the same row of [C | D] in every pass: it
+    // is loaded once and the passes only fetch the (x_k, u_k) rows, four of them in flight)
+    const bool ghoist = ginv && (64 % mk == 0);
+    auto gdot = [&](const V4 (&g)[NQ + 1], const V4 (&zq)[NQ + 1]) {
+        T acc = T(0);
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) acc += g[q][0] * zq[q][0] + g[q][1] * zq[q][1] + g[q][2] * zq[q][2] + g[q][3] * zq[q][3];
+        return acc;
+    };
     auto gmul = [&](T *hd) {
-        for (int i0 = lane; i0 < M; i0 += 64 * GU) {
-            V4 g[GU][NQ + 1];
-            int kk[GU];
+        if (ghoist) {
+            constexpr int ZU = 4;
+            V4 gfix[NQ + 1];
+            const int r = lane - (lane / mk) * mk;
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
-                kk[u] = stepof(i);
-                const int gi = ginv ? i - kk[u] * mk : i;
+            for (int q = 0; q <= NQ; ++q) gfix[q] = Gp[(unsigned)(q * Mg + r)];
+            for (int i0 = lane; i0 < M; i0 += 64 * ZU) {
+                V4 zq[ZU][NQ + 1];
 #pragma unroll
-                for (int q = 0; q <= NQ; ++q) g[u][q] = Gp[(unsigned)(q * Mg + gi)];
-            }
+                for (int u = 0; u < ZU; ++u) {
+                    const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                    const V4 *zr = (const V4 *)(Zp + (unsigned)(stepof(i) * ZL));
 #pragma unroll
-            for (int u = 0; u < GU; ++u) {
-                const V4 *zr = (const V4 *)(Zp + (int64_t)kk[u] * ZL);
-                T acc = T(0);
-#pragma unroll
-                for (int q = 0; q <= NQ; ++q) {
-                    const V4 zq = zr[q];
-                    acc += g[u][q][0] * zq[0] + g[u][q][1] * zq[1] + g[u][q][2] * zq[2] + g[u][q][3] * zq[3];
+                    for (int q = 0; q <= NQ; ++q) zq[u][q] = zr[q];
                 }
-                if (i0 + 64 * u < M) hd[i0 + 64 * u] = acc;
+#pragma unroll
+                for (int u = 0; u < ZU; ++u)
+                    if (i0 + 64 * u < M) hd[i0 + 64 * u] = gdot(gfix, zq[u]);
+            }
+        } else {
+            for (int i0 = lane; i0 < M; i0 += 64 * GU) {
+                V4 g[GU][NQ + 1], zq[GU][NQ + 1];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                    const int k = stepof(i);
+                    const int gi = ginv ? i - k * mk : i;
+                    const V4 *zr = (const V4 *)(Zp + (unsigned)(k * ZL));
+#pragma unroll
+                    for (int q = 0; q <= NQ; ++q) {
+                        g[u][q] = Gp[(unsigned)(q * Mg + gi)];
+                        zq[u][q] = zr[q];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+                    if (i0 + 64 * u < M) hd[i0 + 64 * u] = gdot(g[u], zq[u]);
             }
         }
     };
@@ -634,19 +659,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 T ffs = T(0);
                 if (col0) {
                     const T *ks = KS + (int64_t)kp * (nx * nu + 16);
-                    const T *dd = gD ? gD + kp * sD + rp * nu : nullptr;
+                    T dd[NU], cq[NQ], kq4[NQ][NU], si[NU];  // every load first, then the arithmetic
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) {
+                        dd[i] = (gD && i < nu) ? gD[kp * sD + rp * nu + i] : T(0);
+                        si[i] = (pg < nu && i < nu) ? ks[nx * nu + pg * 4 + i] : T(0);
+                    }
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const int c = 4 * q + pg;
-                        if (c < nx) {
-                            T v = gC ? -gC[kp * sC + rp * nx + c] : T(0);
-                            if (dd)
-                                for (int i = 0; i < nu; ++i) v += ks[c * nu + i] * dd[i];
-                            st[q] = v;
-                        }
+                        cq[q] = (gC && c < nx) ? gC[kp * sC + rp * nx + c] : T(0);
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * nu + i] : T(0);
                     }
-                    if (dd && pg < nu)
-                        for (int l = 0; l < nu; ++l) ffs += ks[nx * nu + pg * 4 + l] * dd[l];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        T v = -cq[q];
+#pragma unroll
+                        for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
+                        st[q] = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) ffs += si[i] * dd[i];
                 }
                 backward(std::false_type{}, kp, st, ffs);
             }
@@ -721,7 +755,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         th[u] = thr[idx[u]];
                         rs[u] = rowslot[idx[u]];
                     }
-                    for (int a = 0; a < nq; ++a) {
+                    int a = 0;
+                    for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
+                        const T ra = rv[a], rb = rv[a + 1];
+                        const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                        T va[SU], vb[SU];
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            va[u] = ha[idx[u]];
+                            vb[u] = hb[idx[u]];
+                        }
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
+                    }
+                    if (a < nq) {
                         const T ra = rv[a];
                         const T *ha = Hs + (int64_t)phys[a] * M;
 #pragma unroll
