@@ -48,7 +48,7 @@ CONFIGS = {
                      "fused build+solve; U/status all_gather timed separately"),
     5: dict(batch=8192, scaling="strong", dtype="f32",
             workload="synthetic LTV nx=12 nu=4 N=64 (n=256 m=1024) with input and state boxes, batch {b} strong-sharded "
-                     "over the GPUs, fp32, propagate + MFMA Gram + one-QP-per-workgroup active-set solve"),
+                     "over the GPUs, fp32, uncondensed stage-wise active-set kernel (Riccati factor + MFMA sweeps), one problem per wavefront"),
 }
 
 
@@ -367,12 +367,16 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
                 "kernel": "mpcqp_bigsolve_kernel<double, K_MID> (+ mpcqp_wip_advance, <2% of the step)",
                 "achieved_gbs": gbs, **common,
                 "note": "fp64 FMA/MFMA-bound by intensity (~100 flop/B); peak = AMD's fp64 vector=matrix figure"}
-    return {"bound": "mfma", "achieved": tfs, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP32_PEAK_TFLOPS,
-            "kernel": "mpcqp_propagate + mpcqp_gram_mfma_f32 + mpcqp_bigsolve<float> (three launches per step; "
-                      "per-kernel durations in profiles/)",
-            "achieved_gbs": gbs, **common,
-            "note": "algorithmic dense flops (the reference's Gram is a full dense product; the kernels skip the causal "
-                    "and symmetric zeros) over the duration of the step's three launches; exact-f32 MFMA peak"}
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "kernel": "mpcqp_stagew_kernel<float, 12> (one launch per step: Riccati factor, LQR sweeps and the dual "
+                      "active set of one problem per wavefront; the condensed QP is never formed)",
+            "dense_equivalent_tflops": tfs, **common,
+            "note": "achieved = the problem's inputs + outputs (SURVEY 8d) over the launch; the kernel's own HBM traffic "
+                    "is ~20x that (per-step factor records written once and re-read by every sweep, see "
+                    "traffic_from_profiles) and the serial sweeps are latency-bound, so the fraction is small. "
+                    "dense_equivalent_tflops prices the reference's dense condense + solve flops (which this path "
+                    "does not execute) over the same time -- above the 157 TFLOP/s fp32 MFMA peak, i.e. out of reach "
+                    "of any dense implementation"}
 
 
 def _accuracy(args, w, run):

@@ -113,6 +113,9 @@ typedef struct MpcqpProblem {
                                         otherwise hands 16 < n <= 128, nx <= 4, nu <= 2, float64 to the stage-wise
                                         kernel, which is faster there and returns the same minimiser)          */
 
+#define MPCQP_OPT_STAGE_WIDE 32   /* mpcqp_stagewise_solve_batch: take the wide kernel (nx <= 16, nu <= 4, MFMA
+                                     sweeps) also where the narrow one (nx <= 4, nu <= 2, float64) applies       */
+
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
     int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */

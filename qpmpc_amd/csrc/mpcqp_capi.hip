@@ -502,12 +502,13 @@ int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_
     KernelArgs ka;
     fill_args(ka, dims, nullptr);
     const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
-    if (stage_supported(ka, dims->dtype))
-        *bytes = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
-    else if (stagew_supported(ka, dims->dtype))
-        *bytes = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
-    else
-        return MPCQP_EUNSUPPORTED;
+    // (the query does not see MpcqpSolveOpts.flags: where both kernels apply it reports the larger workspace)
+    size_t a = 0, b = 0;
+    if (stage_supported(ka, dims->dtype)) a = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    if (stagew_supported(ka, dims->dtype)) b = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+    if (!a && !b && batch > 0) return MPCQP_EUNSUPPORTED;
+    if (!stage_supported(ka, dims->dtype) && !stagew_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    *bytes = a > b ? a : b;
     return 0;
 }
 
@@ -522,8 +523,9 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     if (batch == 0) return 0;
     KernelArgs ka;
     fill_args(ka, dims, problem);
-    const bool narrow = stage_supported(ka, dims->dtype);
+    bool narrow = stage_supported(ka, dims->dtype);
     if (!narrow && !stagew_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (opts && (opts->flags & MPCQP_OPT_STAGE_WIDE) && stagew_supported(ka, dims->dtype)) narrow = false;
     ka.U = U;
     ka.lam = lam;
     ka.status = status;

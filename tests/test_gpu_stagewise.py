@@ -183,3 +183,51 @@ def test_wide_stagewise_config5_dimensions_f64_and_f32():
     assert (np.abs(p64.U.cpu().numpy() - Uo) / scale).max() <= 1e-7
     assert (np.abs(p32.U.double().cpu().numpy() - Uo) / scale).max() <= 1e-3
     assert (np.abs(p32.U.double().cpu().numpy() - d32.U.double().cpu().numpy()) / scale).max() <= 2e-3
+
+
+def test_wide_kernel_equals_narrow_kernel_where_both_apply():
+    """MPCQP_OPT_STAGE_WIDE sends a small system (config 3's wheeled inverted pendulum, nx = 4, nu = 1, float64) through the
+    wide kernel (MFMA sweeps, packed [C | D]): same minimiser, same iteration counts as the narrow kernel."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(W.wip_batch(512, seed=11))
+    a = solve_mpc_batch(bp, formulation="stagewise", return_multipliers=True)
+    b = solve_mpc_batch(bp, formulation="stagewise", return_multipliers=True, flags=_capi.OPT_STAGE_WIDE)
+    torch.cuda.synchronize()
+    assert torch.equal(a.status, b.status) and (a.status == 0).all()
+    assert torch.equal(a.iters, b.iters) and int(a.iters.max()) >= 2
+    assert float((a.U - b.U).abs().max()) <= 1e-9 * max(1.0, float(a.U.abs().max()))
+    assert float((a.multipliers - b.multipliers).abs().max()) <= 1e-7 * max(1.0, float(a.multipliers.abs().max()))
+
+
+def test_large_problems_are_dispatched_to_the_stagewise_kernel_and_agree_with_the_condensed_path():
+    """mpcqp_build_solve_batch hands problems that do not fit the on-chip kernels to the wide stage-wise kernel;
+    MPCQP_OPT_FORCE_CONDENSED keeps the HBM-resident dense path. Both against the oracle; PreparedSolve(formulation=
+    'stagewise') reuses its workspace and returns the same plan as the one-shot call."""
+    from oracle.parallel import solve_workload_parallel
+    from qpmpc_amd import PreparedSolve, _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    w = W.synthetic_ltv_batch(64, seed=5)
+    Uo, _, sto, _ = solve_workload_parallel(w, shard_workload)
+    scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+    for dt, tol in ((torch.float64, 1e-7), (torch.float32, 1e-3)):
+        bp = W.to_batch_problem(w, dtype=dt)
+        auto = solve_mpc_batch(bp)
+        dense = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_CONDENSED)
+        explicit = solve_mpc_batch(bp, formulation="stagewise", max_active=256)
+        ps = PreparedSolve(bp, formulation="stagewise", max_active=256)
+        ps.launch()
+        ps.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(auto.U, explicit.U) and torch.equal(auto.iters, explicit.iters)  # the same kernel ran
+        assert torch.equal(ps.plan.U, explicit.U)
+        for plan in (auto, dense):
+            assert np.array_equal(plan.status.cpu().numpy() == 0, sto == 0)
+            assert (np.abs(plan.U.double().cpu().numpy() - Uo) / scale).max() <= tol
+        if dt == torch.float32:  # nothing is squared into P: the stage-wise path is the more accurate one in float32
+            e_auto = (np.abs(auto.U.double().cpu().numpy() - Uo) / scale).max()
+            e_dense = (np.abs(dense.U.double().cpu().numpy() - Uo) / scale).max()
+            assert e_auto <= 5e-5 and e_auto <= e_dense
