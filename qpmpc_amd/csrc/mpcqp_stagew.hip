@@ -35,9 +35,10 @@ namespace stagew {
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
 constexpr int D = 8;    // the sweeps request their records this many steps ahead
+constexpr int R = 4;    // right-hand sides per sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Mb, Mf, KS, ff, U0, Zp, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
+    int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
     int maxq, mg;
 };
 
@@ -62,9 +63,10 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     w.Mb = take((int64_t)N * na * nq * 64);
     w.Mf = take((int64_t)N * na * (nq + 1) * 64);
     w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
-    w.ff = take((int64_t)N * 4);
+    w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
     w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
-    w.Zp = take((int64_t)N * (nxc + 4));       // (x_k, u_k) of the latest forward sweep, in B-operand order
+    w.Zs = take((int64_t)R * N * (nxc + 4));   // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
+    w.Vc = take((int64_t)R * N * 4);           // ... and its inputs alone (they move into a slot when the row is taken)
     w.mg = ginv ? mk : (int)m;
     w.Gp = take((int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zp's rows, as four-vectors: Gp[j][row], j <= nxc / 4
     w.s0 = take(m);
@@ -143,6 +145,49 @@ __device__ __forceinline__ void mm_t(T *C, const T *A, const T *B, T alpha, cons
     }
 }
 
+// reciprocal: hardware estimate + Newton steps (the IEEE division sequence is ~10 instructions, this is 3 / 5)
+__device__ __forceinline__ float frcp(float x)
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// S = L D L' of a symmetric positive definite 4 x 4 (unit lower L): id[i] = 1 / d_i, l = (l10, l20, l30, l21, l31, l32)
+template <typename T> struct Ldl4 {
+    T id[4], l[6];
+    __device__ __forceinline__ void factor(const T (&s)[10])  // s = (s00, s10, s11, s20, s21, s22, s30, s31, s32, s33)
+    {
+        id[0] = frcp(s[0]);
+        l[0] = s[1] * id[0];
+        l[1] = s[3] * id[0];
+        l[2] = s[6] * id[0];
+        id[1] = frcp(s[2] - l[0] * s[1]);
+        const T t21 = s[4] - l[1] * s[1], t31 = s[7] - l[2] * s[1];
+        l[3] = t21 * id[1];
+        l[4] = t31 * id[1];
+        id[2] = frcp(s[5] - l[1] * s[3] - l[3] * t21);
+        const T t32 = s[8] - l[2] * s[3] - l[4] * t21;
+        l[5] = t32 * id[2];
+        id[3] = frcp(s[9] - l[2] * s[6] - l[4] * t31 - l[5] * t32);
+    }
+    __device__ __forceinline__ void solve(T (&b)[4]) const  // b <- S^-1 b
+    {
+        b[1] -= l[0] * b[0];
+        b[2] -= l[1] * b[0] + l[3] * b[1];
+        b[3] -= l[2] * b[0] + l[4] * b[1] + l[5] * b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] *= id[i];
+        b[2] -= l[5] * b[3];
+        b[1] -= l[3] * b[2] + l[4] * b[3];
+        b[0] -= l[0] * b[1] + l[1] * b[2] + l[2] * b[3];
+    }
+};
+
 // lane j's value as a wave-uniform scalar (v_readlane)
 __device__ __forceinline__ float rl(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 __device__ __forceinline__ double rl(double v, int j)
@@ -171,6 +216,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     constexpr int NB = NA * NQ, NF = NA * (NQ + 1);  // record values per lane and step, backward / forward
     constexpr int ZL = NXC + 4;             // a row of Zp: position g (NQ + 1) + q holds x[4 q + g] (q < NQ), u[g] (q = NQ)
     const bool col0 = c16 == 0;             // the lanes of right-hand side 0
+    const bool colr = c16 < R;              // the lanes of the right-hand sides in use
+    const int cn = colr ? c16 : 0;          // this lane's right-hand side
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
@@ -179,10 +226,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *Sim = Sm + 16, *cst = Sim + 16;  // cst: 0, 1
     T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq;
     int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
+    int *crow = phys + maxq + 1;                                // rows whose P^-1 g' the latest sweeps left in Zs / Vc
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
     T *Mb = ws + wl.Mb, *Mf = ws + wl.Mf, *KS = ws + wl.KS, *ffv = ws + wl.ff;
-    T *U0 = ws + wl.U0, *Zp = ws + wl.Zp, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
+    T *U0 = ws + wl.U0, *Zs = ws + wl.Zs, *Vc = ws + wl.Vc, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
     T *thr = ws + wl.thr;
     V4 *Gp = (V4 *)(ws + wl.Gp);
     const int Mg = wl.mg;
@@ -307,45 +355,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         mm_t<T, LD, 4, 4, 4, 4, NXC>(Sm, Btm, PBm, T(1), nullptr, T(0), pg, c16);     // B' P B
         mm_t<T, LD, LD, LD, 4, 16, NXC>(BPAm, Btm, PAm, T(1), nullptr, T(0), pg, c16); // B' P A
         wsync();
-        // S^-1 (nu <= 4): Gauss-Jordan on the symmetric positive definite S = w_u I + B'PB, every lane the same
+        // S = w_u I + B'PB (nu <= 4, identity on the padding) is factored L D L' in registers, every lane the same; lane
+        // (., c) then solves for column c of K = S^-1 B'PA and of F = -S^-1 B' (row group i writes row i)
+        Ldl4<T> ldl;
         {
-            T S[NU][NU], Si[NU][NU];
+            T sv[10];
 #pragma unroll
-            for (int i = 0; i < NU; ++i)
+            for (int i = 0, e = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    S[i][j] = (i < nu && j < nu) ? Sm[i * 4 + j] + ((i == j) ? wu : T(0)) : ((i == j) ? T(1) : T(0));
-                    Si[i][j] = (i == j) ? T(1) : T(0);
-                }
+                for (int j = 0; j <= i; ++j, ++e) sv[e] = Sm[i * 4 + j] + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
+            ldl.factor(sv);
+            T kc[4], fc[4];
 #pragma unroll
-            for (int c = 0; c < NU; ++c) {
-                const T ip = T(1) / S[c][c];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    S[c][j] *= ip;
-                    Si[c][j] *= ip;
-                }
-#pragma unroll
-                for (int r = 0; r < NU; ++r) {
-                    if (r == c) continue;
-                    const T f = S[r][c];
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) {
-                        S[r][j] -= f * S[c][j];
-                        Si[r][j] -= f * Si[c][j];
-                    }
-                }
+            for (int i = 0; i < 4; ++i) {
+                kc[i] = BPAm[i * LD + c16];
+                fc[i] = Bm[c16 * 4 + i];
             }
-#pragma unroll
-            for (int i = 0; i < NU; ++i)
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {  // (compile-time register indices: no scratch)
-                    if (lane == i * 4 + j) Sim[lane] = Si[i][j];
-                }
+            ldl.solve(kc);
+            ldl.solve(fc);
+            const T kv = pg == 0 ? kc[0] : pg == 1 ? kc[1] : pg == 2 ? kc[2] : kc[3];
+            const T fv = pg == 0 ? fc[0] : pg == 1 ? fc[1] : pg == 2 ? fc[2] : fc[3];
+            Km[pg * LD + c16] = kv;
+            Fm[pg * LD + c16] = -fv;
         }
-        wsync();
-        mm_t<T, 4, LD, LD, 4, 16, 4>(Km, Sim, BPAm, T(1), nullptr, T(0), pg, c16);     // K = S^-1 B'PA
-        mm_t<T, 4, LD, LD, 4, 16, 4>(Fm, Sim, Btm, T(-1), nullptr, T(0), pg, c16);     // F = -S^-1 B'
         wsync();
         mm_t<T, 4, LD, LD, 16, 16, 4>(Acm, Bm, Km, T(-1), Am, T(1), pg, c16);           // Acl = A - B K
         mm_t<T, 4, LD, LD, 16, 16, 4>(Mm, PBm, Km, T(-1), PAm, T(1), pg, c16);          // M = P Acl = PA - PB K
@@ -361,7 +393,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int e = 0; e < NF; ++e) mf[e * 64] = sgnf[e] * Pm[srcf[e]];
             T *ks = KS + (int64_t)k * (nx * nu + 16);
             if (offK >= 0) ks[lane] = Km[offK];
-            if (lane < 16) ks[nx * nu + lane] = Sim[lane];
+            if (lane == 0) {  // the factor of S: 1 / d, then l10, l20, l30, l21, l31, l32
+                T *kf = ks + nx * nu;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
+            }
         }
         wsync();
         // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
@@ -389,13 +427,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     // backward: (p_k, ff_k) = [Acl_k' ; F_k] p_{k+1} (+ the step's linear cost). With `track` the tracking costs from p_N;
     // else the costate of one row of G, which is zero after its step kq: `start` is (p_kq, ff_kq) and the sweep runs
     // over k < kq.
-    auto backward = [&](auto trackc, int kq, MV start, T ffstart) {
+    // Several rows at once: column n of the operand is row n's costate; it is injected at its own step (mykq, per
+    // lane; `start` = (p_kq, ff_kq)) and the sweep starts at the latest of them (kq).
+    auto backward = [&](auto trackc, int kq, MV start, T ffstart, int mykq) {
         constexpr bool track = decltype(trackc)::value;
         const bool tgt = track && stageQ;
         const T wxq = (T)ka.wx;
+        const unsigned ffo = (unsigned)(cn * N * 4 + pg);  // this lane's entries of the feed-forward array
         MV st = start;
         const int kstart = track ? N - 1 : kq - 1;
-        if (!track && col0) ffv[(int64_t)kq * 4 + pg] = ffstart;
+        if (!track) {
+            const bool now = colr && mykq == kq;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st[q] = now ? start[q] : T(0);
+            if (now) ffv[ffo + (unsigned)(kq * 4)] = ffstart;
+        }
         T rec[D][NB], tg[D][NQ];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -432,7 +478,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 for (int q = 0; q < NQ; ++q)
                     if (4 * q + pg < nx) a0[q] -= wxq * tg[d][q];
             }
-            if (col0) ffv[(int64_t)k * 4 + pg] = STACK ? a0[NQ] : a1[0];
+            T ffk = STACK ? a0[NQ] : a1[0];
+            if (!track && k == mykq) {  // this column's row enters here (its costate above is zero)
+                a0 = start;
+                ffk = ffstart;
+            }
+            if (colr) ffv[ffo + (unsigned)(k * 4)] = ffk;
             st = a0;
             if (again) req(d, k - D >= 0 ? k - D : 0);
         };
@@ -449,10 +500,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     };
     // forward: (x_{k+1}, u_k) = [[Acl_k, B_k], [-K_k, I]] (x_k, ff_k) from x_0 = xs (ff_k = 0 for k > kff); writes the
     // inputs to Uo[k][0..3] and (x_k, u_k) to Zp[k]
-    auto forward = [&](const T *xs, int kff, T *Uo) {
+    // per column: ff_k = 0 for k > kff; inputs to Uo[k][0..3], (x_k, u_k) to Zo[k] (lanes with `on`)
+    auto forward = [&](const T *xs, int kff, T *Uo, unsigned uoff, T *Zo, unsigned zoff, bool on) {
         T z[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) z[q] = (xs && col0 && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
+        const unsigned ffo = (unsigned)(cn * N * 4 + pg);
+        uoff += (unsigned)pg;
+        zoff += (unsigned)(pg * (NQ + 1));
         T rec[D][NF], ffr[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -464,7 +519,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             const T *mf = Mf + (int64_t)k * (NF * 64) + lane;
 #pragma unroll
             for (int e = 0; e < NF; ++e) rec[d][e] = mf[e * 64];
-            ffr[d] = ffv[(int64_t)k * 4 + pg];
+            ffr[d] = ffv[ffo + (unsigned)(k * 4)];
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -472,7 +527,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             __builtin_amdgcn_sched_barrier(0);
         }
         auto step = [&](int d, int k, bool again) {
-            const T ffd = (k <= kff && col0) ? ffr[d] : T(0);
+            const T ffd = (k <= kff && on) ? ffr[d] : T(0);
             MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int kk = 0; kk <= NQ; ++kk) {
@@ -481,12 +536,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
             }
             const T u = STACK ? a0[NQ] : a1[0];
-            if (col0) {
-                T *zr = Zp + (int64_t)k * ZL + pg * (NQ + 1);
+            if (on) {
+                const unsigned zr = zoff + (unsigned)(k * ZL);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) zr[q] = z[q];
-                zr[NQ] = u;
-                Uo[(int64_t)k * 4 + pg] = u;
+                for (int q = 0; q < NQ; ++q) Zo[zr + q] = z[q];
+                Zo[zr + NQ] = u;
+                Uo[uoff + (unsigned)(k * 4)] = u;
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) z[q] = a0[q];
@@ -536,7 +591,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int q = 0; q <= NQ; ++q) acc += g[q][0] * zq[q][0] + g[q][1] * zq[q][1] + g[q][2] * zq[q][2] + g[q][3] * zq[q][3];
         return acc;
     };
-    auto gmul = [&](T *hd) {
+    auto gmul = [&](T *hd, const T *Zp) {
         if (ghoist) {
             constexpr int ZU = 4;
             V4 gfix[NQ + 1];
@@ -601,15 +656,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int q = 0; q < NQ; ++q)
                 if (4 * q + pg < nx) pN[q] = -(T)ka.wt * ggoal[4 * q + pg];
         }
-        backward(std::true_type{}, -1, pN, T(0));
+        backward(std::true_type{}, -1, pN, T(0), -1);
     }
     wsync();
     tick(3);
-    forward(gx0, N, U0);
+    forward(gx0, N, U0, 0u, Zs, 0u, col0);
     wsync();
     tick(4);
     const T tol = ka.tol;
-    gmul(sl);
+    gmul(sl, Zs);
     for (int i = lane; i < M; i += 64) {
         const int k = stepof(i), r = i - k * mk;
         const T ev = ge[k * sE + r], sv = ev - sl[i];
@@ -627,6 +682,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         rowslot[i] = -1;
     }
     for (int a = lane; a <= maxq; a += 64) phys[a] = a;
+    if (lane < R) crow[lane] = -1;
     wsync();
 
     tick(5);
@@ -649,26 +705,77 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 break;
             }
             tacc(8);
-            const int kp = bi / mk, rp = bi - kp * mk;
-            // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room
+            // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room. The
+            // sweeps carry R right-hand sides at the price of one, so the rows most likely to be taken next ride along
+            // (V_a does not depend on the active set: a row found in crow[] later costs no sweep; which rows ride along
+            // has no influence on the iterates).
             const int ps = phys[nq];
             T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
-            {
-                // (p_kp, ff_kp) of row (kp, rp): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above kp is zero)
+            int hit = -1;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if (crow[j] == bi) hit = j;
+            if (hit < 0) {
+                // rows[0] = the candidate; then the next most violated rows (per-lane top two, R - 1 wave minima)
+                int rows[R];
+                rows[0] = bi;
+                {
+                    T b1 = INF, b2 = INF;
+                    int i1 = 0x7fffffff, i2 = 0x7fffffff;
+                    for (int i = lane; i < M; i += 64) {
+                        const T sv = sl[i], sc = sv * invn[i];
+                        if (sv < -thr[i] && i != bi) {
+                            if (sc < b1) {
+                                b2 = b1;
+                                i2 = i1;
+                                b1 = sc;
+                                i1 = i;
+                            } else if (sc < b2) {
+                                b2 = sc;
+                                i2 = i;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 1; j < R; ++j) {
+                        T v = b1;
+                        int ix = i1;
+                        wave_argmin(v, ix);
+                        rows[j] = (v < INF) ? ix : -1;
+                        if (v < INF && ix == i1) {
+                            b1 = b2;
+                            i1 = i2;
+                            b2 = INF;
+                            i2 = 0x7fffffff;
+                        }
+                    }
+                }
+                int myrow = -1;
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (c16 == j) myrow = rows[j];
+                // (p_kq, ff_kq) of this lane's row (kq, rq): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above
+                // kq is zero)
                 MV st = {T(0), T(0), T(0), T(0)};
                 T ffs = T(0);
-                if (col0) {
-                    const T *ks = KS + (int64_t)kp * (nx * nu + 16);
-                    T dd[NU], cq[NQ], kq4[NQ][NU], si[NU];  // every load first, then the arithmetic
+                int mykq = -1;
+                if (myrow >= 0) {
+                    const int kq = stepof(myrow), rq = myrow - kq * mk;
+                    mykq = kq;
+                    const T *ks = KS + (int64_t)kq * (nx * nu + 16);
+                    T dd[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
+                    Ldl4<T> ldl;
 #pragma unroll
                     for (int i = 0; i < NU; ++i) {
-                        dd[i] = (gD && i < nu) ? gD[kp * sD + rp * nu + i] : T(0);
-                        si[i] = (pg < nu && i < nu) ? ks[nx * nu + pg * 4 + i] : T(0);
+                        dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
+                        ldl.id[i] = ks[nx * nu + i];
                     }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) ldl.l[i] = ks[nx * nu + 4 + i];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const int c = 4 * q + pg;
-                        cq[q] = (gC && c < nx) ? gC[kp * sC + rp * nx + c] : T(0);
+                        cq[q] = (gC && c < nx) ? gC[kq * sC + rq * nx + c] : T(0);
 #pragma unroll
                         for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * nu + i] : T(0);
                     }
@@ -679,17 +786,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
                         st[q] = v;
                     }
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) ffs += si[i] * dd[i];
+                    ldl.solve(dd);  // S^-1 D'
+                    ffs = pg == 0 ? dd[0] : pg == 1 ? dd[1] : pg == 2 ? dd[2] : dd[3];
                 }
-                backward(std::false_type{}, kp, st, ffs);
+                int kmax = -1;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int kj = rows[j] >= 0 ? stepof(rows[j]) : -1;
+                    kmax = kj > kmax ? kj : kmax;
+                }
+                backward(std::false_type{}, kmax, st, ffs, mykq);
+                wsync();
+                tacc(9);
+                forward(nullptr, mykq, Vc, (unsigned)(cn * nv4), Zs, (unsigned)(cn * N * ZL), myrow >= 0);
+                if (lane < R) crow[lane] = myrow;
+                wsync();
+                tacc(10);
+                hit = 0;
             }
-            wsync();
-            tacc(9);
-            forward(nullptr, kp, Vp);
-            wsync();
-            tacc(10);
-            gmul(hp);
+            // the row's vectors move into the slot: inputs copied, h_p = G V_p from its trajectory
+            for (int i = lane; i < nv4; i += 64) Vp[i] = Vc[(int64_t)hit * nv4 + i];
+            gmul(hp, Zs + (int64_t)hit * N * ZL);
+            if (lane == 0) crow[hit] = -1;
             wsync();
             tacc(11);
             const T dpp = hp[bi];
@@ -939,7 +1057,7 @@ template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, 
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T));
     const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16 + 8);
-    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 32;
+    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64;
     auto kern = mpcqp_stagew_kernel<T, NXC>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
