@@ -131,9 +131,10 @@ template <> struct Mfma<double> {
 // operands read from LDS tiles with compile-time strides. Tiles are 16 or 4 rows / columns (NR, NC) and ZERO outside
 // their valid part, so the products run over the full tile and the padding of the result is zero again; reads past a
 // 4-row / 4-column operand land in the neighbouring tiles and only feed results that are not stored.
-template <typename T, int LDA, int LDB, int LDC, int NR, int NC, int NK>
-__device__ __forceinline__ void mm_t(T *C, const T *A, const T *B, T alpha, const T *Add, T beta, int pg, int c16)
+template <typename T, int LDA, int LDB, int LDC, int NR, int NC, int NK, bool SUB>
+__device__ __forceinline__ void mm_t(T *C, const T *A, const T *B, const T *Add, int pg, int c16)
 {
+    // SUB: C = Add - A B (Add has C's layout), else C = A B
     typename Mfma<T>::V acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
     for (int k = 0; k < NK; k += 4) acc = Mfma<T>::run(A[c16 * LDA + k + pg], B[(k + pg) * LDB + c16], acc);
@@ -141,7 +142,7 @@ __device__ __forceinline__ void mm_t(T *C, const T *A, const T *B, T alpha, cons
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = Mfma<T>::row(pg, t);
-        if (NR == 16 || r < NR) C[r * LDC + c16] = alpha * acc[t] + (Add ? beta * Add[r * LDC + c16] : T(0));
+        if (NR == 16 || r < NR) C[r * LDC + c16] = SUB ? Add[r * LDC + c16] - acc[t] : acc[t];
     }
 }
 
@@ -311,49 +312,51 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             }
         }
     }
-    // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step
-    T pfa[4], pfb;
-    int offA[4], offAt[4], offB = -1, offBt = 0, offK = -1;  // LDS offsets of this lane's entries (-1: none)
+    // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step.
+    // No branches: lanes without an entry re-read the last one and write it to a spare LDS cell.
+    constexpr int NAU = (NXC * NXC + 63) / 64;
+    const int junk = (int)(cst - Pm) + 4;
+    T pfa[NAU], pfb;
+    unsigned idxA[NAU], idxB;
+    int offA[NAU], offAt[NAU], offB = junk, offBt = junk + 1, offK = -1;  // LDS offsets (from Pm) of this lane's entries
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NAU; ++u) {
         const int i = lane + 64 * u, r = i / nx, c = i - r * nx;
-        offA[u] = (i < nx * nx) ? r * LD + c : -1;
-        offAt[u] = c * LD + r;
+        const bool in = i < nx * nx;
+        idxA[u] = (unsigned)(in ? i : nx * nx - 1);
+        offA[u] = in ? (int)(Am - Pm) + r * LD + c : junk;
+        offAt[u] = in ? (int)(Atm - Pm) + c * LD + r : junk + 1;
     }
+    idxB = (unsigned)(lane < nx * nu ? lane : nx * nu - 1);
     if (lane < nx * nu) {
         const int r = lane / nu, c = lane - r * nu;
-        offB = r * 4 + c;
-        offBt = c * LD + r;
+        offB = (int)(Bm - Pm) + r * 4 + c;
+        offBt = (int)(Btm - Pm) + c * LD + r;
         offK = c * LD + r;  // Kt[r][c] = K[c][r]
     }
     auto request = [&](int k) {
+        const T *a = gA + k * sA, *bb = gB + k * sB;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = lane + 64 * u;
-            pfa[u] = (i < nx * nx) ? gA[k * sA + i] : T(0);
-        }
-        pfb = (lane < nx * nu) ? gB[k * sB + lane] : T(0);
+        for (int u = 0; u < NAU; ++u) pfa[u] = a[idxA[u]];
+        pfb = bb[idxB];
     };
     request(N - 1);
     for (int k = N - 1; k >= 0; --k) {
         // stage A_k, A_k', B_k, B_k'
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (offA[u] >= 0) {
-                Am[offA[u]] = pfa[u];
-                Atm[offAt[u]] = pfa[u];
-            }
-        if (offB >= 0) {
-            Bm[offB] = pfb;
-            Btm[offBt] = pfb;
+        for (int u = 0; u < NAU; ++u) {
+            Pm[offA[u]] = pfa[u];
+            Pm[offAt[u]] = pfa[u];
         }
+        Pm[offB] = pfb;
+        Pm[offBt] = pfb;
         wsync();
-        if (k > 0) request(k - 1);
-        mm_t<T, LD, LD, LD, 16, 16, NXC>(PAm, Pm, Am, T(1), nullptr, T(0), pg, c16);    // PA = P A
-        mm_t<T, LD, 4, 4, 16, 4, NXC>(PBm, Pm, Bm, T(1), nullptr, T(0), pg, c16);      // PB = P B
+        request(k > 0 ? k - 1 : 0);
+        mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Pm, Am, nullptr, pg, c16);    // PA = P A
+        mm_t<T, LD, 4, 4, 16, 4, NXC, false>(PBm, Pm, Bm, nullptr, pg, c16);      // PB = P B
         wsync();
-        mm_t<T, LD, 4, 4, 4, 4, NXC>(Sm, Btm, PBm, T(1), nullptr, T(0), pg, c16);     // B' P B
-        mm_t<T, LD, LD, LD, 4, 16, NXC>(BPAm, Btm, PAm, T(1), nullptr, T(0), pg, c16); // B' P A
+        mm_t<T, LD, 4, 4, 4, 4, NXC, false>(Sm, Btm, PBm, nullptr, pg, c16);     // B' P B
+        mm_t<T, LD, LD, LD, 4, 16, NXC, false>(BPAm, Btm, PAm, nullptr, pg, c16); // B' P A
         wsync();
         // S = w_u I + B'PB (nu <= 4, identity on the padding) is factored L D L' in registers, every lane the same; lane
         // (., c) then solves for column c of K = S^-1 B'PA and of F = -S^-1 B' (row group i writes row i)
@@ -379,10 +382,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             Fm[pg * LD + c16] = -fv;
         }
         wsync();
-        mm_t<T, 4, LD, LD, 16, 16, 4>(Acm, Bm, Km, T(-1), Am, T(1), pg, c16);           // Acl = A - B K
-        mm_t<T, 4, LD, LD, 16, 16, 4>(Mm, PBm, Km, T(-1), PAm, T(1), pg, c16);          // M = P Acl = PA - PB K
+        mm_t<T, 4, LD, LD, 16, 16, 4, true>(Acm, Bm, Km, Am, pg, c16);           // Acl = A - B K
+        mm_t<T, 4, LD, LD, 16, 16, 4, true>(Mm, PBm, Km, PAm, pg, c16);          // M = P Acl = PA - PB K
         wsync();
-        mm_t<T, LD, LD, LD, 16, 16, NXC>(PAm, Atm, Mm, T(1), nullptr, T(0), pg, c16);   // A' P Acl (into the PA tile)
+        mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Atm, Mm, nullptr, pg, c16);   // A' P Acl (into the PA tile)
         // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
         // (read at the candidate row's step)
         {
