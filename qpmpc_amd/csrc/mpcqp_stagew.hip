@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
     constexpr int GU = 2;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
-    constexpr int SU = 4;                       // rows per lane in flight in the slack passes
+    constexpr int SU = sizeof(T) == 4 ? 8 : 4;  // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
@@ -594,7 +594,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int q = 0; q <= NQ; ++q) acc += g[q][0] * zq[q][0] + g[q][1] * zq[q][1] + g[q][2] * zq[q][2] + g[q][3] * zq[q][3];
         return acc;
     };
-    auto gmul = [&](T *hd, const T *Zp) {
+    // cap >= 0: also leaves c_a = h[row a] of the active rows in cv[] and returns h[cap]
+    auto gmul = [&](T *hd, const T *Zp, int cap) {
+        T capv = T(0);
+        auto keep = [&](int i, int rs, T v) {  // rs: the row's active index (requested with the row's operands)
+            if (rs >= 0) cv[rs] = v;
+            if (i == cap) capv = v;
+        };
         if (ghoist) {
             constexpr int ZU = 4;
             V4 gfix[NQ + 1];
@@ -603,20 +609,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int q = 0; q <= NQ; ++q) gfix[q] = Gp[(unsigned)(q * Mg + r)];
             for (int i0 = lane; i0 < M; i0 += 64 * ZU) {
                 V4 zq[ZU][NQ + 1];
+                int rs[ZU];
 #pragma unroll
                 for (int u = 0; u < ZU; ++u) {
                     const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
                     const V4 *zr = (const V4 *)(Zp + (unsigned)(stepof(i) * ZL));
 #pragma unroll
                     for (int q = 0; q <= NQ; ++q) zq[u][q] = zr[q];
+                    rs[u] = cap >= 0 ? rowslot[(unsigned)i] : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < ZU; ++u)
-                    if (i0 + 64 * u < M) hd[i0 + 64 * u] = gdot(gfix, zq[u]);
+                    if (i0 + 64 * u < M) {
+                        const T v = gdot(gfix, zq[u]);
+                        hd[i0 + 64 * u] = v;
+                        keep(i0 + 64 * u, rs[u], v);
+                    }
             }
         } else {
             for (int i0 = lane; i0 < M; i0 += 64 * GU) {
                 V4 g[GU][NQ + 1], zq[GU][NQ + 1];
+                int rs[GU];
 #pragma unroll
                 for (int u = 0; u < GU; ++u) {
                     const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
@@ -628,26 +641,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         g[u][q] = Gp[(unsigned)(q * Mg + gi)];
                         zq[u][q] = zr[q];
                     }
+                    rs[u] = cap >= 0 ? rowslot[(unsigned)i] : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < GU; ++u)
-                    if (i0 + 64 * u < M) hd[i0 + 64 * u] = gdot(g[u], zq[u]);
+                    if (i0 + 64 * u < M) {
+                        const T v = gdot(g[u], zq[u]);
+                        hd[i0 + 64 * u] = v;
+                        keep(i0 + 64 * u, rs[u], v);
+                    }
             }
         }
+        return cap >= 0 ? __shfl(capv, cap & 63) : T(0);
     };
     // the violated row farthest from its hyperplane (active rows sit at s = 0 exactly, rows without a bound at ~1e30:
     // neither can be selected); ties go to the lowest row id, like the restatement
-    auto select = [&](T &best, int &bi) {
+    // (TU rows per lane are requested together; `sp` returns the winner's slack)
+    constexpr int TU = 8;
+    auto select = [&](T &best, int &bi, T &sp) {
         best = INF;
         bi = 0x7fffffff;
-        for (int i = lane; i < M; i += 64) {
-            const T sv = sl[i], sc = sv * invn[i];
-            if (sv < -thr[i] && sc < best) {
-                best = sc;
-                bi = i;
+        T bsv = T(0);
+        for (int i0 = lane; i0 < M; i0 += 64 * TU) {
+            T sv[TU], iv[TU], th[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                sv[u] = sl[i];
+                iv[u] = invn[i];
+                th[u] = thr[i];
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const T sc = sv[u] * iv[u];
+                if (i0 + 64 * u < M && sv[u] < -th[u] && sc < best) {
+                    best = sc;
+                    bi = i0 + 64 * u;
+                    bsv = sv[u];
+                }
             }
         }
         wave_argmin(best, bi);
+        sp = __shfl(bsv, bi & 63);  // (row i lives in lane i % 64)
     };
 
     // ================================================================= unconstrained minimiser, slacks
@@ -667,7 +702,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     wsync();
     tick(4);
     const T tol = ka.tol;
-    gmul(sl, Zs);
+    gmul(sl, Zs, -1);
     for (int i = lane; i < M; i += 64) {
         const int k = stepof(i), r = i - k * mk;
         const T ev = ge[k * sE + r], sv = ev - sl[i];
@@ -693,15 +728,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
     bool fail = false, havesel = false;
-    T nbest = INF;
+    T nbest = INF, nsp = T(0);
     int nbi = 0x7fffffff;
     for (int round = 0; round < 4 && !fail; ++round) {
         for (;;) {
             // ---- selection (already made by the slack pass of the step that just ended, if there was one)
             tacc(-1);
-            T best = nbest;
+            T best = nbest, sp = nsp;
             int bi = nbi;
-            if (!havesel) select(best, bi);
+            if (!havesel) select(best, bi, sp);
             havesel = false;
             if (!(best < INF)) {
                 status = MPCQP_SOLVED;
@@ -725,17 +760,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 {
                     T b1 = INF, b2 = INF;
                     int i1 = 0x7fffffff, i2 = 0x7fffffff;
-                    for (int i = lane; i < M; i += 64) {
-                        const T sv = sl[i], sc = sv * invn[i];
-                        if (sv < -thr[i] && i != bi) {
-                            if (sc < b1) {
-                                b2 = b1;
-                                i2 = i1;
-                                b1 = sc;
-                                i1 = i;
-                            } else if (sc < b2) {
-                                b2 = sc;
-                                i2 = i;
+                    for (int i0 = lane; i0 < M; i0 += 64 * TU) {
+                        T sv[TU], iv[TU], th[TU];
+#pragma unroll
+                        for (int u = 0; u < TU; ++u) {
+                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                            sv[u] = sl[i];
+                            iv[u] = invn[i];
+                            th[u] = thr[i];
+                        }
+#pragma unroll
+                        for (int u = 0; u < TU; ++u) {
+                            const int i = i0 + 64 * u;
+                            const T sc = sv[u] * iv[u];
+                            if (i < M && sv[u] < -th[u] && i != bi) {
+                                if (sc < b1) {
+                                    b2 = b1;
+                                    i2 = i1;
+                                    b1 = sc;
+                                    i1 = i;
+                                } else if (sc < b2) {
+                                    b2 = sc;
+                                    i2 = i;
+                                }
                             }
                         }
                     }
@@ -809,13 +856,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             }
             // the row's vectors move into the slot: inputs copied, h_p = G V_p from its trajectory
             for (int i = lane; i < nv4; i += 64) Vp[i] = Vc[(int64_t)hit * nv4 + i];
-            gmul(hp, Zs + (int64_t)hit * N * ZL);
+            const T dpp = gmul(hp, Zs + (int64_t)hit * N * ZL, bi);
             if (lane == 0) crow[hit] = -1;
             wsync();
             tacc(11);
-            const T dpp = hp[bi];
             T up = T(0);
-            bool added = false;
+            bool added = false, fresh = true;  // fresh: cv[] still holds the c_a the pass above left
             while (!added) {
                 if (iters >= max_iter || nq >= maxq) {
                     fail = true;
@@ -823,8 +869,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 }
                 ++iters;
                 // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
-                wsync();
+                if (!fresh) {
+                    for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
+                    wsync();
+                }
+                fresh = false;
                 T cr = T(0);
                 for (int a = lane; a < nq; a += 64) {
                     T acc = T(0);
@@ -850,7 +899,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     }
                 }
                 wave_argmin(t1, l);
-                const T sp = sl[bi];
                 const T t2 = can_move ? -sp / d2 : INF;
                 const T t = t1 < t2 ? t1 : t2;
                 if (!(t < INF)) {
@@ -863,19 +911,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
                 nbest = INF;
                 nbi = 0x7fffffff;
+                T nbsv = T(0), spcap = T(0);
                 for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                    unsigned idx[SU];
-                    int rs[SU];
-                    T z[SU], so[SU], iv[SU], th[SU];
+                    // SU rows per lane in one go: first z = h_p - sum r_a h_a (only z and the slots' values live), then
+                    // the rows' own arrays in halves
+                    T z[SU];
 #pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        idx[u] = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                        z[u] = hp[idx[u]];
-                        so[u] = sl[idx[u]];
-                        iv[u] = invn[idx[u]];
-                        th[u] = thr[idx[u]];
-                        rs[u] = rowslot[idx[u]];
-                    }
+                    for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                     int a = 0;
                     for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
                         const T ra = rv[a], rb = rv[a + 1];
@@ -883,8 +925,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         T va[SU], vb[SU];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
-                            va[u] = ha[idx[u]];
-                            vb[u] = hb[idx[u]];
+                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                            va[u] = ha[i];
+                            vb[u] = hb[i];
                         }
 #pragma unroll
                         for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
@@ -893,23 +936,38 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         const T ra = rv[a];
                         const T *ha = Hs + (int64_t)phys[a] * M;
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] -= ra * ha[idx[u]];
+                        for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                     }
 #pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int i = (int)idx[u];
-                        const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[u];
-                        const T sc = v * iv[u];
-                        const bool viol = v < -th[u] && i != bi;
-                        if (i0 + 64 * u < M) {
-                            sl[i] = v;
-                            if (viol && sc < nbest) {
-                                nbest = sc;
-                                nbi = i;
+                    for (int h = 0; h < SU; h += SU / 2) {
+                        int rs[SU / 2];
+                        T so[SU / 2], iv[SU / 2], th[SU / 2];
+#pragma unroll
+                        for (int u = 0; u < SU / 2; ++u) {
+                            const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
+                            so[u] = sl[i];
+                            iv[u] = invn[i];
+                            th[u] = thr[i];
+                            rs[u] = rowslot[i];
+                        }
+#pragma unroll
+                        for (int u = 0; u < SU / 2; ++u) {
+                            const int i = i0 + 64 * (h + u);
+                            const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[h + u];
+                            const T sc = v * iv[u];
+                            if (i < M) {
+                                sl[i] = v;
+                                if (i == bi) spcap = v;
+                                if (v < -th[u] && i != bi && sc < nbest) {
+                                    nbest = sc;
+                                    nbi = i;
+                                    nbsv = v;
+                                }
                             }
                         }
                     }
                 }
+                sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
                 // ---- multipliers
                 for (int a = lane; a < nq; a += 64) {
                     const T v = lamv[a] - t * rv[a];
@@ -937,6 +995,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     ++nq;
                     added = true;
                     wave_argmin(nbest, nbi);
+                    nsp = __shfl(nbsv, nbi & 63);
                     havesel = true;
                 } else {
                     // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
@@ -988,27 +1047,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         }
         bool dirty = false;
         for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-            unsigned idx[SU];
-                    int rs[SU];
-            T fr[SU], th[SU];
+            T fr[SU];
 #pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                idx[u] = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                fr[u] = s0[idx[u]];
-                th[u] = thr[idx[u]];
-                rs[u] = rowslot[idx[u]];
+            for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+            int a = 0;
+            for (; a + 1 < nq; a += 2) {
+                const T la = lamv[a], lb = lamv[a + 1];
+                const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                T va[SU], vb[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                    va[u] = ha[i];
+                    vb[u] = hb[i];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
             }
-            for (int a = 0; a < nq; ++a) {
+            if (a < nq) {
                 const T la = lamv[a];
                 const T *ha = Hs + (int64_t)phys[a] * M;
 #pragma unroll
-                for (int u = 0; u < SU; ++u) fr[u] += la * ha[idx[u]];
+                for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+            }
+            T th[SU];
+            int rs[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                th[u] = thr[i];
+                rs[u] = rowslot[i];
             }
 #pragma unroll
             for (int u = 0; u < SU; ++u) {
                 const bool act = rs[u] >= 0;
                 if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
-                if (i0 + 64 * u < M) sl[idx[u]] = act ? T(0) : fr[u];
+                if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
             }
         }
         dirty = __ballot(dirty) != 0ull;
