@@ -724,6 +724,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     wsync();
 
     tick(5);
+    if (stamp) {  // (developer probe) slot 15: violated rows at the unconstrained minimiser, and their summed scaled violation
+        int nv = 0;
+        T tv = T(0);
+        for (int i = lane; i < M; i += 64)
+            if (sl[i] < -thr[i]) {
+                ++nv;
+                tv -= sl[i] * invn[i];
+            }
+        nv = (int)wave_sum((T)nv);
+        tv = wave_sum(tv);
+        if (lane == 0) stamp[15] = (long long)nv + ((long long)(tv * T(1000)) << 16);
+    }
     // ================================================================= active-set loop
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
     const int max_iter = ka.max_iter;
