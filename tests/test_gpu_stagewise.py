@@ -231,3 +231,59 @@ def test_large_problems_are_dispatched_to_the_stagewise_kernel_and_agree_with_th
             e_auto = (np.abs(auto.U.double().cpu().numpy() - Uo) / scale).max()
             e_dense = (np.abs(dense.U.double().cpu().numpy() - Uo) / scale).max()
             assert e_auto <= 5e-5 and e_auto <= e_dense
+
+
+@pytest.mark.parametrize("nx,nu,N,mk", [(6, 2, 20, 3), (9, 4, 16, 4), (16, 4, 12, 3), (12, 1, 70, 2), (7, 3, 5, 5)])
+def test_wide_stagewise_kernel_float32_random_ltv(nx, nu, N, mk):
+    """float32 through every row-length instantiation (nx rounded up to 8, 12, 16; one- and two-block stacked matrices;
+    horizons shorter than the sweeps' request ring; mk that does not divide 64; C, D changing along the horizon):
+    against the float64 C oracle at 2e-4 relative, statuses equal."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(7 * nx + N)
+    w = _random_ltv(rng, 32, nx, nu, N, mk)
+    plan = solve_mpc_batch(W.to_batch_problem(w, dtype=torch.float32), formulation="stagewise")
+    torch.cuda.synchronize()
+    U, st = plan.U.double().cpu().numpy(), plan.status.cpu().numpy()
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    ok = (sto == 0) & (st == 0)
+    assert ok.sum() >= 24 and (st[sto == 0] == 0).mean() >= 0.9
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 2e-4
+
+
+def test_wide_stagewise_kernel_infeasible_and_slot_overflow_statuses():
+    """Contradictory rows (u_0 <= -1 and -u_0 <= -1) are reported MPCQP_INFEASIBLE with a zeroed plan, like the dense path;
+    a problem that needs more active rows than max_active allows comes back unsolved (MAX_ITER), never a wrong plan."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(3)
+    w = _random_ltv(rng, 8, 6, 2, 12, 3)
+    w["C"][4:, 0, 0, :] = 0.0
+    w["C"][4:, 0, 1, :] = 0.0
+    w["D"][4:, 0, 0, :] = [1.0, 0.0]
+    w["D"][4:, 0, 1, :] = [-1.0, 0.0]
+    w["e"][4:, 0, 0] = -1.0
+    w["e"][4:, 0, 1] = -1.0
+    bp = W.to_batch_problem(w)
+    plan = solve_mpc_batch(bp, formulation="stagewise")
+    dense = solve_mpc_batch(bp, flags=0)
+    torch.cuda.synchronize()
+    st = plan.status.cpu().numpy()
+    assert (st[:4] == 0).all() and (st[4:] == 2).all(), st  # MPCQP_INFEASIBLE = 2
+    assert np.array_equal(st, dense.status.cpu().numpy())
+    assert float(plan.U[4:].abs().max()) == 0.0
+    assert float((plan.U[:4] - dense.U[:4]).abs().max()) <= 1e-8
+    # slot overflow: one slot only
+    tight = solve_mpc_batch(bp, formulation="stagewise", max_active=1)
+    torch.cuda.synchronize()
+    need = plan.iters.cpu().numpy()
+    st1 = tight.status.cpu().numpy()
+    for b in range(4):
+        if st1[b] == 0:
+            assert float((tight.U[b] - plan.U[b]).abs().max()) <= 1e-9
+        else:
+            assert st1[b] == 1 and need[b] > 1 and float(tight.U[b].abs().max()) == 0.0  # MPCQP_MAX_ITER = 1
+    assert (st1[:4] != 0).any()
