@@ -86,6 +86,13 @@ __device__ __forceinline__ double rl(double x, int lane)  // lane must be wave-u
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
+// a DPP move of a double (two dwords); CTRL: quad_perm 0x00..0xff, row_ror:n = 0x120 + n
+template <int CTRL> __device__ __forceinline__ double dpp64(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -162,65 +169,99 @@ __global__ void __launch_bounds__(64, 2)
     };
     tick(0);
     // ================================================================= factor: Riccati recursion
-    // (serial in k and nonlinear: every lane computes it, the operands arrive through scalar loads)
+    // Serial in k and nonlinear. The NX x NX matrices are spread over 16 lanes -- lane (r, c) = ((lane / 4) % 4, lane % 4)
+    // holds element [r][c]; the four 16-lane rows of the wavefront do the same work -- and a product gathers its operands
+    // with DPP: a row of the left factor is the lane's quad (quad_perm broadcasts), a column of the right factor sits
+    // in the same position of the four quads (row rotations by 4, 8, 12: rotation t delivers row (r - t) mod 4, so
+    // operands that come from memory are fetched in that order). Only (PA)' in P_k = (PA)' Acl needs a general gather
+    // (ds_bpermute). ~90 instructions per step instead of ~350 executed redundantly by every lane.
     {
-        double P[NX * NX];
+        const int r = (lane >> 2) & 3, c = lane & 3;
+        const bool inr = r < NX, inc = c < NX, in = inr && inc;
+        auto q4 = [&](double x, int l) {  // element l of the lane's quad (l: compile-time after unrolling)
+            switch (l) {
+            case 0: return dpp64<0x00>(x);
+            case 1: return dpp64<0x55>(x);
+            case 2: return dpp64<0xaa>(x);
+            default: return dpp64<0xff>(x);
+            }
+        };
+        auto rot = [&](double x, int t) {  // the same position of the quad t below (cyclically): row (r - t) mod 4
+            switch (t) {
+            case 0: return x;
+            case 1: return dpp64<0x124>(x);
+            case 2: return dpp64<0x128>(x);
+            default: return dpp64<0x12c>(x);
+            }
+        };
+        auto gather = [&](double x, int src) {  // any lane's value (src: per-lane lane index)
+            const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(x));
+            const int hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(x));
+            return __hiloint2double(hi, lo);
+        };
+        const int base16 = lane & ~15;
+        int rrow[4];  // (r - t) mod 4
 #pragma unroll
-        for (int i = 0; i < NX * NX; ++i) P[i] = (i / NX == i % NX) ? wt : 0.0;
-        // operands of step k-1 are requested while step k computes (the recursion is a ~12-stage dependent chain
-        // per step: without this every step also waits for its own loads)
-        double An[NX * NX], Bn[NX * NU];
+        for (int t = 0; t < 4; ++t) rrow[t] = (r - t) & 3;
+        double P = (in && r == c) ? wt : 0.0;  // P[r][c]
+        // operands of step k-1 are requested while step k computes
+        double Acn[NX], Ann, Bfn[NX * NU], Brn[4 * NU];  // column c of A; A[r][c]; B; B[(r - t) mod 4][.]
+        auto request = [&](int k) {
+            const double *A = gA + k * sA, *B = gB + k * sB;
 #pragma unroll
-        for (int i = 0; i < NX * NX; ++i) An[i] = gA[(N - 1) * sA + i];
+            for (int l = 0; l < NX; ++l) Acn[l] = inc ? A[l * NX + c] : 0.0;
+            Ann = in ? A[r * NX + c] : 0.0;
 #pragma unroll
-        for (int i = 0; i < NX * NU; ++i) Bn[i] = gB[(N - 1) * sB + i];
+            for (int i = 0; i < NX * NU; ++i) Bfn[i] = B[i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) Brn[t * NU + u] = rrow[t] < NX ? B[rrow[t] * NU + u] : 0.0;
+        };
+        request(N - 1);
         for (int k = N - 1; k >= 0; --k) {
-            double A[NX * NX], B[NX * NU];
+            double Ac[NX], Aown, Bf[NX * NU], Br[4 * NU];
 #pragma unroll
-            for (int i = 0; i < NX * NX; ++i) A[i] = An[i];
+            for (int l = 0; l < NX; ++l) Ac[l] = Acn[l];
+            Aown = Ann;
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) B[i] = Bn[i];
-            const int kn = k > 0 ? k - 1 : 0;
+            for (int i = 0; i < NX * NU; ++i) Bf[i] = Bfn[i];
 #pragma unroll
-            for (int i = 0; i < NX * NX; ++i) An[i] = gA[kn * sA + i];
+            for (int i = 0; i < 4 * NU; ++i) Br[i] = Brn[i];
+            request(k > 0 ? k - 1 : 0);
+            // PA[r][c] = sum_l P[r][l] A[l][c] ; PB[r][u] = sum_l P[r][l] B[l][u]
+            double PA = 0.0, PB[NU];
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bn[i] = gB[kn * sB + i];
-            double PA[NX * NX], PB[NX * NU];
+            for (int u = 0; u < NU; ++u) PB[u] = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
+            for (int l = 0; l < NX; ++l) {
+                const double prl = q4(P, l);
+                PA += prl * Ac[l];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    double a = 0.0;
+                for (int u = 0; u < NU; ++u) PB[u] += prl * Bf[l * NU + u];
+            }
+            // BPA[u][c] = sum_l B[l][u] PA[l][c] ; S[u][v] = w_u delta + sum_l B[l][u] PB[l][v]   (rows in rotated order)
+            double BPA[NU], S[NU * NU];
 #pragma unroll
-                    for (int l = 0; l < NX; ++l) a += P[i * NX + l] * A[l * NX + j];
-                    PA[i * NX + j] = a;
-                }
+            for (int u = 0; u < NU; ++u) {
+                BPA[u] = 0.0;
 #pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    double a = 0.0;
+                for (int v = 0; v < NU; ++v) S[u * NU + v] = (u == v) ? wu : 0.0;
+            }
 #pragma unroll
-                    for (int l = 0; l < NX; ++l) a += P[i * NX + l] * B[l * NU + j];
-                    PB[i * NU + j] = a;
+            for (int t = 0; t < 4; ++t) {
+                const double pa = rot(PA, t);
+                double pb[NU];
+#pragma unroll
+                for (int v = 0; v < NU; ++v) pb[v] = rot(PB[v], t);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    BPA[u] += Br[t * NU + u] * pa;
+#pragma unroll
+                    for (int v = 0; v < NU; ++v) S[u * NU + v] += Br[t * NU + u] * pb[v];
                 }
             }
-            double S[NU * NU], Si[NU * NU], BPA[NU * NX];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-#pragma unroll
-                for (int j = 0; j < NU; ++j) {
-                    double a = (i == j) ? wu : 0.0;
-#pragma unroll
-                    for (int l = 0; l < NX; ++l) a += B[l * NU + i] * PB[l * NU + j];
-                    S[i * NU + j] = a;
-                }
-#pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NX; ++l) a += B[l * NU + i] * PA[l * NX + j];
-                    BPA[i * NX + j] = a;
-                }
-            }
+            double Si[NU * NU];
             if constexpr (NU == 1) {
                 Si[0] = 1.0 / S[0];
             } else {
@@ -230,47 +271,34 @@ __global__ void __launch_bounds__(64, 2)
                 Si[2] = -S[2] * id;
                 Si[3] = S[0] * id;
             }
-            double Kk[NU * NX], Ac[NX * NX];
+            // K[u][c] = sum_v Si[u][v] BPA[v][c] ; Acl[r][c] = A[r][c] - sum_u B[r][u] K[u][c]
+            double Kk[NU], Acl_rc = Aown;
 #pragma unroll
-            for (int i = 0; i < NU; ++i)
+            for (int u = 0; u < NU; ++u) {
+                double a = 0.0;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int l = 0; l < NU; ++l) a += Si[i * NU + l] * BPA[l * NX + j];
-                    Kk[i * NX + j] = a;
-                }
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-#pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    double a = A[i * NX + j];
-#pragma unroll
-                    for (int l = 0; l < NU; ++l) a -= B[i * NU + l] * Kk[l * NX + j];
-                    Ac[i * NX + j] = a;
-                }
-            if (lane == 0) {
-                const int64_t w = wg(k);
-#pragma unroll
-                for (int i = 0; i < NX * NX; ++i) Acl[w * NX * NX + i] = Ac[i];
-#pragma unroll
-                for (int i = 0; i < NU * NX; ++i) Kg[w * NU * NX + i] = Kk[i];
-#pragma unroll
-                for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
+                for (int v = 0; v < NU; ++v) a += Si[u * NU + v] * BPA[v];
+                Kk[u] = a;
+                Acl_rc -= Br[u] * a;  // Br[0 * NU + u] = B[r][u]
             }
-            // P_k = Q_k + A' P_{k+1} Acl, symmetrised (x_0 is data: Q_0 = 0)
-            const double qk = (k >= 1) ? wx : 0.0;
-            // (A' P Acl is symmetric: the upper triangle is computed and mirrored)
+            if (lane < 16) {
+                const int64_t w = wg(k);
+                if (in) Acl[w * NX * NX + r * NX + c] = Acl_rc;
+                if (r == 0 && inc) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i)
-#pragma unroll
-                for (int j = i; j < NX; ++j) {
-                    double a = (i == j) ? qk : 0.0;
-#pragma unroll
-                    for (int l = 0; l < NX; ++l) a += PA[l * NX + i] * Ac[l * NX + j];  // (P A)' Acl = A' P Acl
-                    P[i * NX + j] = a;
-                    P[j * NX + i] = a;
+                    for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + c] = Kk[u];
                 }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
+                }
+            }
+            // P_k[r][c] = Q_k + sum_l PA[l][r] Acl[l][c], symmetrised (x_0 is data: Q_0 = 0)
+            double Pn = (in && r == c && k >= 1) ? wx : 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Pn += gather(PA, base16 + 4 * rrow[t] + r) * rot(Acl_rc, t);
+            const double Pt = gather(Pn, base16 + 4 * c + r);
+            P = 0.5 * (Pn + Pt);
         }
     }
     wsync();

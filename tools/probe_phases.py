@@ -28,3 +28,6 @@ if not one:
     sub = t[:, [0, 8, 9, 10, 11, 1]]
     for nme, a in zip(["stage operands", "x0/e loads, wsync", "chain", "gram", "q row, h"], range(5)):
         print(f"    build/{nme:18s} mean {(sub[:, a+1]-sub[:, a]).mean().item():8.0f} cyc")
+print("  iterations: max", int(it.max().item()), " 99%", torch.quantile(it, 0.99).item(), " 90%", torch.quantile(it, 0.9).item())
+pm = torch.maximum(it[0::2], it[1::2]) if not one else it
+print("  per-wavefront max(iterations of the pair): mean", pm.mean().item(), "max", pm.max().item())
