@@ -86,6 +86,13 @@ __device__ __forceinline__ double rl(double x, int lane)  // lane must be wave-u
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
 }
+// reciprocal: hardware estimate + two Newton steps (the IEEE division sequence is ~15 dependent instructions)
+__device__ __forceinline__ double frcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+}
 // a DPP move of a double (two dwords); CTRL: quad_perm 0x00..0xff, row_ror:n = 0x120 + n
 template <int CTRL> __device__ __forceinline__ double dpp64(double x)
 {
@@ -204,31 +211,36 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int t = 0; t < 4; ++t) rrow[t] = (r - t) & 3;
         double P = (in && r == c) ? wt : 0.0;  // P[r][c]
-        // operands of step k-1 are requested while step k computes
-        double Acn[NX], Ann, Bfn[NX * NU], Brn[4 * NU];  // column c of A; A[r][c]; B; B[(r - t) mod 4][.]
-        auto request = [&](int k) {
+        // operands are requested RD steps ahead into a register ring (a step is shorter than an HBM round trip)
+        constexpr int RD = 3;
+        double Acn[RD][NX], Ann[RD], Bfn[RD][NX * NU], Brn[RD][4 * NU];  // column c of A; A[r][c]; B; B[(r - t) mod 4][.]
+        auto request = [&](int d, int k) {
             const double *A = gA + k * sA, *B = gB + k * sB;
 #pragma unroll
-            for (int l = 0; l < NX; ++l) Acn[l] = inc ? A[l * NX + c] : 0.0;
-            Ann = in ? A[r * NX + c] : 0.0;
+            for (int l = 0; l < NX; ++l) Acn[d][l] = inc ? A[l * NX + c] : 0.0;
+            Ann[d] = in ? A[r * NX + c] : 0.0;
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bfn[i] = B[i];
+            for (int i = 0; i < NX * NU; ++i) Bfn[d][i] = B[i];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int u = 0; u < NU; ++u) Brn[t * NU + u] = rrow[t] < NX ? B[rrow[t] * NU + u] : 0.0;
+                for (int u = 0; u < NU; ++u) Brn[d][t * NU + u] = rrow[t] < NX ? B[rrow[t] * NU + u] : 0.0;
         };
-        request(N - 1);
-        for (int k = N - 1; k >= 0; --k) {
+#pragma unroll
+        for (int d = 0; d < RD; ++d) {
+            request(d, N - 1 - d >= 0 ? N - 1 - d : 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto step = [&](int d, int k) {
             double Ac[NX], Aown, Bf[NX * NU], Br[4 * NU];
 #pragma unroll
-            for (int l = 0; l < NX; ++l) Ac[l] = Acn[l];
-            Aown = Ann;
+            for (int l = 0; l < NX; ++l) Ac[l] = Acn[d][l];
+            Aown = Ann[d];
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bf[i] = Bfn[i];
+            for (int i = 0; i < NX * NU; ++i) Bf[i] = Bfn[d][i];
 #pragma unroll
-            for (int i = 0; i < 4 * NU; ++i) Br[i] = Brn[i];
-            request(k > 0 ? k - 1 : 0);
+            for (int i = 0; i < 4 * NU; ++i) Br[i] = Brn[d][i];
+            request(d, k - RD >= 0 ? k - RD : 0);
             // PA[r][c] = sum_l P[r][l] A[l][c] ; PB[r][u] = sum_l P[r][l] B[l][u]
             double PA = 0.0, PB[NU];
 #pragma unroll
@@ -263,9 +275,9 @@ __global__ void __launch_bounds__(64, 2)
             }
             double Si[NU * NU];
             if constexpr (NU == 1) {
-                Si[0] = 1.0 / S[0];
+                Si[0] = frcp(S[0]);
             } else {
-                const double det = S[0] * S[3] - S[1] * S[2], id = 1.0 / det;
+                const double det = S[0] * S[3] - S[1] * S[2], id = frcp(det);
                 Si[0] = S[3] * id;
                 Si[1] = -S[1] * id;
                 Si[2] = -S[2] * id;
@@ -299,7 +311,18 @@ __global__ void __launch_bounds__(64, 2)
             for (int t = 0; t < 4; ++t) Pn += gather(PA, base16 + 4 * rrow[t] + r) * rot(Acl_rc, t);
             const double Pt = gather(Pn, base16 + 4 * c + r);
             P = 0.5 * (Pn + Pt);
+        };
+        // full groups of RD steps (every step re-requests, clamped at the end: the same loads in flight on every path),
+        // then the remainder
+        int k = N - 1;
+        for (int g = N / RD; g > 0; --g) {
+#pragma unroll
+            for (int d = 0; d < RD; ++d) step(d, k - d);
+            k -= RD;
         }
+#pragma unroll
+        for (int d = 0; d < RD - 1; ++d)
+            if (k - d >= 0) step(d, k - d);
     }
     wsync();
     tick(1);
