@@ -275,6 +275,14 @@ int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t 
                             double target_vel, double length, double gravity, int32_t nsub,
                             void *x0, void *goal, void *targets, int64_t batch, void *stream);
 
+/* The same with the loops' bookkeeping fused in (one launch per period instead of two): if stats is not NULL,
+ * stats[0] += number of loops with status != 0 and stats[1] += sum of iters (iters may be NULL), as
+ * mpcqp_accumulate_stats does. */
+int mpcqp_wip_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride,
+                                  const int32_t *status, const int32_t *iters, int64_t *stats, int32_t N,
+                                  double sampling_period, double target_vel, double length, double gravity,
+                                  int32_t nsub, void *x0, void *goal, void *targets, int64_t batch, void *stream);
+
 /* Bookkeeping of closed loops (the reference's loops count nothing; ours report failures and iterations):
  * stats[0] += number of problems with status != 0, stats[1] += sum of iters. stats: two int64 in DEVICE memory. */
 int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream);

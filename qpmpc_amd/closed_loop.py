@@ -90,21 +90,19 @@ class WIPClosedLoop:
 
     def step(self, nb_mpc_steps: int = 1):
         """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
-        and one fused plant + reference launch (``mpcqp_wip_advance_batch``). Asynchronous."""
+        and one fused plant + reference + bookkeeping launch (``mpcqp_wip_advance_stats_batch``). Asynchronous."""
         lib = _capi.load()
         p, pend = self.problem, self.pendulum
         if self.mpc_steps == 0:
             self._write_references()
         for _ in range(nb_mpc_steps):
             self.solver.launch()
-            rc = lib.mpcqp_wip_advance_batch(
+            rc = lib.mpcqp_wip_advance_stats_batch(
                 _dtype_code(p.dtype), self.states.data_ptr(), self.solver.U.data_ptr(), p.nb_variables,
-                self.solver.status.data_ptr(), pend.nb_timesteps, pend.sampling_period, self.target_vel,
-                pend.length, pend.GRAVITY, NB_SUBSTEPS, p.initial_state.data_ptr(), p.goal_state.data_ptr(),
-                p.target_states.data_ptr(), p.batch_size, _stream_ptr())
-            _capi.check(rc, "mpcqp_wip_advance_batch")
-            lib.mpcqp_accumulate_stats(self.solver.status.data_ptr(), self.solver.iters.data_ptr(), p.batch_size,
-                                       self._stats.data_ptr(), _stream_ptr())
+                self.solver.status.data_ptr(), self.solver.iters.data_ptr(), self._stats.data_ptr(), pend.nb_timesteps,
+                pend.sampling_period, self.target_vel, pend.length, pend.GRAVITY, NB_SUBSTEPS, p.initial_state.data_ptr(),
+                p.goal_state.data_ptr(), p.target_states.data_ptr(), p.batch_size, _stream_ptr())
+            _capi.check(rc, "mpcqp_wip_advance_stats_batch")
             self.mpc_steps += 1
         return self.states
 

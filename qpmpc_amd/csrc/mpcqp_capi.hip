@@ -613,16 +613,26 @@ int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const Mpcq
     return launch_rollout(ka, dims->dtype, batch, (hipStream_t)stream);
 }
 
-int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
-                            int32_t N, double sampling_period, double target_vel, double length, double gravity,
-                            int32_t nsub, void *x0, void *goal, void *targets, int64_t batch, void *stream)
+int mpcqp_wip_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
+                                  const int32_t *iters, int64_t *stats, int32_t N, double sampling_period,
+                                  double target_vel, double length, double gravity, int32_t nsub, void *x0, void *goal,
+                                  void *targets, int64_t batch, void *stream)
 {
     if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
     if (!states || !U || !x0 || !goal || !targets || N <= 0 || nsub <= 0 || batch < 0 || !(length > 0) || !(gravity > 0))
         return MPCQP_EINVAL;
+    if (stats && !status) return MPCQP_EINVAL;
     if (batch == 0) return 0;
-    return launch_wip_advance(dtype, states, U, u_stride, status, N, sampling_period, target_vel, length, gravity,
-                              nsub, x0, goal, targets, batch, (hipStream_t)stream);
+    return launch_wip_advance(dtype, states, U, u_stride, status, iters, stats, N, sampling_period, target_vel, length,
+                              gravity, nsub, x0, goal, targets, batch, (hipStream_t)stream);
+}
+
+int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
+                            int32_t N, double sampling_period, double target_vel, double length, double gravity,
+                            int32_t nsub, void *x0, void *goal, void *targets, int64_t batch, void *stream)
+{
+    return mpcqp_wip_advance_stats_batch(dtype, states, U, u_stride, status, nullptr, nullptr, N, sampling_period,
+                                         target_vel, length, gravity, nsub, x0, goal, targets, batch, stream);
 }
 
 int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream)

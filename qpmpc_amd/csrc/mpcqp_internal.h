@@ -117,9 +117,9 @@ __host__ __device__ inline ModelLayout make_model_layout(int nx, int N, int n, i
     ml.total = o;  // one more element follows: the "P not positive definite" flag
     return ml;
 }
-int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
-                       double Tp, double vel, double length, double gravity, int nsub, void *x0, void *goal,
-                       void *targets, int64_t batch, hipStream_t st);
+int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
+                       const int32_t *iters, int64_t *stats, int N, double Tp, double vel, double length, double gravity,
+                       int nsub, void *x0, void *goal, void *targets, int64_t batch, hipStream_t st);
 int launch_lipm_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
                         double Tp, int nsub, int nb_dsp, int nb_ssp, double max_zmp, int64_t *index,
                         int64_t *stride_index, void *support, const void *strides, const void *foot_size, void *x0,
