@@ -364,9 +364,14 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
                         "each wavefront (instruction issue + dependent latency) sets the time, not HBM or FP64 throughput"}
     if args.config == 3:
         return {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS,
-                "kernel": "mpcqp_bigsolve_kernel<double, K_MID> (+ mpcqp_wip_advance, <2% of the step)",
+                "kernel": "mpcqp_stage_kernel<4, 1> (stage-wise Riccati active set, one problem per wavefront; ~80% of "
+                          "the period) + mpcqp_wip_advance_kernel (plant, references, bookkeeping)",
                 "achieved_gbs": gbs, **common,
-                "note": "fp64 FMA/MFMA-bound by intensity (~100 flop/B); peak = AMD's fp64 vector=matrix figure"}
+                "note": "achieved = the reference's dense condense + solve flops (fp64 FMA/MFMA-bound by intensity, "
+                        "~100 flop/B) over the period; the stage-wise kernel does not execute them (no P, no G): with "
+                        "1024 loops there is one wavefront per SIMD and the period is the latency of one problem's "
+                        "serial chain (Riccati recursion, scans, active-set iterations). Peak = AMD's fp64 "
+                        "vector=matrix figure"}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "kernel": "mpcqp_stagew_kernel<float, 12> (one launch per step: Riccati factor, LQR sweeps and the dual "
                       "active set of one problem per wavefront; the condensed QP is never formed)",
