@@ -303,6 +303,15 @@ int mpcqp_lipm_advance_batch(int32_t dtype, void *states, const void *U, int64_t
                              const void *foot_size, void *x0, void *goal, void *e, int64_t batch,
                              void *stream);
 
+/* The same with the loops' bookkeeping fused in: if stats is not NULL, stats[0] += number of walkers with
+ * status != 0 and stats[1] += sum of iters (iters may be NULL), as mpcqp_accumulate_stats does. */
+int mpcqp_lipm_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride,
+                                   const int32_t *status, const int32_t *iters, int64_t *stats, int32_t N,
+                                   double sampling_period, int32_t nsub, int32_t nb_dsp, int32_t nb_ssp,
+                                   double max_zmp_dist, int64_t *index, int64_t *stride_index, void *support,
+                                   const void *strides, const void *foot_size, void *x0, void *goal, void *e,
+                                   int64_t batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,7 @@ EXPORTS = (
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
     "mpcqp_lipm_advance_batch",
+    "mpcqp_lipm_advance_stats_batch",
 )
 
 
@@ -137,6 +138,9 @@ def load():
     lib.mpcqp_lipm_advance_batch.restype = C.c_int
     lib.mpcqp_lipm_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                              C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.mpcqp_lipm_advance_stats_batch.restype = C.c_int
+    lib.mpcqp_lipm_advance_stats_batch.argtypes = [C.c_int32, vp, vp, i64, vp, vp, vp, C.c_int32, C.c_double, C.c_int32,
+                                                   C.c_int32, C.c_int32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpcqp_rollout_batch.restype = C.c_int
     lib.mpcqp_rollout_batch.argtypes = [C.POINTER(Dims), C.POINTER(Operand), C.POINTER(Operand),
                                         C.POINTER(Operand), vp, i64, vp, vp]

@@ -257,16 +257,17 @@ class LIPMWalkingLoop:
         self.index = index
 
     def _advance_fused(self, first: bool) -> None:
-        """One launch of ``mpcqp_lipm_advance_batch``: plant + phase + next problem (or, for the very
-        first period, only the problem of the current phase)."""
+        """One launch of ``mpcqp_lipm_advance_stats_batch``: plant + phase + next problem + bookkeeping (for the
+        very first period only the problem of the current phase)."""
         p = self.problem
-        rc = _capi.load().mpcqp_lipm_advance_batch(
+        rc = _capi.load().mpcqp_lipm_advance_stats_batch(
             _dtype_code(p.dtype), self.states.data_ptr(), None if first else self.solver.U.data_ptr(), p.nb_variables,
-            None if first else self.solver.status.data_ptr(), self.nb_timesteps, self.sampling_period, self.substeps,
+            None if first else self.solver.status.data_ptr(), None if first else self.solver.iters.data_ptr(),
+            None if first else self._stats.data_ptr(), self.nb_timesteps, self.sampling_period, self.substeps,
             self.nb_dsp, self.nb_ssp, MAX_ZMP_DIST, self.index.data_ptr(), self.stride_index.data_ptr(),
             self.support.data_ptr(), self.strides.data_ptr(), self.foot_size.data_ptr(), p.initial_state.data_ptr(),
             p.goal_state.data_ptr(), p.e.data_ptr(), p.batch_size, _stream_ptr())
-        _capi.check(rc, "mpcqp_lipm_advance_batch")
+        _capi.check(rc, "mpcqp_lipm_advance_stats_batch")
 
     def step(self, nb_mpc_steps: int = 1, fused: bool = True):
         """Advance every walker by ``nb_mpc_steps`` MPC periods: per period one solver launch and one
@@ -293,8 +294,8 @@ class LIPMWalkingLoop:
                 jerk = torch.where(ok, self.solver.U[:, 0], torch.zeros_like(self.solver.U[:, 0]))
                 self._integrate(jerk)
                 self._advance_phase()
-            _capi.load().mpcqp_accumulate_stats(self.solver.status.data_ptr(), self.solver.iters.data_ptr(),
-                                                self.problem.batch_size, self._stats.data_ptr(), _stream_ptr())
+                _capi.load().mpcqp_accumulate_stats(self.solver.status.data_ptr(), self.solver.iters.data_ptr(),
+                                                    self.problem.batch_size, self._stats.data_ptr(), _stream_ptr())
             self.mpc_steps += 1
         return self.states
 

@@ -642,21 +642,33 @@ int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t 
     return launch_stats(status, iters, batch, stats, (hipStream_t)stream);
 }
 
+int mpcqp_lipm_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
+                                   const int32_t *iters, int64_t *stats, int32_t N, double sampling_period, int32_t nsub,
+                                   int32_t nb_dsp, int32_t nb_ssp, double max_zmp_dist, int64_t *index,
+                                   int64_t *stride_index, void *support, const void *strides, const void *foot_size,
+                                   void *x0, void *goal, void *e, int64_t batch, void *stream)
+{
+    if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
+    if (!states || !index || !stride_index || !support || !strides || !foot_size || !x0 || !goal || !e || N <= 0 ||
+        nsub <= 0 || nb_dsp < 0 || nb_ssp < 0 || batch < 0)
+        return MPCQP_EINVAL;
+    if (stats && !status) return MPCQP_EINVAL;
+    if (2 * (nb_dsp + nb_ssp) < N) return MPCQP_EINVAL;  // more than two steps in the receding horizon
+    if (batch == 0) return 0;
+    return launch_lipm_advance(dtype, states, U, u_stride, status, N, sampling_period, nsub, nb_dsp, nb_ssp,
+                               max_zmp_dist, index, stride_index, support, strides, foot_size, x0, goal, e, batch,
+                               iters, stats, (hipStream_t)stream);
+}
+
 int mpcqp_lipm_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
                              int32_t N, double sampling_period, int32_t nsub, int32_t nb_dsp, int32_t nb_ssp,
                              double max_zmp_dist, int64_t *index, int64_t *stride_index, void *support,
                              const void *strides, const void *foot_size, void *x0, void *goal, void *e,
                              int64_t batch, void *stream)
 {
-    if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
-    if (!states || !index || !stride_index || !support || !strides || !foot_size || !x0 || !goal || !e || N <= 0 ||
-        nsub <= 0 || nb_dsp < 0 || nb_ssp < 0 || batch < 0)
-        return MPCQP_EINVAL;
-    if (2 * (nb_dsp + nb_ssp) < N) return MPCQP_EINVAL;  // more than two steps in the receding horizon
-    if (batch == 0) return 0;
-    return launch_lipm_advance(dtype, states, U, u_stride, status, N, sampling_period, nsub, nb_dsp, nb_ssp,
-                               max_zmp_dist, index, stride_index, support, strides, foot_size, x0, goal, e, batch,
-                               (hipStream_t)stream);
+    return mpcqp_lipm_advance_stats_batch(dtype, states, U, u_stride, status, nullptr, nullptr, N, sampling_period, nsub,
+                                          nb_dsp, nb_ssp, max_zmp_dist, index, stride_index, support, strides,
+                                          foot_size, x0, goal, e, batch, stream);
 }
 
 }  // extern "C"

@@ -123,7 +123,7 @@ int launch_wip_advance(int dtype, void *states, const void *U, int64_t u_stride,
 int launch_lipm_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
                         double Tp, int nsub, int nb_dsp, int nb_ssp, double max_zmp, int64_t *index,
                         int64_t *stride_index, void *support, const void *strides, const void *foot_size, void *x0,
-                        void *goal, void *e, int64_t batch, hipStream_t st);
+                        void *goal, void *e, int64_t batch, const int32_t *iters, int64_t *stats, hipStream_t st);
 int launch_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, hipStream_t st);
 int launch_factor_model(const KernelArgs &ka, int dtype, const void *P, const void *G, const void *qb, const void *hb,
                         void *model, hipStream_t st);

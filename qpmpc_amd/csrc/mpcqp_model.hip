@@ -265,9 +265,25 @@ __global__ void __launch_bounds__(256) mpcqp_lipm_advance_kernel(
     T *__restrict__ states, const T *__restrict__ U, int64_t u_stride, const int32_t *__restrict__ status, int N, T Tp,
     int nsub, int nb_dsp, int nb_ssp, T max_zmp, int64_t *__restrict__ index, int64_t *__restrict__ stride_index,
     T *__restrict__ support, const T *__restrict__ strides, const T *__restrict__ foot_size, T *__restrict__ x0,
-    T *__restrict__ goal, T *__restrict__ e, int64_t batch)
+    T *__restrict__ goal, T *__restrict__ e, int64_t batch, const int32_t *__restrict__ iters,
+    unsigned long long *__restrict__ stats)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stats) {  // the loops' bookkeeping (as mpcqp_accumulate_stats): per-wavefront sums, one atomic pair each
+        unsigned long long f = 0, it = 0;
+        if (b < batch) {
+            f = status && status[b] != 0;
+            it = iters ? (unsigned long long)iters[b] : 0;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            f += __shfl_xor(f, o);
+            it += __shfl_xor(it, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (f) atomicAdd(stats, f);
+            if (it) atomicAdd(stats + 1, it);
+        }
+    }
     if (b >= batch) return;
     T p = states[b * 3 + 0], v = states[b * 3 + 1], a = states[b * 3 + 2];
     int idx = (int)index[b], sidx = (int)stride_index[b];
@@ -338,19 +354,20 @@ __global__ void __launch_bounds__(256) mpcqp_lipm_advance_kernel(
 int launch_lipm_advance(int dtype, void *states, const void *U, int64_t u_stride, const int32_t *status, int N,
                         double Tp, int nsub, int nb_dsp, int nb_ssp, double max_zmp, int64_t *index,
                         int64_t *stride_index, void *support, const void *strides, const void *foot_size, void *x0,
-                        void *goal, void *e, int64_t batch, hipStream_t st)
+                        void *goal, void *e, int64_t batch, const int32_t *iters, int64_t *stats, hipStream_t st)
 {
     const unsigned grid = (unsigned)((batch + 255) / 256);
+    unsigned long long *sp = (unsigned long long *)stats;
     if (dtype == MPCQP_F64)
         hipLaunchKernelGGL(mpcqp_lipm_advance_kernel<double>, dim3(grid), dim3(256), 0, st, (double *)states,
                            (const double *)U, u_stride, status, N, Tp, nsub, nb_dsp, nb_ssp, max_zmp, index,
                            stride_index, (double *)support, (const double *)strides, (const double *)foot_size,
-                           (double *)x0, (double *)goal, (double *)e, batch);
+                           (double *)x0, (double *)goal, (double *)e, batch, iters, sp);
     else
         hipLaunchKernelGGL(mpcqp_lipm_advance_kernel<float>, dim3(grid), dim3(256), 0, st, (float *)states,
                            (const float *)U, u_stride, status, N, (float)Tp, nsub, nb_dsp, nb_ssp, (float)max_zmp,
                            index, stride_index, (float *)support, (const float *)strides, (const float *)foot_size,
-                           (float *)x0, (float *)goal, (float *)e, batch);
+                           (float *)x0, (float *)goal, (float *)e, batch, iters, sp);
     return (int)hipGetLastError();
 }
 
