@@ -13,12 +13,15 @@
 //     A-operand order (64 consecutive values per MFMA), with its rows permuted so that the product lands in B-operand
 //     order again -- no shuffles, no LDS, no barrier between the steps. The matrices are stacked so that one product
 //     gives everything a step needs: backward [A_cl' ; -S^-1 B'] p -> (p_k, ff_k); forward [[A_cl, B], [-K, I]] (x, ff)
-//     -> (x_{k+1}, u_k). Records are requested D steps ahead into a register ring.
+//     -> (x_{k+1}, u_k). Records are requested D steps ahead into a register ring. The 16 columns of the operand are
+//     independent right-hand sides: a sweep pair carries the candidate row AND the R - 1 next most violated ones
+//     (V_a = P^-1 g_a' does not depend on the active set, so a later candidate found among them costs no sweep).
+//   * S = w_u I + B'PB (nu <= 4) is factored L D L' in registers; lane (., c) solves for column c of K and of -S^-1 B'.
 //   * ACTIVE SET: every active row a keeps V_a = P^-1 g_a' (inputs only) and h_a = G V_a (all m rows), so an iteration
 //     after the candidate's two sweeps is m-long AXPYs over coalesced arrays: c_a = h_p[row a], slack update
 //     s += t (h_p - sum r_a h_a). Slots are addressed through a permutation, nothing is copied when rows enter or leave.
-// One wavefront per problem and ~10 KB (f32) of LDS: 8+ problems per CU are in flight, against ONE for the dense
-// large-problem solver (its packed L^-1 fills the LDS).
+// One wavefront per problem and ~11 KB (f32) of LDS: 12 problems per CU are in flight (168 VGPRs), against ONE for the
+// dense large-problem solver (its packed L^-1 fills the LDS). DESIGN.md 3.8 has the measurements.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -205,7 +208,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
-    typedef V4 V4u __attribute__((aligned(4)));  // a row of the caller's C / D: element-aligned only
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
     T *Pm = (T *)stagew_smem, *PAm = Pm + 16 * LD, *Mm = PAm + 16 * LD, *Am = Mm + 16 * LD, *Atm = Am + 16 * LD;
     T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
-    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *Sim = Sm + 16, *cst = Sim + 16;  // cst: 0, 1
+    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *cst = Sm + 32;  // cst: 0, 1, spare cells
     T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq;
     int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
     int *crow = phys + maxq + 1;                                // rows whose P^-1 g' the latest sweeps left in Zs / Vc
