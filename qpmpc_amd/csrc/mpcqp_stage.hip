@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(64, 2)
             wsync();
             const double dpp = gdot(kp, wp, rp, Vp, Xp);
             while (!added) {
-                if (iters >= max_iter || nq >= maxq) {
+                if (iters >= max_iter) {
                     fail = true;
                     break;
                 }
@@ -756,6 +756,10 @@ __global__ void __launch_bounds__(64, 2)
                     break;
                 }
                 const bool full = (t2 <= t1);
+                if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
+                    fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
+                    break;
+                }
                 // ---- slacks: s_i -= t g_i . z ,  z = -(V_p - sum_a r_a V_a)  (this lane's chunk)
                 for (int k = k0; k < k1; ++k) {
                     double zu[NU], zx[NX];

@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             T up = T(0);
             bool added = false, fresh = true;  // fresh: cv[] still holds the c_a the pass above left
             while (!added) {
-                if (iters >= max_iter || nq >= maxq) {
+                if (iters >= max_iter) {
                     fail = true;
                     break;
                 }
@@ -921,6 +921,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     break;
                 }
                 const bool full = (t2 <= t1);
+                if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
+                    fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
+                    break;
+                }
                 tacc(12);
                 // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
                 nbest = INF;

@@ -289,3 +289,44 @@ def test_wide_stagewise_kernel_infeasible_and_slot_overflow_statuses():
         else:
             assert st1[b] == 1 and need[b] > 1 and float(tight.U[b].abs().max()) == 0.0  # MPCQP_MAX_ITER = 1
     assert (st1[:4] != 0).any()
+
+
+def test_stagewise_kernels_keep_going_when_every_slot_is_taken():
+    """With nu = 1 the active set can reach n rows (the plan fully determined by constraints) and still has to SWAP rows
+    to get to the minimiser: drops must be possible with full slots (a stress run, tools/stress_stagewise.py, found
+    problems of this family reported MAX_ITER while the condensed path solved them). Same random sequence as that run."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(12345)
+
+    def draw(B, nx, nu, N, mk, tight):
+        A = np.eye(nx) + 0.08 * rng.standard_normal((B, N, nx, nx))
+        Bm = rng.standard_normal((B, N, nx, nu))
+        Cm = rng.standard_normal((B, N, mk, nx))
+        D = rng.standard_normal((B, N, mk, nu))
+        x0 = 0.1 * rng.standard_normal((B, nx))
+        e = np.zeros((B, N, mk))
+        for b in range(B):
+            x = x0[b].copy()
+            for k in range(N):
+                e[b, k] = Cm[b, k] @ x + tight * (0.05 + 0.5 * np.abs(rng.standard_normal(mk)))
+                x = A[b, k] @ x
+        return dict(A=A, B=Bm, C=Cm, D=D, e=e, N=N, wt=2.0, wx=0.5, wu=1e-2, x0=x0,
+                    goal=rng.standard_normal((B, nx)), targets=rng.standard_normal((B, N * nx)))
+
+    w = None
+    for _ in range(7):  # the seventh problem family of the stress run: nx = 14, nu = 1, N = 60, mk = 6
+        nx, nu = int(rng.integers(2, 17)), int(rng.integers(1, 5))
+        N = min(int(rng.integers(3, max(4, 256 // nu))), 60)
+        mk = int(rng.integers(1, 7))
+        w = draw(256, nx, nu, N, mk, float(rng.choice([0.2, 1.0, 3.0])))
+    assert (nx, nu, N, mk) == (14, 1, 60, 6)
+    bp = W.to_batch_problem(w)
+    dense = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_CONDENSED)
+    wide = solve_mpc_batch(bp, formulation="stagewise", max_active=60)
+    torch.cuda.synchronize()
+    assert (dense.status == 0).all() and (wide.status == 0).all()
+    assert int(wide.iters.max()) > 60  # more iterations than slots: rows were swapped
+    scale = dense.U.abs().amax(dim=1).clamp(min=1.0)
+    assert float(((dense.U - wide.U).abs().amax(dim=1) / scale).max()) <= 1e-9
