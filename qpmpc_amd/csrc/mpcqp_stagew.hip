@@ -37,7 +37,6 @@ namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
-constexpr int D = 8;    // the sweeps request their records this many steps ahead
 constexpr int R = 4;    // right-hand sides per sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
@@ -204,10 +203,11 @@ __device__ __forceinline__ double rl(double v, int j)
 using namespace stagew;
 
 template <typename T, int NXC>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 1)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 2)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
+    constexpr int D = sizeof(T) == 4 ? 8 : 4;  // the sweeps request their records this many steps ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             if (k + d < N) step(d, k + d, false);
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
-    constexpr int GU = 2;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
+    constexpr int GU = sizeof(T) == 4 ? 2 : 1;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
     constexpr int SU = sizeof(T) == 4 ? 8 : 4;  // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             if (i == cap) capv = v;
         };
         if (ghoist) {
-            constexpr int ZU = 4;
+            constexpr int ZU = sizeof(T) == 4 ? 4 : 2;
             V4 gfix[NQ + 1];
             const int r = lane - (lane / mk) * mk;
 #pragma unroll
@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     // the violated row farthest from its hyperplane (active rows sit at s = 0 exactly, rows without a bound at ~1e30:
     // neither can be selected); ties go to the lowest row id, like the restatement
     // (TU rows per lane are requested together; `sp` returns the winner's slack)
-    constexpr int TU = 8;
+    constexpr int TU = sizeof(T) == 4 ? 8 : 4;
     auto select = [&](T &best, int &bi, T &sp) {
         best = INF;
         bi = 0x7fffffff;
