@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
-    constexpr int D = sizeof(T) == 4 ? 8 : 4;  // the sweeps request their records this many steps ahead
+    constexpr int D = 4;  // the sweeps request their records this many steps ahead (8 spills registers and gains nothing)
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
