@@ -100,6 +100,9 @@ template <int CTRL> __device__ __forceinline__ double dpp64(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+constexpr int kSerialMaxN = 128;  // horizons up to here take the serial sweeps of the LQR solve (if their factor fits LDS)
+constexpr int serial_fs(int nu) { return (32 + 36 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -129,7 +132,7 @@ __device__ __forceinline__ void wsync()
 
 using namespace stage;
 
-template <int NX, int NU>
+template <int NX, int NU, bool SERIAL>
 __global__ void __launch_bounds__(64, 2)
     mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
 {
@@ -144,6 +147,7 @@ __global__ void __launch_bounds__(64, 2)
     const int64_t NP = 64 * (int64_t)L;             // padded horizon (slot stride of the per-step arrays)
     auto wq = [&](int k) { return (int64_t)(k - k0) * 64 + lane; };  // workspace index of a step of THIS lane's chunk
     auto wg = [&](int k) {                                             // ... of any step
+        if (L == 1) return (int64_t)k;  // (one step per lane: no division in the serial sweeps)
         const int j = k / L;
         return (int64_t)(k - j * L) * 64 + j;
     };
@@ -151,6 +155,15 @@ __global__ void __launch_bounds__(64, 2)
     // ---- LDS: vectors shared by the lanes
     double *cv = (double *)stage_smem, *rv = cv + maxq, *lamv = rv + maxq;
     int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
+    // SERIAL: the factor of every step stays in LDS -- the serial sweeps read nothing else, and nothing of it goes to the
+    // workspace -- already in the ROTATED order in which quad q of a 16-lane row consumes it (16-byte reads):
+    //   FA  Arow[q][t] = Acl[q][(q-t)%4]      FAT Acol[q][t] = Acl[(q-t)%4][q]
+    //   FKR Krot[q][t][i] = K[i][(q-t)%4]     FBR Brot[q][t][i] = B[(q-t)%4][i]      FBO B[q][i]      FSI S^-1
+    constexpr int FA = 0, FAT = 16, FKR = 32, FBR = FKR + 16 * NU, FBO = FBR + 16 * NU, FSI = FBO + 4 * NU;
+    constexpr int FS = (FSI + NU * NU + 1) & ~1;
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    double *Fl = (double *)(actr + maxq);  // (32 maxq bytes precede it: 16-byte aligned)
+    double *ffl = Fl + N * FS;             // ... and the feed-forward terms of the latest backward sweep (N x NU)
     // ---- workspace
     double *ws = wsbase + prob * wl.total;
     double *Acl = ws + wl.Acl, *Kg = ws + wl.Kg, *Sinv = ws + wl.Sinv, *ffv = ws + wl.ff, *U0 = ws + wl.U0, *X0 = ws + wl.X0;
@@ -294,15 +307,36 @@ __global__ void __launch_bounds__(64, 2)
                 Acl_rc -= Br[u] * a;  // Br[0 * NU + u] = B[r][u]
             }
             if (lane < 16) {
-                const int64_t w = wg(k);
-                if (in) Acl[w * NX * NX + r * NX + c] = Acl_rc;
-                if (r == 0 && inc) {
+                if constexpr (SERIAL) {
+                    // every one of the 16 lanes writes its entry of each rotated image (zero outside NX x NX)
+                    double *f = Fl + k * FS;
+                    const int rc = (r - c) & 3, cr = (c - r) & 3;
+                    f[FA + r * 4 + rc] = in ? Acl_rc : 0.0;
+                    f[FAT + c * 4 + cr] = in ? Acl_rc : 0.0;
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + c] = Kk[u];
-                }
-                if (lane == 0) {
+                    for (int u = 0; u < NU; ++u) {
+                        f[FKR + (r * 4 + rc) * NU + u] = inc ? Kk[u] : 0.0;      // K[u][c], read by quad r at t = r - c
+                        f[FBR + (c * 4 + cr) * NU + u] = inr ? Br[u] : 0.0;      // B[r][u], read by quad c at t = c - r
+                    }
+                    if (c == 0) {
 #pragma unroll
-                    for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
+                        for (int u = 0; u < NU; ++u) f[FBO + r * NU + u] = inr ? Br[u] : 0.0;
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < NU * NU; ++i) f[FSI + i] = Si[i];
+                    }
+                } else {
+                    const int64_t w = wg(k);
+                    if (in) Acl[w * NX * NX + r * NX + c] = Acl_rc;
+                    if (r == 0 && inc) {
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + c] = Kk[u];
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
+                    }
                 }
             }
             // P_k[r][c] = Q_k + sum_l PA[l][r] Acl[l][c], symmetrised (x_0 is data: Q_0 = 0)
@@ -326,11 +360,14 @@ __global__ void __launch_bounds__(64, 2)
     }
     wsync();
     tick(1);
+    // Short horizons run the two sweeps of an LQR solve SERIALLY (below): ~100 cycles per step with the vector spread
+    // over the quads of a 16-lane row beat the chunked scans (and their 15 k cycles of prefix products) up to here.
+    constexpr bool serial = SERIAL;  // (a template parameter: the scans' prefix matrices must not stay live here)
     // chunk transition matrix Phi_j = Acl_{k1-1} ... Acl_{k0} of this lane's chunk (identity if empty)
     double Phi[NX * NX];
 #pragma unroll
     for (int i = 0; i < NX * NX; ++i) Phi[i] = (i / NX == i % NX) ? 1.0 : 0.0;
-    for (int k = k0; k < k1; ++k) {
+    for (int k = k0; k < (serial ? k0 : k1); ++k) {
         const double *Ac = Acl + wq(k) * NX * NX;
         double T[NX * NX];
 #pragma unroll
@@ -361,7 +398,7 @@ __global__ void __launch_bounds__(64, 2)
             Qb[i * NX + j] = Phi[j * NX + i];
         }
 #pragma unroll 1
-    for (int sdx = 1; sdx < 8; ++sdx) {
+    for (int sdx = 1; sdx < (serial ? 1 : 8); ++sdx) {
         double Pf[NX * NX], Pb[NX * NX];
 #pragma unroll
         for (int e = 0; e < NX * NX; ++e) {
@@ -627,6 +664,166 @@ __global__ void __launch_bounds__(64, 2)
             for (int i = 0; i < NX; ++i) x[i] = nx_[i];
         }
     };
+    // ---- the same two sweeps, serial in k (N <= kSerialMaxN). Lane layout as in the factor: quad q = (lane / 4) % 4 of a
+    // 16-lane row owns component q of the running vector and keeps the whole vector in ROTATED order, vr[t] =
+    // v[(q - t) mod 4] (three DPP row rotations of the new component after every step); the step's matrix entries are
+    // fetched from the workspace in that order, three steps ahead. No LDS, no scan, ~4 dependent FMAs per step.
+    const int sq = (lane >> 2) & 3;
+    const bool sqin = sq < NX;
+    int srow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) srow[t] = (sq - t) & 3;
+    auto rot4 = [&](double x, int t) {
+        switch (t) {
+        case 0: return x;
+        case 1: return dpp64<0x124>(x);
+        case 2: return dpp64<0x128>(x);
+        default: return dpp64<0x12c>(x);
+        }
+    };
+    constexpr int SRD = 2;  // request distance of the serial sweeps (their operands sit in LDS)
+    auto backward_s = [&](int kq, const double *crow, const double *drow, bool track) {
+        double own = (track && termQ && sqin) ? -ka.wt * ggoal[sq] : 0.0, pr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pr[t] = rot4(own, t);
+        const bool tgt = track && stageQ;
+        const double *tp = tgt ? gtgt : Acl;  // (a readable address when there are no targets)
+        const int kstart = track ? N - 1 : kq;  // the costate of a single row is zero above its step
+        double at[SRD][4], bt[SRD][4 * NU], si[SRD][NU * NU], tg[SRD];
+        auto req = [&](int d, int k) {
+            const double *f = Fl + k * FS;
+            const D2 *a2 = (const D2 *)(f + FAT + sq * 4), *b2 = (const D2 *)(f + FBR + sq * 4 * NU);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const D2 v = a2[h];  // Acl[(q - t)][q], t = 2h, 2h + 1
+                at[d][2 * h] = v[0];
+                at[d][2 * h + 1] = v[1];
+            }
+#pragma unroll
+            for (int h = 0; h < 2 * NU; ++h) {
+                const D2 v = b2[h];  // B[(q - t)][i] at index t NU + i
+                bt[d][2 * h] = v[0];
+                bt[d][2 * h + 1] = v[1];
+            }
+#pragma unroll
+            for (int i = 0; i < NU * NU; ++i) si[d][i] = f[FSI + i];
+            if (tgt) tg[d] = tp[(int64_t)k * NX + (sqin ? sq : 0)];
+        };
+#pragma unroll
+        for (int d = 0; d < SRD; ++d) {
+            req(d, kstart - d >= 0 ? kstart - d : 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto step = [&](int d, int k, bool again) {
+            double tt[NU], pn = 0.0;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) tt[i] = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                pn += at[d][t] * pr[t];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) tt[i] += bt[d][t * NU + i] * pr[t];
+            }
+            if (tgt && k >= 1 && sqin) pn -= ka.wx * tg[d];
+            if (k == kq) {
+                const double *Kq = Fl + k * FS + FKR + sq * 4 * NU;  // Krot[q][0][i] = K[i][q]
+                if (crow && sqin) pn -= crow[sq];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const double dv = drow ? drow[i] : 0.0;
+                    tt[i] -= dv;
+                    pn += Kq[i] * dv;  // - K' r with r = -D row
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NU; ++l) a -= si[d][i * NU + l] * tt[l];
+                if (lane == 0) ffl[k * NU + i] = a;
+            }
+            own = pn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pr[t] = rot4(own, t);
+            if (again) req(d, k - SRD >= 0 ? k - SRD : 0);
+        };
+        int k = kstart;
+        for (int g = (kstart + 1) / SRD; g > 0; --g) {
+#pragma unroll
+            for (int d = 0; d < SRD; ++d) step(d, k - d, true);
+            k -= SRD;
+        }
+#pragma unroll
+        for (int d = 0; d < SRD - 1; ++d)
+            if (k - d >= 0) step(d, k - d, false);
+    };
+    // (kff: the feed-forward terms above step kff were not written by the sweep before and count as zero)
+    auto forward_s = [&](const double *xs, int kff, double *Uo, double *Xo) {
+        double own = (xs && sqin) ? xs[sq] : 0.0, xr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xr[t] = rot4(own, t);
+        double at[SRD][4], kt[SRD][4 * NU], bo[SRD][NU], ff[SRD][NU];
+        auto req = [&](int d, int k) {
+            const double *f = Fl + k * FS, *fk = ffl + k * NU;
+            const D2 *a2 = (const D2 *)(f + FA + sq * 4), *k2 = (const D2 *)(f + FKR + sq * 4 * NU);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const D2 v = a2[h];  // Acl[q][(q - t)]
+                at[d][2 * h] = v[0];
+                at[d][2 * h + 1] = v[1];
+            }
+#pragma unroll
+            for (int h = 0; h < 2 * NU; ++h) {
+                const D2 v = k2[h];  // K[i][(q - t)] at index t NU + i
+                kt[d][2 * h] = v[0];
+                kt[d][2 * h + 1] = v[1];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                bo[d][i] = f[FBO + sq * NU + i];
+                ff[d][i] = fk[i];
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < SRD; ++d) {
+            req(d, d < N ? d : N - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        auto step = [&](int d, int k, bool again) {
+            double xn = 0.0, u[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const double f = (k <= kff) ? ff[d][i] : 0.0;
+                u[i] = f;
+                xn += bo[d][i] * f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                xn += at[d][t] * xr[t];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) u[i] -= kt[d][t * NU + i] * xr[t];
+            }
+            const int64_t w = wg(k);
+            if (lane < 16 && (lane & 3) == 0 && sqin) Xo[w * NX + sq] = own;
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) Uo[w * NU + i] = u[i];
+            }
+            own = xn;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xr[t] = rot4(own, t);
+            if (again) req(d, k + SRD < N ? k + SRD : N - 1);
+        };
+        int k = 0;
+        for (int g = N / SRD; g > 0; --g) {
+#pragma unroll
+            for (int d = 0; d < SRD; ++d) step(d, k + d, true);
+            k += SRD;
+        }
+#pragma unroll
+        for (int d = 0; d < SRD - 1; ++d)
+            if (k + d < N) step(d, k + d, false);
+    };
     // g_(k,r) . (U, X) = C_k[r] x_k + D_k[r] u_k
     auto gdot = [&](int k, int64_t w, int r, const double *Uv, const double *Xv) {  // w = workspace index of step k
         double a = 0.0;
@@ -648,10 +845,16 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
     for (int i = 0; i < (NX > NU ? NX : NU); ++i) zero_row[i] = 0.0;
     tick(2);
-    backward(-1, zero_row, zero_row, true);
+    if constexpr (serial)
+        backward_s(-1, nullptr, nullptr, true);
+    else
+        backward(-1, zero_row, zero_row, true);
     wsync();
     tick(3);
-    forward(gx0, U0, X0);
+    if constexpr (serial)
+        forward_s(gx0, N, U0, X0);
+    else
+        forward(gx0, U0, X0);
     wsync();
     tick(4);
     const double tol = ka.tol;
@@ -708,9 +911,15 @@ __global__ void __launch_bounds__(64, 2)
             double up = 0.0;
             bool added = false;
             // V_p = P^-1 g_p' and its trajectory do not change while p waits for room: solved once
-            backward(kp, qrow, rrow, false);
+            if constexpr (serial)
+                backward_s(kp, gC ? gC + kp * sC + rp * NX : nullptr, gD ? gD + kp * sD + rp * NU : nullptr, false);
+            else
+                backward(kp, qrow, rrow, false);
             wsync();
-            forward(nullptr, Vp, Xp);
+            if constexpr (serial)
+                forward_s(nullptr, kp, Vp, Xp);
+            else
+                forward(nullptr, Vp, Xp);
             wsync();
             const double dpp = gdot(kp, wp, rp, Vp, Xp);
             while (!added) {
@@ -945,17 +1154,26 @@ int stage_default_maxq(const KernelArgs &ka)
 
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
 
-template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+template <int NX, int NU, bool SERIAL>
+static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
-    const size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int));
-    auto kern = mpcqp_stage_kernel<NX, NU>;
+    size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 8;
+    if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU) * sizeof(double);
+    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64), lds, st, ka, wl, (double *)ws, batch);
     return (int)hipGetLastError();
+}
+
+template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    // serial sweeps: short horizons whose factor fits 32 KB of LDS next to the active-set vectors
+    const bool serial = ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(NU) + NU) * sizeof(double) <= 36 * 1024;
+    return serial ? launch_stage_s<NX, NU, true>(ka, maxq, batch, ws, st) : launch_stage_s<NX, NU, false>(ka, maxq, batch, ws, st);
 }
 
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
