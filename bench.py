@@ -364,8 +364,8 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
                         "each wavefront (instruction issue + dependent latency) sets the time, not HBM or FP64 throughput"}
     if args.config == 3:
         return {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS,
-                "kernel": "mpcqp_stage_kernel<4, 1> (stage-wise Riccati active set, one problem per wavefront; ~80% of "
-                          "the period) + mpcqp_wip_advance_kernel (plant, references, bookkeeping)",
+                "kernel": "mpcqp_stage_kernel<4, 1, serial> (stage-wise Riccati active set, one problem per wavefront) with "
+                          "the plant step, next references and bookkeeping as its epilogue: one launch per period",
                 "achieved_gbs": gbs, **common,
                 "note": "achieved = the reference's dense condense + solve flops (fp64 FMA/MFMA-bound by intensity, "
                         "~100 flop/B) over the period; the stage-wise kernel does not execute them (no P, no G): with "

@@ -283,6 +283,20 @@ int mpcqp_wip_advance_stats_batch(int32_t dtype, void *states, const void *U, in
                                   double sampling_period, double target_vel, double length, double gravity,
                                   int32_t nsub, void *x0, void *goal, void *targets, int64_t batch, void *stream);
 
+/* A WHOLE control period of `batch` wheeled-inverted-pendulum loops in ONE launch: mpcqp_build_solve_batch of every
+ * loop's problem, then -- as the epilogue of the solver kernel, by the wavefront that solved it -- the plant step with
+ * the plan's first input (zero when status != 0) and the loop's next problem written IN PLACE over x0 / goal / targets
+ * of `problem`, exactly as mpcqp_wip_advance_batch does (examples/wheeled_inverted_pendulum.py:99-118, one iteration of
+ * the loop). states [batch, 4] is updated in place; loop_stats (int64 [batch, 2], device, may be NULL): [b][0] += 1 if
+ * the plan was not found, [b][1] += iterations. Only for problems mpcqp_build_solve_batch hands to the stage-wise
+ * kernel (float64, nx = 4, nu = 1, 16 < N <= 128, per-loop x0 / goal / targets): MPCQP_EUNSUPPORTED otherwise -- the
+ * caller then launches the solve and mpcqp_wip_advance_stats_batch separately. Workspace: mpcqp_workspace_bytes. */
+int mpcqp_wip_period_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
+                           const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status, int32_t *iters,
+                           void *workspace, size_t workspace_bytes, void *states, int64_t *loop_stats,
+                           double sampling_period, double target_vel, double length, double gravity, int32_t nsub,
+                           void *stream);
+
 /* Bookkeeping of closed loops (the reference's loops count nothing; ours report failures and iterations):
  * stats[0] += number of problems with status != 0, stats[1] += sum of iters. stats: two int64 in DEVICE memory. */
 int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream);

@@ -40,6 +40,7 @@ EXPORTS = (
     "mpcqp_accumulate_stats",
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
+    "mpcqp_wip_period_batch",
     "mpcqp_lipm_advance_batch",
     "mpcqp_lipm_advance_stats_batch",
 )
@@ -132,6 +133,9 @@ def load():
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]
+    lib.mpcqp_wip_period_batch.restype = C.c_int
+    lib.mpcqp_wip_period_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp,
+                                           C.c_size_t, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
     lib.mpcqp_wip_advance_stats_batch.restype = C.c_int
     lib.mpcqp_wip_advance_stats_batch.argtypes = [C.c_int32, vp, vp, i64, vp, vp, vp, C.c_int32, C.c_double, C.c_double,
                                                   C.c_double, C.c_double, C.c_int32, vp, vp, vp, i64, vp]

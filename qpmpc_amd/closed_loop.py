@@ -43,7 +43,10 @@ class WIPClosedLoop:
     """``B`` independent wheeled-inverted-pendulum control loops advancing in lock step."""
 
     def __init__(self, x0, nb_timesteps: int = 50, sampling_period: float = 0.024, target_vel: float = 0.5,
-                 ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False):
+                 ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False, fused_period: bool = True):
+        """``fused_period``: run a whole period (solve + plant + next problem + bookkeeping) in ONE launch,
+        ``mpcqp_wip_period_batch``, where the solver kernel supports it (else, and with ``shared_model``, two
+        launches per period)."""
         import torch
 
         self.pendulum = WheeledInvertedPendulum(nb_timesteps=nb_timesteps, sampling_period=sampling_period)
@@ -65,6 +68,9 @@ class WIPClosedLoop:
         self.mpc_steps = 0
         self._stats = torch.zeros((2,), dtype=torch.int64, device=dev)  # [failed, sum of iterations], mpcqp_accumulate_stats
         self.failed, self.iters_total = self._stats[0], self._stats[1]
+        # per-loop [failed, iterations] counters of the fused period (no atomics in the solver kernel's epilogue)
+        self._loopstats = torch.zeros((self.problem.batch_size, 2), dtype=torch.int64, device=dev)
+        self._fused = bool(fused_period) and not shared_model  # cleared by the first launch if the kernel cannot do it
 
     def _write_references(self) -> None:
         """target_states / goal_state of every loop, in place (so the bound pointers stay valid)."""
@@ -87,6 +93,7 @@ class WIPClosedLoop:
         self.mpc_steps = 0
         self.failed.zero_()
         self.iters_total.zero_()
+        self._loopstats.zero_()
 
     def step(self, nb_mpc_steps: int = 1):
         """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
@@ -96,6 +103,16 @@ class WIPClosedLoop:
         if self.mpc_steps == 0:
             self._write_references()
         for _ in range(nb_mpc_steps):
+            if self._fused:
+                rc = lib.mpcqp_wip_period_batch(
+                    *self.solver._args, self.states.data_ptr(), self._loopstats.data_ptr(), pend.sampling_period,
+                    self.target_vel, pend.length, pend.GRAVITY, NB_SUBSTEPS, _stream_ptr())
+                if rc == _capi.EUNSUPPORTED:
+                    self._fused = False  # (another kernel serves this size: two launches per period)
+                else:
+                    _capi.check(rc, "mpcqp_wip_period_batch")
+                    self.mpc_steps += 1
+                    continue
             self.solver.launch()
             rc = lib.mpcqp_wip_advance_stats_batch(
                 _dtype_code(p.dtype), self.states.data_ptr(), self.solver.U.data_ptr(), p.nb_variables,
@@ -113,8 +130,8 @@ class WIPClosedLoop:
             "loops": B,
             "mpc_steps": self.mpc_steps,
             "builds_and_solves": self.mpc_steps * B,
-            "failed": int(self.failed.item()),
-            "mean_iters": float(self.iters_total.item()) / solves,
+            "failed": int(self.failed.item()) + int(self._loopstats[:, 0].sum().item()),
+            "mean_iters": (float(self.iters_total.item()) + float(self._loopstats[:, 1].sum().item())) / solves,
         }
 
 

@@ -613,6 +613,43 @@ int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A, const Mpcq
     return launch_rollout(ka, dims->dtype, batch, (hipStream_t)stream);
 }
 
+int mpcqp_wip_period_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, const MpcqpSolveOpts *opts,
+                           void *U, void *lam, int32_t *status, int32_t *iters, void *workspace, size_t workspace_bytes,
+                           void *states, int64_t *loop_stats, double sampling_period, double target_vel, double length,
+                           double gravity, int32_t nsub, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_problem(dims, problem))) return rc;
+    if (batch < 0 || !U || !states || nsub <= 0 || !(length > 0) || !(gravity > 0)) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    ka.U = U;
+    ka.lam = lam;
+    ka.status = status;
+    ka.iters = iters;
+    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+    // the plant is the 4-state, 1-input pendulum, every loop with its own x0, goal and targets; only the stage-wise
+    // kernel carries the epilogue
+    if (ka.nx != 4 || ka.nu != 1 || !problem->x0.ptr || !problem->goal.ptr || !problem->targets.ptr ||
+        problem->x0.batch_stride != 4 || problem->goal.batch_stride != 4 || problem->targets.batch_stride != (int64_t)ka.N * 4 ||
+        !use_stage_auto(ka, dims->dtype))
+        return MPCQP_EUNSUPPORTED;
+    const int maxq = stage_default_maxq(ka);
+    const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+    if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+    ka.ep_on = 1;
+    ka.ep_nsub = nsub;
+    ka.ep_Tp = sampling_period;
+    ka.ep_vel = target_vel;
+    ka.ep_omega2 = gravity / length;
+    ka.ep_g = gravity;
+    ka.ep_states = states;
+    ka.ep_loopstats = (long long *)loop_stats;
+    return launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream);
+}
+
 int mpcqp_wip_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,
                                   const int32_t *iters, int64_t *stats, int32_t N, double sampling_period,
                                   double target_vel, double length, double gravity, int32_t nsub, void *x0, void *goal,

@@ -34,6 +34,12 @@ struct KernelArgs {
     void *warm_state;             // per-problem active set + operator (read if warm_start, written at the end), or null
     int warm_start;
     void *probe;                  // developer probe: int64 stamps per problem, or null
+    // closed-loop epilogue of the stage-wise kernel (mpcqp_wip_period_batch): after its solve every wavefront applies
+    // the first input of its plan to the wheeled-inverted-pendulum plant and writes its loop's NEXT problem in place
+    int ep_on, ep_nsub;
+    double ep_Tp, ep_vel, ep_omega2, ep_g;
+    void *ep_states;              // [batch, 4], updated in place
+    long long *ep_loopstats;      // [batch, 2]: += (failed, iterations), or null
 };
 
 // LDS carve, in elements of T. Matrices are row-major with odd row stride ld.

@@ -16,6 +16,7 @@
 
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
+#include "mpcqp_plant.h"
 
 namespace mpcqp {
 
@@ -111,37 +112,6 @@ __global__ void __launch_bounds__(256) mpcqp_model_kernel(const KernelArgs ka, c
     }
 }
 
-// sin and cos of a pendulum angle: on |x| <= 0.5 (where an upright pendulum lives) the Taylor series to x^17 / x^16 in
-// Horner form (truncation < 2e-23, i.e. below one ulp; 18 FMAs instead of the library's ~100 instructions), the library
-// beyond
-__device__ __forceinline__ void sincos_t(double x, double *s, double *c)
-{
-    if (fabs(x) <= 0.5) {
-        const double z = x * x;
-        double ps = 1.0 / 355687428096000.0;  // 1/17!
-        ps = fma(ps, z, -1.0 / 1307674368000.0);
-        ps = fma(ps, z, 1.0 / 6227020800.0);
-        ps = fma(ps, z, -1.0 / 39916800.0);
-        ps = fma(ps, z, 1.0 / 362880.0);
-        ps = fma(ps, z, -1.0 / 5040.0);
-        ps = fma(ps, z, 1.0 / 120.0);
-        ps = fma(ps, z, -1.0 / 6.0);
-        *s = fma(x * z, ps, x);
-        double pc = 1.0 / 20922789888000.0;  // 1/16!
-        pc = fma(pc, z, -1.0 / 87178291200.0);
-        pc = fma(pc, z, 1.0 / 479001600.0);
-        pc = fma(pc, z, -1.0 / 3628800.0);
-        pc = fma(pc, z, 1.0 / 40320.0);
-        pc = fma(pc, z, -1.0 / 720.0);
-        pc = fma(pc, z, 1.0 / 24.0);
-        pc = fma(pc, z, -0.5);
-        *c = fma(z, pc, 1.0);
-    } else {
-        sincos(x, s, c);
-    }
-}
-__device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(x, s, c); }
-
 // Plant + reference update of one control period (include/mpcqp.h: mpcqp_wip_advance_batch), optionally with the
 // loops' bookkeeping (stats[0] += failures, stats[1] += iterations). State = [r, theta, r', theta'].
 // ONE WAVEFRONT PER LOOP, 16 loops per workgroup: every lane integrates the plant (same cost as one lane), then the
@@ -159,36 +129,12 @@ __global__ void __launch_bounds__(1024) mpcqp_wip_advance_kernel(T *__restrict__
     const int64_t b = (int64_t)blockIdx.x * 16 + wave;
     unsigned long long f = 0, it = 0;
     if (b < batch) {
-        T r = states[b * 4 + 0], th = states[b * 4 + 1], rd = states[b * 4 + 2], thd = states[b * 4 + 3];
         const bool failed = status && status[b] != 0;
         const T a = failed ? T(0) : U[b * u_stride];
         f = failed;
         it = iters ? (unsigned long long)iters[b] : 0;
-        const T dt = Tp / (T)nsub, ag = a / g;
-        for (int i = 0; i < nsub; ++i) {
-            T sn, cs;
-            sincos_t(th, &sn, &cs);  // (one argument reduction for both)
-            const T thdd = omega2 * (sn - ag * cs);
-            const T r2 = r + dt * (rd + dt * (a / 2));
-            const T th2 = th + dt * (thd + dt * (thdd / 2));
-            rd = rd + dt * a;
-            thd = thd + dt * thdd;
-            r = r2;
-            th = th2;
-        }
-        if (lane < 4) {
-            const T v = lane == 0 ? r : lane == 1 ? th : lane == 2 ? rd : thd;
-            states[b * 4 + lane] = v;
-            x0[b * 4 + lane] = v;
-            goal[b * 4 + lane] = lane == 0 ? r + ((T)N * Tp) * vel : lane == 2 ? vel : T(0);
-        }
-        T *tg = targets + b * (int64_t)N * 4;
-        for (int k = lane; k < N; k += 64) {
-            tg[k * 4 + 0] = r + ((T)k * Tp) * vel;
-            tg[k * 4 + 1] = T(0);
-            tg[k * 4 + 2] = vel;
-            tg[k * 4 + 3] = T(0);
-        }
+        wip_period_wave<T>(lane, states + b * 4, a, N, Tp, vel, omega2, g, nsub, x0 + b * 4, goal + b * 4,
+                           targets + b * (int64_t)N * 4);
     }
     if (stats) {
         if (lane == 0) {

@@ -35,6 +35,7 @@
 
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
+#include "mpcqp_plant.h"
 
 namespace mpcqp {
 
@@ -1137,6 +1138,18 @@ __global__ void __launch_bounds__(64, 2)
     if (lane == 0) {
         if (ka.status) ka.status[prob] = status;
         if (ka.iters) ka.iters[prob] = iters;
+    }
+    if (ka.ep_on) {
+        // the rest of the control period: plant step with the plan's first input (zero if there is no plan), then the
+        // loop's next problem written over the one just solved (this wavefront is its only reader)
+        wsync();
+        const double a = ok ? ((const double *)ka.U)[prob * (int64_t)N * NU] : 0.0;
+        wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
+                                ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt));
+        if (lane == 0 && ka.ep_loopstats) {
+            ka.ep_loopstats[2 * prob] += ok ? 0 : 1;
+            ka.ep_loopstats[2 * prob + 1] += iters;
+        }
     }
 }
 

@@ -928,3 +928,32 @@ def test_fuzz_dimensions_float32():
         assert both.sum() >= (sto == 0).sum() - 1, ((nx, nu, N, mk), st, sto)
     print("f32 fuzz: families whose solved counts agree with float64:", agree, "of", total // 6)
     assert agree >= F32_FUZZ_AGREE, (agree, total)
+
+
+def test_closed_loop_period_in_one_launch_equals_two_launches():
+    """mpcqp_wip_period_batch (plant step, next problem and bookkeeping as the epilogue of the solver kernel) against the
+    solver launch followed by mpcqp_wip_advance_stats_batch: bitwise the same trajectories, the same counters; a horizon
+    served by another kernel (N = 12: the two-problems-per-wavefront kernel) falls back to two launches by itself."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(5)
+    x0 = rng.standard_normal((96, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    x0[0] = [0.0, 0.3, 0.0, 1.0]  # saturates the input box: iterations are counted
+    a = WIPClosedLoop(x0.copy(), fused_period=True)
+    b = WIPClosedLoop(x0.copy(), fused_period=False)
+    for _ in range(4):
+        a.step(10)
+        b.step(10)
+        torch.cuda.synchronize()
+        assert a._fused and not b._fused
+        assert torch.equal(a.states, b.states)
+        assert torch.equal(a.problem.target_states, b.problem.target_states) and torch.equal(a.problem.goal_state, b.problem.goal_state)
+    sa, sb = a.stats(), b.stats()
+    assert sa == sb and sa["mpc_steps"] == 40 and sa["mean_iters"] > 0.0
+    a.reset(x0)
+    a.step(3)
+    assert a.stats()["mpc_steps"] == 3
+    short = WIPClosedLoop(x0[:8].copy(), nb_timesteps=12, sampling_period=0.1)
+    short.step(5)
+    torch.cuda.synchronize()
+    assert not short._fused and short.stats()["failed"] == 0
