@@ -491,6 +491,10 @@ def other_workloads():
     rng = np.random.default_rng(1)
     loop = WIPClosedLoop(rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1]))
     out["config3_closed_loop_rebuild_every_step"] = rate(loop.step, 1024, 50)
+    x0r = rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    loop_r = WIPClosedLoop(x0r, reuse_factor=True)
+    loop_r.step(2)  # the first period keeps the factor
+    out["config3_closed_loop_factor_reused_resolves"] = rate(loop_r.step, 1024, 50)
     w = W.humanoid_batch(65536)
     bp = W.to_batch_problem(w)
     out["config4_humanoid_sweep_65536_fused"] = rate(PreparedSolve(bp).launch, 65536, 10)

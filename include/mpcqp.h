@@ -116,6 +116,12 @@ typedef struct MpcqpProblem {
 #define MPCQP_OPT_STAGE_WIDE 32   /* mpcqp_stagewise_solve_batch: take the wide kernel (nx <= 16, nu <= 4, MFMA
                                      sweeps) also where the narrow one (nx <= 4, nu <= 2, float64) applies       */
 
+#define MPCQP_OPT_KEEP_FACTOR 64  /* stage-wise kernels: leave the Riccati factor of every problem in the workspace ...  */
+#define MPCQP_OPT_REUSE_FACTOR 128 /* ... and start from it: the caller asserts that A, B and the weights are those of the
+                                      launch that kept it, in the same workspace (build once, then only x0 / goal /
+                                      targets / e change: the reference's update_cost_vector / update_constraint_vector
+                                      usage, mpc_qp.py:129-163). Ignored by the other kernels (they rebuild).          */
+
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
     int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */

@@ -16,6 +16,7 @@ SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
 EUNSUPPORTED = -6
 ABI_VERSION = 5
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
+OPT_KEEP_FACTOR, OPT_REUSE_FACTOR = 64, 128
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")

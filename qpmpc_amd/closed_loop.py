@@ -43,10 +43,14 @@ class WIPClosedLoop:
     """``B`` independent wheeled-inverted-pendulum control loops advancing in lock step."""
 
     def __init__(self, x0, nb_timesteps: int = 50, sampling_period: float = 0.024, target_vel: float = 0.5,
-                 ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False, fused_period: bool = True):
+                 ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False, fused_period: bool = True,
+                 reuse_factor: bool = False):
         """``fused_period``: run a whole period (solve + plant + next problem + bookkeeping) in ONE launch,
         ``mpcqp_wip_period_batch``, where the solver kernel supports it (else, and with ``shared_model``, two
-        launches per period)."""
+        launches per period). ``reuse_factor``: the dynamics and weights never change along the loop, so the
+        stage-wise kernel keeps its Riccati factor in the workspace after the first period and starts from it
+        afterwards (``MPCQP_OPT_KEEP_FACTOR`` / ``MPCQP_OPT_REUSE_FACTOR``: build once, re-solve -- the reference's
+        ``update_cost_vector`` / ``update_constraint_vector`` usage; ignored by kernels that rebuild anyway)."""
         import torch
 
         self.pendulum = WheeledInvertedPendulum(nb_timesteps=nb_timesteps, sampling_period=sampling_period)
@@ -71,6 +75,10 @@ class WIPClosedLoop:
         # per-loop [failed, iterations] counters of the fused period (no atomics in the solver kernel's epilogue)
         self._loopstats = torch.zeros((self.problem.batch_size, 2), dtype=torch.int64, device=dev)
         self._fused = bool(fused_period) and not shared_model  # cleared by the first launch if the kernel cannot do it
+        self._period_args = None
+        self._reuse = bool(reuse_factor) and not shared_model
+        if self._reuse:
+            self.solver._opts.flags |= _capi.OPT_KEEP_FACTOR
 
     def _write_references(self) -> None:
         """target_states / goal_state of every loop, in place (so the bound pointers stay valid)."""
@@ -94,6 +102,7 @@ class WIPClosedLoop:
         self.failed.zero_()
         self.iters_total.zero_()
         self._loopstats.zero_()
+        # (the kept factor stays valid across episodes: it depends on the dynamics and the weights only)
 
     def step(self, nb_mpc_steps: int = 1):
         """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
@@ -103,10 +112,17 @@ class WIPClosedLoop:
         if self.mpc_steps == 0:
             self._write_references()
         for _ in range(nb_mpc_steps):
+            if self._reuse and self.mpc_steps == 1:  # the first period of the episode left the factor in the workspace
+                self.solver._opts.flags = (self.solver._opts.flags & ~_capi.OPT_KEEP_FACTOR) | _capi.OPT_REUSE_FACTOR
             if self._fused:
-                rc = lib.mpcqp_wip_period_batch(
-                    *self.solver._args, self.states.data_ptr(), self._loopstats.data_ptr(), pend.sampling_period,
-                    self.target_vel, pend.length, pend.GRAVITY, NB_SUBSTEPS, _stream_ptr())
+                if self._period_args is None:  # converted once: the call is launch-rate-bound otherwise
+                    import ctypes as C
+
+                    self._period_args = tuple(self.solver._args) + (
+                        C.c_void_p(self.states.data_ptr()), C.c_void_p(self._loopstats.data_ptr()),
+                        C.c_double(pend.sampling_period), C.c_double(self.target_vel), C.c_double(pend.length),
+                        C.c_double(pend.GRAVITY), C.c_int32(NB_SUBSTEPS))
+                rc = lib.mpcqp_wip_period_batch(*self._period_args, _stream_ptr())
                 if rc == _capi.EUNSUPPORTED:
                     self._fused = False  # (another kernel serves this size: two launches per period)
                 else:

@@ -41,8 +41,11 @@ namespace mpcqp {
 
 namespace stage {
 
+constexpr int kSerialMaxN = 128;  // horizons up to here take the serial sweeps of the LQR solve (if their factor fits LDS)
+constexpr int serial_fs(int nu) { return (32 + 36 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
+
 struct Ws {  // per-problem workspace carve, in doubles (host-computed, passed by value)
-    int64_t Acl, Kg, Sinv, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
+    int64_t Acl, Kg, Sinv, Fimg, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
     int maxq;
 };
 
@@ -63,6 +66,7 @@ __host__ __device__ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
     w.Acl = take(NP * nx * nx);
     w.Kg = take(NP * nu * nx);
     w.Sinv = take(NP * nu * nu);
+    w.Fimg = take(N <= kSerialMaxN ? (int64_t)N * serial_fs(nu) : 0);  // copy of the LDS factor image (MPCQP_OPT_KEEP_FACTOR)
     w.ff = take(NP * nu);
     w.U0 = take(NP * nu);
     w.X0 = take(NP * nx);
@@ -101,9 +105,6 @@ template <int CTRL> __device__ __forceinline__ double dpp64(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-constexpr int kSerialMaxN = 128;  // horizons up to here take the serial sweeps of the LQR solve (if their factor fits LDS)
-constexpr int serial_fs(int nu) { return (32 + 36 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
-
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -196,7 +197,10 @@ __global__ void __launch_bounds__(64, 2)
     // in the same position of the four quads (row rotations by 4, 8, 12: rotation t delivers row (r - t) mod 4, so
     // operands that come from memory are fetched in that order). Only (PA)' in P_k = (PA)' Acl needs a general gather
     // (ds_bpermute). ~90 instructions per step instead of ~350 executed redundantly by every lane.
-    {
+    // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
+    // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
+    const bool reuse = ka.opt_flags & MPCQP_OPT_REUSE_FACTOR, keep = ka.opt_flags & MPCQP_OPT_KEEP_FACTOR;
+    if (!reuse) {
         const int r = (lane >> 2) & 3, c = lane & 3;
         const bool inr = r < NX, inc = c < NX, in = inr && inc;
         auto q4 = [&](double x, int l) {  // element l of the lane's quad (l: compile-time after unrolling)
@@ -360,6 +364,27 @@ __global__ void __launch_bounds__(64, 2)
             if (k - d >= 0) step(d, k - d);
     }
     wsync();
+    if constexpr (SERIAL) {
+        // the factor image travels between LDS and the workspace as it is (coalesced, one round trip)
+        double *img = ws + wl.Fimg;
+        if (reuse) {
+            // eight 16-byte requests per lane in flight (a load -> LDS store loop pays one round trip per turn)
+            const D2 *src = (const D2 *)img;
+            D2 *dst = (D2 *)Fl;
+            const int n2 = N * FS / 2;  // (FS is even)
+            for (int i0 = lane; i0 < n2; i0 += 64 * 8) {
+                D2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[i0 + 64 * u < n2 ? i0 + 64 * u : n2 - 1];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 64 * u < n2) dst[i0 + 64 * u] = v[u];
+            }
+            wsync();
+        } else if (keep) {
+            for (int i = lane; i < N * FS; i += 64) img[i] = Fl[i];
+        }
+    }
     tick(1);
     // Short horizons run the two sweeps of an LQR solve SERIALLY (below): ~100 cycles per step with the vector spread
     // over the quads of a 16-lane row beat the chunked scans (and their 15 k cycles of prefix products) up to here.

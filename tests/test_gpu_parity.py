@@ -957,3 +957,28 @@ def test_closed_loop_period_in_one_launch_equals_two_launches():
     short.step(5)
     torch.cuda.synchronize()
     assert not short._fused and short.stats()["failed"] == 0
+
+
+def test_closed_loop_reusing_the_riccati_factor_equals_rebuilding_it():
+    """MPCQP_OPT_KEEP_FACTOR / MPCQP_OPT_REUSE_FACTOR (build once, re-solve: mpc_qp.py:129-163 usage): the factor of the
+    first period serves all later ones -- bitwise the trajectories of the loop that rebuilds it every period, for the
+    serial-sweep variant (N = 50), the scan variant (N = 100) and with two launches per period."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(11)
+    for N, T, fused in ((50, 0.024, True), (100, 0.015, True), (50, 0.024, False)):
+        x0 = rng.standard_normal((40, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+        x0[0] = [0.0, 0.3, 0.0, 1.0]
+        a = WIPClosedLoop(x0.copy(), nb_timesteps=N, sampling_period=T, fused_period=fused, reuse_factor=True)
+        b = WIPClosedLoop(x0.copy(), nb_timesteps=N, sampling_period=T, fused_period=fused)
+        a.step(25)
+        b.step(25)
+        torch.cuda.synchronize()
+        assert torch.equal(a.states, b.states), (N, fused)
+        assert a.stats() == b.stats()
+        a.reset(x0)  # a second episode starts from the kept factor
+        b.reset(x0)
+        a.step(5)
+        b.step(5)
+        torch.cuda.synchronize()
+        assert torch.equal(a.states, b.states)
