@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(64, 2)
     typedef double D2 __attribute__((ext_vector_type(2)));
     double *Fl = (double *)(actr + maxq);  // (32 maxq bytes precede it: 16-byte aligned)
     double *ffl = Fl + N * FS;             // ... and the feed-forward terms of the latest backward sweep (N x NU)
+    double *tgl = ffl + N * NU;            // ... and the targets of the tracking sweep (N x NX)
     // ---- workspace
     double *ws = wsbase + prob * wl.total;
     double *Acl = ws + wl.Acl, *Kg = ws + wl.Kg, *Sinv = ws + wl.Sinv, *ffv = ws + wl.ff, *U0 = ws + wl.U0, *X0 = ws + wl.X0;
@@ -713,7 +714,18 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int t = 0; t < 4; ++t) pr[t] = rot4(own, t);
         const bool tgt = track && stageQ;
-        const double *tp = tgt ? gtgt : Acl;  // (a readable address when there are no targets)
+        if (tgt) {  // the targets come through LDS: one coalesced round trip instead of a request per step
+            for (int i0 = lane; i0 < N * NX; i0 += 64 * 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = gtgt[i0 + 64 * u < N * NX ? i0 + 64 * u : N * NX - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + 64 * u < N * NX) tgl[i0 + 64 * u] = v[u];
+            }
+            wsync();
+        }
+        const double *tp = tgl;
         const int kstart = track ? N - 1 : kq;  // the costate of a single row is zero above its step
         double at[SRD][4], bt[SRD][4 * NU], si[SRD][NU * NU], tg[SRD];
         auto req = [&](int d, int k) {
@@ -733,7 +745,7 @@ __global__ void __launch_bounds__(64, 2)
             }
 #pragma unroll
             for (int i = 0; i < NU * NU; ++i) si[d][i] = f[FSI + i];
-            if (tgt) tg[d] = tp[(int64_t)k * NX + (sqin ? sq : 0)];
+            if (tgt) tg[d] = tp[k * NX + (sqin ? sq : 0)];
         };
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
@@ -1197,7 +1209,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 8;
-    if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU) * sizeof(double);
+    if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double);
     auto kern = mpcqp_stage_kernel<NX, NU, SERIAL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1210,7 +1222,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
 template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     // serial sweeps: short horizons whose factor fits 32 KB of LDS next to the active-set vectors
-    const bool serial = ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(NU) + NU) * sizeof(double) <= 36 * 1024;
+    const bool serial = ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double) <= 40 * 1024;
     return serial ? launch_stage_s<NX, NU, true>(ka, maxq, batch, ws, st) : launch_stage_s<NX, NU, false>(ka, maxq, batch, ws, st);
 }
 
