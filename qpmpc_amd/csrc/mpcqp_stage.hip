@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(64, 2)
     constexpr int FA = 0, FAT = 16, FKR = 32, FBR = FKR + 16 * NU, FBO = FBR + 16 * NU, FSI = FBO + 4 * NU;
     constexpr int FS = (FSI + NU * NU + 1) & ~1;
     typedef double D2 __attribute__((ext_vector_type(2)));
-    double *Fl = (double *)(actr + maxq);  // (32 maxq bytes precede it: 16-byte aligned)
+    double *rsc = (double *)(actr + maxq);  // 32 doubles of exchange for the factor (32 maxq bytes precede it: 16-byte aligned)
+    double *Fl = rsc + 32;
     double *ffl = Fl + N * FS;             // ... and the feed-forward terms of the latest backward sweep (N x NU)
     double *tgl = ffl + N * NU;            // ... and the targets of the tracking sweep (N x NX)
     // ---- workspace
@@ -196,8 +197,8 @@ __global__ void __launch_bounds__(64, 2)
     // holds element [r][c]; the four 16-lane rows of the wavefront do the same work -- and a product gathers its operands
     // with DPP: a row of the left factor is the lane's quad (quad_perm broadcasts), a column of the right factor sits
     // in the same position of the four quads (row rotations by 4, 8, 12: rotation t delivers row (r - t) mod 4, so
-    // operands that come from memory are fetched in that order). Only (PA)' in P_k = (PA)' Acl needs a general gather
-    // (ds_bpermute). ~90 instructions per step instead of ~350 executed redundantly by every lane.
+    // operands that come from memory are fetched in that order). Only P_k = (PA)' Acl, whose two factors are both needed by
+    // column, goes through an LDS transpose. ~90 instructions per step instead of ~350 executed redundantly by every lane.
     // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
     const bool reuse = ka.opt_flags & MPCQP_OPT_REUSE_FACTOR, keep = ka.opt_flags & MPCQP_OPT_KEEP_FACTOR;
@@ -220,12 +221,6 @@ __global__ void __launch_bounds__(64, 2)
             default: return dpp64<0x12c>(x);
             }
         };
-        auto gather = [&](double x, int src) {  // any lane's value (src: per-lane lane index)
-            const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(x));
-            const int hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(x));
-            return __hiloint2double(hi, lo);
-        };
-        const int base16 = lane & ~15;
         int rrow[4];  // (r - t) mod 4
 #pragma unroll
         for (int t = 0; t < 4; ++t) rrow[t] = (r - t) & 3;
@@ -346,11 +341,34 @@ __global__ void __launch_bounds__(64, 2)
                 }
             }
             // P_k[r][c] = Q_k + sum_l PA[l][r] Acl[l][c], symmetrised (x_0 is data: Q_0 = 0)
-            double Pn = (in && r == c && k >= 1) ? wx : 0.0;
+            // Both operands by COLUMN: they go through LDS transposed (one round trip: two writes, eight 16-byte reads),
+            // and lane (r, c) forms P_k[r][c] AND P_k[c][r] itself, so the average is exactly symmetric without a second
+            // exchange (a ds_bpermute gather of PA and another of P_k were two dependent round trips).
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) {
+                rsc[c * 4 + r] = PA;           // PA'  : row c = column c of PA
+                rsc[16 + c * 4 + r] = Acl_rc;  // Acl' : row c = column c of Acl
+            }
+            wsync();
+            double par[4], pac[4], acr[4], acc_[4];
+            {
+                const D2 *t2 = (const D2 *)rsc;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) Pn += gather(PA, base16 + 4 * rrow[t] + r) * rot(Acl_rc, t);
-            const double Pt = gather(Pn, base16 + 4 * c + r);
-            P = 0.5 * (Pn + Pt);
+                for (int h = 0; h < 2; ++h) {
+                    const D2 a = t2[r * 2 + h], b = t2[c * 2 + h], e = t2[8 + r * 2 + h], f = t2[8 + c * 2 + h];
+                    par[2 * h] = a[0], par[2 * h + 1] = a[1];    // PA[l][r]
+                    pac[2 * h] = b[0], pac[2 * h + 1] = b[1];    // PA[l][c]
+                    acr[2 * h] = e[0], acr[2 * h + 1] = e[1];    // Acl[l][r]
+                    acc_[2 * h] = f[0], acc_[2 * h + 1] = f[1];  // Acl[l][c]
+                }
+            }
+            double Prc = 0.0, Pcr = 0.0;
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                Prc += par[l] * acc_[l];
+                Pcr += pac[l] * acr[l];
+            }
+            P = 0.5 * (Prc + Pcr) + ((in && r == c && k >= 1) ? wx : 0.0);
         };
         // full groups of RD steps (every step re-requests, clamped at the end: the same loads in flight on every path),
         // then the remainder
@@ -1208,7 +1226,7 @@ template <int NX, int NU, bool SERIAL>
 static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
-    size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 8;
+    size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
     if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double);
     auto kern = mpcqp_stage_kernel<NX, NU, SERIAL>;
     if (lds > 48 * 1024) {
