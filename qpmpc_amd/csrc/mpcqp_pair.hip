@@ -148,7 +148,7 @@ __device__ __forceinline__ void wsync()
 }
 
 struct Lay {     // LDS carve of ONE problem in doubles (host-computed, passed by value)
-    int off_X;   // build: G image 16 x GS | main: M_A 17 x 16, then the T image 16 x 16 (refinement)
+    int off_X;   // build: G image 16 x GS | main: rows of L^-T 16 x 16, the T image 16 x 16 (refinement), 16 slot ids
     int off_Y;   // build: exchange + staged operands | L 16 x LDM + column buffers | main: M image m x LDM
     int off_hv;  // h_i by lane (32), then y0 (16)
     int off_v;   // kAv, rv, zv and their shadows (6 x 16)
@@ -166,7 +166,9 @@ using namespace pair;
 // chain (terminal cost only, state constraints only); MK == 0: generic chain.
 // MODEL: the problems share a factored model (mpcqp_factor_model: M, L^-T and the linear maps from the states to
 // h and L^-1 q, gA = the model); build, factorisation and forward substitution are skipped (mpc_qp.py:129-163 usage).
-template <int NX, int MK, bool MODEL = false>
+// WARM: the launch carries a warm-start state (MpcqpSolveOpts.warm_state); the cold instantiations drop the repair
+// machinery from the loop.
+template <int NX, int MK, bool MODEL = false, bool WARM = false>
 __global__ void __launch_bounds__(64, 2)
     mpcqp_pair_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ gD, const double *__restrict__ ge, const double *__restrict__ gx0,
@@ -189,7 +191,7 @@ __global__ void __launch_bounds__(64, 2)
     const int n = ka.n, m = ka.m;
     const bool isc = hl < m;  // this lane owns a constraint
     const T INF = HUGE_VAL;
-    T *Gimg = sm + L.off_X, *MAl = sm + L.off_X, *Timg = sm + L.off_X + (NV + 1) * NV;
+    T *Gimg = sm + L.off_X;
     const int GS = (m + 1) | 1;  // the G image is stored by COLUMN with an odd stride
     T *Ll = sm + L.off_Y, *Ml = sm + L.off_Y, *hv = sm + L.off_hv;
     T *y0v = hv + HL;
@@ -492,8 +494,8 @@ __global__ void __launch_bounds__(64, 2)
     tick(2);
 
     // the stored warm-start state is requested now and consumed after the forward substitution
-    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
-    const bool wload = wstate && ka.warm_start && !notpd;
+    double *wstate = (WARM && ka.warm_state) ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
+    const bool wload = WARM && wstate && ka.warm_start && !notpd;
     int wid = -1;
     T wrow[NV];
 #pragma unroll
@@ -594,13 +596,37 @@ __global__ void __launch_bounds__(64, 2)
     bool finished = notpd;  // ... and needs no refinement any more (failed, or accepted)
     if (notpd) status = MPCQP_NOT_PD;
 
-    if (!MODEL && hl == 0) st16(y0v, RT);  // w = L^-1 q ; y0 = -w
-    if (isc) st16(Ml + hl * LDM, RM);  // image of M for the row-p broadcasts
-    for (int i = hl; i < (NV + 1) * NV; i += HL) MAl[i] = T(0);
-    if (low) {
+    // Main-phase carve of the X region: the rows of L^-T (only read when a point is accepted), the T image
+    // (T by columns, refinement only) and the 16 constraint ids of the slots.
+    T *LTimg = sm + L.off_X, *Timg = LTimg + NV * NV;
+    int *actv = reinterpret_cast<int *>(Timg + NV * NV);
+    // colp(a)[0] = element l15 of the row of M held by slot a (actv published by the caller)
+    auto ma_dot = [&](const T (&cf)[NV]) {
+        int aa[NV];
+        const int4 *ap = reinterpret_cast<const int4 *>(actv);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) RT[k] = T(0);  // T = N* starts empty
-    }
+        for (int q = 0; q < NV / 4; ++q) {
+            const int4 t = ap[q];
+            aa[4 * q] = t.x;
+            aa[4 * q + 1] = t.y;
+            aa[4 * q + 2] = t.z;
+            aa[4 * q + 3] = t.w;
+        }
+        T a0 = T(0), a1 = T(0);
+#pragma unroll
+        for (int a = 0; a < NV; a += 2) {
+            a0 += cf[a] * Ml[aa[a] * LDM + l15];
+            a1 += cf[a + 1] * Ml[aa[a + 1] * LDM + l15];
+        }
+        return a0 + a1;  // (M_A' cf)_l15 ; empty slots carry a zero coefficient
+    };
+
+    if (!MODEL && hl == 0) st16(y0v, RT);  // w = L^-1 q ; y0 = -w
+    if (isc) st16(Ml + hl * LDM, RM);  // image of M: row-p broadcasts, and the only copy of M_i once RM holds H M_i
+    if (!low) st16(LTimg + l15 * NV, RT);  // the rows of L^-T leave the registers
+#pragma unroll
+    for (int k = 0; k < NV; ++k) RT[k] = (!low && l15 == k) ? T(1) : T(0);  // T = N* starts empty, H = I
+    zv[l15] = T(0);  // the pending rank-one update's vector
     wsync();
     const T hval = hv[hl];
     T s;
@@ -631,6 +657,10 @@ __global__ void __launch_bounds__(64, 2)
     unsigned mask = 0;  // occupied slots
     bool needp = true, dropping = false;
     T up = T(0);
+    T cT = T(0), cK = T(0);  // pending rank-one update RT += cT v, RM += cK v (applied at the top of the next trip:
+                             // the ONE site that writes the two register rows)
+    bool pdrop = false;      // ... whose vector v is T_l in kAv (a slot leaves) instead of z in zv
+    bool pstore = false;     // slot lanes: this lane's row of T goes to kAv once the pending update is applied
     const T s0 = s;      // slacks at the unconstrained minimiser (cold restart)
     bool warm = false;   // this half started from a stored active set
     bool wfix = false;   // ... and is still repairing it (multipliers that turned negative leave one by one)
@@ -643,10 +673,17 @@ __global__ void __launch_bounds__(64, 2)
         warm = wfix = wdrop = recold = negl = false;
         fails = 0;
         iters = 0;
-        if (low) {
+        T mi[NV];
+        ld16(mi, Ml + (isc ? hl : 0) * LDM);
+        int kk = low ? -1 : l15;
+        asm volatile("" : "+v"(kk));  // (recomputed here: otherwise the 16 unit-vector entries stay live from the start)
 #pragma unroll
-            for (int k = 0; k < NV; ++k) RT[k] = T(0);
+        for (int k = 0; k < NV; ++k) {
+            RT[k] = (kk == k) ? T(1) : T(0);
+            RM[k] = isc ? mi[k] : T(0);
         }
+        cT = cK = T(0);
+        pdrop = pstore = false;
         lam = T(0);
         occ = false;
         pos = -1;
@@ -687,11 +724,6 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
                 for (int k = 0; k < NV; ++k) RT[k] = win ? wrow[k] : T(0);
             }
-            if (win) {  // M_A by slot (the refinement and z = -M_p + M_A' r read it)
-                T row[NV];
-                ld16(row, Ml + a * LDM);
-                st16(MAl + hl * NV, row);
-            }
             occ = win;
             myact = win ? a : 0;
             pos = isc ? mypos : -1;
@@ -703,10 +735,85 @@ __global__ void __launch_bounds__(64, 2)
         }
         wsync();
     }
+    if (WARM && __ballot(warm) != 0ull) {
+        // The projector H = I - M_A' T (rows in lanes 16..31) and the projected rows K_i = H M_i that go with the
+        // stored operator (halves that did not take a stored state come out with H = I, K = M again).
+        if (low) {
+            st16(Timg + hl * NV, RT);  // T by rows
+            actv[hl] = occ ? myact : 0;
+        }
+        wsync();
+        T hrow[NV];
+        int kk = l15;
+        asm volatile("" : "+v"(kk));
+#pragma unroll
+        for (int k = 0; k < NV; ++k) hrow[k] = (kk == k) ? T(1) : T(0);
+        {
+            int aa[NV];
+            const int4 *ap = reinterpret_cast<const int4 *>(actv);
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) {
+                const int4 t = ap[q];
+                aa[4 * q] = t.x;
+                aa[4 * q + 1] = t.y;
+                aa[4 * q + 2] = t.z;
+                aa[4 * q + 3] = t.w;
+            }
+#pragma unroll
+            for (int a = 0; a < NV; ++a) {
+                const T ma = Ml[aa[a] * LDM + l15];  // M_A[a][l15] (the row of T is zero for an empty slot)
+                T ta[NV];
+                ld16(ta, Timg + a * NV);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) hrow[k] -= ma * ta[k];
+            }
+        }
+        wsync();
+        if (!low) st16(Timg + l15 * NV, hrow);  // H by rows (symmetric)
+        wsync();
+        {
+            T kr[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) kr[k] = T(0);
+#pragma unroll
+            for (int jj = 0; jj < NV; ++jj) {
+                T hj[NV];
+                ld16(hj, Timg + jj * NV);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) kr[k] += RM[jj] * hj[k];
+            }
+            if (warm) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) RM[k] = kr[k];
+            }
+        }
+        if (warm && !low) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) RT[k] = hrow[k];
+        }
+        wsync();
+    }
     tick(4);
     for (;;) {
         // ===================================================== active-set loop
         for (;;) {
+            // ---- the previous trip's rank-one update:  T_a += (r_a/d2) z, T_new = -z/d2 ; H -= z z'/d2 ;
+            //      K_i -= (M_i.z/d2) z   (independent of the selection below, which only reads the slacks)
+            {
+                T vv[NV];
+                ld16(vv, pdrop ? kAv : zv);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    RT[k] += cT * vv[k];
+                    RM[k] += cK * vv[k];
+                }
+            }
+            if (WARM && __ballot(pstore) != 0ull) {  // warm-start repair chain: the next slot to leave publishes its row
+                wsync();
+                if (pstore) st16(kAv, RT);
+                pstore = false;
+                wsync();
+            }
             // ---- selection, for the halves that start a new constraint
             {
                 unsigned hi, lo;
@@ -725,8 +832,63 @@ __global__ void __launch_bounds__(64, 2)
                     }
                 }
             }
+            cT = cK = T(0);
+            pdrop = false;
             if (__ballot(!done) == 0ull) break;
             bool stepping = !done && !dropping;
+            const bool drp = !done && dropping;
+            // ---- one pass over both register rows with row p of M (a broadcast read inside the half):
+            //      slot lanes r_a = T_a . M_p ; lanes 16..31 -z_k = H_k . M_p ; constraint lanes -M_i . z = K_i . M_p
+            T rd, kd;
+            {
+                T mp[NV];
+                ld16(mp, Ml + p * LDM);
+                rd = dot16(RT, mp);
+                kd = dot16(RM, mp);
+            }
+            // z by the H lanes (the slot lanes write the shadow); a step cancelled below leaves its coefficients zero
+            zv[low ? 3 * NV + l15 : l15] = stepping ? -rd : T(0);
+            const T mz = -kd;
+            // ---- step length
+            const T d2 = half_get(kd, hb, p);  // |z|^2 = M_p' H M_p = K_p . M_p
+            const T sp = half_get(s, hb, p);
+            const T ip = half_get(invn, hb, p);
+            const bool can_move = (nq < n) && (d2 * ip * ip > DEP) && (d2 > T(0));
+            const T inv = can_move ? fast_rcp(d2) : T(0);
+            const T t2 = can_move ? -sp * inv : INF;
+            const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
+            {
+                // The common trip: every half still in the loop takes a FULL step (no multiplier blocks, nothing
+                // leaves, no limit reached). One ballot decides; anything else goes through the general tail below.
+                const T r0 = occ ? rd : T(0);
+                const bool odd = stepping ? (!can_move || iters >= max_iter || (r0 > T(0) && lam < t2 * r0)) : drp;
+                if (__ballot(odd) == 0ull) {
+                    if (stepping) {
+                        ++iters;
+                        cT = (hl == sl) ? -inv : ((low ? r0 : rd) * inv);
+                        cK = isc ? kd * inv : T(0);
+                        if (isc) s = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
+                        lam -= t2 * r0;
+                        lam = (occ && lam < T(0)) ? T(0) : lam;
+                        up += t2;
+                        if (hl == sl) {
+                            lam = up;
+                            myact = p;
+                            occ = true;
+                        }
+                        if (hl == p) {
+                            pos = sl;
+                            s = T(0);
+                        }
+                        mask |= 1u << sl;
+                        ++nq;
+                        needp = true;
+                    }
+                    wsync();
+                    continue;
+                }
+            }
+            // ---- general tail
             if (stepping && iters >= max_iter) {
                 done = true;
                 finished = !warm;
@@ -734,49 +896,8 @@ __global__ void __launch_bounds__(64, 2)
                 status = MPCQP_MAX_ITER;
                 stepping = false;
             }
-            const bool drp = !done && dropping;
             iters += stepping ? 1 : 0;
-            // ---- r = T M_p ; z = -M_p + M_A' r   (stepping halves; the others compute and ignore)
-            const T *mprow = Ml + p * LDM;  // row p of M, read as a broadcast inside the half
-            T r;
-            {
-                T mp[NV];
-                ld16(mp, mprow);
-                r = dot16(RT, mp);
-            }
-            r = (occ && stepping) ? r : T(0);
-            rv[vofs] = r;
-            const T mpl = mprow[l15];
-            wsync();
-            T z;
-            {
-                T rr[NV];
-                ld16(rr, rv);
-                const T *colp = MAl + l15;
-                T a0 = -mpl, a1 = T(0), a2 = T(0), a3 = T(0);
-#pragma unroll
-                for (int a = 0; a < NV; a += 4) {
-                    a0 += rr[a] * colp[a * NV];
-                    a1 += rr[a + 1] * colp[(a + 1) * NV];
-                    a2 += rr[a + 2] * colp[(a + 2) * NV];
-                    a3 += rr[a + 3] * colp[(a + 3) * NV];
-                }
-                z = (a0 + a1) + (a2 + a3);
-            }
-            z = (low && stepping) ? z : T(0);
-            zv[vofs] = z;
-            wsync();
-            // ---- the vector of this trip's single pass over the rows: z (step) or T_l (drop)
-            T vv[NV];
-            ld16(vv, drp ? kAv : zv);
-            const T mz = dot16(RM, vv);
-            // ---- step length
-            const T d2 = dot16(vv, vv);  // |z|^2, every lane from its own copy
-            const T sp = half_get(s, hb, p);
-            const T ip = half_get(invn, hb, p);
-            const bool can_move = (nq < n) && (d2 * ip * ip > DEP) && (d2 > T(0));
-            const T inv = can_move ? fast_rcp(d2) : T(0);
-            const T t2 = can_move ? -sp * inv : INF;
+            const T r = (occ && stepping) ? rd : T(0);
             const bool cand = occ && (r > T(0));
             // a blocking multiplier exists iff lam_a / r_a < t2 for some slot
             const bool blocked = half_any(stepping && cand && (lam < t2 * r), hb);
@@ -804,21 +925,42 @@ __global__ void __launch_bounds__(64, 2)
             }
             t = stepping ? t : T(0);
             const bool full = stepping && (t2 <= t1);
-            const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
-            // ---- coefficient of the pass  RT += c * vv
-            T c = full ? ((hl == sl) ? -inv : r * inv) : T(0);
+            // ---- coefficients of the (deferred) update with z: slot sl takes -z/d2, the occupied slots r_a/d2,
+            //      H row k -z_k/d2 = (H_k . M_p)/d2, K row i -(M_i . z)/d2 = (K_i . M_p)/d2
+            if (full) {
+                cT = (hl == sl) ? -inv : ((low ? r : rd) * inv);
+                cK = isc ? kd * inv : T(0);
+            }
             if (__ballot(drp) != 0ull) {
                 // slot ldrop leaves (its row T_l is in kAv). With W = T T' implicit,
-                // T_a -= (T_a . T_l / T_l . T_l) T_l ; row l becomes exactly zero.
-                const T tl = dot16(RT, vv);
-                const T tld = half_get(tl, hb, ldrop);
-                const T f = tl * fast_rcp(tld);
-                const T cd = (hl == ldrop) ? T(-1) : (occ ? -f : T(0));
-                c = drp ? cd : c;
-            }
-            c = low ? c : T(0);
+                // T_a -= (T_a . T_l / T_l . T_l) T_l (row l becomes exactly zero); the null space of the active
+                // rows gains the direction T_l:  H += T_l T_l' / T_l . T_l,  K_i += (M_i . T_l / T_l . T_l) T_l.
+                // Only the coefficients are formed here; the update itself is the next trip's.
+                T g = T(0);  // M_i . T_l, in four pieces (register pressure peaks here)
+                {
+                    const double2 *mr = reinterpret_cast<const double2 *>(Ml + (isc ? hl : 0) * LDM);
+                    const double2 *tr = reinterpret_cast<const double2 *>(kAv);
 #pragma unroll
-            for (int k = 0; k < NV; ++k) RT[k] += c * vv[k];
+                    for (int q = 0; q < NV / 2; q += 2) {
+                        const double2 a0 = mr[q], b0 = tr[q], a1 = mr[q + 1], b1 = tr[q + 1];
+                        g += a0.x * b0.x + a0.y * b0.y + a1.x * b1.x + a1.y * b1.y;
+                        pin(g);
+                    }
+                }
+                T tl;
+                {
+                    T vv[NV];
+                    ld16(vv, kAv);
+                    tl = dot16(RT, vv);
+                }
+                const T tld = half_get(tl, hb, ldrop);
+                const T itl = fast_rcp(tld);
+                if (drp) {
+                    cT = low ? ((hl == ldrop) ? T(-1) : (occ ? -tl * itl : T(0))) : kAv[l15] * itl;
+                    cK = isc ? g * itl : T(0);
+                    pdrop = true;
+                }
+            }
             // ---- bookkeeping
             if (stepping) {
                 // the implied primal point moved by t z: s_i -= t M_i . z
@@ -827,9 +969,7 @@ __global__ void __launch_bounds__(64, 2)
                 lam = (occ && lam < T(0)) ? T(0) : lam;
                 up += t;
             }
-            // p takes slot sl (full step); other lanes write the junk row
-            MAl[((low && full) ? sl : NV) * NV + l15] = mpl;
-            if (full) {
+            if (full) {  // p takes slot sl
                 if (hl == sl) {
                     lam = up;
                     myact = p;
@@ -853,7 +993,7 @@ __global__ void __launch_bounds__(64, 2)
                 --nq;
                 dropping = false;
             }
-            if (__ballot(drp && wdrop) != 0ull) {
+            if (WARM && __ballot(drp && wdrop) != 0ull) {
                 // warm-start repair: every slot whose multiplier was negative leaves, one pass each, then the
                 // multipliers are solved again (rows dropped in excess come back through the usual iterations)
                 const bool mine = drp && wdrop;
@@ -863,7 +1003,7 @@ __global__ void __launch_bounds__(64, 2)
                 const int nl = more ? (int)nk : 0;
                 const int cl = half_get(myact, hb, nl);
                 wsync();
-                if (more && hl == nl) st16(kAv, RT);  // its row AFTER this pass
+                pstore = more && hl == nl;  // its row AFTER this pass: stored once the pending update is applied
                 if (more && hl == cl) pos = -1;
                 if (more) {
                     ldrop = nl;
@@ -874,7 +1014,7 @@ __global__ void __launch_bounds__(64, 2)
                 }
             }
             if (__ballot(partial) != 0ull) {
-                // partial step: the next trip removes slot l from T
+                // partial step: the next trip removes slot l from T (no update is pending for this half)
                 const int cl = half_get(myact, hb, l);
                 wsync();
                 if (partial && hl == l) st16(kAv, RT);
@@ -887,11 +1027,8 @@ __global__ void __launch_bounds__(64, 2)
             wsync();
         }
         tick(5);
-        if (__ballot(recold) != 0ull) {
-            // rows of empty slots must read as zero in M_A
+        if (WARM && __ballot(recold) != 0ull) {
             wsync();
-            if (recold)
-                for (int i = hl; i < NV * NV; i += HL) MAl[i] = T(0);
             if (recold) cold_reset();
             wsync();
             if (__ballot(!finished && done) == 0ull) continue;
@@ -903,27 +1040,27 @@ __global__ void __launch_bounds__(64, 2)
         T y = -y0v[l15];       // y0 = -L^-1 q
         T yy[NV];
         T fresh = s0;          // slacks at y0
+        // slacks of all rows at the point whose coordinates are in zv (M_i from the image)
+        auto slacks = [&]() {
+            T mi[NV];
+            ld16(mi, Ml + (isc ? hl : 0) * LDM);
+            const T f = hv[hl] - dot16(mi, yy);
+            return isc ? f : INF;
+        };
+        wsync();
+        if (low) actv[hl] = occ ? myact : 0;
         if (__ballot(!wfix && !finished) != 0ull) {
-            wsync();
             rv[vofs] = lam;
             wsync();
             {
                 T rr[NV];
                 ld16(rr, rv);
-                const T *colp = MAl + l15;
-                T a0 = T(0), a1 = T(0);
-#pragma unroll
-                for (int a = 0; a < NV; a += 2) {
-                    a0 += rr[a] * colp[a * NV];
-                    a1 += rr[a + 1] * colp[(a + 1) * NV];
-                }
-                y -= a0 + a1;  // y = y0 - M_A' lam
+                y -= ma_dot(rr);  // y = y0 - M_A' lam
             }
             zv[vofs] = y;
             wsync();
             ld16(yy, zv);
-            fresh = hv[hl] - dot16(RM, yy);
-            fresh = isc ? fresh : INF;
+            fresh = slacks();
         } else {
             zv[vofs] = y;
             wsync();
@@ -971,24 +1108,18 @@ __global__ void __launch_bounds__(64, 2)
             {
                 T rr[NV];
                 ld16(rr, rv);
-                const T *colp = MAl + l15;
-                T a0 = T(0), a1 = T(0);
-#pragma unroll
-                for (int a = 0; a < NV; a += 2) {
-                    a0 += rr[a] * colp[a * NV];
-                    a1 += rr[a + 1] * colp[(a + 1) * NV];
-                }
-                y -= a0 + a1;
+                y -= ma_dot(rr);
             }
             wsync();
             zv[vofs] = y;
             wsync();
             ld16(yy, zv);
-            fresh = hv[hl] - dot16(RM, yy);
-            fresh = isc ? fresh : INF;
+            fresh = slacks();
         }
+        // the loop's pending-update vector lives in zv: no update is pending here (the loop was left at its
+        // break, after the update was applied and cleared), but the coefficients multiply whatever zv holds
         // ---- warm-start repair: the most negative multiplier's row leaves, then everything is solved again
-        if (__ballot(wfix && !finished) != 0ull) {
+        if (WARM && __ballot(wfix && !finished) != 0ull) {
             unsigned hi, lo;
             ordered(lraw, hi, lo);
             negl = wfix && !finished && occ && lraw < T(0);
@@ -1021,7 +1152,7 @@ __global__ void __launch_bounds__(64, 2)
         //      every active row on its bound -- with stationarity by construction and lam >= 0 these are
         //      the KKT conditions of the strictly convex QP
         bool dirty = half_any(selectable && pos < 0 && !(fresh >= -T(4) * tolh), hb);  // (NaN counts as violated)
-        if (__ballot(warm && !finished) != 0ull) {
+        if (WARM && __ballot(warm && !finished) != 0ull) {
             const T ra = half_get(fresh, hb, myact);
             const T ta = half_get(tolh, hb, myact);
             const bool off = half_any(occ && !(fabs(ra) <= T(1e3) * ta), hb);
@@ -1029,9 +1160,15 @@ __global__ void __launch_bounds__(64, 2)
             dirty = dirty || (warm && (off || neg));
         }
         bool coldnow = false;
+        // u = L^-T y in lanes 16..31 (yy holds y; the rows of L^-T come back from their image)
+        auto primal = [&]() {
+            T lt[NV];
+            ld16(lt, LTimg + l15 * NV);
+            return dot16(lt, yy);
+        };
         if (!finished && done && !wfix) {
             if (!dirty) {
-                xsol = dot16(RT, yy);  // u = L^-T y in lanes 16..31 (yy holds y)
+                xsol = primal();
                 status = MPCQP_SOLVED;
                 finished = true;
             } else if (++fails < 4) {
@@ -1043,15 +1180,13 @@ __global__ void __launch_bounds__(64, 2)
             } else if (warm) {
                 coldnow = true;  // the stored state did not lead to a certified point
             } else {
-                xsol = dot16(RT, yy);
+                xsol = primal();
                 status = MPCQP_MAX_ITER;
                 finished = true;
             }
         }
-        if (__ballot(coldnow) != 0ull) {
+        if (WARM && __ballot(coldnow) != 0ull) {
             wsync();
-            if (coldnow)
-                for (int i = hl; i < NV * NV; i += HL) MAl[i] = T(0);
             if (coldnow) cold_reset();
             wsync();
         }
@@ -1086,7 +1221,7 @@ static Lay make_lay(const KernelArgs &ka)
 {
     Lay L{};
     auto al = [](int c) { return (c + 3) & ~3; };  // 32-byte granules keep every region 16-byte aligned
-    const int gimg = NV * ((ka.m + 1) | 1), main_x = (NV + 1) * NV + NV * NV;
+    const int gimg = NV * ((ka.m + 1) | 1), main_x = 2 * NV * NV + NV;
     L.off_X = 0;
     int o = al(gimg > main_x ? gimg : main_x);
     L.off_Y = o;
@@ -1122,11 +1257,16 @@ template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t
     const Lay L = make_lay(ka);
     const size_t bytes = (size_t)L.per * 2 * sizeof(double);
     const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL((mpcqp_pair_kernel<NX, MK>), dim3(grid), dim3(64), bytes, st, (const double *)ka.A.ptr,
-                       (const double *)ka.B.ptr, (const double *)ka.C.ptr, (const double *)ka.D.ptr,
-                       (const double *)ka.e.ptr, (const double *)ka.x0.ptr, (const double *)ka.goal.ptr,
-                       (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L,
-                       batch);
+    auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
+                           (const double *)ka.C.ptr, (const double *)ka.D.ptr, (const double *)ka.e.ptr,
+                           (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
+                           (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
+    };
+    if (ka.warm_state)
+        go(mpcqp_pair_kernel<NX, MK, false, true>);
+    else
+        go(mpcqp_pair_kernel<NX, MK, false, false>);
     return (int)hipGetLastError();
 }
 
