@@ -814,23 +814,21 @@ __global__ void __launch_bounds__(64, 2)
                 pstore = false;
                 wsync();
             }
-            // ---- selection, for the halves that start a new constraint
+            // ---- selection, for the halves that start a new constraint (straight-line selects: no divergent branches)
             {
                 unsigned hi, lo;
                 ordered(s * invn, hi, lo);
-                const bool want = needp && !done;
-                const unsigned key = (want && selectable && pos < 0 && s < -tolh) ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
+                const bool want = needp & !done;
+                const bool viol = want & selectable & (pos < 0) & (s < -tolh);
+                const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
                 const unsigned mkey = half_min(key);
-                if (want) {
-                    if (mkey == 0xffffffffu) {
-                        done = true;
-                        status = MPCQP_SOLVED;
-                    } else {
-                        p = (int)(mkey & 31u);
-                        up = T(0);
-                        needp = false;
-                    }
-                }
+                const bool none = want & (mkey == 0xffffffffu);
+                const bool got = want & !none;
+                done = done | none;
+                status = none ? (int)MPCQP_SOLVED : status;
+                p = got ? (int)(mkey & 31u) : p;
+                up = got ? T(0) : up;
+                needp = needp & !got;
             }
             cT = cK = T(0);
             pdrop = false;
@@ -853,7 +851,7 @@ __global__ void __launch_bounds__(64, 2)
             const T d2 = half_get(kd, hb, p);  // |z|^2 = M_p' H M_p = K_p . M_p
             const T sp = half_get(s, hb, p);
             const T ip = half_get(invn, hb, p);
-            const bool can_move = (nq < n) && (d2 * ip * ip > DEP) && (d2 > T(0));
+            const bool can_move = (nq < n) & (d2 * ip * ip > DEP) & (d2 > T(0));
             const T inv = can_move ? fast_rcp(d2) : T(0);
             const T t2 = can_move ? -sp * inv : INF;
             const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
@@ -861,29 +859,28 @@ __global__ void __launch_bounds__(64, 2)
                 // The common trip: every half still in the loop takes a FULL step (no multiplier blocks, nothing
                 // leaves, no limit reached). One ballot decides; anything else goes through the general tail below.
                 const T r0 = occ ? rd : T(0);
-                const bool odd = stepping ? (!can_move || iters >= max_iter || (r0 > T(0) && lam < t2 * r0)) : drp;
+                const bool blk = (r0 > T(0)) & (lam < t2 * r0);
+                const bool odd = (stepping & (!can_move | (iters >= max_iter) | blk)) | drp;
                 if (__ballot(odd) == 0ull) {
-                    if (stepping) {
-                        ++iters;
-                        cT = (hl == sl) ? -inv : ((low ? r0 : rd) * inv);
-                        cK = isc ? kd * inv : T(0);
-                        if (isc) s = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
-                        lam -= t2 * r0;
-                        lam = (occ && lam < T(0)) ? T(0) : lam;
-                        up += t2;
-                        if (hl == sl) {
-                            lam = up;
-                            myact = p;
-                            occ = true;
-                        }
-                        if (hl == p) {
-                            pos = sl;
-                            s = T(0);
-                        }
-                        mask |= 1u << sl;
-                        ++nq;
-                        needp = true;
-                    }
+                    const bool st = stepping;
+                    const bool isnew = st & (hl == sl), isp = st & (hl == p);
+                    iters += st ? 1 : 0;
+                    cT = st ? ((hl == sl) ? -inv : ((low ? r0 : rd) * inv)) : T(0);
+                    cK = (st & isc) ? kd * inv : T(0);
+                    const T tt = st ? t2 : T(0);
+                    const T sn = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
+                    s = (st & isc) ? sn : s;
+                    T ln = lam - tt * r0;
+                    ln = (occ & (ln < T(0))) ? T(0) : ln;
+                    up += tt;
+                    lam = isnew ? up : ln;
+                    myact = isnew ? p : myact;
+                    occ = occ | isnew;
+                    pos = isp ? sl : pos;
+                    s = isp ? T(0) : s;
+                    mask |= st ? (1u << sl) : 0u;
+                    nq += st ? 1 : 0;
+                    needp = needp | st;
                     wsync();
                     continue;
                 }
