@@ -814,6 +814,81 @@ __global__ void __launch_bounds__(64, 2)
                 pstore = false;
                 wsync();
             }
+            cT = cK = T(0);
+            pdrop = false;
+            // ---- FAST LOOP. While every half still in the loop is about to take a new constraint and the step
+            //      turns out to be a FULL one (no multiplier blocks, nothing leaves, no limit reached), a trip needs
+            //      none of the general machinery: one ballot per trip checks that, anything else leaves this loop
+            //      and the same trip is redone by the general code below.
+            if (__ballot(!done & (!needp | dropping)) == 0ull) {
+                for (;;) {
+                    {
+                        T vv[NV];
+                        ld16(vv, zv);
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) {
+                            RT[k] += cT * vv[k];
+                            RM[k] += cK * vv[k];
+                        }
+                    }
+                    cT = cK = T(0);
+                    {
+                        unsigned hi, lo;
+                        ordered(s * invn, hi, lo);
+                        const bool viol = !done & selectable & (pos < 0) & (s < -tolh);
+                        const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
+                        const unsigned mkey = half_min(key);
+                        const bool none = !done & (mkey == 0xffffffffu);
+                        done = done | none;
+                        status = none ? (int)MPCQP_SOLVED : status;
+                        p = done ? p : (int)(mkey & 31u);
+                    }
+                    up = T(0);
+                    if (__ballot(!done) == 0ull) break;
+                    T rd, kd;
+                    {
+                        T mp[NV];
+                        ld16(mp, Ml + p * LDM);
+                        rd = dot16(RT, mp);
+                        kd = dot16(RM, mp);
+                    }
+                    const bool st = !done;
+                    zv[low ? 3 * NV + l15 : l15] = st ? -rd : T(0);
+                    const T d2 = half_get(kd, hb, p);
+                    const T sp = half_get(s, hb, p);
+                    const T ip = half_get(invn, hb, p);
+                    const bool can_move = (nq < n) & (d2 * ip * ip > DEP) & (d2 > T(0));
+                    const T inv = can_move ? fast_rcp(d2) : T(0);
+                    const T t2 = can_move ? -sp * inv : INF;
+                    const int sl = (int)__builtin_ctz(~mask);
+                    const T r0 = occ ? rd : T(0);
+                    const bool blk = (r0 > T(0)) & (lam < t2 * r0);
+                    const bool odd = st & (!can_move | (iters >= max_iter) | blk);
+                    if (__ballot(odd) != 0ull) {
+                        needp = done;  // the halves still in the loop hold a selected row and have not stepped
+                        wsync();
+                        break;
+                    }
+                    const bool isnew = st & (hl == sl), isp = st & (hl == p);
+                    iters += st ? 1 : 0;
+                    cT = st ? ((hl == sl) ? -inv : ((low ? r0 : rd) * inv)) : T(0);
+                    cK = (st & isc) ? kd * inv : T(0);
+                    const T tt = st ? t2 : T(0);
+                    const T sn = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
+                    s = (st & isc) ? sn : s;
+                    T ln = lam - tt * r0;
+                    ln = (occ & (ln < T(0))) ? T(0) : ln;
+                    lam = isnew ? tt : ln;
+                    myact = isnew ? p : myact;
+                    occ = occ | isnew;
+                    pos = isp ? sl : pos;
+                    s = isp ? T(0) : s;
+                    mask |= st ? (1u << sl) : 0u;
+                    nq += st ? 1 : 0;
+                    wsync();
+                }
+                // (both exits leave no update pending: the coefficients are cleared right after each update)
+            }
             // ---- selection, for the halves that start a new constraint (straight-line selects: no divergent branches)
             {
                 unsigned hi, lo;
@@ -830,8 +905,6 @@ __global__ void __launch_bounds__(64, 2)
                 up = got ? T(0) : up;
                 needp = needp & !got;
             }
-            cT = cK = T(0);
-            pdrop = false;
             if (__ballot(!done) == 0ull) break;
             bool stepping = !done && !dropping;
             const bool drp = !done && dropping;
@@ -855,36 +928,6 @@ __global__ void __launch_bounds__(64, 2)
             const T inv = can_move ? fast_rcp(d2) : T(0);
             const T t2 = can_move ? -sp * inv : INF;
             const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
-            {
-                // The common trip: every half still in the loop takes a FULL step (no multiplier blocks, nothing
-                // leaves, no limit reached). One ballot decides; anything else goes through the general tail below.
-                const T r0 = occ ? rd : T(0);
-                const bool blk = (r0 > T(0)) & (lam < t2 * r0);
-                const bool odd = (stepping & (!can_move | (iters >= max_iter) | blk)) | drp;
-                if (__ballot(odd) == 0ull) {
-                    const bool st = stepping;
-                    const bool isnew = st & (hl == sl), isp = st & (hl == p);
-                    iters += st ? 1 : 0;
-                    cT = st ? ((hl == sl) ? -inv : ((low ? r0 : rd) * inv)) : T(0);
-                    cK = (st & isc) ? kd * inv : T(0);
-                    const T tt = st ? t2 : T(0);
-                    const T sn = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
-                    s = (st & isc) ? sn : s;
-                    T ln = lam - tt * r0;
-                    ln = (occ & (ln < T(0))) ? T(0) : ln;
-                    up += tt;
-                    lam = isnew ? up : ln;
-                    myact = isnew ? p : myact;
-                    occ = occ | isnew;
-                    pos = isp ? sl : pos;
-                    s = isp ? T(0) : s;
-                    mask |= st ? (1u << sl) : 0u;
-                    nq += st ? 1 : 0;
-                    needp = needp | st;
-                    wsync();
-                    continue;
-                }
-            }
             // ---- general tail
             if (stepping && iters >= max_iter) {
                 done = true;
