@@ -661,6 +661,7 @@ __global__ void __launch_bounds__(64, 2)
                              // the ONE site that writes the two register rows)
     bool pdrop = false;      // ... whose vector v is T_l in kAv (a slot leaves) instead of z in zv
     bool pstore = false;     // slot lanes: this lane's row of T goes to kAv once the pending update is applied
+    bool hkstale = false;    // this half runs on a stored operator while H, K are still those of the empty set
     const T s0 = s;      // slacks at the unconstrained minimiser (cold restart)
     bool warm = false;   // this half started from a stored active set
     bool wfix = false;   // ... and is still repairing it (multipliers that turned negative leave one by one)
@@ -684,6 +685,7 @@ __global__ void __launch_bounds__(64, 2)
         }
         cT = cK = T(0);
         pdrop = pstore = false;
+        hkstale = false;
         lam = T(0);
         occ = false;
         pos = -1;
@@ -730,14 +732,16 @@ __global__ void __launch_bounds__(64, 2)
             mask = wmask;
             nq = cnt;
             warm = wfix = true;
+            hkstale = true;
             done = true;  // straight to the multiplier solve
             needp = false;
         }
         wsync();
     }
-    if (WARM && __ballot(warm) != 0ull) {
-        // The projector H = I - M_A' T (rows in lanes 16..31) and the projected rows K_i = H M_i that go with the
-        // stored operator (halves that did not take a stored state come out with H = I, K = M again).
+    // The projector H = I - M_A' T (rows in lanes 16..31) and the projected rows K_i = H M_i that go with a stored
+    // operator, for the halves in `take`. Built only when such a half really enters the active-set loop: a stored
+    // state that is accepted as it stands (the common case) never needs them.
+    auto rebuild_hk = [&](const bool take) {
         if (low) {
             st16(Timg + hl * NV, RT);  // T by rows
             actv[hl] = occ ? myact : 0;
@@ -749,19 +753,9 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
         for (int k = 0; k < NV; ++k) hrow[k] = (kk == k) ? T(1) : T(0);
         {
-            int aa[NV];
-            const int4 *ap = reinterpret_cast<const int4 *>(actv);
-#pragma unroll
-            for (int q = 0; q < NV / 4; ++q) {
-                const int4 t = ap[q];
-                aa[4 * q] = t.x;
-                aa[4 * q + 1] = t.y;
-                aa[4 * q + 2] = t.z;
-                aa[4 * q + 3] = t.w;
-            }
-#pragma unroll
-            for (int a = 0; a < NV; ++a) {
-                const T ma = Ml[aa[a] * LDM + l15];  // M_A[a][l15] (the row of T is zero for an empty slot)
+#pragma unroll 2
+            for (int a = 0; a < NV; ++a) {  // (rolled: this block runs once per warm start, registers are scarce here)
+                const T ma = Ml[actv[a] * LDM + l15];  // M_A[a][l15] (the row of T is zero for an empty slot)
                 T ta[NV];
                 ld16(ta, Timg + a * NV);
 #pragma unroll
@@ -775,24 +769,26 @@ __global__ void __launch_bounds__(64, 2)
             T kr[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) kr[k] = T(0);
-#pragma unroll
+            const T *mrow = Ml + (isc ? hl : 0) * LDM;  // M_i again (RM still holds it, but indexing it needs unrolling)
+#pragma unroll 2
             for (int jj = 0; jj < NV; ++jj) {
+                const T mij = isc ? mrow[jj] : T(0);
                 T hj[NV];
                 ld16(hj, Timg + jj * NV);
 #pragma unroll
-                for (int k = 0; k < NV; ++k) kr[k] += RM[jj] * hj[k];
+                for (int k = 0; k < NV; ++k) kr[k] += mij * hj[k];
             }
-            if (warm) {
+            if (take) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) RM[k] = kr[k];
             }
         }
-        if (warm && !low) {
+        if (take && !low) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) RT[k] = hrow[k];
         }
         wsync();
-    }
+    };
     tick(4);
     for (;;) {
         // ===================================================== active-set loop
@@ -816,6 +812,11 @@ __global__ void __launch_bounds__(64, 2)
             }
             cT = cK = T(0);
             pdrop = false;
+            if (WARM && __ballot(hkstale & !done) != 0ull) {
+                const bool take = hkstale & !done;
+                rebuild_hk(take);
+                hkstale = hkstale & !take;
+            }
             // ---- FAST LOOP. While every half still in the loop is about to take a new constraint and the step
             //      turns out to be a FULL one (no multiplier blocks, nothing leaves, no limit reached), a trip needs
             //      none of the general machinery: one ballot per trip checks that, anything else leaves this loop
@@ -833,8 +834,9 @@ __global__ void __launch_bounds__(64, 2)
                     }
                     cT = cK = T(0);
                     {
-                        unsigned hi, lo;
-                        ordered(s * invn, hi, lo);
+                        // a violated row's scaled slack is negative: the order of the magnitudes is the order of
+                        // the high words, so the most violated row has the smallest complement
+                        const unsigned hi = ~(unsigned)__double2hiint(s * invn);
                         const bool viol = !done & selectable & (pos < 0) & (s < -tolh);
                         const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
                         const unsigned mkey = half_min(key);
@@ -891,8 +893,7 @@ __global__ void __launch_bounds__(64, 2)
             }
             // ---- selection, for the halves that start a new constraint (straight-line selects: no divergent branches)
             {
-                unsigned hi, lo;
-                ordered(s * invn, hi, lo);
+                const unsigned hi = ~(unsigned)__double2hiint(s * invn);  // (negative for every candidate: see the fast loop)
                 const bool want = needp & !done;
                 const bool viol = want & selectable & (pos < 0) & (s < -tolh);
                 const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
@@ -1142,13 +1143,18 @@ __global__ void __launch_bounds__(64, 2)
                 lam = (occ && lraw < T(0)) ? T(0) : lraw;
             }
             // with dl as it is (not clamped) y moves exactly onto the active hyperplanes
-            wsync();
-            rv[vofs] = dl;
-            wsync();
-            {
+            if constexpr (WARM) {
+                // (a stored operator is not trusted: y must stay y0 - M_A' lam for the acceptance test to mean anything)
+                wsync();
+                rv[vofs] = dl;
+                wsync();
                 T rr[NV];
                 ld16(rr, rv);
                 y -= ma_dot(rr);
+            } else {
+                // y - M_A' dl = y + M_A' T (T' rho) = y + T' rho, because T' rho lies in the range of M_A' where
+                // M_A' T = I - H is the identity (T is this launch's own operator)
+                y += uk;
             }
             wsync();
             zv[vofs] = y;
