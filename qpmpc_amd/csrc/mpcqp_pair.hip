@@ -14,8 +14,9 @@
 //   lane l of a half (l = 0..31):
 //     RM  row M_l of M = G L^-T (constraint l), slack s_l                (all 32 lanes)
 //     RT  l < 16: row l of T = N* (active-set slot l, multiplier, constraint id)
-//         l >= 16: row l-16 of L^-T (identity pushed through the forward substitution),
-//                  so that u = L^-T y is one dot product at the end
+//         l >= 16: row l-16 of L^-T (identity pushed through the forward substitution; parked in LDS
+//                  afterwards, so that u = L^-T y is one dot product at the end); in the active-set
+//                  loop row l-16 of the projector H = I - M_A' T, and RM holds K_l = H M_l
 //   during the build lanes 0..15 own a column of Psi and row l of P -> L, lane 16 the
 //   free response Phi_k x0.
 // The two halves take their own branches of the active-set iteration through
@@ -26,11 +27,17 @@
 // 256-register budget (no scratch), 19.6 KB of LDS per wavefront.
 //
 // Solver: the same dual active-set method (Goldfarb-Idnani 1983) with the explicit
-// operator T = N* as mpcqp_w64.hip; see that file for the derivation. Per step, for
-// the selected row p:  r = T M_p ; z = -M_p + M_A' r ; d2 = |z|^2 ;
+// operator T = N* as mpcqp_w64.hip; see that file for the derivation. Here their
+// operator H (the projector onto the null space of the active rows, in y-coordinates) is
+// kept explicitly as well, and the constraint rows are kept projected, K_i = H M_i, so that
+// ONE pass over the two register rows with the broadcast row M_p gives, for the selected p:
+//   r_a = T_a.M_p (slot lanes) ; -z_k = H_k.M_p (lanes 16..31) ; -M_i.z = K_i.M_p ; |z|^2 = K_p.M_p
 //   t = min(t1 = min lam_a/r_a, t2 = -s_p/d2) ; s_i -= t M_i.z ;
-//   full step: T_a += (r_a/d2) z, T_new = -z/d2 ; partial step: slot l leaves,
-//   T_a -= (T_a.T_l / T_l.T_l) T_l.
+//   full step: T_a += (r_a/d2) z, T_new = -z/d2, H -= z z'/d2, K_i -= (M_i.z/d2) z ;
+//   partial step: slot l leaves, T_a -= (T_a.T_l / T_l.T_l) T_l, H += T_l T_l'/T_l.T_l,
+//   K_i += (M_i.T_l / T_l.T_l) T_l.
+// The rank-one update is deferred to the top of the next trip (the one site that writes the
+// register rows); trips that are plain full steps run in a small loop of their own.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>

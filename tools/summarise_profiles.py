@@ -42,6 +42,6 @@ if "FETCH_SIZE" in traffic:
     write = traffic.get("WRITE_SIZE", 0.0) * 1024.0
     json.dump({"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
                "raw_FETCH_SIZE_KiB": traffic["FETCH_SIZE"], "raw_WRITE_SIZE_KiB": traffic.get("WRITE_SIZE"),
-               "source": f"profiles/r01_{tag}_rocprof_summary.txt"},
+               "source": f"profiles/{rnd}_{tag}_rocprof_summary.txt"},
               open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
