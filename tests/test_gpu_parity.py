@@ -982,3 +982,22 @@ def test_closed_loop_reusing_the_riccati_factor_equals_rebuilding_it():
         b.step(5)
         torch.cuda.synchronize()
         assert torch.equal(a.states, b.states)
+
+
+def test_pair_kernel_random_shapes_with_drops_vs_oracle_and_other_kernels():
+    """The pair kernel's whole envelope (nx in {3, 4}, n <= 16, m <= 32, every cost/constraint layout) on random LTV
+    problems tight enough that partial steps and drops occur (tools/stress_pair.py: its general trip, the drop
+    coefficients of the projector rows and the fast loop all run): statuses equal to the C oracle's and to the
+    one-per-wavefront and workgroup kernels', plans within 1e-7 relative. Replaces qpsolvers.solve_problem at
+    qpmpc/solve_mpc.py:43 like every solver kernel."""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_pair import run
+
+    worst, flagged, drops = run(16, 96, seed=20260929, verbose=False)
+    assert flagged == 0, (worst, flagged)
+    assert worst < 1e-7
+    assert drops > 0  # the drop path was really exercised

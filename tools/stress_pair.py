@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Dev stress run for the pair kernel (mpcqp_pair.hip): random LTV problems inside its envelope (nx in {3, 4},
+n <= 16, m <= 32, float64), tight enough that partial steps, drops and inconsistent rows occur, against the C oracle
+and against the one-problem-per-wavefront kernel and the LDS workgroup kernel (same solver, other formulations).
+Statuses must agree and plans must match to 1e-7 relative. usage: stress_pair.py [rounds] [batch]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+from qpmpc_amd import solve_mpc_batch, _capi, workloads as W
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from stress_stagewise import random_ltv  # noqa
+
+
+def run(rounds, batch, seed=4242, verbose=True):
+    rng = np.random.default_rng(seed)
+    worst, bad, drops = 0.0, 0, 0
+    for it in range(rounds):
+        nx = int(rng.choice([3, 4]))
+        nu = int(rng.integers(1, 3))
+        N = int(rng.integers(2, 16 // nu + 1))
+        mk = int(rng.integers(1, min(4, 32 // N) + 1))
+        tight = float(rng.choice([0.05, 0.2, 1.0, 3.0]))
+        w = random_ltv(rng, batch, nx, nu, N, mk, tight)
+        mode = int(rng.integers(0, 3))
+        if mode == 0:  # terminal cost only
+            w["wx"] = None
+            w["targets"] = None
+        if mode == 1 and rng.random() < 0.5:  # state rows only: the register-pipelined chain when mk == 2
+            w["D"] = None
+        bp = W.to_batch_problem(w)
+        plan = solve_mpc_batch(bp)
+        one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
+        lds = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
+        torch.cuda.synchronize()
+        U, st, iters = plan.U.cpu().numpy(), plan.status.cpu().numpy(), plan.iters.cpu().numpy()
+        Uo, _, sto, _ = oracle.solve_workload(w)
+        ok = (st == 0) & (sto == 0)
+        agree = float(((st == 0) == (sto == 0)).mean())
+        scale = np.maximum(1.0, np.abs(Uo).max(axis=1))
+        err = float(((np.abs(U - Uo).max(axis=1) / scale)[ok]).max()) if ok.any() else 0.0
+        errs = [err]
+        for other in (one, lds):
+            so = other.status.cpu().numpy()
+            both = (st == 0) & (so == 0)
+            agree = min(agree, float(((st == 0) == (so == 0)).mean()))
+            d = np.abs(U - other.U.cpu().numpy()).max(axis=1) / scale
+            errs.append(float(d[both].max()) if both.any() else 0.0)
+        same_iters = float((iters == one.iters.cpu().numpy())[st == 0].mean()) if (st == 0).any() else 1.0
+        n = N * nu
+        # a solved problem that made more trips than it can hold active rows has dropped at least one
+        drops += int(((iters > n) & (st == 0)).sum())
+        worst = max(worst, max(errs))
+        good = agree == 1.0 and max(errs) < 1e-7 and not np.isnan(U).any()
+        bad += not good
+        if verbose:
+            print(f"nx={nx} nu={nu} N={N:2d} mk={mk} n={n:2d} m={N*mk:2d} tight={tight}: solved {float((st==0).mean()):.3f} "
+                  f"(oracle {float((sto==0).mean()):.3f}) agreement {agree:.4f} rel diff oracle/w64/lds "
+                  f"{errs[0]:.1e}/{errs[1]:.1e}/{errs[2]:.1e} iters max {int(iters.max())} same-iters-as-w64 {same_iters:.4f}"
+                  f"{'' if good else '   <-- CHECK'}", flush=True)
+    return worst, bad, drops
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    worst, bad, drops = run(rounds, batch)
+    print("worst rel diff", worst, "rounds flagged", bad, "problems with more trips than variables", drops)
