@@ -136,6 +136,44 @@ __device__ __forceinline__ double dot16(const double (&a)[NV], const double (&b)
 }
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 
+// The value held by lane N of the caller's 16-lane row, in every lane of that row: a 64-bit DPP move
+// (v_mov_b64_dpp row_newbcast:N) -- a register-to-register broadcast on the vector pipe, no LDS round trip.
+template <int N> __device__ __forceinline__ double row_bcast(double x)
+{
+    return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
+}
+// The value held by the SECOND 16-lane row of the caller's half (lanes 16..31), lane for lane, in both rows.
+__device__ __forceinline__ double from_high_row(double x)
+{
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto sl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto sh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)sh[1], (int)sl[1]);
+}
+// row_bcast with the lane given by a loop counter of a fully unrolled loop (the DPP lane select is an immediate:
+// the switch folds once the counter is a constant)
+__device__ __forceinline__ double row_bcast_at(double x, int k)
+{
+    switch (k) {
+    case 0: return row_bcast<0>(x);
+    case 1: return row_bcast<1>(x);
+    case 2: return row_bcast<2>(x);
+    case 3: return row_bcast<3>(x);
+    case 4: return row_bcast<4>(x);
+    case 5: return row_bcast<5>(x);
+    case 6: return row_bcast<6>(x);
+    case 7: return row_bcast<7>(x);
+    case 8: return row_bcast<8>(x);
+    case 9: return row_bcast<9>(x);
+    case 10: return row_bcast<10>(x);
+    case 11: return row_bcast<11>(x);
+    case 12: return row_bcast<12>(x);
+    case 13: return row_bcast<13>(x);
+    case 14: return row_bcast<14>(x);
+    default: return row_bcast<15>(x);
+    }
+}
+
 // 1/x from the hardware estimate plus two Newton steps (operands are never subnormal
 // or zero when the result is used)
 __device__ __forceinline__ double fast_rcp(double x)
@@ -460,43 +498,32 @@ __global__ void __launch_bounds__(64, 2)
 
     tick(1);
     // ------------------------------------------------------------ factorise
-    // Right-looking Cholesky on the rows held by lanes 0..15 of each half. Column j (one entry per
-    // lane) is broadcast through a double-buffered 16-entry LDS vector: column j+1 is brought up to
-    // date and written FIRST in step j, so its round trip overlaps the rest of step j's updates.
+    // Right-looking Cholesky. Lanes 16..31 of each half take a copy of the rows of P first, so that BOTH 16-lane
+    // rows of the half hold the factor: every broadcast of the factorisation and of the forward substitution
+    // is then a DPP row broadcast (lane k's entry of column j to its whole row) instead of an LDS round trip --
+    // these two phases used to be bound by the LDS return path (about 150 sixteen-byte broadcast reads per wavefront).
     bool notpd = false;
-    T myinv = T(1);  // lane j keeps 1 / L_jj
+    T myinv = T(1);  // lanes j and 16 + j keep 1 / L_jj
     if constexpr (!MODEL) {
-        T *cb = Ll + NV * LDM;  // two buffers of NV + 2 (shadow entry for lanes >= 16)
-        const int cw = low ? hl : NV;
-        cb[cw] = Pr[0];
+        if (low) st16(Ll + hl * LDM, Pr);
+        wsync();
+        ld16(Pr, Ll + l15 * LDM);
+        wsync();
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const T *cbj = cb + (j & 1) * (NV + 2);
-            T cv[NV];
-#pragma unroll
-            for (int g = j / 2; g < NV / 2; ++g) {
-                const double2 t = reinterpret_cast<const double2 *>(cbj)[g];
-                cv[2 * g] = t.x;
-                cv[2 * g + 1] = t.y;
-            }
-            const T piv = cv[j];
+            const T pij = Pr[j];                    // P[i][j] of this lane's row, before scaling
+            const T piv = row_bcast_at(pij, j);     // P[j][j]
             if (!(piv > T(0))) notpd = true;
             const T rinv = rsqrt(piv);
-            const T pij = Pr[j];             // P[i][j] of this lane's row, before scaling
-            const T t2 = pij * rinv * rinv;  // P[i][j] / piv
-            if (j + 1 < NV) {
-                Pr[j + 1] -= t2 * cv[j + 1];
-                pin(Pr[j + 1]);
-                (cb + ((j + 1) & 1) * (NV + 2))[cw] = Pr[j + 1];
-            }
+            const T t2 = pij * rinv * rinv;         // P[i][j] / piv
 #pragma unroll
-            for (int k = j + 2; k < NV; ++k) {
-                Pr[k] -= t2 * cv[k];  // cv[k] = P[k][j]
-                pin(Pr[k]);
-            }
-            Pr[j] = pij * rinv;                                    // L[i][j] (lane j: sqrt(piv))
-            if (hl == j) myinv = rinv;
+            for (int k = j + 1; k < NV; ++k) Pr[k] -= t2 * row_bcast_at(pij, k);  // P[k][j] from lane k
+            Pr[j] = pij * rinv;                     // L[i][j] (lane j: sqrt(piv))
+            if (l15 == j) myinv = rinv;
+            pin(Pr[j]);
         }
+        wsync();  // (keeps the next phase's LDS loads out of the factorisation: register pressure)
+        __builtin_amdgcn_sched_barrier(0);
     }
     tick(2);
 
@@ -567,32 +594,25 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
             for (int k = 0; k < NV; ++k) RT[k] = (hl == NV + k) ? T(1) : T(0);
         }
-        // [RM; RT] <- [RM; RT] L^-T, rows of L broadcast from an LDS image (16-byte reads at
-        // half-uniform addresses)
-        if (low) {
-            st16(Ll + hl * LDM, Pr);
-            Ll[hl * LDM + NV] = myinv;
-        }
-        wsync();
+        // [RM; RT] <- [RM; RT] L^-T, right-looking: y_j = x_j / L_jj, then x_k -= y_j L[k][j] for k > j (the updates of
+        // a step are independent of each other); L[k][j] is lane k's entry of column j, a DPP row broadcast.
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const double2 *Lr = reinterpret_cast<const double2 *>(Ll + j * LDM);
-            T am = RM[j], at = RT[j];
+            const T ij = row_bcast_at(myinv, j);
+            RM[j] *= ij;
+            RT[j] *= ij;
+            // (the step's broadcasts stay behind its scaling, and both rows finish the step before the next one starts:
+            // otherwise the scheduler runs the two chains apart and keeps all 120 broadcast values alive in between)
+            T colj = Pr[j];
+            asm volatile("" : "+v"(colj) : "v"(RM[j]), "v"(RT[j]));
 #pragma unroll
-            for (int kk = 0; 2 * kk < j; ++kk) {
-                const double2 t = Lr[kk];
-                am -= RM[2 * kk] * t.x;
-                at -= RT[2 * kk] * t.x;
-                if (2 * kk + 1 < j) {
-                    am -= RM[2 * kk + 1] * t.y;
-                    at -= RT[2 * kk + 1] * t.y;
-                }
+            for (int k = j + 1; k < NV; ++k) {
+                const T lkj = row_bcast_at(colj, k);
+                RM[k] -= RM[j] * lkj;
+                RT[k] -= RT[j] * lkj;
             }
-            const T li = Lr[NV / 2].x;
-            RM[j] = am * li;
-            RT[j] = at * li;
-            pin(RM[j]);  // keeps step j+1's broadcast reads behind step j (register pressure)
-            pin(RT[j]);
+#pragma unroll
+            for (int k = j + 1; k < NV; ++k) asm volatile("" : "+v"(RM[k]), "+v"(RT[k]));
         }
         wsync();  // the M image below reuses the L image
     }
