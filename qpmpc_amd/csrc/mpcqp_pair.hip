@@ -142,6 +142,35 @@ template <int N> __device__ __forceinline__ double row_bcast(double x)
 {
     return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true);
 }
+// acc += (x of lane N of the caller's row) * m in ONE instruction (v_fmac_f64_dpp). The compiler does not fold the DPP
+// move into the FMA, and it cannot see inside the asm: a register written by a VALU instruction needs two wait states
+// before a DPP read, so every batch of these is preceded by dpp_ready(x) on its broadcast source.
+template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double x, double m)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(N));
+}
+__device__ __forceinline__ void dpp_ready(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+__device__ __forceinline__ void fmac_bcast_at(double &acc, double x, double m, int k)
+{
+    switch (k) {
+    case 0: return fmac_bcast<0>(acc, x, m);
+    case 1: return fmac_bcast<1>(acc, x, m);
+    case 2: return fmac_bcast<2>(acc, x, m);
+    case 3: return fmac_bcast<3>(acc, x, m);
+    case 4: return fmac_bcast<4>(acc, x, m);
+    case 5: return fmac_bcast<5>(acc, x, m);
+    case 6: return fmac_bcast<6>(acc, x, m);
+    case 7: return fmac_bcast<7>(acc, x, m);
+    case 8: return fmac_bcast<8>(acc, x, m);
+    case 9: return fmac_bcast<9>(acc, x, m);
+    case 10: return fmac_bcast<10>(acc, x, m);
+    case 11: return fmac_bcast<11>(acc, x, m);
+    case 12: return fmac_bcast<12>(acc, x, m);
+    case 13: return fmac_bcast<13>(acc, x, m);
+    case 14: return fmac_bcast<14>(acc, x, m);
+    default: return fmac_bcast<15>(acc, x, m);
+    }
+}
 // The value held by the SECOND 16-lane row of the caller's half (lanes 16..31), lane for lane, in both rows.
 __device__ __forceinline__ double from_high_row(double x)
 {
@@ -271,33 +300,56 @@ __global__ void __launch_bounds__(64, 2)
         T *As = sm + L.off_stage, *Bs = As + al4(L.nA), *Cs = Bs + al4(L.nB), *Ds = Cs + al4(L.nC);
         // The problem's operands are staged in LDS by the 32 lanes of its half: every load of the
         // four arrays is issued before the first store, so the whole stage costs ONE HBM latency.
+        // The lean instantiations (MK > 0) do not stage A and C at all: lane e of each 16-lane row keeps element e
+        // (and e + 16) of [A_k | C_k] for every step k in registers, straight from HBM, and the chain fetches an
+        // operand as a DPP row broadcast -- the chain used to be bound by the LDS return path (15 doubles broadcast
+        // to every lane per step); now its only LDS traffic is the G rows it writes.
+        constexpr bool LEAN = MK > 0;
+        constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
+        T opa[NV], opb[NV];
+        if constexpr (LEAN) {
+            // (lanes without an element and steps beyond the horizon load a valid address and are never read: no
+            // select, so these registers are written by the loads only -- see dpp_ready)
+            const int e0 = l15, e1 = l15 + 16;
+            const bool ok0 = e0 < NEe, ok1 = e1 < NEe;
+            const T *p0 = (e0 < NAe) ? A + e0 : Cm + (ok0 ? e0 - NAe : 0);
+            const T *p1 = (e1 < NAe) ? A + e1 : Cm + (ok1 ? e1 - NAe : 0);
+            const int s0 = (e0 < NAe) ? sA : sC, s1 = (e1 < NAe) ? sA : sC;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int kc = (k < N) ? k : N - 1;
+                opa[k] = p0[kc * s0];
+                opb[k] = (NEe > 16) ? p1[kc * s1] : T(0);
+            }
+        }
         {
             constexpr int CA = 8, CB2 = 2, CC = 4, CD = 4;  // 32-element chunks held in registers per array
             T ta[CA], tb[CB2], tc[CC], td[CD];
+            const int nAs = LEAN ? 0 : L.nA, nCs = LEAN ? 0 : L.nC;
 #pragma unroll
-            for (int u = 0; u < CA; ++u) ta[u] = (u * HL + hl < L.nA) ? A[u * HL + hl] : T(0);
+            for (int u = 0; u < CA; ++u) ta[u] = (u * HL + hl < nAs) ? A[u * HL + hl] : T(0);
 #pragma unroll
             for (int u = 0; u < CB2; ++u) tb[u] = (u * HL + hl < L.nB) ? B[u * HL + hl] : T(0);
 #pragma unroll
-            for (int u = 0; u < CC; ++u) tc[u] = (u * HL + hl < L.nC) ? Cm[u * HL + hl] : T(0);
+            for (int u = 0; u < CC; ++u) tc[u] = (u * HL + hl < nCs) ? Cm[u * HL + hl] : T(0);
 #pragma unroll
             for (int u = 0; u < CD; ++u) td[u] = (u * HL + hl < L.nD) ? Dm[u * HL + hl] : T(0);
 #pragma unroll
             for (int u = 0; u < CA; ++u)
-                if (u * HL + hl < L.nA) As[u * HL + hl] = ta[u];
+                if (u * HL + hl < nAs) As[u * HL + hl] = ta[u];
 #pragma unroll
             for (int u = 0; u < CB2; ++u)
                 if (u * HL + hl < L.nB) Bs[u * HL + hl] = tb[u];
 #pragma unroll
             for (int u = 0; u < CC; ++u)
-                if (u * HL + hl < L.nC) Cs[u * HL + hl] = tc[u];
+                if (u * HL + hl < nCs) Cs[u * HL + hl] = tc[u];
 #pragma unroll
             for (int u = 0; u < CD; ++u)
                 if (u * HL + hl < L.nD) Ds[u * HL + hl] = td[u];
             // anything beyond the register chunks (long horizons of tiny systems never get here; kept for safety)
-            for (int i = CA * HL + hl; i < L.nA; i += HL) As[i] = A[i];
+            for (int i = CA * HL + hl; i < nAs; i += HL) As[i] = A[i];
             for (int i = CB2 * HL + hl; i < L.nB; i += HL) Bs[i] = B[i];
-            for (int i = CC * HL + hl; i < L.nC; i += HL) Cs[i] = Cm[i];
+            for (int i = CC * HL + hl; i < nCs; i += HL) Cs[i] = Cm[i];
             for (int i = CD * HL + hl; i < L.nD; i += HL) Ds[i] = Dm[i];
         }
         tick(8);
@@ -378,19 +430,30 @@ __global__ void __launch_bounds__(64, 2)
             for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
         };
         if constexpr (MK > 0) {
-            // Terminal cost only, C only, mk == MK (configs 1, 2, 4; the host checks). Register-pipelined
-            // chain on 17 lanes per half: the broadcast LDS reads of A_{k+1}, C_{k+1} are in flight while
-            // step k computes [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k.
-            if (hl <= NV) {
-                constexpr int NA = NX * NX, NC = MK * NX;
-                // one step from register copies of A_k, C_k
-                auto step = [&](int k, const T *a, const T *c) {
+            // Terminal cost only, C only, mk == MK (configs 1, 2, 4; the host checks). [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k
+            // with the operands broadcast from the lanes' registers. EVERY lane runs the chain (a DPP read from a lane
+            // that a branch has switched off returns zero); lanes beyond 16 carry zeros and store nothing.
+            // acc += (element idx of [A_k | C_k]) * x  (idx, k: constants once unrolled)
+            auto mac = [&](T &acc, int idx, int k, T x) {
+                if (idx < 16)
+                    fmac_bcast_at(acc, opa[k], x, idx);
+                else
+                    fmac_bcast_at(acc, opb[k], x, idx - 16);
+            };
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (k < N) {
+                    T g[MK];
 #pragma unroll
                     for (int i2 = 0; i2 < MK; ++i2) {
                         T acc = T(0);
 #pragma unroll
-                        for (int s2 = 0; s2 < NX; ++s2) acc += c[i2 * NX + s2] * v[s2];
-                        gd[k * MK + i2] = acc;
+                        for (int s2 = 0; s2 < NX; ++s2) mac(acc, NAe + i2 * NX + s2, k, v[s2]);
+                        g[i2] = acc;
+                    }
+                    if (hl <= NV) {
+#pragma unroll
+                        for (int i2 = 0; i2 < MK; ++i2) gd[k * MK + i2] = g[i2];
                     }
                     const bool here = (j == k);
                     T w[NX];
@@ -398,73 +461,11 @@ __global__ void __launch_bounds__(64, 2)
                     for (int r = 0; r < NX; ++r) {
                         T acc = T(0);
 #pragma unroll
-                        for (int s2 = 0; s2 < NX; ++s2) acc += a[r * NX + s2] * v[s2];
+                        for (int s2 = 0; s2 < NX; ++s2) mac(acc, r * NX + s2, k, v[s2]);
                         w[r] = acc;
                     }
 #pragma unroll
                     for (int r = 0; r < NX; ++r) v[r] = here ? bcol[r] : w[r];
-                };
-                if (sA && sC) {
-                    // Time-varying A and C: the blocks of steps (k, k+1), k even, are contiguous and 16-byte
-                    // aligned in the staged image, so a PAIR of steps is fetched with 16-byte broadcast reads
-                    // into one of two register sets while the other set's two steps compute.
-                    T pa[2 * NA], pc[2 * NC], qa2[2 * NA], qc[2 * NC];
-                    auto fetch = [&](int k, T(&a)[2 * NA], T(&c)[2 * NC]) {
-                        const double2 *sa = reinterpret_cast<const double2 *>(As + k * NA);
-                        const double2 *sc = reinterpret_cast<const double2 *>(Cs + k * NC);
-#pragma unroll
-                        for (int e = 0; e < NA; ++e) {
-                            const double2 t = sa[e];
-                            a[2 * e] = t.x;
-                            a[2 * e + 1] = t.y;
-                        }
-#pragma unroll
-                        for (int e = 0; e < NC; ++e) {
-                            const double2 t = sc[e];
-                            c[2 * e] = t.x;
-                            c[2 * e + 1] = t.y;
-                        }
-                    };
-                    fetch(0, pa, pc);
-                    for (int k = 0;;) {
-                        fetch((k + 2 < N) ? k + 2 : k, qa2, qc);
-                        step(k, pa, pc);
-                        if (k + 1 < N) step(k + 1, pa + NA, pc + NC);
-                        k += 2;
-                        if (k >= N) break;
-                        fetch((k + 2 < N) ? k + 2 : k, pa, pc);
-                        step(k, qa2, qc);
-                        if (k + 1 < N) step(k + 1, qa2 + NA, qc + NC);
-                        k += 2;
-                        if (k >= N) break;
-                    }
-                } else if (!sA && !sC) {
-                    // time-invariant A and C: fetched once
-                    T a0[NA], c0[NC];
-#pragma unroll
-                    for (int e = 0; e < NA; ++e) a0[e] = As[e];
-#pragma unroll
-                    for (int e = 0; e < NC; ++e) c0[e] = Cs[e];
-                    for (int k = 0; k < N; ++k) step(k, a0, c0);
-                } else {
-                    T a0[NA], c0[NC];
-#pragma unroll
-                    for (int e = 0; e < NA; ++e) a0[e] = As[e];
-#pragma unroll
-                    for (int e = 0; e < NC; ++e) c0[e] = Cs[e];
-                    for (int k = 0; k < N; ++k) {
-                        const int kn = (k + 1 < N) ? k + 1 : k;
-                        T a1[NA], c1[NC];
-#pragma unroll
-                        for (int e = 0; e < NA; ++e) a1[e] = As[kn * sA + e];
-#pragma unroll
-                        for (int e = 0; e < NC; ++e) c1[e] = Cs[kn * sC + e];
-                        step(k, a0, c0);
-#pragma unroll
-                        for (int e = 0; e < NA; ++e) a0[e] = a1[e];
-#pragma unroll
-                        for (int e = 0; e < NC; ++e) c0[e] = c1[e];
-                    }
                 }
             }
         } else if (!stageP && !stageQ) {
@@ -515,9 +516,13 @@ __global__ void __launch_bounds__(64, 2)
             const T piv = row_bcast_at(pij, j);     // P[j][j]
             if (!(piv > T(0))) notpd = true;
             const T rinv = rsqrt(piv);
-            const T t2 = pij * rinv * rinv;         // P[i][j] / piv
+            const T nt2 = -(pij * rinv * rinv);     // -P[i][j] / piv
+            {
+                T src = pij;
+                dpp_ready(src);
 #pragma unroll
-            for (int k = j + 1; k < NV; ++k) Pr[k] -= t2 * row_bcast_at(pij, k);  // P[k][j] from lane k
+                for (int k = j + 1; k < NV; ++k) fmac_bcast_at(Pr[k], src, nt2, k);  // P[k][j] from lane k
+            }
             Pr[j] = pij * rinv;                     // L[i][j] (lane j: sqrt(piv))
             if (l15 == j) myinv = rinv;
             pin(Pr[j]);
@@ -604,12 +609,12 @@ __global__ void __launch_bounds__(64, 2)
             // (the step's broadcasts stay behind its scaling, and both rows finish the step before the next one starts:
             // otherwise the scheduler runs the two chains apart and keeps all 120 broadcast values alive in between)
             T colj = Pr[j];
-            asm volatile("" : "+v"(colj) : "v"(RM[j]), "v"(RT[j]));
+            asm volatile("s_nop 1" : "+v"(colj) : "v"(RM[j]), "v"(RT[j]));  // (also the DPP wait states, see fmac_bcast)
+            const T nm = -RM[j], nt = -RT[j];
 #pragma unroll
             for (int k = j + 1; k < NV; ++k) {
-                const T lkj = row_bcast_at(colj, k);
-                RM[k] -= RM[j] * lkj;
-                RT[k] -= RT[j] * lkj;
+                fmac_bcast_at(RM[k], colj, nm, k);
+                fmac_bcast_at(RT[k], colj, nt, k);
             }
 #pragma unroll
             for (int k = j + 1; k < NV; ++k) asm volatile("" : "+v"(RM[k]), "+v"(RT[k]));
@@ -849,17 +854,18 @@ __global__ void __launch_bounds__(64, 2)
             //      none of the general machinery: one ballot per trip checks that, anything else leaves this loop
             //      and the same trip is redone by the general code below.
             if (__ballot(!done & (!needp | dropping)) == 0ull) {
+                // Inside this loop the update vector never goes through LDS: lane 16 + k of a half produces -z_k, one
+                // v_permlane16_swap pair copies the high row over the low one, and the next trip's update reads
+                // component k as a DPP row broadcast. cTn, cKn are the coefficients of -z.
+                T zn = T(0), cTn = T(0), cKn = T(0);
                 for (;;) {
-                    {
-                        T vv[NV];
-                        ld16(vv, zv);
+                    dpp_ready(zn);
 #pragma unroll
-                        for (int k = 0; k < NV; ++k) {
-                            RT[k] += cT * vv[k];
-                            RM[k] += cK * vv[k];
-                        }
+                    for (int k = 0; k < NV; ++k) {
+                        fmac_bcast_at(RT[k], zn, cTn, k);
+                        fmac_bcast_at(RM[k], zn, cKn, k);
                     }
-                    cT = cK = T(0);
+                    cTn = cKn = T(0);
                     {
                         // a violated row's scaled slack is negative: the order of the magnitudes is the order of
                         // the high words, so the most violated row has the smallest complement
@@ -882,7 +888,6 @@ __global__ void __launch_bounds__(64, 2)
                         kd = dot16(RM, mp);
                     }
                     const bool st = !done;
-                    zv[low ? 3 * NV + l15 : l15] = st ? -rd : T(0);
                     const T d2 = half_get(kd, hb, p);
                     const T sp = half_get(s, hb, p);
                     const T ip = half_get(invn, hb, p);
@@ -895,13 +900,14 @@ __global__ void __launch_bounds__(64, 2)
                     const bool odd = st & (!can_move | (iters >= max_iter) | blk);
                     if (__ballot(odd) != 0ull) {
                         needp = done;  // the halves still in the loop hold a selected row and have not stepped
-                        wsync();
                         break;
                     }
+                    zn = from_high_row(rd);  // -z_k in lanes k and 16 + k
                     const bool isnew = st & (hl == sl), isp = st & (hl == p);
                     iters += st ? 1 : 0;
-                    cT = st ? ((hl == sl) ? -inv : ((low ? r0 : rd) * inv)) : T(0);
-                    cK = (st & isc) ? kd * inv : T(0);
+                    // T_a += (r_a/d2) z, T_new = -z/d2, H_k -= (z_k/d2) z, K_i -= (M_i.z/d2) z, as multiples of -z
+                    cTn = st ? ((hl == sl) ? inv : -((low ? r0 : rd) * inv)) : T(0);
+                    cKn = (st & isc) ? -(kd * inv) : T(0);
                     const T tt = st ? t2 : T(0);
                     const T sn = (pos >= 0) ? T(0) : s + t2 * kd;  // s_i -= t M_i . z
                     s = (st & isc) ? sn : s;
@@ -914,7 +920,6 @@ __global__ void __launch_bounds__(64, 2)
                     s = isp ? T(0) : s;
                     mask |= st ? (1u << sl) : 0u;
                     nq += st ? 1 : 0;
-                    wsync();
                 }
                 // (both exits leave no update pending: the coefficients are cleared right after each update)
             }
