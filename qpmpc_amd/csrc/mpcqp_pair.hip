@@ -306,6 +306,21 @@ __global__ void __launch_bounds__(64, 2)
         // to every lane per step); now its only LDS traffic is the G rows it writes.
         constexpr bool LEAN = MK > 0;
         constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
+        // the per-lane scalars are requested first, so that their latency is the staging's
+        const bool isx = (hl == NV), col = (hl < n);
+        const int j = col ? hl / nu : -1, ii = col ? hl - j * nu : 0;
+        const T eval = isc ? ge[prob * ka.e.batch_stride + (hl / mk) * ka.e.step_stride + (hl % mk)] : INF;
+        T v[NX], gref[NX];
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            v[s] = isx ? x0[s] : T(0);
+            gref[s] = (isx && termQ) ? goal[s] : T(0);
+        }
+        T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
+        if constexpr (LEAN) {
+#pragma unroll
+            for (int r = 0; r < NX; ++r) bcol[r] = col ? B[j * sB + r * nu + ii] : T(0);
+        }
         T opa[NV], opb[NV];
         if constexpr (LEAN) {
             // (lanes without an element and steps beyond the horizon load a valid address and are never read: no
@@ -325,11 +340,11 @@ __global__ void __launch_bounds__(64, 2)
         {
             constexpr int CA = 8, CB2 = 2, CC = 4, CD = 4;  // 32-element chunks held in registers per array
             T ta[CA], tb[CB2], tc[CC], td[CD];
-            const int nAs = LEAN ? 0 : L.nA, nCs = LEAN ? 0 : L.nC;
+            const int nAs = LEAN ? 0 : L.nA, nCs = LEAN ? 0 : L.nC, nBs = LEAN ? 0 : L.nB;  // (lean: D is absent, B per lane above)
 #pragma unroll
             for (int u = 0; u < CA; ++u) ta[u] = (u * HL + hl < nAs) ? A[u * HL + hl] : T(0);
 #pragma unroll
-            for (int u = 0; u < CB2; ++u) tb[u] = (u * HL + hl < L.nB) ? B[u * HL + hl] : T(0);
+            for (int u = 0; u < CB2; ++u) tb[u] = (u * HL + hl < nBs) ? B[u * HL + hl] : T(0);
 #pragma unroll
             for (int u = 0; u < CC; ++u) tc[u] = (u * HL + hl < nCs) ? Cm[u * HL + hl] : T(0);
 #pragma unroll
@@ -339,7 +354,7 @@ __global__ void __launch_bounds__(64, 2)
                 if (u * HL + hl < nAs) As[u * HL + hl] = ta[u];
 #pragma unroll
             for (int u = 0; u < CB2; ++u)
-                if (u * HL + hl < L.nB) Bs[u * HL + hl] = tb[u];
+                if (u * HL + hl < nBs) Bs[u * HL + hl] = tb[u];
 #pragma unroll
             for (int u = 0; u < CC; ++u)
                 if (u * HL + hl < nCs) Cs[u * HL + hl] = tc[u];
@@ -348,29 +363,21 @@ __global__ void __launch_bounds__(64, 2)
                 if (u * HL + hl < L.nD) Ds[u * HL + hl] = td[u];
             // anything beyond the register chunks (long horizons of tiny systems never get here; kept for safety)
             for (int i = CA * HL + hl; i < nAs; i += HL) As[i] = A[i];
-            for (int i = CB2 * HL + hl; i < L.nB; i += HL) Bs[i] = B[i];
+            for (int i = CB2 * HL + hl; i < nBs; i += HL) Bs[i] = B[i];
             for (int i = CC * HL + hl; i < nCs; i += HL) Cs[i] = Cm[i];
             for (int i = CD * HL + hl; i < L.nD; i += HL) Ds[i] = Dm[i];
         }
         tick(8);
-        const bool isx = (hl == NV), col = (hl < n);
-        const int j = col ? hl / nu : -1, ii = col ? hl - j * nu : 0;
-        const T eval = isc ? ge[prob * ka.e.batch_stride + (hl / mk) * ka.e.step_stride + (hl % mk)] : INF;
-        T v[NX], gref[NX];
-#pragma unroll
-        for (int s = 0; s < NX; ++s) {
-            v[s] = isx ? x0[s] : T(0);
-            gref[s] = (isx && termQ) ? goal[s] : T(0);
-        }
         const T wu = (T)ka.wu;
 #pragma unroll
         for (int b = 0; b < NV; ++b) Pr[b] = (hl == b) ? (col ? wu : T(1)) : T(0);
         T qa = T(0);
         wsync();
         tick(9);
-        T bcol[NX];  // this lane's column of B_j (enters the chain at step j)
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
+            for (int r = 0; r < NX; ++r) bcol[r] = col ? Bs[j * sB + r * nu + ii] : T(0);
+        }
 
         // Gram accumulation of one block: Pr[b] += w v_a . v_b, qa += w resid . v_a;
         // ref[] is this lane's reference (non-zero only in lane 16).
