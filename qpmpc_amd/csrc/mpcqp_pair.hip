@@ -383,23 +383,19 @@ __global__ void __launch_bounds__(64, 2)
         // ref[] is this lane's reference (non-zero only in lane 16).
         auto gram = [&](T w, bool useP, bool useQ, const T (&ref)[NX]) {
             if (!useP && !useQ) return;
-            wsync();
-#pragma unroll
-            for (int s = 0; s < NX; ++s) ex[s * 32 + hl] = v[s] - ref[s];
-            wsync();
+            // v_b[s] of column lane b is a DPP row broadcast; the residual of lane 16 (first lane of the half's second
+            // row) comes over with one row swap. Lanes 16..31 accumulate rows nobody reads (they take a copy of
+            // lanes 0..15's rows before the factorisation).
 #pragma unroll
             for (int s = 0; s < NX; ++s) {
+                T res = v[s] - ref[s];
                 const T t = w * v[s];
+                if (useQ) qa += t * row_bcast<0>(from_high_row(res));
                 if (useP) {
-                    T vb[NV];
-                    ld16(vb, ex + s * 32);
+                    dpp_ready(res);
 #pragma unroll
-                    for (int b = 0; b < NV; ++b) {
-                        Pr[b] += t * vb[b];
-                        pin(Pr[b]);
-                    }
+                    for (int b = 0; b < NV; ++b) fmac_bcast_at(Pr[b], res, t, b);
                 }
-                if (useQ) qa += t * ex[s * 32 + NV];
             }
         };
         // G rows of step k from v = Psi_k[:, lane] (lane 16: Phi_k x0); lanes 0..15 fill
