@@ -231,6 +231,12 @@ struct Lay {     // LDS carve of ONE problem in doubles (host-computed, passed b
 };
 
 constexpr double DEP = 1e-14;  // |z|^2 / |M_p|^2 below this: M_p depends on the active rows
+// |z|^2 = M_p' H M_p is read off as K_p . M_p, whose rounding error is LINEAR in the error of the maintained row K_p
+// (about 1e-16 |M_p|^2 times the growth of the updates) while |K_p|^2 is quadratic in it like the |z|^2 of a
+// recomputed z. The fast loop therefore only trusts K_p . M_p well away from dependence; anything closer goes
+// to the general trip, which forms |K_p|^2 (a stress run with inconsistent rows returned 'solved' for a few
+// infeasible problems before: a dependent row slipped past the 1e-14 test on rounding noise).
+constexpr double DEP_FAST = 1e-6;
 
 }  // namespace pair
 
@@ -894,7 +900,7 @@ __global__ void __launch_bounds__(64, 2)
                     const T d2 = half_get(kd, hb, p);
                     const T sp = half_get(s, hb, p);
                     const T ip = half_get(invn, hb, p);
-                    const bool can_move = (nq < n) & (d2 * ip * ip > DEP) & (d2 > T(0));
+                    const bool can_move = (nq < n) & (d2 * ip * ip > DEP_FAST);
                     const T inv = can_move ? fast_rcp(d2) : T(0);
                     const T t2 = can_move ? -sp * inv : INF;
                     const int sl = (int)__builtin_ctz(~mask);
@@ -957,7 +963,7 @@ __global__ void __launch_bounds__(64, 2)
             zv[low ? 3 * NV + l15 : l15] = stepping ? -rd : T(0);
             const T mz = -kd;
             // ---- step length
-            const T d2 = half_get(kd, hb, p);  // |z|^2 = M_p' H M_p = K_p . M_p
+            const T d2 = half_get(dot16(RM, RM), hb, p);  // |z|^2 = |H M_p|^2 = |K_p|^2 (robust near dependence, see DEP_FAST)
             const T sp = half_get(s, hb, p);
             const T ip = half_get(invn, hb, p);
             const bool can_move = (nq < n) & (d2 * ip * ip > DEP) & (d2 > T(0));
@@ -1233,12 +1239,14 @@ __global__ void __launch_bounds__(64, 2)
         //      every active row on its bound -- with stationarity by construction and lam >= 0 these are
         //      the KKT conditions of the strictly convex QP
         bool dirty = half_any(selectable && pos < 0 && !(fresh >= -T(4) * tolh), hb);  // (NaN counts as violated)
-        if (WARM && __ballot(warm && !finished) != 0ull) {
+        if (__ballot(!finished) != 0ull) {
+            // (needed after a warm start, whose operator is not trusted; cheap insurance for the cold solves, whose
+            // refinement relies on the maintained operator as well)
             const T ra = half_get(fresh, hb, myact);
             const T ta = half_get(tolh, hb, myact);
             const bool off = half_any(occ && !(fabs(ra) <= T(1e3) * ta), hb);
             const bool neg = half_any(occ && !(lam >= T(0)), hb);
-            dirty = dirty || (warm && (off || neg));
+            dirty = dirty || off || neg;
         }
         bool coldnow = false;
         // u = L^-T y in lanes 16..31 (yy holds y; the rows of L^-T come back from their image)
