@@ -100,11 +100,15 @@ __device__ __forceinline__ void block_argmin(T &v, int &i, T *redv, int *redi, i
 template <typename T> struct Lim;
 template <> struct Lim<double> {
     static __device__ __forceinline__ double inf() { return HUGE_VAL; }
-    static __device__ __forceinline__ double tiny() { return 1e-28; }
+    // |d2|^2 / |d|^2 below this: the selected row depends on the active ones. (1e-28 until round 2: rounding noise let
+    // dependent rows through and a few INFEASIBLE problems in 10^4 came back 'solved' with |u| ~ 1e13 and violated rows --
+    // found by tools/stress_pair.py. The other kernels use 1e-14 .. 1e-10 on this ratio; with 1e-14 HERE one borderline
+    // problem of the stress run lost accuracy (1e-7 against the other kernels), 1e-18 rejects the noise and keeps it.)
+    static __device__ __forceinline__ double tiny() { return 1e-18; }
 };
 template <> struct Lim<float> {
     static __device__ __forceinline__ float inf() { return HUGE_VALF; }
-    static __device__ __forceinline__ float tiny() { return 1e-12f; }
+    static __device__ __forceinline__ float tiny() { return 1e-10f; }
 };
 
 // ------------------------------------------------------------------ build

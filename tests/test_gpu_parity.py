@@ -1001,3 +1001,44 @@ def test_pair_kernel_random_shapes_with_drops_vs_oracle_and_other_kernels():
     assert flagged == 0, (worst, flagged)
     assert worst < 1e-7
     assert drops > 0  # the drop path was really exercised
+
+
+def test_inconsistent_problems_are_never_reported_solved():
+    """Problems whose rows are inconsistent with their bounds (time-varying data generated consistent, then A and C
+    replaced by their first step): the small-problem kernels (pair, one-per-wavefront, LDS workgroup) must agree on which
+    are solvable, and a plan reported solved must satisfy its rows. (Round 2: the workgroup kernel's dependence test sat
+    at rounding-noise level and returned |u| ~ 1e13 'solutions' for a few such problems; qpsolvers reports found=False
+    there, plan.py:35-40.)"""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_stagewise import random_ltv
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(99)
+    unsolved = 0
+    for _ in range(24):
+        nx, N = int(rng.choice([3, 4])), int(rng.integers(4, 16))
+        w = random_ltv(rng, 128, nx, 1, N, 2, float(rng.choice([0.05, 0.2])))
+        w["wx"] = w["targets"] = w["D"] = None
+        w["A"] = np.ascontiguousarray(w["A"][:, :1])
+        w["C"] = np.ascontiguousarray(w["C"][:, :1])
+        bp = to_batch_problem(w)
+        plans = [solve_mpc_batch(bp, flags=f) for f in (0, _capi.OPT_ONE_PER_WAVE, _capi.OPT_FORCE_LDS)]
+        torch.cuda.synchronize()
+        solved = [p.status.cpu().numpy() == 0 for p in plans]
+        assert (solved[0] == solved[1]).all() and (solved[0] == solved[2]).all()
+        unsolved += int((~solved[0]).sum())
+        # rows of the solved plans: C x_k <= e_k along the roll-out
+        for p, ok in zip(plans, solved):
+            U = p.U.cpu().numpy()
+            x = w["x0"].copy()
+            worst = np.full(x.shape[0], -np.inf)
+            for k in range(N):
+                worst = np.maximum(worst, (np.einsum("bij,bj->bi", w["C"][:, 0], x) - w["e"][:, k]).max(axis=1))
+                x = np.einsum("bij,bj->bi", w["A"][:, 0], x) + w["B"][:, k, :, 0] * U[:, k:k + 1]
+            assert (worst[ok] <= 1e-6).all(), float(worst[ok].max())
+    assert unsolved > 50  # the batch really contains inconsistent problems
