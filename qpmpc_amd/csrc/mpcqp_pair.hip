@@ -38,6 +38,15 @@
 //   K_i += (M_i.T_l / T_l.T_l) T_l.
 // The rank-one update is deferred to the top of the next trip (the one site that writes the
 // register rows); trips that are plain full steps run in a small loop of their own.
+//
+// Broadcasts: wherever the value to broadcast sits in a lane known at compile time -- column j of the
+// Cholesky factor, L[k][j] in the forward substitution, the operands of the Psi chain (lane e keeps
+// element e of [A_k | C_k] for every step), v_b in the Gram accumulation, component k of the update
+// vector in the fast loop -- it is a 64-bit DPP row broadcast folded into the FMA
+// (v_fmac_f64_dpp ... row_newbcast:n), not an LDS round trip: both 16-lane rows of a half hold what
+// the other needs (a v_permlane16_swap pair copies one row over the other). LDS is left with the
+// images addressed by run-time indices: the G image, M (row p of the selected constraint), T by
+// columns in the refinement, the rows of L^-T.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
