@@ -519,7 +519,9 @@ def main(argv=None) -> None:
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # (a single rank launched through torch.distributed.run also goes through RCCL: the only way to execute the
+    # collectives' code path on a one-GPU box)
+    if world > 1 or os.environ.get("TORCHELASTIC_RUN_ID"):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
