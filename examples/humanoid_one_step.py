@@ -5,6 +5,11 @@ A parameter sweep over ONE model: the model-dependent half of the work (P, its C
 M = G L^-T) is done once by ``SharedModel``; every state then only needs the active-set loop.
 Infeasible states come back with ``found = False`` (status 2), exactly like an empty ``Plan``.
 """
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
+
 import torch
 
 from qpmpc_amd import SharedModel

@@ -5,6 +5,11 @@ Every walker has its own stride lengths, foot size and footstep phase; per MPC p
 of its 16-step horizon are rebuilt from that phase (a *list* of inequality vectors in the reference,
 one [B, N, 2] operand here), the QPs are built and solved in one launch and the plants integrated in
 another."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
+
 import numpy as np
 import torch
 

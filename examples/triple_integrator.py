@@ -5,6 +5,11 @@ The single problem is the one of the reference's examples/triple_integrator.py (
 qpmpc_amd/workloads.py::triple_integrator_matrices); here it is solved on the GPU by
 ``solve_mpc(problem, solver="hip_gi")`` and by the batched entry point.
 """
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
+
 import numpy as np
 import torch
 

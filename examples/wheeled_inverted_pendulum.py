@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """1024 wheeled inverted pendulums balancing and driving at 0.5 m/s, closed loop on the device
 (config 3: N = 50, sampling period 24 ms, 15 plant sub-steps per MPC period)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
+
 import numpy as np
 import torch
 
