@@ -309,8 +309,8 @@ __global__ void __launch_bounds__(64, 2)
         const int sC = ka.C.step_stride ? mk * nx : 0, sD = ka.D.step_stride ? mk * nu : 0;
         const bool stageP = ka.flags & MPCQP_P_STAGE, stageQ = (ka.flags & MPCQP_Q_STAGE) && tgt;
         const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
-        T *ex = sm + L.off_Y;           // exchange: ex[s*32 + c] = Psi_k[s][c] (c < 16), ex[s*32 + 16] = residual
-        T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries)
+        T *hp = sm + L.off_Y + 4 * 32;  // hp[row] = C_k Phi_k x0 (m <= 32 entries; the 4 x 32 doubles before it are spare since the
+                                        // Gram accumulation exchanges through DPP)
         auto al4 = [](int c) { return (c + 3) & ~3; };  // as make_lay: every staged array starts 16-byte aligned
         T *As = sm + L.off_stage, *Bs = As + al4(L.nA), *Cs = Bs + al4(L.nB), *Ds = Cs + al4(L.nC);
         // The problem's operands are staged in LDS by the 32 lanes of its half: every load of the
@@ -1323,7 +1323,7 @@ static Lay make_lay(const KernelArgs &ka)
     L.off_X = 0;
     int o = al(gimg > main_x ? gimg : main_x);
     L.off_Y = o;
-    int y_build = 4 * 32 + 32;  // ex (4 x 32), hp
+    int y_build = 4 * 32 + 32;  // (spare 4 x 32), hp
     L.off_stage = L.off_Y + y_build;
     L.nA = (ka.A.step_stride ? ka.N : 1) * ka.nx * ka.nx;
     L.nB = (ka.B.step_stride ? ka.N : 1) * ka.nx * ka.nu;
