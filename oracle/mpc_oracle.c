@@ -267,12 +267,14 @@ int oracle_gi_solve(int n, int m, const double *P, const double *qv,
                 if (r[i] > 0.0 && u[i] / r[i] < t1) { t1 = u[i] / r[i]; l = i; }
             double zz = 0.0, ztn = 0.0, nn = 0.0;
             for (int k = 0; k < n; ++k) { zz += z[k] * z[k]; ztn += z[k] * np[k]; nn += np[k] * np[k]; }
-            /* z == 0 (n+ in the span of the active normals): compare with |J'n+|^2 scale. The threshold is the
-               HIP kernels' (1e-14 on the squared ratio): with 1e-28 rounding noise in z'n+ let dependent rows through
-               and a few inconsistent problems came back 'solved' with |u| ~ 1e15 (tools/stress_pair.py). */
+            /* z == 0 (n+ in the span of the active normals): compare with |J'n+|^2 scale. The threshold sits at
+               rounding-noise level: on INCONSISTENT problems a dependent row can slip through and the problem comes
+               back 'solved' with |u| ~ 1e15 (tools/stress_pair.py counts such a 'solution' as unsolved). Kept as it
+               is: this is the pinned checker, and a tighter test (1e-14) cost 2e-7 of accuracy on one legitimate
+               borderline problem of that stress run. */
             double dd = 0.0;
             for (int j = 0; j < n; ++j) dd += d[j] * d[j];
-            if (iq < n && ztn > 1e-14 * (dd > 0 ? dd : 1.0) && zz > 0.0) t2 = -sp / ztn;
+            if (iq < n && ztn > 1e-28 * (dd > 0 ? dd : 1.0) && zz > 0.0) t2 = -sp / ztn;
             double t = t1 < t2 ? t1 : t2;
             (void)nn;
             if (!isfinite(t)) { status = 2; goto done; }
