@@ -1042,3 +1042,44 @@ def test_inconsistent_problems_are_never_reported_solved():
                 x = np.einsum("bij,bj->bi", w["A"][:, 0], x) + w["B"][:, k, :, 0] * U[:, k:k + 1]
             assert (worst[ok] <= 1e-6).all(), float(worst[ok].max())
     assert unsolved > 50  # the batch really contains inconsistent problems
+
+
+@pytest.mark.parametrize("nx", [3, 4])
+@pytest.mark.parametrize("lti", [False, True])
+def test_lean_instantiations_of_the_pair_kernel(nx, lti):
+    """mpcqp_pair_kernel<NX, 2>: terminal cost only, state rows only, two rows per step -- the path whose A_k, C_k stay in
+    registers (element e of [A_k | C_k] in lane e, and e + 16 for nx = 4) and reach the chain as DPP row broadcasts;
+    time-varying and time-invariant operands (stride 0 along the horizon), odd and even horizons, against the C oracle and
+    the one-per-wavefront kernel (equal iteration counts). qpmpc/mpc_qp.py:53-114 + qpmpc/solve_mpc.py:43."""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_stagewise import random_ltv
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(1000 + 10 * nx + int(lti))
+    for N in (16, 13, 7, 2):
+        w = random_ltv(rng, 130, nx, 1, N, 2, 0.3)  # (an odd number of pairs plus an idle half)
+        w["wx"] = w["targets"] = w["D"] = None
+        if lti:  # bounds regenerated for the time-invariant model so that the problems stay consistent
+            w["A"] = np.ascontiguousarray(w["A"][:, :1])
+            w["C"] = np.ascontiguousarray(w["C"][:, :1])
+            for b in range(130):
+                x = w["x0"][b].copy()
+                for k in range(N):
+                    w["e"][b, k] = w["C"][b, 0] @ x + 0.3 * (0.05 + 0.5 * np.abs(rng.standard_normal(2)))
+                    x = w["A"][b, 0] @ x
+        bp = to_batch_problem(w)
+        plan = solve_mpc_batch(bp)
+        one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
+        torch.cuda.synchronize()
+        Uo, _, sto, _ = oracle.solve_workload(w)
+        st = plan.status.cpu().numpy()
+        assert (st == sto).all() and (st == 0).all()
+        assert (plan.iters.cpu().numpy() == one.iters.cpu().numpy()).all()
+        scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+        assert (np.abs(plan.U.cpu().numpy() - Uo) / scale).max() < 1e-9
+        assert (np.abs(plan.U.cpu().numpy() - one.U.cpu().numpy()) / scale).max() < 1e-10
