@@ -250,3 +250,23 @@ def test_wip_model_constants_match_reference():
     ts = pend.target_states(np.array([0.05, -0.03, 0.1, 0.08]), 0.5)
     zm = np.load(os.path.join(GOLDEN, "wip_n12_moving.npz"))
     assert np.array_equal(ts[:-4], zm["target_states"]) and np.array_equal(ts[-4:], zm["goal_state"])
+
+
+def test_hand_written_dpp_instructions_keep_their_wait_states():
+    """The v_fmac_f64_dpp of mpcqp_pair.hip are inline asm: the compiler cannot insert the two wait states a DPP read needs
+    after a VALU write of the same register, the source does (dpp_ready). tools/check_dpp_hazards.py verifies it on the
+    gfx950 assembly of every instantiation (hipcc cross-compiles without a GPU), and flags a made-up violation."""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import check_dpp_hazards as chk
+
+    bad, ndpp, _ = chk.check("f:\n\tv_add_f64 v[0:1], v[2:3], v[4:5]\n\tv_fmac_f64_dpp v[6:7], v[0:1], v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
+    assert ndpp == 1 and len(bad) == 1
+    bad, _, _ = chk.check("f:\n\tv_add_f64 v[0:1], v[2:3], v[4:5]\n\ts_nop 1\n\tv_fmac_f64_dpp v[6:7], v[0:1], v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
+    assert not bad
+    src = os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", "mpcqp_pair.hip")
+    bad, ndpp, nasm = chk.check(chk.device_asm(src))
+    assert nasm > 1000 and not bad, bad[:3]
