@@ -261,6 +261,18 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model,
                             const MpcqpSolveOpts *opts, void *U, void *lam,
                             int32_t *status, int32_t *iters, void *stream);
 
+/* As mpcqp_solve_model_batch, with the inequality vectors e given PER PROBLEM ([batch, N|1, mk] through `e`'s strides)
+ * instead of taken from the model: the matrices are shared and constant, the bounds move -- the per-step ZMP bounds
+ * that examples/lipm_walking_controller.py:179-213 (update_goal_and_constraints) rewrites every control period while
+ * A, B, C stay, i.e. update_constraint_vector (mpc_qp.py:151-163) with a new e. h = e - (C Phi) x0 uses the model's map.
+ * e == NULL or e->ptr == NULL is mpcqp_solve_model_batch. Served by the pair kernel (n <= 16, m <= 32, float64);
+ * MPCQP_EUNSUPPORTED elsewhere. */
+int mpcqp_solve_model_bounds_batch(const MpcqpDims *dims, const void *model, const MpcqpOperand *e,
+                                   const MpcqpOperand *x0, const MpcqpOperand *goal,
+                                   const MpcqpOperand *targets, int64_t batch,
+                                   const MpcqpSolveOpts *opts, void *U, void *lam,
+                                   int32_t *status, int32_t *iters, void *stream);
+
 /* Replaces MPCProblem.integrate (mpc_problem.py:316-335) as used by Plan.states
  * (plan.py:81-109) for a batch: X[batch*(N+1)*nx], X_0 = x0,
  * X_{k+1} = A_k X_k + B_k U_k. U is packed [batch*N*nu]. */

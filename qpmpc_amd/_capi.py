@@ -38,6 +38,7 @@ EXPORTS = (
     "mpcqp_model_bytes",
     "mpcqp_factor_model",
     "mpcqp_solve_model_batch",
+    "mpcqp_solve_model_bounds_batch",
     "mpcqp_accumulate_stats",
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
@@ -129,6 +130,10 @@ def load():
     lib.mpcqp_solve_model_batch.restype = C.c_int
     lib.mpcqp_solve_model_batch.argtypes = [C.POINTER(Dims), vp, C.POINTER(Operand), C.POINTER(Operand),
                                             C.POINTER(Operand), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp]
+    lib.mpcqp_solve_model_bounds_batch.restype = C.c_int
+    lib.mpcqp_solve_model_bounds_batch.argtypes = [C.POINTER(Dims), vp, C.POINTER(Operand), C.POINTER(Operand),
+                                                   C.POINTER(Operand), C.POINTER(Operand), i64, C.POINTER(SolveOpts),
+                                                   vp, vp, vp, vp, vp]
     lib.mpcqp_accumulate_stats.restype = C.c_int
     lib.mpcqp_accumulate_stats.argtypes = [vp, vp, i64, vp, vp]
     lib.mpcqp_wip_advance_batch.restype = C.c_int

@@ -542,10 +542,14 @@ class SharedModel:
         torch = _torch()
         lib = _capi.load()
         _require_on_gpu(template.initial_state)
-        for name in ("A", "B", "C", "D", "e"):
+        for name in ("A", "B", "C", "D"):
             op = getattr(template, name)
             if op is not None and op.shape[0] != 1:
                 raise ProblemDefinitionError(f"SharedModel: operand {name} differs across the batch")
+        # e may differ per problem (bounds that move while the matrices stay, e.g. the ZMP bounds of the LIPM walking
+        # controller): the model is then factored with the first problem's e and every solve passes its own
+        # (mpcqp_solve_model_bounds_batch)
+        self.per_problem_bounds = template.e is not None and template.e.shape[0] != 1
         self.template = template
         nx, N = template.state_dim, template.nb_timesteps
         n, m = template.nb_variables, template.nb_constraints
@@ -558,7 +562,8 @@ class SharedModel:
         goal[1 + nx: 1 + 2 * nx] = torch.eye(nx, dtype=dt, device=dev)
         tgt[1 + 2 * nx:] = torch.eye(N * nx, dtype=dt, device=dev)
         pseudo = BatchMPCProblem(
-            template.A, template.B, template.C, template.D, template.e, N, template.terminal_cost_weight,
+            template.A, template.B, template.C, template.D, template.e[:1] if self.per_problem_bounds else template.e, N,
+            template.terminal_cost_weight,
             template.stage_state_cost_weight, template.stage_input_cost_weight, x0, goal_state=goal,
             target_states=tgt, dtype=dt, device=dev)
         self.dims = pseudo.dims()  # cost flags from the weights (goal and targets are defined here)
@@ -572,10 +577,10 @@ class SharedModel:
         _capi.check(rc, "mpcqp_factor_model")
         self._keep = qp  # inputs of the asynchronous factorisation
 
-    def problem_for(self, x0, goal=None, targets=None) -> BatchMPCProblem:
-        """A batch sharing this model's operands with the given states."""
+    def problem_for(self, x0, goal=None, targets=None, e=None) -> BatchMPCProblem:
+        """A batch sharing this model's operands with the given states (and, optionally, its own bounds e)."""
         t = self.template
-        return BatchMPCProblem(t.A, t.B, t.C, t.D, t.e, t.nb_timesteps, t.terminal_cost_weight,
+        return BatchMPCProblem(t.A, t.B, t.C, t.D, t.e if e is None else e, t.nb_timesteps, t.terminal_cost_weight,
                                t.stage_state_cost_weight, t.stage_input_cost_weight, x0, goal_state=goal,
                                target_states=targets, dtype=t.dtype, device=t.device)
 
@@ -615,16 +620,21 @@ class PreparedModelSolve:
 
     def rebind(self) -> None:
         p = self.problem
-        self._ops = (p._operand(p.initial_state), p._operand(p.goal_state), p._operand(p.target_states))
-        self._args = (
-            C.byref(self.model.dims), self.model.model.data_ptr(), C.byref(self._ops[0]), C.byref(self._ops[1]),
-            C.byref(self._ops[2]), p.batch_size, C.byref(self._opts), self.U.data_ptr(),
-            None if self.lam is None else self.lam.data_ptr(), self.status.data_ptr(), self.iters.data_ptr(),
-        )
+        self._own_e = p.e is not None and p.e.shape[0] != 1  # bounds per problem
+        self._ops = (p._operand(p.initial_state), p._operand(p.goal_state), p._operand(p.target_states),
+                     p._operand(p.e) if self._own_e else None)
+        tail = (C.byref(self._ops[0]), C.byref(self._ops[1]), C.byref(self._ops[2]), p.batch_size, C.byref(self._opts),
+                self.U.data_ptr(), None if self.lam is None else self.lam.data_ptr(), self.status.data_ptr(),
+                self.iters.data_ptr())
+        head = (C.byref(self.model.dims), self.model.model.data_ptr())
+        self._args = head + ((C.byref(self._ops[3]),) if self._own_e else ()) + tail
 
     def launch(self, stream=None) -> None:
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
-        rc = self._lib.mpcqp_solve_model_batch(*self._args, sp)
+        if self._own_e:
+            rc = self._lib.mpcqp_solve_model_bounds_batch(*self._args, sp)
+        else:
+            rc = self._lib.mpcqp_solve_model_batch(*self._args, sp)
         if rc != 0:
             _capi.check(rc, "mpcqp_solve_model_batch")
 

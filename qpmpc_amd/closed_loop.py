@@ -175,7 +175,7 @@ class LIPMWalkingLoop:
                  state=None, com_height: float = 0.84, dsp_duration: float = 0.1, ssp_duration: float = 0.7,
                  gravity: float = 9.81, init_support_foot_pos: float = 0.09, nb_timesteps: int = 16,
                  sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None,
-                 warm_start: bool = False):
+                 warm_start: bool = False, shared_model: bool = False):
         import torch
 
         _capi.require_gpu()
@@ -214,8 +214,20 @@ class LIPMWalkingLoop:
         # warm_start: every period begins from the previous period's active set and operator (the model
         # A, B, C is time-invariant here, only the bounds e, x0 and the goal move; MpcqpSolveOpts.warm_state)
         self.warm_state = WarmState(self.problem) if warm_start else None
-        self.solver = (PreparedSolve(self.problem, max_iter=max_iter, warm_state=self.warm_state) if warm_start
-                       else PreparedSolve(self.problem, max_iter=max_iter))
+        self.model = None
+        if shared_model:
+            # The matrices never change here, only e / x0 / goal do: factor them ONCE (the reference's own usage of
+            # MPCQP, mpc_qp.py:129-163: build, then update_cost_vector / update_constraint_vector per period) and give
+            # every period's solve its bounds (mpcqp_solve_model_bounds_batch). Same plans as the rebuilding loop.
+            from .batch import SharedModel
+
+            if warm_start:
+                raise ValueError("LIPMWalkingLoop: warm_start and shared_model are exclusive")
+            self.model = SharedModel(self.problem)
+            self.solver = self.model.prepare(self.problem, max_iter=max_iter)
+        else:
+            self.solver = (PreparedSolve(self.problem, max_iter=max_iter, warm_state=self.warm_state) if warm_start
+                           else PreparedSolve(self.problem, max_iter=max_iter))
         self._k = torch.arange(N, device=dev)
         self._problem_written = False  # e / goal / x0 of the CURRENT phase are in the problem buffers
         self.mpc_steps = 0

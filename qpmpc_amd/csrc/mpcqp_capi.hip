@@ -569,6 +569,15 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const Mpcq
                             const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status, int32_t *iters,
                             void *stream)
 {
+    return mpcqp_solve_model_bounds_batch(dims, model, nullptr, x0, goal, targets, batch, opts, U, lam, status, iters,
+                                          stream);
+}
+
+int mpcqp_solve_model_bounds_batch(const MpcqpDims *dims, const void *model, const MpcqpOperand *e,
+                                   const MpcqpOperand *x0, const MpcqpOperand *goal, const MpcqpOperand *targets,
+                                   int64_t batch, const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status,
+                                   int32_t *iters, void *stream)
+{
     int rc = check_dims(dims);
     if (rc) return rc;
     if (!model || !x0 || !x0->ptr || !U || batch < 0) return MPCQP_EINVAL;
@@ -588,6 +597,13 @@ int mpcqp_solve_model_batch(const MpcqpDims *dims, const void *model, const Mpcq
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    const bool own_e = e && e->ptr;  // per-problem bounds: the pair kernel's model mode only
+    if (own_e) {
+        if (ka.m < 1) return MPCQP_EINVAL;
+        ka.e = *e;
+        if (!pair_eligible(ka, MODE_MODEL, dims->dtype)) return MPCQP_EUNSUPPORTED;
+        return launch_pair_model(ka, batch, st);
+    }
     if (!force_lds(ka.opt_flags) && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE_MODEL, dims->dtype))
         return launch_pair_model(ka, batch, st);
     if (!force_lds(ka.opt_flags) && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);

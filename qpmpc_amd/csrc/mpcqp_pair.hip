@@ -591,7 +591,8 @@ __global__ void __launch_bounds__(64, 2)
         }
         T hh = INF;
         if (isc) {
-            hh = model[ml.off_e + hl];
+            // the bounds come with the model, or per problem (mpcqp_solve_model_bounds_batch: matrices shared, e moving)
+            hh = ge ? ge[prob * ka.e.batch_stride + (hl / ka.mk) * ka.e.step_stride + (hl % ka.mk)] : model[ml.off_e + hl];
             for (int c = 0; c < nxr; ++c) hh -= model[ml.off_Hx + (size_t)hl * nxr + c] * x0[c];
         }
         hv[hl] = hh;
@@ -1374,7 +1375,7 @@ int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
     const size_t bytes = (size_t)L.per * 2 * sizeof(double);
     const unsigned grid = (unsigned)((batch + 1) / 2);
     hipLaunchKernelGGL((mpcqp_pair_kernel<3, 0, true>), dim3(grid), dim3(64), bytes, st, (const double *)ka.model,
-                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)ka.e.ptr,
                        (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
                        (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
     return (int)hipGetLastError();

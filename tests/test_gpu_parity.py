@@ -1083,3 +1083,45 @@ def test_lean_instantiations_of_the_pair_kernel(nx, lti):
         scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
         assert (np.abs(plan.U.cpu().numpy() - Uo) / scale).max() < 1e-9
         assert (np.abs(plan.U.cpu().numpy() - one.U.cpu().numpy()) / scale).max() < 1e-10
+
+
+def test_shared_model_with_per_problem_bounds_and_lipm_loop():
+    """mpcqp_solve_model_bounds_batch: matrices factored once, inequality vectors per problem (what
+    update_constraint_vector does with a new e, mpc_qp.py:151-163; the per-step ZMP bounds of
+    examples/lipm_walking_controller.py:179-213). Same plans as the fused build+solve of every problem, and the LIPM
+    walking loop on the shared model walks the same trajectories as the rebuilding loop."""
+    from qpmpc_amd import BatchMPCProblem, SharedModel, solve_mpc_batch
+    from qpmpc_amd.closed_loop import LIPMWalkingLoop
+
+    rng = np.random.default_rng(5)
+    B, N, T = 333, 16, 0.1
+    A = np.array([[1.0, T, T**2 / 2.0], [0.0, 1.0, T], [0.0, 0.0, 1.0]])
+    Bm = np.array([T**3 / 6.0, T**2 / 2.0, T]).reshape((3, 1))
+    Cm = np.array([[1.0, 0.0, -0.0856], [-1.0, 0.0, 0.0856]])
+    centre = rng.uniform(-0.2, 0.2, (B, N, 1))
+    e = np.concatenate([centre + rng.uniform(0.03, 0.2, (B, N, 1)), -centre + rng.uniform(0.03, 0.2, (B, N, 1))], axis=2)
+    x0 = np.concatenate([rng.uniform(-0.05, 0.05, (B, 1)), rng.uniform(-0.1, 0.1, (B, 1)), rng.uniform(-0.2, 0.2, (B, 1))], axis=1)
+    goal = np.concatenate([rng.uniform(-0.3, 0.3, (B, 1)), np.zeros((B, 2))], axis=1)
+    prob = BatchMPCProblem(A, Bm, Cm, None, e, N, 1.0, None, 1e-3, x0, goal_state=goal)
+    fused = solve_mpc_batch(prob)
+    model = SharedModel(prob)
+    assert model.per_problem_bounds
+    run = model.prepare(prob)
+    run.launch()
+    torch.cuda.synchronize()
+    st = fused.status.cpu().numpy()
+    assert (run.status.cpu().numpy() == st).all()
+    ok = st == 0
+    assert ok.sum() > B // 2
+    Uf, Um = fused.U.cpu().numpy()[ok], run.U.cpu().numpy()[ok]
+    assert (np.abs(Uf - Um) / np.maximum(1.0, np.abs(Uf).max(axis=1, keepdims=True))).max() < 1e-8
+    # the walking loop
+    W = 200
+    kw = dict(strides=np.stack([-rng.uniform(0.12, 0.2, W), rng.uniform(0.12, 0.2, W)], axis=1),
+              foot_size=rng.uniform(0.05, 0.08, W), index=rng.integers(0, 8, W))
+    a, b = LIPMWalkingLoop(W, **kw), LIPMWalkingLoop(W, shared_model=True, **kw)
+    a.step(40)
+    b.step(40)
+    torch.cuda.synchronize()
+    assert a.stats()["failed"] == 0 and b.stats()["failed"] == 0
+    assert (a.states - b.states).abs().max().item() < 1e-9
