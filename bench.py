@@ -495,6 +495,11 @@ def other_workloads():
     loop_r = WIPClosedLoop(x0r, reuse_factor=True)
     loop_r.step(2)  # the first period keeps the factor
     out["config3_closed_loop_factor_reused_resolves"] = rate(loop_r.step, 1024, 50)
+    # config 2 in shared-LTI mode (reported separately and labelled): stride-0 operands, then the model
+    # factored once (P, Cholesky, G L^-T hoisted out of the batch)
+    bp2 = W.to_batch_problem(W.triple_integrator_batch(4096, heterogeneous=False))
+    out["config2_shared_lti_operands_fused_batch4096"] = rate(PreparedSolve(bp2).launch, 4096, 200)
+    out["config2_shared_lti_model_factored_once_batch4096"] = rate(SharedModel(bp2).prepare(bp2).launch, 4096, 200)
     w = W.humanoid_batch(65536)
     bp = W.to_batch_problem(w)
     out["config4_humanoid_sweep_65536_fused"] = rate(PreparedSolve(bp).launch, 65536, 10)
@@ -504,6 +509,8 @@ def other_workloads():
         PreparedSolve(W.to_batch_problem(w, dtype=torch.float32)).launch, 1024, 5)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
+    walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)
+    out["lipm_walking_loops_4096_model_factored_once"] = rate(walkers_m.step, 4096, 100)
     return {k: float(v) for k, v in out.items()} | {"unit": "problems/s (builds+solves/s for the loops)"}
 
 
