@@ -15,10 +15,15 @@ timed (configs[1..4]; configs[0] is the reference's single CPU problem):
   4  humanoid one-step N=16, 65,536-state sweep, float64, STRONG-sharded over the N GPUs
      (8192 per GPU at N=8); the all_gather of U/status is timed separately (``all_gather_ms``).
   5  synthetic LTV nx=12 nu=4 N=64 (n=256, m=1024), float32, batch 8192 STRONG-sharded
-     (1024 per GPU at N=8); MFMA Gram; ``roofline.bound`` = mfma.
+     (1024 per GPU at N=8); uncondensed stage-wise active-set kernels (no Gram is formed);
+     ``roofline.bound`` = hbm on the problem's inputs + outputs.
 
-N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; problems never interact, so
-the data path has no collective. Rank 0 prints ONE JSON line.
+N > 1 runs one rank per GPU over RCCL: either launched by ``torch.distributed.run`` (the driver's way) or,
+when started as a plain ``python bench.py --gpus N``, by re-executing itself through it. Problems never
+interact, so the data path has no collective. Rank 0 prints ONE JSON line.
+
+Without a GPU (build container) the same command runs the RANK LOGIC ONLY over gloo with a runner that
+computes nothing: the record then carries ``"value": null`` and ``"dry_run"`` -- it is not a measurement.
 """
 from __future__ import annotations
 
@@ -135,6 +140,23 @@ class _Runner:
     @property
     def iters(self):
         return self.solver.iters
+
+
+class _DryRunner:
+    """No-GPU stand-in for ``_Runner`` (``main`` picks it when torch sees no device): computes NOTHING -- zero
+    plans, status 0 -- so that argument handling, sharding, reductions, the gather and the JSON record of an
+    N-rank launch can be exercised over gloo. ``main`` nulls ``value`` of such a run."""
+
+    def __init__(self, config, w, device="cpu"):
+        import torch
+
+        b, n = int(w["x0"].shape[0]), int(w["N"]) * int(w["B"].shape[-1])
+        self.U = torch.zeros((b, n), dtype=torch.float64)
+        self.status = torch.zeros((b,), dtype=torch.int32)
+        self.iters = torch.zeros((b,), dtype=torch.int32)
+
+    def launch(self, stream=None):
+        pass
 
 
 class _Clock:
@@ -329,17 +351,22 @@ def _dims_of(w):
 
 
 def _traffic_from_profiles(config: int):
-    """HBM bytes per launch from rocprofv3 PMC passes stored under profiles/ (NOT measured by this run)."""
-    for name in (f"r02_pmc_traffic_config{config}.json", "r02_pmc_traffic.json" if config == 2 else None):
-        if name is None:
-            continue
+    """(HBM bytes per launch, source) from the rocprofv3 PMC passes stored under profiles/ for this round's kernels
+    (separate --pmc runs of this same command: tools/collect_profiles.sh; FETCH_SIZE doubled as the microarchitecture
+    guide prescribes for gfx950, WRITE_SIZE as reported). Newest round first; (None, None) when there is none."""
+    names = [f"r03_pmc_traffic_config{config}.json", f"r02_pmc_traffic_config{config}.json"]
+    if config == 2:
+        names += ["r03_pmc_traffic.json", "r02_pmc_traffic.json"]
+    for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
                 d = json.load(f)
-            return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "source": "profiles/" + name,
-                    "note": "stored rocprofv3 FETCH_SIZE/WRITE_SIZE figure (separate --pmc passes), not an observation of this run"}
-    return None
+            if d.get("hbm_bytes_per_launch") is not None:
+                return float(d["hbm_bytes_per_launch"]), ("profiles/" + name + ": rocprofv3 --pmc FETCH_SIZE (x2, gfx950 "
+                                                          "correction) + WRITE_SIZE per launch of the dominant kernel, collected "
+                                                          "in separate counter passes of this command (not by this run)")
+    return None, None
 
 
 def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
@@ -355,7 +382,10 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
     gbs = bytes_pp * local_per_step / kernel_s / 1e9
     tfs = flops_pp * local_per_step / kernel_s / 1e12
     common = {"kernel_ms": kernel_ms, "algorithmic_bytes_per_problem": bytes_pp, "algorithmic_flops_per_problem": flops_pp,
-              "units_per_launch": local_per_step, "traffic": None, "traffic_from_profiles": _traffic_from_profiles(args.config)}
+              "units_per_launch": local_per_step}
+    common["traffic"], common["traffic_source"] = _traffic_from_profiles(args.config)
+    if args.batch:  # the stored counters belong to the configured batch
+        common["traffic"], common["traffic_source"] = None, None
     if args.config in (2, 4):
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "kernel": "mpcqp_pair_kernel (fused build+solve, two problems per wavefront)",
@@ -514,17 +544,43 @@ def other_workloads():
     return {k: float(v) for k, v in out.items()} | {"unit": "problems/s (builds+solves/s for the loops)"}
 
 
-def main(argv=None) -> None:
-    args = parse_args(argv)
-    import torch
+def _free_port() -> int:
+    import socket
 
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _respawn(argv, n: int) -> int:
+    """``python bench.py --gpus N`` started outside torch.distributed.run: launch the N ranks ourselves
+    (same command line the driver uses) and hand its exit code back; rank 0 of the child prints the line."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py --gpus N>1 must be launched with torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _respawn(argv, args.gpus)
+    import torch
+
+    have_gpu = torch.cuda.is_available()
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
+    elif rank == 0:
+        print("bench.py: no GPU visible -- RANK-LOGIC DRY RUN over gloo, nothing is computed, value = null",
+              file=sys.stderr)
     dist = None
     # (a single rank launched through torch.distributed.run also goes through RCCL: the only way to execute the
     # collectives' code path on a one-GPU box)
@@ -532,13 +588,25 @@ def main(argv=None) -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    out = run_bench(args, rank, world, dist)
+        if have_gpu:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    if have_gpu:
+        out = run_bench(args, rank, world, dist)
+    else:
+        args.spinup = 0.0
+        out = run_bench(args, rank, world, dist, make_runner=_DryRunner, device="cpu")
+        if out is not None:
+            out["dry_run"] = "no GPU visible: rank logic over gloo with a runner that computes nothing; NOT a measurement"
+            out["value"] = out["ms_per_step"] = None
+            out["solved_frac"] = out["mean_iters"] = None
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -143,6 +143,62 @@ def test_bench_rank_logic_two_ranks_gloo(tmp_path, config, batch):
         assert abs(one["solved_frac"] - two["solved_frac"]) < 1e-12 and abs(one["mean_iters"] - two["mean_iters"]) < 1e-12
 
 
+@pytest.mark.parametrize("config,batch", [(2, 16), (5, 6)])
+def test_bench_main_spawns_its_own_ranks(config, batch):
+    """``python bench.py --gpus 2`` started WITHOUT torch.distributed.run (how a user, or a driver that only knows
+    the N=1 command, starts it) must launch its two ranks itself and print ONE JSON line from rank 0. On this
+    GPU-less box that is the rank-logic dry run over gloo: ``value`` is null and the record says so."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", str(config), "--steps", "2",
+           "--warmup", "1", "--batch", str(batch)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
+    if torch.cuda.is_available():
+        assert rec["value"] > 0
+    else:
+        assert rec["value"] is None and "dry_run" in rec
+    if config == 2:
+        assert rec["scaling"] == "weak" and rec["config"]["problems_per_step"] == 2 * batch
+    else:
+        assert rec["scaling"] == "strong" and rec["config"]["problems_per_step"] == batch and "all_gather_ms" in rec
+
+
+def test_bench_main_in_process_goes_through_respawn(monkeypatch):
+    """bench.main(["--gpus", "2", ...]) with no WORLD_SIZE in the environment re-executes through
+    torch.distributed.run (the command line is the driver's) instead of exiting with a usage error."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import subprocess
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd
+        return 0
+
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.main(["--gpus", "2", "--config", "2", "--steps", "2", "--warmup", "1"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--config", "2", "--steps", "2", "--warmup", "1"]
+
+
 def test_bench_config5_slices_are_one_global_problem_set():
     a = W.synthetic_ltv_batch_slice(0, 4, N=8)
     b = W.synthetic_ltv_batch_slice(2, 4, N=8)
