@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 5
+#define MPCQP_ABI_VERSION 6
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -150,6 +150,10 @@ typedef struct MpcqpSolveOpts {
     /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (16 for the small-problem
      * kernels, 32 for the mid-size / large ones) that receives shader-clock stamps at phase boundaries. */
     void *probe;
+    /* Size in bytes of the buffer behind warm_state (ABI 6): a launch over `batch` problems needs
+     * batch * mpcqp_warm_state_bytes(); a smaller buffer (a state allocated for another batch or other
+     * dimensions) is refused with MPCQP_EWORKSPACE before anything is launched. Ignored when warm_state is NULL. */
+    size_t warm_state_bytes;
 } MpcqpSolveOpts;
 
 /* ABI version of the loaded library (== MPCQP_ABI_VERSION of its build). */

@@ -14,7 +14,7 @@ F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
 EUNSUPPORTED = -6
-ABI_VERSION = 5
+ABI_VERSION = 6
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR = 64, 128
 
@@ -68,7 +68,7 @@ class SolveOpts(C.Structure):
     _fields_ = [
         ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
         ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("reserved", C.c_int32),
-        ("probe", C.c_void_p),
+        ("probe", C.c_void_p), ("warm_state_bytes", C.c_size_t),
     ]
 
 

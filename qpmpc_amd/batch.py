@@ -343,6 +343,7 @@ def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_state=None, warm_st
     if warm_state is not None:
         buf = warm_state.buffer if isinstance(warm_state, WarmState) else warm_state
         o.warm_state, o.warm_start = buf.data_ptr(), 1 if warm_start else 0
+        o.warm_state_bytes = int(buf.numel() * buf.element_size())  # the C side refuses a buffer smaller than the launch needs
     if probe is not None:
         o.probe = probe.data_ptr()
     return o
@@ -366,14 +367,49 @@ class WarmState:
                 f"(got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype})")
         self.bytes_per_problem = int(nbytes.value)
         self.batch_size = problem.batch_size
+        self.device = problem.device
+        # the operator T (16 x 16 doubles) first, then the slots' constraint ids (int32): everything after T
+        self._ids_at = 16 * 16 * 8
+        assert self._ids_at < self.bytes_per_problem
         self.buffer = torch.zeros((problem.batch_size, self.bytes_per_problem), dtype=torch.uint8, device=problem.device)
-        self.buffer[:, 16 * 16 * 8:] = 0xFF  # constraint ids -1: empty set
+        self.buffer[:, self._ids_at:] = 0xFF  # constraint ids -1: empty set
+
+    def check(self, problem: "BatchMPCProblem") -> None:
+        """Raise ``BackendError`` unless this state was allocated for ``problem``'s batch, dimensions and device
+        (the kernel indexes it by problem: a smaller buffer would be read and written out of bounds)."""
+        lib = _capi.load()
+        dims, nbytes = problem.dims(), C.c_size_t(0)
+        _capi.check(lib.mpcqp_warm_state_bytes(C.byref(dims), C.byref(nbytes)), "mpcqp_warm_state_bytes")
+        if nbytes.value != self.bytes_per_problem or problem.batch_size != self.batch_size:
+            raise BackendError(
+                f"WarmState holds {self.batch_size} problems of {self.bytes_per_problem} bytes; this launch needs "
+                f"{problem.batch_size} of {nbytes.value}: allocate WarmState(problem) for the batch it is used with")
+        if problem.device != self.device:
+            raise BackendError(f"WarmState lives on {self.device}, the problem on {problem.device}")
 
     @property
     def active_set(self):
         """int32 [B, 16]: constraint row held by each slot after the last solve, -1 = empty."""
         torch = _torch()
-        return self.buffer[:, 16 * 16 * 8:].contiguous().view(torch.int32)
+        return self.buffer[:, self._ids_at:].contiguous().view(torch.int32)
+
+
+def _check_warm(problem: "BatchMPCProblem", opt_kw) -> None:
+    """Host-side check of ``warm_state=`` against the launch (batch, dimensions, device); raw uint8 tensors are
+    checked for size and device (the C ABI checks the size again: ``MpcqpSolveOpts.warm_state_bytes``)."""
+    ws = opt_kw.get("warm_state")
+    if ws is None:
+        return
+    if isinstance(ws, WarmState):
+        ws.check(problem)
+        return
+    lib = _capi.load()
+    dims, nbytes = problem.dims(), C.c_size_t(0)
+    _capi.check(lib.mpcqp_warm_state_bytes(C.byref(dims), C.byref(nbytes)), "mpcqp_warm_state_bytes")
+    need = nbytes.value * problem.batch_size
+    if ws.device != problem.device or ws.numel() * ws.element_size() < need or nbytes.value == 0:
+        raise BackendError(f"warm_state tensor: {ws.numel() * ws.element_size()} bytes on {ws.device}; this launch needs "
+                           f"{need} bytes on {problem.device} (mpcqp_warm_state_bytes per problem: {nbytes.value})")
 
 
 class BatchPlan:
@@ -435,6 +471,7 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+    _check_warm(problem, opt_kw)
     dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol, **opt_kw)
     if formulation == "stagewise":
         nbytes = C.c_size_t(0)
@@ -486,6 +523,7 @@ class PreparedSolve:
         self.lam = torch.empty((Bn, m), dtype=problem.dtype, device=problem.device) if return_multipliers else None
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
+        _check_warm(problem, opt_kw)
         self._opts = _opts(max_iter, feas_tol, **opt_kw)
         if self._stagewise:
             dims, nbytes = problem.dims(), C.c_size_t(0)

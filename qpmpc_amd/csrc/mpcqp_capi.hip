@@ -78,6 +78,7 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
     ka.probe = o->probe;
     ka.warm_state = o->warm_state;
     ka.warm_start = o->warm_state ? o->warm_start : 0;
+    ka.warm_state_bytes = o->warm_state ? o->warm_state_bytes : 0;
     return 0;
 }
 
@@ -443,6 +444,8 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    // the state is indexed by problem: a buffer made for a smaller batch would be read and written out of bounds
+    if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * kPairWarmDoubles * sizeof(double)) return MPCQP_EWORKSPACE;
     if (use_stage_auto(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);
         const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;

@@ -33,6 +33,7 @@ struct KernelArgs {
     int opt_flags;                // MPCQP_OPT_*
     void *warm_state;             // per-problem active set + operator (read if warm_start, written at the end), or null
     int warm_start;
+    size_t warm_state_bytes;      // size of the buffer behind warm_state (checked on the host before the launch)
     void *probe;                  // developer probe: int64 stamps per problem, or null
     // closed-loop epilogue of the stage-wise kernel (mpcqp_wip_period_batch): after its solve every wavefront applies
     // the first input of its plan to the wheeled-inverted-pendulum plant and writes its loop's NEXT problem in place

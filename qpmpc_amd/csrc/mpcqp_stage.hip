@@ -202,6 +202,10 @@ __global__ void __launch_bounds__(64, 2)
     // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
     const bool reuse = ka.opt_flags & MPCQP_OPT_REUSE_FACTOR, keep = ka.opt_flags & MPCQP_OPT_KEEP_FACTOR;
+    // S_k = w_u I + B_k' P_{k+1} B_k are the Schur complements of the condensed Hessian in the order u_{N-1}, ..., u_0: P is
+    // positive definite iff every S_k is (mpc_problem.py:104-107 only guarantees w_u > 0; a negative state weight can
+    // still make P indefinite). A pivot that is not positive -> MPCQP_NOT_PD, like the condensed kernels' Cholesky.
+    bool notpd = false;
     if (!reuse) {
         const int r = (lane >> 2) & 3, c = lane & 3;
         const bool inr = r < NX, inc = c < NX, in = inr && inc;
@@ -289,9 +293,11 @@ __global__ void __launch_bounds__(64, 2)
             }
             double Si[NU * NU];
             if constexpr (NU == 1) {
+                notpd |= !(S[0] > 0.0);
                 Si[0] = frcp(S[0]);
             } else {
                 const double det = S[0] * S[3] - S[1] * S[2], id = frcp(det);
+                notpd |= !(S[0] > 0.0) | !(det > 0.0);
                 Si[0] = S[3] * id;
                 Si[1] = -S[1] * id;
                 Si[2] = -S[2] * id;
@@ -382,10 +388,14 @@ __global__ void __launch_bounds__(64, 2)
         for (int d = 0; d < RD - 1; ++d)
             if (k - d >= 0) step(d, k - d);
     }
+    notpd = __ballot(notpd) != 0ull;  // (the lanes sum S in different orders: a pivot at rounding level may differ in sign)
     wsync();
     if constexpr (SERIAL) {
-        // the factor image travels between LDS and the workspace as it is (coalesced, one round trip)
+        // the factor image travels between LDS and the workspace as it is (coalesced, one round trip); a factor that
+        // does not exist is marked by a NaN in its first S^-1 so that a launch reusing it reports MPCQP_NOT_PD as well
         double *img = ws + wl.Fimg;
+        if (!reuse && notpd && lane == 0) Fl[FSI] = __builtin_nan("");
+        if (!reuse && notpd) wsync();
         if (reuse) {
             // eight 16-byte requests per lane in flight (a load -> LDS store loop pays one round trip per turn)
             const D2 *src = (const D2 *)img;
@@ -400,6 +410,7 @@ __global__ void __launch_bounds__(64, 2)
                     if (i0 + 64 * u < n2) dst[i0 + 64 * u] = v[u];
             }
             wsync();
+            notpd = Fl[FSI] != Fl[FSI];
         } else if (keep) {
             for (int i = lane; i < N * FS; i += 64) img[i] = Fl[i];
         }
@@ -901,20 +912,24 @@ __global__ void __launch_bounds__(64, 2)
 #pragma unroll
     for (int i = 0; i < (NX > NU ? NX : NU); ++i) zero_row[i] = 0.0;
     tick(2);
-    if constexpr (serial)
-        backward_s(-1, nullptr, nullptr, true);
-    else
-        backward(-1, zero_row, zero_row, true);
+    if (!notpd) {
+        if constexpr (serial)
+            backward_s(-1, nullptr, nullptr, true);
+        else
+            backward(-1, zero_row, zero_row, true);
+    }
     wsync();
     tick(3);
-    if constexpr (serial)
-        forward_s(gx0, N, U0, X0);
-    else
-        forward(gx0, U0, X0);
+    if (!notpd) {
+        if constexpr (serial)
+            forward_s(gx0, N, U0, X0);
+        else
+            forward(gx0, U0, X0);
+    }
     wsync();
     tick(4);
     const double tol = ka.tol;
-    for (int k = k0; k < k1; ++k)
+    for (int k = k0; k < (notpd ? k0 : k1); ++k)
         for (int r = 0; r < mk; ++r) {
             const int64_t i = wq(k) * mk + r;
             const double ev = ge[k * sE + r];
@@ -936,7 +951,7 @@ __global__ void __launch_bounds__(64, 2)
     const int nvar = N * NU;
     double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
     bool fail = false;
-    for (int round = 0; round < 4 && !fail; ++round) {
+    for (int round = 0; round < 4 && !fail && !notpd; ++round) {
         for (;;) {
             // ---- selection: the violated row farthest from its hyperplane
             double best = INF;
@@ -1175,6 +1190,7 @@ __global__ void __launch_bounds__(64, 2)
     }
     tick(7);
     if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+    if (notpd) status = MPCQP_NOT_PD;
     const bool ok = status == MPCQP_SOLVED;
     if (!ok) {
         double *ou = (double *)ka.U + prob * (int64_t)nvar;

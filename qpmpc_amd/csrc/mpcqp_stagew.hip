@@ -40,9 +40,14 @@ constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA op
 constexpr int R = 4;    // right-hand sides per sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;
+    int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Hc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;  // (Hc unused)
     int maxq, mg;
 };
+
+// FUSE: the constraint matrices C, D do not change along the horizon and have at most 16 rows per step (a multiple of
+// four): h = G (x_k, u_k) of a forward sweep is then formed by the sweep itself, on the matrix cores, with [C | D] as a
+// constant operand held in registers -- no trajectory (Zs) is written and no pass over the m rows reads it back.
+inline bool fuse_ok(int mk, bool ginv) { return ginv && mk <= 16 && (mk & 3) == 0; }
 
 // nxc: nx rounded up to a multiple of 4 (the kernel's compile-time row length)
 inline int nxc_of(int nx) { return (nx + 3) & ~3; }
@@ -67,17 +72,21 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
     w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
     w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
-    w.Zs = take((int64_t)R * N * (nxc + 4));   // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
-    w.Vc = take((int64_t)R * N * 4);           // ... and its inputs alone (they move into a slot when the row is taken)
+    const bool fuse = fuse_ok(mk, ginv);
+    w.Zs = take(fuse ? 0 : (int64_t)R * N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
+    w.Vc = take(fuse ? 0 : (int64_t)R * N * 4);  // ... and its inputs alone (they move into a slot when the row is taken)
+    w.Hc = 0;
     w.mg = ginv ? mk : (int)m;
-    w.Gp = take((int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zp's rows, as four-vectors: Gp[j][row], j <= nxc / 4
+    w.Gp = take(fuse ? 0 : (int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zp's rows, as four-vectors: Gp[j][row], j <= nxc / 4
     w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
     w.thr = take(m);
-    w.rowslot = take((m * 4 + esz - 1) / esz);  // int32 per row
-    w.V = take((int64_t)(maxq + 1) * N * 4);    // slot maxq + 1: the candidate
-    w.H = take((int64_t)(maxq + 1) * m);
+    w.rowslot = take(fuse ? 0 : (m * 4 + esz - 1) / esz);  // int32 per row
+    // slots of V_a = P^-1 g_a' (inputs only) and h_a = G V_a: maxq active rows + the candidate; FUSE: + the R right-hand
+    // sides of a sweep pair, which are written straight into free slots
+    w.V = take((int64_t)(maxq + (fuse ? R : 1)) * N * 4);
+    w.H = take((int64_t)(maxq + (fuse ? R : 1)) * m);
     w.W = take((int64_t)maxq * maxq);
     o = (o + 127) & ~(int64_t)127;  // odd multiple of 512 B / 1 KB between problems (memory channels)
     if (((o >> 7) & 1) == 0) o += 128;
@@ -106,6 +115,13 @@ template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &idx
 __device__ __forceinline__ void wsync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+// hand-over through LDS inside ONE wavefront: its LDS operations execute in order, so nothing has to be waited for --
+// only the compiler must not move the accesses across this point
+__device__ __forceinline__ void lsync()
+{
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 template <typename T> struct Tol;
@@ -163,20 +179,26 @@ __device__ __forceinline__ double frcp(double x)
 // S = L D L' of a symmetric positive definite 4 x 4 (unit lower L): id[i] = 1 / d_i, l = (l10, l20, l30, l21, l31, l32)
 template <typename T> struct Ldl4 {
     T id[4], l[6];
-    __device__ __forceinline__ void factor(const T (&s)[10])  // s = (s00, s10, s11, s20, s21, s22, s30, s31, s32, s33)
+    // returns false when a pivot is not positive (or not a number): S, hence the condensed Hessian, is not positive definite
+    __device__ __forceinline__ bool factor(const T (&s)[10])  // s = (s00, s10, s11, s20, s21, s22, s30, s31, s32, s33)
     {
-        id[0] = frcp(s[0]);
+        const T d0 = s[0];
+        id[0] = frcp(d0);
         l[0] = s[1] * id[0];
         l[1] = s[3] * id[0];
         l[2] = s[6] * id[0];
-        id[1] = frcp(s[2] - l[0] * s[1]);
+        const T d1 = s[2] - l[0] * s[1];
+        id[1] = frcp(d1);
         const T t21 = s[4] - l[1] * s[1], t31 = s[7] - l[2] * s[1];
         l[3] = t21 * id[1];
         l[4] = t31 * id[1];
-        id[2] = frcp(s[5] - l[1] * s[3] - l[3] * t21);
+        const T d2 = s[5] - l[1] * s[3] - l[3] * t21;
+        id[2] = frcp(d2);
         const T t32 = s[8] - l[2] * s[3] - l[4] * t21;
         l[5] = t32 * id[2];
-        id[3] = frcp(s[9] - l[2] * s[6] - l[4] * t31 - l[5] * t32);
+        const T d3 = s[9] - l[2] * s[6] - l[4] * t31 - l[5] * t32;
+        id[3] = frcp(d3);
+        return (d0 > T(0)) & (d1 > T(0)) & (d2 > T(0)) & (d3 > T(0));
     }
     __device__ __forceinline__ void solve(T (&b)[4]) const  // b <- S^-1 b
     {
@@ -202,11 +224,12 @@ __device__ __forceinline__ double rl(double v, int j)
 
 using namespace stagew;
 
-template <typename T, int NXC>
+template <typename T, int NXC, bool FUSE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 2)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
+    using MV = typename Mfma<T>::V;
     constexpr int D = 4;  // the sweeps request their records this many steps ahead (8 spills registers and gains nothing)
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
@@ -224,9 +247,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     const T INF = (T)HUGE_VAL;
     const T DEPTOL = Tol<T>::dep;
     // ---- LDS: matrix tiles of the Riccati step, the sweeps' running vectors, the vectors shared by the lanes
+    // (the stacked instantiations, nx <= 12, run the recursion in registers and carve no tiles: kTileElems below)
     T *Pm = (T *)stagew_smem, *PAm = Pm + 16 * LD, *Mm = PAm + 16 * LD, *Am = Mm + 16 * LD, *Atm = Am + 16 * LD;
     T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
-    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *cst = Sm + 32;  // cst: 0, 1, spare cells
+    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD;
+    T *cst = STACK ? (T *)stagew_smem : Sm + 32;  // cst: 0, 1, spare cells
     T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq;
     int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
     int *crow = phys + maxq + 1;                                // rows whose P^-1 g' the latest sweeps left in Zs / Vc
@@ -271,163 +296,325 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     if (stamp && lane == 0)
         for (int i = 8; i < 16; ++i) stamp[i] = 0;
 
-    // ================================================================= factor: Riccati recursion in LDS
-    for (int i = lane; i < (int)(cst - Pm) + 8; i += 64) Pm[i] = T(0);  // every tile and the constants
-    wsync();
-    if (lane < nx) Pm[lane * LD + lane] = wt;
-    if (lane == 0) cst[1] = T(1);
-    wsync();
-    // where this lane's record values come from (LDS offsets from Pm; fixed along the horizon): entry (blk, kk) of a
-    // record is the stacked matrix at row rowmap(lane % 16) of block blk, column 4 kk + lane / 16
-    int srcb[NB], srcf[NF];
-    T sgnf[NF];
-    {
-        const int zero = (int)(cst - Pm), one = zero + 1, mrow = Mfma<T>::rowmap(c16);
+    // ================================================================= factor: Riccati recursion
+    bool notpd = false;  // a pivot of S_k = w_u I + B_k' P_{k+1} B_k was not positive: the condensed Hessian is not positive definite
+    if constexpr (STACK) {
+        // ---- nx <= 12: the whole recursion in REGISTERS on the matrix cores, no LDS, no barrier.
+        // Every matrix is a 16 x 16 tile in the accumulator layout of the 16x16x4 MFMA ("D layout": register t of lane
+        // (pg, c16) holds physical row Mfma::row(pg, t), column c16). Feeding register t of two such tiles X, Y as the A
+        // and B operand of ONE instruction contracts them over the rows of that register: sum_t mfma(X[t], Y[t]) = X' Y,
+        // again in D layout -- so products chain register to register. Logical indices: row 4 t + pg, column
+        // rowmap(c16) (the same permutation on both sides; identity in float64); states 0..NXC-1 are registers t < NQ,
+        // the inputs NXC..NXC+3 are register NQ, and a contraction over states / inputs only is NQ / one instruction.
+        //   W = [A B],  Z = P W,  H = W' Z = [[A'PA, A'PB], [B'PA, B'PB]],  S = w_u I + H_uu = L D L' (every lane, from
+        //   ten v_readlane), K = S^-1 H_ux and S^-1 through ONE product with S^-1 spread over the input block,
+        //   E = [A 0] - [B; I] [K, S^-1] = [[Acl, F'], [-K, -S^-1]] (F = -S^-1 B': rows t < NQ are the backward record),
+        //   P_k = Q_k + H_xx - H_ux' K (symmetrised by a product with the identity), [Acl', -K'] = [A' 0] - K' [B', I]
+        //   (the forward record). 13 instructions on the matrix cores and ~100 on the vector pipe per step (nx = 12)
+        //   against ~20 + 370 and seven LDS round trips for the tiled version below.
+        constexpr int TI = NQ;  // the register (contraction chunk) of the input rows
+        const int lcol = Mfma<T>::rowmap(c16);
+        const bool scol = lcol < NXC, ucol = lcol >= NXC && lcol < NXC + 4;
+        const int ic = lcol - NXC;  // input index of an input column
+        // this lane's entries of the step's operands: W[t] = [A B][4 t + pg][lcol], WA[t] = A'[4 t + pg][lcol],
+        // mB = -[B', I][pg][lcol]; element offsets inside the step's block (clamped) and validity
+        unsigned offW[NQ], offAt[NQ], offBt;
+        bool okW[NQ], okAt[NQ];
 #pragma unroll
-        for (int blk = 0; blk < NA; ++blk) {
+        for (int t = 0; t < NQ; ++t) {
+            const int lr = 4 * t + pg;
+            okW[t] = scol ? (lr < nx && lcol < nx) : (ucol && ic < nu && lr < nx);
+            offW[t] = okW[t] ? (unsigned)(scol ? lr * nx + lcol : lr * nu + ic) : 0u;
+            okAt[t] = scol && lr < nx && lcol < nx;
+            offAt[t] = okAt[t] ? (unsigned)(lcol * nx + lr) : 0u;
+        }
+        const bool okBt = scol && lcol < nx && pg < nu;
+        offBt = okBt ? (unsigned)(lcol * nu + pg) : 0u;
+        const T cBt = (ucol && ic == pg) ? T(-1) : T(0);
+        const T *baseW = scol ? gA : gB;
+        const int64_t stW = scol ? sA : sB;
+        MV P, Id;  // P_{k+1} (state block; zero elsewhere) and the identity, both in D layout
 #pragma unroll
-            for (int kk = 0; kk <= NQ; ++kk) {
-                const int col = 4 * kk + pg;
-                // the input-sized row this (block, row) is, or -1
-                const int irow = (blk == 0) ? ((STACK && mrow >= NXC && mrow < NXC + 4) ? mrow - NXC : -1) : (mrow < 4 ? mrow : -1);
-                if (kk < NQ) {  // backward: [Acl' ; F], F = -S^-1 B'
-                    int o = zero;
-                    if (blk == 0 && mrow < NXC) o = (int)(Acm - Pm) + col * LD + mrow;
-                    if (irow >= 0) o = (int)(Fm - Pm) + irow * LD + col;
-                    srcb[blk * NQ + kk] = o;
+        for (int t = 0; t < 4; ++t) {
+            const int lr = 4 * t + pg;
+            Id[t] = (t < NQ && lr == lcol) ? T(1) : T(0);
+            P[t] = (t < NQ && lr == lcol && lr < nx) ? wt : T(0);
+        }
+        constexpr int PD = 2;  // operands are requested this many steps ahead
+        T pw[PD][NQ], pa[PD][NQ], pb[PD];
+        auto request = [&](int d, int k) {
+            const T *w = baseW + k * stW, *a = gA + k * sA, *b = gB + k * sB;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                pw[d][t] = w[offW[t]];
+                pa[d][t] = a[offAt[t]];
+            }
+            pb[d] = b[offBt];
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            request(d, N - 1 - d >= 0 ? N - 1 - d : 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const MV zero4 = {T(0), T(0), T(0), T(0)};
+        auto rstep = [&](int d, int k) {
+            MV W = zero4, Wz = zero4, WA = zero4;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                W[t] = okW[t] ? pw[d][t] : T(0);
+                Wz[t] = scol ? W[t] : T(0);
+                WA[t] = okAt[t] ? pa[d][t] : T(0);
+            }
+            const T mB = okBt ? -pb[d] : cBt;
+            request(d, k - PD >= 0 ? k - PD : 0);
+            MV Z = zero4, H = zero4;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) Z = Mfma<T>::run(P[t], W[t], Z);  // Z = P W
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) H = Mfma<T>::run(W[t], Z[t], H);  // H = W' P W
+            // S = w_u I + H_uu (identity on the padding), the same in every lane
+            Ldl4<T> ldl;
+            {
+                T sv[10];
+#pragma unroll
+                for (int i = 0, e = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j, ++e)
+                        sv[e] = rl(H[TI], 16 * i + Mfma<T>::rowmap(NXC + j)) + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
+                notpd |= !ldl.factor(sv);
+            }
+            // S^-1 spread over the input block: lane (pg, input column b) holds S^-1[pg][b]
+            T sfull;
+            {
+                T eb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) eb[i] = (ic == i) ? T(1) : T(0);
+                ldl.solve(eb);
+                const T v = pg == 0 ? eb[0] : pg == 1 ? eb[1] : pg == 2 ? eb[2] : eb[3];
+                sfull = ucol ? v : T(0);
+            }
+            const MV K3 = Mfma<T>::run(sfull, H[TI], zero4);  // rows of the inputs: S^-1 [H_ux, H_uu]
+            const T kfull = scol ? K3[TI] : T(0);              // K = S^-1 H_ux
+            const T ks3 = scol ? K3[TI] : sfull;               // [K, S^-1]
+            const MV E = Mfma<T>::run(mB, ks3, Wz);            // [[Acl, F'], [-K, -S^-1]]
+            MV Hq = H;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) Hq[t] += (4 * t + pg == lcol && lcol < nx && k >= 1) ? wx : T(0);  // (x_0 is data: Q_0 = 0)
+            MV Pk = Mfma<T>::run(H[TI], E[TI], Hq);  // Q_k + H_xx - H_ux' K
+#pragma unroll
+            for (int t = 0; t < 4; ++t) Pk[t] = (t < NQ && scol) ? Pk[t] : T(0);
+            MV PT = zero4;
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) PT = Mfma<T>::run(Pk[t], Id[t], PT);  // P_k'
+            const MV M2 = Mfma<T>::run(kfull, mB, WA);  // [Acl', -K']
+            // factors to the workspace: the sweeps' records (one MFMA operand = 64 consecutive values), K' and the factor
+            // of S (read at the candidate row's step)
+            {
+                T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
+#pragma unroll
+                for (int e = 0; e < NQ; ++e) {
+                    mb[e * 64] = E[e];
+                    mf[e * 64] = M2[e];
                 }
-                {  // forward: [[Acl, B], [-K, I]]
-                    int o = zero;
-                    T sg = T(1);
-                    if (blk == 0 && mrow < NXC) o = col < NXC ? (int)(Acm - Pm) + mrow * LD + col : (int)(Bm - Pm) + mrow * 4 + (col - NXC);
-                    if (irow >= 0) {
-                        if (col < NXC) {
-                            o = (int)(Km - Pm) + irow * LD + col;
-                            sg = T(-1);
-                        } else {
-                            o = (col - NXC == irow) ? one : zero;
-                        }
+                mf[NQ * 64] = -mB;
+                T *ks = KS + (int64_t)k * (nx * nu + 16);
+                if (scol && lcol < nx && pg < nu) ks[lcol * nu + pg] = -E[TI];
+                if (lane == 0) {
+                    T *kf = ks + nx * nu;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) P[t] = T(0.5) * (Pk[t] + PT[t]);
+        };
+        int k = N - 1;
+        for (int g = N / PD; g > 0; --g) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) rstep(d, k - d);
+            k -= PD;
+        }
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+            if (k - d >= 0) rstep(d, k - d);
+        if (lane < 8) cst[lane] = lane == 1 ? T(1) : T(0);
+        wsync();
+    } else {
+        // ---- nx > 12: 16 x 16 tiles in LDS
+        for (int i = lane; i < (int)(cst - Pm) + 8; i += 64) Pm[i] = T(0);  // every tile and the constants
+        wsync();
+        if (lane < nx) Pm[lane * LD + lane] = wt;
+        if (lane == 0) cst[1] = T(1);
+        wsync();
+        // where this lane's record values come from (LDS offsets from Pm; fixed along the horizon): entry (blk, kk) of a
+        // record is the stacked matrix at row rowmap(lane % 16) of block blk, column 4 kk + lane / 16
+        int srcb[NB], srcf[NF];
+        T sgnf[NF];
+        {
+            const int zero = (int)(cst - Pm), one = zero + 1, mrow = Mfma<T>::rowmap(c16);
+    #pragma unroll
+            for (int blk = 0; blk < NA; ++blk) {
+    #pragma unroll
+                for (int kk = 0; kk <= NQ; ++kk) {
+                    const int col = 4 * kk + pg;
+                    // the input-sized row this (block, row) is, or -1
+                    const int irow = (blk == 0) ? ((STACK && mrow >= NXC && mrow < NXC + 4) ? mrow - NXC : -1) : (mrow < 4 ? mrow : -1);
+                    if (kk < NQ) {  // backward: [Acl' ; F], F = -S^-1 B'
+                        int o = zero;
+                        if (blk == 0 && mrow < NXC) o = (int)(Acm - Pm) + col * LD + mrow;
+                        if (irow >= 0) o = (int)(Fm - Pm) + irow * LD + col;
+                        srcb[blk * NQ + kk] = o;
                     }
-                    srcf[blk * (NQ + 1) + kk] = o;
-                    sgnf[blk * (NQ + 1) + kk] = sg;
+                    {  // forward: [[Acl, B], [-K, I]]
+                        int o = zero;
+                        T sg = T(1);
+                        if (blk == 0 && mrow < NXC) o = col < NXC ? (int)(Acm - Pm) + mrow * LD + col : (int)(Bm - Pm) + mrow * 4 + (col - NXC);
+                        if (irow >= 0) {
+                            if (col < NXC) {
+                                o = (int)(Km - Pm) + irow * LD + col;
+                                sg = T(-1);
+                            } else {
+                                o = (col - NXC == irow) ? one : zero;
+                            }
+                        }
+                        srcf[blk * (NQ + 1) + kk] = o;
+                        sgnf[blk * (NQ + 1) + kk] = sg;
+                    }
                 }
             }
         }
-    }
-    // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step.
-    // No branches: lanes without an entry re-read the last one and write it to a spare LDS cell.
-    constexpr int NAU = (NXC * NXC + 63) / 64;
-    const int junk = (int)(cst - Pm) + 4;
-    T pfa[NAU], pfb;
-    unsigned idxA[NAU], idxB;
-    int offA[NAU], offAt[NAU], offB = junk, offBt = junk + 1, offK = -1;  // LDS offsets (from Pm) of this lane's entries
-#pragma unroll
-    for (int u = 0; u < NAU; ++u) {
-        const int i = lane + 64 * u, r = i / nx, c = i - r * nx;
-        const bool in = i < nx * nx;
-        idxA[u] = (unsigned)(in ? i : nx * nx - 1);
-        offA[u] = in ? (int)(Am - Pm) + r * LD + c : junk;
-        offAt[u] = in ? (int)(Atm - Pm) + c * LD + r : junk + 1;
-    }
-    idxB = (unsigned)(lane < nx * nu ? lane : nx * nu - 1);
-    if (lane < nx * nu) {
-        const int r = lane / nu, c = lane - r * nu;
-        offB = (int)(Bm - Pm) + r * 4 + c;
-        offBt = (int)(Btm - Pm) + c * LD + r;
-        offK = c * LD + r;  // Kt[r][c] = K[c][r]
-    }
-    auto request = [&](int k) {
-        const T *a = gA + k * sA, *bb = gB + k * sB;
-#pragma unroll
-        for (int u = 0; u < NAU; ++u) pfa[u] = a[idxA[u]];
-        pfb = bb[idxB];
-    };
-    request(N - 1);
-    for (int k = N - 1; k >= 0; --k) {
-        // stage A_k, A_k', B_k, B_k'
-#pragma unroll
+        // A_k, B_k are requested one step ahead (<= 4 + 1 entries per lane) and land in the LDS tiles at the top of their step.
+        // No branches: lanes without an entry re-read the last one and write it to a spare LDS cell.
+        constexpr int NAU = (NXC * NXC + 63) / 64;
+        const int junk = (int)(cst - Pm) + 4;
+        T pfa[NAU], pfb;
+        unsigned idxA[NAU], idxB;
+        int offA[NAU], offAt[NAU], offB = junk, offBt = junk + 1, offK = -1;  // LDS offsets (from Pm) of this lane's entries
+    #pragma unroll
         for (int u = 0; u < NAU; ++u) {
-            Pm[offA[u]] = pfa[u];
-            Pm[offAt[u]] = pfa[u];
+            const int i = lane + 64 * u, r = i / nx, c = i - r * nx;
+            const bool in = i < nx * nx;
+            idxA[u] = (unsigned)(in ? i : nx * nx - 1);
+            offA[u] = in ? (int)(Am - Pm) + r * LD + c : junk;
+            offAt[u] = in ? (int)(Atm - Pm) + c * LD + r : junk + 1;
         }
-        Pm[offB] = pfb;
-        Pm[offBt] = pfb;
-        wsync();
-        request(k > 0 ? k - 1 : 0);
-        mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Pm, Am, nullptr, pg, c16);    // PA = P A
-        mm_t<T, LD, 4, 4, 16, 4, NXC, false>(PBm, Pm, Bm, nullptr, pg, c16);      // PB = P B
-        wsync();
-        mm_t<T, LD, 4, 4, 4, 4, NXC, false>(Sm, Btm, PBm, nullptr, pg, c16);     // B' P B
-        mm_t<T, LD, LD, LD, 4, 16, NXC, false>(BPAm, Btm, PAm, nullptr, pg, c16); // B' P A
-        wsync();
-        // S = w_u I + B'PB (nu <= 4, identity on the padding) is factored L D L' in registers, every lane the same; lane
-        // (., c) then solves for column c of K = S^-1 B'PA and of F = -S^-1 B' (row group i writes row i)
-        Ldl4<T> ldl;
-        {
-            T sv[10];
-#pragma unroll
-            for (int i = 0, e = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j, ++e) sv[e] = Sm[i * 4 + j] + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
-            ldl.factor(sv);
-            T kc[4], fc[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                kc[i] = BPAm[i * LD + c16];
-                fc[i] = Bm[c16 * 4 + i];
+        idxB = (unsigned)(lane < nx * nu ? lane : nx * nu - 1);
+        if (lane < nx * nu) {
+            const int r = lane / nu, c = lane - r * nu;
+            offB = (int)(Bm - Pm) + r * 4 + c;
+            offBt = (int)(Btm - Pm) + c * LD + r;
+            offK = c * LD + r;  // Kt[r][c] = K[c][r]
+        }
+        auto request = [&](int k) {
+            const T *a = gA + k * sA, *bb = gB + k * sB;
+    #pragma unroll
+            for (int u = 0; u < NAU; ++u) pfa[u] = a[idxA[u]];
+            pfb = bb[idxB];
+        };
+        request(N - 1);
+        for (int k = N - 1; k >= 0; --k) {
+            // stage A_k, A_k', B_k, B_k'
+    #pragma unroll
+            for (int u = 0; u < NAU; ++u) {
+                Pm[offA[u]] = pfa[u];
+                Pm[offAt[u]] = pfa[u];
             }
-            ldl.solve(kc);
-            ldl.solve(fc);
-            const T kv = pg == 0 ? kc[0] : pg == 1 ? kc[1] : pg == 2 ? kc[2] : kc[3];
-            const T fv = pg == 0 ? fc[0] : pg == 1 ? fc[1] : pg == 2 ? fc[2] : fc[3];
-            Km[pg * LD + c16] = kv;
-            Fm[pg * LD + c16] = -fv;
-        }
-        wsync();
-        mm_t<T, 4, LD, LD, 16, 16, 4, true>(Acm, Bm, Km, Am, pg, c16);           // Acl = A - B K
-        mm_t<T, 4, LD, LD, 16, 16, 4, true>(Mm, PBm, Km, PAm, pg, c16);          // M = P Acl = PA - PB K
-        wsync();
-        mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Atm, Mm, nullptr, pg, c16);   // A' P Acl (into the PA tile)
-        // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
-        // (read at the candidate row's step)
-        {
-            T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
-#pragma unroll
-            for (int e = 0; e < NB; ++e) mb[e * 64] = Pm[srcb[e]];
-#pragma unroll
-            for (int e = 0; e < NF; ++e) mf[e * 64] = sgnf[e] * Pm[srcf[e]];
-            T *ks = KS + (int64_t)k * (nx * nu + 16);
-            if (offK >= 0) ks[lane] = Km[offK];
-            if (lane == 0) {  // the factor of S: 1 / d, then l10, l20, l30, l21, l31, l32
-                T *kf = ks + nx * nu;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
-            }
-        }
-        wsync();
-        // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
-        {
-            const T qk = (k >= 1) ? wx : T(0);
-            T pn[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = pg + 4 * t;
-                pn[t] = T(0.5) * (PAm[r * LD + c16] + PAm[c16 * LD + r]) + ((r == c16 && r < nx) ? qk : T(0));  // (zero padding)
+            Pm[offB] = pfb;
+            Pm[offBt] = pfb;
+            wsync();
+            request(k > 0 ? k - 1 : 0);
+            mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Pm, Am, nullptr, pg, c16);    // PA = P A
+            mm_t<T, LD, 4, 4, 16, 4, NXC, false>(PBm, Pm, Bm, nullptr, pg, c16);      // PB = P B
+            wsync();
+            mm_t<T, LD, 4, 4, 4, 4, NXC, false>(Sm, Btm, PBm, nullptr, pg, c16);     // B' P B
+            mm_t<T, LD, LD, LD, 4, 16, NXC, false>(BPAm, Btm, PAm, nullptr, pg, c16); // B' P A
+            wsync();
+            // S = w_u I + B'PB (nu <= 4, identity on the padding) is factored L D L' in registers, every lane the same; lane
+            // (., c) then solves for column c of K = S^-1 B'PA and of F = -S^-1 B' (row group i writes row i)
+            Ldl4<T> ldl;
+            {
+                T sv[10];
+    #pragma unroll
+                for (int i = 0, e = 0; i < 4; ++i)
+    #pragma unroll
+                    for (int j = 0; j <= i; ++j, ++e) sv[e] = Sm[i * 4 + j] + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
+                notpd |= !ldl.factor(sv);
+                T kc[4], fc[4];
+    #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    kc[i] = BPAm[i * LD + c16];
+                    fc[i] = Bm[c16 * 4 + i];
+                }
+                ldl.solve(kc);
+                ldl.solve(fc);
+                const T kv = pg == 0 ? kc[0] : pg == 1 ? kc[1] : pg == 2 ? kc[2] : kc[3];
+                const T fv = pg == 0 ? fc[0] : pg == 1 ? fc[1] : pg == 2 ? fc[2] : fc[3];
+                Km[pg * LD + c16] = kv;
+                Fm[pg * LD + c16] = -fv;
             }
             wsync();
-#pragma unroll
-            for (int t = 0; t < 4; ++t) Pm[(pg + 4 * t) * LD + c16] = pn[t];
+            mm_t<T, 4, LD, LD, 16, 16, 4, true>(Acm, Bm, Km, Am, pg, c16);           // Acl = A - B K
+            mm_t<T, 4, LD, LD, 16, 16, 4, true>(Mm, PBm, Km, PAm, pg, c16);          // M = P Acl = PA - PB K
+            wsync();
+            mm_t<T, LD, LD, LD, 16, 16, NXC, false>(PAm, Atm, Mm, nullptr, pg, c16);   // A' P Acl (into the PA tile)
+            // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
+            // (read at the candidate row's step)
+            {
+                T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
+    #pragma unroll
+                for (int e = 0; e < NB; ++e) mb[e * 64] = Pm[srcb[e]];
+    #pragma unroll
+                for (int e = 0; e < NF; ++e) mf[e * 64] = sgnf[e] * Pm[srcf[e]];
+                T *ks = KS + (int64_t)k * (nx * nu + 16);
+                if (offK >= 0) ks[lane] = Km[offK];
+                if (lane == 0) {  // the factor of S: 1 / d, then l10, l20, l30, l21, l31, l32
+                    T *kf = ks + nx * nu;
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
+    #pragma unroll
+                    for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
+                }
+            }
+            wsync();
+            // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
+            {
+                const T qk = (k >= 1) ? wx : T(0);
+                T pn[4];
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = pg + 4 * t;
+                    pn[t] = T(0.5) * (PAm[r * LD + c16] + PAm[c16 * LD + r]) + ((r == c16 && r < nx) ? qk : T(0));  // (zero padding)
+                }
+                wsync();
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) Pm[(pg + 4 * t) * LD + c16] = pn[t];
+            }
+            wsync();
         }
-        wsync();
     }
     tick(1);
+    if (__ballot(notpd) != 0ull) {
+        // mpc_problem.py:104-107 only guarantees w_u > 0; a negative state weight can still make the Hessian indefinite.
+        // The pivots S_k of the recursion are the Schur complements of the condensed Hessian in the order u_{N-1}, ...,
+        // u_0, so P is positive definite iff every S_k is: report what the condensed kernels' Cholesky reports.
+        T *ou = (T *)ka.U + prob * (int64_t)nvar;
+        for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+        if (ka.lam) {
+            T *ol = (T *)ka.lam + prob * (int64_t)M;
+            for (int i = lane; i < M; i += 64) ol[i] = T(0);
+        }
+        if (lane == 0) {
+            if (ka.status) ka.status[prob] = MPCQP_NOT_PD;
+            if (ka.iters) ka.iters[prob] = 0;
+        }
+        return;
+    }
 
     // ================================================================= the LQR solve: two serial sweeps
     // The running vector is an MFMA B operand: register q of the lanes of row group g = lane / 16 holds component
     // 4 q + g (columns: right-hand sides; column 0 = lanes with lane % 16 == 0 is the one in use).
-    using MV = typename Mfma<T>::V;
     const T *tp = stageQ ? gtgt : Mb;  // (a readable address when there are no targets)
     // backward: (p_k, ff_k) = [Acl_k' ; F_k] p_{k+1} (+ the step's linear cost). With `track` the tracking costs from p_N;
     // else the costate of one row of G, which is zero after its step kq: `start` is (p_kq, ff_kq) and the sweep runs
@@ -506,7 +693,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     // forward: (x_{k+1}, u_k) = [[Acl_k, B_k], [-K_k, I]] (x_k, ff_k) from x_0 = xs (ff_k = 0 for k > kff); writes the
     // inputs to Uo[k][0..3] and (x_k, u_k) to Zp[k]
     // per column: ff_k = 0 for k > kff; inputs to Uo[k][0..3], (x_k, u_k) to Zo[k] (lanes with `on`)
-    auto forward = [&](const T *xs, int kff, T *Uo, unsigned uoff, T *Zo, unsigned zoff, bool on) {
+    // FUSE: [C | D]' as a constant MFMA operand: chunk q of lane (c16, pg) is G[r][4 q + pg] of the row r that lane c16 stands
+    // for (chosen so that row group pg' of the RESULT holds rows 4 pg' .. 4 pg' + 3 in both precisions); the last chunk is D
+    constexpr int NG = NQ + 1;
+    T gT[NG];
+    if constexpr (FUSE) {
+        const int r = sizeof(T) == 4 ? c16 : 4 * (c16 & 3) + (c16 >> 2);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) gT[q] = (gC && r < mk && 4 * q + pg < nx) ? gC[r * nx + 4 * q + pg] : T(0);
+        gT[NQ] = (gD && r < mk && pg < nu) ? gD[r * nu + pg] : T(0);
+    }
+    // ... Ho (FUSE): h = G (x_k, u_k) of every step goes to Ho[k mk + r] (lanes with `on`; per column through hoff)
+    auto forward = [&](const T *xs, int kff, T *Uo, unsigned uoff, T *Zo, unsigned zoff, bool on, T *Ho, unsigned hoff) {
         T z[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) z[q] = (xs && col0 && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
@@ -541,7 +739,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
             }
             const T u = STACK ? a0[NQ] : a1[0];
-            if (on) {
+            if constexpr (FUSE) {
+                MV hk = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) hk = Mfma<T>::run(gT[q], z[q], hk);
+                hk = Mfma<T>::run(gT[NQ], u, hk);
+                if (on) {
+                    Uo[uoff + (unsigned)(k * 4)] = u;
+                    if (4 * pg < mk) *(V4 *)(Ho + (hoff + (unsigned)(k * mk + 4 * pg))) = hk;
+                }
+            } else if (on) {
                 const unsigned zr = zoff + (unsigned)(k * ZL);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) Zo[zr + q] = z[q];
@@ -569,7 +776,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
     // four-vectors, zero-padded, vector-major so that the lanes of a pass read side by side
-    for (int i = lane; i < Mg; i += 64) {
+    for (int i = lane; i < (FUSE ? 0 : Mg); i += 64) {
         const int k = stepof(i), r = i - k * mk;
         V4 g[NQ + 1];
 #pragma unroll
@@ -687,6 +894,104 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         sp = __shfl(bsv, bi & 63);  // (row i lives in lane i % 64)
     };
 
+    // the right-hand sides of a sweep pair: column 0 carries the candidate row bi, columns 1 .. R - 1 the next most violated
+    // rows (V_a = P^-1 g_a' does not depend on the active set: a row found among them later costs no sweep; which rows ride
+    // along has no influence on the iterates). Per lane: its column's row, the row's step, (p_kq, ff_kq) to inject there;
+    // kmax = the latest of the steps.
+    auto candidates = [&](int bi, int &myrow, int &mykq, int &kmax, MV &st, T &ffs) {
+        // rows[0] = the candidate; then the next most violated rows (per-lane top two, R - 1 wave minima)
+        int rows[R];
+        rows[0] = bi;
+        {
+            T b1 = INF, b2 = INF;
+            int i1 = 0x7fffffff, i2 = 0x7fffffff;
+            for (int i0 = lane; i0 < M; i0 += 64 * TU) {
+                T sv[TU], iv[TU], th[TU];
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                    sv[u] = sl[i];
+                    iv[u] = invn[i];
+                    th[u] = thr[i];
+                }
+#pragma unroll
+                for (int u = 0; u < TU; ++u) {
+                    const int i = i0 + 64 * u;
+                    const T sc = sv[u] * iv[u];
+                    if (i < M && sv[u] < -th[u] && i != bi) {
+                        if (sc < b1) {
+                            b2 = b1;
+                            i2 = i1;
+                            b1 = sc;
+                            i1 = i;
+                        } else if (sc < b2) {
+                            b2 = sc;
+                            i2 = i;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                T v = b1;
+                int ix = i1;
+                wave_argmin(v, ix);
+                rows[j] = (v < INF) ? ix : -1;
+                if (v < INF && ix == i1) {
+                    b1 = b2;
+                    i1 = i2;
+                    b2 = INF;
+                    i2 = 0x7fffffff;
+                }
+            }
+        }
+        myrow = -1;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (c16 == j) myrow = rows[j];
+        // (p_kq, ff_kq) of this lane's row (kq, rq): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above
+        // kq is zero)
+        st = MV{T(0), T(0), T(0), T(0)};
+        ffs = T(0);
+        mykq = -1;
+        if (myrow >= 0) {
+            const int kq = stepof(myrow), rq = myrow - kq * mk;
+            mykq = kq;
+            const T *ks = KS + (int64_t)kq * (nx * nu + 16);
+            T dd[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
+            Ldl4<T> ldl;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
+                ldl.id[i] = ks[nx * nu + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ldl.l[i] = ks[nx * nu + 4 + i];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int c = 4 * q + pg;
+                cq[q] = (gC && c < nx) ? gC[kq * sC + rq * nx + c] : T(0);
+#pragma unroll
+                for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * nu + i] : T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                T v = -cq[q];
+#pragma unroll
+                for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
+                st[q] = v;
+            }
+            ldl.solve(dd);  // S^-1 D'
+            ffs = pg == 0 ? dd[0] : pg == 1 ? dd[1] : pg == 2 ? dd[2] : dd[3];
+        }
+        kmax = -1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int kj = rows[j] >= 0 ? stepof(rows[j]) : -1;
+            kmax = kj > kmax ? kj : kmax;
+        }
+    };
+
     // ================================================================= unconstrained minimiser, slacks
     tick(2);
     {
@@ -700,434 +1005,744 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     }
     wsync();
     tick(3);
-    forward(gx0, N, U0, 0u, Zs, 0u, col0);
-    wsync();
-    tick(4);
-    const T tol = ka.tol;
-    gmul(sl, Zs, -1);
-    for (int i = lane; i < M; i += 64) {
-        const int k = stepof(i), r = i - k * mk;
-        const T ev = ge[k * sE + r], sv = ev - sl[i];
-        s0[i] = sv;
-        sl[i] = sv;
-        thr[i] = tol + tol * (T)fabs((double)ev);
-        const int gi = ginv ? r : i;
-        T nn = T(0);
+    if constexpr (FUSE) {
+        // ================================================================= FUSE: constraint matrices fixed along the horizon
+        // What an iteration costs here is not arithmetic but DEPENDENT ROUND TRIPS to HBM (~1 us each under load, and a
+        // wavefront-wide hand-over through global memory needs the stores drained first). So:
+        //   * everything the lanes hand to each other inside an iteration lives in LDS -- c, r, the multipliers, the slot
+        //     bookkeeping and W = (G_A P^-1 G_A')^-1 itself while it has at most WL rows (it moves to the workspace when
+        //     the 33rd row arrives); LDS operations of ONE wavefront execute in order, so those hand-overs need no wait;
+        //   * per-row arrays (slacks, thresholds, h_a) are only ever touched by the lane that owns the row (row i <-> lane
+        //     i % 64, also for the single-row updates when a row enters or leaves): same-lane accesses need no fence;
+        //   * the sweeps write V_a and h_a = G V_a (formed by the forward sweep itself) straight into free SLOTS; taking
+        //     a candidate is bookkeeping, nothing is copied; an active row is marked by an infinite threshold;
+        //   * the feed-forward terms go from the backward to the forward sweep through the same lane.
+        // One store drain per sweep pair is left (its slots are read by every lane).
+        constexpr int WL = 32, WLD = 33;
+        int *cslot = crow + R, *freel = cslot + R;
+        T *Wl = (T *)(((uintptr_t)(freel + maxq) + 15) & ~(uintptr_t)15);
+        forward(gx0, N, U0, 0u, nullptr, 0u, col0, sl, 0u);  // h = G (x, u) of the unconstrained minimiser into sl
+        wsync();
+        tick(4);
+        const T tol = ka.tol;
+        T nnv = T(0);  // |g_r|^2 of the row this lane's column stands for in gT (summed over the four row groups)
 #pragma unroll
-        for (int q = 0; q <= NQ; ++q) {
-            const V4 g = Gp[(unsigned)(q * Mg + gi)];
-            nn += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+        for (int q = 0; q <= NQ; ++q) nnv += gT[q] * gT[q];
+        nnv += __shfl_xor(nnv, 16);
+        nnv += __shfl_xor(nnv, 32);
+        for (int i = lane; i < M; i += 64) {
+            const int k = stepof(i), r = i - k * mk;
+            const T ev = ge[k * sE + r], sv = ev - sl[i];
+            s0[i] = sv;
+            sl[i] = sv;
+            thr[i] = tol + tol * (T)fabs((double)ev);
+            const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
+            invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
         }
-        invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
-        rowslot[i] = -1;
-    }
-    for (int a = lane; a <= maxq; a += 64) phys[a] = a;
-    if (lane < R) crow[lane] = -1;
-    wsync();
-
-    tick(5);
-    if (stamp) {  // (developer probe) slot 15: violated rows at the unconstrained minimiser, and their summed scaled violation
-        int nv = 0;
-        T tv = T(0);
-        for (int i = lane; i < M; i += 64)
-            if (sl[i] < -thr[i]) {
-                ++nv;
-                tv -= sl[i] * invn[i];
+        for (int a = lane; a < maxq; a += 64) freel[a] = maxq + R - 1 - a;  // (popped from the end: slots R, R + 1, ...)
+        if (lane < R) {
+            crow[lane] = -1;
+            cslot[lane] = lane;
+        }
+        lsync();
+        tick(5);
+        int nq = 0, nfree = maxq, iters = 0, status = MPCQP_MAX_ITER;
+        const int max_iter = ka.max_iter;
+        bool fail = false, havesel = false, wglob = false;
+        T nbest = INF, nsp = T(0);
+        int nbi = 0x7fffffff;
+        for (int round = 0; round < 4 && !fail; ++round) {
+            for (;;) {
+                tacc(-1);
+                T best = nbest, sp = nsp;
+                int bi = nbi;
+                if (!havesel) select(best, bi, sp);
+                havesel = false;
+                if (!(best < INF)) {
+                    status = MPCQP_SOLVED;
+                    break;
+                }
+                tacc(8);
+                int hit = -1;
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (crow[j] == bi) hit = j;
+                if (hit < 0) {
+                    int myrow, mykq, kmax;
+                    MV st;
+                    T ffs;
+                    candidates(bi, myrow, mykq, kmax, st, ffs);
+                    backward(std::false_type{}, kmax, st, ffs, mykq);
+                    tacc(9);
+                    const unsigned cs = (unsigned)cslot[cn];
+                    forward(nullptr, mykq, Vs, cs * (unsigned)nv4, nullptr, 0u, myrow >= 0, Hs, cs * (unsigned)M);
+                    if (lane < R) crow[lane] = myrow;
+                    wsync();
+                    tacc(10);
+                    hit = 0;
+                }
+                // h_p = G V_p sits in the candidate's slot: c_a = h_p[row a], g_p . V_p = h_p[p]
+                const T *hp = Hs + (int64_t)cslot[hit] * M;
+                for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
+                const T dpp = hp[bi];
+                lsync();
+                tacc(11);
+                T up = T(0);
+                bool added = false, fresh = true;
+                while (!added) {
+                    if (iters >= max_iter) {
+                        fail = true;
+                        break;
+                    }
+                    ++iters;
+                    if (!fresh) {
+                        for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
+                        lsync();
+                    }
+                    fresh = false;
+                    // ---- r = W c ; d2 = g_p . V_p - c . r
+                    T cr = T(0);
+                    auto matvec = [&](const T *Wp, int ld) {
+                        for (int a = lane; a < nq; a += 64) {
+                            T acc = T(0);
+                            for (int b = 0; b < nq; ++b) acc += Wp[b * ld + a] * cv[b];  // W is symmetric
+                            rv[a] = acc;
+                            cr += acc * cv[a];
+                        }
+                    };
+                    if (wglob)
+                        matvec(Wm, maxq);
+                    else
+                        matvec(Wl, WLD);
+                    cr = wave_sum(cr);
+                    lsync();
+                    const T d2 = dpp - cr;
+                    const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
+                    // ---- ratio test on the multipliers
+                    T t1 = INF;
+                    int l = 0x7fffffff;
+                    for (int a = lane; a < nq; a += 64) {
+                        const T ra = rv[a];
+                        if (ra > T(0)) {
+                            const T q = lamv[a] / ra;
+                            if (q < t1) {
+                                t1 = q;
+                                l = a;
+                            }
+                        }
+                    }
+                    wave_argmin(t1, l);
+                    const T t2 = can_move ? -sp / d2 : INF;
+                    const T t = t1 < t2 ? t1 : t2;
+                    if (!(t < INF)) {
+                        status = MPCQP_INFEASIBLE;
+                        fail = true;
+                        break;
+                    }
+                    const bool full = (t2 <= t1);
+                    if (full && nq >= maxq) {  // every slot is taken (max_active < min(n, m)) -> MPCQP_MAX_ITER
+                        fail = true;
+                        break;
+                    }
+                    tacc(12);
+                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
+                    nbest = INF;
+                    nbi = 0x7fffffff;
+                    T nbsv = T(0), spcap = T(0);
+                    for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                        T z[SU];
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                        int a = 0;
+                        for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
+                            const T ra = rv[a], rb = rv[a + 1];
+                            const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                            T va[SU], vb[SU];
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                                va[u] = ha[i];
+                                vb[u] = hb[i];
+                            }
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
+                        }
+                        if (a < nq) {
+                            const T ra = rv[a];
+                            const T *ha = Hs + (int64_t)phys[a] * M;
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                        }
+#pragma unroll
+                        for (int h = 0; h < SU; h += SU / 2) {
+                            T so[SU / 2], iv[SU / 2], th[SU / 2];
+#pragma unroll
+                            for (int u = 0; u < SU / 2; ++u) {
+                                const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
+                                so[u] = sl[i];
+                                iv[u] = invn[i];
+                                th[u] = thr[i];
+                            }
+#pragma unroll
+                            for (int u = 0; u < SU / 2; ++u) {
+                                const int i = i0 + 64 * (h + u);
+                                const T v = (th[u] == INF) ? T(0) : so[u] + t * z[h + u];  // (active rows stay on their bounds)
+                                const T sc = v * iv[u];
+                                if (i < M) {
+                                    sl[i] = v;
+                                    if (i == bi) spcap = v;
+                                    if (v < -th[u] && i != bi && sc < nbest) {
+                                        nbest = sc;
+                                        nbi = i;
+                                        nbsv = v;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
+                    // ---- multipliers
+                    for (int a = lane; a < nq; a += 64) {
+                        const T v = lamv[a] - t * rv[a];
+                        lamv[a] = v < T(0) ? T(0) : v;
+                    }
+                    up += t;
+                    tacc(13);
+                    if (full) {
+                        // p becomes active at index nq, in the slot its vectors already occupy: W is bordered
+                        const T id2 = T(1) / d2;
+                        if (!wglob && nq >= WL) {  // W outgrows its LDS tile: it moves to the workspace
+                            for (int b = 0; b < nq; ++b)
+                                for (int a = lane; a < nq; a += 64) Wm[(int64_t)b * maxq + a] = Wl[b * WLD + a];
+                            wglob = true;
+                            wsync();
+                        }
+                        auto border = [&](T *Wp, int ld) {
+                            for (int a = lane; a < nq; a += 64) {
+                                const T ra = rv[a];
+                                for (int b = 0; b < nq; ++b) Wp[b * ld + a] += rv[b] * ra * id2;
+                                Wp[nq * ld + a] = -ra * id2;
+                                Wp[a * ld + nq] = -ra * id2;
+                            }
+                            if (lane == 0) Wp[nq * ld + nq] = id2;
+                        };
+                        if (wglob)
+                            border(Wm, maxq);
+                        else
+                            border(Wl, WLD);
+                        if (lane == 0) {
+                            lamv[nq] = up;
+                            actrow[nq] = bi;
+                            phys[nq] = cslot[hit];
+                            cslot[hit] = freel[nfree - 1];
+                            crow[hit] = -1;
+                        }
+                        if (lane == (bi & 63)) {  // (the row's owner)
+                            thr[bi] = INF;
+                            sl[bi] = T(0);
+                        }
+                        ++nq;
+                        --nfree;
+                        added = true;
+                        wave_argmin(nbest, nbi);
+                        nsp = __shfl(nbsv, nbi & 63);
+                        havesel = true;
+                    } else {
+                        // partial step: index l leaves; W is deflated, the last index moves into the hole, its slot is free
+                        const int last = nq - 1, rowl = actrow[l];
+                        auto deflate = [&](T *Wp, int ld, auto sync) {
+                            const T iw = T(1) / Wp[l * ld + l];
+                            for (int a = lane; a < nq; a += 64) cv[a] = Wp[l * ld + a];  // row l before the update
+                            sync();
+                            for (int a = lane; a < nq; a += 64) {
+                                const T wa = cv[a];
+                                for (int b = 0; b < nq; ++b) Wp[b * ld + a] -= cv[b] * wa * iw;
+                            }
+                            sync();
+                            if (l != last) {
+                                for (int a = lane; a < nq; a += 64) Wp[l * ld + a] = Wp[last * ld + a];
+                                sync();
+                                for (int b = lane; b < nq; b += 64) Wp[b * ld + l] = Wp[b * ld + last];
+                                sync();
+                            }
+                        };
+                        if (wglob)
+                            deflate(Wm, maxq, [&] { wsync(); });
+                        else
+                            deflate(Wl, WLD, [&] { lsync(); });
+                        if (lane == (rowl & 63)) {  // (the row's owner) the row can be selected again
+                            const int k = stepof(rowl), r = rowl - k * mk;
+                            thr[rowl] = tol + tol * (T)fabs((double)ge[k * sE + r]);
+                        }
+                        if (lane == 0) {
+                            freel[nfree] = phys[l];
+                            if (l != last) {
+                                lamv[l] = lamv[last];
+                                actrow[l] = actrow[last];
+                                phys[l] = phys[last];
+                            }
+                        }
+                        --nq;
+                        ++nfree;
+                    }
+                    if (wglob)
+                        wsync();
+                    else
+                        lsync();
+                    tacc(14);
+                }
+                if (fail) break;
             }
-        nv = (int)wave_sum((T)nv);
-        tv = wave_sum(tv);
-        if (lane == 0) stamp[15] = (long long)nv + ((long long)(tv * T(1000)) << 16);
-    }
-    // ================================================================= active-set loop
-    int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
-    const int max_iter = ka.max_iter;
-    bool fail = false, havesel = false;
-    T nbest = INF, nsp = T(0);
-    int nbi = 0x7fffffff;
-    for (int round = 0; round < 4 && !fail; ++round) {
-        for (;;) {
-            // ---- selection (already made by the slack pass of the step that just ended, if there was one)
-            tacc(-1);
-            T best = nbest, sp = nsp;
-            int bi = nbi;
-            if (!havesel) select(best, bi, sp);
-            havesel = false;
-            if (!(best < INF)) {
+            if (fail) break;
+            tick(6);
+            // ================================================================= primal point, verification
+            // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a. Inactive rows must be feasible;
+            // ACTIVE rows must sit on their bounds (W is only ever updated, never refactored: if it drifted, one step of
+            // refinement lam -= W rho_A puts them back, and a point that still fails is not reported solved)
+            bool dirty = false;
+            for (int pass = 0; pass < 2; ++pass) {
+                // residuals of the active rows through their own entries of the h_b (nq x nq gathers)
+                T worst = T(0);
+                for (int a = lane; a < nq; a += 64) {
+                    const int ra = actrow[a];
+                    T acc = s0[ra];
+                    for (int b = 0; b < nq; ++b) acc += lamv[b] * Hs[(int64_t)phys[b] * M + ra];
+                    cv[a] = acc;
+                    const int k = stepof(ra), r = ra - k * mk;
+                    const T lim = T(1000) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
+                    const T ex = (T)fabs((double)acc) - lim;
+                    worst = !(ex <= T(0)) || !(lamv[a] >= T(0)) ? INF : worst;
+                }
+                lsync();
+                const bool off = __ballot(worst > T(0)) != 0ull;
+                if (!off) break;
+                if (pass == 1) {
+                    fail = true;
+                    break;
+                }
+                auto refine = [&](const T *Wp, int ld) {
+                    for (int a = lane; a < nq; a += 64) {
+                        T acc = T(0);
+                        for (int b = 0; b < nq; ++b) acc += Wp[b * ld + a] * cv[b];
+                        const T v = lamv[a] - acc;
+                        lamv[a] = v < T(0) ? T(0) : v;
+                    }
+                };
+                if (wglob)
+                    refine(Wm, maxq);
+                else
+                    refine(Wl, WLD);
+                lsync();
+            }
+            if (fail) break;
+            T *ou = (T *)ka.U + prob * (int64_t)nvar;
+            for (int i = lane; i < nv4; i += 64) {
+                T u = U0[i];
+                for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
+                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
+            }
+            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                T fr[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                int a = 0;
+                for (; a + 1 < nq; a += 2) {
+                    const T la = lamv[a], lb = lamv[a + 1];
+                    const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                    T va[SU], vb[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                        va[u] = ha[i];
+                        vb[u] = hb[i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
+                }
+                if (a < nq) {
+                    const T la = lamv[a];
+                    const T *ha = Hs + (int64_t)phys[a] * M;
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                }
+                T th[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) th[u] = thr[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const bool act = th[u] == INF;
+                    if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
+                    if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
+                }
+            }
+            dirty = __ballot(dirty) != 0ull;
+            if (!dirty) {
                 status = MPCQP_SOLVED;
                 break;
             }
-            tacc(8);
-            // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room. The
-            // sweeps carry R right-hand sides at the price of one, so the rows most likely to be taken next ride along
-            // (V_a does not depend on the active set: a row found in crow[] later costs no sweep; which rows ride along
-            // has no influence on the iterates).
-            const int ps = phys[nq];
-            T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
-            int hit = -1;
-#pragma unroll
-            for (int j = 0; j < R; ++j)
-                if (crow[j] == bi) hit = j;
-            if (hit < 0) {
-                // rows[0] = the candidate; then the next most violated rows (per-lane top two, R - 1 wave minima)
-                int rows[R];
-                rows[0] = bi;
-                {
-                    T b1 = INF, b2 = INF;
-                    int i1 = 0x7fffffff, i2 = 0x7fffffff;
-                    for (int i0 = lane; i0 < M; i0 += 64 * TU) {
-                        T sv[TU], iv[TU], th[TU];
-#pragma unroll
-                        for (int u = 0; u < TU; ++u) {
-                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                            sv[u] = sl[i];
-                            iv[u] = invn[i];
-                            th[u] = thr[i];
-                        }
-#pragma unroll
-                        for (int u = 0; u < TU; ++u) {
-                            const int i = i0 + 64 * u;
-                            const T sc = sv[u] * iv[u];
-                            if (i < M && sv[u] < -th[u] && i != bi) {
-                                if (sc < b1) {
-                                    b2 = b1;
-                                    i2 = i1;
-                                    b1 = sc;
-                                    i1 = i;
-                                } else if (sc < b2) {
-                                    b2 = sc;
-                                    i2 = i;
-                                }
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 1; j < R; ++j) {
-                        T v = b1;
-                        int ix = i1;
-                        wave_argmin(v, ix);
-                        rows[j] = (v < INF) ? ix : -1;
-                        if (v < INF && ix == i1) {
-                            b1 = b2;
-                            i1 = i2;
-                            b2 = INF;
-                            i2 = 0x7fffffff;
-                        }
-                    }
-                }
-                int myrow = -1;
-#pragma unroll
-                for (int j = 0; j < R; ++j)
-                    if (c16 == j) myrow = rows[j];
-                // (p_kq, ff_kq) of this lane's row (kq, rq): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above
-                // kq is zero)
-                MV st = {T(0), T(0), T(0), T(0)};
-                T ffs = T(0);
-                int mykq = -1;
-                if (myrow >= 0) {
-                    const int kq = stepof(myrow), rq = myrow - kq * mk;
-                    mykq = kq;
-                    const T *ks = KS + (int64_t)kq * (nx * nu + 16);
-                    T dd[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
-                    Ldl4<T> ldl;
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) {
-                        dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
-                        ldl.id[i] = ks[nx * nu + i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) ldl.l[i] = ks[nx * nu + 4 + i];
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const int c = 4 * q + pg;
-                        cq[q] = (gC && c < nx) ? gC[kq * sC + rq * nx + c] : T(0);
-#pragma unroll
-                        for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * nu + i] : T(0);
-                    }
-#pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        T v = -cq[q];
-#pragma unroll
-                        for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
-                        st[q] = v;
-                    }
-                    ldl.solve(dd);  // S^-1 D'
-                    ffs = pg == 0 ? dd[0] : pg == 1 ? dd[1] : pg == 2 ? dd[2] : dd[3];
-                }
-                int kmax = -1;
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const int kj = rows[j] >= 0 ? stepof(rows[j]) : -1;
-                    kmax = kj > kmax ? kj : kmax;
-                }
-                backward(std::false_type{}, kmax, st, ffs, mykq);
-                wsync();
-                tacc(9);
-                forward(nullptr, mykq, Vc, (unsigned)(cn * nv4), Zs, (unsigned)(cn * N * ZL), myrow >= 0);
-                if (lane < R) crow[lane] = myrow;
-                wsync();
-                tacc(10);
-                hit = 0;
-            }
-            // the row's vectors move into the slot: inputs copied, h_p = G V_p from its trajectory
-            for (int i = lane; i < nv4; i += 64) Vp[i] = Vc[(int64_t)hit * nv4 + i];
-            const T dpp = gmul(hp, Zs + (int64_t)hit * N * ZL, bi);
-            if (lane == 0) crow[hit] = -1;
+            status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
+        }
+        tick(7);
+        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+        const bool ok = status == MPCQP_SOLVED;
+        if (!ok) {
+            T *ou = (T *)ka.U + prob * (int64_t)nvar;
+            for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+        }
+        if (ka.lam) {
+            T *ol = (T *)ka.lam + prob * (int64_t)M;
+            for (int i = lane; i < M; i += 64) ol[i] = T(0);
             wsync();
-            tacc(11);
-            T up = T(0);
-            bool added = false, fresh = true;  // fresh: cv[] still holds the c_a the pass above left
-            while (!added) {
-                if (iters >= max_iter) {
-                    fail = true;
+            if (ok)
+                for (int a = lane; a < nq; a += 64) ol[actrow[a]] = lamv[a];
+        }
+        if (lane == 0) {
+            if (ka.status) ka.status[prob] = status;
+            if (ka.iters) ka.iters[prob] = iters;
+        }
+    } else {
+        forward(gx0, N, U0, 0u, Zs, 0u, col0, nullptr, 0u);
+        wsync();
+        tick(4);
+        const T tol = ka.tol;
+        gmul(sl, Zs, -1);
+        for (int i = lane; i < M; i += 64) {
+            const int k = stepof(i), r = i - k * mk;
+            const T ev = ge[k * sE + r], sv = ev - sl[i];
+            s0[i] = sv;
+            sl[i] = sv;
+            thr[i] = tol + tol * (T)fabs((double)ev);
+            const int gi = ginv ? r : i;
+            T nn = T(0);
+    #pragma unroll
+            for (int q = 0; q <= NQ; ++q) {
+                const V4 g = Gp[(unsigned)(q * Mg + gi)];
+                nn += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+            }
+            invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+            rowslot[i] = -1;
+        }
+        for (int a = lane; a <= maxq; a += 64) phys[a] = a;
+        if (lane < R) crow[lane] = -1;
+        wsync();
+
+        tick(5);
+        if (stamp) {  // (developer probe) slot 15: violated rows at the unconstrained minimiser, and their summed scaled violation
+            int nv = 0;
+            T tv = T(0);
+            for (int i = lane; i < M; i += 64)
+                if (sl[i] < -thr[i]) {
+                    ++nv;
+                    tv -= sl[i] * invn[i];
+                }
+            nv = (int)wave_sum((T)nv);
+            tv = wave_sum(tv);
+            if (lane == 0) stamp[15] = (long long)nv + ((long long)(tv * T(1000)) << 16);
+        }
+        // ================================================================= active-set loop
+        int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
+        const int max_iter = ka.max_iter;
+        bool fail = false, havesel = false;
+        T nbest = INF, nsp = T(0);
+        int nbi = 0x7fffffff;
+        for (int round = 0; round < 4 && !fail; ++round) {
+            for (;;) {
+                // ---- selection (already made by the slack pass of the step that just ended, if there was one)
+                tacc(-1);
+                T best = nbest, sp = nsp;
+                int bi = nbi;
+                if (!havesel) select(best, bi, sp);
+                havesel = false;
+                if (!(best < INF)) {
+                    status = MPCQP_SOLVED;
                     break;
                 }
-                ++iters;
-                // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                if (!fresh) {
-                    for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
+                tacc(8);
+                // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room. The
+                // sweeps carry R right-hand sides at the price of one, so the rows most likely to be taken next ride along
+                // (V_a does not depend on the active set: a row found in crow[] later costs no sweep; which rows ride along
+                // has no influence on the iterates).
+                const int ps = phys[nq];
+                T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
+                int hit = -1;
+    #pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (crow[j] == bi) hit = j;
+                if (hit < 0) {
+                    int myrow, mykq, kmax;
+                    MV st;
+                    T ffs;
+                    candidates(bi, myrow, mykq, kmax, st, ffs);
+                    backward(std::false_type{}, kmax, st, ffs, mykq);
                     wsync();
+                    tacc(9);
+                    forward(nullptr, mykq, Vc, (unsigned)(cn * nv4), Zs, (unsigned)(cn * N * ZL), myrow >= 0, nullptr, 0u);
+                    if (lane < R) crow[lane] = myrow;
+                    wsync();
+                    tacc(10);
+                    hit = 0;
                 }
-                fresh = false;
-                T cr = T(0);
-                for (int a = lane; a < nq; a += 64) {
-                    T acc = T(0);
-                    for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
-                    rv[a] = acc;
-                    cr += acc * cv[a];
-                }
-                cr = wave_sum(cr);
+                // the row's vectors move into the slot: inputs copied, h_p = G V_p from its trajectory
+                for (int i = lane; i < nv4; i += 64) Vp[i] = Vc[(int64_t)hit * nv4 + i];
+                const T dpp = gmul(hp, Zs + (int64_t)hit * N * ZL, bi);
+                if (lane == 0) crow[hit] = -1;
                 wsync();
-                const T d2 = dpp - cr;
-                const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
-                // ---- ratio test on the multipliers
-                T t1 = INF;
-                int l = 0x7fffffff;
-                for (int a = lane; a < nq; a += 64) {
-                    const T ra = rv[a];
-                    if (ra > T(0)) {
-                        const T q = lamv[a] / ra;
-                        if (q < t1) {
-                            t1 = q;
-                            l = a;
-                        }
+                tacc(11);
+                T up = T(0);
+                bool added = false, fresh = true;  // fresh: cv[] still holds the c_a the pass above left
+                while (!added) {
+                    if (iters >= max_iter) {
+                        fail = true;
+                        break;
                     }
-                }
-                wave_argmin(t1, l);
-                const T t2 = can_move ? -sp / d2 : INF;
-                const T t = t1 < t2 ? t1 : t2;
-                if (!(t < INF)) {
-                    status = MPCQP_INFEASIBLE;
-                    fail = true;
-                    break;
-                }
-                const bool full = (t2 <= t1);
-                if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
-                    fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
-                    break;
-                }
-                tacc(12);
-                // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
-                nbest = INF;
-                nbi = 0x7fffffff;
-                T nbsv = T(0), spcap = T(0);
-                for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                    // SU rows per lane in one go: first z = h_p - sum r_a h_a (only z and the slots' values live), then
-                    // the rows' own arrays in halves
-                    T z[SU];
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                    int a = 0;
-                    for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
-                        const T ra = rv[a], rb = rv[a + 1];
-                        const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                        T va[SU], vb[SU];
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) {
-                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                            va[u] = ha[i];
-                            vb[u] = hb[i];
-                        }
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
+                    ++iters;
+                    // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
+                    if (!fresh) {
+                        for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
+                        wsync();
                     }
-                    if (a < nq) {
+                    fresh = false;
+                    T cr = T(0);
+                    for (int a = lane; a < nq; a += 64) {
+                        T acc = T(0);
+                        for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
+                        rv[a] = acc;
+                        cr += acc * cv[a];
+                    }
+                    cr = wave_sum(cr);
+                    wsync();
+                    const T d2 = dpp - cr;
+                    const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
+                    // ---- ratio test on the multipliers
+                    T t1 = INF;
+                    int l = 0x7fffffff;
+                    for (int a = lane; a < nq; a += 64) {
                         const T ra = rv[a];
-                        const T *ha = Hs + (int64_t)phys[a] * M;
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                    }
-#pragma unroll
-                    for (int h = 0; h < SU; h += SU / 2) {
-                        int rs[SU / 2];
-                        T so[SU / 2], iv[SU / 2], th[SU / 2];
-#pragma unroll
-                        for (int u = 0; u < SU / 2; ++u) {
-                            const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
-                            so[u] = sl[i];
-                            iv[u] = invn[i];
-                            th[u] = thr[i];
-                            rs[u] = rowslot[i];
+                        if (ra > T(0)) {
+                            const T q = lamv[a] / ra;
+                            if (q < t1) {
+                                t1 = q;
+                                l = a;
+                            }
                         }
-#pragma unroll
-                        for (int u = 0; u < SU / 2; ++u) {
-                            const int i = i0 + 64 * (h + u);
-                            const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[h + u];
-                            const T sc = v * iv[u];
-                            if (i < M) {
-                                sl[i] = v;
-                                if (i == bi) spcap = v;
-                                if (v < -th[u] && i != bi && sc < nbest) {
-                                    nbest = sc;
-                                    nbi = i;
-                                    nbsv = v;
+                    }
+                    wave_argmin(t1, l);
+                    const T t2 = can_move ? -sp / d2 : INF;
+                    const T t = t1 < t2 ? t1 : t2;
+                    if (!(t < INF)) {
+                        status = MPCQP_INFEASIBLE;
+                        fail = true;
+                        break;
+                    }
+                    const bool full = (t2 <= t1);
+                    if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
+                        fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
+                        break;
+                    }
+                    tacc(12);
+                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
+                    nbest = INF;
+                    nbi = 0x7fffffff;
+                    T nbsv = T(0), spcap = T(0);
+                    for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                        // SU rows per lane in one go: first z = h_p - sum r_a h_a (only z and the slots' values live), then
+                        // the rows' own arrays in halves
+                        T z[SU];
+    #pragma unroll
+                        for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                        int a = 0;
+                        for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
+                            const T ra = rv[a], rb = rv[a + 1];
+                            const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                            T va[SU], vb[SU];
+    #pragma unroll
+                            for (int u = 0; u < SU; ++u) {
+                                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                                va[u] = ha[i];
+                                vb[u] = hb[i];
+                            }
+    #pragma unroll
+                            for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
+                        }
+                        if (a < nq) {
+                            const T ra = rv[a];
+                            const T *ha = Hs + (int64_t)phys[a] * M;
+    #pragma unroll
+                            for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                        }
+    #pragma unroll
+                        for (int h = 0; h < SU; h += SU / 2) {
+                            int rs[SU / 2];
+                            T so[SU / 2], iv[SU / 2], th[SU / 2];
+    #pragma unroll
+                            for (int u = 0; u < SU / 2; ++u) {
+                                const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
+                                so[u] = sl[i];
+                                iv[u] = invn[i];
+                                th[u] = thr[i];
+                                rs[u] = rowslot[i];
+                            }
+    #pragma unroll
+                            for (int u = 0; u < SU / 2; ++u) {
+                                const int i = i0 + 64 * (h + u);
+                                const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[h + u];
+                                const T sc = v * iv[u];
+                                if (i < M) {
+                                    sl[i] = v;
+                                    if (i == bi) spcap = v;
+                                    if (v < -th[u] && i != bi && sc < nbest) {
+                                        nbest = sc;
+                                        nbi = i;
+                                        nbsv = v;
+                                    }
                                 }
                             }
                         }
                     }
-                }
-                sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
-                // ---- multipliers
-                for (int a = lane; a < nq; a += 64) {
-                    const T v = lamv[a] - t * rv[a];
-                    lamv[a] = v < T(0) ? T(0) : v;
-                }
-                up += t;
-                wsync();
-                tacc(13);
-                if (full) {
-                    // p becomes active at index nq (its slot is already phys[nq]): W is bordered
-                    const T id2 = T(1) / d2;
+                    sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
+                    // ---- multipliers
                     for (int a = lane; a < nq; a += 64) {
-                        const T ra = rv[a];
-                        for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] += rv[b] * ra * id2;
-                        Wm[(int64_t)nq * maxq + a] = -ra * id2;
-                        Wm[(int64_t)a * maxq + nq] = -ra * id2;
+                        const T v = lamv[a] - t * rv[a];
+                        lamv[a] = v < T(0) ? T(0) : v;
                     }
-                    if (lane == 0) {
-                        Wm[(int64_t)nq * maxq + nq] = id2;
-                        lamv[nq] = up;
-                        actrow[nq] = bi;
-                        rowslot[bi] = nq;
-                        sl[bi] = T(0);
-                    }
-                    ++nq;
-                    added = true;
-                    wave_argmin(nbest, nbi);
-                    nsp = __shfl(nbsv, nbi & 63);
-                    havesel = true;
-                } else {
-                    // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
-                    // through the permutation (the candidate's stays where it is)
-                    const T wll = Wm[(int64_t)l * maxq + l];
-                    const T iw = T(1) / wll;
-                    for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
+                    up += t;
                     wsync();
-                    for (int a = lane; a < nq; a += 64) {
-                        const T wa = cv[a];
-                        for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
-                    }
-                    wsync();
-                    const int last = nq - 1;
-                    if (l != last) {
-                        for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
-                        wsync();
-                        for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
-                        wsync();
-                    }
-                    if (lane == 0) {
-                        rowslot[actrow[l]] = -1;
-                        const int freed = phys[l];
-                        if (l != last) {
-                            lamv[l] = lamv[last];
-                            actrow[l] = actrow[last];
-                            rowslot[actrow[last]] = l;
-                            phys[l] = phys[last];
+                    tacc(13);
+                    if (full) {
+                        // p becomes active at index nq (its slot is already phys[nq]): W is bordered
+                        const T id2 = T(1) / d2;
+                        for (int a = lane; a < nq; a += 64) {
+                            const T ra = rv[a];
+                            for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] += rv[b] * ra * id2;
+                            Wm[(int64_t)nq * maxq + a] = -ra * id2;
+                            Wm[(int64_t)a * maxq + nq] = -ra * id2;
                         }
-                        phys[last] = phys[nq];
-                        phys[nq] = freed;
+                        if (lane == 0) {
+                            Wm[(int64_t)nq * maxq + nq] = id2;
+                            lamv[nq] = up;
+                            actrow[nq] = bi;
+                            rowslot[bi] = nq;
+                            sl[bi] = T(0);
+                        }
+                        ++nq;
+                        added = true;
+                        wave_argmin(nbest, nbi);
+                        nsp = __shfl(nbsv, nbi & 63);
+                        havesel = true;
+                    } else {
+                        // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
+                        // through the permutation (the candidate's stays where it is)
+                        const T wll = Wm[(int64_t)l * maxq + l];
+                        const T iw = T(1) / wll;
+                        for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
+                        wsync();
+                        for (int a = lane; a < nq; a += 64) {
+                            const T wa = cv[a];
+                            for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
+                        }
+                        wsync();
+                        const int last = nq - 1;
+                        if (l != last) {
+                            for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
+                            wsync();
+                            for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
+                            wsync();
+                        }
+                        if (lane == 0) {
+                            rowslot[actrow[l]] = -1;
+                            const int freed = phys[l];
+                            if (l != last) {
+                                lamv[l] = lamv[last];
+                                actrow[l] = actrow[last];
+                                rowslot[actrow[last]] = l;
+                                phys[l] = phys[last];
+                            }
+                            phys[last] = phys[nq];
+                            phys[nq] = freed;
+                        }
+                        --nq;
                     }
-                    --nq;
+                    wsync();
+                    tacc(14);
                 }
-                wsync();
-                tacc(14);
+                if (fail) break;
             }
             if (fail) break;
-        }
-        if (fail) break;
-        tick(6);
-        // ================================================================= primal point, verification
-        // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
-        T *ou = (T *)ka.U + prob * (int64_t)nvar;
-        for (int i = lane; i < nv4; i += 64) {
-            T u = U0[i];
-            for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
-            if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
-        }
-        bool dirty = false;
-        for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-            T fr[SU];
-#pragma unroll
-            for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-            int a = 0;
-            for (; a + 1 < nq; a += 2) {
-                const T la = lamv[a], lb = lamv[a + 1];
-                const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                T va[SU], vb[SU];
-#pragma unroll
+            tick(6);
+            // ================================================================= primal point, verification
+            // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
+            T *ou = (T *)ka.U + prob * (int64_t)nvar;
+            for (int i = lane; i < nv4; i += 64) {
+                T u = U0[i];
+                for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
+                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
+            }
+            bool dirty = false;
+            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                T fr[SU];
+    #pragma unroll
+                for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                int a = 0;
+                for (; a + 1 < nq; a += 2) {
+                    const T la = lamv[a], lb = lamv[a + 1];
+                    const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
+                    T va[SU], vb[SU];
+    #pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                        va[u] = ha[i];
+                        vb[u] = hb[i];
+                    }
+    #pragma unroll
+                    for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
+                }
+                if (a < nq) {
+                    const T la = lamv[a];
+                    const T *ha = Hs + (int64_t)phys[a] * M;
+    #pragma unroll
+                    for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                }
+                T th[SU];
+                int rs[SU];
+    #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                    va[u] = ha[i];
-                    vb[u] = hb[i];
+                    th[u] = thr[i];
+                    rs[u] = rowslot[i];
                 }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
+    #pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const bool act = rs[u] >= 0;
+                    if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
+                    if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
+                }
             }
-            if (a < nq) {
-                const T la = lamv[a];
-                const T *ha = Hs + (int64_t)phys[a] * M;
-#pragma unroll
-                for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+            dirty = __ballot(dirty) != 0ull;
+            wsync();
+            if (!dirty) {
+                status = MPCQP_SOLVED;
+                break;
             }
-            T th[SU];
-            int rs[SU];
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                th[u] = thr[i];
-                rs[u] = rowslot[i];
-            }
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const bool act = rs[u] >= 0;
-                if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
-                if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
+            status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
+        }
+        tick(7);
+        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+        const bool ok = status == MPCQP_SOLVED;
+        if (!ok) {
+            T *ou = (T *)ka.U + prob * (int64_t)nvar;
+            for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+        }
+        if (ka.lam) {
+            T *ol = (T *)ka.lam + prob * (int64_t)M;
+            for (int i = lane; i < M; i += 64) {
+                const int sidx = rowslot[i];
+                ol[i] = (ok && sidx >= 0) ? lamv[sidx] : T(0);
             }
         }
-        dirty = __ballot(dirty) != 0ull;
-        wsync();
-        if (!dirty) {
-            status = MPCQP_SOLVED;
-            break;
+        if (lane == 0) {
+            if (ka.status) ka.status[prob] = status;
+            if (ka.iters) ka.iters[prob] = iters;
         }
-        status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
-    }
-    tick(7);
-    if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
-    const bool ok = status == MPCQP_SOLVED;
-    if (!ok) {
-        T *ou = (T *)ka.U + prob * (int64_t)nvar;
-        for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
-    }
-    if (ka.lam) {
-        T *ol = (T *)ka.lam + prob * (int64_t)M;
-        for (int i = lane; i < M; i += 64) {
-            const int sidx = rowslot[i];
-            ol[i] = (ok && sidx >= 0) ? lamv[sidx] : T(0);
-        }
-    }
-    if (lane == 0) {
-        if (ka.status) ka.status[prob] = status;
-        if (ka.iters) ka.iters[prob] = iters;
     }
 }
 
@@ -1145,15 +1760,24 @@ bool stagew_supported(const KernelArgs &ka, int dtype)
 
 size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 {
-    return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), dtype == MPCQP_F64 ? 8 : 4).total;
+    // (a size query carries no operands and does not know which layout the launch will take: the larger of the two)
+    const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
+    const size_t a = (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), esz).total;
+    const size_t b = ka.A.ptr ? 0 : (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, true, esz).total;
+    return a > b ? a : b;
 }
 
-template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+template <typename T, int NXC, bool FUSE>
+static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T));
-    const size_t tiles = (size_t)(6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16 + 8);
-    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64;
-    auto kern = mpcqp_stagew_kernel<T, NXC>;
+    // the matrix tiles of the LDS Riccati recursion only exist for nx > 12; then 8 constant / spare cells
+    const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
+    // + c, r, multipliers, active rows, slot permutation, the sweeps' rows; FUSE: + the candidates' slots, the free list
+    // and the 32 x 33 tile of W
+    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64 +
+                       (FUSE ? (size_t)(R + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0);
+    auto kern = mpcqp_stagew_kernel<T, NXC, FUSE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -1162,14 +1786,20 @@ template <typename T, int NXC> static int launch_stagew_t(const KernelArgs &ka, 
     return (int)hipGetLastError();
 }
 
-template <typename T> static int launch_stagew_d(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+template <typename T, bool FUSE> static int launch_stagew_f(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     switch (nxc_of(ka.nx)) {
-    case 4: return launch_stagew_t<T, 4>(ka, maxq, batch, ws, st);
-    case 8: return launch_stagew_t<T, 8>(ka, maxq, batch, ws, st);
-    case 12: return launch_stagew_t<T, 12>(ka, maxq, batch, ws, st);
-    default: return launch_stagew_t<T, 16>(ka, maxq, batch, ws, st);
+    case 4: return launch_stagew_t<T, 4, FUSE>(ka, maxq, batch, ws, st);
+    case 8: return launch_stagew_t<T, 8, FUSE>(ka, maxq, batch, ws, st);
+    case 12: return launch_stagew_t<T, 12, FUSE>(ka, maxq, batch, ws, st);
+    default: return launch_stagew_t<T, 16, FUSE>(ka, maxq, batch, ws, st);
     }
+}
+
+template <typename T> static int launch_stagew_d(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    return fuse_ok(ka.mk, g_invariant(ka)) ? launch_stagew_f<T, true>(ka, maxq, batch, ws, st)
+                                           : launch_stagew_f<T, false>(ka, maxq, batch, ws, st);
 }
 
 int launch_stagew(const KernelArgs &ka, int dtype, int maxq, int64_t batch, void *ws, hipStream_t st)

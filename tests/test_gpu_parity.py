@@ -1032,6 +1032,13 @@ def test_inconsistent_problems_are_never_reported_solved():
         solved = [p.status.cpu().numpy() == 0 for p in plans]
         assert (solved[0] == solved[1]).all() and (solved[0] == solved[2]).all()
         unsolved += int((~solved[0]).sum())
+        # ... and with the CPU oracle (round 3: its from-scratch acceptance check turns the 'solved with |u| ~ 1e13' ends of
+        # inconsistent problems into status 2; no magnitude filter anywhere): same statuses, same plans
+        Uo, _, sto, _ = oracle.solve_workload(w)
+        assert np.array_equal(plans[0].status.cpu().numpy() == 0, sto == 0), np.flatnonzero((plans[0].status.cpu().numpy() == 0) != (sto == 0))
+        both = solved[0] & (sto == 0)
+        Uk = plans[0].U.cpu().numpy()
+        assert (np.abs(Uk - Uo)[both] / np.maximum(1.0, np.abs(Uo[both]).max(axis=1, keepdims=True))).max() <= 1e-6
         # rows of the solved plans: C x_k <= e_k along the roll-out
         for p, ok in zip(plans, solved):
             U = p.U.cpu().numpy()

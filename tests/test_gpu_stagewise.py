@@ -330,3 +330,50 @@ def test_stagewise_kernels_keep_going_when_every_slot_is_taken():
     assert int(wide.iters.max()) > 60  # more iterations than slots: rows were swapped
     scale = dense.U.abs().amax(dim=1).clamp(min=1.0)
     assert float(((dense.U - wide.U).abs().amax(dim=1) / scale).max()) <= 1e-9
+
+
+@pytest.mark.parametrize("case", ["narrow_serial", "narrow_scan", "wide_f64", "wide_f32", "wide_nx16"])
+def test_indefinite_hessian_is_status_not_pd_on_the_mpc_path(case):
+    """A negative state weight makes the condensed Hessian indefinite (mpc_problem.py:104-107 only checks w_u > 0). The
+    condensed kernels' Cholesky reports MPCQP_NOT_PD (3); the stage-wise kernels -- which mpcqp_build_solve_batch picks by
+    itself for 16 < n <= 128 (small systems) and for everything that does not fit on chip -- must report the same (the
+    pivots S_k of the Riccati recursion are the Schur complements of P), not decay through NaN to MAX_ITER or return a
+    stationary non-minimiser as solved. Same batch with its weight restored: solved again (nothing sticks)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    if case == "narrow_serial":
+        w, dt = W.wip_batch(6), torch.float64  # nx = 4, nu = 1, N = 50: narrow kernel, serial sweeps
+    elif case == "narrow_scan":
+        w, dt = W.wip_batch(6, N=120), torch.float64  # chunked scans (the factor image does not fit LDS)
+    elif case == "wide_nx16":
+        rng = np.random.default_rng(5)
+        w, dt = W.synthetic_ltv_batch(4, N=20), torch.float64  # nx = 16: the tiled (LDS) recursion of the wide kernel
+        A = np.zeros((4, 20, 16, 16))
+        A[:, :, :12, :12] = w["A"]
+        A[:, :, 12:, 12:] = 0.5 * np.eye(4)
+        w["A"] = A
+        w["B"] = np.concatenate([w["B"], rng.standard_normal((4, 20, 4, 4)) / 4.0], axis=2)
+        w["C"] = np.concatenate([w["C"], np.zeros((16, 4))], axis=1)
+        w["x0"] = np.concatenate([w["x0"], np.zeros((4, 4))], axis=1)
+        w["goal"] = np.zeros(16)
+        w["targets"] = np.zeros(20 * 16)
+    else:
+        w, dt = W.synthetic_ltv_batch(4, N=64), torch.float64 if case == "wide_f64" else torch.float32
+    good = dict(w)
+    w = dict(w)
+    w["wt"] = -50.0
+    _, _, sto, _ = oracle.solve_workload(w)
+    assert (sto == 3).all(), sto
+    for ww, want in ((w, 3), (good, 0)):
+        plan = solve_mpc_batch(W.to_batch_problem(ww, dtype=dt), return_multipliers=True)
+        torch.cuda.synchronize()
+        st = plan.status.cpu().numpy()
+        assert (st == want).all(), (case, want, st)
+        if want == 3:
+            assert (plan.U.cpu().numpy() == 0).all() and (plan.multipliers.cpu().numpy() == 0).all()
+            assert (plan.iters.cpu().numpy() == 0).all()
+    if case.startswith("narrow"):  # the condensed kernels on the same batch
+        plan = solve_mpc_batch(W.to_batch_problem(w, dtype=dt), flags=_capi.OPT_FORCE_CONDENSED)
+        torch.cuda.synchronize()
+        assert (plan.status.cpu().numpy() == 3).all()

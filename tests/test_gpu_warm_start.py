@@ -132,3 +132,38 @@ def test_warm_start_is_refused_where_it_is_not_implemented():
     ws = WarmState(small)
     with pytest.raises(BackendError, match="-6"):  # MPCQP_EUNSUPPORTED through the C ABI
         solve_mpc_batch(small, warm_state=ws, flags=_capi.OPT_FORCE_LDS)
+
+
+def test_warm_state_of_another_batch_is_refused_before_any_launch():
+    """The state is indexed by problem: one allocated for a smaller batch (or a short raw buffer) must be refused on
+    the host and, behind it, by the C ABI (MpcqpSolveOpts.warm_state_bytes -> MPCQP_EWORKSPACE), never read out of bounds."""
+    import ctypes as C
+
+    from qpmpc_amd import BackendError, PreparedSolve, WarmState, _capi, solve_mpc_batch
+    from qpmpc_amd import batch as Bt
+    from qpmpc_amd import workloads as W
+
+    small = W.to_batch_problem(W.triple_integrator_batch(8))
+    large = W.to_batch_problem(W.triple_integrator_batch(64))
+    ws = WarmState(small)
+    with pytest.raises(BackendError, match="WarmState holds 8 problems"):
+        solve_mpc_batch(large, warm_state=ws)
+    with pytest.raises(BackendError, match="WarmState holds 8 problems"):
+        PreparedSolve(large, warm_state=ws)
+    raw = torch.zeros(64 * ws.bytes_per_problem - 8, dtype=torch.uint8, device="cuda")
+    with pytest.raises(BackendError, match="warm_state tensor"):
+        solve_mpc_batch(large, warm_state=raw)
+    # the C ABI's own check, below the host's
+    lib = _capi.load()
+    dims, cp = large.dims(), large.c_problem()
+    opts = Bt._opts(warm_state=ws.buffer)
+    U = torch.empty((64, 16), dtype=torch.float64, device="cuda")
+    st = torch.full((64,), -7, dtype=torch.int32, device="cuda")
+    rc = lib.mpcqp_build_solve_batch(C.byref(dims), C.byref(cp), 64, C.byref(opts), U.data_ptr(), None, st.data_ptr(), None,
+                                     None, 0, Bt._stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == -5 and (st.cpu().numpy() == -7).all()
+    # the right size is accepted
+    plan = solve_mpc_batch(large, warm_state=WarmState(large))
+    torch.cuda.synchronize()
+    assert (plan.status.cpu().numpy() == 0).all()
