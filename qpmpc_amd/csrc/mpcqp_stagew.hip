@@ -33,11 +33,32 @@
 
 namespace mpcqp {
 
+// (build-time knobs of the developer's A/B runs: tools/ab_stagew.sh builds variants of this unit with -D...)
+#ifndef STAGEW_D
+#define STAGEW_D 4
+#endif
+#ifndef STAGEW_WPE32
+#define STAGEW_WPE32 3
+#endif
+#ifndef STAGEW_SU32
+#define STAGEW_SU32 8
+#endif
+#ifndef STAGEW_SG
+#define STAGEW_SG 2
+#endif
+#ifndef STAGEW_RF
+#define STAGEW_RF 8
+#endif
+
 namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
-constexpr int R = 4;    // right-hand sides per sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows
+// right-hand sides per sweep pair (columns of the MFMA B operand): the candidate + R - 1 speculated rows. The matrix cores
+// compute all 16 columns whatever their number; what a column costs is its stores (inputs, and h = G V in the FUSE layout,
+// where they go straight into free slots). Measured on config 5: 8 beats 4 by 3 %, 16 loses (later candidates are rarely among
+// the rows that were violated when the sweep ran, and the sweep starts at the latest of its rows' steps).
+constexpr int R_PLAIN = 4, R_FUSE = STAGEW_RF;
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
     int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Hc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;  // (Hc unused)
@@ -66,13 +87,15 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     const int64_t m = (int64_t)N * mk;
     // per-step records of the sweeps, in MFMA A-operand order: nq (backward) and nq + 1 (forward) chunks of 64 values
     // for each of the na row blocks of the stacked matrix (one when nxc + 4 <= 16)
+    // (lane-major, in groups of four values per lane: 256 values per group)
     const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
-    w.Mb = take((int64_t)N * na * nq * 64);
-    w.Mf = take((int64_t)N * na * (nq + 1) * 64);
+    w.Mb = take((int64_t)N * ((na * nq + 3) / 4) * 256);
+    w.Mf = take((int64_t)N * ((na * (nq + 1) + 3) / 4) * 256);
     w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
-    w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
     w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
     const bool fuse = fuse_ok(mk, ginv);
+    const int R = fuse ? R_FUSE : R_PLAIN;
+    w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
     w.Zs = take(fuse ? 0 : (int64_t)R * N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
     w.Vc = take(fuse ? 0 : (int64_t)R * N * 4);  // ... and its inputs alone (they move into a slot when the row is taken)
     w.Hc = 0;
@@ -225,12 +248,12 @@ __device__ __forceinline__ double rl(double v, int j)
 using namespace stagew;
 
 template <typename T, int NXC, bool FUSE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? 3 : 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? STAGEW_WPE32 : 2)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
     using MV = typename Mfma<T>::V;
-    constexpr int D = 4;  // the sweeps request their records this many steps ahead (8 spills registers and gains nothing)
+    constexpr int D = sizeof(T) == 4 ? STAGEW_D : 4;  // the sweeps request their records this many steps ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -240,6 +263,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     constexpr bool STACK = NXC <= 12;       // the input-sized rows fit under the state-sized ones in one 16-row block
     constexpr int NA = STACK ? 1 : 2;       // row blocks of the stacked matrices
     constexpr int NB = NA * NQ, NF = NA * (NQ + 1);  // record values per lane and step, backward / forward
+    // a step's record is stored lane-major in groups of four values (one 16- / 32-byte load per lane and group: the sweeps
+    // are bound by the ISSUE of their loads, not by latency -- measured): value e of lane l sits at (e / 4) 256 + 4 l + e % 4
+    constexpr int GB = (NB + 3) / 4, GF = (NF + 3) / 4;
+    constexpr int R = FUSE ? R_FUSE : R_PLAIN;  // right-hand sides per sweep pair
     constexpr int ZL = NXC + 4;             // a row of Zp: position g (NQ + 1) + q holds x[4 q + g] (q < NQ), u[g] (q = NQ)
     const bool col0 = c16 == 0;             // the lanes of right-hand side 0
     const bool colr = c16 < R;              // the lanes of the right-hand sides in use
@@ -340,14 +367,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             Id[t] = (t < NQ && lr == lcol) ? T(1) : T(0);
             P[t] = (t < NQ && lr == lcol && lr < nx) ? wt : T(0);
         }
+        // The backward sweep of the UNCONSTRAINED minimiser rides along: its costate p_k = Acl_k' p_{k+1} - w_x xref_k and
+        // feed-forward term ff_k = F_k p_{k+1} need exactly the record this step produces ([Acl, F'] = rows t < NQ of E),
+        // run in the same direction, and their three products fill gaps of the recursion's dependent chain: the
+        // separate sweep (64 serial steps, ~7 % of a config-5 problem) is gone. Column 0 of the operand, as in the sweeps.
+        const bool tgtq = stageQ;
+        const T wxq = (T)ka.wx;
+        MV pst = {T(0), T(0), T(0), T(0)};
+        if (termQ && col0) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (4 * q + pg < nx) pst[q] = -(T)ka.wt * ggoal[4 * q + pg];
+        }
+        const T *tp0 = stageQ ? gtgt : gA;  // (a readable address when there are no targets)
         constexpr int PD = 2;  // operands are requested this many steps ahead
-        T pw[PD][NQ], pa[PD][NQ], pb[PD];
+        T pw[PD][NQ], pa[PD][NQ], pb[PD], ptg[PD][NQ];
         auto request = [&](int d, int k) {
             const T *w = baseW + k * stW, *a = gA + k * sA, *b = gB + k * sB;
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 pw[d][t] = w[offW[t]];
                 pa[d][t] = a[offAt[t]];
+                ptg[d][t] = tp0[(int64_t)(tgtq ? k : 0) * nx + (4 * t + pg < nx ? 4 * t + pg : nx - 1)];
             }
             pb[d] = b[offBt];
         };
@@ -359,11 +400,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         const MV zero4 = {T(0), T(0), T(0), T(0)};
         auto rstep = [&](int d, int k) {
             MV W = zero4, Wz = zero4, WA = zero4;
+            T tgk[NQ];
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 W[t] = okW[t] ? pw[d][t] : T(0);
                 Wz[t] = scol ? W[t] : T(0);
                 WA[t] = okAt[t] ? pa[d][t] : T(0);
+                tgk[t] = ptg[d][t];
             }
             const T mB = okBt ? -pb[d] : cBt;
             request(d, k - PD >= 0 ? k - PD : 0);
@@ -400,6 +443,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             MV Hq = H;
 #pragma unroll
             for (int t = 0; t < NQ; ++t) Hq[t] += (4 * t + pg == lcol && lcol < nx && k >= 1) ? wx : T(0);  // (x_0 is data: Q_0 = 0)
+            {  // (p_k, ff_k) = [Acl' ; F] p_{k+1} (+ the tracking cost of step k)
+                MV a0 = zero4;
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) a0 = Mfma<T>::run(E[t], pst[t], a0);
+                if (col0) ffv[(unsigned)(k * 4 + pg)] = a0[NQ];
+#pragma unroll
+                for (int t = 0; t < NQ; ++t)
+                    pst[t] = a0[t] - ((tgtq && k >= 1 && col0 && 4 * t + pg < nx) ? wxq * tgk[t] : T(0));
+            }
             MV Pk = Mfma<T>::run(H[TI], E[TI], Hq);  // Q_k + H_xx - H_ux' K
 #pragma unroll
             for (int t = 0; t < 4; ++t) Pk[t] = (t < NQ && scol) ? Pk[t] : T(0);
@@ -410,13 +462,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             // factors to the workspace: the sweeps' records (one MFMA operand = 64 consecutive values), K' and the factor
             // of S (read at the candidate row's step)
             {
-                T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
+                V4 rb = {T(0), T(0), T(0), T(0)}, rf = {T(0), T(0), T(0), T(0)};
 #pragma unroll
                 for (int e = 0; e < NQ; ++e) {
-                    mb[e * 64] = E[e];
-                    mf[e * 64] = M2[e];
+                    rb[e] = E[e];
+                    rf[e] = M2[e];
                 }
-                mf[NQ * 64] = -mB;
+                rf[NQ] = -mB;
+                *(V4 *)(Mb + (int64_t)k * (GB * 256) + lane * 4) = rb;
+                *(V4 *)(Mf + (int64_t)k * (GF * 256) + lane * 4) = rf;
                 T *ks = KS + (int64_t)k * (nx * nu + 16);
                 if (scol && lcol < nx && pg < nu) ks[lcol * nu + pg] = -E[TI];
                 if (lane == 0) {
@@ -454,9 +508,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         T sgnf[NF];
         {
             const int zero = (int)(cst - Pm), one = zero + 1, mrow = Mfma<T>::rowmap(c16);
-    #pragma unroll
+#pragma unroll
             for (int blk = 0; blk < NA; ++blk) {
-    #pragma unroll
+#pragma unroll
                 for (int kk = 0; kk <= NQ; ++kk) {
                     const int col = 4 * kk + pg;
                     // the input-sized row this (block, row) is, or -1
@@ -492,7 +546,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         T pfa[NAU], pfb;
         unsigned idxA[NAU], idxB;
         int offA[NAU], offAt[NAU], offB = junk, offBt = junk + 1, offK = -1;  // LDS offsets (from Pm) of this lane's entries
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NAU; ++u) {
             const int i = lane + 64 * u, r = i / nx, c = i - r * nx;
             const bool in = i < nx * nx;
@@ -509,14 +563,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         }
         auto request = [&](int k) {
             const T *a = gA + k * sA, *bb = gB + k * sB;
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < NAU; ++u) pfa[u] = a[idxA[u]];
             pfb = bb[idxB];
         };
         request(N - 1);
         for (int k = N - 1; k >= 0; --k) {
             // stage A_k, A_k', B_k, B_k'
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < NAU; ++u) {
                 Pm[offA[u]] = pfa[u];
                 Pm[offAt[u]] = pfa[u];
@@ -536,13 +590,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             Ldl4<T> ldl;
             {
                 T sv[10];
-    #pragma unroll
+#pragma unroll
                 for (int i = 0, e = 0; i < 4; ++i)
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j <= i; ++j, ++e) sv[e] = Sm[i * 4 + j] + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
                 notpd |= !ldl.factor(sv);
                 T kc[4], fc[4];
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     kc[i] = BPAm[i * LD + c16];
                     fc[i] = Bm[c16 * 4 + i];
@@ -562,18 +616,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
             // (read at the candidate row's step)
             {
-                T *mb = Mb + (int64_t)k * (NB * 64) + lane, *mf = Mf + (int64_t)k * (NF * 64) + lane;
-    #pragma unroll
-                for (int e = 0; e < NB; ++e) mb[e * 64] = Pm[srcb[e]];
-    #pragma unroll
-                for (int e = 0; e < NF; ++e) mf[e * 64] = sgnf[e] * Pm[srcf[e]];
+                T *mb = Mb + (int64_t)k * (GB * 256) + lane * 4, *mf = Mf + (int64_t)k * (GF * 256) + lane * 4;
+#pragma unroll
+                for (int g = 0; g < GB; ++g) {
+                    V4 v = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * g + j < NB) v[j] = Pm[srcb[4 * g + j]];
+                    *(V4 *)(mb + g * 256) = v;
+                }
+#pragma unroll
+                for (int g = 0; g < GF; ++g) {
+                    V4 v = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4 * g + j < NF) v[j] = sgnf[4 * g + j] * Pm[srcf[4 * g + j]];
+                    *(V4 *)(mf + g * 256) = v;
+                }
                 T *ks = KS + (int64_t)k * (nx * nu + 16);
                 if (offK >= 0) ks[lane] = Km[offK];
                 if (lane == 0) {  // the factor of S: 1 / d, then l10, l20, l30, l21, l31, l32
                     T *kf = ks + nx * nu;
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
-    #pragma unroll
+#pragma unroll
                     for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
                 }
             }
@@ -582,13 +648,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             {
                 const T qk = (k >= 1) ? wx : T(0);
                 T pn[4];
-    #pragma unroll
+#pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int r = pg + 4 * t;
                     pn[t] = T(0.5) * (PAm[r * LD + c16] + PAm[c16 * LD + r]) + ((r == c16 && r < nx) ? qk : T(0));  // (zero padding)
                 }
                 wsync();
-    #pragma unroll
+#pragma unroll
                 for (int t = 0; t < 4; ++t) Pm[(pg + 4 * t) * LD + c16] = pn[t];
             }
             wsync();
@@ -643,9 +709,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int q = 0; q < NQ; ++q) tg[d][q] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *mb = Mb + (int64_t)k * (NB * 64) + lane;
+            const T *mb = Mb + (int64_t)k * (GB * 256) + lane * 4;
 #pragma unroll
-            for (int e = 0; e < NB; ++e) rec[d][e] = mb[e * 64];
+            for (int g = 0; g < GB; ++g) {
+                const V4 v = *(const V4 *)(mb + g * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * g + j < NB) rec[d][4 * g + j] = v[j];
+            }
             if (track) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) tg[d][q] = tp[(int64_t)k * nx + (4 * q + pg < nx ? 4 * q + pg : nx - 1)];
@@ -675,9 +746,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 a0 = start;
                 ffk = ffstart;
             }
+#ifndef STAGEW_DBG_NOSTORE
             if (colr) ffv[ffo + (unsigned)(k * 4)] = ffk;
+#endif
             st = a0;
+#ifndef STAGEW_DBG_NOLOAD
             if (again) req(d, k - D >= 0 ? k - D : 0);
+#endif
         };
         // full groups of D steps (every step re-requests: same loads in flight on every path), then the remainder
         int k = kstart;
@@ -719,9 +794,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int e = 0; e < NF; ++e) rec[d][e] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *mf = Mf + (int64_t)k * (NF * 64) + lane;
+            const T *mf = Mf + (int64_t)k * (GF * 256) + lane * 4;
 #pragma unroll
-            for (int e = 0; e < NF; ++e) rec[d][e] = mf[e * 64];
+            for (int g = 0; g < GF; ++g) {
+                const V4 v = *(const V4 *)(mf + g * 256);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * g + j < NF) rec[d][4 * g + j] = v[j];
+            }
             ffr[d] = ffv[ffo + (unsigned)(k * 4)];
         };
 #pragma unroll
@@ -771,7 +851,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
     constexpr int GU = sizeof(T) == 4 ? 2 : 1;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
-    constexpr int SU = sizeof(T) == 4 ? 8 : 4;  // rows per lane in flight in the slack passes
+    constexpr int SU = sizeof(T) == 4 ? STAGEW_SU32 : 4;  // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
@@ -1001,7 +1081,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             for (int q = 0; q < NQ; ++q)
                 if (4 * q + pg < nx) pN[q] = -(T)ka.wt * ggoal[4 * q + pg];
         }
-        backward(std::true_type{}, -1, pN, T(0), -1);
+        if constexpr (!STACK) backward(std::true_type{}, -1, pN, T(0), -1);  // (nx <= 12: done inside the recursion)
     }
     wsync();
     tick(3);
@@ -1063,10 +1143,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     break;
                 }
                 tacc(8);
-                int hit = -1;
-#pragma unroll
-                for (int j = 0; j < R; ++j)
-                    if (crow[j] == bi) hit = j;
+                int hit;
+                {
+                    const unsigned long long hm = __ballot(lane < R && crow[lane < R ? lane : 0] == bi);
+                    hit = hm ? (int)__builtin_ctzll(hm) : -1;
+                }
                 if (hit < 0) {
                     int myrow, mykq, kmax;
                     MV st;
@@ -1150,52 +1231,45 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     nbi = 0x7fffffff;
                     T nbsv = T(0), spcap = T(0);
                     for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                        T z[SU];
+                        // every load of the rows' own arrays first (they are needed last), then the slots in groups of
+                        // SG with all their loads in flight together: what a pass costs is its dependent round trips
+                        constexpr int SG = STAGEW_SG;
+                        T z[SU], so[SU], iv[SU], th[SU];
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                        int a = 0;
-                        for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
-                            const T ra = rv[a], rb = rv[a + 1];
-                            const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                            T va[SU], vb[SU];
+                        for (int u = 0; u < SU; ++u) {
+                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                            z[u] = hp[i];
+                            so[u] = sl[i];
+                            iv[u] = invn[i];
+                            th[u] = thr[i];
+                        }
+                        for (int a = 0; a < nq; a += SG) {
+                            T ra[SG], va[SG][SU];
 #pragma unroll
-                            for (int u = 0; u < SU; ++u) {
-                                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                                va[u] = ha[i];
-                                vb[u] = hb[i];
+                            for (int j = 0; j < SG; ++j) {
+                                const int aj = a + j < nq ? a + j : a;
+                                ra[j] = a + j < nq ? rv[aj] : T(0);
+                                const T *ha = Hs + (int64_t)phys[aj] * M;
+#pragma unroll
+                                for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                             }
 #pragma unroll
-                            for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
-                        }
-                        if (a < nq) {
-                            const T ra = rv[a];
-                            const T *ha = Hs + (int64_t)phys[a] * M;
+                            for (int j = 0; j < SG; ++j)
 #pragma unroll
-                            for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                                for (int u = 0; u < SU; ++u) z[u] -= ra[j] * va[j][u];
                         }
 #pragma unroll
-                        for (int h = 0; h < SU; h += SU / 2) {
-                            T so[SU / 2], iv[SU / 2], th[SU / 2];
-#pragma unroll
-                            for (int u = 0; u < SU / 2; ++u) {
-                                const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
-                                so[u] = sl[i];
-                                iv[u] = invn[i];
-                                th[u] = thr[i];
-                            }
-#pragma unroll
-                            for (int u = 0; u < SU / 2; ++u) {
-                                const int i = i0 + 64 * (h + u);
-                                const T v = (th[u] == INF) ? T(0) : so[u] + t * z[h + u];  // (active rows stay on their bounds)
-                                const T sc = v * iv[u];
-                                if (i < M) {
-                                    sl[i] = v;
-                                    if (i == bi) spcap = v;
-                                    if (v < -th[u] && i != bi && sc < nbest) {
-                                        nbest = sc;
-                                        nbi = i;
-                                        nbsv = v;
-                                    }
+                        for (int u = 0; u < SU; ++u) {
+                            const int i = i0 + 64 * u;
+                            const T v = (th[u] == INF) ? T(0) : so[u] + t * z[u];  // (active rows stay on their bounds)
+                            const T sc = v * iv[u];
+                            if (i < M) {
+                                sl[i] = v;
+                                if (i == bi) spcap = v;
+                                if (v < -th[u] && i != bi && sc < nbest) {
+                                    nbest = sc;
+                                    nbi = i;
+                                    nbsv = v;
                                 }
                             }
                         }
@@ -1414,7 +1488,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             thr[i] = tol + tol * (T)fabs((double)ev);
             const int gi = ginv ? r : i;
             T nn = T(0);
-    #pragma unroll
+#pragma unroll
             for (int q = 0; q <= NQ; ++q) {
                 const V4 g = Gp[(unsigned)(q * Mg + gi)];
                 nn += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
@@ -1465,7 +1539,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 const int ps = phys[nq];
                 T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
                 int hit = -1;
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < R; ++j)
                     if (crow[j] == bi) hit = j;
                 if (hit < 0) {
@@ -1548,33 +1622,33 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         // SU rows per lane in one go: first z = h_p - sum r_a h_a (only z and the slots' values live), then
                         // the rows' own arrays in halves
                         T z[SU];
-    #pragma unroll
+#pragma unroll
                         for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                         int a = 0;
                         for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
                             const T ra = rv[a], rb = rv[a + 1];
                             const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
                             T va[SU], vb[SU];
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < SU; ++u) {
                                 const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                                 va[u] = ha[i];
                                 vb[u] = hb[i];
                             }
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
                         }
                         if (a < nq) {
                             const T ra = rv[a];
                             const T *ha = Hs + (int64_t)phys[a] * M;
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                         }
-    #pragma unroll
+#pragma unroll
                         for (int h = 0; h < SU; h += SU / 2) {
                             int rs[SU / 2];
                             T so[SU / 2], iv[SU / 2], th[SU / 2];
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < SU / 2; ++u) {
                                 const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
                                 so[u] = sl[i];
@@ -1582,7 +1656,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                                 th[u] = thr[i];
                                 rs[u] = rowslot[i];
                             }
-    #pragma unroll
+#pragma unroll
                             for (int u = 0; u < SU / 2; ++u) {
                                 const int i = i0 + 64 * (h + u);
                                 const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[h + u];
@@ -1680,37 +1754,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             bool dirty = false;
             for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                 T fr[SU];
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                 int a = 0;
                 for (; a + 1 < nq; a += 2) {
                     const T la = lamv[a], lb = lamv[a + 1];
                     const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
                     T va[SU], vb[SU];
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < SU; ++u) {
                         const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                         va[u] = ha[i];
                         vb[u] = hb[i];
                     }
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
                 }
                 if (a < nq) {
                     const T la = lamv[a];
                     const T *ha = Hs + (int64_t)phys[a] * M;
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
                 }
                 T th[SU];
                 int rs[SU];
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                     th[u] = thr[i];
                     rs[u] = rowslot[i];
                 }
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const bool act = rs[u] >= 0;
                     if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
@@ -1776,7 +1850,8 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     // + c, r, multipliers, active rows, slot permutation, the sweeps' rows; FUSE: + the candidates' slots, the free list
     // and the 32 x 33 tile of W
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64 +
-                       (FUSE ? (size_t)(R + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0);
+                       (FUSE ? (size_t)(R_FUSE + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0) +
+                       (size_t)(FUSE ? R_FUSE : R_PLAIN) * sizeof(int);
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Dev tool: build variants of the wide stage-wise unit with different -D knobs into qpmpc_amd/lib/ab/<tag>.so
+# (all other objects are reused), for A/B runs on the GPU box with MPCQP_LIB=<that file>.
+# usage: tools/ab_stagew.sh tag "-DSTAGEW_D=8 -DSTAGEW_WPE32=2" [tag2 "flags2" ...]
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $R/qpmpc_amd/lib/ab
+OBJS=$(ls $R/qpmpc_amd/lib/obj/*.o | grep -v mpcqp_stagew)
+while [ $# -ge 2 ]; do
+  tag=$1; flags=$2; shift 2
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -I$R/include -I$R/qpmpc_amd/csrc -c $R/qpmpc_amd/csrc/mpcqp_stagew.hip -o $R/qpmpc_amd/lib/ab/$tag.o &&
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $R/qpmpc_amd/lib/ab/$tag.o -o $R/qpmpc_amd/lib/ab/$tag.so && rm $R/qpmpc_amd/lib/ab/$tag.o && echo built $tag ) &
+done
+wait
