@@ -778,6 +778,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int q = 0; q < NQ; ++q) gT[q] = (gC && r < mk && 4 * q + pg < nx) ? gC[r * nx + 4 * q + pg] : T(0);
         gT[NQ] = (gD && r < mk && pg < nu) ? gD[r * nu + pg] : T(0);
     }
+    // chunks of [C | D] that are zero in every lane cost no instruction (box constraints touch few states; under load the
+    // forward sweep is bound by the matrix pipe, three wavefronts sharing it)
+    bool gnz[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) gnz[q] = FUSE && __ballot(gT[q] != T(0)) != 0ull;
     // ... Ho (FUSE): h = G (x_k, u_k) of every step goes to Ho[k mk + r] (lanes with `on`; per column through hoff)
     auto forward = [&](const T *xs, int kff, T *Uo, unsigned uoff, T *Zo, unsigned zoff, bool on, T *Ho, unsigned hoff) {
         T z[NQ];
@@ -822,8 +827,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             if constexpr (FUSE) {
                 MV hk = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) hk = Mfma<T>::run(gT[q], z[q], hk);
-                hk = Mfma<T>::run(gT[NQ], u, hk);
+                for (int q = 0; q < NQ; ++q)
+                    if (gnz[q]) hk = Mfma<T>::run(gT[q], z[q], hk);
+                if (gnz[NQ]) hk = Mfma<T>::run(gT[NQ], u, hk);
                 if (on) {
                     Uo[uoff + (unsigned)(k * 4)] = u;
                     if (4 * pg < mk) *(V4 *)(Ho + (hoff + (unsigned)(k * mk + 4 * pg))) = hk;
@@ -1110,14 +1116,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         for (int q = 0; q <= NQ; ++q) nnv += gT[q] * gT[q];
         nnv += __shfl_xor(nnv, 16);
         nnv += __shfl_xor(nnv, 32);
-        for (int i = lane; i < M; i += 64) {
-            const int k = stepof(i), r = i - k * mk;
-            const T ev = ge[k * sE + r], sv = ev - sl[i];
-            s0[i] = sv;
-            sl[i] = sv;
-            thr[i] = tol + tol * (T)fabs((double)ev);
-            const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
-            invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+        for (int i0 = lane; i0 < M; i0 += 64 * SU) {  // (SU rows per lane with their loads in flight together)
+            T ev[SU], hv[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                const int k = stepof(i), r = i - k * mk;
+                ev[u] = ge[k * sE + r];
+                hv[u] = sl[i];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                const int r = i - stepof(i) * mk;
+                const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
+                if (i0 + 64 * u < M) {
+                    const T sv = ev[u] - hv[u];
+                    s0[i] = sv;
+                    sl[i] = sv;
+                    thr[i] = tol + tol * (T)fabs((double)ev[u]);
+                    invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+                }
+            }
         }
         for (int a = lane; a < maxq; a += 64) freel[a] = maxq + R - 1 - a;  // (popped from the end: slots R, R + 1, ...)
         if (lane < R) {
@@ -1375,25 +1395,64 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
             // refinement lam -= W rho_A puts them back, and a point that still fails is not reported solved)
             bool dirty = false;
             for (int pass = 0; pass < 2; ++pass) {
-                // residuals of the active rows through their own entries of the h_b (nq x nq gathers)
-                T worst = T(0);
+                // ONE pass over the rows: s = s0 + sum_a lam_a h_a with the slots' loads in flight in groups
+                constexpr int SG = STAGEW_SG;
+                bool offa = false;
+                dirty = false;
+                for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
+                for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                    T fr[SU], th[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                        fr[u] = s0[i];
+                        th[u] = thr[i];
+                    }
+                    for (int a = 0; a < nq; a += SG) {
+                        T la[SG], va[SG][SU];
+#pragma unroll
+                        for (int j = 0; j < SG; ++j) {
+                            const int aj = a + j < nq ? a + j : a;
+                            la[j] = a + j < nq ? lamv[aj] : T(0);
+                            const T *ha = Hs + (int64_t)phys[aj] * M;
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                        }
+#pragma unroll
+                        for (int j = 0; j < SG; ++j)
+#pragma unroll
+                            for (int u = 0; u < SU; ++u) fr[u] += la[j] * va[j][u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int i = i0 + 64 * u;
+                        if (i < M) {
+                            const bool act = th[u] == INF;
+                            if (act) {  // (rare) the row's own threshold is gone: from its bound
+                                const int k = stepof(i), r = i - k * mk;
+                                const T lim = T(1000) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
+                                offa |= !((T)fabs((double)fr[u]) <= lim);
+                            } else if (!(fr[u] >= T(-4) * th[u])) {
+                                dirty = true;
+                            }
+                            sl[i] = act ? T(0) : fr[u];
+                        }
+                    }
+                }
+                if (__ballot(offa) == 0ull) break;
+                if (pass == 1) {
+                    fail = true;
+                    break;
+                }
+                // (rare) an active row sits off its bound or a multiplier is not >= 0: residuals of the active rows through
+                // their own entries of the h_b, then lam -= W rho_A, and the pass again
                 for (int a = lane; a < nq; a += 64) {
                     const int ra = actrow[a];
                     T acc = s0[ra];
                     for (int b = 0; b < nq; ++b) acc += lamv[b] * Hs[(int64_t)phys[b] * M + ra];
                     cv[a] = acc;
-                    const int k = stepof(ra), r = ra - k * mk;
-                    const T lim = T(1000) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
-                    const T ex = (T)fabs((double)acc) - lim;
-                    worst = !(ex <= T(0)) || !(lamv[a] >= T(0)) ? INF : worst;
                 }
                 lsync();
-                const bool off = __ballot(worst > T(0)) != 0ull;
-                if (!off) break;
-                if (pass == 1) {
-                    fail = true;
-                    break;
-                }
                 auto refine = [&](const T *Wp, int ld) {
                     for (int a = lane; a < nq; a += 64) {
                         T acc = T(0);
@@ -1409,46 +1468,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 lsync();
             }
             if (fail) break;
-            T *ou = (T *)ka.U + prob * (int64_t)nvar;
-            for (int i = lane; i < nv4; i += 64) {
-                T u = U0[i];
-                for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
-                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
-            }
-            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                T fr[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                int a = 0;
-                for (; a + 1 < nq; a += 2) {
-                    const T la = lamv[a], lb = lamv[a + 1];
-                    const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                    T va[SU], vb[SU];
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                        va[u] = ha[i];
-                        vb[u] = hb[i];
-                    }
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) fr[u] += la * va[u] + lb * vb[u];
-                }
-                if (a < nq) {
-                    const T la = lamv[a];
-                    const T *ha = Hs + (int64_t)phys[a] * M;
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) fr[u] += la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                }
-                T th[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) th[u] = thr[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const bool act = th[u] == INF;
-                    if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
-                    if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
-                }
-            }
             dirty = __ballot(dirty) != 0ull;
             if (!dirty) {
                 status = MPCQP_SOLVED;
@@ -1459,9 +1478,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         tick(7);
         if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
         const bool ok = status == MPCQP_SOLVED;
-        if (!ok) {
+        {
+            // u = u0 - sum_a lam_a V_a (zero when there is no plan), four slots' loads in flight
             T *ou = (T *)ka.U + prob * (int64_t)nvar;
-            for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+            for (int i = lane; i < nv4; i += 64) {
+                T u = ok ? U0[i] : T(0);
+                for (int a = 0; ok && a < nq; a += 4) {
+                    T la[4], va[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int aj = a + j < nq ? a + j : a;
+                        la[j] = a + j < nq ? lamv[aj] : T(0);
+                        va[j] = Vs[(int64_t)phys[aj] * nv4 + i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u -= la[j] * va[j];
+                }
+                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
+            }
         }
         if (ka.lam) {
             T *ol = (T *)ka.lam + prob * (int64_t)M;
