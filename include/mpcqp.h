@@ -53,10 +53,13 @@ extern "C" {
 #define MPCQP_MAX_ITER 1
 #define MPCQP_INFEASIBLE 2
 #define MPCQP_NOT_PD 3
+#define MPCQP_SLOTS_FULL 4 /* stage-wise kernels only: more rows wanted to be active at once than the launch's max_active
+                              slots hold (possible when max_active < min(n, m), i.e. n, m > 128 / 256 with the defaults);
+                              solve the problem again with a larger max_active (the Python host does: solve_mpc_batch) */
 
 /* negative return codes */
 #define MPCQP_EINVAL (-1)    /* NULL/negative/inconsistent argument           */
-#define MPCQP_ETOOLARGE (-2) /* problem does not fit the on-chip (LDS) path   */
+#define MPCQP_ETOOLARGE (-2) /* no kernel for these dimensions: does not fit a CU's LDS and nx > 16 or nu > 4 with n > 256 */
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
 #define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
 #define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */
@@ -226,9 +229,11 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
  * This entry point solves the same QP as mpcqp_build_solve_batch -- same operands, same outputs, same
  * minimiser -- without forming P or G: Riccati gains once per problem, then per active-set iteration
  * one LQR solve (two sweeps over the horizon) and O(|A| N) vector work; O(N) memory. No cap on
- * N; float64, 2 <= nx <= 4, 1 <= nu <= 2 (MPCQP_EUNSUPPORTED otherwise). `max_active` bounds the number
- * of simultaneously active rows (<= 0: min(n, m, 128)); a problem that needs more returns
- * status MPCQP_MAX_ITER. The workspace is caller-owned (mpcqp_stagewise_workspace_bytes). */
+ * N; float64 with 2 <= nx <= 4, 1 <= nu <= 2 (chunked scans over the horizon), or float64 / float32 with nx <= 16,
+ * nu <= 4 (matrix-core sweeps; MPCQP_EUNSUPPORTED otherwise). `max_active` bounds the number of simultaneously active
+ * rows (<= 0: min(n, m, 128)); a problem that needs more returns status MPCQP_SLOTS_FULL. The workspace is caller-owned
+ * (mpcqp_stagewise_workspace_bytes). mpcqp_build_solve_batch reaches the same kernels by itself for every problem that
+ * does not fit the on-chip condensed kernels (any n = N nu). */
 int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes);
 int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
                                 const MpcqpSolveOpts *opts, int32_t max_active, void *U, void *lam,

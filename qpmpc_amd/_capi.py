@@ -12,7 +12,7 @@ from .exceptions import BackendError
 
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
-SOLVED, MAX_ITER, INFEASIBLE, NOT_PD = 0, 1, 2, 3
+SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EUNSUPPORTED = -6
 ABI_VERSION = 6
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
@@ -166,9 +166,8 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().mpcqp_error_string(code).decode()
         if code == -2:  # MPCQP_ETOOLARGE: name the envelope instead of leaving the caller guessing
-            msg += (". Supported by the dense condensed path: n = N*nu <= 256 variables; problems that do not fit "
-                    "160 KiB of LDS additionally need nx <= 16. Longer horizons: solve_mpc_batch(..., "
-                    "formulation='stagewise')")
+            msg += (". Served: everything that fits 160 KiB of LDS; beyond that any horizon for systems with nx <= 16, "
+                    "nu <= 4 (stage-wise kernels) and n = N*nu <= 256 variables for wider systems (dense HBM-resident path)")
         raise BackendError(f"{what} failed with code {code}: {msg}")
 
 

@@ -196,6 +196,19 @@ class BatchMPCProblem:
             )
         self.target_states = t.contiguous()
 
+    def select(self, index) -> "BatchMPCProblem":
+        """The sub-batch of the problems ``index`` (a 1-D int64 device tensor): per-problem operands are gathered,
+        shared ones (batch dimension 1) stay shared."""
+        sub = BatchMPCProblem.__new__(BatchMPCProblem)
+        sub.__dict__.update(self.__dict__)
+        for name in ("A", "B", "C", "D", "e", "initial_state", "goal_state", "target_states"):
+            t = getattr(self, name)
+            if t is not None and t.shape[0] != 1:
+                setattr(sub, name, t.index_select(0, index).contiguous())
+        if self.initial_state.shape[0] == 1:  # (a batch of one keeps its only problem)
+            sub.initial_state = self.initial_state
+        return sub
+
     # ------------------------------------------------------------ C ABI views
     def cost_flags(self) -> int:
         """MPCQP_P_* / MPCQP_Q_* bits (see include/mpcqp.h for why they differ)."""
@@ -451,13 +464,17 @@ class BatchPlan:
 
 def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_multipliers: bool = False,
                     max_iter: Optional[int] = None, feas_tol: Optional[float] = None, formulation: str = "condensed",
-                    max_active: Optional[int] = None, **opt_kw) -> BatchPlan:
+                    max_active: Optional[int] = None, retry_slots: bool = True, **opt_kw) -> BatchPlan:
     """Build and solve every problem of the batch in ONE fused launch
-    (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem).
+    (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem). Any problem size is served: what does not
+    fit one CU's LDS goes to the stage-wise kernels (systems with nx <= 16, nu <= 4, any horizon) or, for wider systems
+    with n = N*nu <= 256, to the dense HBM-resident path.
 
-    ``formulation="stagewise"`` solves the same QP without condensing it (``mpcqp_stagewise_solve_batch``:
-    Riccati-based dual active set, O(N) memory and O(N) work per iteration, no cap on the horizon;
-    float64, nx <= 4, nu <= 2); ``max_active`` bounds the active rows it can hold (default min(n, m, 128)).
+    ``formulation="stagewise"`` asks for the uncondensed solver explicitly (``mpcqp_stagewise_solve_batch``:
+    Riccati-based dual active set, O(N) memory and O(N) work per iteration); ``max_active`` bounds the active rows
+    it can hold (default min(n, m, 128)). A problem that needs more comes back ``MPCQP_SLOTS_FULL`` from the kernel and
+    -- ``retry_slots`` -- is solved again with twice the slots until it fits (this reads the statuses: a
+    synchronisation, only for problems with more than 128 variables and rows).
 
     ``opt_kw``: ``warm_state`` (a :class:`WarmState`, updated by every solve) with ``warm_start=True``
     to begin from it, ``flags`` (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
@@ -485,6 +502,8 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
         _capi.check(rc, "mpcqp_stagewise_solve_batch")
         plan = BatchPlan(problem, U, status, iters, lam)
         plan._workspace = (ws, opt_kw)
+        if retry_slots:
+            _retry_slots_full(plan, int(max_active or 128), max_iter, feas_tol, opt_kw)
         return plan
     if formulation != "condensed":
         raise ProblemDefinitionError(f"formulation must be 'condensed' or 'stagewise', not {formulation!r}")
@@ -495,7 +514,37 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     _capi.check(rc, "mpcqp_build_solve_batch")
     plan = BatchPlan(problem, U, status, iters, lam)
     plan._workspace = (ws, opt_kw)  # keep the scratch (and the opts' tensors) alive until the stream has consumed them
+    if retry_slots and min(n, m) > 128:
+        # (the stage-wise kernels take what does not fit on chip; the narrow one holds 128 active rows by default, the
+        # wide one 256 -- mpcqp_capi.hip)
+        narrow = problem.dtype == torch.float64 and problem.state_dim <= 4 and problem.input_dim <= 2
+        _retry_slots_full(plan, 128 if narrow else 256, max_iter, feas_tol, opt_kw)
     return plan
+
+
+def _retry_slots_full(plan: "BatchPlan", held: int, max_iter, feas_tol, opt_kw) -> None:
+    """Problems that came back ``MPCQP_SLOTS_FULL`` -- more rows active at once than the launch's ``held`` slots -- are
+    solved again through the stage-wise entry point with twice the slots, until they fit (at most min(n, m) rows can
+    be active) -- the reference's backends have no such cap (solve_mpc.py:42-44). Reading the statuses synchronises;
+    this is only reached for problems with more than 128 variables and rows, where the cap exists."""
+    torch = _torch()
+    problem = plan.problem
+    cap = min(problem.nb_variables, problem.nb_constraints)
+    kw = {k: v for k, v in opt_kw.items() if k not in ("warm_state", "warm_start", "probe")}
+    while held < cap:
+        full = plan.status == _capi.SLOTS_FULL
+        if not bool(full.any().item()):
+            return
+        index = full.nonzero().flatten()
+        held = min(2 * held, cap)
+        again = solve_mpc_batch(problem.select(index), return_multipliers=plan.multipliers is not None, max_iter=max_iter,
+                                feas_tol=feas_tol, formulation="stagewise", max_active=held, retry_slots=False, **kw)
+        plan.U.index_copy_(0, index, again.U)
+        plan.status.index_copy_(0, index, again.status)
+        plan.iters.index_copy_(0, index, again.iters)
+        if plan.multipliers is not None:
+            plan.multipliers.index_copy_(0, index, again.multipliers)
+        plan._states = None
 
 
 class PreparedSolve:

@@ -124,6 +124,15 @@ bool use_stagew_auto(const KernelArgs &ka, int dtype)
     return !(ka.opt_flags & override_bits) && !ka.warm_state && stagew_supported(ka, dtype) && ka.m >= 1 &&
            !fits_on_chip(ka, true, true, MODE_FUSED, dtype);
 }
+// ... and the narrow stage-wise kernel (float64, nx <= 4, nu <= 2: chunked scans, depth ~2 N / 64 per sweep instead of N
+// serial steps) takes what does not fit on chip among the systems it serves: horizons of any length (n > 256 included)
+bool use_stage_long(const KernelArgs &ka, int dtype)
+{
+    const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
+                              MPCQP_OPT_ONE_PER_WAVE;
+    return !(ka.opt_flags & override_bits) && !ka.warm_state && stage_supported(ka, dtype) && ka.m >= 1 && ka.n > 128 &&
+           !fits_on_chip(ka, true, true, MODE_FUSED, dtype);
+}
 int stagew_auto_maxq(const KernelArgs &ka)
 {
     const int q = ka.n < ka.m ? ka.n : ka.m;
@@ -241,7 +250,7 @@ const char *mpcqp_error_string(int code)
     switch (code) {
     case 0: return "ok";
     case MPCQP_EINVAL: return "invalid argument";
-    case MPCQP_ETOOLARGE: return "problem does not fit the on-chip (LDS) path";
+    case MPCQP_ETOOLARGE: return "no kernel for these dimensions (does not fit a CU's LDS; the stage-wise kernels serve nx <= 16, nu <= 4; the dense HBM-resident path n <= 256)";
     case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
     case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
     case MPCQP_EWORKSPACE: return "workspace missing or too small (see mpcqp_workspace_bytes)";
@@ -287,6 +296,7 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
     // The query sees dimensions, not operand strides or MpcqpSolveOpts.flags, while the launch picks its kernel
     // with both (bulkier operands need more LDS): report the LARGEST workspace any path the launch may take needs.
     size_t need = 0;
+    bool served = false;  // the automatic dispatch (fl == 0, first) has a kernel for these dimensions
     for (int fl : kFlagVariants) {
         ka.opt_flags = fl;
         const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
@@ -296,15 +306,24 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
             const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
             if (sw > v) v = sw;
         }
+        if (for_solve && use_stage_long(ka, dims->dtype)) {
+            const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+            if (sw > v) v = sw;
+            served = true;
+        }
         if (for_solve && use_stagew_auto(ka, dims->dtype)) {
             const size_t sw = stagew_ws_elems(ka, stagew_auto_maxq(ka), dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
             if (sw > v) v = sw;
+            served = true;
         } else if (!fits_on_chip(ka, true, true, mode, dims->dtype)) {
             if (big_supported(ka) && ka.n <= 256) {
                 const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
                 const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
                 if (big > v) v = big;
-            } else if (!maybe_mid) {
+                served = true;
+            } else if (!maybe_mid && fl == 0 && !served) {
+                // (only the automatic dispatch decides: an override combination that has no kernel for these
+                // dimensions is refused by the launch that carries it, not by the size query)
                 return MPCQP_ETOOLARGE;
             }
         }
@@ -459,6 +478,12 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     }
     if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
         return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
+    if (use_stage_long(ka, dims->dtype)) {
+        const int maxq = stage_default_maxq(ka);
+        const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_stage(ka, maxq, batch, workspace, st);
+    }
     if (use_stagew_auto(ka, dims->dtype)) {
         const int maxq = stagew_auto_maxq(ka);
         const size_t need = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;

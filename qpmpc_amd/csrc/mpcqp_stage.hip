@@ -950,7 +950,7 @@ __global__ void __launch_bounds__(64, 2)
     const int max_iter = ka.max_iter;
     const int nvar = N * NU;
     double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
-    bool fail = false;
+    bool fail = false, slotsfull = false;
     for (int round = 0; round < 4 && !fail && !notpd; ++round) {
         for (;;) {
             // ---- selection: the violated row farthest from its hyperplane
@@ -1037,7 +1037,8 @@ __global__ void __launch_bounds__(64, 2)
                 }
                 const bool full = (t2 <= t1);
                 if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
-                    fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
+                    fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_SLOTS_FULL
+                    slotsfull = true;
                     break;
                 }
                 // ---- slacks: s_i -= t g_i . z ,  z = -(V_p - sum_a r_a V_a)  (this lane's chunk)
@@ -1190,6 +1191,7 @@ __global__ void __launch_bounds__(64, 2)
     }
     tick(7);
     if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+    if (slotsfull) status = MPCQP_SLOTS_FULL;
     if (notpd) status = MPCQP_NOT_PD;
     const bool ok = status == MPCQP_SOLVED;
     if (!ok) {

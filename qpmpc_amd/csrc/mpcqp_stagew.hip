@@ -1148,7 +1148,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         tick(5);
         int nq = 0, nfree = maxq, iters = 0, status = MPCQP_MAX_ITER;
         const int max_iter = ka.max_iter;
-        bool fail = false, havesel = false, wglob = false;
+        bool fail = false, havesel = false, wglob = false, slotsfull = false;
         T nbest = INF, nsp = T(0);
         int nbi = 0x7fffffff;
         for (int round = 0; round < 4 && !fail; ++round) {
@@ -1241,8 +1241,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                         break;
                     }
                     const bool full = (t2 <= t1);
-                    if (full && nq >= maxq) {  // every slot is taken (max_active < min(n, m)) -> MPCQP_MAX_ITER
+                    if (full && nq >= maxq) {  // every slot is taken (max_active < min(n, m)) -> MPCQP_SLOTS_FULL
                         fail = true;
+                        slotsfull = true;
                         break;
                     }
                     tacc(12);
@@ -1477,6 +1478,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         }
         tick(7);
         if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+        if (slotsfull) status = MPCQP_SLOTS_FULL;
         const bool ok = status == MPCQP_SOLVED;
         {
             // u = u0 - sum_a lam_a V_a (zero when there is no plan), four slots' loads in flight
@@ -1550,7 +1552,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         // ================================================================= active-set loop
         int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
         const int max_iter = ka.max_iter;
-        bool fail = false, havesel = false;
+        bool fail = false, havesel = false, slotsfull = false;
         T nbest = INF, nsp = T(0);
         int nbi = 0x7fffffff;
         for (int round = 0; round < 4 && !fail; ++round) {
@@ -1644,7 +1646,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                     }
                     const bool full = (t2 <= t1);
                     if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
-                        fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_MAX_ITER
+                        fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_SLOTS_FULL
+                        slotsfull = true;
                         break;
                     }
                     tacc(12);
@@ -1835,6 +1838,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
         }
         tick(7);
         if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+        if (slotsfull) status = MPCQP_SLOTS_FULL;
         const bool ok = status == MPCQP_SOLVED;
         if (!ok) {
             T *ou = (T *)ka.U + prob * (int64_t)nvar;

@@ -40,10 +40,12 @@ def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) 
             to a dual active-set method -- qpsolvers' quadprog wrapper ignores it the same way, with a
             warning) and ``verbose``. Any other keyword raises ``TypeError``: nothing is dropped silently.
 
-    Supported sizes of the HIP path: ``n = N*nu <= 256`` variables when the problem does not fit one
-    CU's LDS (then ``nx <= 16``); beyond that the C ABI returns ``MPCQP_ETOOLARGE`` and a
-    ``BackendError`` naming the limit is raised (the stage-wise solver ``formulation="stagewise"`` of
-    ``solve_mpc_batch`` has no such cap on the horizon).
+    Supported sizes of the HIP path: any. Problems that fit one CU's LDS take the fused on-chip kernels; beyond
+    that the stage-wise kernels serve systems with ``nx <= 16``, ``nu <= 4`` for any horizon (n = N*nu of 1024 or
+    4096 included; a problem that wants more rows active at once than the kernel's slots hold is solved again
+    with more slots), and wider systems go to the dense HBM-resident path up to ``n = N*nu <= 256`` (a slow
+    fallback: DESIGN.md 3.3). Only ``nx > 16`` or ``nu > 4`` together with ``n > 256`` has no kernel
+    (``MPCQP_ETOOLARGE`` -> ``BackendError`` naming the envelope).
 
     Returns:
         A ``Plan``; empty (``is_empty``) when no solution was found.

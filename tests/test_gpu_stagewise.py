@@ -74,8 +74,8 @@ def test_stagewise_equals_condensed_path_on_configs_2_and_3():
 
 
 def test_stagewise_runs_where_the_condensed_path_is_too_large():
-    """N = 1024 (n = 1024 > 256): mpcqp_build_solve_batch returns MPCQP_ETOOLARGE, the stage-wise path solves a
-    batch of 64 different problems; every solution is KKT-certified without any condensed matrix."""
+    """N = 1024 (n = 1024 > 256, where the dense kernels stop): the stage-wise path solves a batch of 64 different problems
+    -- through the default entry point too --; every solution is KKT-certified without any condensed matrix."""
     from oracle import stagewise_np as S
     from qpmpc_amd import BackendError, BatchMPCProblem, solve_mpc_batch
 
@@ -88,10 +88,12 @@ def test_stagewise_runs_where_the_condensed_path_is_too_large():
     big = BatchMPCProblem(bp.A[0, 0], bp.B[0, 0], bp.C[0, 0], None, bp.e[0, 0], 1024, p.terminal_cost_weight,
                           p.stage_state_cost_weight, p.stage_input_cost_weight, x0, goal_state=goal,
                           target_states=np.tile(goal, (1, 1024)))
-    with pytest.raises(BackendError, match="-2"):
-        solve_mpc_batch(big)
+    # (round 3) the default entry point serves it as well: what does not fit on chip goes to the stage-wise kernels
+    auto = solve_mpc_batch(big)
     plan = solve_mpc_batch(big, formulation="stagewise", return_multipliers=True)
     torch.cuda.synchronize()
+    assert (auto.status.cpu().numpy() == 0).all()
+    assert np.abs(auto.U.cpu().numpy() - plan.U.cpu().numpy()).max() <= 1e-9 * max(1.0, float(plan.U.abs().max()))
     st = plan.status.cpu().numpy()
     assert (st == 0).all(), st
     U, lam = plan.U.cpu().numpy(), plan.multipliers.cpu().numpy()
@@ -257,7 +259,7 @@ def test_wide_stagewise_kernel_float32_random_ltv(nx, nu, N, mk):
 
 def test_wide_stagewise_kernel_infeasible_and_slot_overflow_statuses():
     """Contradictory rows (u_0 <= -1 and -u_0 <= -1) are reported MPCQP_INFEASIBLE with a zeroed plan, like the dense path;
-    a problem that needs more active rows than max_active allows comes back unsolved (MAX_ITER), never a wrong plan."""
+    a problem that needs more active rows than max_active allows comes back unsolved (SLOTS_FULL), never a wrong plan."""
     from qpmpc_amd import solve_mpc_batch
     from qpmpc_amd import workloads as W
 
@@ -279,7 +281,7 @@ def test_wide_stagewise_kernel_infeasible_and_slot_overflow_statuses():
     assert float(plan.U[4:].abs().max()) == 0.0
     assert float((plan.U[:4] - dense.U[:4]).abs().max()) <= 1e-8
     # slot overflow: one slot only
-    tight = solve_mpc_batch(bp, formulation="stagewise", max_active=1)
+    tight = solve_mpc_batch(bp, formulation="stagewise", max_active=1, retry_slots=False)
     torch.cuda.synchronize()
     need = plan.iters.cpu().numpy()
     st1 = tight.status.cpu().numpy()
@@ -287,8 +289,13 @@ def test_wide_stagewise_kernel_infeasible_and_slot_overflow_statuses():
         if st1[b] == 0:
             assert float((tight.U[b] - plan.U[b]).abs().max()) <= 1e-9
         else:
-            assert st1[b] == 1 and need[b] > 1 and float(tight.U[b].abs().max()) == 0.0  # MPCQP_MAX_ITER = 1
+            assert st1[b] == 4 and need[b] > 1 and float(tight.U[b].abs().max()) == 0.0  # MPCQP_SLOTS_FULL = 4
     assert (st1[:4] != 0).any()
+    # ... and the host solves those again with more slots (the default)
+    again = solve_mpc_batch(bp, formulation="stagewise", max_active=1)
+    torch.cuda.synchronize()
+    assert np.array_equal(again.status.cpu().numpy(), st)
+    assert float((again.U - plan.U).abs().max()) <= 1e-9
 
 
 def test_stagewise_kernels_keep_going_when_every_slot_is_taken():
@@ -377,3 +384,50 @@ def test_indefinite_hessian_is_status_not_pd_on_the_mpc_path(case):
         plan = solve_mpc_batch(W.to_batch_problem(w, dtype=dt), flags=_capi.OPT_FORCE_CONDENSED)
         torch.cuda.synchronize()
         assert (plan.status.cpu().numpy() == 3).all()
+
+
+@pytest.mark.parametrize("name", ["stagewise_triple_n1024", "stagewise_triple_n1024_b"])
+def test_solve_mpc_takes_any_horizon_through_the_default_entry_point(name):
+    """solve_mpc(problem, "hip_gi") -- the reference's own call, solve_mpc.py:42-44 -- on the N = 1024 fixtures (n = 1024:
+    the dense kernels stop at 256): the minimiser of the REFERENCE-built dense QP to 1e-7 |U|, states rolled out."""
+    from qpmpc_amd import solve_mpc
+
+    p, f = _load(name)
+    plan = solve_mpc(p, "hip_gi")
+    assert not plan.is_empty
+    U = np.asarray(plan.inputs).ravel()
+    Us = f["U_star"].ravel()
+    assert np.abs(U - Us).max() <= 1e-7 * max(1.0, np.abs(Us).max())
+    assert plan.states.shape == (1025, 3)
+
+
+def test_slot_overflow_is_retried_with_more_slots():
+    """N = 4096 (n = 4096, m = 16384): with the default 128 slots a few problems want more rows active at once and the kernel
+    reports MPCQP_SLOTS_FULL (4) for them; solve_mpc_batch solves those again with 256, 512, ... slots: 100 % solved, and the
+    re-solved ones equal a solve that had enough slots from the start."""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from bench_stagewise import long_batch
+    from qpmpc_amd import _capi, solve_mpc_batch
+
+    bp = long_batch(192, 4096, 1.0 / 128)
+    raw = solve_mpc_batch(bp, retry_slots=False)
+    torch.cuda.synchronize()
+    st = raw.status.cpu().numpy()
+    assert set(np.unique(st)) <= {0, _capi.SLOTS_FULL}
+    plan = solve_mpc_batch(bp)
+    torch.cuda.synchronize()
+    assert (plan.status.cpu().numpy() == 0).all()
+    if (st == _capi.SLOTS_FULL).any():
+        idx = np.flatnonzero(st == _capi.SLOTS_FULL)
+        sub = bp.select(torch.as_tensor(idx, device=bp.device))
+        wide = solve_mpc_batch(sub, formulation="stagewise", max_active=1024, retry_slots=False)
+        torch.cuda.synchronize()
+        assert (wide.status.cpu().numpy() == 0).all()
+        a, b = plan.U.cpu().numpy()[idx], wide.U.cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())
+    ok = st == 0
+    assert np.array_equal(plan.U.cpu().numpy()[ok], raw.U.cpu().numpy()[ok])
