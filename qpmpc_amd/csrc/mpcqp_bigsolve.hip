@@ -1167,7 +1167,8 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
             for (int i = tid; i < m; i += BS) {
                 const T hi = tolv[i];  // h was parked here by the front end
                 sv[i] = hi - mid_row(i);
-                tolv[i] = (hi < T(1e29)) ? tol + tol * fabs(hi) : INF;
+                // (no room for h itself in LDS: the tolerance carries its sign, the acceptance test at the end recovers it)
+                tolv[i] = (hi < T(1e29)) ? (T)copysign((double)(tol + tol * fabs(hi)), (double)hi) : INF;
                 pos[i] = -1;
             }
         } else if constexpr (STRUCT) {
@@ -1234,7 +1235,7 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
             int bi = 0x7fffffff;
             for (int i = tid; i < m; i += BS) {
                 const T s = sv[i];
-                if (pos[i] < 0 && s < -tolv[i]) {
+                if (pos[i] < 0 && s < -(T)fabs(tolv[i])) {
                     const T key = s * gin[i];
                     if (key < best) {
                         best = key;
@@ -1483,6 +1484,40 @@ __global__ void __launch_bounds__(64 * NWV, (KIND == 2 && NWV == 4 && sizeof(T) 
                 if (tid < n) zx[tid] = a;
             }
             __syncthreads();
+            // Acceptance, from scratch: every ACTIVE row must sit on its bound (the loop only ever looks at inactive
+            // rows, and sets the active ones' slacks to zero). On an inconsistent problem a row that depends on the
+            // active ones can slip past the pivot test on rounding noise -- float32 (4, 1, 50, 2) of the fuzz test came
+            // back 'solved' with |u| ~ 2e6 and rows violated by 6e6 -- and then the active rows are far off.
+            if (status == MPCQP_SOLVED) {
+                // |residual| <= (1 + |h_i|) max(1e3 tol, 1e-6): the contract's 1e-6 in float64 (no refinement step here: an
+                // ill-conditioned but legitimate plan leaves ~1e-8), 1e-2 in float32
+                const T kacc = T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol;
+                bool bad = false;
+                if constexpr (MID) {
+                    rollout();
+                    for (int a = tid; a < nq; a += BS) {
+                        const int i = act[a];
+                        const T tv = tolv[i], hi = (T)copysign((double)(((T)fabs(tv) - tol) / tol), (double)tv);
+                        bad |= !((T)fabs(hi - mid_row(i)) <= kacc * (T)fabs(tv)) || !(lam[a] >= T(0));
+                    }
+                } else if constexpr (STRUCT) {
+                    rollout();
+#pragma unroll
+                    for (int j = 0; j < RS; ++j) {
+                        const int i = tid + BS * j;
+                        if (i < m && pos[i] >= 0) bad |= !((T)fabs(h[i] - struct_row(j)) <= kacc * tolv[i]);
+                    }
+                } else {
+                    for (int a = tid; a < nq; a += BS) {
+                        const int i = act[a];
+                        T dot = T(0);
+                        for (int k = 0; k < n; ++k) dot += GT[(int64_t)k * m + i] * zx[k];
+                        bad |= !((T)fabs(h[i] - dot) <= kacc * tolv[i]) || !(lam[a] >= T(0));
+                    }
+                }
+                if (tid < n) bad |= !(zx[tid] - zx[tid] == T(0));  // (finite)
+                if (__syncthreads_or(bad)) status = MPCQP_MAX_ITER;
+            }
         }
         if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
     }

@@ -431,3 +431,26 @@ def test_slot_overflow_is_retried_with_more_slots():
         assert np.abs(a - b).max() <= 1e-7 * max(1.0, np.abs(b).max())
     ok = st == 0
     assert np.array_equal(plan.U.cpu().numpy()[ok], raw.U.cpu().numpy()[ok])
+
+
+def test_config5_at_the_per_gpu_size_through_the_default_dispatch_against_the_oracle():
+    """BASELINE configs[4] at the size ONE GPU of the eight gets (1024 of the 8192 problems, bench.py's own slice), through
+    the default entry point (-> wide stage-wise kernel): float32 at the config's 1e-3, float64 at 1e-7, against the C oracle
+    on every host core (280 problems/s there: a few seconds)."""
+    from oracle.parallel import solve_workload_parallel
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    w = W.synthetic_ltv_batch_slice(0, 1024)
+    Uo, _, sto, _ = solve_workload_parallel(w, shard_workload)
+    assert (sto == 0).all()
+    scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+    p32 = solve_mpc_batch(W.to_batch_problem(w, dtype=torch.float32))
+    p64 = solve_mpc_batch(W.to_batch_problem(w))
+    torch.cuda.synchronize()
+    assert (p32.status == 0).all() and (p64.status == 0).all()
+    e32 = float((np.abs(p32.U.double().cpu().numpy() - Uo) / scale).max())
+    e64 = float((np.abs(p64.U.cpu().numpy() - Uo) / scale).max())
+    print("config 5, 1024 problems: float32", e32, "float64", e64, "mean iterations", float(p32.iters.float().mean()))
+    assert e32 <= 1e-3 and e64 <= 1e-7
