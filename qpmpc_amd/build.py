@@ -7,6 +7,8 @@ library travels to the GPU box with the tree.
 """
 from __future__ import annotations
 
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -17,7 +19,8 @@ _ROOT = os.path.dirname(_PKG)
 _UNITS = ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_pair.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip",
           "mpcqp_model.hip", "mpcqp_stage.hip", "mpcqp_stagew.hip", "mpcqp_capi.hip")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in _UNITS]
-HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h"), os.path.join(_PKG, "csrc", "mpcqp_internal.h")]
+# every header a unit may include: the public one and everything under csrc/ (mpcqp_internal.h, mpcqp_plant.h, ...)
+HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h")] + sorted(glob.glob(os.path.join(_PKG, "csrc", "*.h")))
 LIB_PATH = os.path.join(_PKG, "lib", "libmpcqp_hip.so")
 OBJ_DIR = os.path.join(_PKG, "lib", "obj")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
@@ -41,12 +44,14 @@ def is_stale() -> bool:
     return any(os.path.getmtime(s) > t for s in _sources() + HEADERS)
 
 
-def _obj_for(src: str) -> str:
-    return os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+def _obj_for(src: str, extra=()) -> str:
+    # the flags are part of the object's name: an object built with other flags is never reused
+    tag = hashlib.sha1(" ".join([*FLAGS, *extra]).encode()).hexdigest()[:8]
+    return os.path.join(OBJ_DIR, f"{os.path.basename(src)}.{tag}.o")
 
 
 def _compile(src: str, force: bool, verbose: bool, extra) -> str:
-    obj = _obj_for(src)
+    obj = _obj_for(src, extra)
     deps = [src] + HEADERS
     if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
         return obj

@@ -71,8 +71,8 @@ class WIPClosedLoop:
         self._ramp = torch.arange(N + 1, device=dev, dtype=dt) * (T * self.target_vel)
         self.mpc_steps = 0
         self._stats = torch.zeros((2,), dtype=torch.int64, device=dev)  # [failed, sum of iterations], mpcqp_accumulate_stats
-        self.failed, self.iters_total = self._stats[0], self._stats[1]
-        # per-loop [failed, iterations] counters of the fused period (no atomics in the solver kernel's epilogue)
+        # per-loop [failed, iterations] counters of the fused period (no atomics in the solver kernel's epilogue);
+        # the public counters ``failed`` / ``iters_total`` (properties below) add both
         self._loopstats = torch.zeros((self.problem.batch_size, 2), dtype=torch.int64, device=dev)
         self._fused = bool(fused_period) and not shared_model  # cleared by the first launch if the kernel cannot do it
         self._period_args = None
@@ -99,10 +99,20 @@ class WIPClosedLoop:
 
         self.states.copy_(torch.as_tensor(np.asarray(x0, dtype=float), dtype=self.states.dtype, device=self.states.device))
         self.mpc_steps = 0
-        self.failed.zero_()
-        self.iters_total.zero_()
+        self._stats.zero_()
         self._loopstats.zero_()
         # (the kept factor stays valid across episodes: it depends on the dynamics and the weights only)
+
+    @property
+    def failed(self):
+        """0-d int64 device tensor: periods of any loop whose plan was not found, whichever launch counted them
+        (the two-launch period's global counter + the fused period's per-loop counters)."""
+        return self._stats[0] + self._loopstats[:, 0].sum()
+
+    @property
+    def iters_total(self):
+        """0-d int64 device tensor: active-set iterations of all solves so far."""
+        return self._stats[1] + self._loopstats[:, 1].sum()
 
     def step(self, nb_mpc_steps: int = 1):
         """Advance every loop by ``nb_mpc_steps`` MPC periods: per period one solver launch
@@ -146,8 +156,8 @@ class WIPClosedLoop:
             "loops": B,
             "mpc_steps": self.mpc_steps,
             "builds_and_solves": self.mpc_steps * B,
-            "failed": int(self.failed.item()) + int(self._loopstats[:, 0].sum().item()),
-            "mean_iters": (float(self.iters_total.item()) + float(self._loopstats[:, 1].sum().item())) / solves,
+            "failed": int(self.failed.item()),
+            "mean_iters": float(self.iters_total.item()) / solves,
         }
 
 

@@ -746,13 +746,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                 a0 = start;
                 ffk = ffstart;
             }
-#ifndef STAGEW_DBG_NOSTORE
             if (colr) ffv[ffo + (unsigned)(k * 4)] = ffk;
-#endif
             st = a0;
-#ifndef STAGEW_DBG_NOLOAD
             if (again) req(d, k - D >= 0 ? k - D : 0);
-#endif
         };
         // full groups of D steps (every step re-requests: same loads in flight on every path), then the remainder
         int k = kstart;

@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/qpmpc_amd/lib/ab
-OBJS=$(ls $R/qpmpc_amd/lib/obj/*.o | grep -v mpcqp_stagew)
+OBJS=$(ls -t $R/qpmpc_amd/lib/obj/*.o | grep -v mpcqp_stagew | awk -F/ '{split($NF,a,"."); if (!(a[1] in seen)) {seen[a[1]]=1; print}}')
 while [ $# -ge 2 ]; do
   tag=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $flags -I$R/include -I$R/qpmpc_amd/csrc -c $R/qpmpc_amd/csrc/mpcqp_stagew.hip -o $R/qpmpc_amd/lib/ab/$tag.o &&
