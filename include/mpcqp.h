@@ -125,6 +125,17 @@ typedef struct MpcqpProblem {
                                       targets / e change: the reference's update_cost_vector / update_constraint_vector
                                       usage, mpc_qp.py:129-163). Ignored by the other kernels (they rebuild).          */
 
+#define MPCQP_OPT_PIPELINE_FACTOR 256 /* stage-wise kernel (float64, nx <= 4, nu <= 2, horizons whose factor fits LDS: N <= 64
+                                      for nx = 4, nu = 1): TWO wavefronts per problem. One solves with the factor image
+                                      `factor_slot` that a previous launch left in the workspace (as REUSE_FACTOR); the other,
+                                      concurrently on another SIMD, factors the problem's operands as they are NOW into the
+                                      other image, for the NEXT launch (which passes factor_slot ^ 1). The factor is still
+                                      rebuilt once per launch -- what the reference's solve_mpc does every period,
+                                      solve_mpc.py:42 -- but off the critical path. Contract: the operands A, B and the weights
+                                      this launch sees are the ones the next launch will solve with (time-invariant or
+                                      pre-scheduled dynamics); the first launch of a sequence uses KEEP_FACTOR.
+                                      MPCQP_EUNSUPPORTED for other dimensions. */
+
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
     int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */
@@ -149,7 +160,8 @@ typedef struct MpcqpSolveOpts {
      * MPCQP_EUNSUPPORTED when warm_state is given. */
     void *warm_state;
     int32_t warm_start;
-    int32_t reserved;
+    int32_t factor_slot; /* 0 | 1: the factor image of the stage-wise workspace that KEEP_FACTOR writes, REUSE_FACTOR and
+                            PIPELINE_FACTOR read (PIPELINE_FACTOR writes the other one). 0 unless a loop alternates them. */
     /* Developer probe, NULL in production: DEVICE buffer of int64 per problem (16 for the small-problem
      * kernels, 32 for the mid-size / large ones) that receives shader-clock stamps at phase boundaries. */
     void *probe;

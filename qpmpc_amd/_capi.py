@@ -16,7 +16,7 @@ SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EUNSUPPORTED = -6
 ABI_VERSION = 6
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
-OPT_KEEP_FACTOR, OPT_REUSE_FACTOR = 64, 128
+OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR = 64, 128, 256
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -67,7 +67,7 @@ class Problem(C.Structure):
 class SolveOpts(C.Structure):
     _fields_ = [
         ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
-        ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("reserved", C.c_int32),
+        ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("factor_slot", C.c_int32),
         ("probe", C.c_void_p), ("warm_state_bytes", C.c_size_t),
     ]
 

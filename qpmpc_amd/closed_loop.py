@@ -44,13 +44,18 @@ class WIPClosedLoop:
 
     def __init__(self, x0, nb_timesteps: int = 50, sampling_period: float = 0.024, target_vel: float = 0.5,
                  ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False, fused_period: bool = True,
-                 reuse_factor: bool = False):
+                 reuse_factor: bool = False, pipeline_factor: bool = False):
         """``fused_period``: run a whole period (solve + plant + next problem + bookkeeping) in ONE launch,
         ``mpcqp_wip_period_batch``, where the solver kernel supports it (else, and with ``shared_model``, two
         launches per period). ``reuse_factor``: the dynamics and weights never change along the loop, so the
         stage-wise kernel keeps its Riccati factor in the workspace after the first period and starts from it
         afterwards (``MPCQP_OPT_KEEP_FACTOR`` / ``MPCQP_OPT_REUSE_FACTOR``: build once, re-solve -- the reference's
-        ``update_cost_vector`` / ``update_constraint_vector`` usage; ignored by kernels that rebuild anyway)."""
+        ``update_cost_vector`` / ``update_constraint_vector`` usage; ignored by kernels that rebuild anyway).
+        ``pipeline_factor``: the factor is REBUILT every period, like the reference's ``solve_mpc`` does, but by a second
+        wavefront that works on the next period's factor while the first one solves this period with the factor the
+        previous launch left (``MPCQP_OPT_PIPELINE_FACTOR``; the operands of the next period are known here: they do
+        not change). Same trajectories, bit for bit; falls back to the plain rebuilding period where the kernel does
+        not offer it."""
         import torch
 
         self.pendulum = WheeledInvertedPendulum(nb_timesteps=nb_timesteps, sampling_period=sampling_period)
@@ -77,7 +82,8 @@ class WIPClosedLoop:
         self._fused = bool(fused_period) and not shared_model  # cleared by the first launch if the kernel cannot do it
         self._period_args = None
         self._reuse = bool(reuse_factor) and not shared_model
-        if self._reuse:
+        self._pipe = bool(pipeline_factor) and not shared_model and not self._reuse
+        if self._reuse or self._pipe:
             self.solver._opts.flags |= _capi.OPT_KEEP_FACTOR
 
     def _write_references(self) -> None:
@@ -124,6 +130,14 @@ class WIPClosedLoop:
         for _ in range(nb_mpc_steps):
             if self._reuse and self.mpc_steps == 1:  # the first period of the episode left the factor in the workspace
                 self.solver._opts.flags = (self.solver._opts.flags & ~_capi.OPT_KEEP_FACTOR) | _capi.OPT_REUSE_FACTOR
+            if self._pipe:
+                o = self.solver._opts
+                if self.mpc_steps == 0:  # the first period factors for itself and keeps the factor in image 0
+                    o.flags = (o.flags & ~_capi.OPT_PIPELINE_FACTOR) | _capi.OPT_KEEP_FACTOR
+                    o.factor_slot = 0
+                else:  # period t solves with image (t - 1) % 2 while the factor for period t + 1 goes into image t % 2
+                    o.flags = (o.flags & ~_capi.OPT_KEEP_FACTOR) | _capi.OPT_PIPELINE_FACTOR
+                    o.factor_slot = (self.mpc_steps - 1) % 2
             if self._fused:
                 if self._period_args is None:  # converted once: the call is launch-rate-bound otherwise
                     import ctypes as C
@@ -133,13 +147,26 @@ class WIPClosedLoop:
                         C.c_double(pend.sampling_period), C.c_double(self.target_vel), C.c_double(pend.length),
                         C.c_double(pend.GRAVITY), C.c_int32(NB_SUBSTEPS))
                 rc = lib.mpcqp_wip_period_batch(*self._period_args, _stream_ptr())
+                if rc == _capi.EUNSUPPORTED and self._pipe and self.mpc_steps > 0:
+                    # (this horizon has no factor image to pipeline through: plain rebuilding periods)
+                    self._pipe = False
+                    self.solver._opts.flags &= ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_KEEP_FACTOR)
+                    rc = lib.mpcqp_wip_period_batch(*self._period_args, _stream_ptr())
                 if rc == _capi.EUNSUPPORTED:
                     self._fused = False  # (another kernel serves this size: two launches per period)
                 else:
                     _capi.check(rc, "mpcqp_wip_period_batch")
                     self.mpc_steps += 1
                     continue
-            self.solver.launch()
+            if self._pipe:
+                rc = self.solver._entry(*self.solver._args, _stream_ptr())
+                if rc == _capi.EUNSUPPORTED:  # (a kernel without factor images serves this size: plain rebuilds)
+                    self._pipe = False
+                    self.solver._opts.flags &= ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_KEEP_FACTOR)
+                    rc = self.solver._entry(*self.solver._args, _stream_ptr())
+                _capi.check(rc, "mpcqp_build_solve_batch")
+            else:
+                self.solver.launch()
             rc = lib.mpcqp_wip_advance_stats_batch(
                 _dtype_code(p.dtype), self.states.data_ptr(), self.solver.U.data_ptr(), p.nb_variables,
                 self.solver.status.data_ptr(), self.solver.iters.data_ptr(), self._stats.data_ptr(), pend.nb_timesteps,

@@ -79,6 +79,7 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
     ka.warm_state = o->warm_state;
     ka.warm_start = o->warm_state ? o->warm_start : 0;
     ka.warm_state_bytes = o->warm_state ? o->warm_state_bytes : 0;
+    ka.factor_slot = o->factor_slot & 1;
     return 0;
 }
 
@@ -463,6 +464,8 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if ((ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR) && !(use_stage_auto(ka, dims->dtype) && stage_pipeline_supported(ka, dims->dtype)))
+        return MPCQP_EUNSUPPORTED;
     // the state is indexed by problem: a buffer made for a smaller batch would be read and written out of bounds
     if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * kPairWarmDoubles * sizeof(double)) return MPCQP_EWORKSPACE;
     if (use_stage_auto(ka, dims->dtype)) {

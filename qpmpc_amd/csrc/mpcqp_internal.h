@@ -33,6 +33,7 @@ struct KernelArgs {
     int opt_flags;                // MPCQP_OPT_*
     void *warm_state;             // per-problem active set + operator (read if warm_start, written at the end), or null
     int warm_start;
+    int factor_slot;              // which of the two factor images of the stage-wise kernel this launch keeps / reuses
     size_t warm_state_bytes;      // size of the buffer behind warm_state (checked on the host before the launch)
     void *probe;                  // developer probe: int64 stamps per problem, or null
     // closed-loop epilogue of the stage-wise kernel (mpcqp_wip_period_batch): after its solve every wavefront applies
@@ -160,6 +161,7 @@ int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *
 // stage-wise formulation (mpcqp_stage.hip): one problem per wavefront, O(N) per iteration
 bool stage_supported(const KernelArgs &ka, int dtype);
 int stage_default_maxq(const KernelArgs &ka);
+bool stage_pipeline_supported(const KernelArgs &ka, int dtype);
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq);
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st);
 // ... for wider systems (mpcqp_stagew.hip): nx <= 16, nu <= 4, f64 and f32; workspace in elements of the dtype

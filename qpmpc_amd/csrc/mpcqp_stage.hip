@@ -66,7 +66,9 @@ __host__ __device__ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
     w.Acl = take(NP * nx * nx);
     w.Kg = take(NP * nu * nx);
     w.Sinv = take(NP * nu * nu);
-    w.Fimg = take(N <= kSerialMaxN ? (int64_t)N * serial_fs(nu) : 0);  // copy of the LDS factor image (MPCQP_OPT_KEEP_FACTOR)
+    // two copies of the LDS factor image (MPCQP_OPT_KEEP_FACTOR / REUSE_FACTOR: slot MpcqpSolveOpts.factor_slot;
+    // MPCQP_OPT_PIPELINE_FACTOR: the solve reads one while the next launch's factor is written into the other)
+    w.Fimg = take(N <= kSerialMaxN ? 2 * (int64_t)N * serial_fs(nu) : 0);
     w.ff = take(NP * nu);
     w.U0 = take(NP * nu);
     w.X0 = take(NP * nx);
@@ -130,16 +132,31 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// hand-over through LDS inside ONE wavefront: its LDS operations execute in order, so nothing has to be waited for --
+// only the compiler must not move the accesses across this point
+__device__ __forceinline__ void lsync()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace stage
 
 using namespace stage;
 
-template <int NX, int NU, bool SERIAL>
-__global__ void __launch_bounds__(64, 2)
+// PIPE (MPCQP_OPT_PIPELINE_FACTOR; serial instantiations): TWO wavefronts per problem. Wavefront 0 solves with the factor a
+// previous launch left in the workspace (as MPCQP_OPT_REUSE_FACTOR does), wavefront 1 -- on another SIMD, at the same time --
+// runs the Riccati recursion on the problem's operands as they are NOW and leaves that factor in the other image for the
+// NEXT launch. In a receding-horizon loop whose operands for the next period are known when this period is solved
+// (time-invariant or pre-scheduled LTV dynamics: examples/wheeled_inverted_pendulum.py:99-118) the factor is still rebuilt
+// every period, like the reference's solve_mpc does, but off the period's critical path.
+template <int NX, int NU, bool SERIAL, bool PIPE>
+__global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool factor_wave = PIPE && (threadIdx.x >> 6) == 1;
     const int64_t prob = blockIdx.x;
     const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int L = (N + 63) / 64;                    // steps per chunk
@@ -201,7 +218,12 @@ __global__ void __launch_bounds__(64, 2)
     // column, goes through an LDS transpose. ~90 instructions per step instead of ~350 executed redundantly by every lane.
     // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
-    const bool reuse = ka.opt_flags & MPCQP_OPT_REUSE_FACTOR, keep = ka.opt_flags & MPCQP_OPT_KEEP_FACTOR;
+    const bool reuse = PIPE ? !factor_wave : (ka.opt_flags & MPCQP_OPT_REUSE_FACTOR) != 0;
+    const bool keep = !PIPE && (ka.opt_flags & MPCQP_OPT_KEEP_FACTOR);
+    // factor images in the workspace: this launch's (read by REUSE / the solving wavefront, written by KEEP) and the next one's
+    double *img = ws + wl.Fimg + (int64_t)(ka.factor_slot & 1) * N * FS;
+    double *img_next = ws + wl.Fimg + (int64_t)((ka.factor_slot & 1) ^ 1) * N * FS;
+    if constexpr (PIPE) rsc += 32 + (int64_t)N * (FS + NU + NX);  // (the factor wavefront's own exchange cells, after everything)
     // S_k = w_u I + B_k' P_{k+1} B_k are the Schur complements of the condensed Hessian in the order u_{N-1}, ..., u_0: P is
     // positive definite iff every S_k is (mpc_problem.py:104-107 only guarantees w_u > 0; a negative state weight can
     // still make P indefinite). A pivot that is not positive -> MPCQP_NOT_PD, like the condensed kernels' Cholesky.
@@ -232,8 +254,34 @@ __global__ void __launch_bounds__(64, 2)
         // operands are requested RD steps ahead into a register ring (a step is shorter than an HBM round trip)
         constexpr int RD = 3;
         double Acn[RD][NX], Ann[RD], Bfn[RD][NX * NU], Brn[RD][4 * NU];  // column c of A; A[r][c]; B; B[(r - t) mod 4][.]
+        // PIPE: the factor wavefront writes its factor to the WORKSPACE, and a load issued behind those stores would wait for
+        // them (vector memory operations retire in order): the operands come through LDS instead, one bulk copy up front
+        const double *rA = gA, *rB = gB;
+        if constexpr (PIPE) {
+            double *la = rsc + 32, *lb = la + (int64_t)N * NX * NX;
+            const int na = (sA ? N : 1) * NX * NX, nb = (sB ? N : 1) * NX * NU;
+            for (int i0 = lane; i0 < na; i0 += 64 * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = gA[i0 + 64 * u < na ? i0 + 64 * u : na - 1];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 64 * u < na) la[i0 + 64 * u] = v[u];
+            }
+            for (int i0 = lane; i0 < nb; i0 += 64 * 4) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = gB[i0 + 64 * u < nb ? i0 + 64 * u : nb - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + 64 * u < nb) lb[i0 + 64 * u] = v[u];
+            }
+            wsync();
+            rA = la;
+            rB = lb;
+        }
         auto request = [&](int d, int k) {
-            const double *A = gA + k * sA, *B = gB + k * sB;
+            const double *A = rA + k * sA, *B = rB + k * sB;
 #pragma unroll
             for (int l = 0; l < NX; ++l) Acn[d][l] = inc ? A[l * NX + c] : 0.0;
             Ann[d] = in ? A[r * NX + c] : 0.0;
@@ -315,8 +363,9 @@ __global__ void __launch_bounds__(64, 2)
             }
             if (lane < 16) {
                 if constexpr (SERIAL) {
-                    // every one of the 16 lanes writes its entry of each rotated image (zero outside NX x NX)
-                    double *f = Fl + k * FS;
+                    // every one of the 16 lanes writes its entry of each rotated image (zero outside NX x NX); PIPE: straight
+                    // into the next launch's image in the workspace (the LDS image belongs to the solving wavefront)
+                    double *f = (PIPE ? img_next : Fl) + k * FS;
                     const int rc = (r - c) & 3, cr = (c - r) & 3;
                     f[FA + r * 4 + rc] = in ? Acl_rc : 0.0;
                     f[FAT + c * 4 + cr] = in ? Acl_rc : 0.0;
@@ -355,7 +404,7 @@ __global__ void __launch_bounds__(64, 2)
                 rsc[c * 4 + r] = PA;           // PA'  : row c = column c of PA
                 rsc[16 + c * 4 + r] = Acl_rc;  // Acl' : row c = column c of Acl
             }
-            wsync();
+            lsync();  // (LDS only: the factor's stores -- global ones in the pipelined mode -- are not waited for)
             double par[4], pac[4], acr[4], acc_[4];
             {
                 const D2 *t2 = (const D2 *)rsc;
@@ -390,10 +439,15 @@ __global__ void __launch_bounds__(64, 2)
     }
     notpd = __ballot(notpd) != 0ull;  // (the lanes sum S in different orders: a pivot at rounding level may differ in sign)
     wsync();
+    if constexpr (PIPE) {
+        if (factor_wave) {  // this wavefront's work is done: mark a factor that does not exist, like KEEP does
+            if (notpd && lane == 0) img_next[FSI] = __builtin_nan("");
+            return;
+        }
+    }
     if constexpr (SERIAL) {
         // the factor image travels between LDS and the workspace as it is (coalesced, one round trip); a factor that
         // does not exist is marked by a NaN in its first S^-1 so that a launch reusing it reports MPCQP_NOT_PD as well
-        double *img = ws + wl.Fimg;
         if (!reuse && notpd && lane == 0) Fl[FSI] = __builtin_nan("");
         if (!reuse && notpd) wsync();
         if (reuse) {
@@ -1240,26 +1294,38 @@ int stage_default_maxq(const KernelArgs &ka)
 
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
 
-template <int NX, int NU, bool SERIAL>
+template <int NX, int NU, bool SERIAL, bool PIPE>
 static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
     if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double);
-    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL>;
+    if (PIPE) lds += (32 + (size_t)ka.N * (NX * NX + NX * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands
+    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64), lds, st, ka, wl, (double *)ws, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(PIPE ? 128 : 64), lds, st, ka, wl, (double *)ws, batch);
     return (int)hipGetLastError();
 }
 
-template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+static bool stage_serial(const KernelArgs &ka)
 {
     // serial sweeps: short horizons whose factor fits 32 KB of LDS next to the active-set vectors
-    const bool serial = ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double) <= 40 * 1024;
-    return serial ? launch_stage_s<NX, NU, true>(ka, maxq, batch, ws, st) : launch_stage_s<NX, NU, false>(ka, maxq, batch, ws, st);
+    return ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(ka.nu) + ka.nu + ka.nx) * sizeof(double) <= 40 * 1024;
+}
+
+// MPCQP_OPT_PIPELINE_FACTOR needs the factor image of the serial instantiations
+bool stage_pipeline_supported(const KernelArgs &ka, int dtype) { return stage_supported(ka, dtype) && stage_serial(ka); }
+
+template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    const bool serial = stage_serial(ka);
+    if (ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR)
+        return serial ? launch_stage_s<NX, NU, true, true>(ka, maxq, batch, ws, st) : MPCQP_EUNSUPPORTED;
+    return serial ? launch_stage_s<NX, NU, true, false>(ka, maxq, batch, ws, st)
+                  : launch_stage_s<NX, NU, false, false>(ka, maxq, batch, ws, st);
 }
 
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)

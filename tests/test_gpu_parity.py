@@ -1161,3 +1161,46 @@ def test_shared_model_with_per_problem_bounds_and_lipm_loop():
     torch.cuda.synchronize()
     assert a.stats()["failed"] == 0 and b.stats()["failed"] == 0
     assert (a.states - b.states).abs().max().item() < 1e-9
+
+
+def test_closed_loop_with_the_factor_pipelined_equals_the_rebuilding_loop():
+    """MPCQP_OPT_PIPELINE_FACTOR: a second wavefront rebuilds the Riccati factor for the NEXT period while the first one solves
+    this period with the factor the previous launch left (examples/wheeled_inverted_pendulum.py:99-118 rebuilds every period;
+    so does this -- off the critical path). Trajectories, references and counters bitwise those of the plain rebuilding
+    loop, over periods with active input boxes; a new episode (reset) starts the pipeline again; a horizon served by a
+    kernel without factor images (N = 12: the pair kernel) falls back by itself."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(6)
+    x0 = rng.standard_normal((96, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    x0[0] = [0.0, 0.3, 0.0, 1.0]  # saturates the input box: iterations are counted
+    x0[1] = [0.0, -0.25, 0.0, -0.8]
+    a = WIPClosedLoop(x0.copy(), pipeline_factor=True)
+    b = WIPClosedLoop(x0.copy())
+    for _ in range(5):
+        a.step(7)
+        b.step(7)
+        torch.cuda.synchronize()
+        assert a._fused and a._pipe
+        assert torch.equal(a.states, b.states)
+        assert torch.equal(a.problem.target_states, b.problem.target_states) and torch.equal(a.problem.goal_state, b.problem.goal_state)
+    assert a.stats() == b.stats() and a.stats()["mean_iters"] > 0.0
+    a.reset(x0[::-1].copy())
+    b.reset(x0[::-1].copy())
+    a.step(9)
+    b.step(9)
+    torch.cuda.synchronize()
+    assert torch.equal(a.states, b.states) and a.stats() == b.stats()
+    # two launches per period (fused_period=False): the solver launch carries the flag
+    c = WIPClosedLoop(x0.copy(), pipeline_factor=True, fused_period=False)
+    d = WIPClosedLoop(x0.copy(), fused_period=False)
+    c.step(6)
+    d.step(6)
+    torch.cuda.synchronize()
+    assert c._pipe and torch.equal(c.states, d.states)
+    short = WIPClosedLoop(x0[:8].copy(), nb_timesteps=12, sampling_period=0.1, pipeline_factor=True)
+    ref = WIPClosedLoop(x0[:8].copy(), nb_timesteps=12, sampling_period=0.1)
+    short.step(5)
+    ref.step(5)
+    torch.cuda.synchronize()
+    assert not short._pipe and torch.equal(short.states, ref.states)
