@@ -47,7 +47,8 @@ CONFIGS = {
                      "fp64, fused condense + dual active-set solve, one launch per step"),
     3: dict(batch=1024, scaling="weak", dtype="f64",
             workload="{b} wheeled-inverted-pendulum receding-horizon loops, N=50 T=0.024 s (nx=4 nu=1, n=50 m=100), LTV "
-                     "lists, fp64; one step = one MPC period: fused build+solve rebuilt every step + plant (15 sub-steps)"),
+                     "lists, fp64; one step = one MPC period: fused build+solve rebuilt every step (the factor by a second "
+                     "wavefront one period ahead) + plant (15 sub-steps)"),
     4: dict(batch=65536, scaling="strong", dtype="f64",
             workload="humanoid one-step (LIPM) N=16 (n=16 m=32), {b}-state sweep strong-sharded over the GPUs, fp64, "
                      "fused build+solve; U/status all_gather timed separately"),
@@ -117,7 +118,9 @@ class _Runner:
         if config == 3:
             from qpmpc_amd.closed_loop import WIPClosedLoop
 
-            self.loop = WIPClosedLoop(np.asarray(w["x0"]))
+            # the factor is rebuilt every period like the reference's solve_mpc does (solve_mpc.py:42), by a second wavefront
+            # working one period ahead (MPCQP_OPT_PIPELINE_FACTOR); other_workloads has the unpipelined rate
+            self.loop = WIPClosedLoop(np.asarray(w["x0"]), pipeline_factor=True)
             self.solver = self.loop.solver
             self.launch = lambda stream=None: self.loop.step()
             # the timed region is ONE EPISODE from the random initial states ("x0 ~ N(0, diag(.05,.05,
@@ -393,15 +396,20 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
                 "note": "nominally HBM-bound (4 flop/B) but a launch moves only ~11 MB: the serial active-set chain of "
                         "each wavefront (instruction issue + dependent latency) sets the time, not HBM or FP64 throughput"}
     if args.config == 3:
-        return {"bound": "mfma", "achieved": tfs, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / FP64_PEAK_TFLOPS,
-                "kernel": "mpcqp_stage_kernel<4, 1, serial> (stage-wise Riccati active set, one problem per wavefront) with "
-                          "the plant step, next references and bookkeeping as its epilogue: one launch per period",
-                "achieved_gbs": gbs, **common,
-                "note": "achieved = the reference's dense condense + solve flops (fp64 FMA/MFMA-bound by intensity, "
-                        "~100 flop/B) over the period; the stage-wise kernel does not execute them (no P, no G): with "
-                        "1024 loops there is one wavefront per SIMD and the period is the latency of one problem's "
-                        "serial chain (Riccati recursion, scans, active-set iterations). Peak = AMD's fp64 "
-                        "vector=matrix figure"}
+        # what the stage-wise kernel EXECUTES (it forms neither P nor G), not the reference's dense flops
+        ex = W.stagewise_executed_flops(nx, nu, N, mk, mean_iters)
+        etf = ex * local_per_step / kernel_s / 1e12
+        common["algorithmic_flops_per_problem"] = ex
+        return {"bound": "mfma", "achieved": etf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": etf / FP64_PEAK_TFLOPS,
+                "kernel": "mpcqp_stage_kernel<4, 1, serial, pipelined> (stage-wise Riccati active set; two wavefronts per loop: "
+                          "one solves this period, the other rebuilds the factor for the next one) with the plant step, next "
+                          "references and bookkeeping as its epilogue: one launch per period",
+                "achieved_gbs": gbs, "dense_equivalent_tflops": tfs, **common,
+                "note": "achieved = float64 operations the kernel executes per period (Riccati recursion, sweeps, slack "
+                        "passes: ~3e4 per loop) over the period; dense_equivalent_tflops prices the reference's dense "
+                        "condense + solve flops, which this path does not execute. With 1024 loops there are two wavefronts "
+                        "per SIMD and the period is the latency of one problem's serial chain (dependent float64 "
+                        "operations, LDS round trips), nowhere near a throughput roof. Peak = AMD's fp64 vector=matrix figure"}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "kernel": "mpcqp_stagew_kernel<float, 12> (one launch per step: Riccati factor, LQR sweeps and the dual "
                       "active set of one problem per wavefront; the condensed QP is never formed)",
@@ -521,6 +529,9 @@ def other_workloads():
     rng = np.random.default_rng(1)
     loop = WIPClosedLoop(rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1]))
     out["config3_closed_loop_rebuild_every_step"] = rate(loop.step, 1024, 50)
+    loop_p = WIPClosedLoop(rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1]), pipeline_factor=True)
+    loop_p.step(2)  # the first period factors for itself
+    out["config3_closed_loop_rebuild_pipelined"] = rate(loop_p.step, 1024, 50)
     x0r = rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
     loop_r = WIPClosedLoop(x0r, reuse_factor=True)
     loop_r.step(2)  # the first period keeps the factor
@@ -537,6 +548,12 @@ def other_workloads():
     w = W.synthetic_ltv_batch(1024)
     out["config5_synthetic_ltv_n256_m1024_f32_batch1024"] = rate(
         PreparedSolve(W.to_batch_problem(w, dtype=torch.float32)).launch, 1024, 5)
+    # the dense HBM-resident path (propagate + MFMA Gram + one-QP-per-workgroup solver): what systems with nx > 16 or
+    # nu > 4 get -- a slow fallback, an order of magnitude behind the stage-wise kernels
+    from qpmpc_amd import _capi
+
+    out["dense_fallback_path_n256_m1024_f32_batch1024"] = rate(
+        PreparedSolve(W.to_batch_problem(w, dtype=torch.float32), flags=_capi.OPT_FORCE_CONDENSED).launch, 1024, 3)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
     walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)

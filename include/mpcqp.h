@@ -156,7 +156,13 @@ typedef struct MpcqpSolveOpts {
      *   contract is not trusted: with a warm start a solution is accepted only after its KKT conditions
      *   were re-checked from scratch (stationarity holds by construction, multipliers >= 0, active rows
      *   on their bounds, inactive rows feasible); a stale state costs a cold restart, never a wrong plan.
-     * Supported by the small-problem fused kernel (n <= 16, m <= 32, float64); other dimensions return
+     * Supported by the small-problem fused kernel (n <= 16, m <= 32, float64) as described, and by the stage-wise kernel
+     * that mpcqp_build_solve_batch picks for small systems with 16 < n <= 128 (float64, nx <= 4, nu <= 2): there the record
+     * holds the active rows' ids only -- their vectors V_a = P^-1 g_a', the trajectories and W = (G_A P^-1 G_A')^-1 stay
+     * in the WORKSPACE, so a warm start needs the same workspace as the launch before and MPCQP_OPT_REUSE_FACTOR (same
+     * contract: matrices and weights unchanged); the multipliers are lam = -W s_A at the new unconstrained minimiser,
+     * rows with a negative one leave, and a state whose active rows do not end up on their bounds (another problem's, or
+     * another workspace's -- the record carries the workspace's address) costs a cold restart. Other dimensions return
      * MPCQP_EUNSUPPORTED when warm_state is given. */
     void *warm_state;
     int32_t warm_start;

@@ -376,16 +376,21 @@ class WarmState:
         _capi.check(lib.mpcqp_warm_state_bytes(C.byref(dims), C.byref(nbytes)), "mpcqp_warm_state_bytes")
         if nbytes.value == 0:
             raise BackendError(
-                "warm start is available for n = N*nu <= 16 variables, m <= 32 rows, float64 "
-                f"(got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype})")
+                "warm start is available for float64 problems with n = N*nu <= 16 variables and m <= 32 rows (the active-set "
+                "operator persists) and for small systems (nx <= 4, nu <= 2) with 16 < n <= 128 (the active rows' vectors "
+                f"persist in the solver's workspace); got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype}")
         self.bytes_per_problem = int(nbytes.value)
         self.batch_size = problem.batch_size
         self.device = problem.device
-        # the operator T (16 x 16 doubles) first, then the slots' constraint ids (int32): everything after T
-        self._ids_at = 16 * 16 * 8
-        assert self._ids_at < self.bytes_per_problem
+        # "pair": the operator T (16 x 16 doubles) first, then the slots' constraint ids (int32); "stage": int32 record
+        # [nq, slots, workspace tag (2), row steps ..., row indices ...] -- the vectors themselves stay in the workspace of
+        # the PreparedSolve that is re-launched (MPCQP_OPT_REUSE_FACTOR contract), so this kind only acts there
+        self.kind = "pair" if problem.nb_variables <= 16 else "stage"
+        self._mk = problem.ineq_dim
+        self._ids_at = 16 * 16 * 8 if self.kind == "pair" else 0
         self.buffer = torch.zeros((problem.batch_size, self.bytes_per_problem), dtype=torch.uint8, device=problem.device)
-        self.buffer[:, self._ids_at:] = 0xFF  # constraint ids -1: empty set
+        if self.kind == "pair":
+            self.buffer[:, self._ids_at:] = 0xFF  # constraint ids -1: empty set
 
     def check(self, problem: "BatchMPCProblem") -> None:
         """Raise ``BackendError`` unless this state was allocated for ``problem``'s batch, dimensions and device
@@ -402,9 +407,17 @@ class WarmState:
 
     @property
     def active_set(self):
-        """int32 [B, 16]: constraint row held by each slot after the last solve, -1 = empty."""
+        """int32 [B, slots]: constraint row (k * mk + r) held by each slot after the last solve, -1 = empty."""
         torch = _torch()
-        return self.buffer[:, self._ids_at:].contiguous().view(torch.int32)
+        if self.kind == "pair":
+            return self.buffer[:, self._ids_at:].contiguous().view(torch.int32)
+        rec = self.buffer.view(torch.int32)  # [B, 4 + 2 slots (+ padding)]
+        slots = int(rec[0, 1].item()) if int(rec[0, 1].item()) > 0 else (rec.shape[1] - 4) // 2
+        nq = rec[:, 0:1]
+        k, r = rec[:, 4:4 + slots], rec[:, 4 + slots:4 + 2 * slots]
+        rows = k * self._mk + r
+        live = torch.arange(slots, device=rec.device)[None, :] < nq
+        return torch.where(live, rows, torch.full_like(rows, -1))
 
 
 def _check_warm(problem: "BatchMPCProblem", opt_kw) -> None:
@@ -574,6 +587,12 @@ class PreparedSolve:
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         _check_warm(problem, opt_kw)
         self._opts = _opts(max_iter, feas_tol, **opt_kw)
+        ws_ = opt_kw.get("warm_state")
+        # the stage-wise kernel's warm start continues from the vectors its previous launch left in THIS object's
+        # workspace: the first launch keeps the Riccati factor, set_warm_start(True) switches to re-using it
+        self._stage_warm = isinstance(ws_, WarmState) and ws_.kind == "stage"
+        if self._stage_warm:
+            self._opts.flags |= _capi.OPT_KEEP_FACTOR
         if self._stagewise:
             dims, nbytes = problem.dims(), C.c_size_t(0)
             _capi.check(self._lib.mpcqp_stagewise_workspace_bytes(C.byref(dims), Bn, self._max_active, C.byref(nbytes)),
@@ -599,6 +618,9 @@ class PreparedSolve:
         if "warm_state" not in self._opt_kw:
             raise BackendError("PreparedSolve was built without warm_state=WarmState(problem)")
         self._opts.warm_start = 1 if on else 0
+        if self._stage_warm:  # (contract of both: A, B, C, D and the weights are those of the launch before)
+            keep, reuse = _capi.OPT_KEEP_FACTOR, _capi.OPT_REUSE_FACTOR
+            self._opts.flags = (self._opts.flags & ~(keep | reuse)) | (reuse if on else keep)
 
     def launch(self, stream=None) -> None:
         """Enqueue one fused build+solve of the whole batch on ``stream``

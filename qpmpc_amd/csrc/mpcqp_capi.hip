@@ -109,8 +109,7 @@ bool use_stage_auto(const KernelArgs &ka, int dtype)
 {
     const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
                               MPCQP_OPT_ONE_PER_WAVE;
-    return !(ka.opt_flags & override_bits) && !ka.warm_state && stage_supported(ka, dtype) && ka.n > 16 && ka.n <= 128 &&
-           ka.m >= 1;
+    return !(ka.opt_flags & override_bits) && stage_supported(ka, dtype) && ka.n > 16 && ka.n <= 128 && ka.m >= 1;
 }
 
 // Fused build+solve of problems that do NOT fit the on-chip condensed kernels goes to the wide stage-wise kernel
@@ -138,6 +137,17 @@ int stagew_auto_maxq(const KernelArgs &ka)
 {
     const int q = ka.n < ka.m ? ka.n : ka.m;
     return q < 256 ? q : 256;
+}
+
+// warm start: the small-problem pair kernel (operator + slot ids) and the narrow stage-wise kernel (row ids; the rows'
+// vectors stay in its workspace); 0 = not offered for these dimensions
+size_t warm_bytes_per_problem(KernelArgs ka, int dtype)
+{
+    ka.opt_flags = 0;
+    ka.warm_state = nullptr;
+    if (pair_eligible(ka, MODE_FUSED, dtype)) return kPairWarmDoubles * sizeof(double);
+    if (use_stage_auto(ka, dtype)) return stage_warm_bytes(stage_default_maxq(ka));
+    return 0;
 }
 
 bool use_bigsolve(int n, int m, int dtype, int fl) { return !force_gws(fl) && m > 0 && bigsolve_supported(n, m, dtype); }
@@ -281,7 +291,7 @@ int mpcqp_warm_state_bytes(const MpcqpDims *dims, size_t *bytes)
     if (!bytes) return MPCQP_EINVAL;
     KernelArgs ka;
     fill_args(ka, dims, nullptr);
-    *bytes = pair_eligible(ka, MODE_FUSED, dims->dtype) ? kPairWarmDoubles * sizeof(double) : 0;
+    *bytes = warm_bytes_per_problem(ka, dims->dtype);
     return 0;
 }
 
@@ -463,11 +473,11 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
-    if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype) && !use_stage_auto(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
     if ((ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR) && !(use_stage_auto(ka, dims->dtype) && stage_pipeline_supported(ka, dims->dtype)))
         return MPCQP_EUNSUPPORTED;
     // the state is indexed by problem: a buffer made for a smaller batch would be read and written out of bounds
-    if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * kPairWarmDoubles * sizeof(double)) return MPCQP_EWORKSPACE;
+    if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * warm_bytes_per_problem(ka, dims->dtype)) return MPCQP_EWORKSPACE;
     if (use_stage_auto(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);
         const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;

@@ -162,6 +162,7 @@ int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *
 bool stage_supported(const KernelArgs &ka, int dtype);
 int stage_default_maxq(const KernelArgs &ka);
 bool stage_pipeline_supported(const KernelArgs &ka, int dtype);
+__host__ __device__ size_t stage_warm_bytes(int maxq);
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq);
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st);
 // ... for wider systems (mpcqp_stagew.hip): nx <= 16, nu <= 4, f64 and f32; workspace in elements of the dtype

@@ -144,6 +144,9 @@ __device__ __forceinline__ void lsync()
 
 using namespace stage;
 
+// bytes per problem of the warm-state record (MpcqpSolveOpts.warm_state) for `maxq` slots
+__host__ __device__ size_t stage_warm_bytes(int maxq) { return ((size_t)(4 + 2 * maxq) * sizeof(int) + 15) & ~(size_t)15; }
+
 // PIPE (MPCQP_OPT_PIPELINE_FACTOR; serial instantiations): TWO wavefronts per problem. Wavefront 0 solves with the factor a
 // previous launch left in the workspace (as MPCQP_OPT_REUSE_FACTOR does), wavefront 1 -- on another SIMD, at the same time --
 // runs the Riccati recursion on the problem's operands as they are NOW and leaves that factor in the other image for the
@@ -1005,6 +1008,160 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     const int nvar = N * NU;
     double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
     bool fail = false, slotsfull = false;
+    // slot l leaves the active set: W is deflated and the last slot moves into the hole (nq is decremented by the caller)
+    auto drop_slot = [&](int l) {
+        const double wll = Wm[(int64_t)l * maxq + l];
+        const double iw = 1.0 / wll;
+        for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
+        wsync();
+        for (int a = lane; a < nq; a += 64) {
+            const double wa = cv[a];
+            for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
+        }
+        wsync();
+        const int last = nq - 1;
+        const int64_t drow = wg(actk[l]) * mk + actr[l];
+        if (l != last) {
+            for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
+            wsync();
+            for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
+            wsync();
+            const double *vs = Vs + (int64_t)last * NP * NU, *xs = XVs + (int64_t)last * NP * NX;
+            double *vd = Vs + (int64_t)l * NP * NU, *xd = XVs + (int64_t)l * NP * NX;
+            for (int k = k0; k < k1; ++k) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) vd[wq(k) * NU + i] = vs[wq(k) * NU + i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xd[wq(k) * NX + i] = xs[wq(k) * NX + i];
+            }
+        }
+        if (lane == 0) {
+            rowslot[drow] = -1;
+            if (l != last) {
+                lamv[l] = lamv[last];
+                actk[l] = actk[last];
+                actr[l] = actr[last];
+                rowslot[wg(actk[last]) * mk + actr[last]] = l;
+            }
+        }
+    };
+    // the primal point of the current multipliers, u = u0 - sum_a lam_a V_a (x likewise), and every row's slack from scratch:
+    // inactive rows get their fresh slack (dirty: one of them is infeasible beyond 4 tol), active rows are set to zero after
+    // checking that they really sit on their bounds (offa: W is only ever updated, never refactored -- and a warm start takes
+    // it from a previous launch); with `write_u` the inputs go to the output
+    // (an active row may be off by (1 + |e_i|) max(1e3 tol, 1e-6): the contract's 1e-6 -- an ill-conditioned but legitimate
+    // plan leaves ~1e-9 here, no refinement step in this kernel)
+    const double kacc = 1e3 > 1e-6 / tol ? 1e3 : 1e-6 / tol;
+    auto eval_point = [&](bool write_u, bool &dirty, bool &offa) {
+        for (int k = k0; k < k1; ++k) {
+            double u[NU], x[NX];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u[i] = U0[wq(k) * NU + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = X0[wq(k) * NX + i];
+            for (int a = 0; a < nq; ++a) {
+                const double la = lamv[a];
+                const double *va = Vs + ((int64_t)a * NP + wq(k)) * NU, *xa = XVs + ((int64_t)a * NP + wq(k)) * NX;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) u[i] -= la * va[i];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] -= la * xa[i];
+            }
+            if (write_u) {
+                double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) ou[i] = u[i];
+            }
+            for (int r = 0; r < mk; ++r) {
+                const int64_t i = wq(k) * mk + r;
+                const double ev = ge[k * sE + r];
+                double g = 0.0;
+                if (gC)
+#pragma unroll
+                    for (int c = 0; c < NX; ++c) g += gC[k * sC + r * NX + c] * x[c];
+                if (gD)
+#pragma unroll
+                    for (int c = 0; c < NU; ++c) g += gD[k * sD + r * NU + c] * u[c];
+                const double fresh = ev - g, th = tol + tol * fabs(ev);
+                const bool act = rowslot[i] >= 0;
+                if (ev < 1e29 && !act && !(fresh >= -4.0 * th)) dirty = true;
+                if (act && !(fabs(fresh) <= kacc * th)) offa = true;
+                sl[i] = act ? 0.0 : fresh;
+            }
+        }
+        dirty = __ballot(dirty) != 0ull;
+        offa = __ballot(offa) != 0ull;
+        wsync();
+    };
+    // back to the empty active set at the unconstrained minimiser
+    auto cold_start = [&]() {
+        for (int a = lane; a < nq; a += 64) rowslot[wg(actk[a]) * mk + actr[a]] = -1;
+        wsync();
+        nq = 0;
+        bool d = false, o = false;
+        eval_point(false, d, o);
+    };
+    // ---- warm start (MpcqpSolveOpts.warm_state / warm_start with MPCQP_OPT_REUSE_FACTOR, include/mpcqp.h): the previous
+    // launch left its active rows' vectors V_a, X_a and W = (G_A P^-1 G_A')^-1 in this workspace and the rows' ids in the
+    // warm-state record. They depend on the matrices only, so for new x0 / goal / targets / e the multipliers are
+    // lam = -W s0_A; rows whose multiplier comes out negative leave (one deflation each), the rest is the starting active
+    // set: a period whose active set did not move costs no sweep at all.
+    const int wrec = (int)(stage_warm_bytes(maxq) / sizeof(int));  // ints per problem: nq, maxq, workspace tag (2), row steps, row indices
+    int *wst = ka.warm_state ? (int *)ka.warm_state + prob * (int64_t)wrec : nullptr;
+    const unsigned long long wtag = (unsigned long long)(uintptr_t)ws;
+    if (wst && ka.warm_start && reuse && !notpd) {
+        int nqs = wst[0];
+        const bool same = wst[1] == maxq && (unsigned)wst[2] == (unsigned)wtag && (unsigned)wst[3] == (unsigned)(wtag >> 32);
+        if (!same || nqs < 0 || nqs > maxq) nqs = 0;
+        bool bad = false;
+        for (int a = lane; a < nqs; a += 64) {
+            const int k = wst[4 + a], r = wst[4 + maxq + a];
+            actk[a] = k;
+            actr[a] = r;
+            bad |= k < 0 || k >= N || r < 0 || r >= mk;
+        }
+        if (__ballot(bad) != 0ull) nqs = 0;
+        wsync();
+        for (int a = lane; a < nqs; a += 64) rowslot[wg(actk[a]) * mk + actr[a]] = a;
+        wsync();
+        bad = false;
+        for (int a = lane; a < nqs; a += 64) bad |= rowslot[wg(actk[a]) * mk + actr[a]] != a;  // (a row listed twice)
+        nq = nqs;
+        if (__ballot(bad) != 0ull) cold_start();
+        while (nq > 0) {
+            for (int a = lane; a < nq; a += 64) cv[a] = sl[wg(actk[a]) * mk + actr[a]];  // slacks at the unconstrained minimiser
+            wsync();
+            double lmin = INF;
+            int l = 0x7fffffff;
+            bool nan = false;
+            for (int a = lane; a < nq; a += 64) {
+                double acc = 0.0;
+                for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];
+                lamv[a] = -acc;
+                nan |= !(acc == acc) || fabs(acc) > 1e300;
+                if (-acc < lmin) {
+                    lmin = -acc;
+                    l = a;
+                }
+            }
+            if (__ballot(nan) != 0ull) {  // (not a state this kernel left: start cold)
+                cold_start();
+                break;
+            }
+            wave_argmin(lmin, l);
+            wsync();
+            if (!(lmin < 0.0)) break;
+            drop_slot(l);
+            --nq;
+            ++iters;
+            wsync();
+        }
+        if (nq > 0) {
+            bool d = false, o = false;
+            eval_point(false, d, o);
+            if (o) cold_start();  // the stored rows do not sit on their bounds with these vectors: not this problem's state
+        }
+    }
     for (int round = 0; round < 4 && !fail && !notpd; ++round) {
         for (;;) {
             // ---- selection: the violated row farthest from its hyperplane
@@ -1156,41 +1313,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                     ++nq;
                     added = true;
                 } else {
-                    // partial step: slot l leaves; W is deflated and the last slot moves into the hole
-                    const double wll = Wm[(int64_t)l * maxq + l];
-                    const double iw = 1.0 / wll;
-                    for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
-                    wsync();
-                    for (int a = lane; a < nq; a += 64) {
-                        const double wa = cv[a];
-                        for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
-                    }
-                    wsync();
-                    const int last = nq - 1;
-                    const int64_t drow = wg(actk[l]) * mk + actr[l];
-                    if (l != last) {
-                        for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
-                        wsync();
-                        for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
-                        wsync();
-                        const double *vs = Vs + (int64_t)last * NP * NU, *xs = XVs + (int64_t)last * NP * NX;
-                        double *vd = Vs + (int64_t)l * NP * NU, *xd = XVs + (int64_t)l * NP * NX;
-                        for (int k = k0; k < k1; ++k) {
-#pragma unroll
-                            for (int i = 0; i < NU; ++i) vd[wq(k) * NU + i] = vs[wq(k) * NU + i];
-#pragma unroll
-                            for (int i = 0; i < NX; ++i) xd[wq(k) * NX + i] = xs[wq(k) * NX + i];
-                        }
-                    }
-                    if (lane == 0) {
-                        rowslot[drow] = -1;
-                        if (l != last) {
-                            lamv[l] = lamv[last];
-                            actk[l] = actk[last];
-                            actr[l] = actr[last];
-                            rowslot[wg(actk[last]) * mk + actr[last]] = l;
-                        }
-                    }
+                    // partial step: slot l leaves
+                    drop_slot(l);
                     --nq;
                 }
                 wsync();
@@ -1201,42 +1325,13 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         tick(6);
         // ================================================================= primal point, verification
         // u = u0 - sum_a lam_a V_a ; slacks from scratch through x = x0 - sum_a lam_a X_a
-        bool dirty = false;
-        for (int k = k0; k < k1; ++k) {
-            double u[NU], x[NX];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) u[i] = U0[wq(k) * NU + i];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = X0[wq(k) * NX + i];
-            for (int a = 0; a < nq; ++a) {
-                const double la = lamv[a];
-                const double *va = Vs + ((int64_t)a * NP + wq(k)) * NU, *xa = XVs + ((int64_t)a * NP + wq(k)) * NX;
-#pragma unroll
-                for (int i = 0; i < NU; ++i) u[i] -= la * va[i];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] -= la * xa[i];
-            }
-            double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) ou[i] = u[i];
-            for (int r = 0; r < mk; ++r) {
-                const int64_t i = wq(k) * mk + r;
-                const double ev = ge[k * sE + r];
-                double g = 0.0;
-                if (gC)
-#pragma unroll
-                    for (int c = 0; c < NX; ++c) g += gC[k * sC + r * NX + c] * x[c];
-                if (gD)
-#pragma unroll
-                    for (int c = 0; c < NU; ++c) g += gD[k * sD + r * NU + c] * u[c];
-                const double fresh = ev - g;
-                const bool act = rowslot[i] >= 0;
-                if (ev < 1e29 && !act && !(fresh >= -4.0 * (tol + tol * fabs(ev)))) dirty = true;
-                sl[i] = act ? 0.0 : fresh;
-            }
+        bool dirty = false, offa = false;
+        eval_point(true, dirty, offa);
+        if (offa) {  // an active row is off its bound (W drifted, or a warm state that was not this problem's): start cold
+            cold_start();
+            status = MPCQP_MAX_ITER;
+            continue;
         }
-        dirty = __ballot(dirty) != 0ull;
-        wsync();
         if (!dirty) {
             status = MPCQP_SOLVED;
             break;
@@ -1261,6 +1356,18 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                 const int sidx = rowslot[wq(k) * mk + r];
                 ol[(int64_t)k * mk + r] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
             }
+    }
+    if (wst) {  // the warm-state record of the next launch: the active rows (their vectors and W stay in the workspace)
+        for (int a = lane; a < (ok ? nq : 0); a += 64) {
+            wst[4 + a] = actk[a];
+            wst[4 + maxq + a] = actr[a];
+        }
+        if (lane == 0) {
+            wst[0] = ok ? nq : 0;
+            wst[1] = maxq;
+            wst[2] = (int)(unsigned)wtag;
+            wst[3] = (int)(unsigned)(wtag >> 32);
+        }
     }
     if (lane == 0) {
         if (ka.status) ka.status[prob] = status;

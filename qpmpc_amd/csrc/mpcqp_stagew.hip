@@ -1427,7 +1427,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(
                             const bool act = th[u] == INF;
                             if (act) {  // (rare) the row's own threshold is gone: from its bound
                                 const int k = stepof(i), r = i - k * mk;
-                                const T lim = T(1000) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
+                                const T lim = (T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
                                 offa |= !((T)fabs((double)fr[u]) <= lim);
                             } else if (!(fr[u] >= T(-4) * th[u])) {
                                 dirty = true;

@@ -210,6 +210,18 @@ def algorithmic_build_flops(nx: int, nu: int, N: int, mk: int, stage: bool, term
     return float(f + 2 * N * nx * nx + 2 * N * nx * n)
 
 
+def stagewise_executed_flops(nx: int, nu: int, N: int, mk: int, iters: float) -> float:
+    """Floating-point operations the stage-wise kernels EXECUTE per problem (useful ones: one copy of every product, not
+    the redundant lanes): the Riccati recursion (P A, P B, B'PA, B'PB, K = S^-1 B'PA, A_cl = A - B K, P_k = A'P A_cl,
+    symmetrised), the two sweeps of the unconstrained minimiser, the initial slacks, and per active-set iteration one more
+    sweep pair plus the slack update over the m rows and the |A| slots (|A| ~ iters / 2 on average)."""
+    ricc = 2.0 * (2 * nx ** 3 + 3 * nx * nx * nu + 2 * nx * nu * nu) + nu ** 3
+    sweep = 2.0 * (nx * nx + 2 * nx * nu) + 2.0 * nu * nu  # one step of one sweep
+    slack0 = 2.0 * mk * (nx + nu)
+    per_iter = 2 * N * sweep + N * slack0 + 2.0 * N * mk * (1.0 + 0.5 * iters)
+    return float(N * (ricc + 2 * sweep + slack0) + iters * per_iter)
+
+
 def algorithmic_solve_flops(n: int, m: int, iters: float) -> float:
     """Active-set model of SURVEY.md 8d: n^3/3 + iters (2 m n + 4 n^2)."""
     return n ** 3 / 3.0 + iters * (2.0 * m * n + 4.0 * n * n)
