@@ -153,7 +153,9 @@ __host__ __device__ size_t stage_warm_bytes(int maxq) { return ((size_t)(4 + 2 *
 // NEXT launch. In a receding-horizon loop whose operands for the next period are known when this period is solved
 // (time-invariant or pre-scheduled LTV dynamics: examples/wheeled_inverted_pendulum.py:99-118) the factor is still rebuilt
 // every period, like the reference's solve_mpc does, but off the period's critical path.
-template <int NX, int NU, bool SERIAL, bool PIPE>
+// WARM: the warm-start machinery (MpcqpSolveOpts.warm_state) is compiled only into the instantiations that a launch with a
+// warm-state record selects: the cold instantiations keep the registers and the code size they had without it.
+template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
 __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
 {
@@ -1107,9 +1109,9 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     // lam = -W s0_A; rows whose multiplier comes out negative leave (one deflation each), the rest is the starting active
     // set: a period whose active set did not move costs no sweep at all.
     const int wrec = (int)(stage_warm_bytes(maxq) / sizeof(int));  // ints per problem: nq, maxq, workspace tag (2), row steps, row indices
-    int *wst = ka.warm_state ? (int *)ka.warm_state + prob * (int64_t)wrec : nullptr;
+    int *wst = (WARM && ka.warm_state) ? (int *)ka.warm_state + prob * (int64_t)wrec : nullptr;
     const unsigned long long wtag = (unsigned long long)(uintptr_t)ws;
-    if (wst && ka.warm_start && reuse && !notpd) {
+    if constexpr (WARM) if (wst && ka.warm_start && reuse && !notpd) {
         int nqs = wst[0];
         const bool same = wst[1] == maxq && (unsigned)wst[2] == (unsigned)wtag && (unsigned)wst[3] == (unsigned)(wtag >> 32);
         if (!same || nqs < 0 || nqs > maxq) nqs = 0;
@@ -1357,7 +1359,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                 ol[(int64_t)k * mk + r] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
             }
     }
-    if (wst) {  // the warm-state record of the next launch: the active rows (their vectors and W stay in the workspace)
+    if constexpr (WARM) if (wst) {  // the warm-state record of the next launch: the active rows (their vectors and W stay in the workspace)
         for (int a = lane; a < (ok ? nq : 0); a += 64) {
             wst[4 + a] = actk[a];
             wst[4 + maxq + a] = actr[a];
@@ -1401,14 +1403,14 @@ int stage_default_maxq(const KernelArgs &ka)
 
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
 
-template <int NX, int NU, bool SERIAL, bool PIPE>
+template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
 static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
     if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double);
     if (PIPE) lds += (32 + (size_t)ka.N * (NX * NX + NX * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands
-    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE>;
+    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE, WARM>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -1429,10 +1431,13 @@ bool stage_pipeline_supported(const KernelArgs &ka, int dtype) { return stage_su
 template <int NX, int NU> static int launch_stage_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const bool serial = stage_serial(ka);
-    if (ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR)
-        return serial ? launch_stage_s<NX, NU, true, true>(ka, maxq, batch, ws, st) : MPCQP_EUNSUPPORTED;
-    return serial ? launch_stage_s<NX, NU, true, false>(ka, maxq, batch, ws, st)
-                  : launch_stage_s<NX, NU, false, false>(ka, maxq, batch, ws, st);
+    if (ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR)  // (a rebuilt factor: the stored active set is not used, warm_state is ignored)
+        return serial ? launch_stage_s<NX, NU, true, true, false>(ka, maxq, batch, ws, st) : MPCQP_EUNSUPPORTED;
+    if (ka.warm_state)
+        return serial ? launch_stage_s<NX, NU, true, false, true>(ka, maxq, batch, ws, st)
+                      : launch_stage_s<NX, NU, false, false, true>(ka, maxq, batch, ws, st);
+    return serial ? launch_stage_s<NX, NU, true, false, false>(ka, maxq, batch, ws, st)
+                  : launch_stage_s<NX, NU, false, false, false>(ka, maxq, batch, ws, st);
 }
 
 int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
