@@ -147,6 +147,62 @@ bool big_supported(const KernelArgs &ka);
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
                         void *G, void *h, void *rownorm_inv, hipStream_t st);
 // large-problem solver (mpcqp_bigsolve.hip): one problem per workgroup, L^-1 packed in LDS
+#ifdef __HIPCC__
+// ---- wavefront all-reductions on the vector pipe (the stage-wise kernels; __shfl_xor is a ds_bpermute per dword and step:
+// 18 dependent LDS round trips for one (double, int) arg-min). Four DPP steps reduce every 16-lane row in all of its lanes
+// (xor 1, xor 2 inside the quads, row_half_mirror, row_mirror: every step pairs each lane with a lane of the other half of
+// its group, and the operations are commutative, so the lanes of a row end with the same bits); the four row results meet
+// through v_readlane. Call with all 64 lanes active.
+template <int CTRL, typename T> __device__ __forceinline__ T dpp_mov(T x)
+{
+    if constexpr (sizeof(T) == 8) {
+        const long long b = __builtin_bit_cast(long long, x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned)lo);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+    }
+}
+template <typename T> __device__ __forceinline__ T lane_get(T x, int l)  // (l: wavefront-uniform)
+{
+    if constexpr (sizeof(T) == 8) {
+        const long long b = __builtin_bit_cast(long long, x);
+        const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned)lo);
+    } else {
+        return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+    }
+}
+template <typename T> __device__ __forceinline__ T wave_sum_dpp(T v)
+{
+    v += dpp_mov<0xb1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4e>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+// (value, index) arg-min; ties -> lowest index (a total order: any reduction tree gives the same pair); every lane gets it
+template <typename T> __device__ __forceinline__ void wave_argmin_dpp(T &v, int &idx)
+{
+    auto merge = [&](T ov, int oi) {
+        const bool take = (ov < v) || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    };
+    merge(dpp_mov<0xb1>(v), dpp_mov<0xb1>(idx));
+    merge(dpp_mov<0x4e>(v), dpp_mov<0x4e>(idx));
+    merge(dpp_mov<0x141>(v), dpp_mov<0x141>(idx));
+    merge(dpp_mov<0x140>(v), dpp_mov<0x140>(idx));
+    const T v1 = lane_get(v, 16), v2 = lane_get(v, 32), v3 = lane_get(v, 48);
+    const int i1 = lane_get(idx, 16), i2 = lane_get(idx, 32), i3 = lane_get(idx, 48);
+    v = lane_get(v, 0);
+    idx = lane_get(idx, 0);
+    merge(v1, i1);
+    merge(v2, i2);
+    merge(v3, i3);
+}
+#endif
 bool bigsolve_supported(int n, int m, int dtype);
 size_t bigsolve_ws_elems(int n);
 bool bigsolve_struct_supported(const KernelArgs &ka, int dtype);

@@ -43,11 +43,13 @@ __device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(
 // then write the N reference rows side by side): the input a is applied to the second-order Taylor plant for nsub
 // sub-steps (qpmpc/systems/wheeled_inverted_pendulum.py:127-160), then the next MPC problem's x0 [4], goal [4] and
 // targets [N * 4] are written (examples/wheeled_inverted_pendulum.py:65-83,101-108). st / x0 / goal / tg: this loop's.
+// (s0: the loop's state as it stands in st -- the fused period requests it at the top of the solver kernel, so that its
+// round trip is not on the period's tail)
 template <typename T>
-__device__ __forceinline__ void wip_period_wave(int lane, T *st, T a, int N, T Tp, T vel, T omega2, T g, int nsub, T *x0, T *goal,
-                                                T *tg)
+__device__ __forceinline__ void wip_period_wave(int lane, T *st, const T (&s0)[4], T a, int N, T Tp, T vel, T omega2, T g, int nsub,
+                                                T *x0, T *goal, T *tg)
 {
-    T r = st[0], th = st[1], rd = st[2], thd = st[3];
+    T r = s0[0], th = s0[1], rd = s0[2], thd = s0[3];
     const T dt = Tp / (T)nsub, ag = a / g;
     for (int i = 0; i < nsub; ++i) {
         T sn, cs;
@@ -73,6 +75,13 @@ __device__ __forceinline__ void wip_period_wave(int lane, T *st, T a, int N, T T
         tg[k * 4 + 2] = vel;
         tg[k * 4 + 3] = T(0);
     }
+}
+template <typename T>
+__device__ __forceinline__ void wip_period_wave(int lane, T *st, T a, int N, T Tp, T vel, T omega2, T g, int nsub, T *x0, T *goal,
+                                                T *tg)
+{
+    const T s0[4] = {st[0], st[1], st[2], st[3]};
+    wip_period_wave<T>(lane, st, s0, a, N, Tp, vel, omega2, g, nsub, x0, goal, tg);
 }
 
 }  // namespace mpcqp

@@ -107,24 +107,9 @@ template <int CTRL> __device__ __forceinline__ double dpp64(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // (value, index) arg-min over the wavefront; ties -> lowest index; every lane gets the result
-__device__ __forceinline__ void wave_argmin(double &v, int &idx)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        const bool take = (ov < v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
-    }
-}
+__device__ __forceinline__ void wave_argmin(double &v, int &idx) { wave_argmin_dpp(v, idx); }
 // stores of one lane become visible to the other lanes of the wavefront (same CU, same L1)
 __device__ __forceinline__ void wsync()
 {
@@ -213,7 +198,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     auto tick = [&](int slot) {
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
-    tick(0);
+    tick(factor_wave ? 9 : 0);
+    // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
+    double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ka.ep_on && !factor_wave)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ep_s0[i] = ((const double *)ka.ep_states)[prob * 4 + i];
     // ================================================================= factor: Riccati recursion
     // Serial in k and nonlinear. The NX x NX matrices are spread over 16 lanes -- lane (r, c) = ((lane / 4) % 4, lane % 4)
     // holds element [r][c]; the four 16-lane rows of the wavefront do the same work -- and a product gathers its operands
@@ -447,6 +437,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     if constexpr (PIPE) {
         if (factor_wave) {  // this wavefront's work is done: mark a factor that does not exist, like KEEP does
             if (notpd && lane == 0) img_next[FSI] = __builtin_nan("");
+            tick(10);
             return;
         }
     }
@@ -456,18 +447,17 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         if (!reuse && notpd && lane == 0) Fl[FSI] = __builtin_nan("");
         if (!reuse && notpd) wsync();
         if (reuse) {
-            // eight 16-byte requests per lane in flight (a load -> LDS store loop pays one round trip per turn)
+            // straight into LDS (global_load_lds_dwordx4: 1 KB per instruction, no staging registers), every request in
+            // flight at once: ONE round trip for the image (a load -> LDS store loop paid one per turn of eight requests)
+            typedef __attribute__((address_space(3))) void lds_void;
+            typedef __attribute__((address_space(1))) const void glb_void;
             const D2 *src = (const D2 *)img;
             D2 *dst = (D2 *)Fl;
             const int n2 = N * FS / 2;  // (FS is even)
-            for (int i0 = lane; i0 < n2; i0 += 64 * 8) {
-                D2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[i0 + 64 * u < n2 ? i0 + 64 * u : n2 - 1];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (i0 + 64 * u < n2) dst[i0 + 64 * u] = v[u];
-            }
+            const int nfull = n2 >> 6;
+            for (int c = 0; c < nfull; ++c)
+                __builtin_amdgcn_global_load_lds((glb_void *)(src + c * 64 + lane), (lds_void *)(dst + c * 64), 16, 0, 0);
+            if (nfull * 64 + lane < n2) dst[nfull * 64 + lane] = src[nfull * 64 + lane];
             wsync();
             notpd = Fl[FSI] != Fl[FSI];
         } else if (keep) {
@@ -988,19 +978,39 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     wsync();
     tick(4);
     const double tol = ka.tol;
-    for (int k = k0; k < (notpd ? k0 : k1); ++k)
+    // The same pass makes the FIRST selection (the values are in registers: the loop's own selection pass would wait for
+    // them to come back from the workspace) and keeps the unconstrained inputs of the lane's first step: a problem none of
+    // whose rows is violated there -- most periods of a well-conditioned loop -- is finished after this pass.
+    double best = INF, u_first[NU];
+    int bi = 0x7fffffff;
+    bool presel = true;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u_first[i] = 0.0;
+    for (int k = k0; k < (notpd ? k0 : k1); ++k) {
+        if (k == k0)
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u_first[i] = U0[wq(k) * NU + i];
         for (int r = 0; r < mk; ++r) {
             const int64_t i = wq(k) * mk + r;
             const double ev = ge[k * sE + r];
-            sl[i] = ev - gdot(k, wq(k), r, U0, X0);
+            const double sv = ev - gdot(k, wq(k), r, U0, X0);
+            sl[i] = sv;
             double nn = 0.0;
             if (gC)
                 for (int c = 0; c < NX; ++c) nn += gC[k * sC + r * NX + c] * gC[k * sC + r * NX + c];
             if (gD)
                 for (int c = 0; c < NU; ++c) nn += gD[k * sD + r * NU + c] * gD[k * sD + r * NU + c];
-            invn[i] = nn > 0.0 ? rsqrt(nn) : 1.0;
+            const double in = nn > 0.0 ? rsqrt(nn) : 1.0;
+            invn[i] = in;
             rowslot[i] = -1;
+            const bool viol = ev < 1e29 && sv < -(tol + tol * fabs(ev));
+            const double sc = sv * in;
+            if (viol && sc < best) {
+                best = sc;
+                bi = k * mk + r;
+            }
         }
+    }
     wsync();
 
     tick(5);
@@ -1009,7 +1019,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     const int max_iter = ka.max_iter;
     const int nvar = N * NU;
     double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
-    bool fail = false, slotsfull = false;
+    bool fail = false, slotsfull = false, unconstrained = false;
     // slot l leaves the active set: W is deflated and the last slot moves into the hole (nq is decremented by the caller)
     auto drop_slot = [&](int l) {
         const double wll = Wm[(int64_t)l * maxq + l];
@@ -1073,6 +1083,9 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                 double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
 #pragma unroll
                 for (int i = 0; i < NU; ++i) ou[i] = u[i];
+                if (k == k0)
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) u_first[i] = u[i];
             }
             for (int r = 0; r < mk; ++r) {
                 const int64_t i = wq(k) * mk + r;
@@ -1112,6 +1125,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     int *wst = (WARM && ka.warm_state) ? (int *)ka.warm_state + prob * (int64_t)wrec : nullptr;
     const unsigned long long wtag = (unsigned long long)(uintptr_t)ws;
     if constexpr (WARM) if (wst && ka.warm_start && reuse && !notpd) {
+        presel = false;  // (the slacks move with the stored active set)
         int nqs = wst[0];
         const bool same = wst[1] == maxq && (unsigned)wst[2] == (unsigned)wtag && (unsigned)wst[3] == (unsigned)(wtag >> 32);
         if (!same || nqs < 0 || nqs > maxq) nqs = 0;
@@ -1166,10 +1180,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     }
     for (int round = 0; round < 4 && !fail && !notpd; ++round) {
         for (;;) {
-            // ---- selection: the violated row farthest from its hyperplane
-            double best = INF;
-            int bi = 0x7fffffff;
-            for (int k = k0; k < k1; ++k)
+            // ---- selection: the violated row farthest from its hyperplane (the first one was made by the slack pass)
+            if (!presel) {
+                best = INF;
+                bi = 0x7fffffff;
+            }
+            for (int k = k0; k < (presel ? k0 : k1); ++k)
                 for (int r = 0; r < mk; ++r) {
                     const int64_t i = wq(k) * mk + r;
                     const double ev = ge[k * sE + r], sv = sl[i];
@@ -1180,9 +1196,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                         bi = k * mk + r;  // natural row id: ties go to the lowest one, like the restatement
                     }
                 }
+            const bool first_sel = presel;
+            presel = false;
             wave_argmin(best, bi);
             if (!(best < INF)) {
                 status = MPCQP_SOLVED;
+                if (first_sel) unconstrained = true;  // nothing was violated at the unconstrained minimiser: it is the plan
                 break;
             }
             const int kp = bi / mk, rp = bi - kp * mk;
@@ -1328,7 +1347,16 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         // ================================================================= primal point, verification
         // u = u0 - sum_a lam_a V_a ; slacks from scratch through x = x0 - sum_a lam_a X_a
         bool dirty = false, offa = false;
-        eval_point(true, dirty, offa);
+        if (unconstrained) {
+            // the slack pass evaluated exactly this point (no active row, u = u0): only the inputs are left to write
+            for (int k = k0; k < k1; ++k) {
+                double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
+#pragma unroll
+                for (int i = 0; i < NU; ++i) ou[i] = k == k0 ? u_first[i] : U0[wq(k) * NU + i];
+            }
+        } else {
+            eval_point(true, dirty, offa);
+        }
         if (offa) {  // an active row is off its bound (W drifted, or a warm state that was not this problem's): start cold
             cold_start();
             status = MPCQP_MAX_ITER;
@@ -1355,8 +1383,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         double *ol = (double *)ka.lam + prob * (int64_t)N * mk;
         for (int k = k0; k < k1; ++k)
             for (int r = 0; r < mk; ++r) {
-                const int sidx = rowslot[wq(k) * mk + r];
-                ol[(int64_t)k * mk + r] = (ok && sidx >= 0) ? lamv[sidx] : 0.0;
+                const int sidx = (ok && nq > 0) ? rowslot[wq(k) * mk + r] : -1;
+                ol[(int64_t)k * mk + r] = sidx >= 0 ? lamv[sidx] : 0.0;
             }
     }
     if constexpr (WARM) if (wst) {  // the warm-state record of the next launch: the active rows (their vectors and W stay in the workspace)
@@ -1378,15 +1406,16 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     if (ka.ep_on) {
         // the rest of the control period: plant step with the plan's first input (zero if there is no plan), then the
         // loop's next problem written over the one just solved (this wavefront is its only reader)
-        wsync();
-        const double a = ok ? ((const double *)ka.U)[prob * (int64_t)N * NU] : 0.0;
-        wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
+        // (the plan's first input is lane 0's: step 0 is the first step of its chunk)
+        const double a = ok ? __shfl(u_first[0], 0) : 0.0;
+        wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, ep_s0, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
                                 ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt));
         if (lane == 0 && ka.ep_loopstats) {
             ka.ep_loopstats[2 * prob] += ok ? 0 : 1;
             ka.ep_loopstats[2 * prob + 1] += iters;
         }
     }
+    tick(8);
 }
 
 // ------------------------------------------------------------ host side

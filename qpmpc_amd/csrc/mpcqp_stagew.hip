@@ -118,23 +118,8 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     return w;
 }
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &idx)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const T ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(idx, o);
-        const bool take = (ov < v) || (ov == v && oi < idx);
-        v = take ? ov : v;
-        idx = take ? oi : idx;
-    }
-}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_sum_dpp(v); }
+template <typename T> __device__ __forceinline__ void wave_argmin(T &v, int &idx) { wave_argmin_dpp(v, idx); }
 __device__ __forceinline__ void wsync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
