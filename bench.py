@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6   # MI355X vector/matrix fp64 peak (AMD spec; not in the guide)
 FP32_PEAK_TFLOPS = 157.3  # MI355X f32 vector = f32-input MFMA peak (MI355X_MICROARCH.md)
+PERIODS_PER_LAUNCH = 20   # config 3: consecutive control periods of the closed loops per launch
 
 CONFIGS = {
     2: dict(batch=4096, scaling="weak", dtype="f64",
@@ -48,7 +49,7 @@ CONFIGS = {
     3: dict(batch=1024, scaling="weak", dtype="f64",
             workload="{b} wheeled-inverted-pendulum receding-horizon loops, N=50 T=0.024 s (nx=4 nu=1, n=50 m=100), LTV "
                      "lists, fp64; one step = one MPC period: fused build+solve rebuilt every step (the factor by a second "
-                     "wavefront one period ahead) + plant (15 sub-steps)"),
+                     "wavefront one period ahead) + plant (15 sub-steps); up to 20 consecutive periods per launch"),
     4: dict(batch=65536, scaling="strong", dtype="f64",
             workload="humanoid one-step (LIPM) N=16 (n=16 m=32), {b}-state sweep strong-sharded over the GPUs, fp64, "
                      "fused build+solve; U/status all_gather timed separately"),
@@ -120,9 +121,12 @@ class _Runner:
 
             # the factor is rebuilt every period like the reference's solve_mpc does (solve_mpc.py:42), by a second wavefront
             # working one period ahead (MPCQP_OPT_PIPELINE_FACTOR); other_workloads has the unpipelined rate
-            self.loop = WIPClosedLoop(np.asarray(w["x0"]), pipeline_factor=True)
+            # ... and up to PERIODS_PER_LAUNCH consecutive periods run in one launch (mpcqp_wip_periods_batch: the wavefront
+            # that solved period t carries on with t + 1; same trajectories bit for bit, no dispatch gap between periods)
+            self.loop = WIPClosedLoop(np.asarray(w["x0"]), pipeline_factor=True, periods_per_launch=PERIODS_PER_LAUNCH)
             self.solver = self.loop.solver
             self.launch = lambda stream=None: self.loop.step()
+            self.launch_steps = lambda n: self.loop.step(n)  # K steps = K periods, in ceil(K / PERIODS_PER_LAUNCH) launches
             # the timed region is ONE EPISODE from the random initial states ("x0 ~ N(0, diag(.05,.05,
             # .1,.1)^2), ... repeat >= 100 MPC steps"): warm-up and spin-up periods must not leave the loops in
             # their constraint-free steady state
@@ -176,7 +180,7 @@ class _Clock:
 
             torch.cuda.synchronize()
 
-    def time(self, launch, steps: int):
+    def time(self, launch, steps: int, launch_steps=None):
         import torch
 
         self.sync()
@@ -185,8 +189,11 @@ class _Clock:
         t0 = time.perf_counter()
         if self.cuda:
             e0.record()
-        for _ in range(steps):
-            launch()
+        if launch_steps is not None:
+            launch_steps(steps)
+        else:
+            for _ in range(steps):
+                launch()
         if self.cuda:
             e1.record()
         self.sync()
@@ -229,7 +236,7 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
         run.reset()
     clock.sync()
     barrier()
-    elapsed, kernel_s = clock.time(run.launch, args.steps)
+    elapsed, kernel_s = clock.time(run.launch, args.steps, getattr(run, "launch_steps", None))
     barrier()
     kernel_ms = kernel_s / args.steps * 1e3  # average duration of one step's launches, HIP events
 
@@ -402,7 +409,7 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
         common["algorithmic_flops_per_problem"] = ex
         return {"bound": "mfma", "achieved": etf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": etf / FP64_PEAK_TFLOPS,
                 "kernel": "mpcqp_stage_kernel<4, 1, serial, pipelined> (stage-wise Riccati active set; two wavefronts per loop: "
-                          "one solves this period, the other rebuilds the factor for the next one) with the plant step, next "
+                          "one solves this period, the other rebuilds the factor for the next one; up to 20 periods per launch, kernel_ms is per period) with the plant step, next "
                           "references and bookkeeping as its epilogue: one launch per period",
                 "achieved_gbs": gbs, "dense_equivalent_tflops": tfs, **common,
                 "note": "achieved = float64 operations the kernel executes per period (Riccati recursion, sweeps, slack "
@@ -536,6 +543,11 @@ def other_workloads():
     loop_r = WIPClosedLoop(x0r, reuse_factor=True)
     loop_r.step(2)  # the first period keeps the factor
     out["config3_closed_loop_factor_reused_resolves"] = rate(loop_r.step, 1024, 50)
+    for key, kw in (("config3_closed_loop_rebuild_pipelined_20_periods_per_launch", {"pipeline_factor": True}),
+                    ("config3_closed_loop_factor_reused_20_periods_per_launch", {"reuse_factor": True})):
+        lp = WIPClosedLoop(rng.standard_normal((1024, 4)) * np.array([0.05, 0.05, 0.1, 0.1]), periods_per_launch=20, **kw)
+        lp.step(2)
+        out[key] = rate(lambda: lp.step(20), 1024 * 20, 4)
     # config 2 in shared-LTI mode (reported separately and labelled): stride-0 operands, then the model
     # factored once (P, Cholesky, G L^-T hoisted out of the batch)
     bp2 = W.to_batch_problem(W.triple_integrator_batch(4096, heterogeneous=False))

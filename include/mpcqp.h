@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 6
+#define MPCQP_ABI_VERSION 7
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -341,6 +341,22 @@ int mpcqp_wip_period_batch(const MpcqpDims *dims, const MpcqpProblem *problem, i
                            void *workspace, size_t workspace_bytes, void *states, int64_t *loop_stats,
                            double sampling_period, double target_vel, double length, double gravity, int32_t nsub,
                            void *stream);
+
+/* `nperiods` consecutive control periods of every loop in ONE launch (ABI 7): what nperiods calls of
+ * mpcqp_wip_period_batch do -- the epilogue writes the loop's next problem in place, so the wavefront that solved period t
+ * carries on with period t + 1 -- without the launch boundary between them (a period of 1024 loops is ~30 us of work
+ * behind ~8 us of dispatch; the loops never interact, so nothing has to meet at a period's end). Trajectories, U / lam /
+ * status / iters (those of the LAST period) and loop_stats are bitwise what the one-period calls leave. With
+ * MPCQP_OPT_PIPELINE_FACTOR the two factor images alternate from period to period starting at opts->factor_slot: the
+ * caller's next launch passes factor_slot ^ (nperiods & 1). MPCQP_OPT_KEEP_FACTOR, warm_state and horizons whose factor
+ * does not fit LDS (N > 64 for nx = 4, nu = 1) need nperiods == 1 (MPCQP_EUNSUPPORTED otherwise); nperiods < 1 is
+ * MPCQP_EINVAL. examples/wheeled_inverted_pendulum.py:99-118, nperiods
+ * iterations of the loop. */
+int mpcqp_wip_periods_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
+                            const MpcqpSolveOpts *opts, void *U, void *lam, int32_t *status, int32_t *iters,
+                            void *workspace, size_t workspace_bytes, void *states, int64_t *loop_stats,
+                            double sampling_period, double target_vel, double length, double gravity, int32_t nsub,
+                            int32_t nperiods, void *stream);
 
 /* Bookkeeping of closed loops (the reference's loops count nothing; ours report failures and iterations):
  * stats[0] += number of problems with status != 0, stats[1] += sum of iters. stats: two int64 in DEVICE memory. */

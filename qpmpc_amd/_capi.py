@@ -13,8 +13,8 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
-EUNSUPPORTED = -6
-ABI_VERSION = 6
+EINVAL, EUNSUPPORTED = -1, -6
+ABI_VERSION = 7
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR = 64, 128, 256
 
@@ -43,6 +43,7 @@ EXPORTS = (
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
     "mpcqp_wip_period_batch",
+    "mpcqp_wip_periods_batch",
     "mpcqp_lipm_advance_batch",
     "mpcqp_lipm_advance_stats_batch",
 )
@@ -142,6 +143,8 @@ def load():
     lib.mpcqp_wip_period_batch.restype = C.c_int
     lib.mpcqp_wip_period_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.POINTER(SolveOpts), vp, vp, vp, vp, vp,
                                            C.c_size_t, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp]
+    lib.mpcqp_wip_periods_batch.restype = C.c_int
+    lib.mpcqp_wip_periods_batch.argtypes = lib.mpcqp_wip_period_batch.argtypes[:-1] + [C.c_int32, vp]
     lib.mpcqp_wip_advance_stats_batch.restype = C.c_int
     lib.mpcqp_wip_advance_stats_batch.argtypes = [C.c_int32, vp, vp, i64, vp, vp, vp, C.c_int32, C.c_double, C.c_double,
                                                   C.c_double, C.c_double, C.c_int32, vp, vp, vp, i64, vp]

@@ -44,7 +44,7 @@ class WIPClosedLoop:
 
     def __init__(self, x0, nb_timesteps: int = 50, sampling_period: float = 0.024, target_vel: float = 0.5,
                  ltv: bool = True, max_iter: Optional[int] = None, shared_model: bool = False, fused_period: bool = True,
-                 reuse_factor: bool = False, pipeline_factor: bool = False):
+                 reuse_factor: bool = False, pipeline_factor: bool = False, periods_per_launch: int = 1):
         """``fused_period``: run a whole period (solve + plant + next problem + bookkeeping) in ONE launch,
         ``mpcqp_wip_period_batch``, where the solver kernel supports it (else, and with ``shared_model``, two
         launches per period). ``reuse_factor``: the dynamics and weights never change along the loop, so the
@@ -55,7 +55,10 @@ class WIPClosedLoop:
         wavefront that works on the next period's factor while the first one solves this period with the factor the
         previous launch left (``MPCQP_OPT_PIPELINE_FACTOR``; the operands of the next period are known here: they do
         not change). Same trajectories, bit for bit; falls back to the plain rebuilding period where the kernel does
-        not offer it."""
+        not offer it. ``periods_per_launch``: with the fused period, ``step(n)`` runs up to that many consecutive periods
+        per launch (``mpcqp_wip_periods_batch``: the wavefront that solved period t carries on with period t + 1; the
+        loops never interact, so nothing has to meet at a period's end) -- same trajectories bit for bit, without the
+        dispatch gap between the periods. The first period of an episode is always a launch of its own."""
         import torch
 
         self.pendulum = WheeledInvertedPendulum(nb_timesteps=nb_timesteps, sampling_period=sampling_period)
@@ -81,6 +84,7 @@ class WIPClosedLoop:
         self._loopstats = torch.zeros((self.problem.batch_size, 2), dtype=torch.int64, device=dev)
         self._fused = bool(fused_period) and not shared_model  # cleared by the first launch if the kernel cannot do it
         self._period_args = None
+        self._ppl = max(1, int(periods_per_launch))
         self._reuse = bool(reuse_factor) and not shared_model
         self._pipe = bool(pipeline_factor) and not shared_model and not self._reuse
         if self._reuse or self._pipe:
@@ -127,7 +131,9 @@ class WIPClosedLoop:
         p, pend = self.problem, self.pendulum
         if self.mpc_steps == 0:
             self._write_references()
-        for _ in range(nb_mpc_steps):
+        left = int(nb_mpc_steps)
+        while left > 0:
+            left -= 1
             if self._reuse and self.mpc_steps == 1:  # the first period of the episode left the factor in the workspace
                 self.solver._opts.flags = (self.solver._opts.flags & ~_capi.OPT_KEEP_FACTOR) | _capi.OPT_REUSE_FACTOR
             if self._pipe:
@@ -146,17 +152,20 @@ class WIPClosedLoop:
                         C.c_void_p(self.states.data_ptr()), C.c_void_p(self._loopstats.data_ptr()),
                         C.c_double(pend.sampling_period), C.c_double(self.target_vel), C.c_double(pend.length),
                         C.c_double(pend.GRAVITY), C.c_int32(NB_SUBSTEPS))
-                rc = lib.mpcqp_wip_period_batch(*self._period_args, _stream_ptr())
+                # periods of this launch: the episode's first period stands alone (it keeps its factor for the others)
+                k = 1 if self.mpc_steps == 0 else min(self._ppl, left + 1)
+                rc = lib.mpcqp_wip_periods_batch(*self._period_args, k, _stream_ptr())
                 if rc == _capi.EUNSUPPORTED and self._pipe and self.mpc_steps > 0:
                     # (this horizon has no factor image to pipeline through: plain rebuilding periods)
                     self._pipe = False
                     self.solver._opts.flags &= ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_KEEP_FACTOR)
-                    rc = lib.mpcqp_wip_period_batch(*self._period_args, _stream_ptr())
+                    rc = lib.mpcqp_wip_periods_batch(*self._period_args, k, _stream_ptr())
                 if rc == _capi.EUNSUPPORTED:
                     self._fused = False  # (another kernel serves this size: two launches per period)
                 else:
-                    _capi.check(rc, "mpcqp_wip_period_batch")
-                    self.mpc_steps += 1
+                    _capi.check(rc, "mpcqp_wip_periods_batch")
+                    self.mpc_steps += k
+                    left -= k - 1
                     continue
             if self._pipe:
                 rc = self.solver._entry(*self.solver._args, _stream_ptr())

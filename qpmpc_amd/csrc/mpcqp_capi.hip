@@ -675,6 +675,16 @@ int mpcqp_wip_period_batch(const MpcqpDims *dims, const MpcqpProblem *problem, i
                            void *states, int64_t *loop_stats, double sampling_period, double target_vel, double length,
                            double gravity, int32_t nsub, void *stream)
 {
+    return mpcqp_wip_periods_batch(dims, problem, batch, opts, U, lam, status, iters, workspace, workspace_bytes, states,
+                                   loop_stats, sampling_period, target_vel, length, gravity, nsub, 1, stream);
+}
+
+int mpcqp_wip_periods_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, const MpcqpSolveOpts *opts,
+                            void *U, void *lam, int32_t *status, int32_t *iters, void *workspace, size_t workspace_bytes,
+                            void *states, int64_t *loop_stats, double sampling_period, double target_vel, double length,
+                            double gravity, int32_t nsub, int32_t nperiods, void *stream)
+{
+    if (nperiods < 1) return MPCQP_EINVAL;
     int rc = check_dims(dims);
     if (rc) return rc;
     if ((rc = check_problem(dims, problem))) return rc;
@@ -696,7 +706,12 @@ int mpcqp_wip_period_batch(const MpcqpDims *dims, const MpcqpProblem *problem, i
     const int maxq = stage_default_maxq(ka);
     const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
     if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+    // several periods per launch: a factor that is kept is the FIRST period's business (the caller's next launch reuses
+    // or pipelines it), and the warm-state record is per launch
+    if (nperiods > 1 && ((ka.opt_flags & MPCQP_OPT_KEEP_FACTOR) || ka.warm_state || !stage_pipeline_supported(ka, dims->dtype)))
+        return MPCQP_EUNSUPPORTED;  // (... and the period loop is compiled into the short-horizon instantiations only)
     ka.ep_on = 1;
+    ka.ep_periods = nperiods;
     ka.ep_nsub = nsub;
     ka.ep_Tp = sampling_period;
     ka.ep_vel = target_vel;

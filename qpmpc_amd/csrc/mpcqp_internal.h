@@ -38,7 +38,7 @@ struct KernelArgs {
     void *probe;                  // developer probe: int64 stamps per problem, or null
     // closed-loop epilogue of the stage-wise kernel (mpcqp_wip_period_batch): after its solve every wavefront applies
     // the first input of its plan to the wheeled-inverted-pendulum plant and writes its loop's NEXT problem in place
-    int ep_on, ep_nsub;
+    int ep_on, ep_nsub, ep_periods;  // (ep_periods: control periods per launch, mpcqp_wip_periods_batch; 0 / 1 = one)
     double ep_Tp, ep_vel, ep_omega2, ep_g;
     void *ep_states;              // [batch, 4], updated in place
     long long *ep_loopstats;      // [batch, 2]: += (failed, iterations), or null

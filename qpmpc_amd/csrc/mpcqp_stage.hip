@@ -142,12 +142,30 @@ __host__ __device__ size_t stage_warm_bytes(int maxq) { return ((size_t)(4 + 2 *
 // warm-state record selects: the cold instantiations keep the registers and the code size they had without it.
 template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
 __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
-    mpcqp_stage_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, const int64_t batch)
+    mpcqp_stage_kernel(const KernelArgs ka_, const Ws wl_, double *__restrict__ wsbase_, const int64_t batch)
 {
+    // ONE PERIOD = one build + solve (+ the fused plant epilogue). A launch runs ka.ep_periods of them back to back
+    // (mpcqp_wip_periods_batch: the loop's next problem is written by the epilogue, so the wavefront carries on with it --
+    // no launch boundary, no dispatch gap between the periods); every other entry point runs one. (Everything, the
+    // address arithmetic included, is inside the period: nothing but the kernel's arguments stays live across periods.)
+    auto period = [&](const int per) {
+    // (the lane and problem indices pass through an empty asm: the optimiser must not hoist the period's address
+    // arithmetic out of the period loop, where all of it would stay live across the whole period -- that version of the
+    // kernel spilled 50-200 VGPRs)
+    typedef const __attribute__((address_space(4))) unsigned char *KargPtr;
+    KargPtr kbase = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    int tid = threadIdx.x;
+    int64_t prob = blockIdx.x;
+    if constexpr (SERIAL) asm volatile("" : "+s"(kbase), "+s"(prob), "+v"(tid));
+    // (the kernel's arguments, read where they lie in the kernarg segment: ka_ first, wl_ and wsbase_ behind it)
+    constexpr size_t off_wl = (sizeof(KernelArgs) + alignof(Ws) - 1) / alignof(Ws) * alignof(Ws);
+    constexpr size_t off_ws = (off_wl + sizeof(Ws) + 7) / 8 * 8;
+    const __attribute__((address_space(4))) KernelArgs &ka = *(const __attribute__((address_space(4))) KernelArgs *)kbase;
+    const __attribute__((address_space(4))) Ws &wl = *(const __attribute__((address_space(4))) Ws *)(kbase + off_wl);
+    double *wsbase = *(double *const __attribute__((address_space(4))) *)(kbase + off_ws);
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
-    const int lane = threadIdx.x & 63;
-    const bool factor_wave = PIPE && (threadIdx.x >> 6) == 1;
-    const int64_t prob = blockIdx.x;
+    const int lane = tid & 63;
+    const bool factor_wave = PIPE && (tid >> 6) == 1;
     const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int L = (N + 63) / 64;                    // steps per chunk
     const int k0 = lane * L < N ? lane * L : N;     // this lane's chunk [k0, k1)
@@ -198,12 +216,6 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     auto tick = [&](int slot) {
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
-    tick(factor_wave ? 9 : 0);
-    // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
-    double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
-    if (ka.ep_on && !factor_wave)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ep_s0[i] = ((const double *)ka.ep_states)[prob * 4 + i];
     // ================================================================= factor: Riccati recursion
     // Serial in k and nonlinear. The NX x NX matrices are spread over 16 lanes -- lane (r, c) = ((lane / 4) % 4, lane % 4)
     // holds element [r][c]; the four 16-lane rows of the wavefront do the same work -- and a product gathers its operands
@@ -215,10 +227,18 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
     const bool reuse = PIPE ? !factor_wave : (ka.opt_flags & MPCQP_OPT_REUSE_FACTOR) != 0;
     const bool keep = !PIPE && (ka.opt_flags & MPCQP_OPT_KEEP_FACTOR);
-    // factor images in the workspace: this launch's (read by REUSE / the solving wavefront, written by KEEP) and the next one's
-    double *img = ws + wl.Fimg + (int64_t)(ka.factor_slot & 1) * N * FS;
-    double *img_next = ws + wl.Fimg + (int64_t)((ka.factor_slot & 1) ^ 1) * N * FS;
     if constexpr (PIPE) rsc += 32 + (int64_t)N * (FS + NU + NX);  // (the factor wavefront's own exchange cells, after everything)
+    tick(factor_wave ? 9 : 0);
+    // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
+    double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ka.ep_on && !factor_wave)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ep_s0[i] = ((const double *)ka.ep_states)[prob * 4 + i];
+    // factor images in the workspace: this period's (read by REUSE / the solving wavefront, written by KEEP) and the next one's
+    // (PIPE: the two alternate from period to period)
+    const int slot = (ka.factor_slot + (PIPE ? per : 0)) & 1;
+    double *img = ws + wl.Fimg + (int64_t)slot * N * FS;
+    double *img_next = ws + wl.Fimg + (int64_t)(slot ^ 1) * N * FS;
     // S_k = w_u I + B_k' P_{k+1} B_k are the Schur complements of the condensed Hessian in the order u_{N-1}, ..., u_0: P is
     // positive definite iff every S_k is (mpc_problem.py:104-107 only guarantees w_u > 0; a negative state weight can
     // still make P indefinite). A pivot that is not positive -> MPCQP_NOT_PD, like the condensed kernels' Cholesky.
@@ -1416,6 +1436,23 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         }
     }
     tick(8);
+    };  // period
+    if constexpr (!SERIAL) {  // (long horizons: one period per launch, mpcqp_wip_periods_batch refuses more)
+        period(0);
+        return;
+    }
+    const int nper = (ka_.ep_on && ka_.ep_periods > 1) ? ka_.ep_periods : 1;
+    for (int per = 0; per < nper; ++per) {
+        period(per);
+        if (per + 1 < nper) {
+            // the next period's x0 / goal / targets / state were written by this wavefront, its factor image by the other
+            // one (PIPE): same CU, same L1 -- the stores have to be complete, nothing has to be invalidated but the
+            // scalar cache
+            wsync();
+            __builtin_amdgcn_s_dcache_inv();
+            if constexpr (PIPE) __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------ host side

@@ -1204,3 +1204,50 @@ def test_closed_loop_with_the_factor_pipelined_equals_the_rebuilding_loop():
     ref.step(5)
     torch.cuda.synchronize()
     assert not short._pipe and torch.equal(short.states, ref.states)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [{}, {"pipeline_factor": True}, {"reuse_factor": True}])
+def test_several_periods_per_launch_equal_one_period_per_launch(mode):
+    """mpcqp_wip_periods_batch: the wavefront that solved period t carries on with period t + 1 inside the same launch
+    (examples/wheeled_inverted_pendulum.py:99-118, several iterations of the loop). States, references, the last period's
+    plan and the loops' counters are bitwise those of one launch per period -- rebuilding, with the factor pipelined by the
+    second wavefront (the two factor images alternate inside the launch) and with the factor reused; step counts that are
+    not a multiple of the periods per launch, a reset in between, and the refusals (nperiods < 1, a kept factor)."""
+    import ctypes as C
+
+    from qpmpc_amd import _capi
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(16)
+    x0 = rng.standard_normal((160, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    x0[0] = [0.0, 0.3, 0.0, 1.0]  # saturates the input box: iterations are counted
+    x0[1] = [0.0, -0.25, 0.0, -0.8]
+    a = WIPClosedLoop(x0.copy(), periods_per_launch=4, **mode)
+    b = WIPClosedLoop(x0.copy(), **mode)
+    for n in (1, 9, 4, 7):
+        a.step(n)
+        b.step(n)
+        torch.cuda.synchronize()
+        assert a._fused and a.mpc_steps == b.mpc_steps
+        assert torch.equal(a.states, b.states)
+        assert torch.equal(a.problem.target_states, b.problem.target_states) and torch.equal(a.problem.goal_state, b.problem.goal_state)
+        assert torch.equal(a.problem.initial_state, b.problem.initial_state)
+        assert torch.equal(a.solver.U, b.solver.U) and torch.equal(a.solver.status, b.solver.status)
+    assert a.stats() == b.stats() and a.stats()["mean_iters"] > 0.0
+    a.reset(x0[::-1].copy())
+    b.reset(x0[::-1].copy())
+    a.step(11)
+    b.step(11)
+    torch.cuda.synchronize()
+    assert torch.equal(a.states, b.states) and a.stats() == b.stats()
+    # refusals
+    lib = _capi.load()
+    args = a._period_args
+    assert lib.mpcqp_wip_periods_batch(*args, 0, None) == _capi.EINVAL
+    if mode:
+        o = a.solver._opts
+        keep = o.flags
+        o.flags = (o.flags & ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_REUSE_FACTOR)) | _capi.OPT_KEEP_FACTOR
+        assert lib.mpcqp_wip_periods_batch(*args, 2, None) == _capi.EUNSUPPORTED
+        o.flags = keep

@@ -7,7 +7,9 @@ from qpmpc_amd.closed_loop import WIPClosedLoop
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rng = np.random.default_rng(1)
 x0 = rng.standard_normal((B, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # periods per launch
 for name, kw in (("rebuild", {}), ("pipeline_factor", {"pipeline_factor": True}), ("reuse_factor", {"reuse_factor": True})):
+    kw = dict(kw, periods_per_launch=P)
     loop = WIPClosedLoop(x0.copy(), **kw)
     loop.step(20); torch.cuda.synchronize()
     best = 1e9
