@@ -156,7 +156,9 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     KargPtr kbase = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int tid = threadIdx.x;
     int64_t prob = blockIdx.x;
-    if constexpr (SERIAL) asm volatile("" : "+s"(kbase), "+s"(prob), "+v"(tid));
+    // MULTI: the instantiations that mpcqp_wip_periods_batch reaches (the plant of the fused period has nx = 4, nu = 1)
+    constexpr bool MULTI = SERIAL && NX == 4 && NU == 1;
+    if constexpr (MULTI) asm volatile("" : "+s"(kbase), "+s"(prob), "+v"(tid));
     // (the kernel's arguments, read where they lie in the kernarg segment: ka_ first, wl_ and wsbase_ behind it)
     constexpr size_t off_wl = (sizeof(KernelArgs) + alignof(Ws) - 1) / alignof(Ws) * alignof(Ws);
     constexpr size_t off_ws = (off_wl + sizeof(Ws) + 7) / 8 * 8;
@@ -1003,11 +1005,11 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     // whose rows is violated there -- most periods of a well-conditioned loop -- is finished after this pass.
     double best = INF, u_first[NU];
     int bi = 0x7fffffff;
-    bool presel = true;
+    bool presel = SERIAL;  // (the long-horizon instantiations have no registers to spare for it: 254 VGPRs)
 #pragma unroll
     for (int i = 0; i < NU; ++i) u_first[i] = 0.0;
     for (int k = k0; k < (notpd ? k0 : k1); ++k) {
-        if (k == k0)
+        if (SERIAL && k == k0)
 #pragma unroll
             for (int i = 0; i < NU; ++i) u_first[i] = U0[wq(k) * NU + i];
         for (int r = 0; r < mk; ++r) {
@@ -1023,11 +1025,13 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
             const double in = nn > 0.0 ? rsqrt(nn) : 1.0;
             invn[i] = in;
             rowslot[i] = -1;
-            const bool viol = ev < 1e29 && sv < -(tol + tol * fabs(ev));
-            const double sc = sv * in;
-            if (viol && sc < best) {
-                best = sc;
-                bi = k * mk + r;
+            if constexpr (SERIAL) {
+                const bool viol = ev < 1e29 && sv < -(tol + tol * fabs(ev));
+                const double sc = sv * in;
+                if (viol && sc < best) {
+                    best = sc;
+                    bi = k * mk + r;
+                }
             }
         }
     }
@@ -1103,7 +1107,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
                 double *ou = (double *)ka.U + prob * (int64_t)nvar + (int64_t)k * NU;
 #pragma unroll
                 for (int i = 0; i < NU; ++i) ou[i] = u[i];
-                if (k == k0)
+                if (SERIAL && k == k0)
 #pragma unroll
                     for (int i = 0; i < NU; ++i) u_first[i] = u[i];
             }
@@ -1427,7 +1431,13 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
         // the rest of the control period: plant step with the plan's first input (zero if there is no plan), then the
         // loop's next problem written over the one just solved (this wavefront is its only reader)
         // (the plan's first input is lane 0's: step 0 is the first step of its chunk)
-        const double a = ok ? __shfl(u_first[0], 0) : 0.0;
+        double a = 0.0;
+        if constexpr (SERIAL) {
+            a = ok ? __shfl(u_first[0], 0) : 0.0;
+        } else {
+            wsync();
+            a = ok ? ((const double *)ka.U)[prob * (int64_t)N * NU] : 0.0;
+        }
         wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, ep_s0, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
                                 ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt));
         if (lane == 0 && ka.ep_loopstats) {
@@ -1437,7 +1447,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     }
     tick(8);
     };  // period
-    if constexpr (!SERIAL) {  // (long horizons: one period per launch, mpcqp_wip_periods_batch refuses more)
+    if constexpr (!(SERIAL && NX == 4 && NU == 1)) {  // (one period per launch: mpcqp_wip_periods_batch refuses more)
         period(0);
         return;
     }
