@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
@@ -19,7 +21,7 @@ namespace mpcqp {
 
 namespace big {
 constexpr int NXMAX = 16;  // state dimension held in registers by the propagation
-constexpr int KC = 16;     // rows of Psi staged per Gram step
+constexpr int KC = 32;     // rows of Psi staged per Gram step
 }  // namespace big
 using namespace big;
 
@@ -228,28 +230,38 @@ __global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArg
 
 // ------------------------------------------------------------------ Gram, MFMA f32
 // P = w_u I + sum_rows w_row Psi[row,:]' Psi[row,:]  (n x n, n a multiple of 32, <= 256)
-// One workgroup of 8 wavefronts per problem. Wavefront w owns tile row w of the LOWER triangle:
-// the tiles P[32w : 32w+32, 32t : 32t+32], t <= w, as accumulators of v_mfma_f32_32x32x2_f32
-// (the upper triangle is mirrored in the epilogue through LDS). Psi is streamed through LDS
-// KC rows at a time; the A operand (this wavefront's 32 columns, scaled by the row weight) is
-// loaded once per k-step and reused for every tile of the strip.
-// Causality is used twice: row block k of Psi is zero from column k nu on (u_j with j >= k does
-// not reach x_k, qpmpc/mpc_qp.py:80-90), so a chunk of rows is only staged up to that column and
-// only the strips that start below it do any MFMA. With the symmetry this is 120 of the
-// 512 tile-rows of the dense product for N = 64 (the wavefront with most work does 20 of 64).
+// One workgroup of 8 wavefronts per problem; the NT (NT + 1) / 2 tiles of 32 x 32 of the LOWER triangle are
+// accumulators of v_mfma_f32_32x32x2_f32 (the upper triangle is mirrored in the epilogue through LDS). Psi is streamed
+// through LDS KC rows at a time, the next chunk requested into registers while this one feeds the matrix cores.
+// Causality is used twice: row block k of Psi is zero from column k nu on (u_j with j >= k does not reach x_k,
+// qpmpc/mpc_qp.py:80-90), so a chunk of rows is only staged up to that column and only the tiles whose ROW block starts
+// below it do any MFMA: with the symmetry 5760 MFMAs per config-5 problem instead of the dense product's 24,576.
+// Which wavefront owns which tile decides how busy the matrix cores are: the chunks are walked in lock step (one barrier
+// pair per chunk), and at the chunk of step k only the tile rows I < ceil(k nu / 32) are active. Round 1-2 gave wavefront w
+// tile row w: the last chunks kept one wavefront busy with 8 tiles while wavefront 0 had one (matrix cores <= 42 % busy by
+// construction, 24 % measured). Now the tiles are dealt round-robin IN THEIR ORDER OF ACTIVATION (row-major over the lower
+// triangle: tile t -> wavefront t mod 8, its slot t / 8): at every chunk the active tiles are the first c (c + 1) / 2 of
+// that order, so the wavefronts' counts differ by at most one (>= 79 % by construction), and a wavefront holds at most
+// ceil(36 / 8) = 5 accumulators instead of 8 (80 instead of 128 registers: two problems per CU).
+// The tile's row stride in LDS is 256 + 32 floats: the two k-rows an MFMA operand read touches (lanes 0..31 / 32..63) fall
+// into different halves of the 64 banks.
 // q = Psi' W resid is accumulated by the first n threads from the same tile.
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int NT>  // NT = n / 32 tiles per strip
-__global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelArgs ka, const float *__restrict__ Psi_ws,
-                                                                   const float *__restrict__ res_ws,
-                                                                   float *__restrict__ oP, float *__restrict__ oq)
+template <int NT>  // NT = n / 32 tile rows
+__global__ void __launch_bounds__(512, 4) mpcqp_gram_mfma_f32_kernel(const KernelArgs ka, const float *__restrict__ Psi_ws,
+                                                                      const float *__restrict__ res_ws,
+                                                                      float *__restrict__ oP, float *__restrict__ oq)
 {
-    __shared__ __attribute__((aligned(16))) float tile[KC * 256];
+    constexpr int NTL = NT * (NT + 1) / 2;  // tiles of the lower triangle
+    constexpr int SL = (NTL + 7) / 8;       // accumulators per wavefront
+    constexpr int LDT = 256 + 32;           // row stride of the staged chunk
+    __shared__ __attribute__((aligned(16))) float tile[KC * LDT];
     __shared__ float tr[8][32 * 33];
     __shared__ float wrow[KC], rrow[KC];
     const int nx = ka.nx, nu = ka.nu, N = ka.N, n = ka.n;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t prob = blockIdx.x;
     const int K = (N + 1) * nx;
     const float *Psi = Psi_ws + prob * (int64_t)K * n;
@@ -258,13 +270,22 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
     const float wtp = (ka.flags & MPCQP_P_TERMINAL) ? (float)ka.wt : 0.0f;
     const float wxq = (ka.flags & MPCQP_Q_STAGE) ? (float)ka.wx : 0.0f;
     const float wtq = (ka.flags & MPCQP_Q_TERMINAL) ? (float)ka.wt : 0.0f;
-    f32x16 acc[NT];
+    // this wavefront's tiles: t = wv + 8 s -> (I, J) with t = I (I + 1) / 2 + J, J <= I (wavefront-uniform)
+    int tI[SL], tJ[SL];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int s = 0; s < SL; ++s) {
+        const int t = wv + 8 * s;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= t) ++I;
+        tI[s] = t < NTL ? I : NT;  // (a slot without a tile never becomes active: its row block starts at n)
+        tJ[s] = t < NTL ? t - I * (I + 1) / 2 : 0;
+    }
+    f32x16 acc[SL];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    for (int s = 0; s < SL; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
     float qacc = 0.0f;
-    const bool strip = wv < NT;  // wavefronts beyond n/32 only help with the staging
     // block 0 of Psi is zero: start at row nx. The NEXT chunk's rows are requested into registers before this
     // chunk's MFMAs and land in LDS after them, so the HBM latency of the staging overlaps the matrix work.
     auto chunk_cols = [&](int row0, int &cnz, int &cmax) {
@@ -272,20 +293,19 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
         cnz = min(n, klast * nu);
         cmax = min(n, (cnz + 31) & ~31);
     };
-    float4 pf[2];
+    // staging: wavefront w carries rows w, w + 8, ... of the chunk, lane l the columns 4 l .. 4 l + 3 (no index arithmetic
+    // beyond that: a division by the chunk's width per staged vector cost more than the matrix work)
+    constexpr int NPF = KC / 8;
+    float4 pf[NPF];
     float pw = 0.0f, pr = 0.0f;
     auto request = [&](int row0) {
         int cnz, cmax;
         chunk_cols(row0, cnz, cmax);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid * 4 + u * 2048;
+        for (int u = 0; u < NPF; ++u) {
+            const int row = row0 + wv + 8 * u;
             pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < KC * cmax) {
-                const int r = i / cmax, c = i - r * cmax;
-                const int row = row0 + r;
-                if (row < K) pf[u] = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + c);
-            }
+            if (4 * lane < cmax && row < K) pf[u] = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + 4 * lane);
         }
         if (tid < KC) {
             const int row = row0 + tid;
@@ -294,70 +314,83 @@ __global__ void __launch_bounds__(512) mpcqp_gram_mfma_f32_kernel(const KernelAr
             pr = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
         }
     };
+    // operand reads: this lane's k-row of an MFMA step and its column inside a tile (a register), the tile's column block
+    // (wavefront-uniform: a scalar), the step (an immediate)
+    const float *tlane = tile + (lane >> 5) * LDT + l31;
+    int cA[SL], cB[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        cA[s] = __builtin_amdgcn_readfirstlane(32 * (tI[s] < NT ? tI[s] : 0));
+        cB[s] = __builtin_amdgcn_readfirstlane(32 * tJ[s]);
+    }
     request(nx);
     for (int row0 = nx; row0 < K; row0 += KC) {
         int cnz, cmax;
         chunk_cols(row0, cnz, cmax);
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid * 4 + u * 2048;
-            if (i < KC * cmax) {
-                const int r = i / cmax, c = i - r * cmax;
-                *reinterpret_cast<float4 *>(tile + r * 256 + c) = pf[u];
-            }
-        }
+        for (int u = 0; u < NPF; ++u)
+            if (4 * lane < cmax) *reinterpret_cast<float4 *>(tile + (wv + 8 * u) * LDT + 4 * lane) = pf[u];
         if (tid < KC) {
             wrow[tid] = pw;
             rrow[tid] = pr;
         }
         __syncthreads();
         if (row0 + KC < K) request(row0 + KC);
-        if (strip && 32 * wv < cnz) {
+        // slots are in activation order: the active ones are a prefix
+        int nact = 0;
 #pragma unroll
-            for (int kk = 0; kk < KC; kk += 2) {
-                const int kr = kk + (lane >> 5);
-                // A[i][k] = w_k Psi[k][32 wv + i],  B[k][j] = Psi[k][32 t + j]
-                const float a = wrow[kr] * tile[kr * 256 + 32 * wv + l31];
+        for (int s = 0; s < SL; ++s) nact += (32 * tI[s] < cnz) ? 1 : 0;
+        // (four MFMA steps per turn: unrolled further, the compiler hoists every operand read of the chunk and spills -- so
+        // does reading two steps' operands ahead of their MFMAs, measured; the active slots are a prefix: one scalar branch per
+        // slot and step, operand reads at immediate offsets, one multiply)
+        if (nact > 0) {
+#pragma unroll 1
+            for (int k0 = 0; k0 < KC; k0 += 8) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (t <= wv) {
-                        const float b = tile[kr * 256 + 32 * t + l31];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                for (int kk = 0; kk < 8; kk += 2) {
+                    // A[i][k] = w_k Psi[k][32 I + i],  B[k][j] = Psi[k][32 J + j]; k = k0 + kk + (lane >> 5): in the slot offsets
+                    const float wk = wrow[k0 + kk + (lane >> 5)];
+#pragma unroll
+                    for (int s = 0; s < SL; ++s) {
+                        if (s < nact) {
+                            const float av = wk * tlane[cA[s] + (k0 + kk) * LDT];
+                            const float bv = tlane[cB[s] + (k0 + kk) * LDT];
+                            acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[s], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
         if (tid < cmax) {
 #pragma unroll
-            for (int r = 0; r < KC; ++r) qacc += rrow[r] * tile[r * 256 + tid];
+            for (int r = 0; r < KC; ++r) qacc += rrow[r] * tile[r * LDT + tid];
         }
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float *P = oP + prob * (int64_t)n * n;
-    if (strip) {
-        const float wu = (float)ka.wu;
+    const float wu = (float)ka.wu;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t > wv) continue;
+    for (int s = 0; s < SL; ++s) {
+        const int I = tI[s], J = tJ[s];
+        if (I >= NT) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int il = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int i = 32 * I + il, jj = 32 * J + l31;
+            const float v = acc[s][r] + ((i == jj) ? wu : 0.0f);
+            P[(int64_t)i * n + jj] = v;
+            if (J < I) tr[wv][il * 33 + l31] = v;
+        }
+        if (J < I) {
+            // mirrored tile P[32 J + j][32 I + i], written with i across the lanes (coalesced)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int il = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int i = 32 * wv + il, jj = 32 * t + l31;
-                const float v = acc[t][r] + ((i == jj) ? wu : 0.0f);
-                P[(int64_t)i * n + jj] = v;
-                if (t < wv) tr[wv][il * 33 + l31] = v;
+                const int jl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                P[(int64_t)(32 * J + jl) * n + 32 * I + l31] = tr[wv][l31 * 33 + jl];
             }
-            if (t < wv) {
-                // mirrored tile P[32t + j][32wv + i], written with i across the lanes (coalesced)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    P[(int64_t)(32 * t + jl) * n + 32 * wv + l31] = tr[wv][l31 * 33 + jl];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
     if (tid < n) oq[prob * (int64_t)n + tid] = qacc;
