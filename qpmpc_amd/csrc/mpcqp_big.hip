@@ -35,7 +35,7 @@ using namespace big;
 // |G_i|^2 = C_i S_k C_i' + |D_i|^2 because Psi_k is zero in the columns of u_k).
 // NXC > 0: the state dimension at compile time (straight-line 16-byte broadcast reads of A_k, C_k); 0: any nx <= NXMAX.
 template <typename T, bool NRM, int NXC>
-__global__ void __launch_bounds__(320, 5) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
+__global__ void __launch_bounds__(320, (sizeof(T) == 8 || NXC == 0) ? 2 : 5) mpcqp_propagate_kernel(const KernelArgs ka, T *__restrict__ Psi_ws,
                                                               T *__restrict__ res_ws, T *__restrict__ oG,
                                                               T *__restrict__ oh, T *__restrict__ onrm)
 {

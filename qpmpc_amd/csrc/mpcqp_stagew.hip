@@ -233,7 +233,10 @@ __device__ __forceinline__ double rl(double v, int j)
 using namespace stagew;
 
 template <typename T, int NXC, bool FUSE>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 ? STAGEW_WPE32 : 2)))
+// (float32: three wavefronts per SIMD, 168 VGPRs -- except the instantiations that do not fit them without spilling: nx = 16, and
+// the general constraint layout at nx = 12, take two)
+__global__ void __launch_bounds__(64)
+    __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && NXC < 16 && (FUSE || NXC < 12)) ? STAGEW_WPE32 : 2)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
