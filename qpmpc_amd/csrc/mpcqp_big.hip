@@ -256,9 +256,12 @@ __global__ void __launch_bounds__(512, 4) mpcqp_gram_mfma_f32_kernel(const Kerne
     constexpr int NTL = NT * (NT + 1) / 2;  // tiles of the lower triangle
     constexpr int SL = (NTL + 7) / 8;       // accumulators per wavefront
     constexpr int LDT = 256 + 32;           // row stride of the staged chunk
-    __shared__ __attribute__((aligned(16))) float tile[KC * LDT];
-    __shared__ float tr[8][32 * 33];
-    __shared__ float wrow[KC], rrow[KC];
+    // two chunk buffers (the next chunk lands in one while the matrix cores read the other), the weighted residuals of every
+    // row; the epilogue's transposers reuse the first buffer
+    extern __shared__ float rr[];  // (dynamic: (N + 1) nx + KC floats, rows of Psi_all rounded up past the last chunk)
+    __shared__ __attribute__((aligned(16))) float tile0[KC * LDT];
+    __shared__ __attribute__((aligned(16))) float tile1[KC * LDT];
+    static_assert(8 * 32 * 33 <= KC * LDT, "the transposers must fit the first chunk buffer");
     const int nx = ka.nx, nu = ka.nu, N = ka.N, n = ka.n;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,71 +289,63 @@ __global__ void __launch_bounds__(512, 4) mpcqp_gram_mfma_f32_kernel(const Kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
     float qacc = 0.0f;
-    // block 0 of Psi is zero: start at row nx. The NEXT chunk's rows are requested into registers before this
-    // chunk's MFMAs and land in LDS after them, so the HBM latency of the staging overlaps the matrix work.
     auto chunk_cols = [&](int row0, int &cnz, int &cmax) {
         const int klast = min(row0 + KC - 1, K - 1) / nx;  // columns that can be non-zero: below k_last nu
         cnz = min(n, klast * nu);
         cmax = min(n, (cnz + 31) & ~31);
     };
-    // staging: wavefront w carries rows w, w + 8, ... of the chunk, lane l the columns 4 l .. 4 l + 3 (no index arithmetic
-    // beyond that: a division by the chunk's width per staged vector cost more than the matrix work)
-    constexpr int NPF = KC / 8;
-    float4 pf[NPF];
-    float pw = 0.0f, pr = 0.0f;
-    auto request = [&](int row0) {
+    // Both buffers start as zeros: a chunk is only staged up to its last non-zero column block, and that bound never
+    // shrinks along the rows, so what lies beyond it in a buffer has never been written. (Rows past the end of Psi in the
+    // last chunk keep an older chunk's values: their weight is zero.)
+    for (int i = tid; i < KC * LDT; i += 512) tile0[i] = tile1[i] = 0.0f;
+    for (int i = tid; i < K + KC; i += 512) {
+        const bool term = i >= N * nx;
+        rr[i] = i < K ? (term ? wtq : wxq) * res[i] : 0.0f;
+    }
+    __syncthreads();
+    // staging: straight into LDS (global_load_lds_dwordx4: no registers, no LDS store pass): wavefront w carries rows w, w + 8,
+    // ... of the chunk, one instruction per row (lane l the columns 4 l .. 4 l + 3: 1 KB contiguous in LDS)
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    auto request = [&](int row0, float *dst) {
         int cnz, cmax;
         chunk_cols(row0, cnz, cmax);
 #pragma unroll
-        for (int u = 0; u < NPF; ++u) {
-            const int row = row0 + wv + 8 * u;
-            pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * lane < cmax && row < K) pf[u] = *reinterpret_cast<const float4 *>(Psi + (int64_t)row * n + 4 * lane);
-        }
-        if (tid < KC) {
-            const int row = row0 + tid;
-            const bool term = row >= N * nx;
-            pw = (row < K) ? (term ? wtp : wxp) : 0.0f;
-            pr = (row < K) ? (term ? wtq : wxq) * res[row] : 0.0f;
+        for (int u = 0; u < KC / 8; ++u) {
+            const int r = wv + 8 * u, row = row0 + r;
+            if (row < K && 4 * lane < cmax)
+                __builtin_amdgcn_global_load_lds((glb_void *)(Psi + (int64_t)row * n + 4 * lane), (lds_void *)(dst + r * LDT), 16, 0, 0);
         }
     };
-    // operand reads: this lane's k-row of an MFMA step and its column inside a tile (a register), the tile's column block
-    // (wavefront-uniform: a scalar), the step (an immediate)
-    const float *tlane = tile + (lane >> 5) * LDT + l31;
     int cA[SL], cB[SL];
 #pragma unroll
     for (int s = 0; s < SL; ++s) {
         cA[s] = __builtin_amdgcn_readfirstlane(32 * (tI[s] < NT ? tI[s] : 0));
         cB[s] = __builtin_amdgcn_readfirstlane(32 * tJ[s]);
     }
-    request(nx);
-    for (int row0 = nx; row0 < K; row0 += KC) {
+    // one chunk: wait for it (this wavefront's requests, then everybody's: the barrier also says that every wavefront has
+    // finished reading the OTHER buffer), request the next chunk into that other buffer, feed the matrix cores
+    auto chunk = [&](int row0, const float *cur, float *nxt) __attribute__((always_inline)) {
         int cnz, cmax;
         chunk_cols(row0, cnz, cmax);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < NPF; ++u)
-            if (4 * lane < cmax) *reinterpret_cast<float4 *>(tile + (wv + 8 * u) * LDT + 4 * lane) = pf[u];
-        if (tid < KC) {
-            wrow[tid] = pw;
-            rrow[tid] = pr;
-        }
-        __syncthreads();
-        if (row0 + KC < K) request(row0 + KC);
+        if (row0 + KC < K) request(row0 + KC, nxt);
         // slots are in activation order: the active ones are a prefix
         int nact = 0;
 #pragma unroll
         for (int s = 0; s < SL; ++s) nact += (32 * tI[s] < cnz) ? 1 : 0;
-        // (four MFMA steps per turn: unrolled further, the compiler hoists every operand read of the chunk and spills -- so
-        // does reading two steps' operands ahead of their MFMAs, measured; the active slots are a prefix: one scalar branch per
-        // slot and step, operand reads at immediate offsets, one multiply)
+        // operand reads: this lane's k-row of an MFMA step and its column inside a tile (a register), the tile's column
+        // block (wavefront-uniform: a scalar), the step (an immediate)
+        const float *tlane = cur + (lane >> 5) * LDT + l31;
         if (nact > 0) {
 #pragma unroll 1
             for (int k0 = 0; k0 < KC; k0 += 8) {
 #pragma unroll
                 for (int kk = 0; kk < 8; kk += 2) {
-                    // A[i][k] = w_k Psi[k][32 I + i],  B[k][j] = Psi[k][32 J + j]; k = k0 + kk + (lane >> 5): in the slot offsets
-                    const float wk = wrow[k0 + kk + (lane >> 5)];
+                    // A[i][k] = w_k Psi[k][32 I + i],  B[k][j] = Psi[k][32 J + j]; k = k0 + kk + (lane >> 5)
+                    const int row = row0 + k0 + kk + (lane >> 5);
+                    const float wk = row < N * nx ? wxp : (row < K ? wtp : 0.0f);
 #pragma unroll
                     for (int s = 0; s < SL; ++s) {
                         if (s < nact) {
@@ -364,9 +359,17 @@ __global__ void __launch_bounds__(512, 4) mpcqp_gram_mfma_f32_kernel(const Kerne
         }
         if (tid < cmax) {
 #pragma unroll
-            for (int r = 0; r < KC; ++r) qacc += rrow[r] * tile[r * LDT + tid];
+            for (int r = 0; r < KC; ++r) qacc += rr[row0 + r] * cur[r * LDT + tid];
         }
+    };
+    // block 0 of Psi is zero: start at row nx
+    request(nx, tile0);
+    for (int row0 = nx; row0 < K; row0 += 2 * KC) {
+        chunk(row0, tile0, tile1);
+        if (row0 + KC < K) chunk(row0 + KC, tile1, tile0);
     }
+    __syncthreads();  // (the transposers below overwrite the first chunk buffer)
+    float(*tr)[32 * 33] = reinterpret_cast<float(*)[32 * 33]>(tile0);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     float *P = oP + prob * (int64_t)n * n;
     const float wu = (float)ka.wu;
@@ -460,7 +463,8 @@ int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Ps
         switch (ka.n / 32) {
 #define GRAM_CASE(NTV)                                                                                              \
     case NTV:                                                                                                       \
-        hipLaunchKernelGGL(mpcqp_gram_mfma_f32_kernel<NTV>, dim3((unsigned)batch), dim3(512), 0, st, ka, ps, rs,   \
+        hipLaunchKernelGGL(mpcqp_gram_mfma_f32_kernel<NTV>, dim3((unsigned)batch), dim3(512),                      \
+                           ((size_t)(ka.N + 1) * ka.nx + KC) * sizeof(float), st, ka, ps, rs,                      \
                            (float *)P, (float *)q);                                                                 \
         break;
             GRAM_CASE(1) GRAM_CASE(2) GRAM_CASE(3) GRAM_CASE(4) GRAM_CASE(5) GRAM_CASE(6) GRAM_CASE(7) GRAM_CASE(8)
