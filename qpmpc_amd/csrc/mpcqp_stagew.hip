@@ -65,6 +65,13 @@ struct Ws {  // per-problem workspace carve, in elements of T (host-computed, pa
     int maxq, mg;
 };
 
+// a lane's group of L record values (L < 4: packed, so that a step's record has no padding -- 12-byte loads for L = 3)
+template <typename T, int L> struct __attribute__((packed, aligned(sizeof(T)))) RecN {
+    T v[L];
+};
+// floats of one step's record with `nv` values per lane: groups of four, or ONE group of nv when nv < 4
+inline int64_t rec_elems(int nv) { return nv < 4 ? 64 * nv : (int64_t)((nv + 3) / 4) * 256; }
+
 // FUSE: the constraint matrices C, D do not change along the horizon and have at most 16 rows per step (a multiple of
 // four): h = G (x_k, u_k) of a forward sweep is then formed by the sweep itself, on the matrix cores, with [C | D] as a
 // constant operand held in registers -- no trajectory (Zs) is written and no pass over the m rows reads it back.
@@ -89,8 +96,8 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     // for each of the na row blocks of the stacked matrix (one when nxc + 4 <= 16)
     // (lane-major, in groups of four values per lane: 256 values per group)
     const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
-    w.Mb = take((int64_t)N * ((na * nq + 3) / 4) * 256);
-    w.Mf = take((int64_t)N * ((na * (nq + 1) + 3) / 4) * 256);
+    w.Mb = take((int64_t)N * rec_elems(na * nq));
+    w.Mf = take((int64_t)N * rec_elems(na * (nq + 1)));
     w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
     w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
     const bool fuse = fuse_ok(mk, ginv);
@@ -251,9 +258,15 @@ __global__ void __launch_bounds__(64)
     constexpr bool STACK = NXC <= 12;       // the input-sized rows fit under the state-sized ones in one 16-row block
     constexpr int NA = STACK ? 1 : 2;       // row blocks of the stacked matrices
     constexpr int NB = NA * NQ, NF = NA * (NQ + 1);  // record values per lane and step, backward / forward
-    // a step's record is stored lane-major in groups of four values (one 16- / 32-byte load per lane and group: the sweeps
-    // are bound by the ISSUE of their loads, not by latency -- measured): value e of lane l sits at (e / 4) 256 + 4 l + e % 4
-    constexpr int GB = (NB + 3) / 4, GF = (NF + 3) / 4;
+    // a step's record is stored lane-major in groups of LB (LF) <= 4 values (one load per lane and group: the sweeps are
+    // bound by the ISSUE of their loads, not by latency -- measured): value e of lane l sits at (e / L) 64 L + L l + e % L.
+    // Fewer than four values per lane form ONE group of that many (round 3: the records are the kernel's HBM traffic, and
+    // config 5's backward record -- three values -- was padded to four).
+    constexpr int LB = NB < 4 ? NB : 4, LF = NF < 4 ? NF : 4;
+    constexpr int GB = (NB + LB - 1) / LB, GF = (NF + LF - 1) / LF;
+    constexpr int SB = GB * 64 * LB, SF = GF * 64 * LF;  // elements per step
+    using RecB = RecN<T, LB>;
+    using RecF = RecN<T, LF>;
     constexpr int R = FUSE ? R_FUSE : R_PLAIN;  // right-hand sides per sweep pair
     constexpr int ZL = NXC + 4;             // a row of Zp: position g (NQ + 1) + q holds x[4 q + g] (q < NQ), u[g] (q = NQ)
     const bool col0 = c16 == 0;             // the lanes of right-hand side 0
@@ -450,15 +463,16 @@ __global__ void __launch_bounds__(64)
             // factors to the workspace: the sweeps' records (one MFMA operand = 64 consecutive values), K' and the factor
             // of S (read at the candidate row's step)
             {
-                V4 rb = {T(0), T(0), T(0), T(0)}, rf = {T(0), T(0), T(0), T(0)};
+                RecB rb;  // (this branch: NB = NQ <= 3 and NF = NQ + 1 <= 4 values per lane, one group each)
+                RecF rf;
 #pragma unroll
                 for (int e = 0; e < NQ; ++e) {
-                    rb[e] = E[e];
-                    rf[e] = M2[e];
+                    rb.v[e] = E[e];
+                    rf.v[e] = M2[e];
                 }
-                rf[NQ] = -mB;
-                *(V4 *)(Mb + (int64_t)k * (GB * 256) + lane * 4) = rb;
-                *(V4 *)(Mf + (int64_t)k * (GF * 256) + lane * 4) = rf;
+                rf.v[NQ] = -mB;
+                *(RecB *)(Mb + (int64_t)k * SB + lane * LB) = rb;
+                *(RecF *)(Mf + (int64_t)k * SF + lane * LF) = rf;
                 T *ks = KS + (int64_t)k * (nx * nu + 16);
                 if (scol && lcol < nx && pg < nu) ks[lcol * nu + pg] = -E[TI];
                 if (lane == 0) {
@@ -604,22 +618,21 @@ __global__ void __launch_bounds__(64)
             // factors to the workspace: the sweeps' records (A-operand order, 64 consecutive values per MFMA), and K', S^-1
             // (read at the candidate row's step)
             {
-                T *mb = Mb + (int64_t)k * (GB * 256) + lane * 4, *mf = Mf + (int64_t)k * (GF * 256) + lane * 4;
+                T *mb = Mb + (int64_t)k * SB + lane * LB, *mf = Mf + (int64_t)k * SF + lane * LF;
 #pragma unroll
                 for (int g = 0; g < GB; ++g) {
-                    V4 v = {T(0), T(0), T(0), T(0)};
+                    RecB v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (4 * g + j < NB) v[j] = Pm[srcb[4 * g + j]];
-                    *(V4 *)(mb + g * 256) = v;
+                    for (int j = 0; j < LB; ++j) v.v[j] = (LB * g + j < NB) ? Pm[srcb[LB * g + j < NB ? LB * g + j : 0]] : T(0);
+                    *(RecB *)(mb + g * 64 * LB) = v;
                 }
 #pragma unroll
                 for (int g = 0; g < GF; ++g) {
-                    V4 v = {T(0), T(0), T(0), T(0)};
+                    RecF v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (4 * g + j < NF) v[j] = sgnf[4 * g + j] * Pm[srcf[4 * g + j]];
-                    *(V4 *)(mf + g * 256) = v;
+                    for (int j = 0; j < LF; ++j)
+                        v.v[j] = (LF * g + j < NF) ? sgnf[LF * g + j < NF ? LF * g + j : 0] * Pm[srcf[LF * g + j < NF ? LF * g + j : 0]] : T(0);
+                    *(RecF *)(mf + g * 64 * LF) = v;
                 }
                 T *ks = KS + (int64_t)k * (nx * nu + 16);
                 if (offK >= 0) ks[lane] = Km[offK];
@@ -697,13 +710,13 @@ __global__ void __launch_bounds__(64)
             for (int q = 0; q < NQ; ++q) tg[d][q] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *mb = Mb + (int64_t)k * (GB * 256) + lane * 4;
+            const T *mb = Mb + (int64_t)k * SB + lane * LB;
 #pragma unroll
             for (int g = 0; g < GB; ++g) {
-                const V4 v = *(const V4 *)(mb + g * 256);
+                const RecB v = *(const RecB *)(mb + g * 64 * LB);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * g + j < NB) rec[d][4 * g + j] = v[j];
+                for (int j = 0; j < LB; ++j)
+                    if (LB * g + j < NB) rec[d][LB * g + j] = v.v[j];
             }
             if (track) {
 #pragma unroll
@@ -783,13 +796,13 @@ __global__ void __launch_bounds__(64)
             for (int e = 0; e < NF; ++e) rec[d][e] = T(0);
         }
         auto req = [&](int d, int k) {
-            const T *mf = Mf + (int64_t)k * (GF * 256) + lane * 4;
+            const T *mf = Mf + (int64_t)k * SF + lane * LF;
 #pragma unroll
             for (int g = 0; g < GF; ++g) {
-                const V4 v = *(const V4 *)(mf + g * 256);
+                const RecF v = *(const RecF *)(mf + g * 64 * LF);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * g + j < NF) rec[d][4 * g + j] = v[j];
+                for (int j = 0; j < LF; ++j)
+                    if (LF * g + j < NF) rec[d][LF * g + j] = v.v[j];
             }
             ffr[d] = ffv[ffo + (unsigned)(k * 4)];
         };
