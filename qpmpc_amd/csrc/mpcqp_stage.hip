@@ -1461,6 +1461,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
             wsync();
             __builtin_amdgcn_s_dcache_inv();
             if constexpr (PIPE) __syncthreads();
+            // (no vector-L1 invalidate: the two wavefronts of a workgroup share their CU's L1, which its own stores keep
+            // coherent -- workgroup scope in the AMDGPU memory model; an agent-scope acquire here cost 4-8 us per period)
         }
     }
 }
