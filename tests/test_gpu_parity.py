@@ -435,6 +435,28 @@ def test_config5_condense_mfma_gram_full_size():
         assert np.abs(P - P.T).max() <= 1e-5 * np.abs(P).max()
 
 
+@pytest.mark.parametrize("N", [20, 24, 32, 40, 48, 56])
+def test_large_condense_mfma_gram_other_tile_counts(N):
+    """The MFMA Gram deals its lower-triangle tiles to eight wavefronts in their order of activation: every
+    tile count n / 32 = 3 .. 7 of config 5's system (nx = 12, nu = 4, shorter horizons; n = 80 is not a multiple of 32 and
+    takes the generic Gram) against the float64 oracle -- P, q, exact enough symmetry, and the terminal-cost rows that share
+    the last chunk with stage rows (mpc_qp.py:99-105)."""
+    from qpmpc_amd import BatchMPCQP
+    from qpmpc_amd.workloads import synthetic_ltv_batch, to_batch_problem
+
+    w = synthetic_ltv_batch(3, N=N)
+    qp = BatchMPCQP(to_batch_problem(w, dtype=torch.float32), keep_propagators=False)
+    torch.cuda.synchronize()
+    for b in (0, 2):
+        cq = _oracle_condense_workload(w, b)
+        for name, got, want in (("P", qp.P[b], cq.P), ("q", qp.q[b], cq.q), ("G", qp.G[b], cq.G), ("h", qp.h[b], cq.h)):
+            g = got.double().cpu().numpy()
+            assert g.shape == want.shape, name
+            assert _rel(g, want) <= 2e-5, (name, N, _rel(g, want))
+        P = qp.P[b].cpu().numpy()
+        assert np.abs(P - P.T).max() <= 1e-5 * np.abs(P).max()
+
+
 def test_config5_condense_f64_large_path():
     """Same path in float64 (VALU Gram) at a size that does not fit LDS: parity 1e-12."""
     from qpmpc_amd import BatchMPCQP
