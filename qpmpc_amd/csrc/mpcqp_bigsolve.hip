@@ -1581,6 +1581,9 @@ bool bigsolve_supported(int n, int m, int dtype)
 // structured (matrix-free G) mode: needs the roll-out table in LDS too, nx and nu within the lane map
 bool bigsolve_struct_supported(const KernelArgs &ka, int dtype)
 {
+    // float32 only: with the problem's A, B, C, D resident in registers the float64 instantiation needed ~860 VGPRs (512 +
+    // 352 spilled, 484 B of scratch) and was 4 % faster than forming G, which is what float64 problems get now
+    if (dtype == MPCQP_F64) return false;
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
     return ka.m > 0 && ka.m <= 4 * bigs::BS && ka.mk > 0 && ka.nx <= 16 && ka.nu <= 8 && ka.N <= 65 &&
            ka.n >= 64 && ka.n <= bigs::BS && (ka.n % 2 == 0) &&
@@ -1632,8 +1635,7 @@ int launch_bigsolve(const KernelArgs &ka, int dtype, int64_t batch, const void *
 int launch_bigsolve_struct(const KernelArgs &ka, int dtype, int64_t batch, const void *P, const void *q,
                            const void *Psi_all, const void *h, const void *rownorm_inv, void *ws, hipStream_t st)
 {
-    if (dtype == MPCQP_F64)
-        return launch_bigsolve_t<double, K_STRUCT>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
+    if (dtype == MPCQP_F64) return MPCQP_EUNSUPPORTED;  // (bigsolve_struct_supported: float32 only)
     return launch_bigsolve_t<float, K_STRUCT>(ka, batch, P, q, nullptr, Psi_all, h, rownorm_inv, ws, st);
 }
 
