@@ -154,6 +154,12 @@ def test_c_abi_library_exports_every_declared_symbol():
     # bad arguments are refused on the host, before any launch
     assert lib.mpcqp_solve_batch(0, 0, 0, None, None, None, None, 1, None, None, None, None, None, None, 0, None) == -1
     assert lib.mpcqp_build_solve_batch(None, None, 1, None, None, None, None, None, None, 0, None) == -1
+    # (ABI 7) several control periods per launch: the period count is checked first, then the arguments like the one-period call
+    d3 = _capi.Dims(4, 1, 50, 2, _capi.F64, 15, 10.0, 1.0, 1e-3)
+    args = (C.byref(d3), None, 1024, None, None, None, None, None, None, 0, None, None, 0.024, 0.5, 1.0, 9.81, 15)
+    assert lib.mpcqp_wip_periods_batch(*args, 0, None) == _capi.EINVAL
+    assert lib.mpcqp_wip_periods_batch(*args, 20, None) == _capi.EINVAL  # (NULL problem)
+    assert lib.mpcqp_wip_period_batch(*args, None) == _capi.EINVAL
     # workspace queries are host-only: config 2 needs none, config 5 (n=256, m=1024, f32) does
     d = _capi.Dims(3, 1, 16, 2, _capi.F64, 5, 1.0, 0.0, 1e-6)
     assert lib.mpcqp_workspace_bytes(C.byref(d), 4096, 1, C.byref(b)) == 0 and b.value == 0
