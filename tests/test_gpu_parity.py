@@ -1263,6 +1263,13 @@ def test_several_periods_per_launch_equal_one_period_per_launch(mode):
     b.step(11)
     torch.cuda.synchronize()
     assert torch.equal(a.states, b.states) and a.stats() == b.stats()
+    # a horizon another kernel serves (N = 12: the pair kernel has no fused period): two launches per period, same loop
+    short = WIPClosedLoop(x0[:8].copy(), nb_timesteps=12, sampling_period=0.1, periods_per_launch=4, **mode)
+    ref = WIPClosedLoop(x0[:8].copy(), nb_timesteps=12, sampling_period=0.1)
+    short.step(7)
+    ref.step(7)
+    torch.cuda.synchronize()
+    assert not short._fused and short.mpc_steps == 7 and torch.equal(short.states, ref.states)
     # refusals
     lib = _capi.load()
     args = a._period_args
