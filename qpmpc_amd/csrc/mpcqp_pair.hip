@@ -1159,10 +1159,17 @@ __global__ void __launch_bounds__(64, 2)
             ld16(yy, zv);
         }
         T lraw = lam;  // multipliers before the clamp at zero (repair phase)
-        if (__ballot(nq > 0 && !finished) != 0ull) {
-            // active residuals rho_a = h_a - M_a y should vanish: dlam = -W rho_A = -T (T' rho_A)
-            T rho = half_get(fresh, hb, myact);
-            rho = occ ? rho : T(0);
+        // active residuals rho_a = h_a - M_a y should vanish. When they already do to REFTOL (1 + |h_a|) in both halves --
+        // the usual case: a dozen rank-one updates of T in float64 -- the refinement step below would move y by less than
+        // that and is skipped (two exchanged mat-vecs and a second evaluation of all slacks).
+        T rho = half_get(fresh, hb, myact);
+        rho = occ ? rho : T(0);
+        // (warm-started launches always take it: there it is what computes the multipliers of a stored set)
+        constexpr double REFTOL = 1e-11;
+        const bool needref = WARM ? (nq > 0 && !finished)
+                                  : (occ && !finished && !(fabs(rho) <= T(REFTOL) * (T(1) + fabs(half_get(hval, hb, myact)))));
+        if (__ballot(needref) != 0ull) {
+            // dlam = -W rho_A = -T (T' rho_A)
             wsync();
             kAv[vofs] = rho;
             if (low) st16(Timg + hl * NV, RT);  // T by columns is only needed here
