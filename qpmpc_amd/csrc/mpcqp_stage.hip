@@ -1447,6 +1447,20 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     }
     tick(8);
     };  // period
+    {
+        // The period reads its arguments where they lie in the kernarg segment (explicit arguments first, naturally aligned: the
+        // ABI's layout, but an assumption of THIS file): checked once per wavefront -- one that finds something else there stops
+        // instead of computing on garbage.
+        typedef const __attribute__((address_space(4))) unsigned char *KargPtr0;
+        KargPtr0 kb = (KargPtr0)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr size_t o_wl = (sizeof(KernelArgs) + alignof(Ws) - 1) / alignof(Ws) * alignof(Ws);
+        constexpr size_t o_ws = (o_wl + sizeof(Ws) + 7) / 8 * 8;
+        const auto *kq = (const __attribute__((address_space(4))) KernelArgs *)kb;
+        const auto *wq0 = (const __attribute__((address_space(4))) Ws *)(kb + o_wl);
+        if (kq->N != ka_.N || kq->max_iter != ka_.max_iter || wq0->total != wl_.total ||
+            *(double *const __attribute__((address_space(4))) *)(kb + o_ws) != wsbase_)
+            __builtin_trap();
+    }
     if constexpr (!(SERIAL && NX == 4 && NU == 1)) {  // (one period per launch: mpcqp_wip_periods_batch refuses more)
         period(0);
         return;
