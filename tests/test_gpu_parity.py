@@ -457,6 +457,31 @@ def test_large_condense_mfma_gram_other_tile_counts(N):
         assert np.abs(P - P.T).max() <= 1e-5 * np.abs(P).max()
 
 
+@pytest.mark.parametrize("nx,nu,N,mk", [(8, 1, 256, 2), (16, 2, 128, 3), (5, 1, 224, 1)])
+def test_large_condense_long_horizons(nx, nu, N, mk):
+    """The dense large-problem condensing on LONG horizons of narrow-input systems (n = N nu up to 256 with N up to 256: the
+    Gram's chunk staging, its weighted-residual table in dynamic LDS and the causality bounds at their extremes) against the
+    float64 oracle (mpc_qp.py:53-122)."""
+    import sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_stagewise import random_ltv
+    from qpmpc_amd import BatchMPCQP
+    from qpmpc_amd.workloads import problem_from_workload, to_batch_problem
+
+    rng = np.random.default_rng(4)
+    w = random_ltv(rng, 2, nx, nu, N, mk, 1.0)
+    w["A"] = np.eye(nx) + 0.02 * (w["A"] - np.eye(nx))  # keep the long propagation well scaled
+    qp = BatchMPCQP(to_batch_problem(w, dtype=torch.float32), keep_propagators=False)
+    torch.cuda.synchronize()
+    for b in range(2):
+        cq = oracle.condense_one(problem_from_workload(w, b))
+        for name, got in (("P", qp.P[b]), ("q", qp.q[b]), ("G", qp.G[b]), ("h", qp.h[b])):
+            assert _rel(got.double().cpu().numpy(), cq[name]) <= 5e-5, (name, _rel(got.double().cpu().numpy(), cq[name]))
+
+
 def test_config5_condense_f64_large_path():
     """Same path in float64 (VALU Gram) at a size that does not fit LDS: parity 1e-12."""
     from qpmpc_amd import BatchMPCQP
