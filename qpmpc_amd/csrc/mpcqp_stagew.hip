@@ -59,6 +59,12 @@ constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA op
 // where they go straight into free slots). Measured on config 5: 8 beats 4 by 3 %, 16 loses (later candidates are rarely among
 // the rows that were violated when the sweep ran, and the sweep starts at the latest of its rows' steps).
 constexpr int R_PLAIN = 4, R_FUSE = STAGEW_RF;
+// LOW (float32, FUSE layout): the instantiation for batches that do not fill the SIMDs -- a launch of at most one wavefront per
+// SIMD (the 8-GPU share of config 5: 1024 problems) is bounded by the LATENCY of its longest problem, and the registers of
+// the empty wavefront slots buy some of it back: one wavefront per SIMD (512 VGPRs), twelve right-hand sides per sweep
+// pair, a six-step request ring, sixteen rows per lane and four slots in flight in the slack passes. Measured on config 5 at
+// batch 1024: 0.325 -> 0.303 ms; at two wavefronts per SIMD and beyond the default instantiation wins.
+constexpr int R_FUSE_LOW = 12, D_LOW = 6, SU_LOW = 16, SG_LOW = 4;
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
     int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Hc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;  // (Hc unused)
@@ -81,7 +87,7 @@ inline bool fuse_ok(int mk, bool ginv) { return ginv && mk <= 16 && (mk & 3) == 
 inline int nxc_of(int nx) { return (nx + 3) & ~3; }
 
 // ginv: C and D do not change along the horizon (their packed copy holds mk rows instead of N mk)
-inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz)
+inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz, bool low = false)
 {
     Ws w{};
     int64_t o = 0;
@@ -101,7 +107,7 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
     w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
     const bool fuse = fuse_ok(mk, ginv);
-    const int R = fuse ? R_FUSE : R_PLAIN;
+    const int R = fuse ? (low ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
     w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
     w.Zs = take(fuse ? 0 : (int64_t)R * N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
     w.Vc = take(fuse ? 0 : (int64_t)R * N * 4);  // ... and its inputs alone (they move into a slot when the row is taken)
@@ -239,16 +245,16 @@ __device__ __forceinline__ double rl(double v, int j)
 
 using namespace stagew;
 
-template <typename T, int NXC, bool FUSE>
+template <typename T, int NXC, bool FUSE, bool LOW = false>
 // (float32: three wavefronts per SIMD, 168 VGPRs -- except the instantiations that do not fit them without spilling: nx = 16, and
 // the general constraint layout at nx = 12, take two)
 __global__ void __launch_bounds__(64)
-    __attribute__((amdgpu_waves_per_eu((sizeof(T) == 4 && NXC < 16 && (FUSE || NXC < 12)) ? STAGEW_WPE32 : 2)))
+    __attribute__((amdgpu_waves_per_eu(LOW ? 1 : (sizeof(T) == 4 && NXC < 16 && (FUSE || NXC < 12)) ? STAGEW_WPE32 : 2)))
     mpcqp_stagew_kernel(const KernelArgs ka, const Ws wl, T *__restrict__ wsbase, const int64_t batch)
 {
     using V4 = __attribute__((ext_vector_type(4))) T;
     using MV = typename Mfma<T>::V;
-    constexpr int D = sizeof(T) == 4 ? STAGEW_D : 4;  // the sweeps request their records this many steps ahead
+    constexpr int D = sizeof(T) == 4 ? (LOW ? D_LOW : STAGEW_D) : 4;  // the sweeps request their records this many steps ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -267,7 +273,7 @@ __global__ void __launch_bounds__(64)
     constexpr int SB = GB * 64 * LB, SF = GF * 64 * LF;  // elements per step
     using RecB = RecN<T, LB>;
     using RecF = RecN<T, LF>;
-    constexpr int R = FUSE ? R_FUSE : R_PLAIN;  // right-hand sides per sweep pair
+    constexpr int R = FUSE ? (LOW ? R_FUSE_LOW : R_FUSE) : R_PLAIN;  // right-hand sides per sweep pair
     constexpr int ZL = NXC + 4;             // a row of Zp: position g (NQ + 1) + q holds x[4 q + g] (q < NQ), u[g] (q = NQ)
     const bool col0 = c16 == 0;             // the lanes of right-hand side 0
     const bool colr = c16 < R;              // the lanes of the right-hand sides in use
@@ -854,7 +860,7 @@ __global__ void __launch_bounds__(64)
     };
     // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
     constexpr int GU = sizeof(T) == 4 ? 2 : 1;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
-    constexpr int SU = sizeof(T) == 4 ? STAGEW_SU32 : 4;  // rows per lane in flight in the slack passes
+    constexpr int SU = sizeof(T) == 4 ? (LOW ? SU_LOW : STAGEW_SU32) : 4;  // rows per lane in flight in the slack passes
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
@@ -1251,7 +1257,7 @@ __global__ void __launch_bounds__(64)
                     for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                         // every load of the rows' own arrays first (they are needed last), then the slots in groups of
                         // SG with all their loads in flight together: what a pass costs is its dependent round trips
-                        constexpr int SG = STAGEW_SG;
+                        constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
                         T z[SU], so[SU], iv[SU], th[SU];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
@@ -1394,7 +1400,7 @@ __global__ void __launch_bounds__(64)
             bool dirty = false;
             for (int pass = 0; pass < 2; ++pass) {
                 // ONE pass over the rows: s = s0 + sum_a lam_a h_a with the slots' loads in flight in groups
-                constexpr int SG = STAGEW_SG;
+                constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
                 bool offa = false;
                 dirty = false;
                 for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
@@ -1871,23 +1877,48 @@ size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 {
     // (a size query carries no operands and does not know which layout the launch will take: the larger of the two)
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
-    const size_t a = (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), esz).total;
-    const size_t b = ka.A.ptr ? 0 : (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, true, esz).total;
-    return a > b ? a : b;
+    // (... and not whether the small-batch instantiation, with its larger carve, will serve it: a workspace sized for one batch may
+    // be used for a smaller one)
+    size_t best = 0;
+    for (int low = 0; low < 2; ++low) {
+        const size_t a = (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), esz, low != 0).total;
+        const size_t b = ka.A.ptr ? 0 : (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, true, esz, low != 0).total;
+        best = a > best ? a : best;
+        best = b > best ? b : best;
+    }
+    return best;
 }
 
-template <typename T, int NXC, bool FUSE>
+// SIMDs of the current device (the small-batch instantiation serves launches of at most one wavefront per SIMD)
+static int64_t device_simds()
+{
+    static int64_t cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = 4 * (int64_t)cus;
+        else
+            cached = 1024;
+    }
+    return cached;
+}
+
+template <typename T, int NXC, bool FUSE, bool LOW = false>
 static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
-    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T));
+    if constexpr (std::is_same<T, float>::value && FUSE && !LOW) {
+        if (batch <= device_simds()) return launch_stagew_t<T, NXC, FUSE, true>(ka, maxq, batch, ws, st);
+    }
+    constexpr int RR = FUSE ? (LOW ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
+    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T), LOW);
     // the matrix tiles of the LDS Riccati recursion only exist for nx > 12; then 8 constant / spare cells
     const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
     // + c, r, multipliers, active rows, slot permutation, the sweeps' rows; FUSE: + the candidates' slots, the free list
     // and the 32 x 33 tile of W
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64 +
-                       (FUSE ? (size_t)(R_FUSE + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0) +
-                       (size_t)(FUSE ? R_FUSE : R_PLAIN) * sizeof(int);
-    auto kern = mpcqp_stagew_kernel<T, NXC, FUSE>;
+                       (FUSE ? (size_t)(RR + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0) +
+                       (size_t)RR * sizeof(int);
+    auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;

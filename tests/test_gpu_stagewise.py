@@ -454,3 +454,22 @@ def test_config5_at_the_per_gpu_size_through_the_default_dispatch_against_the_or
     e64 = float((np.abs(p64.U.cpu().numpy() - Uo) / scale).max())
     print("config 5, 1024 problems: float32", e32, "float64", e64, "mean iterations", float(p32.iters.float().mean()))
     assert e32 <= 1e-3 and e64 <= 1e-7
+
+
+def test_small_batch_instantiation_gives_the_same_iterates_as_the_default_one():
+    """A float32 launch that does not fill the SIMDs (batch <= 4 x CUs) takes the small-batch instantiation of the wide kernel
+    (one wavefront per SIMD, twelve right-hand sides per sweep pair, deeper request rings: DESIGN 3.8); a larger launch the
+    default one. Which rows ride along with a sweep cannot change the iterates: the first 1024 problems of config 5 solved
+    alone and as part of a batch of 1100 need the same iterations and give the same plans."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    w = W.synthetic_ltv_batch_slice(0, 1100)
+    big = solve_mpc_batch(W.to_batch_problem(w, dtype=torch.float32))
+    w1 = {k: (v[:1024] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == 1100 else v) for k, v in w.items()}
+    small = solve_mpc_batch(W.to_batch_problem(w1, dtype=torch.float32))
+    torch.cuda.synchronize()
+    assert (big.status == 0).all() and (small.status == 0).all()
+    assert torch.equal(big.iters[:1024], small.iters)
+    scale = big.U[:1024].abs().max(dim=1, keepdim=True).values.clamp(min=1.0)
+    assert float(((big.U[:1024] - small.U).abs() / scale).max()) <= 1e-4
