@@ -184,3 +184,33 @@ def require_gpu():
             "devices and has no CPU fallback"
         )
     return torch.device("cuda", torch.cuda.current_device())
+
+
+_gpu_ok = False
+_streams = {}
+
+
+def current_stream():
+    """(torch stream object, raw hipStream_t as int) of torch's CURRENT stream, without the ~8 us that
+    ``torch.cuda.current_stream()`` spends on device-index handling per call: the raw handle comes from torch's C
+    layer and the stream object is cached per (device, handle). Raises ``BackendError`` without a GPU (every launch
+    goes through here, so nothing can silently run elsewhere)."""
+    global _gpu_ok
+    import torch
+
+    if not _gpu_ok:
+        require_gpu()
+        _gpu_ok = True
+    try:
+        dev = torch._C._cuda_getDevice()
+        raw = torch._C._cuda_getCurrentRawStream(dev)
+    except AttributeError:  # (another torch build: the public, slower way)
+        s = torch.cuda.current_stream()
+        return s, s.cuda_stream
+    s = _streams.get((dev, raw))
+    if s is None:
+        s = torch.cuda.current_stream()
+        if s.cuda_stream != raw:  # (should not happen: fall back to what torch says)
+            return s, s.cuda_stream
+        _streams[(dev, raw)] = s
+    return s, raw

@@ -318,9 +318,7 @@ class BatchMPCProblem:
 def _stream_ptr():
     """hipStream_t of torch's current stream; raises BackendError without a GPU
     (every launch goes through here, so nothing can silently run elsewhere)."""
-    torch = _torch()
-    _capi.require_gpu()
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_capi.current_stream()[1])
 
 
 def _require_on_gpu(*tensors) -> None:

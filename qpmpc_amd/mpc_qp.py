@@ -192,11 +192,11 @@ class MPCQP:
         cp = u["cp"]
         cp.goal = u["goal_op"] if goal is not None else _capi.Operand(None, 0, 0)
         cp.targets = u["tgt_op"] if tgt is not None else _capi.Operand(None, 0, 0)
-        stream = torch.cuda.current_stream()
+        stream, raw_stream = _capi.current_stream()
         out = u["h_out"].data_ptr()
         rc = _capi.load().mpcqp_update_vectors_batch(
             C.byref(dims), C.byref(cp), ctx["Phi"], 0, ctx["Psi"], 0, 1, out,
-            (out + 8 * n) if m else None, C.c_void_p(stream.cuda_stream))
+            (out + 8 * n) if m else None, C.c_void_p(raw_stream))
         _capi.check(rc, "mpcqp_update_vectors_batch")
         stream.synchronize()
         res = u["h_out"].numpy()

@@ -165,12 +165,12 @@ def condense_single(problem):
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
     base = c_out.data_ptr()
     ptr = [base + 8 * int(o) for o in offs[:-1]]
-    stream = torch.cuda.current_stream()
+    stream, raw_stream = _capi.current_stream()
     r.d_in.copy_(r.h_in, non_blocking=True)
     rc = lib.mpcqp_condense_batch(C.byref(dims), C.byref(r.cp), 1, ptr[2], ptr[4], ptr[3] if m else None,
                                   ptr[5] if m else None, ptr[0], ptr[1],
                                   None if r.c_ws is None else r.c_ws.data_ptr(), 0 if r.c_ws is None else r.c_ws.numel(),
-                                  C.c_void_p(stream.cuda_stream))
+                                  C.c_void_p(raw_stream))
     _capi.check(rc, "mpcqp_condense_batch")
     r.c_host.copy_(c_out, non_blocking=True)
     own_in = r.d_in.clone()
@@ -199,8 +199,8 @@ def solve_single(problem, max_iter=None, feas_tol=None):
     torch, lib = r.torch, r.lib
     N, nx = r.N, r.nx
     opts = _capi.SolveOpts(int(max_iter or 0), 0, float(feas_tol or 0.0))  # remaining fields: NULL / 0
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
+    stream, raw_stream = _capi.current_stream()
+    sp = C.c_void_p(raw_stream)
     cp = r.cp_host if r.zero_copy else r.cp
     if not r.zero_copy:
         r.d_in.copy_(r.h_in, non_blocking=True)
