@@ -475,7 +475,8 @@ class BatchPlan:
 
 def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_multipliers: bool = False,
                     max_iter: Optional[int] = None, feas_tol: Optional[float] = None, formulation: str = "condensed",
-                    max_active: Optional[int] = None, retry_slots: bool = True, **opt_kw) -> BatchPlan:
+                    max_active: Optional[int] = None, retry_slots: bool = True, retry_unsolved: bool = False,
+                    **opt_kw) -> BatchPlan:
     """Build and solve every problem of the batch in ONE fused launch
     (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem). Any problem size is served: what does not
     fit one CU's LDS goes to the stage-wise kernels (systems with nx <= 16, nu <= 4, any horizon) or, for wider systems
@@ -486,6 +487,12 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     it can hold (default min(n, m, 128)). A problem that needs more comes back ``MPCQP_SLOTS_FULL`` from the kernel and
     -- ``retry_slots`` -- is solved again with twice the slots until it fits (this reads the statuses: a
     synchronisation, only for problems with more than 128 variables and rows).
+
+    ``retry_unsolved``: problems that come back ``MPCQP_MAX_ITER`` are solved once more through the OTHER formulations of the
+    same solver on the GPU (the LDS workgroup kernel -- Householder-based, the sturdiest of them --, then the stage-wise one):
+    a handful of degenerate problems in 10^4 (hundreds of iterations, rows nearly conflicting) end the mid-size dense kernel's
+    verification rounds unsolved while the others -- and the reference's backends -- solve them. It reads the statuses (a
+    synchronisation), hence off by default here and on in ``solve_mpc``.
 
     ``opt_kw``: ``warm_state`` (a :class:`WarmState`, updated by every solve) with ``warm_start=True``
     to begin from it, ``flags`` (``_capi.OPT_*`` dispatch overrides for cross-checks), ``probe``."""
@@ -530,7 +537,36 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
         # wide one 256 -- mpcqp_capi.hip)
         narrow = problem.dtype == torch.float64 and problem.state_dim <= 4 and problem.input_dim <= 2
         _retry_slots_full(plan, 128 if narrow else 256, max_iter, feas_tol, opt_kw)
+    if retry_unsolved and not (opt_kw.get("flags") or 0):
+        _retry_unsolved(plan, max_iter, feas_tol, opt_kw)
     return plan
+
+
+def _retry_unsolved(plan: "BatchPlan", max_iter, feas_tol, opt_kw) -> None:
+    """``MPCQP_MAX_ITER`` items of a default-dispatch solve, once more through the other formulations (see solve_mpc_batch)."""
+    problem = plan.problem
+    kw = {k: v for k, v in opt_kw.items() if k not in ("warm_state", "warm_start", "probe", "flags")}
+    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"formulation": "stagewise"}):
+        left = plan.status == _capi.MAX_ITER
+        if not bool(left.any().item()):
+            return
+        index = left.nonzero().flatten()
+        try:
+            again = solve_mpc_batch(problem.select(index), return_multipliers=plan.multipliers is not None, max_iter=max_iter,
+                                    feas_tol=feas_tol, retry_unsolved=False, **attempt, **kw)
+        except BackendError:  # (this formulation does not serve these dimensions)
+            continue
+        better = again.status == _capi.SOLVED
+        if not bool(better.any().item()):
+            continue
+        sub = better.nonzero().flatten()
+        dst = index.index_select(0, sub)
+        plan.U.index_copy_(0, dst, again.U.index_select(0, sub))
+        plan.status.index_copy_(0, dst, again.status.index_select(0, sub))
+        plan.iters.index_copy_(0, dst, again.iters.index_select(0, sub))
+        if plan.multipliers is not None:
+            plan.multipliers.index_copy_(0, dst, again.multipliers.index_select(0, sub))
+        plan._states = None
 
 
 def _retry_slots_full(plan: "BatchPlan", held: int, max_iter, feas_tol, opt_kw) -> None:

@@ -215,7 +215,9 @@ def solve_single(problem, max_iter=None, feas_tol=None):
     stream.synchronize()
     out = r.h_out_np
     status, iters = int(r.h_out_i32[0]), int(r.h_out_i32[1])
-    if status == _capi.SLOTS_FULL:  # the stage-wise kernel's slots were too few: the batch path solves again with more
+    if status in (_capi.SLOTS_FULL, _capi.MAX_ITER):
+        # the stage-wise kernel's slots were too few, or the kernel gave up on a degenerate problem: the batch path solves
+        # again (more slots / the other formulations of the solver)
         return None
     if status != 0:
         return None, None, None, status, iters

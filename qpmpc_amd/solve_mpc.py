@@ -71,7 +71,7 @@ def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) 
             return plan
         bp = BatchMPCProblem.from_problems([problem])
         opt_kw = {} if warm_state is None else {"warm_state": warm_state, "warm_start": warm_start}
-        bplan = solve_mpc_batch(bp, solver=solver, return_multipliers=True,
+        bplan = solve_mpc_batch(bp, solver=solver, return_multipliers=True, retry_unsolved=warm_state is None,
                                 max_iter=kwargs.get("max_iter"), feas_tol=kwargs.get("feas_tol"), **opt_kw)
         status = int(bplan.status[0].item())
         x = bplan.U[0].cpu().numpy()

@@ -1305,3 +1305,35 @@ def test_several_periods_per_launch_equal_one_period_per_launch(mode):
         o.flags = (o.flags & ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_REUSE_FACTOR)) | _capi.OPT_KEEP_FACTOR
         assert lib.mpcqp_wip_periods_batch(*args, 2, None) == _capi.EUNSUPPORTED
         o.flags = keep
+
+
+@pytest.mark.gpu
+def test_degenerate_problems_are_solved_through_the_other_formulations():
+    """Two problems of a stress round (tests/golden/degenerate_nx8_n37.npz, tools/gen_golden_degenerate.py: nx = 8, N = 37, rows
+    nearly conflicting, 150+ active-set iterations in the oracle) end the mid-size dense kernel's verification rounds with
+    MPCQP_MAX_ITER -- an honest failure, never a wrong plan. ``retry_unsolved`` (on in ``solve_mpc``, like a qpsolvers backend
+    that simply solves them: solve_mpc.py:42-44) takes such items through the LDS workgroup kernel / the stage-wise kernel:
+    all four problems of the fixture then match the oracle."""
+    from qpmpc_amd import solve_mpc, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "degenerate_nx8_n37.npz"))
+    wx = None if float(d["wx"]) < 0 else float(d["wx"])
+    w = W._pack(d["A"], d["B"], d["C"], d["D"], d["e"], int(d["N"]), float(d["wt"]), wx, float(d["wu"]), d["x0"], d["goal"],
+                d["targets"] if "targets" in d.files else None, name="degenerate")
+    Uo = d["U_oracle"]
+    assert (d["status_oracle"] == 0).all()
+    scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+    plain = solve_mpc_batch(W.to_batch_problem(w))
+    retried = solve_mpc_batch(W.to_batch_problem(w), retry_unsolved=True)
+    torch.cuda.synchronize()
+    st = plain.status.cpu().numpy()
+    assert set(st.tolist()) <= {0, 1}  # solved, or given up: never 'infeasible', never a wrong plan
+    ok = st == 0
+    assert (np.abs(plain.U.cpu().numpy() - Uo)[ok] / scale[ok]).max() <= 1e-6
+    assert (retried.status == 0).all()
+    assert (np.abs(retried.U.cpu().numpy() - Uo) / scale).max() <= 1e-6
+    for b in (0, 1):
+        plan = solve_mpc(W.problem_from_workload(w, b), solver="hip_gi")
+        assert not plan.is_empty
+        assert np.abs(plan.inputs.ravel() - Uo[b]).max() <= 1e-6 * scale[b, 0]
