@@ -13,7 +13,7 @@ from stress_stagewise import random_ltv  # noqa
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    rng = np.random.default_rng(777)
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "777")))
     worst, bad = 0.0, 0
     for it in range(rounds):
         nx, nu = int(rng.integers(1, 9)), int(rng.integers(1, 4))
