@@ -317,7 +317,7 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
     }
     bsync();
 
-    int nq = 0;
+    int nq = 0, refined = 0;
     for (;;) {
         // step 1: slacks in y coordinates and the most violated inactive row
         T best = INF;
@@ -336,6 +336,45 @@ __device__ __forceinline__ void solve_phase(const Layout &L, T *sm, int n, int m
         }
         block_argmin<T, WAVES>(best, bi, redv, redi, tid);
         if (!(best < INF)) {
+            // No inactive row is violated. The ACTIVE rows are on their bounds by construction -- but y is moved by increments,
+            // and after several hundred iterations of a degenerate problem they drift (a stress run: a row 5e-7 inside its
+            // bound after 455 iterations). Their slacks rho_A were just evaluated with all the others: when one is off, y is put
+            // back on the active hyperplanes, dy = M_A' (M_A M_A')^-1 rho_A = -Q1 S' rho_A (-M_A' = Q1 R, S = R^-1), the
+            // multipliers follow (u -= S S' rho_A), and the slacks are evaluated again (at most twice).
+            if (nq > 0 && refined < 2) {
+                T flag = T(0);
+                for (int i = tid; i < nq; i += BS) {
+                    const int a = act[i];
+                    const T rho = sv[a];
+                    r[i] = rho;
+                    if (!(fabs(rho) <= T(64) * (tol + tol * fabs(hv[a])))) flag = T(1);
+                }
+                if (block_sum<T, WAVES>(flag, redv, tid) > T(0)) {
+                    ++refined;
+                    bsync();
+                    for (int j = tid; j < nq; j += BS) {  // g = S' rho
+                        T acc = T(0);
+                        for (int i = 0; i <= j; ++i) acc += Sm[i * ld + j] * r[i];
+                        d[j] = acc;
+                    }
+                    bsync();
+                    for (int k = tid; k < n; k += BS) {  // y -= Q1 g
+                        const T *row = Qm + k * ld;
+                        T acc = T(0);
+                        for (int j = 0; j < nq; ++j) acc += row[j] * d[j];
+                        y[k] -= acc;
+                    }
+                    for (int i = tid; i < nq; i += BS) {  // u -= S g
+                        const T *row = Sm + i * ld;
+                        T acc = T(0);
+                        for (int j = i; j < nq; ++j) acc += row[j] * d[j];
+                        const T v = u[i] - acc;
+                        u[i] = v < T(0) ? T(0) : v;
+                    }
+                    bsync();
+                    continue;
+                }
+            }
             status = MPCQP_SOLVED;
             break;
         }

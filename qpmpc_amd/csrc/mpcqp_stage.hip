@@ -1088,7 +1088,9 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     // (an active row may be off by (1 + |e_i|) max(1e3 tol, 1e-6): the contract's 1e-6 -- an ill-conditioned but legitimate
     // plan leaves ~1e-9 here, no refinement step in this kernel)
     const double kacc = 1e3 > 1e-6 / tol ? 1e3 : 1e-6 / tol;
+    bool rough = false;  // (set by eval_point) an active row is further than 1e3 tol (1 + |e|) from its bound
     auto eval_point = [&](bool write_u, bool &dirty, bool &offa) {
+        rough = false;
         for (int k = k0; k < k1; ++k) {
             double u[NU], x[NX];
 #pragma unroll
@@ -1122,14 +1124,20 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
 #pragma unroll
                     for (int c = 0; c < NU; ++c) g += gD[k * sD + r * NU + c] * u[c];
                 const double fresh = ev - g, th = tol + tol * fabs(ev);
-                const bool act = rowslot[i] >= 0;
+                const int rsl = rowslot[i];
+                const bool act = rsl >= 0;
                 if (ev < 1e29 && !act && !(fresh >= -4.0 * th)) dirty = true;
                 if (act && !(fabs(fresh) <= kacc * th)) offa = true;
+                if (act) {  // the active rows' residuals, for the refinement step of the final evaluation
+                    cv[rsl] = fresh;
+                    if (!(fabs(fresh) <= 1e3 * th)) rough = true;
+                }
                 sl[i] = act ? 0.0 : fresh;
             }
         }
         dirty = __ballot(dirty) != 0ull;
         offa = __ballot(offa) != 0ull;
+        rough = __ballot(rough) != 0ull;
         wsync();
     };
     // back to the empty active set at the unconstrained minimiser
@@ -1380,6 +1388,23 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
             }
         } else {
             eval_point(true, dirty, offa);
+            if (rough && nq > 0) {
+                // W is only ever updated: after a hundred iterations the active rows drift off their bounds (1e-8 .. 1e-6). One
+                // step of refinement, lam -= W rho_A with the residuals the evaluation just left in cv, and the evaluation again.
+                for (int a = lane; a < nq; a += 64) {
+                    double acc = 0.0;
+                    for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
+                    rv[a] = acc;
+                }
+                wsync();
+                for (int a = lane; a < nq; a += 64) {
+                    const double v = lamv[a] - rv[a];
+                    lamv[a] = v < 0.0 ? 0.0 : v;
+                }
+                wsync();
+                dirty = offa = false;
+                eval_point(true, dirty, offa);
+            }
         }
         if (offa) {  // an active row is off its bound (W drifted, or a warm state that was not this problem's): start cold
             cold_start();

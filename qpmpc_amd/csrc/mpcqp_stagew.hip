@@ -1434,7 +1434,10 @@ __global__ void __launch_bounds__(64)
                             const bool act = th[u] == INF;
                             if (act) {  // (rare) the row's own threshold is gone: from its bound
                                 const int k = stepof(i), r = i - k * mk;
-                                const T lim = (T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol) * (tol + tol * (T)fabs((double)ge[k * sE + r]));
+                                // first pass: 1e3 tol (1 + |e|) TRIGGERS the refinement; second pass: what is acceptable after it
+                                // (the contract's 1e-6 in float64)
+                                const T fac = (sizeof(T) == 4 || pass == 0 || T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol;
+                                const T lim = fac * (tol + tol * (T)fabs((double)ge[k * sE + r]));
                                 offa |= !((T)fabs((double)fr[u]) <= lim);
                             } else if (!(fr[u] >= T(-4) * th[u])) {
                                 dirty = true;
@@ -1785,13 +1788,15 @@ __global__ void __launch_bounds__(64)
             tick(6);
             // ================================================================= primal point, verification
             // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
-            T *ou = (T *)ka.U + prob * (int64_t)nvar;
-            for (int i = lane; i < nv4; i += 64) {
-                T u = U0[i];
-                for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
-                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
-            }
+            // ACTIVE rows must sit on their bounds (W is only ever updated, never refactored: a stress run found plans with rows
+            // 5e-7 off after 450 iterations): beyond 1e3 tol (1 + |e|) one step of refinement lam -= W rho_A puts them back, and a
+            // point that still fails the contract's bound is not reported solved -- as in the layout above.
             bool dirty = false;
+            for (int pass = 0; pass < 2; ++pass) {
+            bool offa = false;
+            dirty = false;
+            for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
+            const T afac = (pass == 0 || T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol;
             for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                 T fr[SU];
 #pragma unroll
@@ -1828,7 +1833,38 @@ __global__ void __launch_bounds__(64)
                 for (int u = 0; u < SU; ++u) {
                     const bool act = rs[u] >= 0;
                     if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
+                    if (act && i0 + 64 * u < M && !((T)fabs((double)fr[u]) <= afac * th[u])) offa = true;
                     if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
+                }
+            }
+            if (__ballot(offa) == 0ull) break;
+            if (pass == 1) {
+                fail = true;
+                break;
+            }
+            wsync();
+            for (int a = lane; a < nq; a += 64) {  // residuals of the active rows, then lam -= W rho_A
+                const int ra = actrow[a];
+                T acc = s0[ra];
+                for (int b = 0; b < nq; ++b) acc += lamv[b] * Hs[(int64_t)phys[b] * M + ra];
+                cv[a] = acc;
+            }
+            wsync();
+            for (int a = lane; a < nq; a += 64) {
+                T acc = T(0);
+                for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];
+                const T v = lamv[a] - acc;
+                lamv[a] = v < T(0) ? T(0) : v;
+            }
+            wsync();
+            }
+            if (fail) break;
+            {
+                T *ou = (T *)ka.U + prob * (int64_t)nvar;
+                for (int i = lane; i < nv4; i += 64) {
+                    T u = U0[i];
+                    for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
+                    if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
                 }
             }
             dirty = __ballot(dirty) != 0ull;
