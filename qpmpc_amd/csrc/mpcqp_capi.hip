@@ -121,8 +121,14 @@ bool use_stagew_auto(const KernelArgs &ka, int dtype)
 {
     const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
                               MPCQP_OPT_ONE_PER_WAVE;
+    // Round 3: ... and what DOES fit on chip but is no small problem (n > 24): measured on batches of 512 random LTV problems
+    // (tools/probe_f32_dispatch.py), the stage-wise kernel is 2-2.5x the mid-size / LDS condensed kernels in float64 (nx = 6 .. 12,
+    // n = 37 .. 64: 590-980 us against 1180-2170 us) and 2-3x in float32, where it is also 5-30x closer to the float64 oracle
+    // (the condensed float32 path squares the conditioning into P: 1e-3 at n ~ 130). Small problems (n <= 24) stay on chip.
     return !(ka.opt_flags & override_bits) && !ka.warm_state && stagew_supported(ka, dtype) && ka.m >= 1 &&
-           !fits_on_chip(ka, true, true, MODE_FUSED, dtype);
+           ((ka.n > 24 && (dtype == MPCQP_F64 || ka.nx <= 12)) || !fits_on_chip(ka, true, true, MODE_FUSED, dtype));
+    // (float32 with nx > 12 -- the LDS-tiled Riccati recursion -- stays on chip while it fits: on borderline problems of that size
+    // the condensed float32 kernel was the closer one, 1e-3 against 3e-3)
 }
 // ... and the narrow stage-wise kernel (float64, nx <= 4, nu <= 2: chunked scans, depth ~2 N / 64 per sweep instead of N
 // serial steps) takes what does not fit on chip among the systems it serves: horizons of any length (n > 256 included)
@@ -484,13 +490,6 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
         return launch_stage(ka, maxq, batch, workspace, st);
     }
-    if (use_mid(ka, dims->dtype)) {
-        const size_t need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;
-        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
-        return launch_mid(ka, dims->dtype, batch, workspace, st);
-    }
-    if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
-        return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
     if (use_stage_long(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);
         const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
@@ -503,6 +502,13 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
         return launch_stagew(ka, dims->dtype, maxq, batch, workspace, st);
     }
+    if (use_mid(ka, dims->dtype)) {
+        const size_t need = bigsolve_ws_elems(ka.n) * elem_size(dims->dtype) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_mid(ka, dims->dtype, batch, workspace, st);
+    }
+    if (fits_on_chip(ka, stepA, stepB, MODE_FUSED, dims->dtype))
+        return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
     // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the
     // general solver with its arrays in the workspace as well
     if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
