@@ -112,9 +112,10 @@ typedef struct MpcqpProblem {
 #define MPCQP_OPT_FORCE_GWS 2      /* large QPs: general kernel with its arrays in the workspace          */
 #define MPCQP_OPT_FORCE_DENSE_G 4  /* large fused path: form G (and its transpose) instead of applying it */
 #define MPCQP_OPT_ONE_PER_WAVE 8   /* small problems: one problem per wavefront instead of two            */
-#define MPCQP_OPT_FORCE_CONDENSED 16 /* mid-size problems: keep the condensed kernels (mpcqp_build_solve_batch
-                                        otherwise hands 16 < n <= 128, nx <= 4, nu <= 2, float64 to the stage-wise
-                                        kernel, which is faster there and returns the same minimiser)          */
+#define MPCQP_OPT_FORCE_CONDENSED 16 /* keep the condensed kernels (mpcqp_build_solve_batch otherwise hands 16 < n <= 128,
+                                        nx <= 4, nu <= 2, float64 -- and every other problem of more than 24 variables with
+                                        nx <= 16 (float32: 12), nu <= 4 -- to the stage-wise kernels, which are faster
+                                        there and return the same minimiser)                                      */
 
 #define MPCQP_OPT_STAGE_WIDE 32   /* mpcqp_stagewise_solve_batch: take the wide kernel (nx <= 16, nu <= 4, MFMA
                                      sweeps) also where the narrow one (nx <= 4, nu <= 2, float64) applies       */
