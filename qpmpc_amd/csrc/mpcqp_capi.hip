@@ -136,8 +136,15 @@ bool use_stage_long(const KernelArgs &ka, int dtype)
 {
     const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
                               MPCQP_OPT_ONE_PER_WAVE;
-    return !(ka.opt_flags & override_bits) && !ka.warm_state && stage_supported(ka, dtype) && ka.m >= 1 && ka.n > 128 &&
-           !fits_on_chip(ka, true, true, MODE_FUSED, dtype);
+    // Round 3, late: no longer taken by the automatic dispatch. On long horizons the two stage-wise kernels tie when few rows become
+    // active (triple integrator, N = 256 / 1024 / 4096, 3.5-12 iterations: 4.97 / 52.2 / 399 ms narrow against 6.03 / 54.2 / 387 ms
+    // wide) and the wide one -- active-set state in LDS, eight right-hand sides per sweep pair, 256 slots -- is 1.3-2x faster when
+    // many do (random LTV, n = 160 .. 256, 50-140 iterations: 7.5 / 40.3 / 13.4 / 42.9 ms against 5.0 / 26.8 / 6.9 / 32.7 ms;
+    // tools/probe_long_narrow.py, tools/probe_narrow_vs_wide.py): n > 128 goes to the wide kernel (use_stagew_auto). The narrow
+    // kernel stays reachable through mpcqp_stagewise_solve_batch.
+    (void)override_bits;
+    (void)dtype;
+    return false;
 }
 int stagew_auto_maxq(const KernelArgs &ka)
 {
