@@ -532,11 +532,10 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     _capi.check(rc, "mpcqp_build_solve_batch")
     plan = BatchPlan(problem, U, status, iters, lam)
     plan._workspace = (ws, opt_kw)  # keep the scratch (and the opts' tensors) alive until the stream has consumed them
-    if retry_slots and min(n, m) > 128:
-        # (the stage-wise kernels take what does not fit on chip; the narrow one holds 128 active rows by default, the
-        # wide one 256 -- mpcqp_capi.hip)
-        narrow = problem.dtype == torch.float64 and problem.state_dim <= 4 and problem.input_dim <= 2
-        _retry_slots_full(plan, 128 if narrow else 256, max_iter, feas_tol, opt_kw)
+    if retry_slots and min(n, m) > 256:
+        # (the automatic dispatch sends what can have more than 128 active rows to the wide stage-wise kernel, which holds
+        # min(n, m, 256) of them -- mpcqp_capi.hip)
+        _retry_slots_full(plan, 256, max_iter, feas_tol, opt_kw)
     if retry_unsolved and not (opt_kw.get("flags") or 0):
         _retry_unsolved(plan, max_iter, feas_tol, opt_kw)
     return plan
