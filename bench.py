@@ -566,6 +566,21 @@ def other_workloads():
 
     out["dense_fallback_path_n256_m1024_f32_batch1024"] = rate(
         PreparedSolve(W.to_batch_problem(w, dtype=torch.float32), flags=_capi.OPT_FORCE_CONDENSED).launch, 1024, 3)
+    # a mid-size problem family of a wider system (random LTV, nx = 8, nu = 2, N = 20: n = 40, m = 80, float64): the automatic
+    # dispatch (wide stage-wise kernel since round 3) next to the condensed on-chip kernels it used to take
+    import os as _os
+
+    _tools = _os.path.join(ROOT, "tools")
+    if _tools not in sys.path:
+        sys.path.insert(0, _tools)
+    from stress_stagewise import random_ltv
+
+    wm = random_ltv(np.random.default_rng(5), 4096, 8, 2, 20, 4, 1.0)
+    wm["A"] = np.eye(8) + 0.3 * (wm["A"] - np.eye(8))
+    bpm = W.to_batch_problem(wm)
+    out["midsize_ltv_nx8_nu2_n40_m80_f64_batch4096"] = rate(PreparedSolve(bpm).launch, 4096, 5)
+    out["midsize_ltv_nx8_nu2_n40_m80_f64_batch4096_condensed_kernels"] = rate(
+        PreparedSolve(bpm, flags=_capi.OPT_FORCE_CONDENSED).launch, 4096, 3)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
     walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)
