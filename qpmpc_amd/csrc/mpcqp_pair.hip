@@ -289,7 +289,10 @@ __global__ void __launch_bounds__(64, 2)
     // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[16] per problem
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     auto tick = [&](int slot) {
-        if (stamp && hl == 0 && valid) stamp[slot] = (long long)__builtin_readcyclecounter();
+        if (stamp && hl == 0 && valid) {
+            stamp[slot] = (long long)__builtin_readcyclecounter();  // (shader clock: its base differs from CU to CU)
+            if (slot == 0 || slot == 6) stamp[slot ? 13 : 12] = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, one base
+        }
     };
     tick(0);
 
