@@ -84,5 +84,5 @@ def run(rounds, batch, seed=4242, verbose=True):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    worst, bad, drops = run(rounds, batch)
+    worst, bad, drops = run(rounds, batch, seed=int(os.environ.get("STRESS_SEED", "4242")))
     print("worst rel diff", worst, "rounds flagged", bad, "problems with more trips than variables", drops)

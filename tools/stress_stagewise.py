@@ -25,7 +25,7 @@ if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     narrow = len(sys.argv) > 3 and sys.argv[3] == "narrow"  # small systems through mpcqp_stage.hip
-    rng = np.random.default_rng(12345)
+    rng = np.random.default_rng(int(os.environ.get("STRESS_SEED", "12345")))
     worst, bad = 0.0, 0
     for it in range(rounds):
         nx, nu = (int(rng.integers(2, 5)), int(rng.integers(1, 3))) if narrow else (int(rng.integers(2, 17)), int(rng.integers(1, 5)))
