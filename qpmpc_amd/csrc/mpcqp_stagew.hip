@@ -37,6 +37,12 @@ namespace mpcqp {
 #ifndef STAGEW_D
 #define STAGEW_D 4
 #endif
+#ifndef STAGEW_VTRIG32
+#define STAGEW_VTRIG32 8
+#endif
+#ifndef STAGEW_VPASS32
+#define STAGEW_VPASS32 2
+#endif
 #ifndef STAGEW_WPE32
 #define STAGEW_WPE32 3
 #endif
@@ -255,6 +261,11 @@ __global__ void __launch_bounds__(64)
     using V4 = __attribute__((ext_vector_type(4))) T;
     using MV = typename Mfma<T>::V;
     constexpr int D = sizeof(T) == 4 ? (LOW ? D_LOW : STAGEW_D) : 4;  // the sweeps request their records this many steps ahead
+    // passes of the final verification: every pass but the last one triggers a refinement step of the multipliers when an
+    // active row is off its bound by more than 1e3 tol (1 + |e|) (float64) / STAGEW_VTRIG32 tol (1 + |e|) (float32: 8, was 64
+    // -- a stress run in float32 left rows 6e-4 off their bounds and plans 1.5e-3 off the oracle's; a SECOND refinement step
+    // in float32 helps some of those problems and hurts others (W has drifted too), so it stays one: tools/stress_f32.py)
+    constexpr int VPASS = sizeof(T) == 4 ? STAGEW_VPASS32 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -1398,7 +1409,7 @@ __global__ void __launch_bounds__(64)
             // ACTIVE rows must sit on their bounds (W is only ever updated, never refactored: if it drifted, one step of
             // refinement lam -= W rho_A puts them back, and a point that still fails is not reported solved)
             bool dirty = false;
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < VPASS; ++pass) {
                 // ONE pass over the rows: s = s0 + sum_a lam_a h_a with the slots' loads in flight in groups
                 constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
                 bool offa = false;
@@ -1436,7 +1447,7 @@ __global__ void __launch_bounds__(64)
                                 const int k = stepof(i), r = i - k * mk;
                                 // first pass: 1e3 tol (1 + |e|) TRIGGERS the refinement; second pass: what is acceptable after it
                                 // (the contract's 1e-6 in float64)
-                                const T fac = pass == 0 ? T(sizeof(T) == 4 ? 64 : 1000) : ((sizeof(T) == 4 || T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol);
+                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : ((sizeof(T) == 4 || T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol);
                                 const T lim = fac * (tol + tol * (T)fabs((double)ge[k * sE + r]));
                                 offa |= !((T)fabs((double)fr[u]) <= lim);
                             } else if (!(fr[u] >= T(-4) * th[u])) {
@@ -1447,7 +1458,7 @@ __global__ void __launch_bounds__(64)
                     }
                 }
                 if (__ballot(offa) == 0ull) break;
-                if (pass == 1) {
+                if (pass == VPASS - 1) {
                     fail = true;
                     break;
                 }
@@ -1792,11 +1803,11 @@ __global__ void __launch_bounds__(64)
             // 5e-7 off after 450 iterations): beyond 1e3 tol (1 + |e|) one step of refinement lam -= W rho_A puts them back, and a
             // point that still fails the contract's bound is not reported solved -- as in the layout above.
             bool dirty = false;
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < VPASS; ++pass) {
             bool offa = false;
             dirty = false;
             for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
-            const T afac = pass == 0 ? T(sizeof(T) == 4 ? 64 : 1000) : (T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol);
+            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol);
             for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                 T fr[SU];
 #pragma unroll
@@ -1838,7 +1849,7 @@ __global__ void __launch_bounds__(64)
                 }
             }
             if (__ballot(offa) == 0ull) break;
-            if (pass == 1) {
+            if (pass == VPASS - 1) {
                 fail = true;
                 break;
             }
