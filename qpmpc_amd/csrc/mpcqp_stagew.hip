@@ -40,6 +40,9 @@ namespace mpcqp {
 #ifndef STAGEW_VTRIG32
 #define STAGEW_VTRIG32 8
 #endif
+#ifndef STAGEW_VACC32
+#define STAGEW_VACC32 1000
+#endif
 #ifndef STAGEW_VPASS32
 #define STAGEW_VPASS32 2
 #endif
@@ -1447,7 +1450,7 @@ __global__ void __launch_bounds__(64)
                                 const int k = stepof(i), r = i - k * mk;
                                 // first pass: 1e3 tol (1 + |e|) TRIGGERS the refinement; second pass: what is acceptable after it
                                 // (the contract's 1e-6 in float64)
-                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : ((sizeof(T) == 4 || T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol);
+                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol);
                                 const T lim = fac * (tol + tol * (T)fabs((double)ge[k * sE + r]));
                                 offa |= !((T)fabs((double)fr[u]) <= lim);
                             } else if (!(fr[u] >= T(-4) * th[u])) {
@@ -1807,7 +1810,7 @@ __global__ void __launch_bounds__(64)
             bool offa = false;
             dirty = false;
             for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
-            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol);
+            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol);
             for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                 T fr[SU];
 #pragma unroll
