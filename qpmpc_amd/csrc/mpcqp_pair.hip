@@ -257,8 +257,12 @@ using namespace pair;
 // h and L^-1 q, gA = the model); build, factorisation and forward substitution are skipped (mpc_qp.py:129-163 usage).
 // WARM: the launch carries a warm-start state (MpcqpSolveOpts.warm_state); the cold instantiations drop the repair
 // machinery from the loop.
-template <int NX, int MK, bool MODEL = false, bool WARM = false>
-__global__ void __launch_bounds__(64, 2)
+// WPB: wavefronts per workgroup, each with its own two problems and its own LDS carve (they share nothing: no barrier
+// anywhere). A launch that fills the machine exactly once (two wavefronts per SIMD) is 3 % shorter with workgroups of two -- 25.6 against
+// 26.4 us for 4096 problems; 3, 4 and 8 lose: 35.7 / 27.5 / 27.6 --, launches of several rounds are faster with single
+// wavefronts (8192 problems: 47.2 against 53.3 us; 65,536: 310 against 320), see launch_pair_t.
+template <int NX, int MK, bool MODEL = false, bool WARM = false, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB, 2)
     mpcqp_pair_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ gD, const double *__restrict__ ge, const double *__restrict__ gx0,
                       const double *__restrict__ ggoal, const double *__restrict__ gtgt, double *__restrict__ oU,
@@ -267,15 +271,16 @@ __global__ void __launch_bounds__(64, 2)
 {
     using T = double;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;  // wavefront of the workgroup (the wavefronts share nothing: no barrier anywhere)
     const int hb = lane & 32;   // first lane of this half
     const int hl = lane & 31;   // lane inside the half
     const int l15 = lane & 15;
     const bool low = hl < NV;
-    int64_t prob = 2 * (int64_t)blockIdx.x + (hb >> 5);
+    int64_t prob = 2 * ((int64_t)blockIdx.x * WPB + wv) + (hb >> 5);
     const bool valid = prob < batch;  // an odd batch leaves the last half idle: it repeats the last problem, stores nothing
     prob = valid ? prob : batch - 1;
-    T *sm = (T *)smem_raw + (hb ? L.per : 0);
+    T *sm = (T *)smem_raw + (2 * wv + (hb ? 1 : 0)) * L.per;
     const int vofs = low ? hl : 3 * NV + l15;  // element of an exchange vector (shadow copy for lanes >= 16)
     const int n = ka.n, m = ka.m;
     const bool isc = hl < m;  // this lane owns a constraint
@@ -1361,21 +1366,40 @@ bool pair_eligible(const KernelArgs &ka, int mode, int dtype)
     return (size_t)L.per * 2 * sizeof(double) <= 64 * 1024;
 }
 
+// true when the launch fills the machine exactly once (two wavefronts on every SIMD: BASELINE config 2's 4096 problems on
+// this chip, per GPU): workgroups of two wavefronts pay there and only there -- a partly filled machine is better served by
+// single wavefronts, which the dispatcher spreads over all compute units (2048 problems: 18.9 against 22.8 us; 3500: 24.2
+// against 26.5; 3900: 26.7 against 27.5; 4000: 27.0 against 28.0; 4096: 26.4 against 25.6)
+static bool one_round(int64_t waves)
+{
+    static const int simds = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return 4 * cus;
+    }();
+    return waves <= 2 * (int64_t)simds && waves > 2 * (int64_t)simds - 8;
+}
+
 template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     const Lay L = make_lay(ka);
-    const size_t bytes = (size_t)L.per * 2 * sizeof(double);
-    const unsigned grid = (unsigned)((batch + 1) / 2);
-    auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
+    const int64_t waves = (batch + 1) / 2;
+    auto go = [&](auto kern, int wpb) {
+        const size_t bytes = (size_t)L.per * 2 * sizeof(double) * wpb;
+        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
                            (const double *)ka.C.ptr, (const double *)ka.D.ptr, (const double *)ka.e.ptr,
                            (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
                            (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
     };
     if (ka.warm_state)
-        go(mpcqp_pair_kernel<NX, MK, false, true>);
+        go(mpcqp_pair_kernel<NX, MK, false, true>, 1);
+#ifndef PAIR_FORCE_WPB1
+    else if (waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024)
+        go(mpcqp_pair_kernel<NX, MK, false, false, 2>, 2);
+#endif
     else
-        go(mpcqp_pair_kernel<NX, MK, false, false>);
+        go(mpcqp_pair_kernel<NX, MK, false, false>, 1);
     return (int)hipGetLastError();
 }
 
