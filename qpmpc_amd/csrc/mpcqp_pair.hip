@@ -1392,26 +1392,36 @@ template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t
                            (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
                            (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
     };
-    if (ka.warm_state)
-        go(mpcqp_pair_kernel<NX, MK, false, true>, 1);
-#ifndef PAIR_FORCE_WPB1
-    else if (waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024)
-        go(mpcqp_pair_kernel<NX, MK, false, false, 2>, 2);
+    bool two = waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024;
+#ifdef PAIR_FORCE_WPB1
+    two = false;
 #endif
-    else
+    if (ka.warm_state) {  // (workgroups of two measured no different here: 23.1 us either way for a stored state that is accepted)
+        go(mpcqp_pair_kernel<NX, MK, false, true>, 1);
+    } else if (two) {
+        go(mpcqp_pair_kernel<NX, MK, false, false, 2>, 2);
+    } else {
         go(mpcqp_pair_kernel<NX, MK, false, false>, 1);
+    }
     return (int)hipGetLastError();
 }
 
 int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     const Lay L = make_lay(ka);
-    const size_t bytes = (size_t)L.per * 2 * sizeof(double);
-    const unsigned grid = (unsigned)((batch + 1) / 2);
-    hipLaunchKernelGGL((mpcqp_pair_kernel<3, 0, true>), dim3(grid), dim3(64), bytes, st, (const double *)ka.model,
-                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)ka.e.ptr,
-                       (const double *)ka.x0.ptr, (const double *)ka.goal.ptr, (const double *)ka.targets.ptr,
-                       (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, L, batch);
+    const int64_t waves = (batch + 1) / 2;
+    auto go = [&](auto kern, int wpb) {
+        const size_t bytes = (size_t)L.per * 2 * sizeof(double) * wpb;
+        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), bytes, st, (const double *)ka.model, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
+                           (const double *)ka.goal.ptr, (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status,
+                           ka.iters, ka, L, batch);
+    };
+    if (waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024)
+        go(mpcqp_pair_kernel<3, 0, true, false, 2>, 2);
+    else
+        go(mpcqp_pair_kernel<3, 0, true, false, 1>, 1);
     return (int)hipGetLastError();
 }
 
