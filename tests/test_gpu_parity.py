@@ -1343,3 +1343,37 @@ def test_degenerate_problems_of_the_stress_run():
     assert (np.abs(plan.U.cpu().numpy() - Uo) / scale).max() <= 1e-6
     sol = solve_mpc(W.problem_from_workload(w, 0), solver="hip_gi")
     assert not sol.is_empty and np.abs(sol.inputs.ravel() - Uo[0]).max() <= 1e-6 * scale[0, 0]
+
+
+@pytest.mark.gpu
+def test_exactly_full_launch_of_the_pair_kernel_equals_the_other_launch_shapes():
+    """A launch of the pair kernel that fills the machine exactly once (two wavefronts on every SIMD: 16 problems per compute
+    unit, 4096 on MI355X -- BASELINE config 2) goes out as workgroups of TWO wavefronts, every other size as single
+    wavefronts. Same kernel body, same problem -> wavefront half mapping: the full launch must give bit for bit what the same
+    problems give in a launch one problem longer (two rounds, single wavefronts) and in a half-size one, with multipliers, for
+    the per-problem build and for the shared model."""
+    from qpmpc_amd import SharedModel, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    full = 16 * torch.cuda.get_device_properties(0).multi_processor_count
+    w = W.triple_integrator_batch(full + 1)
+    cut = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == full + 1 else v) for k, v in w.items()}
+    longer = solve_mpc_batch(W.to_batch_problem(w), return_multipliers=True)
+    exact = solve_mpc_batch(W.to_batch_problem(cut(full)), return_multipliers=True)
+    half = solve_mpc_batch(W.to_batch_problem(cut(full // 2)), return_multipliers=True)
+    torch.cuda.synchronize()
+    assert torch.equal(exact.status, longer.status[:full]) and torch.equal(exact.iters, longer.iters[:full])
+    assert torch.equal(exact.U, longer.U[:full]) and torch.equal(exact.multipliers, longer.multipliers[:full])
+    assert torch.equal(half.U, exact.U[: full // 2]) and torch.equal(half.iters, exact.iters[: full // 2])
+    Uo, _, sto, _ = oracle_batch(cut(full))
+    assert np.array_equal(exact.status.cpu().numpy() == 0, sto == 0)
+    ok = sto == 0
+    assert np.abs(exact.U.cpu().numpy()[ok] - Uo[ok]).max() <= 1e-8
+    # shared model (the batch's matrices are the same for every problem when the operands are not heterogeneous)
+    ws = W.triple_integrator_batch(full + 1, heterogeneous=False)
+    cuts = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == full + 1 else v) for k, v in ws.items()}
+    bl, be = W.to_batch_problem(ws), W.to_batch_problem(cuts(full))
+    pl, pe = SharedModel(bl).prepare(bl), SharedModel(be).prepare(be)
+    pl.launch(), pe.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(pe.U, pl.U[:full]) and torch.equal(pe.iters, pl.iters[:full]) and torch.equal(pe.status, pl.status[:full])
