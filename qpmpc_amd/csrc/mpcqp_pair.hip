@@ -54,6 +54,9 @@
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
+#ifndef PAIR_EARLY_ARGS
+#define PAIR_EARLY_ARGS 2
+#endif
 namespace mpcqp {
 
 namespace pair {
@@ -271,6 +274,21 @@ __global__ void __launch_bounds__(64 * WPB, 2)
 {
     using T = double;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+#if PAIR_EARLY_ARGS
+    {  // every kernel argument the operand addresses and the LDS carve need, requested in ONE batch of scalar loads at the top:
+       // left to itself the compiler fetches them where they are first used -- eight dependent scalar-load round trips before
+       // the first operand load is issued (25.6 -> 25.0 us per 4096 problems, tools/ab_unit.sh)
+        const int64_t b0 = ka.A.batch_stride, b1 = ka.B.batch_stride, b2 = ka.C.batch_stride, b3 = ka.e.batch_stride,
+                      b4 = ka.x0.batch_stride, b5 = ka.goal.batch_stride;
+        const int64_t s0 = ka.A.step_stride, s1 = ka.B.step_stride, s2 = ka.C.step_stride, s3 = ka.e.step_stride;
+        asm volatile("" ::"s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(ka.N), "s"(ka.nu),
+                     "s"(ka.mk), "s"(ka.flags), "s"(ka.probe), "s"(gA), "s"(gB), "s"(gC), "s"(ge), "s"(gx0), "s"(ggoal));
+#if PAIR_EARLY_ARGS >= 2
+        asm volatile("" ::"s"(gD), "s"(gtgt), "s"(ka.D.step_stride), "s"(ka.n), "s"(ka.m), "s"(L.off_X), "s"(L.off_Y), "s"(L.off_hv),
+                     "s"(L.off_v), "s"(L.off_stage), "s"(L.per), "s"(L.nA), "s"(L.nB), "s"(L.nC), "s"(L.nD), "s"(batch));
+#endif
+    }
+#endif
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;  // wavefront of the workgroup (the wavefronts share nothing: no barrier anywhere)
     const int hb = lane & 32;   // first lane of this half
