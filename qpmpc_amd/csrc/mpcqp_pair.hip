@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
     // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
     if constexpr (!MODEL) {
         constexpr int nx = NX;
-        const int nu = ka.nu, N = ka.N, mk = ka.mk;
+        const int nu = ka.nu, N = ka.N, mk = MK > 0 ? MK : ka.mk;  // (a compile-time mk spares the prologue an integer division)
         const T *A = gA + prob * ka.A.batch_stride;
         const T *B = gB + prob * ka.B.batch_stride;
         const T *Cm = gC ? gC + prob * ka.C.batch_stride : nullptr;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
         constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
         // the per-lane scalars are requested first, so that their latency is the staging's
         const bool isx = (hl == NV), col = (hl < n);
-        const int j = col ? hl / nu : -1, ii = col ? hl - j * nu : 0;
+        const int j = col ? (nu == 1 ? hl : hl / nu) : -1, ii = col ? hl - j * nu : 0;  // (nu == 1: no division before the loads)
         const T eval = isc ? ge[prob * ka.e.batch_stride + (hl / mk) * ka.e.step_stride + (hl % mk)] : INF;
         T v[NX], gref[NX];
 #pragma unroll
@@ -618,7 +618,8 @@ __global__ void __launch_bounds__(64 * WPB, 2)
         T hh = INF;
         if (isc) {
             // the bounds come with the model, or per problem (mpcqp_solve_model_bounds_batch: matrices shared, e moving)
-            hh = ge ? ge[prob * ka.e.batch_stride + (hl / ka.mk) * ka.e.step_stride + (hl % ka.mk)] : model[ml.off_e + hl];
+            const int mkr = ka.mk, kq = mkr == 2 ? hl >> 1 : hl / mkr;  // (two rows per step: no integer division in the prologue)
+            hh = ge ? ge[prob * ka.e.batch_stride + kq * ka.e.step_stride + (hl - kq * mkr)] : model[ml.off_e + hl];
             for (int c = 0; c < nxr; ++c) hh -= model[ml.off_Hx + (size_t)hl * nxr + c] * x0[c];
         }
         hv[hl] = hh;
