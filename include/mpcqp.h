@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 7
+#define MPCQP_ABI_VERSION 8
 
 /* element type of every floating-point buffer of a call */
 #define MPCQP_F64 0
@@ -137,6 +137,19 @@ typedef struct MpcqpProblem {
                                       pre-scheduled dynamics); the first launch of a sequence uses KEEP_FACTOR.
                                       MPCQP_EUNSUPPORTED for other dimensions. */
 
+#define MPCQP_OPT_SEED_VIOLATED 512 /* small-problem fused kernel (n <= 16, m <= 32): before the Goldfarb-Idnani iterations, the
+                                 rows violated at the unconstrained minimiser enter by SEED STEPS (same rank-one updates, no
+                                 selection, no ratio test; rows whose multiplier comes out negative leave again). Same
+                                 minimiser; measured 5 % SLOWER than the plain iterations on BASELINE config 2,
+                                 hence opt-in: the seed steps are what MPCQP_WARM_ACTIVE_SET starts from. */
+
+/* MpcqpSolveOpts.warm_start */
+#define MPCQP_WARM_OPERATOR 1   /* begin from the stored active set AND operator N* (contract: matrices unchanged)          */
+#define MPCQP_WARM_ACTIVE_SET 2 /* begin from the stored active set's ROW IDS only, moved by warm_shift rows: the rows enter
+                                   by seed steps on THIS problem's matrices, so the matrices, bounds and states may all have
+                                   changed -- the receding-horizon case, where row (k, i) of last period is row (k - 1, i)
+                                   now: warm_shift = mk. Small-problem fused kernel only (MPCQP_EUNSUPPORTED elsewhere).   */
+
 typedef struct MpcqpSolveOpts {
     int32_t max_iter; /* active-set iterations per problem; <=0 -> 10*(n+m)     */
     int32_t flags;    /* MPCQP_OPT_* (0 = automatic dispatch)                    */
@@ -176,6 +189,10 @@ typedef struct MpcqpSolveOpts {
      * batch * mpcqp_warm_state_bytes(); a smaller buffer (a state allocated for another batch or other
      * dimensions) is refused with MPCQP_EWORKSPACE before anything is launched. Ignored when warm_state is NULL. */
     size_t warm_state_bytes;
+    /* MPCQP_WARM_ACTIVE_SET (ABI 8): stored row id r is taken as row r - warm_shift of this launch's problem; ids that
+     * fall off the horizon's start (or name a padded row) are dropped. 0: the rows kept their places. */
+    int32_t warm_shift;
+    int32_t reserved_;
 } MpcqpSolveOpts;
 
 /* ABI version of the loaded library (== MPCQP_ABI_VERSION of its build). */

@@ -14,9 +14,10 @@ F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EINVAL, EUNSUPPORTED = -1, -6
-ABI_VERSION = 7
+ABI_VERSION = 8
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
-OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR = 64, 128, 256
+OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED = 64, 128, 256, 512
+WARM_OPERATOR, WARM_ACTIVE_SET = 1, 2
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
 LIB_PATH = os.environ.get("MPCQP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmpcqp_hip.so")
@@ -69,7 +70,7 @@ class SolveOpts(C.Structure):
     _fields_ = [
         ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
         ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("factor_slot", C.c_int32),
-        ("probe", C.c_void_p), ("warm_state_bytes", C.c_size_t),
+        ("probe", C.c_void_p), ("warm_state_bytes", C.c_size_t), ("warm_shift", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -345,15 +345,27 @@ def _ws_args(ws):
     return (None, 0) if ws is None else (ws.data_ptr(), ws.numel())
 
 
-def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_state=None, warm_start: bool = False, probe=None):
+def _warm_mode(warm_start) -> int:
+    """False / True / "operator" / "active_set" (or the MPCQP_WARM_* integers) -> MpcqpSolveOpts.warm_start."""
+    if isinstance(warm_start, str):
+        try:
+            return {"operator": _capi.WARM_OPERATOR, "active_set": _capi.WARM_ACTIVE_SET}[warm_start]
+        except KeyError:
+            raise BackendError(f"warm_start must be False, True, 'operator' or 'active_set', not {warm_start!r}") from None
+    return int(warm_start) if warm_start else 0
+
+
+def _opts(max_iter=None, feas_tol=None, flags: int = 0, warm_state=None, warm_start=False, probe=None, warm_shift: int = 0):
     """``MpcqpSolveOpts``. ``warm_state``: a :class:`WarmState` (or a uint8 device tensor) that every solve
-    updates and, with ``warm_start=True``, starts from; ``flags``: the explicit dispatch overrides
+    updates and, with ``warm_start``, starts from -- ``True`` / ``"operator"``: the stored active set and operator
+    (matrices unchanged); ``"active_set"``: the stored rows only, moved down by ``warm_shift`` rows (receding horizon:
+    ``warm_shift = mk`` per step the horizon advanced); ``flags``: the explicit dispatch overrides
     ``_capi.OPT_*`` (tests); ``probe``: an int64 device tensor for the developer stamps."""
     o = _capi.SolveOpts()
     o.max_iter, o.flags, o.feas_tol = int(max_iter or 0), int(flags), float(feas_tol or 0.0)
     if warm_state is not None:
         buf = warm_state.buffer if isinstance(warm_state, WarmState) else warm_state
-        o.warm_state, o.warm_start = buf.data_ptr(), 1 if warm_start else 0
+        o.warm_state, o.warm_start, o.warm_shift = buf.data_ptr(), _warm_mode(warm_start), int(warm_shift)
         o.warm_state_bytes = int(buf.numel() * buf.element_size())  # the C side refuses a buffer smaller than the launch needs
     if probe is not None:
         o.probe = probe.data_ptr()
@@ -507,6 +519,12 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     _check_warm(problem, opt_kw)
+    ws_ = opt_kw.get("warm_state")
+    if isinstance(ws_, WarmState) and ws_.kind == "stage" and opt_kw.get("warm_start"):
+        # the stage-wise kernel's warm start continues from the vectors its previous launch left in the SAME workspace;
+        # this function allocates a fresh one per call, so the request could only ever be a silent cold start
+        raise BackendError("a stage-kind WarmState warm-starts through PreparedSolve (one workspace kept across launches), "
+                           "not through solve_mpc_batch(warm_start=True)")
     dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol, **opt_kw)
     if formulation == "stagewise":
         nbytes = C.c_size_t(0)
@@ -624,6 +642,9 @@ class PreparedSolve:
         # the stage-wise kernel's warm start continues from the vectors its previous launch left in THIS object's
         # workspace: the first launch keeps the Riccati factor, set_warm_start(True) switches to re-using it
         self._stage_warm = isinstance(ws_, WarmState) and ws_.kind == "stage"
+        # (warm_start=True at construction: the first launch has nothing to continue from -- it factors, keeps the factor
+        # and starts cold; launch() switches to the re-used factor + warm start right after it)
+        self._stage_warm_pending = self._stage_warm and bool(self._opts.warm_start)
         if self._stage_warm:
             self._opts.flags |= _capi.OPT_KEEP_FACTOR
         if self._stagewise:
@@ -646,11 +667,15 @@ class PreparedSolve:
         )
         self._entry = self._lib.mpcqp_stagewise_solve_batch if self._stagewise else self._lib.mpcqp_build_solve_batch
 
-    def set_warm_start(self, on: bool) -> None:
-        """Begin the next launches from the ``warm_state`` given at construction (or from the empty set)."""
+    def set_warm_start(self, on, warm_shift: Optional[int] = None) -> None:
+        """Begin the next launches from the ``warm_state`` given at construction (or from the empty set): ``True`` /
+        ``"operator"`` -- the stored active set and operator --, ``"active_set"`` -- the stored rows only, moved down by
+        ``warm_shift`` rows (receding horizon: ``mk`` per step the horizon advanced; small problems only)."""
         if "warm_state" not in self._opt_kw:
             raise BackendError("PreparedSolve was built without warm_state=WarmState(problem)")
-        self._opts.warm_start = 1 if on else 0
+        self._opts.warm_start = _warm_mode(on)
+        if warm_shift is not None:
+            self._opts.warm_shift = int(warm_shift)
         if self._stage_warm:  # (contract of both: A, B, C, D and the weights are those of the launch before)
             keep, reuse = _capi.OPT_KEEP_FACTOR, _capi.OPT_REUSE_FACTOR
             self._opts.flags = (self._opts.flags & ~(keep | reuse)) | (reuse if on else keep)
@@ -662,6 +687,9 @@ class PreparedSolve:
         rc = self._entry(*self._args, sp)
         if rc != 0:
             _capi.check(rc, "mpcqp_stagewise_solve_batch" if self._stagewise else "mpcqp_build_solve_batch")
+        if self._stage_warm_pending:
+            self._stage_warm_pending = False
+            self.set_warm_start(True)
 
     @property
     def plan(self) -> BatchPlan:

@@ -160,6 +160,10 @@ class WIPClosedLoop:
                     self._pipe = False
                     self.solver._opts.flags &= ~(_capi.OPT_PIPELINE_FACTOR | _capi.OPT_KEEP_FACTOR)
                     rc = lib.mpcqp_wip_periods_batch(*self._period_args, k, _stream_ptr())
+                if rc == _capi.EUNSUPPORTED and k > 1:
+                    # (this horizon has no multi-period instantiation; the fused single-period launch may still exist)
+                    self._ppl = k = 1
+                    rc = lib.mpcqp_wip_periods_batch(*self._period_args, k, _stream_ptr())
                 if rc == _capi.EUNSUPPORTED:
                     self._fused = False  # (another kernel serves this size: two launches per period)
                 else:
@@ -221,7 +225,7 @@ class LIPMWalkingLoop:
                  state=None, com_height: float = 0.84, dsp_duration: float = 0.1, ssp_duration: float = 0.7,
                  gravity: float = 9.81, init_support_foot_pos: float = 0.09, nb_timesteps: int = 16,
                  sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None,
-                 warm_start: bool = False, shared_model: bool = False):
+                 warm_start=False, shared_model: bool = False):
         import torch
 
         _capi.require_gpu()
@@ -259,7 +263,10 @@ class LIPMWalkingLoop:
                                        goal_state=np.zeros((batch, 3)))
         # warm_start: every period begins from the previous period's active set and operator (the model
         # A, B, C is time-invariant here, only the bounds e, x0 and the goal move; MpcqpSolveOpts.warm_state)
+        # warm_start="active_set": only last period's active ROWS are kept and enter first, moved one step down the horizon
+        # (MPCQP_WARM_ACTIVE_SET with warm_shift = mk = 2: row (k, i) of the last period is row (k - 1, i) of this one)
         self.warm_state = WarmState(self.problem) if warm_start else None
+        self._warm_mode = warm_start
         self.model = None
         if shared_model:
             # The matrices never change here, only e / x0 / goal do: factor them ONCE (the reference's own usage of
@@ -372,7 +379,7 @@ class LIPMWalkingLoop:
                     self._advance_fused(first=True)
                 self.solver.launch()
                 if self.warm_state is not None and self.mpc_steps == 0:
-                    self.solver.set_warm_start(True)  # from the second period on
+                    self.solver.set_warm_start(self._warm_mode, warm_shift=2)  # from the second period on
                 self._advance_fused(first=False)
                 self._problem_written = True
             else:
@@ -380,7 +387,7 @@ class LIPMWalkingLoop:
                 self._write_goal_and_constraints()
                 self.solver.launch()
                 if self.warm_state is not None and self.mpc_steps == 0:
-                    self.solver.set_warm_start(True)
+                    self.solver.set_warm_start(self._warm_mode, warm_shift=2)
                 ok = self.solver.status == 0
                 jerk = torch.where(ok, self.solver.U[:, 0], torch.zeros_like(self.solver.U[:, 0]))
                 self._integrate(jerk)

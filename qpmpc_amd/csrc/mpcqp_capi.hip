@@ -78,6 +78,8 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
     ka.probe = o->probe;
     ka.warm_state = o->warm_state;
     ka.warm_start = o->warm_state ? o->warm_start : 0;
+    ka.warm_shift = o->warm_state ? o->warm_shift : 0;
+    if (ka.warm_start < 0 || ka.warm_start > MPCQP_WARM_ACTIVE_SET) return MPCQP_EINVAL;
     ka.warm_state_bytes = o->warm_state ? o->warm_state_bytes : 0;
     ka.factor_slot = o->factor_slot & 1;
     return 0;
@@ -487,6 +489,7 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype) && !use_stage_auto(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (ka.warm_start == MPCQP_WARM_ACTIVE_SET && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
     if ((ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR) && !(use_stage_auto(ka, dims->dtype) && stage_pipeline_supported(ka, dims->dtype)))
         return MPCQP_EUNSUPPORTED;
     // the state is indexed by problem: a buffer made for a smaller batch would be read and written out of bounds
@@ -719,6 +722,9 @@ int mpcqp_wip_periods_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     const int maxq = stage_default_maxq(ka);
     const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
     if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+    // (as in mpcqp_build_solve_batch: the warm-state record is indexed by problem and written by the kernel, so a buffer
+    // that is too small -- or an old caller that leaves warm_state_bytes at zero -- is refused before anything is launched)
+    if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * warm_bytes_per_problem(ka, dims->dtype)) return MPCQP_EWORKSPACE;
     // several periods per launch: a factor that is kept is the FIRST period's business (the caller's next launch reuses
     // or pipelines it), and the warm-state record is per launch
     if (nperiods > 1 && ((ka.opt_flags & MPCQP_OPT_KEEP_FACTOR) || ka.warm_state || !stage_pipeline_supported(ka, dims->dtype)))

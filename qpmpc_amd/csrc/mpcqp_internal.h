@@ -32,7 +32,8 @@ struct KernelArgs {
     // MpcqpSolveOpts beyond max_iter / feas_tol
     int opt_flags;                // MPCQP_OPT_*
     void *warm_state;             // per-problem active set + operator (read if warm_start, written at the end), or null
-    int warm_start;
+    int warm_start;               // 0 | MPCQP_WARM_OPERATOR | MPCQP_WARM_ACTIVE_SET
+    int warm_shift;               // MPCQP_WARM_ACTIVE_SET: rows the stored ids move down by
     int factor_slot;              // which of the two factor images of the stage-wise kernel this launch keeps / reuses
     size_t warm_state_bytes;      // size of the buffer behind warm_state (checked on the host before the launch)
     void *probe;                  // developer probe: int64 stamps per problem, or null

@@ -84,6 +84,16 @@ __device__ __forceinline__ unsigned half_min(unsigned v)
     const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
     return min((unsigned)sw[0], (unsigned)sw[1]);
 }
+// all-reduce (or) over the 32 lanes of each half
+__device__ __forceinline__ unsigned half_or(unsigned v)
+{
+    v |= dpp_u<ROR8>(v);
+    v |= dpp_u<ROR4>(v);
+    v |= dpp_u<ROR2>(v);
+    v |= dpp_u<ROR1>(v);
+    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (unsigned)sw[0] | (unsigned)sw[1];
+}
 // value of lane `idx` (0..31, uniform inside a half) of the caller's own half
 __device__ __forceinline__ int half_get(int x, int hb, int idx)
 {
@@ -577,8 +587,12 @@ __global__ void __launch_bounds__(64 * WPB, 2)
     tick(2);
 
     // the stored warm-start state is requested now and consumed after the forward substitution
-    double *wstate = (WARM && ka.warm_state) ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
-    const bool wload = WARM && wstate && ka.warm_start && !notpd;
+    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
+    const bool wload = WARM && wstate && ka.warm_start == MPCQP_WARM_OPERATOR && !notpd;
+    // MPCQP_WARM_ACTIVE_SET: only the stored row ids are read (the cold instantiation serves it: see the seeded start)
+    const bool wseed = !WARM && wstate && ka.warm_start == MPCQP_WARM_ACTIVE_SET;
+    int sid = -1;
+    if (wseed && low) sid = reinterpret_cast<const int *>(wstate + NV * NV)[hl];
     int wid = -1;
     T wrow[NV];
 #pragma unroll
@@ -867,6 +881,107 @@ __global__ void __launch_bounds__(64 * WPB, 2)
         }
         wsync();
     };
+    // ------------------------------------------------------------ seeded start
+    // The rows violated at the unconstrained minimiser predict the final active set well when the bounds are simple
+    // (BASELINE config 2: 98 % of them end up active, 83 % of the final set is among them), and what a trip of the
+    // loop below costs is mostly NOT arithmetic: the selection's reduction, the row of M whose address depends on it, the
+    // ratio test and the flags form one dependent chain of ~1.5 k cycles around 64 FMAs. A SEED STEP adds the next row of
+    // that list -- lowest index first, only while it is still violated -- with everything the selection needed known one
+    // step ahead and without a ratio test: the same rank-one updates of T, H, K, the same move of the implied primal
+    // point, multipliers allowed to turn negative. What it reaches is the minimiser on the seeded rows' hyperplanes; rows
+    // whose multiplier came out negative then leave one by one (`negfix`, first thing in the loop below: the ordinary drop
+    // pass, extended by the move a non-zero multiplier implies), which restores an S-pair in Goldfarb-Idnani's sense, and
+    // the ordinary iterations finish from there. Same minimiser (strict convexity). Measured (tools/ab_seed.py): a seed step
+    // costs 1.04 k cycles against 1.56 k for a trip, but the rows it misses cost full trips afterwards and the slowest wavefront of a
+    // one-round launch gets no shorter -- 25.7 against 24.4 us per 4096 config-2 problems --, so seeding from the violated rows is
+    // opt-in (MPCQP_OPT_SEED_VIOLATED); the seed steps are what MPCQP_WARM_ACTIVE_SET -- last period's active rows, moved with the
+    // horizon -- starts from: those rows enter whether or not they are violated yet.
+    bool negfix = false;  // this half holds negative multipliers left by the seed steps
+    if ((ka.opt_flags & MPCQP_OPT_SEED_VIOLATED) || wseed) {
+        // rows that enter whether or not they are violated at the moment: last period's active set, moved with the horizon
+        unsigned force = 0u;
+        if (wseed) {
+            const int a = sid - ka.warm_shift;
+            const bool okrow = low && sid >= 0 && a >= 0 && a < m && hv[(a >= 0 && a < m) ? a : 0] < T(1e29);
+            force = half_or(okrow ? (1u << a) : 0u);
+            force = done ? 0u : force;
+        }
+        unsigned rem = force;  // (half-uniform)
+        if (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED) rem |= (unsigned)(__ballot(!done & !warm & selectable & (s < -tolh)) >> hb);
+        rem = (__builtin_popcount(rem) > n) ? 0u : rem;  // more rows than slots: left to the ordinary iterations
+        force &= rem;
+        const bool forced = (force >> hl) & 1u;  // this lane's row is one of them
+        if (__ballot(rem != 0u) != 0ull) {
+            // Software pipeline: while step t runs, the seed of step t + 1 is chosen -- from the slacks as they are BEFORE
+            // step t, one step stale -- and its row of M is on its way from LDS; lane p itself re-checks, with the slacks of
+            // the moment, that its row is still violated (a row that step t repaired makes step t + 1 an empty one).
+            T zn = T(0), cTn = T(0), cKn = T(0);
+            int ps = 0;
+            bool st = false;
+            // next seed of this half: lowest remaining row that is violated now
+            auto next_seed = [&](T (&mpn)[NV]) {
+                const unsigned vnow = (unsigned)(__ballot(selectable & (pos < 0) & (s < -tolh)) >> hb);
+                const unsigned cand = rem & (vnow | force);
+                st = (cand != 0u);
+                ps = st ? (int)__builtin_ctz(cand) : 0;
+                rem = st ? (cand & ~(1u << ps)) : 0u;
+                ld16(mpn, Ml + ps * LDM);
+            };
+            auto seed_step = [&](const T (&mp)[NV], T (&mpn)[NV]) {
+                const int pc = ps;        // this step's row (chosen one step ago)
+                const bool sc = st & (__builtin_popcount(mask) < n);
+                next_seed(mpn);
+                dpp_ready(zn);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    fmac_bcast_at(RT[k], zn, cTn, k);
+                    fmac_bcast_at(RM[k], zn, cKn, k);
+                }
+                const T rd = dot16(RT, mp), kd = dot16(RM, mp);
+                // |z|^2 = K_p . M_p, trusted only well away from dependence (see DEP_FAST); lane pc decides for its row,
+                // which must still be violated
+                const T kx = ((kd * invn * invn > T(DEP_FAST)) & ((s < -tolh) | forced)) ? kd : T(0);
+                const T d2 = half_get(kx, hb, pc);
+                const T sp = half_get(s, hb, pc);
+                const bool go = sc & (d2 > T(0));
+                const T inv = go ? fast_rcp(d2) : T(0);
+                const T tt = -sp * inv;  // (zero for a half that does not step)
+                zn = from_high_row(rd);  // -z_k in lanes k and 16 + k
+                const int sl = (int)__builtin_ctz(~mask);
+                const bool isnew = go & (hl == sl);
+                // T_a += (r_a/d2) z, T_new = -z/d2, H_k -= (z_k/d2) z, K_i -= (M_i.z/d2) z, as multiples of -z (an empty
+                // slot's row of T is zero, so is its r_a; rows of lanes without a constraint are zero)
+                cTn = (hl == sl) ? inv : -(rd * inv);
+                cKn = -(kd * inv);
+                s = fma(tt, kd, s);  // s_i -= t M_i . z ; an active row's K_i vanishes (their slacks are reset below)
+                const T ln = low ? fma(-tt, rd, lam) : lam;  // (no ratio test, no clamp)
+                lam = isnew ? tt : ln;
+                myact = isnew ? pc : myact;
+                occ = occ | isnew;
+                pos = (go & (hl == pc)) ? sl : pos;
+                mask |= go ? (1u << sl) : 0u;
+            };
+            T mpa[NV], mpb[NV];
+            next_seed(mpa);
+            for (;;) {
+                if (__ballot(st) == 0ull) break;
+                seed_step(mpa, mpb);
+                if (__ballot(st) == 0ull) break;
+                seed_step(mpb, mpa);
+            }
+            // the last step's update
+            dpp_ready(zn);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                fmac_bcast_at(RT[k], zn, cTn, k);
+                fmac_bcast_at(RM[k], zn, cKn, k);
+            }
+            nq = __builtin_popcount(mask);
+            iters += nq;
+            s = (pos >= 0) ? T(0) : s;
+            negfix = half_any(occ & (lam < T(0)), hb);
+        }
+    }
     tick(4);
     for (;;) {
         // ===================================================== active-set loop
@@ -899,7 +1014,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
             //      turns out to be a FULL one (no multiplier blocks, nothing leaves, no limit reached), a trip needs
             //      none of the general machinery: one ballot per trip checks that, anything else leaves this loop
             //      and the same trip is redone by the general code below.
-            if (__ballot(!done & (!needp | dropping)) == 0ull) {
+            if (__ballot(!done & (!needp | dropping | negfix)) == 0ull) {
                 // Inside this loop the update vector never goes through LDS: lane 16 + k of a half produces -z_k, one
                 // v_permlane16_swap pair copies the high row over the low one, and the next trip's update reads
                 // component k as a DPP row broadcast. cTn, cKn are the coefficients of -z.
@@ -969,10 +1084,31 @@ __global__ void __launch_bounds__(64 * WPB, 2)
                 }
                 // (both exits leave no update pending: the coefficients are cleared right after each update)
             }
+            // ---- seeded start: a slot whose multiplier came out negative leaves -- the most negative one first, one per
+            //      trip -- before anything else is selected (rare: ~0.2 rows per config-2 problem)
+            bool ndrop = false;  // this trip's drop pass carries a non-zero multiplier
+            if (__ballot(negfix & !done & !dropping) != 0ull) {
+                const bool rep = negfix & !done & !dropping;
+                unsigned hi, lo;
+                ordered(lam, hi, lo);
+                const bool ng = rep & occ & (lam < T(0));
+                const unsigned mkey = half_min(ng ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu);
+                const bool any = rep & (mkey != 0xffffffffu);
+                const int ln = (int)(mkey & 31u);
+                const int cl = half_get(myact, hb, ln);
+                wsync();
+                if (any && hl == ln) st16(kAv, RT);  // (the pending update was applied at the top of this trip)
+                if (any && hl == cl) pos = -1;
+                wsync();
+                ldrop = any ? ln : ldrop;
+                dropping = dropping | any;
+                ndrop = any;
+                negfix = negfix & !(rep & !any);  // none left: (y, A) is an S-pair, the ordinary iterations take over
+            }
             // ---- selection, for the halves that start a new constraint (straight-line selects: no divergent branches)
             {
                 const unsigned hi = ~(unsigned)__double2hiint(s * invn);  // (negative for every candidate: see the fast loop)
-                const bool want = needp & !done;
+                const bool want = needp & !done & !dropping;
                 const bool viol = want & selectable & (pos < 0) & (s < -tolh);
                 const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
                 const unsigned mkey = half_min(key);
@@ -1078,6 +1214,15 @@ __global__ void __launch_bounds__(64 * WPB, 2)
                     cT = low ? ((hl == ldrop) ? T(-1) : (occ ? -tl * itl : T(0))) : kAv[l15] * itl;
                     cK = isc ? g * itl : T(0);
                     pdrop = true;
+                }
+                if (__ballot(ndrop) != 0ull) {
+                    // the slot leaves with a multiplier lam_l < 0 (seeded start): the minimiser on the remaining rows'
+                    // hyperplanes is y + (lam_l / |T_l|^2) T_l, its multipliers lam_a - lam_l (T_a . T_l) / |T_l|^2
+                    const T f = half_get(lam, hb, ldrop) * itl;
+                    if (drp && ndrop) {
+                        if (isc) s = (pos >= 0) ? T(0) : s - f * g;
+                        lam = occ ? lam - f * tl : lam;
+                    }
                 }
             }
             // ---- bookkeeping
@@ -1341,9 +1486,15 @@ __global__ void __launch_bounds__(64 * WPB, 2)
             if (oiters) oiters[prob] = iters;
         }
         if (wstate && low) {  // the operator and the active set for the next period's warm start
-            double2 *dst = reinterpret_cast<double2 *>(wstate + hl * NV);
+            if constexpr (WARM) {
+                double2 *dst = reinterpret_cast<double2 *>(wstate + hl * NV);
 #pragma unroll
-            for (int i = 0; i < NV / 2; ++i) dst[i] = double2{RT[2 * i], RT[2 * i + 1]};
+                for (int i = 0; i < NV / 2; ++i) dst[i] = double2{RT[2 * i], RT[2 * i + 1]};
+            } else {
+                // (MPCQP_WARM_ACTIVE_SET launches keep the row ids only: the operator's rows are marked as absent, so that
+                // an MPCQP_WARM_OPERATOR launch that meets this record starts cold instead of trusting stale rows)
+                wstate[hl * NV] = __builtin_nan("");
+            }
             reinterpret_cast<int *>(wstate + NV * NV)[hl] = (ok && occ) ? myact : -1;
         }
     }
@@ -1415,7 +1566,7 @@ template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t
 #ifdef PAIR_FORCE_WPB1
     two = false;
 #endif
-    if (ka.warm_state) {  // (workgroups of two measured no different here: 23.1 us either way for a stored state that is accepted)
+    if (ka.warm_state && ka.warm_start != MPCQP_WARM_ACTIVE_SET) {  // (workgroups of two measured no different here: 23.1 us either way for a stored state that is accepted)
         go(mpcqp_pair_kernel<NX, MK, false, true>, 1);
     } else if (two) {
         go(mpcqp_pair_kernel<NX, MK, false, false, 2>, 2);

@@ -307,3 +307,99 @@ def test_stage_kernel_warm_start_with_a_foreign_or_garbage_state_is_still_correc
     okb = stb == 0
     assert np.array_equal(a.status.cpu().numpy() == 0, okb)
     assert (np.abs(a.U.cpu().numpy() - Ub)[okb] / _scale(Ub[okb])).max() <= 1e-7
+
+
+# ---------------------------------------------------------------- seed steps (MPCQP_OPT_SEED_VIOLATED, MPCQP_WARM_ACTIVE_SET)
+@pytest.mark.parametrize("family", ["triple", "humanoid", "random"])
+def test_seeded_start_gives_the_plain_iterations_minimiser(family):
+    """Rows violated at the unconstrained minimiser entered by seed steps (no selection, no ratio test, negative
+    multipliers repaired by drops) before the Goldfarb-Idnani iterations: same statuses, same plans as the plain
+    iterations and as the oracle -- infeasible items of the humanoid sweep and inconsistent random rows included."""
+    from qpmpc_amd import _capi
+    from qpmpc_amd import workloads as W
+
+    if family == "random":
+        import sys, os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        from stress_stagewise import random_ltv
+
+        rng = np.random.default_rng(77)
+        w = random_ltv(rng, 384, 4, 2, 8, 2, 0.2)
+    else:
+        w = W.triple_integrator_batch(1023) if family == "triple" else W.humanoid_batch(2047)
+    bp = W.to_batch_problem(w)
+    U0, st0, it0, lam0 = _solve(bp)
+    U1, st1, it1, lam1 = _solve(bp, flags=_capi.OPT_SEED_VIOLATED)
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    assert np.array_equal(st0, st1) and np.array_equal(st1 == 0, sto == 0)
+    ok = st0 == 0
+    assert ok.any()
+    assert (np.abs(U1[ok] - U0[ok]) / _scale(U0[ok])).max() <= 1e-8
+    assert (np.abs(U1[ok] - Uo[ok]) / _scale(Uo[ok])).max() <= 1e-8
+    assert np.abs(lam1[ok] - lam0[ok]).max() <= 1e-6 * max(1.0, np.abs(lam0[ok]).max())
+    assert (lam1[ok] >= 0).all()
+
+
+def test_active_set_warm_start_receding_horizon_same_plans():
+    """MPCQP_WARM_ACTIVE_SET: last period's active ROWS (ids only), moved one step down the horizon, enter first by
+    seed steps on the new period's own matrices. Plans and statuses must be those of the cold solve every period."""
+    from qpmpc_amd import PreparedSolve, WarmState
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(1024, heterogeneous=False)
+    bp_c, bp_w = W.to_batch_problem(w), W.to_batch_problem(w)
+    ws = WarmState(bp_w)
+    cold, warm = PreparedSolve(bp_c), PreparedSolve(bp_w, warm_state=ws)
+    A = torch.as_tensor(w["A"], device="cuda")
+    Bm = torch.as_tensor(w["B"], device="cuda").reshape(3)
+    for period in range(10):
+        cold.launch()
+        warm.launch()
+        torch.cuda.synchronize()
+        sc, sw = cold.status.cpu().numpy(), warm.status.cpu().numpy()
+        assert np.array_equal(sc, sw), period
+        ok = sc == 0
+        Uc, Uw = cold.U.cpu().numpy(), warm.U.cpu().numpy()
+        assert (np.abs(Uw[ok] - Uc[ok]) / _scale(Uc[ok])).max() <= 1e-8, period
+        xn = bp_c.initial_state @ A.T + cold.U[:, :1] * Bm
+        bp_c.initial_state.copy_(xn)
+        bp_w.initial_state.copy_(xn)
+        warm.set_warm_start("active_set", warm_shift=2)  # mk = 2 rows per step
+    # the record of such a launch holds row ids only; an operator-mode start that meets it must fall back to a cold start
+    warm.set_warm_start(True)
+    cold.launch()
+    warm.launch()
+    torch.cuda.synchronize()
+    ok = cold.status.cpu().numpy() == 0
+    assert np.array_equal(cold.status.cpu().numpy(), warm.status.cpu().numpy())
+    assert (np.abs(warm.U.cpu().numpy()[ok] - cold.U.cpu().numpy()[ok]) / _scale(cold.U.cpu().numpy()[ok])).max() <= 1e-8
+
+
+def test_active_set_warm_start_with_garbage_ids_and_lipm_loop():
+    """Stored ids are not trusted: random, duplicate and out-of-range rows (and shifts past the horizon) still end at the
+    oracle's plans; the LIPM walking loop warm-started from shifted active sets follows the cold loop's trajectory."""
+    from qpmpc_amd import WarmState
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.closed_loop import LIPMWalkingLoop
+
+    w = W.humanoid_batch(512)
+    bp = W.to_batch_problem(w)
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    ok = sto == 0
+    ws = WarmState(bp)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for shift in (0, 2, 7, 40, -3):
+        ids = torch.randint(-3, 40, ws.active_set.shape, dtype=torch.int32, device="cuda", generator=g)
+        ws.buffer[:, 16 * 16 * 8:] = ids.view(torch.uint8)
+        U, st, _, _ = _solve(bp, warm_state=ws, warm_start="active_set", warm_shift=shift)
+        assert np.array_equal(st, sto), shift
+        assert (np.abs(U[ok] - Uo[ok]) / _scale(Uo[ok])).max() <= 1e-8, shift
+    rng = np.random.default_rng(3)
+    strides = np.stack([-rng.uniform(0.12, 0.2, 96), rng.uniform(0.12, 0.2, 96)], axis=1)
+    a = LIPMWalkingLoop(96, strides=strides, index=np.arange(96) % 8)
+    b = LIPMWalkingLoop(96, strides=strides, index=np.arange(96) % 8, warm_start="active_set")
+    a.step(30)
+    b.step(30)
+    torch.cuda.synchronize()
+    assert a.stats()["failed"] == 0 and b.stats()["failed"] == 0
+    assert float((a.states - b.states).abs().max()) <= 1e-9

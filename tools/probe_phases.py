@@ -10,7 +10,7 @@ one = len(sys.argv) > 2 and sys.argv[2] == "w64"
 SL = 8 if one else 16
 buf = torch.zeros(batch * SL, dtype=torch.int64, device="cuda")
 from qpmpc_amd import _capi
-flags = _capi.OPT_ONE_PER_WAVE if (len(sys.argv) > 2 and sys.argv[2] == "w64") else 0
+flags = _capi.OPT_ONE_PER_WAVE if (len(sys.argv) > 2 and sys.argv[2] == "w64") else (_capi.OPT_SEED_VIOLATED if (len(sys.argv) > 2 and sys.argv[2] == "seed") else 0)
 run = PreparedSolve(bp, probe=buf, flags=flags)
 for _ in range(3): run.launch()
 torch.cuda.synchronize()
@@ -31,3 +31,6 @@ if not one:
 print("  iterations: max", int(it.max().item()), " 99%", torch.quantile(it, 0.99).item(), " 90%", torch.quantile(it, 0.9).item())
 pm = torch.maximum(it[0::2], it[1::2]) if not one else it
 print("  per-wavefront max(iterations of the pair): mean", pm.mean().item(), "max", pm.max().item())
+if not one:
+    rt = t[:, 12:14]
+    print(f"  real time (100 MHz): first start -> last end {(rt[:,0].max()-rt[:,1].min()).item()/100:.2f} us ; wavefront mean {(rt[:,0]-rt[:,1]).mean().item()/100:.2f} us max {(rt[:,0]-rt[:,1]).max().item()/100:.2f} us ; start spread {(rt[:,1].max()-rt[:,1].min()).item()/100:.2f} us")
