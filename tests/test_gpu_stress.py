@@ -1,0 +1,60 @@
+"""GPU tests (-m gpu): the developer stress campaigns (tools/stress_*.py) at fixed seeds, so that the round-end GPU tier
+covers the DISPATCH SPACE -- random shapes over every kernel's envelope, a quarter of the small problems with rows made
+inconsistent -- and not only the hand-picked shapes of the other test files. Each campaign compares the HIP path through
+the C ABI with the float64 C oracle (and, where the tool does, with the other formulations of the same solver):
+statuses must agree and plans must match to 1e-7 relative (float64; the reference contract is 1e-6) / 1e-3
+(float32). The reference has no such test -- its solver is third party (qpmpc/solve_mpc.py:43) --;
+the families are the ones the round-2/3 campaigns (profiles/r03_stress_summary.txt) ran by hand.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _campaign(tool, args, seed, extra_env=None):
+    env = dict(os.environ, STRESS_SEED=str(seed), **(extra_env or {}))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), *map(str, args)], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = [line for line in out.stdout.splitlines() if line.startswith("worst rel diff")]
+    assert last, out.stdout[-2000:]
+    m = re.match(r"worst rel diff ([0-9.eE+-]+) rounds flagged (\d+)", last[-1])
+    assert m, last[-1]
+    flagged = [line for line in out.stdout.splitlines() if "<-- CHECK" in line]
+    return float(m.group(1)), int(m.group(2)), flagged
+
+
+@pytest.mark.parametrize("tool,args,seed,bound", [
+    ("stress_pair.py", (24, 128), 3, 1e-7),             # n <= 16, m <= 32: pair / one-per-wavefront / workgroup kernels vs the oracle
+    ("stress_dense.py", (24, 48), 41, 1e-7),            # default dispatch, float64, n up to ~190
+    ("stress_stagewise.py", (20, 64), 2, 1e-6),         # wide stage-wise kernel vs the condensed path
+    ("stress_stagewise.py", (20, 64, "narrow"), 3, 1e-6),  # narrow stage-wise kernel (nx <= 4, nu <= 2)
+    ("stress_f32.py", (24, 64), 41, 1e-3),              # float32 through the default dispatch vs the float64 oracle
+    ("stress_f32.py", (24, 64), 46, 1e-3),
+])
+def test_stress_campaign(tool, args, seed, bound):
+    worst, nflag, flagged = _campaign(tool, args, seed)
+    assert nflag == 0, "\n".join(flagged)
+    assert worst <= bound, (tool, seed, worst)
+
+
+def test_stress_campaign_inconsistent_rows():
+    """Rows made inconsistent with their bounds (infeasible and borderline problems): statuses must follow the oracle's.
+    (On a few solvable-but-degenerate problems of this family ALL formulations, oracle included, only agree to 1e-3 in u --
+    DESIGN section 5 --, so the plans are not compared here beyond the tool's own report.)"""
+    env = dict(os.environ, STRESS_SEED="5", STRESS_INCONSISTENT="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_dense.py"), "16", "48"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [line for line in out.stdout.splitlines() if line.startswith("nx=")]
+    assert len(rows) == 16
+    for line in rows:
+        agreement = float(re.search(r"agreement ([0-9.]+)", line).group(1))
+        assert agreement == 1.0, line
