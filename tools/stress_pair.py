@@ -41,7 +41,7 @@ def run(rounds, batch, seed=4242, verbose=True):
         if mode == 1 and rng.random() < 0.5:  # state rows only
             w["D"] = None
         bp = W.to_batch_problem(w)
-        plan = solve_mpc_batch(bp)
+        plan = solve_mpc_batch(bp, flags=_capi.OPT_SEED_VIOLATED if os.environ.get("STRESS_SEEDED") else 0)  # (STRESS_SEEDED: the seeded start)
         one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
         lds = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
         torch.cuda.synchronize()
