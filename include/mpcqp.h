@@ -35,7 +35,12 @@ extern "C" {
 
 #define MPCQP_ABI_VERSION 8
 
-/* element type of every floating-point buffer of a call */
+/* element type of every floating-point buffer of a call. It is the STORAGE type: mpcqp_build_solve_batch computes
+ * MPCQP_F32 problems of at most 160 variables (and every float32 problem only the general stage-wise kernel serves) in
+ * float64 on copies of the operands converted into the workspace -- the float32 condensed kernels square the
+ * conditioning into P and returned plans 2e-2 from the float64 ones as solved on ill-conditioned problems;
+ * larger float32 problems (BASELINE config 5) run the float32 stage-wise kernel, whose acceptance test is 16 tol (1 + |e|)
+ * on the active rows. Contract either way: |u - u_float64| <= 1e-3 max(1, |u|), or status != MPCQP_SOLVED. */
 #define MPCQP_F64 0
 #define MPCQP_F32 1
 
@@ -59,7 +64,10 @@ extern "C" {
 
 /* negative return codes */
 #define MPCQP_EINVAL (-1)    /* NULL/negative/inconsistent argument           */
-#define MPCQP_ETOOLARGE (-2) /* no kernel for these dimensions: does not fit a CU's LDS and nx > 16 or nu > 4 with n > 256 */
+#define MPCQP_ETOOLARGE (-2) /* no kernel for these dimensions: does not fit a CU's LDS and nx > 32 or nu > 8 with n > 256
+                                (ABI 8: systems with nx <= 32, nu <= 8 are served at any horizon -- the general stage-wise
+                                kernel, float64 arithmetic, takes what the MFMA stage-wise kernels (nx <= 16, nu <= 4) and
+                                the dense path (n <= 256) do not: qpmpc/solve_mpc.py:42-44 accepts any dimension) */
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
 #define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
 #define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */

@@ -491,8 +491,8 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
                     **opt_kw) -> BatchPlan:
     """Build and solve every problem of the batch in ONE fused launch
     (``mpcqp_build_solve_batch``; replaces solve_mpc.py:42-44 per problem). Any problem size is served: what does not
-    fit one CU's LDS goes to the stage-wise kernels (systems with nx <= 16, nu <= 4, any horizon) or, for wider systems
-    with n = N*nu <= 256, to the dense HBM-resident path.
+    fit one CU's LDS goes to the stage-wise kernels (systems with nx <= 16, nu <= 4, any horizon) or, for wider systems,
+    to the dense HBM-resident path (n = N*nu <= 256) and the general stage-wise kernel (nx <= 32, nu <= 8, any horizon).
 
     ``formulation="stagewise"`` asks for the uncondensed solver explicitly (``mpcqp_stagewise_solve_batch``:
     Riccati-based dual active set, O(N) memory and O(N) work per iteration); ``max_active`` bounds the active rows

@@ -330,7 +330,10 @@ bool promote_f32(const KernelArgs &ka, int dtype)
     // nx = 8, n = 40); float32 arithmetic is kept where it is what makes the size affordable.
     constexpr int kPromoteN = 160;
     if (use_stagew_auto(ka, MPCQP_F32)) return ka.n <= kPromoteN && use_stagew_auto(ka, MPCQP_F64);
-    if (!fits_on_chip(ka, true, true, MODE_FUSED, MPCQP_F32) && !use_mid(ka, MPCQP_F32)) return false;  // dense HBM-resident fallback
+    if (!fits_on_chip(ka, true, true, MODE_FUSED, MPCQP_F32) && !use_mid(ka, MPCQP_F32))
+        // the dense HBM-resident fallback stays in float32; what even that path cannot hold goes to the general stage-wise
+        // kernel, which is float64 only
+        return !(big_supported(ka) && ka.n <= 256) && stageg_supported(ka, MPCQP_F64);
     // ... and the float64 dispatch must have an on-chip / stage-wise kernel for it
     return pair_eligible(ka, MODE_FUSED, MPCQP_F64) || use_stage_auto(ka, MPCQP_F64) || use_stagew_auto(ka, MPCQP_F64) ||
            use_mid(ka, MPCQP_F64) || fits_on_chip(ka, true, true, MODE_FUSED, MPCQP_F64);
@@ -347,7 +350,7 @@ const char *mpcqp_error_string(int code)
     switch (code) {
     case 0: return "ok";
     case MPCQP_EINVAL: return "invalid argument";
-    case MPCQP_ETOOLARGE: return "no kernel for these dimensions (does not fit a CU's LDS; the stage-wise kernels serve nx <= 16, nu <= 4; the dense HBM-resident path n <= 256)";
+    case MPCQP_ETOOLARGE: return "no kernel for these dimensions (the stage-wise kernels serve nx <= 32, nu <= 8 at any horizon; the dense HBM-resident path any system with n <= 256)";
     case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
     case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
     case MPCQP_EWORKSPACE: return "workspace missing or too small (see mpcqp_workspace_bytes)";
@@ -394,6 +397,7 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
     // with both (bulkier operands need more LDS): report the LARGEST workspace any path the launch may take needs.
     size_t need = 0;
     bool served = false;  // the automatic dispatch (fl == 0, first) has a kernel for these dimensions
+    bool toolarge = false;
     for (int fl : kFlagVariants) {
         ka.opt_flags = fl;
         const bool maybe_mid = for_solve && problem_strides_unknown_mid(ka, dims->dtype);
@@ -418,10 +422,15 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
                 const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
                 if (big > v) v = big;
                 served = true;
+            } else if (for_solve && stageg_supported(ka, dims->dtype)) {
+                const size_t sg = stageg_ws_doubles(ka, stageg_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+                if (sg > v) v = sg;
+                served = true;
             } else if (!maybe_mid && fl == 0 && !served) {
                 // (only the automatic dispatch decides: an override combination that has no kernel for these
                 // dimensions is refused by the launch that carries it, not by the size query)
-                return MPCQP_ETOOLARGE;
+                if (!(for_solve && dims->dtype == MPCQP_F32)) return MPCQP_ETOOLARGE;
+                toolarge = true;  // (float32: unless the launch is one that is solved in float64, below)
             }
         }
         if (v > need) need = v;
@@ -440,9 +449,11 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
                 const int64_t per = N * (nx * nx + nx * nu + mk * nx + mk * nu + mk) + 2 * nx + N * nx + ka.n + ka.m;
                 const size_t v = (size_t)(per * 8 * batch + 10 * 256) + inner;  // (every segment starts 256-byte aligned)
                 if (v > need) need = v;
+                toolarge = false;
             }
         }
     }
+    if (toolarge) return MPCQP_ETOOLARGE;
     *bytes = need;
     return 0;
 }
@@ -650,7 +661,15 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
     // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the
     // general solver with its arrays in the workspace as well
-    if (!big_supported(ka) || ka.n > 256) return MPCQP_ETOOLARGE;
+    if (!big_supported(ka) || ka.n > 256) {
+        // wide systems on horizons the dense path cannot hold: the general stage-wise kernel (float64; float32 launches of
+        // these dimensions arrive here converted, promote_f32)
+        if (!stageg_supported(ka, dims->dtype) || ka.warm_state) return MPCQP_ETOOLARGE;
+        const int maxq = stageg_default_maxq(ka);
+        const size_t need = stageg_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+        if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+        return launch_stageg(ka, maxq, batch, workspace, st);
+    }
     const size_t esz = elem_size(dims->dtype), nb = (size_t)batch;
     const BigPlan b = big_plan(ka, dims->dtype, true, true);
     if (!workspace || workspace_bytes < b.total(true) * esz * nb) return MPCQP_EWORKSPACE;
@@ -692,8 +711,12 @@ int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_
     size_t a = 0, b = 0;
     if (stage_supported(ka, dims->dtype)) a = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
     if (stagew_supported(ka, dims->dtype)) b = stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+    if (!stage_supported(ka, dims->dtype) && !stagew_supported(ka, dims->dtype)) {
+        if (!stageg_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+        *bytes = stageg_ws_doubles(ka, max_active > 0 ? max_active : stageg_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+        return 0;
+    }
     if (!a && !b && batch > 0) return MPCQP_EUNSUPPORTED;
-    if (!stage_supported(ka, dims->dtype) && !stagew_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
     *bytes = a > b ? a : b;
     return 0;
 }
@@ -710,7 +733,18 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     KernelArgs ka;
     fill_args(ka, dims, problem);
     bool narrow = stage_supported(ka, dims->dtype);
-    if (!narrow && !stagew_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (!narrow && !stagew_supported(ka, dims->dtype)) {
+        if (!stageg_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;  // (float32: through mpcqp_build_solve_batch, which converts)
+        ka.U = U;
+        ka.lam = lam;
+        ka.status = status;
+        ka.iters = iters;
+        if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+        if (ka.warm_state) return MPCQP_EUNSUPPORTED;
+        const int mq = max_active > 0 ? max_active : stageg_default_maxq(ka);
+        if (!workspace || workspace_bytes < stageg_ws_doubles(ka, mq) * sizeof(double) * (size_t)batch) return MPCQP_EWORKSPACE;
+        return launch_stageg(ka, mq, batch, workspace, (hipStream_t)stream);
+    }
     if (opts && (opts->flags & MPCQP_OPT_STAGE_WIDE) && stagew_supported(ka, dims->dtype)) narrow = false;
     ka.U = U;
     ka.lam = lam;

@@ -226,6 +226,12 @@ int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStr
 bool stagew_supported(const KernelArgs &ka, int dtype);
 size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype);
 int launch_stagew(const KernelArgs &ka, int dtype, int maxq, int64_t batch, void *ws, hipStream_t st);
+// ... and for every other system (mpcqp_stageg.hip): nx <= 32, nu <= 8, float64, any horizon; one workgroup per problem, all
+// arrays in the workspace -- a general fallback, not a tuned path
+bool stageg_supported(const KernelArgs &ka, int dtype);
+int stageg_default_maxq(const KernelArgs &ka);
+size_t stageg_ws_doubles(const KernelArgs &ka, int maxq);
+int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st);
 // small-problem kernel (mpcqp_pair.hip): two problems per wavefront, fused build+solve
 bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
 constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids

@@ -1,0 +1,647 @@
+// mpcqp_stageg.hip -- gfx950: stage-wise (uncondensed) solve of the MPC QP for WIDE systems, any horizon.
+//
+// Replaces the same reference code as the other solver units -- MPCQP.__init__ + qpsolvers.solve_problem, i.e. the whole
+// of solve_mpc (qpmpc/solve_mpc.py:42-44), which accepts ANY (nx, nu, N) -- for the dimensions no other kernel of this
+// library serves: nx > 16 or nu > 4 (the wide stage-wise kernel's MFMA tiles stop there) together with n = N nu > 256
+// (the dense HBM-resident path stops there). Until round 4 such a problem -- a 20-state, 6-input model at N = 64 -- came
+// back MPCQP_ETOOLARGE.
+//
+// Same method as mpcqp_stage.hip / mpcqp_stagew.hip (oracle/stagewise_np.py restates it): Riccati factor of the LQR problem
+// whose Hessian is the condensed P (once per problem), v -> P^-1 v as one backward and one forward sweep, a row of G applied
+// to a vector as a read of that vector's trajectory, Goldfarb-Idnani's dual active set in the metric of P with
+// W = (G_A P^-1 G_A')^-1 bordered / deflated by rank-one updates; per active row the slot keeps V_a = P^-1 g_a' (inputs) and
+// h_a = G V_a (all m rows), so an iteration is one sweep pair plus AXPYs over m-long arrays.
+//
+// Written for GENERALITY, not speed: float64 only (float32 launches are converted, mpcqp_capi.hip), one workgroup of 256
+// threads per problem, every per-problem array in a caller-owned HBM workspace, the per-step matrices of the recursion
+// (at most 32 x 32) in LDS, one barrier between the dependent pieces of a step. nx <= 32, nu <= 8, any N, any mk.
+// What bounds it: the 2 N serial steps of a sweep pair at ~3 barriers each (latency), then the m-row passes (HBM).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+namespace stageg {
+
+constexpr int NXM = 32, NUM = 8, BS = 256;
+
+struct Ws {  // per-problem workspace carve in doubles (host-computed, passed by value)
+    int64_t Acl, Kt, Si, U0, ff, s0, s, invn, thr, V, H, W, lam, cv, rv, ints, total;
+    int maxq;
+};
+
+inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
+{
+    Ws w{};
+    int64_t o = 0;
+    auto take = [&](int64_t c) {
+        const int64_t at = o;
+        o += (c + 1) & ~(int64_t)1;
+        return at;
+    };
+    const int64_t n = (int64_t)N * nu, m = (int64_t)N * mk;
+    w.Acl = take((int64_t)N * nx * nx);
+    w.Kt = take((int64_t)N * nu * nx);
+    w.Si = take((int64_t)N * nu * nu);
+    w.U0 = take(n);
+    w.ff = take(n);
+    w.s0 = take(m);
+    w.s = take(m);
+    w.invn = take(m);
+    w.thr = take(m);
+    w.V = take((int64_t)(maxq + 1) * n);
+    w.H = take((int64_t)(maxq + 1) * m);
+    w.W = take((int64_t)maxq * maxq);
+    w.lam = take(maxq + 1);
+    w.cv = take(maxq + 1);
+    w.rv = take(maxq + 1);
+    w.ints = take((m + 2 * (maxq + 2)) / 2 + 2);  // int32: pos[m], actrow[maxq + 1], phys[maxq + 1]
+    w.total = (o + 15) & ~(int64_t)15;
+    w.maxq = maxq;
+    return w;
+}
+
+__device__ __forceinline__ void bsync() { __syncthreads(); }
+
+// block-wide arg-min of (v, i): ties -> lowest index; every thread gets the result
+__device__ __forceinline__ void block_argmin(double &v, int &i, double *redv, int *redi, int tid)
+{
+    wave_argmin_dpp(v, i);
+    if ((tid & 63) == 0) {
+        redv[tid >> 6] = v;
+        redi[tid >> 6] = i;
+    }
+    bsync();
+    v = redv[0];
+    i = redi[0];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) {
+        const double ov = redv[w];
+        const int oi = redi[w];
+        if (ov < v || (ov == v && oi < i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+    bsync();
+}
+__device__ __forceinline__ double block_sum(double v, double *redv, int tid)
+{
+    v = wave_sum_dpp(v);
+    if ((tid & 63) == 0) redv[tid >> 6] = v;
+    bsync();
+    double s = redv[0];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) s += redv[w];
+    bsync();
+    return s;
+}
+__device__ __forceinline__ bool block_any(bool p, int *redi, int tid)
+{
+    const bool w = __ballot(p) != 0ull;
+    if ((tid & 63) == 0) redi[tid >> 6] = w;
+    bsync();
+    bool r = false;
+#pragma unroll
+    for (int k = 0; k < BS / 64; ++k) r = r || redi[k];
+    bsync();
+    return r;
+}
+
+}  // namespace stageg
+
+using namespace stageg;
+
+__global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase)
+{
+    using T = double;
+    __shared__ T Pm[NXM * NXM], PAm[NXM * NXM], Tm[NXM * NXM], Am[NXM * NXM], PBm[NXM * NUM], Bm[NXM * NUM], G1[NUM * NXM], Km[NUM * NXM];
+    __shared__ T Sm[NUM * NUM], Sim[NUM * NUM], pv[NXM], pn[NXM], xv[NXM], xn[NXM], tv[NUM], uv[NUM], redv[BS / 64];
+    __shared__ int redi[BS / 64], flag;
+    const int tid = threadIdx.x;
+    const int64_t prob = blockIdx.x;
+    const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
+    const int n = N * nu, M = N * mk;
+    const T INF = HUGE_VAL;
+    T *ws = wsbase + prob * wl.total;
+    T *Acl = ws + wl.Acl, *Kt = ws + wl.Kt, *Si = ws + wl.Si, *U0 = ws + wl.U0, *ffv = ws + wl.ff, *s0 = ws + wl.s0, *sl = ws + wl.s;
+    T *invn = ws + wl.invn, *thr = ws + wl.thr, *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W, *lamv = ws + wl.lam;
+    T *cv = ws + wl.cv, *rv = ws + wl.rv;
+    int *pos = (int *)(ws + wl.ints), *actrow = pos + M, *phys = actrow + maxq + 1;
+    const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
+    const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
+    const T *gC = ka.C.ptr ? (const T *)ka.C.ptr + prob * ka.C.batch_stride : nullptr;
+    const T *gD = ka.D.ptr ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+    const T *ge = (const T *)ka.e.ptr + prob * ka.e.batch_stride;
+    const T *gx0 = (const T *)ka.x0.ptr + prob * ka.x0.batch_stride;
+    const T *ggoal = ka.goal.ptr ? (const T *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+    const T *gtgt = ka.targets.ptr ? (const T *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+    const int64_t sA = ka.A.step_stride, sB = ka.B.step_stride, sC = ka.C.step_stride, sD = ka.D.step_stride, sE = ka.e.step_stride;
+    const bool stageP = ka.flags & MPCQP_P_STAGE, termP = ka.flags & MPCQP_P_TERMINAL;
+    const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
+    const T wu = ka.wu, wx = stageP ? ka.wx : 0.0, wt = termP ? ka.wt : 0.0, tol = ka.tol;
+
+    // ================================================================= factor: Riccati recursion (oracle/stagewise_np.py::Riccati)
+    for (int i = tid; i < nx * nx; i += BS) Pm[i] = (i / nx == i % nx) ? wt : 0.0;
+    if (tid == 0) flag = 0;
+    bsync();
+    for (int k = N - 1; k >= 0; --k) {
+        const T *A = gA + k * sA, *B = gB + k * sB;
+        for (int i = tid; i < nx * nx; i += BS) Am[i] = A[i];
+        for (int i = tid; i < nx * nu; i += BS) Bm[i] = B[i];
+        bsync();
+        for (int e = tid; e < nx * nx; e += BS) {  // PA = P A
+            const int i = e / nx, j = e - i * nx;
+            T acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += Pm[i * nx + l] * Am[l * nx + j];
+            PAm[e] = acc;
+        }
+        for (int e = tid; e < nx * nu; e += BS) {  // PB = P B
+            const int i = e / nu, j = e - i * nu;
+            T acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += Pm[i * nx + l] * Bm[l * nu + j];
+            PBm[e] = acc;
+        }
+        bsync();
+        for (int e = tid; e < nu * nu; e += BS) {  // S = w_u I + B' P B
+            const int a = e / nu, b = e - a * nu;
+            T acc = (a == b) ? wu : 0.0;
+            for (int l = 0; l < nx; ++l) acc += Bm[l * nu + a] * PBm[l * nu + b];
+            Sm[e] = acc;
+        }
+        for (int e = tid; e < nu * nx; e += BS) {  // G1 = B' P A
+            const int a = e / nx, j = e - a * nx;
+            T acc = 0.0;
+            for (int l = 0; l < nx; ++l) acc += Bm[l * nu + a] * PAm[l * nx + j];
+            G1[e] = acc;
+        }
+        bsync();
+        if (tid == 0) {  // S^-1 by Gauss-Jordan (nu <= 8; S is a Schur complement of the condensed Hessian: pivots must be positive)
+            T a[NUM][2 * NUM];
+            for (int r = 0; r < nu; ++r)
+                for (int c = 0; c < nu; ++c) {
+                    a[r][c] = Sm[r * nu + c];
+                    a[r][nu + c] = (r == c) ? 1.0 : 0.0;
+                }
+            bool bad = false;
+            for (int c = 0; c < nu; ++c) {
+                const T piv = a[c][c];
+                if (!(piv > 0.0)) {
+                    bad = true;
+                    break;
+                }
+                const T ip = 1.0 / piv;
+                for (int j = 0; j < 2 * nu; ++j) a[c][j] *= ip;
+                for (int r = 0; r < nu; ++r)
+                    if (r != c) {
+                        const T f = a[r][c];
+                        for (int j = 0; j < 2 * nu; ++j) a[r][j] -= f * a[c][j];
+                    }
+            }
+            if (bad) flag = 1;
+            for (int r = 0; r < nu; ++r)
+                for (int c = 0; c < nu; ++c) Sim[r * nu + c] = bad ? 0.0 : a[r][nu + c];
+        }
+        bsync();
+        for (int e = tid; e < nu * nu; e += BS) Si[(int64_t)k * nu * nu + e] = Sim[e];
+        for (int e = tid; e < nu * nx; e += BS) {  // K = S^-1 B' P A
+            const int a = e / nx, j = e - a * nx;
+            T acc = 0.0;
+            for (int b = 0; b < nu; ++b) acc += Sim[a * nu + b] * G1[b * nx + j];
+            Km[e] = acc;
+            Kt[(int64_t)k * nu * nx + e] = acc;
+        }
+        bsync();
+        for (int e = tid; e < nx * nx; e += BS) {  // Acl = A - B K ; T = P Acl = PA - PB K
+            const int i = e / nx, j = e - i * nx;
+            T a1 = Am[e], a2 = PAm[e];
+            for (int a = 0; a < nu; ++a) {
+                a1 -= Bm[i * nu + a] * Km[a * nx + j];
+                a2 -= PBm[i * nu + a] * Km[a * nx + j];
+            }
+            Acl[(int64_t)k * nx * nx + e] = a1;
+            Tm[e] = a2;
+        }
+        bsync();
+        for (int e = tid; e < nx * nx; e += BS) {  // Pn = Q_k + A' P Acl (x_0 is data: Q_0 = 0)
+            const int i = e / nx, j = e - i * nx;
+            T acc = (i == j && k >= 1) ? wx : 0.0;
+            for (int l = 0; l < nx; ++l) acc += Am[l * nx + i] * Tm[l * nx + j];
+            PAm[e] = acc;
+        }
+        bsync();
+        for (int e = tid; e < nx * nx; e += BS) {
+            const int i = e / nx, j = e - i * nx;
+            Pm[e] = 0.5 * (PAm[e] + PAm[j * nx + i]);
+        }
+        bsync();
+    }
+    const bool notpd = flag != 0;
+
+    // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
+    //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
+    auto sweep = [&](int kp, int rp, bool tracking, const T *xstart, T *Vout, T *Hout) {
+        for (int i = tid; i < nx; i += BS) pv[i] = (tracking && termQ) ? -ka.wt * ggoal[i] : 0.0;
+        const int ktop = tracking ? N - 1 : kp;
+        for (int i = tid; i < n; i += BS)
+            if (i >= (ktop + 1) * nu) ffv[i] = 0.0;
+        bsync();
+        for (int k = ktop; k >= 0; --k) {
+            const T *B = gB + k * sB, *Ak = Acl + (int64_t)k * nx * nx, *Kk = Kt + (int64_t)k * nu * nx, *Sk = Si + (int64_t)k * nu * nu;
+            const bool here = !tracking && k == kp;
+            const T *Dr = (here && gD) ? gD + k * sD + rp * nu : nullptr;
+            const T *Cr = (here && gC) ? gC + k * sC + rp * nx : nullptr;
+            if (tid < nu) {  // t = B' p + rl  (rl = -D[kp, rp] at the row's stage)
+                T acc = Dr ? -Dr[tid] : 0.0;
+                for (int l = 0; l < nx; ++l) acc += B[l * nu + tid] * pv[l];
+                tv[tid] = acc;
+            }
+            if (tid >= 64 && tid < 64 + nx) {  // p_k = ql + Acl' p - K' rl
+                const int i = tid - 64;
+                T acc = Cr ? -Cr[i] : 0.0;
+                if (tracking && stageQ && k >= 1) acc -= ka.wx * gtgt[(int64_t)k * nx + i];
+                for (int l = 0; l < nx; ++l) acc += Ak[l * nx + i] * pv[l];
+                if (Dr)
+                    for (int a = 0; a < nu; ++a) acc += Kk[a * nx + i] * Dr[a];
+                pn[i] = acc;
+            }
+            bsync();
+            if (tid < nu) {  // ff = -S^-1 t
+                T acc = 0.0;
+                for (int b = 0; b < nu; ++b) acc -= Sk[tid * nu + b] * tv[b];
+                ffv[k * nu + tid] = acc;
+            }
+            if (tid >= 64 && tid < 64 + nx) pv[tid - 64] = pn[tid - 64];
+            bsync();
+        }
+        for (int i = tid; i < nx; i += BS) xv[i] = xstart ? xstart[i] : 0.0;
+        bsync();
+        for (int k = 0; k < N; ++k) {
+            const T *A = gA + k * sA, *B = gB + k * sB, *Kk = Kt + (int64_t)k * nu * nx;
+            if (tid < nu) {  // u = -K x + ff
+                T acc = ffv[k * nu + tid];
+                for (int i = 0; i < nx; ++i) acc -= Kk[tid * nx + i] * xv[i];
+                uv[tid] = acc;
+                Vout[k * nu + tid] = acc;
+            }
+            bsync();
+            for (int r = tid; r < mk; r += BS) {  // rows of G at this stage
+                T acc = 0.0;
+                if (gC)
+                    for (int i = 0; i < nx; ++i) acc += gC[k * sC + r * nx + i] * xv[i];
+                if (gD)
+                    for (int a = 0; a < nu; ++a) acc += gD[k * sD + r * nu + a] * uv[a];
+                Hout[k * mk + r] = acc;
+            }
+            if (tid >= 64 && tid < 64 + nx) {  // x+ = A x + B u
+                const int i = tid - 64;
+                T acc = 0.0;
+                for (int l = 0; l < nx; ++l) acc += A[i * nx + l] * xv[l];
+                for (int a = 0; a < nu; ++a) acc += B[i * nu + a] * uv[a];
+                xn[i] = acc;
+            }
+            bsync();
+            if (tid < nx) xv[tid] = xn[tid];
+            bsync();
+        }
+    };
+
+    int status = notpd ? (int)MPCQP_NOT_PD : (int)MPCQP_MAX_ITER, iters = 0, nq = 0;
+    // ---- W = (G_A P^-1 G_A')^-1 FROM SCRATCH: the Gram matrix of the active rows is read off the slots (its entry (a, b) is
+    //      row a's entry of h_b = G V_b) and inverted in place by Gauss-Jordan (symmetric positive definite: no pivoting).
+    //      W is otherwise only ever bordered / deflated by rank-one updates, and after several hundred of them its error
+    //      makes |z|^2 = g_p V_p - c' W c of a perfectly addable row come out negative -- the problem would be reported
+    //      infeasible (the NumPy restatement, which has no refresh, does that after 948 iterations on one of the tests'
+    //      problems). Returns false when a pivot is not positive (the active rows have become dependent).
+    auto refresh_W = [&]() -> bool {
+        for (int e = tid; e < nq * nq; e += BS) {
+            const int a = e / nq, b = e - a * nq;
+            Wm[(int64_t)a * maxq + b] = Hs[(int64_t)phys[b] * M + actrow[a]];
+        }
+        bsync();
+        bool good = true;
+        for (int c = 0; c < nq; ++c) {
+            const T piv = Wm[(int64_t)c * maxq + c];
+            if (!(piv > 0.0)) {
+                good = false;
+                break;
+            }
+            for (int a = tid; a < nq; a += BS) {
+                cv[a] = Wm[(int64_t)a * maxq + c];  // column c
+                rv[a] = Wm[(int64_t)c * maxq + a];  // row c
+            }
+            bsync();
+            const T ip = 1.0 / piv;
+            for (int e = tid; e < nq * nq; e += BS) {
+                const int a = e / nq, b = e - a * nq;
+                T v;
+                if (a == c)
+                    v = b == c ? ip : rv[b] * ip;
+                else if (b == c)
+                    v = -cv[a] * ip;
+                else
+                    v = Wm[(int64_t)a * maxq + b] - cv[a] * rv[b] * ip;
+                Wm[(int64_t)a * maxq + b] = v;
+            }
+            bsync();
+        }
+        return good;
+    };
+    // ... and with it the multipliers lam = -W s0_A and every slack s = s0 + sum_a lam_a h_a (between two selections, where
+    // (u, A) is an S-pair: the active rows sit on their bounds)
+    auto refresh_state = [&]() -> bool {
+        if (!refresh_W()) return false;
+        for (int a = tid; a < nq; a += BS) {
+            T acc = 0.0;
+            for (int b = 0; b < nq; ++b) acc -= Wm[(int64_t)a * maxq + b] * s0[actrow[b]];
+            rv[a] = acc < 0.0 ? 0.0 : acc;
+        }
+        bsync();
+        for (int a = tid; a < nq; a += BS) lamv[a] = rv[a];
+        bsync();
+        for (int i = tid; i < M; i += BS) {
+            T fr = s0[i];
+            for (int a = 0; a < nq; ++a) fr += lamv[a] * Hs[(int64_t)phys[a] * M + i];
+            sl[i] = pos[i] >= 0 ? 0.0 : fr;
+        }
+        bsync();
+        return true;
+    };
+    if (!notpd) {
+        // unconstrained minimiser and its slacks (tracking terms as linear costs: q of mpc_qp.py:129-149)
+        sweep(0, 0, true, gx0, U0, sl);
+        for (int i = tid; i < M; i += BS) {
+            const int k = i / mk, r = i - k * mk;
+            const T ev = ge[k * sE + r];
+            const T sv = ev - sl[i];
+            s0[i] = sv;
+            sl[i] = sv;
+            thr[i] = tol + tol * fabs(ev);
+            T nn = 0.0;
+            if (gC)
+                for (int j = 0; j < nx; ++j) nn += gC[k * sC + r * nx + j] * gC[k * sC + r * nx + j];
+            if (gD)
+                for (int a = 0; a < nu; ++a) nn += gD[k * sD + r * nu + a] * gD[k * sD + r * nu + a];
+            invn[i] = nn > 0.0 ? rsqrt(nn) : 1.0;
+            pos[i] = ev < 1e29 ? -1 : -2;  // -2: padded row, never selectable
+        }
+        for (int a = tid; a <= maxq; a += BS) phys[a] = a;
+        bsync();
+        const int max_iter = ka.max_iter;
+        bool fail = false, slotsfull = false;
+        int fails = 0, next_refresh = 64, rescues = 0;
+        for (;;) {
+            // ---- active-set loop (oracle/stagewise_np.py::solve_stagewise)
+            for (;;) {
+                if (nq > 0 && iters >= next_refresh) {  // every 64 iterations: W, lam and the slacks from scratch
+                    next_refresh = iters + 64;
+                    refresh_state();  // (a failed refresh leaves W as it was rebuilt so far: the verification below decides)
+                }
+                T best = INF;
+                int bi = 0x7fffffff;
+                for (int i = tid; i < M; i += BS) {
+                    const T sv = sl[i];
+                    if (pos[i] == -1 && sv < -thr[i]) {
+                        const T sc = sv * invn[i];
+                        if (sc < best || (sc == best && i < bi)) {
+                            best = sc;
+                            bi = i;
+                        }
+                    }
+                }
+                block_argmin(best, bi, redv, redi, tid);
+                if (!(best < INF)) {
+                    status = MPCQP_SOLVED;
+                    break;
+                }
+                const int rowp = bi, kp = rowp / mk, rp = rowp - kp * mk;
+                T up = 0.0;
+                bool added = false, stop = false, rescued = false;
+                while (!added) {
+                    if (iters >= max_iter) {
+                        status = MPCQP_MAX_ITER;
+                        stop = fail = true;
+                        break;
+                    }
+                    ++iters;
+                    T *Vp = Vs + (int64_t)phys[nq] * n, *Hp = Hs + (int64_t)phys[nq] * M;
+                    sweep(kp, rp, false, nullptr, Vp, Hp);
+                    // V_p = -P^-1 (-g_p') ... the sweep solved with ql = -C, rl = -D: its result IS P^-1 g_p'
+                    for (int a = tid; a < nq; a += BS) cv[a] = Hp[actrow[a]];
+                    bsync();
+                    const T dpp = Hp[rowp];
+                    for (int a = tid; a < nq; a += BS) {
+                        T acc = 0.0;
+                        for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * cv[b];
+                        rv[a] = acc;
+                    }
+                    bsync();
+                    T part = 0.0;
+                    for (int a = tid; a < nq; a += BS) part += cv[a] * rv[a];
+                    const T cr = block_sum(part, redv, tid);
+                    const T d2 = dpp - cr;
+                    const bool can_move = nq < n && d2 > 1e-13 * dpp && d2 > 0.0;
+                    if (can_move && nq >= maxq) {  // the step would need one more slot than this launch holds
+                        slotsfull = stop = fail = true;
+                        break;
+                    }
+                    T t1 = INF;
+                    int l = 0x7fffffff;
+                    for (int a = tid; a < nq; a += BS) {
+                        const T ra = rv[a];
+                        if (ra > 0.0) {
+                            const T q = lamv[a] / ra;
+                            if (q < t1 || (q == t1 && a < l)) {
+                                t1 = q;
+                                l = a;
+                            }
+                        }
+                    }
+                    block_argmin(t1, l, redv, redi, tid);
+                    const T t2 = can_move ? -sl[rowp] / d2 : INF;
+                    const T t = t1 < t2 ? t1 : t2;
+                    if (!(t < INF)) {
+                        if (!rescued && nq > 0) {  // before the verdict: the same trip once more on a W rebuilt from scratch
+                            rescued = true;
+                            if (refresh_W()) {
+                                --iters;
+                                continue;
+                            }
+                        }
+                        if (rescues < 3 && nq > 0) {
+                            // ... and once more from a state rebuilt from scratch (W, multipliers, every slack): after a
+                            // thousand iterations the carried slacks can show a row violated by 1e-11 that sits ON its
+                            // bound and depends on the active rows -- there is no step for such a row, and no need for one
+                            ++rescues;
+                            if (refresh_state()) break;  // (select again)
+                        }
+                        status = MPCQP_INFEASIBLE;
+                        stop = fail = true;
+                        break;
+                    }
+                    // s -= t G z with z = -(V_p - sum_a r_a V_a)
+                    for (int i = tid; i < M; i += BS) {
+                        T gz = Hp[i];
+                        for (int a = 0; a < nq; ++a) gz -= rv[a] * Hs[(int64_t)phys[a] * M + i];
+                        sl[i] = pos[i] >= 0 ? 0.0 : sl[i] + t * gz;
+                    }
+                    for (int a = tid; a < nq; a += BS) {
+                        const T v = lamv[a] - t * rv[a];
+                        lamv[a] = v < 0.0 ? 0.0 : v;
+                    }
+                    up += t;
+                    bsync();
+                    if (t2 <= t1) {  // full step: p takes slot nq (its vectors are already there)
+                        const T id2 = 1.0 / d2;
+                        for (int e = tid; e < nq * nq; e += BS) {
+                            const int a = e / nq, b = e - a * nq;
+                            Wm[(int64_t)a * maxq + b] += rv[a] * rv[b] * id2;
+                        }
+                        for (int a = tid; a < nq; a += BS) {
+                            Wm[(int64_t)a * maxq + nq] = -rv[a] * id2;
+                            Wm[(int64_t)nq * maxq + a] = -rv[a] * id2;
+                        }
+                        if (tid == 0) {
+                            Wm[(int64_t)nq * maxq + nq] = id2;
+                            lamv[nq] = up;
+                            actrow[nq] = rowp;
+                            pos[rowp] = nq;
+                            sl[rowp] = 0.0;
+                        }
+                        ++nq;
+                        added = true;
+                        bsync();
+                    } else {  // partial step: slot l leaves; the last slot takes its place
+                        const T wll = Wm[(int64_t)l * maxq + l];
+                        for (int a = tid; a < nq; a += BS) cv[a] = Wm[(int64_t)a * maxq + l];
+                        bsync();
+                        const T iw = 1.0 / wll;
+                        for (int e = tid; e < nq * nq; e += BS) {
+                            const int a = e / nq, b = e - a * nq;
+                            Wm[(int64_t)a * maxq + b] -= cv[a] * cv[b] * iw;
+                        }
+                        bsync();
+                        const int last = nq - 1;
+                        // the leaving row's slack is no longer pinned: it is zero now and moves with the next steps
+                        if (l != last) {
+                            for (int a = tid; a < nq; a += BS) {  // column `last` -> column l, then row
+                                Wm[(int64_t)a * maxq + l] = Wm[(int64_t)a * maxq + last];
+                            }
+                            bsync();
+                            for (int b = tid; b < nq; b += BS) Wm[(int64_t)l * maxq + b] = Wm[(int64_t)last * maxq + b];
+                            bsync();
+                            if (tid == 0) Wm[(int64_t)l * maxq + l] = Wm[(int64_t)last * maxq + last];
+                        }
+                        bsync();
+                        if (tid == 0) {
+                            const int rl_ = actrow[l];
+                            pos[rl_] = -1;
+                            const int pl = phys[l];
+                            if (l != last) {
+                                phys[l] = phys[last];
+                                actrow[l] = actrow[last];
+                                lamv[l] = lamv[last];
+                                pos[actrow[l]] = l;
+                            }
+                            // the candidate's buffer follows the shrinking slot count
+                            phys[last] = phys[nq];
+                            phys[nq] = pl;
+                        }
+                        --nq;
+                        bsync();
+                    }
+                }
+                if (stop) break;
+            }
+            if (fail) break;
+            // ---- verification from scratch: s = s0 + sum_a lam_a h_a ; active rows on their bounds, inactive rows feasible
+            bool dirty = false, offa = false;
+            for (int pass = 0; pass < 2; ++pass) {
+                dirty = offa = false;
+                for (int a = tid; a < nq; a += BS) offa |= !(lamv[a] >= 0.0);
+                for (int i = tid; i < M; i += BS) {
+                    T fr = s0[i];
+                    for (int a = 0; a < nq; ++a) fr += lamv[a] * Hs[(int64_t)phys[a] * M + i];
+                    const bool act = pos[i] >= 0;
+                    const T fac = pass == 0 ? 1000.0 : (1000.0 > 1e-6 / tol ? 1000.0 : 1e-6 / tol);
+                    if (act)
+                        offa |= !(fabs(fr) <= fac * thr[i]);
+                    else if (pos[i] == -1 && !(fr >= -4.0 * thr[i]))
+                        dirty = true;
+                    sl[i] = act ? 0.0 : fr;
+                    if (act) cv[pos[i]] = fr;
+                }
+                offa = block_any(offa, redi, tid);
+                if (!offa) break;
+                if (pass == 1) {
+                    fail = true;
+                    break;
+                }
+                for (int a = tid; a < nq; a += BS) {  // lam -= W rho_A
+                    T acc = 0.0;
+                    for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * cv[b];
+                    rv[a] = acc;
+                }
+                bsync();
+                for (int a = tid; a < nq; a += BS) {
+                    const T v = lamv[a] - rv[a];
+                    lamv[a] = v < 0.0 ? 0.0 : v;
+                }
+                bsync();
+            }
+            if (fail) {
+                status = MPCQP_MAX_ITER;
+                break;
+            }
+            dirty = block_any(dirty, redi, tid);
+            if (!dirty) {
+                status = MPCQP_SOLVED;
+                break;
+            }
+            if (++fails >= 4) {
+                status = MPCQP_MAX_ITER;
+                break;
+            }
+        }
+        if (slotsfull) status = MPCQP_SLOTS_FULL;
+    }
+    const bool ok = status == MPCQP_SOLVED;
+    T *ou = (T *)ka.U + prob * (int64_t)n;
+    for (int i = tid; i < n; i += BS) {
+        T u = ok ? U0[i] : 0.0;
+        for (int a = 0; ok && a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * n + i];
+        ou[i] = u;
+    }
+    if (ka.lam) {
+        T *ol = (T *)ka.lam + prob * (int64_t)M;
+        for (int i = tid; i < M; i += BS) ol[i] = (ok && !notpd && pos[i] >= 0) ? lamv[pos[i]] : 0.0;
+    }
+    if (tid == 0) {
+        if (ka.status) ka.status[prob] = status;
+        if (ka.iters) ka.iters[prob] = iters;
+    }
+}
+
+// ------------------------------------------------------------ host side
+bool stageg_supported(const KernelArgs &ka, int dtype)
+{
+    return dtype == MPCQP_F64 && ka.nx >= 1 && ka.nx <= NXM && ka.nu >= 1 && ka.nu <= NUM && ka.m >= 1;
+}
+int stageg_default_maxq(const KernelArgs &ka)
+{
+    int q = ka.n < ka.m ? ka.n : ka.m;
+    return q < 256 ? q : 256;
+}
+size_t stageg_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
+
+int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
+{
+    const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
+    hipLaunchKernelGGL(mpcqp_stageg_kernel, dim3((unsigned)batch), dim3(BS), 0, st, ka, wl, (double *)ws);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mpcqp

@@ -44,8 +44,10 @@ def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) 
     that the stage-wise kernels serve systems with ``nx <= 16``, ``nu <= 4`` for any horizon (n = N*nu of 1024 or
     4096 included; a problem that wants more rows active at once than the kernel's slots hold is solved again
     with more slots), and wider systems go to the dense HBM-resident path up to ``n = N*nu <= 256`` (a slow
-    fallback: DESIGN.md 3.3). Only ``nx > 16`` or ``nu > 4`` together with ``n > 256`` has no kernel
-    (``MPCQP_ETOOLARGE`` -> ``BackendError`` naming the envelope).
+    fallback: DESIGN.md 3.3) and beyond that to the general stage-wise kernel (``nx <= 32``, ``nu <= 8``, any horizon;
+    float64 arithmetic, slower still: one workgroup per problem, everything in HBM). Only ``nx > 32`` or ``nu > 8``
+    together with ``n > 256`` has no kernel (``MPCQP_ETOOLARGE`` -> ``BackendError`` naming the envelope).
+    float32 problems with at most 160 variables are solved in float64 on converted operands (mpcqp_capi.hip).
 
     Returns:
         A ``Plan``; empty (``is_empty``) when no solution was found.

@@ -473,3 +473,47 @@ def test_small_batch_instantiation_gives_the_same_iterates_as_the_default_one():
     assert torch.equal(big.iters[:1024], small.iters)
     scale = big.U[:1024].abs().max(dim=1, keepdim=True).values.clamp(min=1.0)
     assert float(((big.U[:1024] - small.U).abs() / scale).max()) <= 1e-4
+
+
+# ---------------------------------------------------------------- wide systems (mpcqp_stageg.hip)
+@pytest.mark.parametrize("nx,nu,N,mk,dtype,tol", [
+    (24, 6, 64, 4, "f64", 1e-7), (32, 8, 40, 6, "f64", 1e-7), (24, 6, 64, 4, "f32", 1e-3), (32, 8, 40, 6, "f32", 1e-3),
+    (20, 6, 16, 8, "f64", 1e-7),   # n = 96 <= 256: the dense HBM-resident path keeps it
+    (17, 1, 260, 2, "f64", 1e-7),  # one input, long horizon
+])
+def test_wide_systems_any_horizon_against_the_oracle(nx, nu, N, mk, dtype, tol):
+    """solve_mpc accepts any (nx, nu, N) upstream (qpmpc/solve_mpc.py:42-44, qpmpc/mpc_qp.py:39-122). Systems wider than the
+    MFMA stage-wise kernel's tiles (nx > 16 or nu > 4) on horizons the dense path cannot hold (n = N nu > 256) used to come
+    back MPCQP_ETOOLARGE; the general stage-wise kernel serves them (nx <= 32, nu <= 8, float64 arithmetic; float32
+    launches are converted). Plans against the float64 C oracle through the default dispatch."""
+    import os
+    import sys
+
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd.workloads import to_batch_problem
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from stress_stagewise import random_ltv
+
+    rng = np.random.default_rng(1000 * nx + N)
+    w = random_ltv(rng, 8, nx, nu, N, mk, 3.0)
+    w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
+    td = torch.float32 if dtype == "f32" else torch.float64
+    bp = to_batch_problem(w, dtype=td)
+    plan = solve_mpc_batch(bp, return_multipliers=True)
+    torch.cuda.synchronize()
+    U, st = plan.U.double().cpu().numpy(), plan.status.cpu().numpy()
+    Uo, lamo, sto, _ = oracle.solve_workload(w)
+    assert np.array_equal(st == 0, sto == 0), (st, sto)
+    ok = sto == 0
+    assert ok.sum() >= 2
+    scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= tol
+    lam = plan.multipliers.double().cpu().numpy()
+    assert (lam >= 0).all()
+    if N * nu > 256 and dtype == "f64":
+        # the same kernel through the stage-wise entry point
+        again = solve_mpc_batch(bp, formulation="stagewise")
+        torch.cuda.synchronize()
+        assert np.array_equal(again.status.cpu().numpy(), st)
+        assert (np.abs(again.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-9
