@@ -322,6 +322,10 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
         out["overlap_2_streams"] = overlap
     if device == "cuda":
         out["roofline"] = _roofline(args, w, local_per_step, kernel_ms, out["mean_iters"])
+        if args.config == 5:
+            # north_star's "fraction of the dense-GEMM roofline": the benched path forms no Gram, so the MFMA Gram kernel of
+            # the dense path (qpmpc/mpc_qp.py:99-105) is timed by itself, in this run, on this workload's problems
+            out["roofline"]["gram_mfma"] = _gram_mfma_block(w)
         out["accuracy"] = _accuracy(args, w, run)
         if not args.no_extras and world == 1 and args.config == 2:
             try:
@@ -427,8 +431,10 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
         common["algorithmic_flops_per_problem"] = ex
         return {"bound": "mfma", "achieved": etf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": etf / FP64_PEAK_TFLOPS,
                 "kernel": "mpcqp_stage_kernel<4, 1, serial, pipelined> (stage-wise Riccati active set; two wavefronts per loop: "
-                          "one solves this period, the other rebuilds the factor for the next one; up to 20 periods per launch, kernel_ms is per period) with the plant step, next "
-                          "references and bookkeeping as its epilogue: one launch per period",
+                          "one solves this period, the other rebuilds the factor for the next one) with the plant step, next "
+                          "references and bookkeeping as its epilogue; up to periods_per_launch consecutive periods per launch "
+                          "(the episode's first period is a launch of its own), kernel_ms is per period",
+                "periods_per_launch": PERIODS_PER_LAUNCH, "pipeline_factor": True,
                 "achieved_gbs": gbs, "dense_equivalent_tflops": tfs, **common,
                 "note": "achieved = float64 operations the kernel executes per period (Riccati recursion, sweeps, slack "
                         "passes: ~3e4 per loop) over the period; dense_equivalent_tflops prices the reference's dense "
@@ -446,6 +452,68 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
                     "dense_equivalent_tflops prices the reference's dense condense + solve flops (which this path "
                     "does not execute) over the same time -- above the 157 TFLOP/s fp32 MFMA peak, i.e. out of reach "
                     "of any dense implementation"}
+
+
+def _gram_mfma_block(w, batch=2048, reps=10):
+    """In-run HIP-event time of mpcqp_gram_mfma_f32_kernel (phase 2 of mpcqp_condense_phase_batch) on the first `batch`
+    problems of the config-5 workload: executed flops (the causal lower triangle's MFMAs) and the dense-equivalent flops of
+    the reference's product (mpc_qp.py:99-105) against the 157.3 TFLOP/s dense float32 matrix-core peak."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from qpmpc_amd import _capi
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.batch import _stream_ptr
+
+    lib = _capi.load()
+    nx, nu, N, mk = _dims_of(w)
+    n, m = N * nu, N * mk
+    B = min(batch, int(w["x0"].shape[0]))
+    sub = {k: (v[:B] if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[0] == w["x0"].shape[0] else v) for k, v in w.items()}
+    bp = W.to_batch_problem(sub, dtype=torch.float32)
+    dims, cp = bp.dims(), bp.c_problem()
+    dev = bp.device
+    P = torch.empty((B, n, n), dtype=torch.float32, device=dev)
+    q = torch.empty((B, n), dtype=torch.float32, device=dev)
+    G = torch.empty((B, m, n), dtype=torch.float32, device=dev)
+    h = torch.empty((B, m), dtype=torch.float32, device=dev)
+    Psi = torch.empty((B, (N + 1) * nx * n), dtype=torch.float32, device=dev)
+    ws = torch.empty((B * (N + 1) * nx * 4,), dtype=torch.uint8, device=dev)
+    sp = _stream_ptr()
+    args = (C.byref(dims), C.byref(cp), B)
+    tail = (P.data_ptr(), q.data_ptr(), G.data_ptr(), h.data_ptr(), Psi.data_ptr(), ws.data_ptr(), ws.numel(), sp)
+    _capi.check(lib.mpcqp_condense_phase_batch(*args, 1, *tail), "mpcqp_condense_phase_batch(1)")
+    for _ in range(3):
+        _capi.check(lib.mpcqp_condense_phase_batch(*args, 2, *tail), "mpcqp_condense_phase_batch(2)")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.mpcqp_condense_phase_batch(*args, 2, *tail)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    # tiles of 32 x 32 of the lower triangle, active from the step whose columns reach them: the kernel's own count
+    mfmas = 0
+    nt = n // 32
+    for k in range(1, N + 1):                      # block row k of Psi: nx rows, non-zero in columns < k nu
+        rows = nx
+        act = min(nt, -(-(k * nu) // 32))          # tile rows / columns that see non-zero columns
+        mfmas += (act * (act + 1) // 2) * (rows / 2.0)   # one 32x32x2 instruction per two rows and tile
+    executed = mfmas * 32 * 32 * 2 * 2
+    dense = 2.0 * (N + 1) * nx * n * n
+    peak = 157.3
+    return {"kernel": "mpcqp_gram_mfma_f32_kernel<8> (v_mfma_f32_32x32x2_f32; P = w_u I + Psi' W Psi of the dense path, "
+                      "mpcqp_condense_phase_batch phase 2)",
+            "batch": B, "kernel_ms": ms, "executed_flops_per_problem": executed, "dense_equivalent_flops_per_problem": dense,
+            "achieved_tflops_executed": executed * B / (ms * 1e-3) / 1e12, "peak_tflops_f32_mfma_dense": peak,
+            "frac": executed * B / (ms * 1e-3) / 1e12 / peak,
+            "dense_equivalent_tflops": dense * B / (ms * 1e-3) / 1e12,
+            "source_profile": "profiles/r04_config5_dense_path.txt",
+            "note": "event time over `reps` launches of the Gram product alone on torch's current stream (the stream the "
+                    "library launches on); executed = the causal, symmetric part the kernel computes"}
 
 
 def _accuracy(args, w, run):

@@ -238,6 +238,17 @@ int mpcqp_condense_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                          void *Phi, void *Psi, void *workspace,
                          size_t workspace_bytes, void *stream);
 
+/* The two launches of mpcqp_condense_batch for problems that do not fit a CU's LDS (BASELINE config 5's size), one at a
+ * time -- for measurement (bench.py times the Gram product alone: `roofline.gram_mfma`) and for callers that overlap them
+ * with other work. phase 1 replaces the propagation loop of MPCQP.__init__ (qpmpc/mpc_qp.py:53-98): Psi (caller's buffer,
+ * same packing as mpcqp_condense_batch), G, h and the tracking residuals (workspace: (N + 1) nx elements per problem).
+ * phase 2 replaces the Hessian and cost-vector products (qpmpc/mpc_qp.py:99-105, 129-149): P = w_u I + Psi' W Psi and
+ * q = Psi' W resid from what phase 1 left in Psi and the workspace -- float32 with n a multiple of 32: on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, the causal lower triangle only). MPCQP_EUNSUPPORTED for problems the on-chip kernel condenses. */
+int mpcqp_condense_phase_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, int32_t phase,
+                               void *P, void *q, void *G, void *h, void *Psi, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* Replaces MPCQP.update_cost_vector (mpc_qp.py:129-149) and
  * MPCQP.update_constraint_vector (mpc_qp.py:151-163) for a batch, from the
  * Phi/Psi kept by mpcqp_condense_batch (same packing; batch strides

@@ -30,6 +30,7 @@ EXPORTS = (
     "mpcqp_warm_state_bytes",
     "mpcqp_solve_workspace_bytes",
     "mpcqp_condense_batch",
+    "mpcqp_condense_phase_batch",
     "mpcqp_update_vectors_batch",
     "mpcqp_solve_batch",
     "mpcqp_build_solve_batch",
@@ -109,6 +110,8 @@ def load():
     lib.mpcqp_warm_state_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
     lib.mpcqp_solve_workspace_bytes.restype = C.c_int
     lib.mpcqp_solve_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, i64, C.POINTER(C.c_size_t)]
+    lib.mpcqp_condense_phase_batch.restype = C.c_int
+    lib.mpcqp_condense_phase_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     lib.mpcqp_condense_batch.restype = C.c_int
     lib.mpcqp_condense_batch.argtypes = [C.POINTER(Dims), C.POINTER(Problem), i64, vp, vp, vp, vp, vp, vp, vp,
                                          C.c_size_t, vp]

@@ -438,8 +438,9 @@ size_t big_condense_ws_elems(const KernelArgs &ka) { return (size_t)(ka.N + 1) *
 bool big_supported(const KernelArgs &ka) { return ka.nx <= NXMAX && ka.n <= 256; }
 
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
-                        void *G, void *h, void *rownorm_inv, hipStream_t st)
+                        void *G, void *h, void *rownorm_inv, hipStream_t st, int phase)
 {
+    // phase 0: both launches; 1: propagation only (Psi, residuals, G, h); 2: the Gram product only (P, q from Psi)
     const size_t esz = dtype == MPCQP_F64 ? 8 : 4;
     auto al4 = [](size_t c) { return (c + 3) & ~(size_t)3; };
     const size_t lds = (3 * al4((size_t)ka.nx * ka.nx) + al4((size_t)ka.nx * ka.nu) + 2 * al4((size_t)ka.mk * ka.nx) +
@@ -447,7 +448,8 @@ int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Ps
 #define PROPAGATE(TY, NRMV, NXV)                                                                                \
     hipLaunchKernelGGL((mpcqp_propagate_kernel<TY, NRMV, NXV>), dim3((unsigned)batch), dim3(320), lds, st, ka,  \
                        (TY *)Psi_ws, (TY *)res_ws, (TY *)G, (TY *)h, (TY *)rownorm_inv)
-    if (dtype == MPCQP_F64) {
+    if (phase == 2) {
+    } else if (dtype == MPCQP_F64) {
         if (rownorm_inv) PROPAGATE(double, true, 0); else PROPAGATE(double, false, 0);
     } else if (ka.nx == 12) {  // config 5's state dimension at compile time
         if (rownorm_inv) PROPAGATE(float, true, 12); else PROPAGATE(float, false, 12);
@@ -456,7 +458,7 @@ int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Ps
     }
 #undef PROPAGATE
     int rc = (int)hipGetLastError();
-    if (rc) return rc;
+    if (rc || phase == 1) return rc;
     const bool mfma = (dtype == MPCQP_F32) && (ka.n % 32 == 0) && (ka.n <= 256);
     if (mfma) {
         const float *ps = (const float *)Psi_ws, *rs = (const float *)res_ws;

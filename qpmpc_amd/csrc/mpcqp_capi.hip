@@ -540,6 +540,32 @@ int mpcqp_update_vectors_batch(const MpcqpDims *dims, const MpcqpProblem *proble
     return launch_update(ka, dims->dtype, phi_batch_stride, psi_batch_stride, batch, (hipStream_t)stream);
 }
 
+int mpcqp_condense_phase_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch, int32_t phase, void *P,
+                               void *q, void *G, void *h, void *Psi, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_problem(dims, problem))) return rc;
+    if (batch < 0 || (phase != 1 && phase != 2) || !Psi) return MPCQP_EINVAL;
+    if (phase == 1 && dims->mk > 0 && (!G || !h)) return MPCQP_EINVAL;
+    if (phase == 2 && (!P || !q)) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, problem);
+    ka.P = P;
+    ka.q = q;
+    ka.G = G;
+    ka.h = h;
+    ka.Psi = Psi;
+    Layout L;
+    // only where mpcqp_condense_batch itself runs as two launches: problems that do not fit a CU's LDS
+    if (layout_for(ka, problem->A.step_stride != 0, problem->B.step_stride != 0, MODE_CONDENSE, dims->dtype, L) == 0 || !big_supported(ka))
+        return MPCQP_EUNSUPPORTED;
+    const size_t need = (size_t)(ka.N + 1) * ka.nx * (size_t)batch * elem_size(dims->dtype);  // the tracking residuals
+    if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
+    return launch_big_condense(ka, dims->dtype, batch, Psi, workspace, P, q, G, h, nullptr, (hipStream_t)stream, phase);
+}
+
 int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P, const void *q, const void *G,
                       const void *h, int64_t batch, const MpcqpSolveOpts *opts, void *x, void *lam,
                       int32_t *status, int32_t *iters, void *workspace, size_t workspace_bytes, void *stream)

@@ -146,7 +146,7 @@ size_t big_condense_ws_elems(const KernelArgs &ka);
 bool big_supported(const KernelArgs &ka);
 // G may be null (not formed); rownorm_inv (1/|G_i|, [batch, m]) is optional
 int launch_big_condense(const KernelArgs &ka, int dtype, int64_t batch, void *Psi_ws, void *res_ws, void *P, void *q,
-                        void *G, void *h, void *rownorm_inv, hipStream_t st);
+                        void *G, void *h, void *rownorm_inv, hipStream_t st, int phase = 0);
 // large-problem solver (mpcqp_bigsolve.hip): one problem per workgroup, L^-1 packed in LDS
 #ifdef __HIPCC__
 // ---- wavefront all-reductions on the vector pipe (the stage-wise kernels; __shfl_xor is a ds_bpermute per dword and step:
