@@ -108,18 +108,29 @@ def test_stagewise_runs_where_the_condensed_path_is_too_large():
 
 
 def test_stagewise_refuses_unsupported_dimensions():
+    """nx = 20 is served by the general stage-wise kernel since round 4 (float64); what has no stage-wise kernel at all is a
+    system wider than 32 states: MPCQP_EUNSUPPORTED from the entry point, MPCQP_ETOOLARGE from the default dispatch once the
+    dense path cannot hold it either (n > 256)."""
     from qpmpc_amd import BackendError, solve_mpc_batch
     from qpmpc_amd import workloads as W
 
-    w = W.synthetic_ltv_batch(2, N=8)
-    w["A"] = np.concatenate([np.concatenate([w["A"], np.zeros((2, 8, 12, 8))], axis=3), np.zeros((2, 8, 8, 20))], axis=2)  # nx = 20
-    w["B"] = np.concatenate([w["B"], np.zeros((2, 8, 8, 4))], axis=2)
-    w["C"] = np.concatenate([w["C"], np.zeros((16, 8))], axis=1)
-    w["x0"] = np.concatenate([w["x0"], np.zeros((2, 8))], axis=1)
-    w["goal"], w["targets"] = np.zeros(20), np.zeros(8 * 20)
-    bp = W.to_batch_problem(w)
+    def widened(nx, N):
+        w = W.synthetic_ltv_batch(2, N=N)
+        pad = nx - 12
+        w["A"] = np.concatenate([np.concatenate([w["A"], np.zeros((2, N, 12, pad))], axis=3), np.zeros((2, N, pad, nx))], axis=2)
+        w["B"] = np.concatenate([w["B"], np.zeros((2, N, pad, 4))], axis=2)
+        w["C"] = np.concatenate([w["C"], np.zeros((16, pad))], axis=1)
+        w["x0"] = np.concatenate([w["x0"], np.zeros((2, pad))], axis=1)
+        w["goal"], w["targets"] = np.zeros(nx), np.zeros(N * nx)
+        return w
+
+    ok = solve_mpc_batch(W.to_batch_problem(widened(20, 8)), formulation="stagewise")
+    torch.cuda.synchronize()
+    assert (ok.status.cpu().numpy() == 0).all()
     with pytest.raises(BackendError, match="-6"):
-        solve_mpc_batch(bp, formulation="stagewise")
+        solve_mpc_batch(W.to_batch_problem(widened(40, 8)), formulation="stagewise")
+    with pytest.raises(BackendError, match="-2"):
+        solve_mpc_batch(W.to_batch_problem(widened(40, 80)))
 
 
 # ---------------------------------------------------------------- wider systems (mpcqp_stagew.hip)
