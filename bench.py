@@ -380,9 +380,9 @@ def _traffic_from_profiles(config: int):
     """(HBM bytes per launch, source) from the rocprofv3 PMC passes stored under profiles/ for this round's kernels
     (separate --pmc runs of this same command: tools/collect_profiles.sh; FETCH_SIZE doubled as the microarchitecture
     guide prescribes for gfx950, WRITE_SIZE as reported). Newest round first; (None, None) when there is none."""
-    names = [f"r03_pmc_traffic_config{config}.json", f"r02_pmc_traffic_config{config}.json"]
+    names = [f"r04_pmc_traffic_config{config}.json", f"r03_pmc_traffic_config{config}.json", f"r02_pmc_traffic_config{config}.json"]
     if config == 2:
-        names += ["r03_pmc_traffic.json", "r02_pmc_traffic.json"]
+        names += ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):

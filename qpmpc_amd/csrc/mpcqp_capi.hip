@@ -127,7 +127,7 @@ bool use_stagew_auto(const KernelArgs &ka, int dtype)
     // (tools/probe_f32_dispatch.py), the stage-wise kernel is 2-2.5x the mid-size / LDS condensed kernels in float64 (nx = 6 .. 12,
     // n = 37 .. 64: 590-980 us against 1180-2170 us) and 2-3x in float32, where it is also 5-30x closer to the float64 oracle
     // (the condensed float32 path squares the conditioning into P: 1e-3 at n ~ 130). Small problems (n <= 24) stay on chip.
-    return !(ka.opt_flags & override_bits) && !ka.warm_state && stagew_supported(ka, dtype) && ka.m >= 1 &&
+    return !(ka.opt_flags & override_bits) && !(ka.warm_state && ka.warm_start == MPCQP_WARM_OPERATOR) && stagew_supported(ka, dtype) && ka.m >= 1 &&
            ((ka.n > 24 && (dtype == MPCQP_F64 || ka.nx <= 12)) || !fits_on_chip(ka, true, true, MODE_FUSED, dtype));
     // (float32 with nx > 12 -- the LDS-tiled Riccati recursion -- stays on chip while it fits: on borderline problems of that size
     // the condensed float32 kernel was the closer one, 1e-3 against 3e-3)
@@ -156,12 +156,15 @@ int stagew_auto_maxq(const KernelArgs &ka)
 
 // warm start: the small-problem pair kernel (operator + slot ids) and the narrow stage-wise kernel (row ids; the rows'
 // vectors stay in its workspace); 0 = not offered for these dimensions
+bool promote_f32(const KernelArgs &ka, int dtype);
 size_t warm_bytes_per_problem(KernelArgs ka, int dtype)
 {
     ka.opt_flags = 0;
     ka.warm_state = nullptr;
+    if (dtype == MPCQP_F32 && promote_f32(ka, dtype)) dtype = MPCQP_F64;  // (the launch that is solved in float64: its kernel's record)
     if (pair_eligible(ka, MODE_FUSED, dtype)) return kPairWarmDoubles * sizeof(double);
     if (use_stage_auto(ka, dtype)) return stage_warm_bytes(stage_default_maxq(ka));
+    if (use_stagew_auto(ka, dtype)) return stagew_warm_bytes(stagew_auto_maxq(ka));  // row ids only (MPCQP_WARM_ACTIVE_SET)
     return 0;
 }
 
@@ -321,7 +324,7 @@ bool promote_f32(const KernelArgs &ka, int dtype)
 {
     const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
                               MPCQP_OPT_ONE_PER_WAVE;
-    if (dtype != MPCQP_F32 || (ka.opt_flags & override_bits) || ka.warm_state || ka.m < 1) return false;
+    if (dtype != MPCQP_F32 || (ka.opt_flags & override_bits) || ka.m < 1) return false;
     // The wide stage-wise kernel squares nothing, and BASELINE config 5 (n = 256) comes out 1e-6 from the float64 plan in
     // float32 -- but on adversarial mid-size families (bounds at the edge of consistency, 60-270 iterations) one plan in
     // ~1500 came back SOLVED 1.4e-3 .. 3.6e-3 away with every active row on its bound to rounding noise: the error sits in the
@@ -654,8 +657,13 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         if (lam) out.seg[out.nseg++] = ConvSeg{w + offL, lam, batch * ka.m};
         return launch_convert(out, st);
     }
-    if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype) && !use_stage_auto(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
-    if (ka.warm_start == MPCQP_WARM_ACTIVE_SET && !pair_eligible(ka, MODE_FUSED, dims->dtype)) return MPCQP_EUNSUPPORTED;
+    if (ka.warm_state && !pair_eligible(ka, MODE_FUSED, dims->dtype) && !use_stage_auto(ka, dims->dtype) && !use_stagew_auto(ka, dims->dtype))
+        return MPCQP_EUNSUPPORTED;
+    // (row-id warm starts: the pair kernel and the wide stage-wise kernel; the narrow stage-wise kernel, which the dispatch
+    // prefers for small systems with 16 < n <= 128, has its own kind of record)
+    if (ka.warm_start == MPCQP_WARM_ACTIVE_SET && !pair_eligible(ka, MODE_FUSED, dims->dtype) &&
+        (use_stage_auto(ka, dims->dtype) || !use_stagew_auto(ka, dims->dtype)))
+        return MPCQP_EUNSUPPORTED;
     if ((ka.opt_flags & MPCQP_OPT_PIPELINE_FACTOR) && !(use_stage_auto(ka, dims->dtype) && stage_pipeline_supported(ka, dims->dtype)))
         return MPCQP_EUNSUPPORTED;
     // the state is indexed by problem: a buffer made for a smaller batch would be read and written out of bounds

@@ -226,6 +226,8 @@ int launch_stage(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStr
 bool stagew_supported(const KernelArgs &ka, int dtype);
 size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype);
 int launch_stagew(const KernelArgs &ka, int dtype, int maxq, int64_t batch, void *ws, hipStream_t st);
+// warm-state record of the wide stage-wise kernel (MPCQP_WARM_ACTIVE_SET): int32 count, then the active rows' ids
+__host__ __device__ inline size_t stagew_warm_bytes(int maxq) { return ((size_t)(maxq + 1) * 4 + 15) & ~(size_t)15; }
 // ... and for every other system (mpcqp_stageg.hip): nx <= 32, nu <= 8, float64, any horizon; one workgroup per problem, all
 // arrays in the workspace -- a general fallback, not a tuned path
 bool stageg_supported(const KernelArgs &ka, int dtype);

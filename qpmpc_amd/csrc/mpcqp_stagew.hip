@@ -1006,10 +1006,43 @@ __global__ void __launch_bounds__(64)
     // rows (V_a = P^-1 g_a' does not depend on the active set: a row found among them later costs no sweep; which rows ride
     // along has no influence on the iterates). Per lane: its column's row, the row's step, (p_kq, ff_kq) to inject there;
     // kmax = the latest of the steps.
+    // warm-state record (MpcqpSolveOpts.warm_state): int32 count, then the rows that were active when the last solve ended
+    int *wrec = ka.warm_state ? (int *)((char *)ka.warm_state + prob * (int64_t)stagew_warm_bytes(maxq)) : nullptr;
+    int wcnt = 0, wpos = 0;
+    if (wrec && ka.warm_start == MPCQP_WARM_ACTIVE_SET) {
+        wcnt = __builtin_amdgcn_readfirstlane(wrec[0]);  // (wave-uniform: scalar registers)
+        wcnt = (wcnt < 0 || wcnt > maxq) ? 0 : wcnt;     // (a record that is not one: no warm rows)
+    }
     auto candidates = [&](int bi, int &myrow, int &mykq, int &kmax, MV &st, T &ffs) {
         // rows[0] = the candidate; then the next most violated rows (per-lane top two, R - 1 wave minima)
         int rows[R];
         rows[0] = bi;
+        int jstart = 1;  // rows[1 .. jstart - 1] come from the warm list
+        if (wpos < wcnt) {
+            // MPCQP_WARM_ACTIVE_SET: the rows that were active at the end of the previous solve (moved with the horizon) ride
+            // along FIRST -- V_a = P^-1 g_a' does not depend on the active set, so when the iterations ask for one of them
+            // its sweeps are already done. Sixteen ids are examined per call (one round trip): in range, not the candidate,
+            // not active now.
+            const int t = lane & 15;
+            const int id = wpos + t < wcnt ? wrec[1 + wpos + t] - ka.warm_shift : -1;
+            bool okr = id >= 0 && id < M && id != bi && lane < 16;
+            if (okr) okr = FUSE ? !(thr[id] == INF) : rowslot[id] < 0;
+            unsigned okm = (unsigned)__ballot(okr) & 0xffffu;
+            int last = -1;
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                if (okm) {
+                    const int b = (int)__builtin_ctz(okm);
+                    okm &= okm - 1;
+                    rows[j] = __shfl(id, b);
+                    last = b;
+                    jstart = j + 1;
+                } else {
+                    rows[j] = -1;
+                }
+            }
+            wpos += (okm != 0u) ? last + 1 : 16;  // (ids left over are examined again by the next call)
+        }
         {
             T b1 = INF, b2 = INF;
             int i1 = 0x7fffffff, i2 = 0x7fffffff;
@@ -1041,6 +1074,7 @@ __global__ void __launch_bounds__(64)
             }
 #pragma unroll
             for (int j = 1; j < R; ++j) {
+                if (j < jstart) continue;  // (wave-uniform)
                 T v = b1;
                 int ix = i1;
                 wave_argmin(v, ix);
@@ -1540,6 +1574,10 @@ __global__ void __launch_bounds__(64)
             if (ok)
                 for (int a = lane; a < nq; a += 64) ol[actrow[a]] = lamv[a];
         }
+        if (wrec) {  // the rows that are active now: the next solve's warm rows (MPCQP_WARM_ACTIVE_SET)
+            if (lane == 0) wrec[0] = ok ? nq : 0;
+            for (int a = lane; ok && a < nq; a += 64) wrec[1 + a] = actrow[a];
+        }
         if (lane == 0) {
             if (ka.status) ka.status[prob] = status;
             if (ka.iters) ka.iters[prob] = iters;
@@ -1929,6 +1967,10 @@ __global__ void __launch_bounds__(64)
                 const int sidx = rowslot[i];
                 ol[i] = (ok && sidx >= 0) ? lamv[sidx] : T(0);
             }
+        }
+        if (wrec) {  // the rows that are active now: the next solve's warm rows (MPCQP_WARM_ACTIVE_SET)
+            if (lane == 0) wrec[0] = ok ? nq : 0;
+            for (int a = lane; ok && a < nq; a += 64) wrec[1 + a] = actrow[a];
         }
         if (lane == 0) {
             if (ka.status) ka.status[prob] = status;
