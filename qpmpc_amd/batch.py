@@ -387,15 +387,19 @@ class WarmState:
         if nbytes.value == 0:
             raise BackendError(
                 "warm start is available for float64 problems with n = N*nu <= 16 variables and m <= 32 rows (the active-set "
-                "operator persists) and for small systems (nx <= 4, nu <= 2) with 16 < n <= 128 (the active rows' vectors "
-                f"persist in the solver's workspace); got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype}")
+                "operator persists), for small systems (nx <= 4, nu <= 2) with 16 < n <= 128 (the active rows' vectors "
+                "persist in the solver's workspace) and for what the wide stage-wise kernel takes (nx <= 16, nu <= 4: the active "
+                f"rows' ids); got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype}")
         self.bytes_per_problem = int(nbytes.value)
         self.batch_size = problem.batch_size
         self.device = problem.device
         # "pair": the operator T (16 x 16 doubles) first, then the slots' constraint ids (int32); "stage": int32 record
         # [nq, slots, workspace tag (2), row steps ..., row indices ...] -- the vectors themselves stay in the workspace of
         # the PreparedSolve that is re-launched (MPCQP_OPT_REUSE_FACTOR contract), so this kind only acts there
-        self.kind = "pair" if problem.nb_variables <= 16 else "stage"
+        # "stagew" (round 4): the wide stage-wise kernel -- int32 count, then the active rows' ids; started from with
+        # warm_start="active_set" only (the rows' vectors ride along with the first sweeps)
+        narrow = problem.state_dim <= 4 and problem.input_dim <= 2 and problem.nb_variables <= 128 and problem.dtype == torch.float64
+        self.kind = "pair" if problem.nb_variables <= 16 else ("stage" if narrow else "stagew")
         self._mk = problem.ineq_dim
         self._ids_at = 16 * 16 * 8 if self.kind == "pair" else 0
         self.buffer = torch.zeros((problem.batch_size, self.bytes_per_problem), dtype=torch.uint8, device=problem.device)
@@ -421,6 +425,11 @@ class WarmState:
         torch = _torch()
         if self.kind == "pair":
             return self.buffer[:, self._ids_at:].contiguous().view(torch.int32)
+        if self.kind == "stagew":
+            rec = self.buffer.view(torch.int32)  # [B, 1 + slots (+ padding)]
+            rows, nq = rec[:, 1:], rec[:, 0:1]
+            live = torch.arange(rows.shape[1], device=rec.device)[None, :] < nq
+            return torch.where(live, rows, torch.full_like(rows, -1))
         rec = self.buffer.view(torch.int32)  # [B, 4 + 2 slots (+ padding)]
         slots = int(rec[0, 1].item()) if int(rec[0, 1].item()) > 0 else (rec.shape[1] - 4) // 2
         nq = rec[:, 0:1]

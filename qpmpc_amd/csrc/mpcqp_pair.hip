@@ -274,7 +274,9 @@ using namespace pair;
 // anywhere). A launch that fills the machine exactly once (two wavefronts per SIMD) is 3 % shorter with workgroups of two -- 25.6 against
 // 26.4 us for 4096 problems; 3, 4 and 8 lose: 35.7 / 27.5 / 27.6 --, launches of several rounds are faster with single
 // wavefronts (8192 problems: 47.2 against 53.3 us; 65,536: 310 against 320), see launch_pair_t.
-template <int NX, int MK, bool MODEL = false, bool WARM = false, int WPB = 1>
+// SEED: the instantiation that carries the seed steps (MPCQP_OPT_SEED_VIOLATED, MPCQP_WARM_ACTIVE_SET): compiled into the plain
+// cold instantiation they cost its launches 2 % (198 instead of 192 registers, one more ballot per trip).
+template <int NX, int MK, bool MODEL = false, bool WARM = false, int WPB = 1, bool SEED = false>
 __global__ void __launch_bounds__(64 * WPB, 2)
     mpcqp_pair_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ gD, const double *__restrict__ ge, const double *__restrict__ gx0,
@@ -587,10 +589,10 @@ __global__ void __launch_bounds__(64 * WPB, 2)
     tick(2);
 
     // the stored warm-start state is requested now and consumed after the forward substitution
-    double *wstate = ka.warm_state ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
+    double *wstate = ((WARM || SEED) && ka.warm_state) ? (double *)ka.warm_state + prob * (int64_t)kPairWarmDoubles : nullptr;
     const bool wload = WARM && wstate && ka.warm_start == MPCQP_WARM_OPERATOR && !notpd;
     // MPCQP_WARM_ACTIVE_SET: only the stored row ids are read (the cold instantiation serves it: see the seeded start)
-    const bool wseed = !WARM && wstate && ka.warm_start == MPCQP_WARM_ACTIVE_SET;
+    const bool wseed = SEED && !WARM && wstate && ka.warm_start == MPCQP_WARM_ACTIVE_SET;
     int sid = -1;
     if (wseed && low) sid = reinterpret_cast<const int *>(wstate + NV * NV)[hl];
     int wid = -1;
@@ -897,7 +899,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
     // opt-in (MPCQP_OPT_SEED_VIOLATED); the seed steps are what MPCQP_WARM_ACTIVE_SET -- last period's active rows, moved with the
     // horizon -- starts from: those rows enter whether or not they are violated yet.
     bool negfix = false;  // this half holds negative multipliers left by the seed steps
-    if ((ka.opt_flags & MPCQP_OPT_SEED_VIOLATED) || wseed) {
+    if (SEED && ((ka.opt_flags & MPCQP_OPT_SEED_VIOLATED) || wseed)) {
         // rows that enter whether or not they are violated at the moment: last period's active set, moved with the horizon
         unsigned force = 0u;
         if (wseed) {
@@ -1014,7 +1016,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
             //      turns out to be a FULL one (no multiplier blocks, nothing leaves, no limit reached), a trip needs
             //      none of the general machinery: one ballot per trip checks that, anything else leaves this loop
             //      and the same trip is redone by the general code below.
-            if (__ballot(!done & (!needp | dropping | negfix)) == 0ull) {
+            if (__ballot(!done & (!needp | dropping | (SEED & negfix))) == 0ull) {
                 // Inside this loop the update vector never goes through LDS: lane 16 + k of a half produces -z_k, one
                 // v_permlane16_swap pair copies the high row over the low one, and the next trip's update reads
                 // component k as a DPP row broadcast. cTn, cKn are the coefficients of -z.
@@ -1087,7 +1089,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
             // ---- seeded start: a slot whose multiplier came out negative leaves -- the most negative one first, one per
             //      trip -- before anything else is selected (rare: ~0.2 rows per config-2 problem)
             bool ndrop = false;  // this trip's drop pass carries a non-zero multiplier
-            if (__ballot(negfix & !done & !dropping) != 0ull) {
+            if (SEED && __ballot(negfix & !done & !dropping) != 0ull) {
                 const bool rep = negfix & !done & !dropping;
                 unsigned hi, lo;
                 ordered(lam, hi, lo);
@@ -1108,7 +1110,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
             // ---- selection, for the halves that start a new constraint (straight-line selects: no divergent branches)
             {
                 const unsigned hi = ~(unsigned)__double2hiint(s * invn);  // (negative for every candidate: see the fast loop)
-                const bool want = needp & !done & !dropping;
+                const bool want = needp & !done & (SEED ? !dropping : true);
                 const bool viol = want & selectable & (pos < 0) & (s < -tolh);
                 const unsigned key = viol ? ((hi & ~31u) | (unsigned)hl) : 0xffffffffu;
                 const unsigned mkey = half_min(key);
@@ -1215,7 +1217,7 @@ __global__ void __launch_bounds__(64 * WPB, 2)
                     cK = isc ? g * itl : T(0);
                     pdrop = true;
                 }
-                if (__ballot(ndrop) != 0ull) {
+                if (SEED && __ballot(ndrop) != 0ull) {
                     // the slot leaves with a multiplier lam_l < 0 (seeded start): the minimiser on the remaining rows'
                     // hyperplanes is y + (lam_l / |T_l|^2) T_l, its multipliers lam_a - lam_l (T_a . T_l) / |T_l|^2
                     const T f = half_get(lam, hb, ldrop) * itl;
@@ -1566,7 +1568,10 @@ template <int NX, int MK> static int launch_pair_t(const KernelArgs &ka, int64_t
 #ifdef PAIR_FORCE_WPB1
     two = false;
 #endif
-    if (ka.warm_state && ka.warm_start != MPCQP_WARM_ACTIVE_SET) {  // (workgroups of two measured no different here: 23.1 us either way for a stored state that is accepted)
+    const bool seeded = (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED) || (ka.warm_state && ka.warm_start == MPCQP_WARM_ACTIVE_SET);
+    if (seeded && !(ka.warm_state && ka.warm_start != MPCQP_WARM_ACTIVE_SET)) {
+        go(mpcqp_pair_kernel<NX, MK, false, false, 1, true>, 1);
+    } else if (ka.warm_state && ka.warm_start != MPCQP_WARM_ACTIVE_SET) {  // (workgroups of two measured no different here: 23.1 us either way for a stored state that is accepted)
         go(mpcqp_pair_kernel<NX, MK, false, true>, 1);
     } else if (two) {
         go(mpcqp_pair_kernel<NX, MK, false, false, 2>, 2);
