@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                 a1 -= Bm[i * nu + a] * Km[a * nx + j];
                 a2 -= PBm[i * nu + a] * Km[a * nx + j];
             }
-            Acl[(int64_t)k * nx * nx + e] = a1;
+            Acl[(int64_t)k * nx * nx + j * nx + i] = a1;  // (transposed: the backward sweep reads columns)
             Tm[e] = a2;
         }
         bsync();
@@ -243,68 +243,139 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
 
     // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
     //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
+    // Every step's matrices come from HBM (N nx^2 doubles do not fit a CU), and a step is too short to hide that round trip:
+    // each thread therefore requests the entries of step k -+ 1 it will use -- one role per thread: tid < nu the input-sized
+    // rows, 64 <= tid < 64 + nx the state rows, 128 <= tid the rows of G -- into registers while step k computes.
     auto sweep = [&](int kp, int rp, bool tracking, const T *xstart, T *Vout, T *Hout) {
         for (int i = tid; i < nx; i += BS) pv[i] = (tracking && termQ) ? -ka.wt * ggoal[i] : 0.0;
         const int ktop = tracking ? N - 1 : kp;
         for (int i = tid; i < n; i += BS)
             if (i >= (ktop + 1) * nu) ffv[i] = 0.0;
+        const bool roleT = tid < nu, roleP = tid >= 64 && tid < 64 + nx, roleG = tid >= 128 && tid - 128 < mk;
+        const int pi = tid - 64, gr = tid - 128;
+        T cur[NXM], cur2[NUM], nxt[NXM], nxt2[NUM], curs = 0.0, nxts = 0.0;
+#pragma unroll
+        for (int l = 0; l < NXM; ++l) cur[l] = nxt[l] = 0.0;
+#pragma unroll
+        for (int a = 0; a < NUM; ++a) cur2[a] = nxt2[a] = 0.0;
+        auto req_b = [&](int k) {  // backward operands of step k
+            if (roleT) {
+                const T *B = gB + k * sB, *Sk = Si + (int64_t)k * nu * nu;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? B[l * nu + tid] : 0.0;
+#pragma unroll
+                for (int a = 0; a < NUM; ++a) nxt2[a] = a < nu ? Sk[tid * nu + a] : 0.0;
+            } else if (roleP) {
+                const T *Ak = Acl + (int64_t)k * nx * nx + pi * nx;  // (stored transposed: row i = column i of Acl)
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? Ak[l] : 0.0;
+                nxts = (tracking && stageQ && k >= 1) ? gtgt[(int64_t)k * nx + pi] : 0.0;
+            }
+        };
+        auto rotate = [&]() {
+#pragma unroll
+            for (int l = 0; l < NXM; ++l) cur[l] = nxt[l];
+#pragma unroll
+            for (int a = 0; a < NUM; ++a) cur2[a] = nxt2[a];
+            curs = nxts;
+        };
+        req_b(ktop);
+        rotate();
         bsync();
         for (int k = ktop; k >= 0; --k) {
-            const T *B = gB + k * sB, *Ak = Acl + (int64_t)k * nx * nx, *Kk = Kt + (int64_t)k * nu * nx, *Sk = Si + (int64_t)k * nu * nu;
+            if (k > 0) req_b(k - 1);
             const bool here = !tracking && k == kp;
             const T *Dr = (here && gD) ? gD + k * sD + rp * nu : nullptr;
             const T *Cr = (here && gC) ? gC + k * sC + rp * nx : nullptr;
-            if (tid < nu) {  // t = B' p + rl  (rl = -D[kp, rp] at the row's stage)
+            if (roleT) {  // t = B' p + rl  (rl = -D[kp, rp] at the row's stage)
                 T acc = Dr ? -Dr[tid] : 0.0;
-                for (int l = 0; l < nx; ++l) acc += B[l * nu + tid] * pv[l];
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? pv[l] : 0.0);
                 tv[tid] = acc;
             }
-            if (tid >= 64 && tid < 64 + nx) {  // p_k = ql + Acl' p - K' rl
-                const int i = tid - 64;
-                T acc = Cr ? -Cr[i] : 0.0;
-                if (tracking && stageQ && k >= 1) acc -= ka.wx * gtgt[(int64_t)k * nx + i];
-                for (int l = 0; l < nx; ++l) acc += Ak[l * nx + i] * pv[l];
-                if (Dr)
-                    for (int a = 0; a < nu; ++a) acc += Kk[a * nx + i] * Dr[a];
-                pn[i] = acc;
+            if (roleP) {  // p_k = ql + Acl' p - K' rl
+                T acc = Cr ? -Cr[pi] : 0.0;
+                acc -= ka.wx * curs;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? pv[l] : 0.0);
+                if (Dr) {
+                    const T *Kk = Kt + (int64_t)k * nu * nx;
+                    for (int a = 0; a < nu; ++a) acc += Kk[a * nx + pi] * Dr[a];
+                }
+                pn[pi] = acc;
             }
             bsync();
-            if (tid < nu) {  // ff = -S^-1 t
+            if (roleT) {  // ff = -S^-1 t
                 T acc = 0.0;
-                for (int b = 0; b < nu; ++b) acc -= Sk[tid * nu + b] * tv[b];
+#pragma unroll
+                for (int b = 0; b < NUM; ++b) acc -= cur2[b] * (b < nu ? tv[b] : 0.0);
                 ffv[k * nu + tid] = acc;
             }
-            if (tid >= 64 && tid < 64 + nx) pv[tid - 64] = pn[tid - 64];
+            if (roleP) pv[pi] = pn[pi];
+            rotate();
             bsync();
         }
         for (int i = tid; i < nx; i += BS) xv[i] = xstart ? xstart[i] : 0.0;
-        bsync();
+        auto req_f = [&](int k) {  // forward operands of step k
+            if (roleT) {
+                const T *Kk = Kt + (int64_t)k * nu * nx + tid * nx;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? Kk[l] : 0.0;
+                nxts = ffv[k * nu + tid];
+            } else if (roleP) {
+                const T *A = gA + k * sA + pi * nx, *B = gB + k * sB + pi * nu;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? A[l] : 0.0;
+#pragma unroll
+                for (int a = 0; a < NUM; ++a) nxt2[a] = a < nu ? B[a] : 0.0;
+            } else if (roleG) {
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) nxt[l] = (gC && l < nx) ? gC[k * sC + gr * nx + l] : 0.0;
+#pragma unroll
+                for (int a = 0; a < NUM; ++a) nxt2[a] = (gD && a < nu) ? gD[k * sD + gr * nu + a] : 0.0;
+            }
+        };
+        bsync();  // (ffv of the backward sweep is complete)
+        req_f(0);
+        rotate();
         for (int k = 0; k < N; ++k) {
-            const T *A = gA + k * sA, *B = gB + k * sB, *Kk = Kt + (int64_t)k * nu * nx;
-            if (tid < nu) {  // u = -K x + ff
-                T acc = ffv[k * nu + tid];
-                for (int i = 0; i < nx; ++i) acc -= Kk[tid * nx + i] * xv[i];
+            if (k + 1 < N) req_f(k + 1);
+            if (roleT) {  // u = -K x + ff
+                T acc = curs;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) acc -= cur[l] * (l < nx ? xv[l] : 0.0);
                 uv[tid] = acc;
                 Vout[k * nu + tid] = acc;
             }
             bsync();
-            for (int r = tid; r < mk; r += BS) {  // rows of G at this stage
+            if (roleG) {  // rows of G at this stage
+                T acc = 0.0;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? xv[l] : 0.0);
+#pragma unroll
+                for (int a = 0; a < NUM; ++a) acc += cur2[a] * (a < nu ? uv[a] : 0.0);
+                Hout[k * mk + gr] = acc;
+            }
+            for (int r = tid; r + 128 < mk; r += BS) {  // (more than 128 rows per stage: the rest, without the read-ahead)
+                const int rr = r + 128;
                 T acc = 0.0;
                 if (gC)
-                    for (int i = 0; i < nx; ++i) acc += gC[k * sC + r * nx + i] * xv[i];
+                    for (int i = 0; i < nx; ++i) acc += gC[k * sC + rr * nx + i] * xv[i];
                 if (gD)
-                    for (int a = 0; a < nu; ++a) acc += gD[k * sD + r * nu + a] * uv[a];
-                Hout[k * mk + r] = acc;
+                    for (int a = 0; a < nu; ++a) acc += gD[k * sD + rr * nu + a] * uv[a];
+                Hout[k * mk + rr] = acc;
             }
-            if (tid >= 64 && tid < 64 + nx) {  // x+ = A x + B u
-                const int i = tid - 64;
+            if (roleP) {  // x+ = A x + B u
                 T acc = 0.0;
-                for (int l = 0; l < nx; ++l) acc += A[i * nx + l] * xv[l];
-                for (int a = 0; a < nu; ++a) acc += B[i * nu + a] * uv[a];
-                xn[i] = acc;
+#pragma unroll
+                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? xv[l] : 0.0);
+#pragma unroll
+                for (int a = 0; a < NUM; ++a) acc += cur2[a] * (a < nu ? uv[a] : 0.0);
+                xn[pi] = acc;
             }
             bsync();
             if (tid < nx) xv[tid] = xn[tid];
+            rotate();
             bsync();
         }
     };
