@@ -31,6 +31,7 @@
 // small vectors shared by the lanes (c, r, multipliers, the active list) live in LDS.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "mpcqp.h"
@@ -140,10 +141,21 @@ __host__ __device__ size_t stage_warm_bytes(int maxq) { return ((size_t)(4 + 2 *
 // every period, like the reference's solve_mpc does, but off the period's critical path.
 // WARM: the warm-start machinery (MpcqpSolveOpts.warm_state) is compiled only into the instantiations that a launch with a
 // warm-state record selects: the cold instantiations keep the registers and the code size they had without it.
+// The kernel's ONE argument (round-3 advisor finding): the period below reads its arguments where they lie in the kernarg
+// segment, so their offsets are offsetof() of this type -- the single by-value argument starts the segment -- instead of
+// hand-computed positions of four separate parameters.
+struct StageArgs {
+    KernelArgs ka;
+    Ws wl;
+    double *wsbase;
+    int64_t batch;
+};
+static_assert(offsetof(StageArgs, ka) == 0, "the kernel argument block starts with KernelArgs");
+
 template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
-__global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
-    mpcqp_stage_kernel(const KernelArgs ka_, const Ws wl_, double *__restrict__ wsbase_, const int64_t batch)
+__global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const StageArgs sa_)
 {
+    const KernelArgs &ka_ = sa_.ka;
     // ONE PERIOD = one build + solve (+ the fused plant epilogue). A launch runs ka.ep_periods of them back to back
     // (mpcqp_wip_periods_batch: the loop's next problem is written by the epilogue, so the wavefront carries on with it --
     // no launch boundary, no dispatch gap between the periods); every other entry point runs one. (Everything, the
@@ -159,9 +171,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     // MULTI: the instantiations that mpcqp_wip_periods_batch reaches (the plant of the fused period has nx = 4, nu = 1)
     constexpr bool MULTI = SERIAL && NX == 4 && NU == 1;
     if constexpr (MULTI) asm volatile("" : "+s"(kbase), "+s"(prob), "+v"(tid));
-    // (the kernel's arguments, read where they lie in the kernarg segment: ka_ first, wl_ and wsbase_ behind it)
-    constexpr size_t off_wl = (sizeof(KernelArgs) + alignof(Ws) - 1) / alignof(Ws) * alignof(Ws);
-    constexpr size_t off_ws = (off_wl + sizeof(Ws) + 7) / 8 * 8;
+    // (the kernel's arguments, read where they lie in the kernarg segment: the fields of StageArgs)
+    constexpr size_t off_wl = offsetof(StageArgs, wl), off_ws = offsetof(StageArgs, wsbase);
     const __attribute__((address_space(4))) KernelArgs &ka = *(const __attribute__((address_space(4))) KernelArgs *)kbase;
     const __attribute__((address_space(4))) Ws &wl = *(const __attribute__((address_space(4))) Ws *)(kbase + off_wl);
     double *wsbase = *(double *const __attribute__((address_space(4))) *)(kbase + off_ws);
@@ -1472,20 +1483,6 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2)
     }
     tick(8);
     };  // period
-    {
-        // The period reads its arguments where they lie in the kernarg segment (explicit arguments first, naturally aligned: the
-        // ABI's layout, but an assumption of THIS file): checked once per wavefront -- one that finds something else there stops
-        // instead of computing on garbage.
-        typedef const __attribute__((address_space(4))) unsigned char *KargPtr0;
-        KargPtr0 kb = (KargPtr0)__builtin_amdgcn_kernarg_segment_ptr();
-        constexpr size_t o_wl = (sizeof(KernelArgs) + alignof(Ws) - 1) / alignof(Ws) * alignof(Ws);
-        constexpr size_t o_ws = (o_wl + sizeof(Ws) + 7) / 8 * 8;
-        const auto *kq = (const __attribute__((address_space(4))) KernelArgs *)kb;
-        const auto *wq0 = (const __attribute__((address_space(4))) Ws *)(kb + o_wl);
-        if (kq->N != ka_.N || kq->max_iter != ka_.max_iter || wq0->total != wl_.total ||
-            *(double *const __attribute__((address_space(4))) *)(kb + o_ws) != wsbase_)
-            __builtin_trap();
-    }
     if constexpr (!(SERIAL && NX == 4 && NU == 1)) {  // (one period per launch: mpcqp_wip_periods_batch refuses more)
         period(0);
         return;
@@ -1532,7 +1529,8 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(PIPE ? 128 : 64), lds, st, ka, wl, (double *)ws, batch);
+    const StageArgs sa{ka, wl, (double *)ws, batch};
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(PIPE ? 128 : 64), lds, st, sa);
     return (int)hipGetLastError();
 }
 
