@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_PEAK_TFLOPS = 78.6   # MI355X vector/matrix fp64 peak (AMD spec; not in the guide)
 FP32_PEAK_TFLOPS = 157.3  # MI355X f32 vector = f32-input MFMA peak (MI355X_MICROARCH.md)
-PERIODS_PER_LAUNCH = 20   # config 3: consecutive control periods of the closed loops per launch
+PERIODS_PER_LAUNCH = 50   # config 3: consecutive control periods of the closed loops per launch
 
 CONFIGS = {
     2: dict(batch=4096, scaling="weak", dtype="f64",
