@@ -1,0 +1,8 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): the round's final stress campaign on the final build; prints one line per (tool, seed).
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+for s in 70 71 72 73 74 75 76 77; do echo "stress_dense 120x64 seed $s: $(STRESS_SEED=$s python tools/stress_dense.py 120 64 2>&1 | tail -1)"; done
+for s in 21 22 23 24 25 26; do echo "stress_pair 40x256 seed $s: $(STRESS_SEED=$s python tools/stress_pair.py 40 256 2>&1 | tail -1)"; done
+for s in 21 22 23 24; do echo "stress_pair SEEDED 40x256 seed $s: $(STRESS_SEEDED=1 STRESS_SEED=$s python tools/stress_pair.py 40 256 2>&1 | tail -1)"; done
+for s in 6 7 8 9; do echo "stress_stagewise wide 20x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 20 128 2>&1 | tail -1)"; echo "stress_stagewise narrow 20x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 20 128 narrow 2>&1 | tail -1)"; done
+for s in 56 57 58 59 60 61 62 63; do echo "stress_f32 60x128 seed $s: $(STRESS_SEED=$s python tools/stress_f32.py 60 128 2>&1 | grep -E 'CHECK|worst' | tr '\n' ' ')"; done
