@@ -151,6 +151,11 @@ typedef struct MpcqpProblem {
                                  minimiser; measured 5 % SLOWER than the plain iterations on BASELINE config 2,
                                  hence opt-in: the seed steps are what MPCQP_WARM_ACTIVE_SET starts from. */
 
+#define MPCQP_OPT_EXACT_SELECTION 1024 /* wide stage-wise kernel, constraint matrices fixed along the horizon: every iteration
+                                 selects the most violated row of ALL rows (a pass over the m slacks per step) instead of
+                                 preferring a violated row whose sweeps are already done and deferring the pass (lazy
+                                 slacks, the default since ABI 8). Same minimiser; other iterates. */
+
 /* MpcqpSolveOpts.warm_start */
 #define MPCQP_WARM_OPERATOR 1   /* begin from the stored active set AND operator N* (contract: matrices unchanged)          */
 #define MPCQP_WARM_ACTIVE_SET 2 /* begin from the stored active set's ROW IDS only, moved by warm_shift rows: the rows enter

@@ -16,7 +16,7 @@ SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EINVAL, EUNSUPPORTED = -1, -6
 ABI_VERSION = 8
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
-OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED = 64, 128, 256, 512
+OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED, OPT_EXACT_SELECTION = 64, 128, 256, 512, 1024
 WARM_OPERATOR, WARM_ACTIVE_SET = 1, 2
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.

@@ -1163,6 +1163,23 @@ __global__ void __launch_bounds__(64)
         constexpr int WL = 32, WLD = 33;
         int *cslot = crow + R, *freel = cslot + R;
         T *Wl = (T *)(((uintptr_t)(freel + maxq) + 15) & ~(uintptr_t)15);
+        // LAZY SLACKS (round 4). A full step moves every slack by t (h_p - sum_a r_a h_a): one pass over the m rows that reads
+        // |A| + 1 slot arrays -- a quarter of an iteration's time at batch 8192 (HBM) and most of its dependent round trips
+        // at batch 1024 -- although the next iteration only needs the slack of ONE row when that row's vectors are already
+        // in a candidate slot. The pass is therefore DEFERRED: the step is folded into pending coefficients pcv[a] (true
+        // slack = sl + sum_a pcv[a] h_a), the next candidate is looked for among the cached rows first, each evaluated
+        // exactly from its own entries of the h_a (|A| loads per row, one round trip), and the pending sum is applied in one
+        // pass only when none of them is violated (then the most violated row of ALL is selected, as before), before a row
+        // leaves, and before the verification. On config 5 that is 2.1 full passes per problem instead of 6.4
+        // (tools/sim_lazy.py; measured: 1.215 against 1.278 ms per 8192 problems); the price is the selection rule -- a violated cached row is preferred to a more violated row
+        // that would need a sweep -- i.e. other iterates (4 % more iterations), the same minimiser. MPCQP_OPT_EXACT_SELECTION
+        // keeps the old rule (the tests that compare iteration counts across instantiations).
+        T *pcv = Wl + WL * WLD;
+        // (not in the small-batch instantiation: one wavefront per SIMD is bound by the longest problem's dependent round
+        // trips, and there the extra evaluation and the 4 % more iterations cost 9 % -- 0.318 against 0.292 ms per 1024)
+        const bool lazy = !LOW && !(ka.opt_flags & MPCQP_OPT_EXACT_SELECTION);
+        bool pend = false;
+        for (int a = lane; a < maxq; a += 64) pcv[a] = T(0);
         forward(gx0, N, U0, 0u, nullptr, 0u, col0, sl, 0u);  // h = G (x, u) of the unconstrained minimiser into sl
         wsync();
         tick(4);
@@ -1207,11 +1224,117 @@ __global__ void __launch_bounds__(64)
         bool fail = false, havesel = false, wglob = false, slotsfull = false;
         T nbest = INF, nsp = T(0);
         int nbi = 0x7fffffff;
+        // lazy mode's pass over the m rows: sl += cP hp + sum_a pcv[a] h_a (active rows stay on their bounds), the pending
+        // coefficients are cleared, and the most violated row other than `excl` is selected on the way (ob, oi, osv);
+        // returns the new slack of row `excl`
+        auto gpass = [&](const T *hp, T cP, int excl, T &ob, int &oi, T &osp) -> T {
+            constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
+            ob = INF;
+            oi = 0x7fffffff;
+            T osv = T(0), cap = T(0);
+            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
+                T z[SU], so[SU], iv[SU], th[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
+                    z[u] = hp ? cP * hp[i] : T(0);
+                    so[u] = sl[i];
+                    iv[u] = invn[i];
+                    th[u] = thr[i];
+                }
+                for (int a = 0; a < nq; a += SG) {
+                    T ca[SG], va[SG][SU];
+#pragma unroll
+                    for (int j = 0; j < SG; ++j) {
+                        const int aj = a + j < nq ? a + j : a;
+                        ca[j] = a + j < nq ? pcv[aj] : T(0);
+                        const T *ha = Hs + (int64_t)phys[aj] * M;
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < SG; ++j)
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) z[u] += ca[j] * va[j][u];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + 64 * u;
+                    const T v = (th[u] == INF) ? T(0) : so[u] + z[u];
+                    const T sc = v * iv[u];
+                    if (i < M) {
+                        sl[i] = v;
+                        if (i == excl) cap = v;
+                        if (v < -th[u] && i != excl && sc < ob) {
+                            ob = sc;
+                            oi = i;
+                            osv = v;
+                        }
+                    }
+                }
+            }
+            lsync();
+            for (int a = lane; a < nq; a += 64) pcv[a] = T(0);
+            lsync();
+            wave_argmin(ob, oi);
+            osp = __shfl(osv, oi & 63);
+            return excl >= 0 ? __shfl(cap, excl & 63) : T(0);
+        };
         for (int round = 0; round < 4 && !fail; ++round) {
             for (;;) {
                 tacc(-1);
                 T best = nbest, sp = nsp;
                 int bi = nbi;
+                int hit = -1;
+                if (lazy && !havesel) {
+                    // the cached rows first, each with its exact slack
+                    // (PER lanes per cached row share its |A| loads: one round trip for all of them)
+                    constexpr int PER = R <= 8 ? 8 : 4;
+                    const int cj = lane / PER, ai = lane % PER;
+                    const int rj = cj < R ? crow[cj] : -1;
+                    T sc = INF, sv = T(0);
+                    {
+                        const unsigned ri = (unsigned)(rj >= 0 ? rj : 0);
+                        T part = T(0);
+                        if (pend && rj >= 0) {
+                            for (int a0 = ai; a0 < nq; a0 += 4 * PER) {
+                                T hv[4], cf[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int a = a0 + u * PER < nq ? a0 + u * PER : a0;
+                                    cf[u] = a0 + u * PER < nq ? pcv[a] : T(0);
+                                    hv[u] = Hs[(int64_t)phys[a] * M + ri];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) part += cf[u] * hv[u];
+                            }
+                        }
+                        const T s_own = sl[ri], th_own = thr[ri], iv_own = invn[ri];
+#pragma unroll
+                        for (int d = 1; d < PER; d <<= 1) part += __shfl_xor(part, d);
+                        const T v = s_own + part;
+                        if (rj >= 0 && ai == 0 && v < -th_own) {
+                            sc = v * iv_own;
+                            sv = v;
+                        }
+                    }
+                    int jl = lane;
+                    wave_argmin(sc, jl);
+                    if (sc < INF) {
+                        best = sc;
+                        hit = jl / PER;
+                        bi = __shfl(rj, jl);
+                        sp = __shfl(sv, jl);
+                        havesel = true;
+                    } else if (pend) {
+                        gpass(nullptr, T(0), -1, nbest, nbi, nsp);  // none of them is violated: the pending sum is applied, all rows looked at
+                        pend = false;
+                        best = nbest;
+                        bi = nbi;
+                        sp = nsp;
+                        havesel = true;
+                    }
+                }
                 if (!havesel) select(best, bi, sp);
                 havesel = false;
                 if (!(best < INF)) {
@@ -1219,8 +1342,7 @@ __global__ void __launch_bounds__(64)
                     break;
                 }
                 tacc(8);
-                int hit;
-                {
+                if (hit < 0) {
                     const unsigned long long hm = __ballot(lane < R && crow[lane < R ? lane : 0] == bi);
                     hit = hm ? (int)__builtin_ctzll(hm) : -1;
                 }
@@ -1303,10 +1425,25 @@ __global__ void __launch_bounds__(64)
                         break;
                     }
                     tacc(12);
-                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
+                    T nbsv = T(0), spcap = T(0);
                     nbest = INF;
                     nbi = 0x7fffffff;
-                    T nbsv = T(0), spcap = T(0);
+                    if (lazy) {
+                        // the step folded into the pending coefficients; a FULL step leaves it at that, a partial one (a row
+                        // is about to leave, and its h_a with it) applies everything now
+                        for (int a = lane; a < nq; a += 64) pcv[a] -= t * rv[a];
+                        lsync();
+                        if (full) {
+                            pend = true;
+                        } else {
+                            T db;
+                            int di;
+                            T ds;
+                            spcap = gpass(hp, t, bi, db, di, ds);
+                            pend = false;
+                        }
+                    } else
+                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
                     for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                         // every load of the rows' own arrays first (they are needed last), then the slots in groups of
                         // SG with all their loads in flight together: what a pass costs is its dependent round trips
@@ -1351,7 +1488,7 @@ __global__ void __launch_bounds__(64)
                             }
                         }
                     }
-                    sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
+                    sp = lazy ? spcap : __shfl(spcap, bi & 63);  // the candidate's slack after the step
                     // ---- multipliers
                     for (int a = lane; a < nq; a += 64) {
                         const T v = lamv[a] - t * rv[a];
@@ -1387,6 +1524,7 @@ __global__ void __launch_bounds__(64)
                             phys[nq] = cslot[hit];
                             cslot[hit] = freel[nfree - 1];
                             crow[hit] = -1;
+                            pcv[nq] = lazy ? t : T(0);  // (lazy: this step's own move along h_p is pending as well)
                         }
                         if (lane == (bi & 63)) {  // (the row's owner)
                             thr[bi] = INF;
@@ -1395,9 +1533,11 @@ __global__ void __launch_bounds__(64)
                         ++nq;
                         --nfree;
                         added = true;
-                        wave_argmin(nbest, nbi);
-                        nsp = __shfl(nbsv, nbi & 63);
-                        havesel = true;
+                        if (!lazy) {
+                            wave_argmin(nbest, nbi);
+                            nsp = __shfl(nbsv, nbi & 63);
+                            havesel = true;
+                        }
                     } else {
                         // partial step: index l leaves; W is deflated, the last index moves into the hole, its slot is free
                         const int last = nq - 1, rowl = actrow[l];
@@ -2034,7 +2174,7 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     // + c, r, multipliers, active rows, slot permutation, the sweeps' rows; FUSE: + the candidates' slots, the free list
     // and the 32 x 33 tile of W
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64 +
-                       (FUSE ? (size_t)(RR + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) : 0) +
+                       (FUSE ? (size_t)(RR + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) + (size_t)maxq * sizeof(T) : 0) +
                        (size_t)RR * sizeof(int);
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     if (lds > 48 * 1024) {

@@ -144,14 +144,15 @@ def test_wide_stagewise_active_set_warm_start_same_plans_fewer_sweeps():
     for the same batch, for perturbed states, for garbage ids; and the re-solve must not be slower than the cold one."""
     import time
 
-    from qpmpc_amd import PreparedSolve, WarmState
+    from qpmpc_amd import PreparedSolve, WarmState, _capi
     from qpmpc_amd import workloads as W
 
     w = W.synthetic_ltv_batch(256)
     for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
         bp_c, bp_w = W.to_batch_problem(w, dtype=dtype), W.to_batch_problem(w, dtype=dtype)
         ws = WarmState(bp_w)
-        cold, warm = PreparedSolve(bp_c), PreparedSolve(bp_w, warm_state=ws)
+        # (MPCQP_OPT_EXACT_SELECTION: under the default rule -- lazy slacks -- the rows that ride along do steer the selection)
+        cold, warm = PreparedSolve(bp_c, flags=_capi.OPT_EXACT_SELECTION), PreparedSolve(bp_w, warm_state=ws, flags=_capi.OPT_EXACT_SELECTION)
         g = torch.Generator(device="cuda").manual_seed(2)
         x0 = bp_c.initial_state.clone()
         for period in range(4):
