@@ -34,16 +34,33 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 #include "mpcqp_plant.h"
 
 namespace mpcqp {
 
+// (developer knob: tools/ab_unit.sh builds variants)
+#ifndef STAGE_SRD
+#define STAGE_SRD 4
+#endif
+#ifndef STAGE_DBG
+#define STAGE_DBG 0 /* timing experiments only (wrong results): 1 no re-requests, 2 no stores, 4 no arithmetic in the serial sweeps */
+#endif
+
 namespace stage {
 
 constexpr int kSerialMaxN = 128;  // horizons up to here take the serial sweeps of the LQR solve (if their factor fits LDS)
-constexpr int serial_fs(int nu) { return (32 + 36 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
+constexpr int serial_fs(int nu) { return (32 + 12 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
+// LDS doubles of a serial instantiation behind the active-set vectors: exchange cells, the image (STAGE_SRD steps of slack on
+// either side: the sweeps request that far ahead without clamping), the feed-forward terms, the targets / the staged trajectory
+// ... and one cell of nu doubles per lane that takes the stores of the lanes whose value is not wanted (no exec masking)
+constexpr int64_t serial_lds_doubles(int N, int nx, int nu)
+{
+    return 32 + 2 * STAGE_SRD * serial_fs(nu) + (int64_t)N * (serial_fs(nu) + nu + nx) + 64 * nu;
+}
 
 struct Ws {  // per-problem workspace carve, in doubles (host-computed, passed by value)
     int64_t Acl, Kg, Sinv, Fimg, ff, U0, X0, s, invn, rowslot, V, XV, W, total;
@@ -108,6 +125,37 @@ template <int CTRL> __device__ __forceinline__ double dpp64(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// acc += (x of lane N of the caller's 16-lane row) * m in ONE instruction (the row broadcast folded into the FMA; the compiler
+// does not do that itself). A register written by a VALU instruction needs two wait states before a DPP read: dpp_ready(x)
+// goes in front of every batch (tools/check_dpp_hazards.py verifies the assembly).
+template <int LANE> __device__ __forceinline__ void fmac_bcast(double &acc, double x, double m)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(LANE));
+}
+__device__ __forceinline__ void dpp_ready(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+// One step of a serial sweep in ONE asm block (nothing is scheduled into it): with x_j = the value of lane 4 j of the row,
+//   a += sum_j x_j ca[j] ;  b[i] += sum_j x_j cb[j NU + i]      (the two or three sums interleaved: dependent FMAs apart)
+#define STAGE_FB(acc, c, n) "v_fmac_f64_dpp " acc ", %[x], " c " row_newbcast:" n " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void sweep_chain(double &a, double (&b)[1], double x, const double (&ca)[4], const double (&cb)[4])
+{
+    asm volatile("s_nop 1\n\t" STAGE_FB("%[a]", "%[a0]", "0") STAGE_FB("%[b]", "%[b0]", "0") STAGE_FB("%[a]", "%[a1]", "4")
+                     STAGE_FB("%[b]", "%[b1]", "4") STAGE_FB("%[a]", "%[a2]", "8") STAGE_FB("%[b]", "%[b2]", "8")
+                         STAGE_FB("%[a]", "%[a3]", "12") STAGE_FB("%[b]", "%[b3]", "12")
+                 : [a] "+v"(a), [b] "+v"(b[0])
+                 : [x] "v"(x), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]), [b1] "v"(cb[1]),
+                   [b2] "v"(cb[2]), [b3] "v"(cb[3]));
+}
+__device__ __forceinline__ void sweep_chain(double &a, double (&b)[2], double x, const double (&ca)[4], const double (&cb)[8])
+{
+    asm volatile("s_nop 1\n\t" STAGE_FB("%[a]", "%[a0]", "0") STAGE_FB("%[b]", "%[b0]", "0") STAGE_FB("%[c]", "%[c0]", "0")
+                     STAGE_FB("%[a]", "%[a1]", "4") STAGE_FB("%[b]", "%[b1]", "4") STAGE_FB("%[c]", "%[c1]", "4")
+                         STAGE_FB("%[a]", "%[a2]", "8") STAGE_FB("%[b]", "%[b2]", "8") STAGE_FB("%[c]", "%[c2]", "8")
+                             STAGE_FB("%[a]", "%[a3]", "12") STAGE_FB("%[b]", "%[b3]", "12") STAGE_FB("%[c]", "%[c3]", "12")
+                 : [a] "+v"(a), [b] "+v"(b[0]), [c] "+v"(b[1])
+                 : [x] "v"(x), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]), [b1] "v"(cb[2]),
+                   [b2] "v"(cb[4]), [b3] "v"(cb[6]), [c0] "v"(cb[1]), [c1] "v"(cb[3]), [c2] "v"(cb[5]), [c3] "v"(cb[7]));
+}
+#undef STAGE_FB
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // (value, index) arg-min over the wavefront; ties -> lowest index; every lane gets the result
 __device__ __forceinline__ void wave_argmin(double &v, int &idx) { wave_argmin_dpp(v, idx); }
@@ -196,14 +244,16 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     double *cv = (double *)stage_smem, *rv = cv + maxq, *lamv = rv + maxq;
     int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
     // SERIAL: the factor of every step stays in LDS -- the serial sweeps read nothing else, and nothing of it goes to the
-    // workspace -- already in the ROTATED order in which quad q of a 16-lane row consumes it (16-byte reads):
-    //   FA  Arow[q][t] = Acl[q][(q-t)%4]      FAT Acol[q][t] = Acl[(q-t)%4][q]
-    //   FKR Krot[q][t][i] = K[i][(q-t)%4]     FBR Brot[q][t][i] = B[(q-t)%4][i]      FBO B[q][i]      FSI S^-1
-    constexpr int FA = 0, FAT = 16, FKR = 32, FBR = FKR + 16 * NU, FBO = FBR + 16 * NU, FSI = FBO + 4 * NU;
-    constexpr int FS = (FSI + NU * NU + 1) & ~1;
+    // workspace -- in the order in which quad q of a 16-lane row consumes it (16-byte reads):
+    //   FA  Acl[q][j]     FAT Acl[j][q]     (row q / column q: four values per quad)
+    //   FKN -K[i][j] at j NU + i     FBS -(S^-1 B')[i][j] at j NU + i     (the same 4 NU values for every lane)
+    //   FBO B[q][i]      FSI S^-1
+    constexpr int FA = 0, FAT = 16, FKN = 32, FBS = FKN + 4 * NU, FBO = FBS + 4 * NU, FSI = FBO + 4 * NU;
+    constexpr int FS = serial_fs(NU);
+    static_assert(FS >= FSI + NU * NU && (FS & 1) == 0, "factor image");
     typedef double D2 __attribute__((ext_vector_type(2)));
     double *rsc = (double *)(actr + maxq);  // 32 doubles of exchange for the factor (32 maxq bytes precede it: 16-byte aligned)
-    double *Fl = rsc + 32;
+    double *Fl = rsc + 32 + STAGE_SRD * FS;  // (SRD steps of slack below the image and above the targets: serial_lds_doubles)
     double *ffl = Fl + N * FS;             // ... and the feed-forward terms of the latest backward sweep (N x NU)
     double *tgl = ffl + N * NU;            // ... and the targets of the tracking sweep (N x NX)
     // ---- workspace
@@ -240,7 +290,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
     const bool reuse = PIPE ? !factor_wave : (ka.opt_flags & MPCQP_OPT_REUSE_FACTOR) != 0;
     const bool keep = !PIPE && (ka.opt_flags & MPCQP_OPT_KEEP_FACTOR);
-    if constexpr (PIPE) rsc += 32 + (int64_t)N * (FS + NU + NX);  // (the factor wavefront's own exchange cells, after everything)
+    if constexpr (PIPE) rsc += serial_lds_doubles(N, NX, NU);  // (the factor wavefront's own exchange cells, after everything)
     tick(factor_wave ? 9 : 0);
     // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
     double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
@@ -394,17 +444,21 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                     // every one of the 16 lanes writes its entry of each rotated image (zero outside NX x NX); PIPE: straight
                     // into the next launch's image in the workspace (the LDS image belongs to the solving wavefront)
                     double *f = (PIPE ? img_next : Fl) + k * FS;
-                    const int rc = (r - c) & 3, cr = (c - r) & 3;
-                    f[FA + r * 4 + rc] = in ? Acl_rc : 0.0;
-                    f[FAT + c * 4 + cr] = in ? Acl_rc : 0.0;
+                    f[FA + r * 4 + c] = in ? Acl_rc : 0.0;
+                    f[FAT + c * 4 + r] = in ? Acl_rc : 0.0;
+                    if (r == 0) {
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
-                        f[FKR + (r * 4 + rc) * NU + u] = inc ? Kk[u] : 0.0;      // K[u][c], read by quad r at t = r - c
-                        f[FBR + (c * 4 + cr) * NU + u] = inr ? Br[u] : 0.0;      // B[r][u], read by quad c at t = c - r
+                        for (int u = 0; u < NU; ++u) f[FKN + c * NU + u] = inc ? -Kk[u] : 0.0;  // K[u][c]
                     }
                     if (c == 0) {
 #pragma unroll
-                        for (int u = 0; u < NU; ++u) f[FBO + r * NU + u] = inr ? Br[u] : 0.0;
+                        for (int u = 0; u < NU; ++u) {
+                            double bsv = 0.0;  // -(S^-1 B')[u][r]: the backward sweep's feed-forward row, S^-1 folded in here
+#pragma unroll
+                            for (int v = 0; v < NU; ++v) bsv -= Si[u * NU + v] * Br[v];  // Br[0 * NU + v] = B[r][v]
+                            f[FBS + r * NU + u] = inr ? bsv : 0.0;
+                            f[FBO + r * NU + u] = inr ? Br[u] : 0.0;
+                        }
                     }
                     if (lane == 0) {
 #pragma unroll
@@ -498,7 +552,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
         }
     }
     tick(1);
-    // Short horizons run the two sweeps of an LQR solve SERIALLY (below): ~100 cycles per step with the vector spread
+    // Short horizons run the two sweeps of an LQR solve SERIALLY (below): ~165 cycles per step with the vector spread
     // over the quads of a 16-lane row beat the chunked scans (and their 15 k cycles of prefix products) up to here.
     constexpr bool serial = SERIAL;  // (a template parameter: the scans' prefix matrices must not stay live here)
     // chunk transition matrix Phi_j = Acl_{k1-1} ... Acl_{k0} of this lane's chunk (identity if empty)
@@ -802,176 +856,196 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
             for (int i = 0; i < NX; ++i) x[i] = nx_[i];
         }
     };
-    // ---- the same two sweeps, serial in k (N <= kSerialMaxN). Lane layout as in the factor: quad q = (lane / 4) % 4 of a
-    // 16-lane row owns component q of the running vector and keeps the whole vector in ROTATED order, vr[t] =
-    // v[(q - t) mod 4] (three DPP row rotations of the new component after every step); the step's matrix entries are
-    // fetched from the workspace in that order, three steps ahead. No LDS, no scan, ~4 dependent FMAs per step.
+    // ---- the same two sweeps, serial in k (N <= kSerialMaxN). Quad q = (lane / 4) % 4 of every 16-lane row owns component q of
+    // the running vector (the four rows run the same stream), so "component j" is the value of lane 4 j of the row, and a term
+    // of the step's dot products is ONE instruction: v_fmac_f64_dpp row_newbcast:4j (the broadcast folded into the FMA; no
+    // rotations, nothing of the vector in LDS). The step's coefficients come from the LDS image, requested STAGE_SRD steps
+    // ahead through running pointers (no clamping: the image has that many steps of slack on either side); S^-1 is folded
+    // into the feed-forward rows by the factor; nothing is stored under an exec mask. 22 instructions per step, ~165 cycles
+    // (one wavefront per SIMD: a step costs what its instructions issue, 56 of them the eight dependent FMAs --
+    // tools/ubench/dpp_rate.hip). Round 4; before: the vector in rotated order in every lane, three DPP rotations and two
+    // masked stores per step, ~55 instructions, 370-540 cycles.
     const int sq = (lane >> 2) & 3;
     const bool sqin = sq < NX;
-    int srow[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) srow[t] = (sq - t) & 3;
-    auto rot4 = [&](double x, int t) {
-        switch (t) {
-        case 0: return x;
-        case 1: return dpp64<0x124>(x);
-        case 2: return dpp64<0x128>(x);
-        default: return dpp64<0x12c>(x);
-        }
-    };
-    constexpr int SRD = 2;  // request distance of the serial sweeps (their operands sit in LDS)
-    auto backward_s = [&](int kq, const double *crow, const double *drow, bool track) {
-        double own = (track && termQ && sqin) ? -ka.wt * ggoal[sq] : 0.0, pr[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pr[t] = rot4(own, t);
-        const bool tgt = track && stageQ;
-        if (tgt) {  // the targets come through LDS: one coalesced round trip instead of a request per step
+    constexpr int SRD = STAGE_SRD;  // request distance of the serial sweeps, in steps (their operands sit in LDS: ~100+ cycles, a step is ~80)
+    // A value that only one lane (or one lane per quad) has to store is stored by EVERY lane, each to an address of its own:
+    // the wanted lanes walk the array, the others hit their cell of `junkl` (a masked store costs the wavefront two exec
+    // writes and a branch in the middle of a ~20-instruction step).
+    double *junkl = tgl + N * NX + STAGE_SRD * FS + lane * NU;
+    // TRACK: the sweep of the unconstrained minimiser (terminal costate, targets); otherwise the costate of ONE row (kq, crow, drow):
+    // zero above its step, the row itself at its step -- that step is formed directly, the loop starts below it
+    auto backward_s = [&](int kq, const double *crow, const double *drow, auto trackc) {
+        constexpr bool track = decltype(trackc)::value;
+        double own;
+        int kstart;
+        if constexpr (track) {
+            own = (termQ && sqin) ? -ka.wt * ggoal[sq] : 0.0;
+            kstart = N - 1;
+            // the targets come through LDS, already scaled (-w_x target; step 0 carries no state cost): one coalesced round
+            // trip instead of a request per step, and the step starts its sum from them
+            const bool tgt = stageQ;
+            const double mwx = -ka.wx;
             for (int i0 = lane; i0 < N * NX; i0 += 64 * 4) {
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = gtgt[i0 + 64 * u < N * NX ? i0 + 64 * u : N * NX - 1];
+                for (int u = 0; u < 4; ++u) v[u] = tgt ? gtgt[i0 + 64 * u < N * NX ? i0 + 64 * u : N * NX - 1] : 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i0 + 64 * u < N * NX) tgl[i0 + 64 * u] = v[u];
+                    if (i0 + 64 * u < N * NX) tgl[i0 + 64 * u] = (i0 + 64 * u >= NX) ? mwx * v[u] : 0.0;
             }
             wsync();
+        } else {
+            const double *f = Fl + kq * FS;
+            double pn = 0.0;
+            if (crow && sqin) pn -= crow[sq];
+            double dv[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                dv[i] = drow ? drow[i] : 0.0;
+                pn -= f[FKN + sq * NU + i] * dv[i];  // - K' r with r = -D row   (FKN holds -K[i][q])
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int l = 0; l < NU; ++l) a += f[FSI + i * NU + l] * dv[l];
+                    ffl[kq * NU + i] = a;
+                }
+            }
+            // (the feed-forward terms above the row's step count as zero in the forward sweep)
+            for (int i = (kq + 1) * NU + lane; i < N * NU; i += 64) ffl[i] = 0.0;
+            own = sqin ? pn : 0.0;
+            kstart = kq - 1;
         }
-        const double *tp = tgl;
-        const int kstart = track ? N - 1 : kq;  // the costate of a single row is zero above its step
-        double at[SRD][4], bt[SRD][4 * NU], si[SRD][NU * NU], tg[SRD];
-        auto req = [&](int d, int k) {
-            const double *f = Fl + k * FS;
-            const D2 *a2 = (const D2 *)(f + FAT + sq * 4), *b2 = (const D2 *)(f + FBR + sq * 4 * NU);
+        double at[SRD][4], bs[SRD][4 * NU], tg[SRD];
+        const double *fq = Fl + FAT + sq * 4 + kstart * FS, *tq = tgl + ((NX == 4 || sqin) ? sq : 0) + kstart * NX;
+        double *fw = lane == 0 ? ffl + kstart * NU : junkl;  // where this lane stores the step's feed-forward term
+        const int fws = lane == 0 ? -NU : 0;
+        auto req = [&](int d, const double *f, const double *t) {
+            const D2 *a2 = (const D2 *)f, *b2 = (const D2 *)(f + (FBS - FAT - sq * 4));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const D2 v = a2[h];  // Acl[(q - t)][q], t = 2h, 2h + 1
+                const D2 v = a2[h];  // Acl[j][q], j = 2h, 2h + 1
                 at[d][2 * h] = v[0];
                 at[d][2 * h + 1] = v[1];
             }
 #pragma unroll
             for (int h = 0; h < 2 * NU; ++h) {
-                const D2 v = b2[h];  // B[(q - t)][i] at index t NU + i
-                bt[d][2 * h] = v[0];
-                bt[d][2 * h + 1] = v[1];
+                const D2 v = b2[h];  // -(S^-1 B')[i][j] at index j NU + i
+                bs[d][2 * h] = v[0];
+                bs[d][2 * h + 1] = v[1];
             }
-#pragma unroll
-            for (int i = 0; i < NU * NU; ++i) si[d][i] = f[FSI + i];
-            if (tgt) tg[d] = tp[k * NX + (sqin ? sq : 0)];
+            if constexpr (track) tg[d] = *t;
         };
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
-            req(d, kstart - d >= 0 ? kstart - d : 0);
+            req(d, fq - d * FS, tq - d * NX);
             __builtin_amdgcn_sched_barrier(0);
         }
-        auto step = [&](int d, int k, bool again) {
-            double tt[NU], pn = 0.0;
+        fq -= SRD * FS;  // (the pointers run SRD steps ahead of the step that computes)
+        tq -= SRD * NX;
+        auto step = [&](int d, bool again) {
+            double pn = track ? tg[d] : 0.0, fn[NU];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) tt[i] = 0.0;
+            for (int i = 0; i < NU; ++i) fn[i] = 0.0;
+            if (!(STAGE_DBG & 4)) sweep_chain(pn, fn, own, at[d], bs[d]);
+            if (!(STAGE_DBG & 2)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                pn += at[d][t] * pr[t];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) tt[i] += bt[d][t * NU + i] * pr[t];
+                for (int i = 0; i < NU; ++i) fw[i] = fn[i];
+                fw += fws;
             }
-            if (tgt && k >= 1 && sqin) pn -= ka.wx * tg[d];
-            if (k == kq) {
-                const double *Kq = Fl + k * FS + FKR + sq * 4 * NU;  // Krot[q][0][i] = K[i][q]
-                if (crow && sqin) pn -= crow[sq];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const double dv = drow ? drow[i] : 0.0;
-                    tt[i] -= dv;
-                    pn += Kq[i] * dv;  // - K' r with r = -D row
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                double a = 0.0;
-#pragma unroll
-                for (int l = 0; l < NU; ++l) a -= si[d][i * NU + l] * tt[l];
-                if (lane == 0) ffl[k * NU + i] = a;
-            }
-            own = pn;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) pr[t] = rot4(own, t);
-            if (again) req(d, k - SRD >= 0 ? k - SRD : 0);
+            own = (NX == 4 || sqin) ? pn : 0.0;
+            if (again && !(STAGE_DBG & 1)) req(d, fq, tq);
+            fq -= FS;
+            tq -= NX;
         };
         int k = kstart;
         for (int g = (kstart + 1) / SRD; g > 0; --g) {
 #pragma unroll
-            for (int d = 0; d < SRD; ++d) step(d, k - d, true);
+            for (int d = 0; d < SRD; ++d) step(d, true);
             k -= SRD;
         }
 #pragma unroll
         for (int d = 0; d < SRD - 1; ++d)
-            if (k - d >= 0) step(d, k - d, false);
+            if (k - d >= 0) step(d, false);
     };
-    // (kff: the feed-forward terms above step kff were not written by the sweep before and count as zero)
-    auto forward_s = [&](const double *xs, int kff, double *Uo, double *Xo) {
-        double own = (xs && sqin) ? xs[sq] : 0.0, xr[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xr[t] = rot4(own, t);
-        double at[SRD][4], kt[SRD][4 * NU], bo[SRD][NU], ff[SRD][NU];
-        auto req = [&](int d, int k) {
-            const double *f = Fl + k * FS, *fk = ffl + k * NU;
-            const D2 *a2 = (const D2 *)(f + FA + sq * 4), *k2 = (const D2 *)(f + FKR + sq * 4 * NU);
+    // The trajectory is staged in LDS while the sweep runs (x_k over the targets, u_k over the feed-forward term it was formed
+    // from: both are dead by then); the lanes copy their chunks to the workspace arrays (Uo, Xo) in one coalesced pass
+    // afterwards. (The feed-forward terms above a single row's step were zeroed by its backward sweep.)
+    double *xl = tgl, *ul = ffl;
+    auto forward_s = [&](const double *xs, double *Uo, double *Xo) {
+        double own = (xs && sqin) ? xs[sq] : 0.0;
+        double ar[SRD][4], kn[SRD][4 * NU], bo[SRD][NU], ff[SRD][NU];
+        const double *fq = Fl + FA + sq * 4, *fk = ffl;
+        const bool xwl = lane < 16 && (lane & 3) == 0 && sqin;
+        double *xw = xwl ? xl + sq : junkl, *uw = lane == 0 ? ul : junkl;
+        const int xws = xwl ? NX : 0, uws = lane == 0 ? NU : 0;
+        auto req = [&](int d, const double *f, const double *fkk) {
+            const D2 *a2 = (const D2 *)f, *k2 = (const D2 *)(f + (FKN - FA - sq * 4));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const D2 v = a2[h];  // Acl[q][(q - t)]
-                at[d][2 * h] = v[0];
-                at[d][2 * h + 1] = v[1];
+                const D2 v = a2[h];  // Acl[q][j]
+                ar[d][2 * h] = v[0];
+                ar[d][2 * h + 1] = v[1];
             }
 #pragma unroll
             for (int h = 0; h < 2 * NU; ++h) {
-                const D2 v = k2[h];  // K[i][(q - t)] at index t NU + i
-                kt[d][2 * h] = v[0];
-                kt[d][2 * h + 1] = v[1];
+                const D2 v = k2[h];  // -K[i][j] at index j NU + i
+                kn[d][2 * h] = v[0];
+                kn[d][2 * h + 1] = v[1];
             }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                bo[d][i] = f[FBO + sq * NU + i];
-                ff[d][i] = fk[i];
+                bo[d][i] = f[FBO - FA - sq * 4 + sq * NU + i];
+                ff[d][i] = fkk[i];
             }
         };
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
-            req(d, d < N ? d : N - 1);
+            req(d, fq + d * FS, fk + d * NU);
             __builtin_amdgcn_sched_barrier(0);
         }
-        auto step = [&](int d, int k, bool again) {
+        fq += SRD * FS;
+        fk += SRD * NU;
+        auto step = [&](int d, bool again) {
+            if (!(STAGE_DBG & 2)) {
+                *xw = own;
+                xw += xws;
+            }
             double xn = 0.0, u[NU];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const double f = (k <= kff) ? ff[d][i] : 0.0;
-                u[i] = f;
-                xn += bo[d][i] * f;
+                u[i] = ff[d][i];
+                xn += bo[d][i] * u[i];
             }
+            if (!(STAGE_DBG & 4)) sweep_chain(xn, u, own, ar[d], kn[d]);
+            if (!(STAGE_DBG & 2)) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xn += at[d][t] * xr[t];
-#pragma unroll
-                for (int i = 0; i < NU; ++i) u[i] -= kt[d][t * NU + i] * xr[t];
+                for (int i = 0; i < NU; ++i) uw[i] = u[i];
+                uw += uws;
             }
-            const int64_t w = wg(k);
-            if (lane < 16 && (lane & 3) == 0 && sqin) Xo[w * NX + sq] = own;
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) Uo[w * NU + i] = u[i];
-            }
-            own = xn;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) xr[t] = rot4(own, t);
-            if (again) req(d, k + SRD < N ? k + SRD : N - 1);
+            own = (NX == 4 || sqin) ? xn : 0.0;
+            if (again && !(STAGE_DBG & 1)) req(d, fq, fk);
+            fq += FS;
+            fk += NU;
         };
         int k = 0;
         for (int g = N / SRD; g > 0; --g) {
 #pragma unroll
-            for (int d = 0; d < SRD; ++d) step(d, k + d, true);
+            for (int d = 0; d < SRD; ++d) step(d, true);
             k += SRD;
         }
 #pragma unroll
         for (int d = 0; d < SRD - 1; ++d)
-            if (k + d < N) step(d, k + d, false);
+            if (k + d < N) step(d, false);
+        lsync();
+        for (int kk = k0; kk < k1; ++kk) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) Uo[wq(kk) * NU + i] = ul[kk * NU + i];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) Xo[wq(kk) * NX + i] = xl[kk * NX + i];
+        }
     };
     // g_(k,r) . (U, X) = C_k[r] x_k + D_k[r] u_k
     auto gdot = [&](int k, int64_t w, int r, const double *Uv, const double *Xv) {  // w = workspace index of step k
@@ -996,7 +1070,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     tick(2);
     if (!notpd) {
         if constexpr (serial)
-            backward_s(-1, nullptr, nullptr, true);
+            backward_s(-1, nullptr, nullptr, std::true_type{});
         else
             backward(-1, zero_row, zero_row, true);
     }
@@ -1004,7 +1078,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     tick(3);
     if (!notpd) {
         if constexpr (serial)
-            forward_s(gx0, N, U0, X0);
+            forward_s(gx0, U0, X0);
         else
             forward(gx0, U0, X0);
     }
@@ -1019,14 +1093,17 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     bool presel = SERIAL;  // (the long-horizon instantiations have no registers to spare for it: 254 VGPRs)
 #pragma unroll
     for (int i = 0; i < NU; ++i) u_first[i] = 0.0;
+    // (SERIAL: the trajectory is still staged in LDS, in step order -- no wait for the workspace copy to come back)
+    const double *Us = SERIAL ? ul : U0, *Xs = SERIAL ? xl : X0;
     for (int k = k0; k < (notpd ? k0 : k1); ++k) {
+        const int64_t wk = SERIAL ? (int64_t)k : wq(k);
         if (SERIAL && k == k0)
 #pragma unroll
-            for (int i = 0; i < NU; ++i) u_first[i] = U0[wq(k) * NU + i];
+            for (int i = 0; i < NU; ++i) u_first[i] = Us[wk * NU + i];
         for (int r = 0; r < mk; ++r) {
             const int64_t i = wq(k) * mk + r;
             const double ev = ge[k * sE + r];
-            const double sv = ev - gdot(k, wq(k), r, U0, X0);
+            const double sv = ev - gdot(k, wk, r, Us, Xs);
             sl[i] = sv;
             double nn = 0.0;
             if (gC)
@@ -1258,12 +1335,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
             bool added = false;
             // V_p = P^-1 g_p' and its trajectory do not change while p waits for room: solved once
             if constexpr (serial)
-                backward_s(kp, gC ? gC + kp * sC + rp * NX : nullptr, gD ? gD + kp * sD + rp * NU : nullptr, false);
+                backward_s(kp, gC ? gC + kp * sC + rp * NX : nullptr, gD ? gD + kp * sD + rp * NU : nullptr, std::false_type{});
             else
                 backward(kp, qrow, rrow, false);
             wsync();
             if constexpr (serial)
-                forward_s(nullptr, kp, Vp, Xp);
+                forward_s(nullptr, Vp, Xp);
             else
                 forward(nullptr, Vp, Xp);
             wsync();
@@ -1522,7 +1599,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
-    if (SERIAL) lds += (size_t)ka.N * (serial_fs(NU) + NU + NX) * sizeof(double);
+    if (SERIAL) lds += (size_t)(serial_lds_doubles(ka.N, NX, NU) - 32) * sizeof(double);
     if (PIPE) lds += (32 + (size_t)ka.N * (NX * NX + NX * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands
     auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE, WARM>;
     if (lds > 48 * 1024) {
@@ -1537,7 +1614,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
 static bool stage_serial(const KernelArgs &ka)
 {
     // serial sweeps: short horizons whose factor fits 32 KB of LDS next to the active-set vectors
-    return ka.N <= kSerialMaxN && (size_t)ka.N * (serial_fs(ka.nu) + ka.nu + ka.nx) * sizeof(double) <= 40 * 1024;
+    return ka.N <= kSerialMaxN && (size_t)serial_lds_doubles(ka.N, ka.nx, ka.nu) * sizeof(double) <= 40 * 1024;
 }
 
 // MPCQP_OPT_PIPELINE_FACTOR needs the factor image of the serial instantiations

@@ -56,6 +56,56 @@ template <int MODE> __global__ void k(double *out, long long *cyc, double xin, d
                 double s = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 3), __builtin_amdgcn_readlane(__double2loint(x), 3));
                 asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc[i]) : "s"(s), "v"(m));
             }
+        } else if (MODE >= 10 && MODE <= 15) {
+            // the serial sweep's step: x_next = c + sum_j bcast_j(x) a_j, a second sum f interleaved; NACC/2 steps per iteration
+#pragma unroll
+            for (int i = 0; i < NACC / 2; ++i) {
+                double pn = acc[1], fn = 0.0, p2 = 0.0;
+                if (MODE == 10) {  // one dependent sum of four + interleaved second sum (what the kernel runs)
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %2, %3 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %2, %3 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %2, %3 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(pn), "+v"(fn) : "v"(x), "v"(m));
+                } else if (MODE == 11) {  // the same without DPP
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %3\n\tv_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %3\n\t"
+                                 "v_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %3\n\tv_fmac_f64 %0, %2, %3\n\tv_fmac_f64 %1, %2, %3"
+                                 : "+v"(pn), "+v"(fn) : "v"(x), "v"(m));
+                } else if (MODE == 12) {  // x's sum split in two halves + one add
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %2, %3, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %2, %3, %4 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_add_f64 %0, %0, %2\n\t"
+                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(pn), "+v"(fn), "+v"(p2) : "v"(x), "v"(m));
+                } else if (MODE == 13) {  // only the four dependent DPP FMAs
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(pn) : "v"(x), "v"(m));
+                } else if (MODE == 14) {  // ONE DPP FMA per step (the bare loop-carried latency)
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(pn) : "v"(x), "v"(m));
+                } else {  // 15: one plain FMA per step
+                    asm volatile("s_nop 1\n\tv_fmac_f64 %0, %1, %2" : "+v"(pn) : "v"(x), "v"(m));
+                }
+                x = pn;
+                acc[0] += fn;
+            }
         } else if (MODE == 9) {  // v_fma_f32 for reference
             float a32[NACC];
 #pragma unroll
@@ -99,6 +149,12 @@ int main()
         run<7>("2 x v_mov_b32_dpp + v_add_f64", threads);
         run<8>("2 x v_readlane + v_fmac_f64 sgpr", threads);
         run<9>("v_fmac_f32 (+cvt outside?)", threads);
+        run<10>("sweep step: 4+4 dpp fmac (x2 slots)", threads);
+        run<11>("sweep step: 4+4 plain fmac", threads);
+        run<12>("sweep step: split sum + add", threads);
+        run<13>("sweep step: 4 dependent dpp fmac", threads);
+        run<14>("sweep step: 1 dpp fmac", threads);
+        run<15>("sweep step: 1 plain fmac", threads);
     }
     return 0;
 }
