@@ -156,6 +156,30 @@ __device__ __forceinline__ void sweep_chain(double &a, double (&b)[2], double x,
                    [b2] "v"(cb[4]), [b3] "v"(cb[6]), [c0] "v"(cb[1]), [c1] "v"(cb[3]), [c2] "v"(cb[5]), [c3] "v"(cb[7]));
 }
 #undef STAGE_FB
+// a += sum_j x_j ca[j] ; b += sum_j y_j cb[j]   (two vectors x, y: value of lane 4 j of the row)
+#define STAGE_FB2(acc, src, c, n) "v_fmac_f64_dpp " acc ", " src ", " c " row_newbcast:" n " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void sweep_chain2(double &a, double &b, double x, double y, const double (&ca)[4], const double (&cb)[4])
+{
+    asm volatile("s_nop 1\n\t" STAGE_FB2("%[a]", "%[x]", "%[a0]", "0") STAGE_FB2("%[b]", "%[y]", "%[b0]", "0")
+                     STAGE_FB2("%[a]", "%[x]", "%[a1]", "4") STAGE_FB2("%[b]", "%[y]", "%[b1]", "4")
+                         STAGE_FB2("%[a]", "%[x]", "%[a2]", "8") STAGE_FB2("%[b]", "%[y]", "%[b2]", "8")
+                             STAGE_FB2("%[a]", "%[x]", "%[a3]", "12") STAGE_FB2("%[b]", "%[y]", "%[b3]", "12")
+                 : [a] "+v"(a), [b] "+v"(b)
+                 : [x] "v"(x), [y] "v"(y), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]),
+                   [b1] "v"(cb[1]), [b2] "v"(cb[2]), [b3] "v"(cb[3]));
+}
+#undef STAGE_FB2
+// dst of every lane of the 16-lane row rho <- src of lane 4 rho of that row: four row-masked broadcasts
+__device__ __forceinline__ void row_gather(double &dst, double src)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0x1 bank_mask:0xf\n\t"
+                 "v_mov_b64_dpp %0, %1 row_newbcast:4 row_mask:0x2 bank_mask:0xf\n\t"
+                 "v_mov_b64_dpp %0, %1 row_newbcast:8 row_mask:0x4 bank_mask:0xf\n\t"
+                 "v_mov_b64_dpp %0, %1 row_newbcast:12 row_mask:0x8 bank_mask:0xf"
+                 : "+v"(dst)
+                 : "v"(src));
+}
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // (value, index) arg-min over the wavefront; ties -> lowest index; every lane gets the result
 __device__ __forceinline__ void wave_argmin(double &v, int &idx) { wave_argmin_dpp(v, idx); }
@@ -280,12 +304,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
     // ================================================================= factor: Riccati recursion
-    // Serial in k and nonlinear. The NX x NX matrices are spread over 16 lanes -- lane (r, c) = ((lane / 4) % 4, lane % 4)
-    // holds element [r][c]; the four 16-lane rows of the wavefront do the same work -- and a product gathers its operands
-    // with DPP: a row of the left factor is the lane's quad (quad_perm broadcasts), a column of the right factor sits
-    // in the same position of the four quads (row rotations by 4, 8, 12: rotation t delivers row (r - t) mod 4, so
-    // operands that come from memory are fetched in that order). Only P_k = (PA)' Acl, whose two factors are both needed by
-    // column, goes through an LDS transpose. ~90 instructions per step instead of ~350 executed redundantly by every lane.
+    // Serial in k and nonlinear; the lane layout is described where the recursion starts (below).
     // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
     // (MPCQP_OPT_KEEP_FACTOR): the recursion is skipped -- build once, re-solve (mpc_qp.py:129-163 usage).
     const bool reuse = PIPE ? !factor_wave : (ka.opt_flags & MPCQP_OPT_REUSE_FACTOR) != 0;
@@ -307,68 +326,89 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     // still make P indefinite). A pivot that is not positive -> MPCQP_NOT_PD, like the condensed kernels' Cholesky.
     bool notpd = false;
     if (!reuse) {
-        const int r = (lane >> 2) & 3, c = lane & 3;
-        const bool inr = r < NX, inc = c < NX, in = inr && inc;
-        auto q4 = [&](double x, int l) {  // element l of the lane's quad (l: compile-time after unrolling)
-            switch (l) {
-            case 0: return dpp64<0x00>(x);
-            case 1: return dpp64<0x55>(x);
-            case 2: return dpp64<0xaa>(x);
-            default: return dpp64<0xff>(x);
-            }
-        };
-        auto rot = [&](double x, int t) {  // the same position of the quad t below (cyclically): row (r - t) mod 4
-            switch (t) {
-            case 0: return x;
-            case 1: return dpp64<0x124>(x);
-            case 2: return dpp64<0x128>(x);
-            default: return dpp64<0x12c>(x);
-            }
-        };
-        int rrow[4];  // (r - t) mod 4
-#pragma unroll
-        for (int t = 0; t < 4; ++t) rrow[t] = (r - t) & 3;
-        double P = (in && r == c) ? wt : 0.0;  // P[r][c]
+        // (round 4) Every 4 x 4 matrix is spread over ALL 64 lanes by COLUMN: the 16-lane row rho = lane / 16 holds column rho, its
+        // quad q = (lane / 4) % 4 element [q][rho] (four copies) -- the layout of a serial sweep's vector, once per column. A
+        // product M' v of a matrix known by its coefficients (A, B: from memory; A_cl: formed in registers) with a column held
+        // this way is four v_fmac_f64_dpp row_newbcast (sweep_chain), all four columns at once:
+        //   rows of P A and P B from P's columns (P is symmetric) -> the four P B through v_readlane into scalars -> S, B'PA, K
+        //   by FMAs with a scalar operand, identical in every lane -> K_rho by four row-masked DPP moves -> A_cl ->
+        //   P_k = Q + A_cl' (P A), whose right factor is needed by column: ONE 8-byte LDS write + five reads per lane, issued
+        //   right after the first product and hidden behind everything up to the last. ~85 instructions per step, no exec masking
+        //   (every store is unmasked: the copies of a value are bitwise equal), against ~140 with DPP rotations, quad
+        //   broadcasts, masked stores and register copies before.
+        const int rho = lane >> 4, q = (lane >> 2) & 3;
+        const bool inq = q < NX, inr = rho < NX, in = inq && inr;
+        double P = (in && q == rho) ? wt : 0.0;  // P[q][rho]
         // operands are requested RD steps ahead into a register ring (a step is shorter than an HBM round trip)
         constexpr int RD = 3;
-        double Acn[RD][NX], Ann[RD], Bfn[RD][NX * NU], Brn[RD][4 * NU];  // column c of A; A[r][c]; B; B[(r - t) mod 4][.]
+        double Acn[RD][4], Ann[RD], Bln[RD][4 * NU], Bqn[RD][NU];  // A[l][q]; A[q][rho]; B[l][u] at l NU + u; B[q][u]
         // PIPE: the factor wavefront writes its factor to the WORKSPACE, and a load issued behind those stores would wait for
-        // them (vector memory operations retire in order): the operands come through LDS instead, one bulk copy up front
-        const double *rA = gA, *rB = gB;
+        // them (vector memory operations retire in order): the operands come through LDS instead, one bulk copy up front --
+        // A transposed and both padded to four rows (zeros), so that a lane's values are two 16-byte reads
+        const double *la = rsc + 32, *lb = la;
+        const int sAl = sA ? 16 : 0, sBl = sB ? 4 * NU : 0;
         if constexpr (PIPE) {
-            double *la = rsc + 32, *lb = la + (int64_t)N * NX * NX;
-            const int na = (sA ? N : 1) * NX * NX, nb = (sB ? N : 1) * NX * NU;
+            double *wa = rsc + 32;
+            const int na = (sA ? N : 1) * 16, nb = (sB ? N : 1) * 4 * NU;
+            double *wb = wa + na;
+            lb = wb;
             for (int i0 = lane; i0 < na; i0 += 64 * 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = gA[i0 + 64 * u < na ? i0 + 64 * u : na - 1];
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + 64 * u < na ? i0 + 64 * u : na - 1;
+                    const int kk = i >> 4, cc = (i >> 2) & 3, rr = i & 3;  // la[k][c][r] = A_k[r][c]
+                    v[u] = (rr < NX && cc < NX) ? gA[(int64_t)kk * sA + rr * NX + cc] : 0.0;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (i0 + 64 * u < na) la[i0 + 64 * u] = v[u];
+                    if (i0 + 64 * u < na) wa[i0 + 64 * u] = v[u];
             }
             for (int i0 = lane; i0 < nb; i0 += 64 * 4) {
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = gB[i0 + 64 * u < nb ? i0 + 64 * u : nb - 1];
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 64 * u < nb ? i0 + 64 * u : nb - 1;
+                    const int kk = i / (4 * NU), e = i - kk * 4 * NU;  // lb[k][l][u] = B_k[l][u], l < 4
+                    v[u] = e < NX * NU ? gB[(int64_t)kk * sB + e] : 0.0;
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i0 + 64 * u < nb) lb[i0 + 64 * u] = v[u];
+                    if (i0 + 64 * u < nb) wb[i0 + 64 * u] = v[u];
             }
             wsync();
-            rA = la;
-            rB = lb;
         }
         auto request = [&](int d, int k) {
-            const double *A = rA + k * sA, *B = rB + k * sB;
+            if constexpr (PIPE) {
+                const double *A = la + k * sAl, *B = lb + k * sBl;
+                const D2 *a2 = (const D2 *)(A + q * 4), *b2 = (const D2 *)B;
 #pragma unroll
-            for (int l = 0; l < NX; ++l) Acn[d][l] = inc ? A[l * NX + c] : 0.0;
-            Ann[d] = in ? A[r * NX + c] : 0.0;
+                for (int h = 0; h < 2; ++h) {
+                    const D2 v = a2[h];
+                    Acn[d][2 * h] = v[0];
+                    Acn[d][2 * h + 1] = v[1];
+                }
+                Ann[d] = A[rho * 4 + q];
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bfn[d][i] = B[i];
+                for (int h = 0; h < 2 * NU; ++h) {
+                    const D2 v = b2[h];
+                    Bln[d][2 * h] = v[0];
+                    Bln[d][2 * h + 1] = v[1];
+                }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int u = 0; u < NU; ++u) Bqn[d][u] = B[q * NU + u];
+            } else {
+                const double *A = gA + k * sA, *B = gB + k * sB;
 #pragma unroll
-                for (int u = 0; u < NU; ++u) Brn[d][t * NU + u] = rrow[t] < NX ? B[rrow[t] * NU + u] : 0.0;
+                for (int l = 0; l < 4; ++l) Acn[d][l] = (l < NX && inq) ? A[l * NX + q] : 0.0;
+                Ann[d] = in ? A[q * NX + rho] : 0.0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) Bln[d][l * NU + u] = l < NX ? B[l * NU + u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) Bqn[d][u] = inq ? B[q * NU + u] : 0.0;
+            }
         };
 #pragma unroll
         for (int d = 0; d < RD; ++d) {
@@ -376,27 +416,24 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
             __builtin_amdgcn_sched_barrier(0);
         }
         auto step = [&](int d, int k) {
-            double Ac[NX], Aown, Bf[NX * NU], Br[4 * NU];
+            // rows of P A and of P B: T[q] = (P A)[rho][q], PBr[u] = (P B)[rho][u]
+            double T = 0.0, PBr[NU];
 #pragma unroll
-            for (int l = 0; l < NX; ++l) Ac[l] = Acn[d][l];
-            Aown = Ann[d];
+            for (int u = 0; u < NU; ++u) PBr[u] = 0.0;
+            sweep_chain(T, PBr, P, Acn[d], Bln[d]);
+            // ... P A again by column, for the last product: through LDS, the read comes back while the rest runs
+            rsc[rho * 4 + q] = T;
+            lsync();
+            const double Tq = rsc[q * 4 + rho];  // (P A)[q][rho]
+            double Tc[4];                        // (P A)[l][q]: column q, for the mirrored sum below
 #pragma unroll
-            for (int i = 0; i < NX * NU; ++i) Bf[i] = Bfn[d][i];
+            for (int l = 0; l < 4; ++l) Tc[l] = rsc[l * 4 + q];
+            double PBs[4][NU];  // P B, every entry in every lane (scalars)
 #pragma unroll
-            for (int i = 0; i < 4 * NU; ++i) Br[i] = Brn[d][i];
-            request(d, k - RD >= 0 ? k - RD : 0);
-            // PA[r][c] = sum_l P[r][l] A[l][c] ; PB[r][u] = sum_l P[r][l] B[l][u]
-            double PA = 0.0, PB[NU];
+            for (int l = 0; l < 4; ++l)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) PB[u] = 0.0;
-#pragma unroll
-            for (int l = 0; l < NX; ++l) {
-                const double prl = q4(P, l);
-                PA += prl * Ac[l];
-#pragma unroll
-                for (int u = 0; u < NU; ++u) PB[u] += prl * Bf[l * NU + u];
-            }
-            // BPA[u][c] = sum_l B[l][u] PA[l][c] ; S[u][v] = w_u delta + sum_l B[l][u] PB[l][v]   (rows in rotated order)
+                for (int u = 0; u < NU; ++u) PBs[l][u] = rl(PBr[u], 16 * l);
+            // S[u][v] = w_u delta + sum_l B[l][u] PB[l][v] ; BPA[u] = (B' P A)[u][q] = sum_l PB[l][u] A[l][q]
             double BPA[NU], S[NU * NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
@@ -405,18 +442,13 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                 for (int v = 0; v < NU; ++v) S[u * NU + v] = (u == v) ? wu : 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const double pa = rot(PA, t);
-                double pb[NU];
-#pragma unroll
-                for (int v = 0; v < NU; ++v) pb[v] = rot(PB[v], t);
+            for (int l = 0; l < 4; ++l)
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    BPA[u] += Br[t * NU + u] * pa;
+                    BPA[u] += PBs[l][u] * Acn[d][l];
 #pragma unroll
-                    for (int v = 0; v < NU; ++v) S[u * NU + v] += Br[t * NU + u] * pb[v];
+                    for (int v = 0; v < NU; ++v) S[u * NU + v] += Bln[d][l * NU + u] * PBs[l][v];
                 }
-            }
             double Si[NU * NU];
             if constexpr (NU == 1) {
                 notpd |= !(S[0] > 0.0);
@@ -429,47 +461,59 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                 Si[2] = -S[2] * id;
                 Si[3] = S[0] * id;
             }
-            // K[u][c] = sum_v Si[u][v] BPA[v][c] ; Acl[r][c] = A[r][c] - sum_u B[r][u] K[u][c]
-            double Kk[NU], Acl_rc = Aown;
+            // K[u] = K[u][q] in quad q of every row; Kr[u] = K[u][rho] in every lane of row rho
+            double Kk[NU], Kr[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 double a = 0.0;
 #pragma unroll
                 for (int v = 0; v < NU; ++v) a += Si[u * NU + v] * BPA[v];
                 Kk[u] = a;
-                Acl_rc -= Br[u] * a;  // Br[0 * NU + u] = B[r][u]
+                Kr[u] = 0.0;
             }
-            if (lane < 16) {
-                if constexpr (SERIAL) {
-                    // every one of the 16 lanes writes its entry of each rotated image (zero outside NX x NX); PIPE: straight
-                    // into the next launch's image in the workspace (the LDS image belongs to the solving wavefront)
-                    double *f = (PIPE ? img_next : Fl) + k * FS;
-                    f[FA + r * 4 + c] = in ? Acl_rc : 0.0;
-                    f[FAT + c * 4 + r] = in ? Acl_rc : 0.0;
-                    if (r == 0) {
 #pragma unroll
-                        for (int u = 0; u < NU; ++u) f[FKN + c * NU + u] = inc ? -Kk[u] : 0.0;  // K[u][c]
-                    }
-                    if (c == 0) {
+            for (int u = 0; u < NU; ++u) row_gather(Kr[u], Kk[u]);
+            // Acl[q][rho] (this lane's element) and column q of Acl (the coefficients of the last product)
+            double Aclo = Ann[d], Acc[4];
 #pragma unroll
-                        for (int u = 0; u < NU; ++u) {
-                            double bsv = 0.0;  // -(S^-1 B')[u][r]: the backward sweep's feed-forward row, S^-1 folded in here
+            for (int u = 0; u < NU; ++u) Aclo -= Bqn[d][u] * Kr[u];
 #pragma unroll
-                            for (int v = 0; v < NU; ++v) bsv -= Si[u * NU + v] * Br[v];  // Br[0 * NU + v] = B[r][v]
-                            f[FBS + r * NU + u] = inr ? bsv : 0.0;
-                            f[FBO + r * NU + u] = inr ? Br[u] : 0.0;
-                        }
-                    }
-                    if (lane == 0) {
+            for (int l = 0; l < 4; ++l) {
+                double a = Acn[d][l];
 #pragma unroll
-                        for (int i = 0; i < NU * NU; ++i) f[FSI + i] = Si[i];
-                    }
-                } else {
-                    const int64_t w = wg(k);
-                    if (in) Acl[w * NX * NX + r * NX + c] = Acl_rc;
-                    if (r == 0 && inc) {
+                for (int u = 0; u < NU; ++u) a -= Bln[d][l * NU + u] * Kk[u];
+                Acc[l] = a;
+            }
+            // P_k[q][rho] = Q_k + sum_l Acl[l][q] (P A)[l][rho]   (x_0 is data: Q_0 = 0), symmetrised: the lane forms the sum of
+            // [q][rho] AND that of [rho][q] (the same products in the same order as its mirror lane: exactly symmetric without a
+            // second exchange) -- without it the antisymmetric rounding error is multiplied by ~|Acl| |A| per step (1e-6 after 40)
+            double s1 = 0.0, s2 = 0.0;
+            sweep_chain2(s1, s2, Tq, Aclo, Acc, Tc);
+            const double Pn = 0.5 * (s1 + s2) + ((in && q == rho && k >= 1) ? wx : 0.0);
+            if constexpr (SERIAL) {
+                // every lane stores (the copies of a value are bitwise equal; zero outside NX x NX); PIPE: straight into the next
+                // launch's image in the workspace (the LDS image belongs to the solving wavefront)
+                double *f = (PIPE ? img_next : Fl) + k * FS;
+                f[FA + q * 4 + rho] = Aclo;
+                f[FAT + rho * 4 + q] = Aclo;
 #pragma unroll
-                        for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + c] = Kk[u];
+                for (int u = 0; u < NU; ++u) {
+                    double bsv = 0.0;  // -(S^-1 B')[u][q]: the backward sweep's feed-forward row, S^-1 folded in here
+#pragma unroll
+                    for (int v = 0; v < NU; ++v) bsv -= Si[u * NU + v] * Bqn[d][v];
+                    f[FKN + q * NU + u] = -Kk[u];
+                    f[FBS + q * NU + u] = bsv;
+                    f[FBO + q * NU + u] = Bqn[d][u];
+                }
+#pragma unroll
+                for (int i = 0; i < NU * NU; ++i) f[FSI + i] = Si[i];
+            } else {
+                const int64_t w = wg(k);
+                if ((lane & 3) == 0) {
+                    if (in) Acl[w * NX * NX + q * NX + rho] = Aclo;
+                    if (rho == 0 && inq) {
+#pragma unroll
+                        for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + q] = Kk[u];
                     }
                     if (lane == 0) {
 #pragma unroll
@@ -477,35 +521,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                     }
                 }
             }
-            // P_k[r][c] = Q_k + sum_l PA[l][r] Acl[l][c], symmetrised (x_0 is data: Q_0 = 0)
-            // Both operands by COLUMN: they go through LDS transposed (one round trip: two writes, eight 16-byte reads),
-            // and lane (r, c) forms P_k[r][c] AND P_k[c][r] itself, so the average is exactly symmetric without a second
-            // exchange (a ds_bpermute gather of PA and another of P_k were two dependent round trips).
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 16) {
-                rsc[c * 4 + r] = PA;           // PA'  : row c = column c of PA
-                rsc[16 + c * 4 + r] = Acl_rc;  // Acl' : row c = column c of Acl
-            }
-            lsync();  // (LDS only: the factor's stores -- global ones in the pipelined mode -- are not waited for)
-            double par[4], pac[4], acr[4], acc_[4];
-            {
-                const D2 *t2 = (const D2 *)rsc;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const D2 a = t2[r * 2 + h], b = t2[c * 2 + h], e = t2[8 + r * 2 + h], f = t2[8 + c * 2 + h];
-                    par[2 * h] = a[0], par[2 * h + 1] = a[1];    // PA[l][r]
-                    pac[2 * h] = b[0], pac[2 * h + 1] = b[1];    // PA[l][c]
-                    acr[2 * h] = e[0], acr[2 * h + 1] = e[1];    // Acl[l][r]
-                    acc_[2 * h] = f[0], acc_[2 * h + 1] = f[1];  // Acl[l][c]
-                }
-            }
-            double Prc = 0.0, Pcr = 0.0;
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                Prc += par[l] * acc_[l];
-                Pcr += pac[l] * acr[l];
-            }
-            P = 0.5 * (Prc + Pcr) + ((in && r == c && k >= 1) ? wx : 0.0);
+            P = Pn;
+            request(d, k - RD >= 0 ? k - RD : 0);
         };
         // full groups of RD steps (every step re-requests, clamped at the end: the same loads in flight on every path),
         // then the remainder
@@ -519,7 +536,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
         for (int d = 0; d < RD - 1; ++d)
             if (k - d >= 0) step(d, k - d);
     }
-    notpd = __ballot(notpd) != 0ull;  // (the lanes sum S in different orders: a pivot at rounding level may differ in sign)
+    notpd = __ballot(notpd) != 0ull;
     wsync();
     if constexpr (PIPE) {
         if (factor_wave) {  // this wavefront's work is done: mark a factor that does not exist, like KEEP does
@@ -1600,7 +1617,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
     if (SERIAL) lds += (size_t)(serial_lds_doubles(ka.N, NX, NU) - 32) * sizeof(double);
-    if (PIPE) lds += (32 + (size_t)ka.N * (NX * NX + NX * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands
+    if (PIPE) lds += (32 + (size_t)ka.N * (16 + 4 * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands (padded)
     auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE, WARM>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
