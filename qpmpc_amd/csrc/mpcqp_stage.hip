@@ -250,6 +250,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     double *wsbase = *(double *const __attribute__((address_space(4))) *)(kbase + off_ws);
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
     const int lane = tid & 63;
+    const int sq = (lane >> 2) & 3;  // (serial sweeps: the quad of a 16-lane row that owns component sq of the running vector)
+    const bool sqin = sq < NX;
     const bool factor_wave = PIPE && (tid >> 6) == 1;
     const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int L = (N + 63) / 64;                    // steps per chunk
@@ -316,6 +318,20 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     if (ka.ep_on && !factor_wave)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ep_s0[i] = ((const double *)ka.ep_states)[prob * 4 + i];
+    // (serial sweeps) the problem's own data, requested now and used once the factor is in place: x0 and the goal (this
+    // lane's component), the targets (64 consecutive values per register; they go to LDS in the tracking sweep)
+    constexpr int TGV = SERIAL ? (kSerialMaxN * NX + 63) / 64 : 1;
+    double x0own = 0.0, goalown = 0.0, tgv[TGV];
+#pragma unroll
+    for (int u = 0; u < TGV; ++u) tgv[u] = 0.0;
+    if constexpr (SERIAL) {
+        if (!factor_wave) {
+            x0own = sqin ? gx0[sq] : 0.0;
+            goalown = (termQ && sqin) ? ggoal[sq] : 0.0;
+#pragma unroll
+            for (int u = 0; u < TGV; ++u) tgv[u] = (stageQ && lane + 64 * u < N * NX) ? gtgt[lane + 64 * u] : 0.0;
+        }
+    }
     // factor images in the workspace: this period's (read by REUSE / the solving wavefront, written by KEEP) and the next one's
     // (PIPE: the two alternate from period to period)
     const int slot = (ka.factor_slot + (PIPE ? per : 0)) & 1;
@@ -882,8 +898,6 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     // (one wavefront per SIMD: a step costs what its instructions issue, 56 of them the eight dependent FMAs --
     // tools/ubench/dpp_rate.hip). Round 4; before: the vector in rotated order in every lane, three DPP rotations and two
     // masked stores per step, ~55 instructions, 370-540 cycles.
-    const int sq = (lane >> 2) & 3;
-    const bool sqin = sq < NX;
     constexpr int SRD = STAGE_SRD;  // request distance of the serial sweeps, in steps (their operands sit in LDS: ~100+ cycles, a step is ~80)
     // A value that only one lane (or one lane per quad) has to store is stored by EVERY lane, each to an address of its own:
     // the wanted lanes walk the array, the others hit their cell of `junkl` (a masked store costs the wavefront two exec
@@ -896,21 +910,15 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
         double own;
         int kstart;
         if constexpr (track) {
-            own = (termQ && sqin) ? -ka.wt * ggoal[sq] : 0.0;
+            own = (termQ && sqin) ? -ka.wt * goalown : 0.0;
             kstart = N - 1;
-            // the targets come through LDS, already scaled (-w_x target; step 0 carries no state cost): one coalesced round
-            // trip instead of a request per step, and the step starts its sum from them
-            const bool tgt = stageQ;
+            // the targets come through LDS, already scaled (-w_x target; step 0 carries no state cost), and the step starts its
+            // sum from them (they were requested at the top of the period)
             const double mwx = -ka.wx;
-            for (int i0 = lane; i0 < N * NX; i0 += 64 * 4) {
-                double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = tgt ? gtgt[i0 + 64 * u < N * NX ? i0 + 64 * u : N * NX - 1] : 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + 64 * u < N * NX) tgl[i0 + 64 * u] = (i0 + 64 * u >= NX) ? mwx * v[u] : 0.0;
-            }
-            wsync();
+            for (int u = 0; u < TGV; ++u)
+                if (lane + 64 * u < N * NX) tgl[lane + 64 * u] = (lane + 64 * u >= NX) ? mwx * tgv[u] : 0.0;
+            lsync();
         } else {
             const double *f = Fl + kq * FS;
             double pn = 0.0;
@@ -991,8 +999,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     // from: both are dead by then); the lanes copy their chunks to the workspace arrays (Uo, Xo) in one coalesced pass
     // afterwards. (The feed-forward terms above a single row's step were zeroed by its backward sweep.)
     double *xl = tgl, *ul = ffl;
-    auto forward_s = [&](const double *xs, double *Uo, double *Xo) {
-        double own = (xs && sqin) ? xs[sq] : 0.0;
+    auto forward_s = [&](double x0q, double *Uo, double *Xo) {  // x0q: this lane's component of the initial state
+        double own = x0q;
         double ar[SRD][4], kn[SRD][4 * NU], bo[SRD][NU], ff[SRD][NU];
         const double *fq = Fl + FA + sq * 4, *fk = ffl;
         const bool xwl = lane < 16 && (lane & 3) == 0 && sqin;
@@ -1091,15 +1099,18 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
         else
             backward(-1, zero_row, zero_row, true);
     }
-    wsync();
+    if constexpr (serial)
+        lsync();  // (the feed-forward terms go from lane to lane through LDS: nothing to wait for)
+    else
+        wsync();
     tick(3);
     if (!notpd) {
         if constexpr (serial)
-            forward_s(gx0, U0, X0);
+            forward_s(x0own, U0, X0);
         else
             forward(gx0, U0, X0);
     }
-    wsync();
+    if constexpr (!serial) wsync();  // (serial: the slack pass below reads the trajectory where the sweep staged it, in LDS)
     tick(4);
     const double tol = ka.tol;
     // The same pass makes the FIRST selection (the values are in registers: the loop's own selection pass would wait for
@@ -1140,7 +1151,10 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
             }
         }
     }
-    wsync();
+    // (the slacks, norms and slot table just stored are read by other lanes from the first iteration on. SERIAL cold start: the
+    // first selection comes from registers, so the wait for those stores is taken only if a row IS violated -- below)
+    constexpr bool late_fence = SERIAL && !WARM;
+    if constexpr (!late_fence) wsync();
 
     tick(5);
     // ================================================================= active-set loop
@@ -1341,6 +1355,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                 if (first_sel) unconstrained = true;  // nothing was violated at the unconstrained minimiser: it is the plan
                 break;
             }
+            if constexpr (late_fence)
+                if (first_sel) wsync();
             const int kp = bi / mk, rp = bi - kp * mk;
             const int64_t wp = wg(kp), bw = wp * mk + rp;  // workspace index of step kp / of row p
             double qrow[NX], rrow[NU];
@@ -1355,9 +1371,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                 backward_s(kp, gC ? gC + kp * sC + rp * NX : nullptr, gD ? gD + kp * sD + rp * NU : nullptr, std::false_type{});
             else
                 backward(kp, qrow, rrow, false);
-            wsync();
             if constexpr (serial)
-                forward_s(nullptr, Vp, Xp);
+                lsync();
+            else
+                wsync();
+            if constexpr (serial)
+                forward_s(0.0, Vp, Xp);
             else
                 forward(nullptr, Vp, Xp);
             wsync();
