@@ -46,6 +46,12 @@ namespace mpcqp {
 #ifndef STAGE_SRD
 #define STAGE_SRD 4
 #endif
+#ifndef STAGE_SROWL
+// lanes that run the serial sweeps: 16 = one 16-lane row, 64 = all four rows redundantly. Same cycle count either way; with
+// the factor wavefronts running next to the solving ones (PIPE: two busy wavefronts on every SIMD of the chip, shader clock
+// ~1.8 GHz instead of ~2.25) three idle rows are worth 2.5 % of the period, alone on its SIMD the exec mask costs 2 %.
+#define STAGE_SROWL (PIPE ? 16 : 64)
+#endif
 #ifndef STAGE_DBG
 #define STAGE_DBG 0 /* timing experiments only (wrong results): 1 no re-requests, 2 no stores, 4 no arithmetic in the serial sweeps */
 #endif
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     // no launch boundary, no dispatch gap between the periods); every other entry point runs one. (Everything, the
     // address arithmetic included, is inside the period: nothing but the kernel's arguments stays live across periods.)
     auto period = [&](const int per) {
+    const long long t_entry = (long long)__builtin_readcyclecounter();  // (developer probe: slot 11)
     // (the lane and problem indices pass through an empty asm: the optimiser must not hoist the period's address
     // arithmetic out of the period loop, where all of it would stay live across the whole period -- that version of the
     // kernel spilled 50-200 VGPRs)
@@ -313,6 +320,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     const bool keep = !PIPE && (ka.opt_flags & MPCQP_OPT_KEEP_FACTOR);
     if constexpr (PIPE) rsc += serial_lds_doubles(N, NX, NU);  // (the factor wavefront's own exchange cells, after everything)
     tick(factor_wave ? 9 : 0);
+    if (stamp && lane == 0 && !factor_wave) stamp[11] = t_entry;
+    if (stamp && lane == 0) stamp[factor_wave ? 15 : 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID: wave, SIMD, CU
     // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
     double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
     if (ka.ep_on && !factor_wave)
@@ -963,6 +972,7 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
             }
             if constexpr (track) tg[d] = *t;
         };
+        if (lane >= STAGE_SROWL) return;  // (the four 16-lane rows would run the same stream)
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
             req(d, fq - d * FS, tq - d * NX);
@@ -1026,6 +1036,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
                 ff[d][i] = fkk[i];
             }
         };
+        auto run = [&]() {
+        if (lane >= STAGE_SROWL) return;  // (the four 16-lane rows would run the same stream)
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
             req(d, fq + d * FS, fk + d * NU);
@@ -1064,6 +1076,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
 #pragma unroll
         for (int d = 0; d < SRD - 1; ++d)
             if (k + d < N) step(d, false);
+        };
+        run();
         lsync();
         for (int kk = k0; kk < k1; ++kk) {
 #pragma unroll
@@ -1604,12 +1618,16 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     for (int per = 0; per < nper; ++per) {
         period(per);
         if (per + 1 < nper) {
+            if (ka_.probe && threadIdx.x == 0)  // (developer probe: slot 13 = the period's end, slot 12 = the end of the hand-over)
+                ((long long *)ka_.probe)[(int64_t)blockIdx.x * 16 + 13] = (long long)__builtin_readcyclecounter();
             // the next period's x0 / goal / targets / state were written by this wavefront, its factor image by the other
             // one (PIPE): same CU, same L1 -- the stores have to be complete, nothing has to be invalidated but the
             // scalar cache
             wsync();
             __builtin_amdgcn_s_dcache_inv();
             if constexpr (PIPE) __syncthreads();
+            if (ka_.probe && threadIdx.x == 0)  // (developer probe: the end of the hand-over to the next period)
+                ((long long *)ka_.probe)[(int64_t)blockIdx.x * 16 + 12] = (long long)__builtin_readcyclecounter();
             // (no vector-L1 invalidate: the two wavefronts of a workgroup share their CU's L1, which its own stores keep
             // coherent -- workgroup scope in the AMDGPU memory model; an agent-scope acquire here cost 4-8 us per period)
         }
