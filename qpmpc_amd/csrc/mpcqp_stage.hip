@@ -52,6 +52,17 @@ namespace mpcqp {
 // ~1.8 GHz instead of ~2.25) three idle rows are worth 2.5 % of the period, alone on its SIMD the exec mask costs 2 %.
 #define STAGE_SROWL (PIPE ? 16 : 64)
 #endif
+#ifndef STAGE_PW
+// problems per workgroup of the pipelined instantiation (when four of them fit the CU's LDS; else 1). 4: eight wavefronts, the
+// solving wavefront of problem j is wavefront j, its factor wavefront j + 4 -- the dispatcher deals a workgroup's wavefronts
+// round-robin over the four SIMDs, so the two wavefronts of a problem SHARE a SIMD and each SIMD is a closed system. 1: two
+// wavefronts per workgroup on neighbouring SIMDs, every SIMD hosting the solving wavefront of one problem and the factor
+// wavefront of another. Measured on config 3 (tools/probe_config3_loop.py 1024 50): with 1 the workgroups of a CU split into
+// fast and slow ones (solving wavefront 36 k ... 51 k cycles, factor wavefront 34 k), with 4 all take the same 46 k -- and
+// the period is 22.5 against 22.0 us: either way a SIMD issues one solving and one factor wavefront's instructions per
+// period (~10 k instructions), which is what the period costs. Default 1 (no lock step between problems, a quarter of the LDS).
+#define STAGE_PW 1
+#endif
 #ifndef STAGE_DBG
 #define STAGE_DBG 0 /* timing experiments only (wrong results): 1 no re-requests, 2 no stores, 4 no arithmetic in the serial sweeps */
 #endif
@@ -227,11 +238,12 @@ struct StageArgs {
     Ws wl;
     double *wsbase;
     int64_t batch;
+    int64_t lds_problem;  // dynamic LDS bytes of ONE problem (the pipelined instantiation packs STAGE_PW problems per workgroup)
 };
 static_assert(offsetof(StageArgs, ka) == 0, "the kernel argument block starts with KernelArgs");
 
-template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
-__global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const StageArgs sa_)
+template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM, int PWT = 1>
+__global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 2) mpcqp_stage_kernel(const StageArgs sa_)
 {
     const KernelArgs &ka_ = sa_.ka;
     // ONE PERIOD = one build + solve (+ the fused plant epilogue). A launch runs ka.ep_periods of them back to back
@@ -246,7 +258,9 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     typedef const __attribute__((address_space(4))) unsigned char *KargPtr;
     KargPtr kbase = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     int tid = threadIdx.x;
-    int64_t prob = blockIdx.x;
+    constexpr int PW = PIPE ? PWT : 1;  // problems per workgroup
+    const int wvi = PIPE ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;  // wavefront of the workgroup
+    int64_t prob = (int64_t)blockIdx.x * PW + (wvi % PW);
     // MULTI: the instantiations that mpcqp_wip_periods_batch reaches (the plant of the fused period has nx = 4, nu = 1)
     constexpr bool MULTI = SERIAL && NX == 4 && NU == 1;
     if constexpr (MULTI) asm volatile("" : "+s"(kbase), "+s"(prob), "+v"(tid));
@@ -255,11 +269,12 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     const __attribute__((address_space(4))) KernelArgs &ka = *(const __attribute__((address_space(4))) KernelArgs *)kbase;
     const __attribute__((address_space(4))) Ws &wl = *(const __attribute__((address_space(4))) Ws *)(kbase + off_wl);
     double *wsbase = *(double *const __attribute__((address_space(4))) *)(kbase + off_ws);
-    extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem_all[];
+    unsigned char *stage_smem = stage_smem_all + (PW > 1 ? (size_t)(wvi % PW) * (size_t)sa_.lds_problem : 0);
     const int lane = tid & 63;
     const int sq = (lane >> 2) & 3;  // (serial sweeps: the quad of a 16-lane row that owns component sq of the running vector)
     const bool sqin = sq < NX;
-    const bool factor_wave = PIPE && (tid >> 6) == 1;
+    const bool factor_wave = PIPE && wvi >= PW;
     const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int L = (N + 63) / 64;                    // steps per chunk
     const int k0 = lane * L < N ? lane * L : N;     // this lane's chunk [k0, k1)
@@ -321,7 +336,8 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     if constexpr (PIPE) rsc += serial_lds_doubles(N, NX, NU);  // (the factor wavefront's own exchange cells, after everything)
     tick(factor_wave ? 9 : 0);
     if (stamp && lane == 0 && !factor_wave) stamp[11] = t_entry;
-    if (stamp && lane == 0) stamp[factor_wave ? 15 : 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID: wave, SIMD, CU
+    if (stamp && lane == 0)  // HW_ID (wave, SIMD, CU, SH, SE) | XCC_ID << 32
+        stamp[factor_wave ? 15 : 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32);
     // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
     double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
     if (ka.ep_on && !factor_wave)
@@ -1611,23 +1627,29 @@ __global__ void __launch_bounds__(PIPE ? 128 : 64, 2) mpcqp_stage_kernel(const S
     tick(8);
     };  // period
     if constexpr (!(SERIAL && NX == 4 && NU == 1)) {  // (one period per launch: mpcqp_wip_periods_batch refuses more)
-        period(0);
+        constexpr int PW1 = PIPE ? PWT : 1;
+        if ((int64_t)blockIdx.x * PW1 + (((int)threadIdx.x >> 6) % PW1) < sa_.batch) period(0);
         return;
     }
     const int nper = (ka_.ep_on && ka_.ep_periods > 1) ? ka_.ep_periods : 1;
+    constexpr int PWo = PIPE ? PWT : 1;
+    const int wvo = (int)threadIdx.x >> 6;
+    const int64_t probo = (int64_t)blockIdx.x * PWo + (wvo % PWo);
+    const bool valid = probo < sa_.batch;  // (the last workgroup of a pipelined launch may hold fewer than PW problems)
+    const bool stamper = ka_.probe && valid && (threadIdx.x & 63) == 0 && wvo < PWo;
     for (int per = 0; per < nper; ++per) {
-        period(per);
+        if (valid) period(per);
         if (per + 1 < nper) {
-            if (ka_.probe && threadIdx.x == 0)  // (developer probe: slot 13 = the period's end, slot 12 = the end of the hand-over)
-                ((long long *)ka_.probe)[(int64_t)blockIdx.x * 16 + 13] = (long long)__builtin_readcyclecounter();
+            if (stamper)  // (developer probe: slot 13 = the period's end, slot 12 = the end of the hand-over)
+                ((long long *)ka_.probe)[probo * 16 + 13] = (long long)__builtin_readcyclecounter();
             // the next period's x0 / goal / targets / state were written by this wavefront, its factor image by the other
             // one (PIPE): same CU, same L1 -- the stores have to be complete, nothing has to be invalidated but the
             // scalar cache
             wsync();
             __builtin_amdgcn_s_dcache_inv();
             if constexpr (PIPE) __syncthreads();
-            if (ka_.probe && threadIdx.x == 0)  // (developer probe: the end of the hand-over to the next period)
-                ((long long *)ka_.probe)[(int64_t)blockIdx.x * 16 + 12] = (long long)__builtin_readcyclecounter();
+            if (stamper)  // (developer probe: the end of the hand-over to the next period)
+                ((long long *)ka_.probe)[probo * 16 + 12] = (long long)__builtin_readcyclecounter();
             // (no vector-L1 invalidate: the two wavefronts of a workgroup share their CU's L1, which its own stores keep
             // coherent -- workgroup scope in the AMDGPU memory model; an agent-scope acquire here cost 4-8 us per period)
         }
@@ -1648,6 +1670,20 @@ int stage_default_maxq(const KernelArgs &ka)
 
 size_t stage_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq).total; }
 
+template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM, int PW = 1>
+static int launch_stage_p(const KernelArgs &ka, const Ws &wl, size_t lds_problem, int64_t batch, void *ws, hipStream_t st)
+{
+    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE, WARM, PW>;
+    const size_t lds = lds_problem * PW;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    const StageArgs sa{ka, wl, (double *)ws, batch, (int64_t)lds_problem};
+    hipLaunchKernelGGL(kern, dim3((unsigned)((batch + PW - 1) / PW)), dim3(PIPE ? 128 * PW : 64), lds, st, sa);
+    return (int)hipGetLastError();
+}
+
 template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM>
 static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
@@ -1655,14 +1691,12 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
     size_t lds = (size_t)maxq * (3 * sizeof(double) + 2 * sizeof(int)) + 32 * sizeof(double);
     if (SERIAL) lds += (size_t)(serial_lds_doubles(ka.N, NX, NU) - 32) * sizeof(double);
     if (PIPE) lds += (32 + (size_t)ka.N * (16 + 4 * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands (padded)
-    auto kern = mpcqp_stage_kernel<NX, NU, SERIAL, PIPE, WARM>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+    lds = (lds + 15) & ~(size_t)15;
+    if constexpr (PIPE && STAGE_PW == 4) {
+        // four problems per workgroup -- the two wavefronts of a problem on ONE SIMD -- when they fit the CU's 160 KB
+        if (4 * lds <= 160 * 1024) return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 4>(ka, wl, lds, batch, ws, st);
     }
-    const StageArgs sa{ka, wl, (double *)ws, batch};
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(PIPE ? 128 : 64), lds, st, sa);
-    return (int)hipGetLastError();
+    return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 1>(ka, wl, lds, batch, ws, st);
 }
 
 static bool stage_serial(const KernelArgs &ka)

@@ -34,12 +34,22 @@ for name, kw in (("rebuild", {}), ("pipeline_factor", {"pipeline_factor": True})
         simd_s, simd_f = (hs >> 4) & 3, (hf >> 4) & 3
         cu = lambda h: ((h >> 8) & 15) | (((h >> 12) & 1) << 4) | (((h >> 13) & 7) << 5)
         print("    solver SIMD == factor SIMD in", int((simd_s == simd_f).sum()), "workgroups; mean solving there", 
-              int(sol[simd_s == simd_f].mean()) if (simd_s == simd_f).any() else -1, "elsewhere", int(sol[simd_s != simd_f].mean()))
+              int(sol[simd_s == simd_f].mean()) if (simd_s == simd_f).any() else -1, "elsewhere", int(sol[simd_s != simd_f].mean()) if (simd_s != simd_f).any() else -1)
         for sd in range(4):
             print(f"    solver on SIMD {sd}: {int((simd_s == sd).sum())} workgroups, mean solving {int(sol[simd_s == sd].mean()) if (simd_s == sd).any() else -1};"
                   f" factor on SIMD {sd}: {int((simd_f == sd).sum())}")
         slow = sol > 44000
         print("    slow workgroups:", int(slow.sum()), "; their solver SIMDs", torch.bincount(simd_s[slow], minlength=4).tolist(), "factor SIMDs", torch.bincount(simd_f[slow], minlength=4).tolist())
+        cuid = (cu(hs) | ((hs >> 32) & 15) << 8)  # (XCC, SE, SH, CU)
+        ids, inv = torch.unique(cuid, return_inverse=True)
+        cnt = torch.bincount(inv); mean_cu = torch.bincount(inv, weights=sol) / cnt
+        within = float(((sol - mean_cu[inv]) ** 2).mean().sqrt()); between = float(mean_cu.std())
+        print(f"    {len(ids)} CUs, workgroups per CU min {int(cnt.min())} max {int(cnt.max())}; solving time: std between CUs {between:.0f}, within a CU {within:.0f};"
+              f" slowest CUs' means {sorted(mean_cu.tolist())[-3:]}, fastest {sorted(mean_cu.tolist())[:3]}")
+        slowfrac = torch.bincount(inv, weights=slow.double()) / cnt
+        print("    fraction of slow workgroups per CU: histogram", torch.histc(slowfrac, bins=5, min=0, max=1).tolist())
+        xcc = (hs >> 32) & 15
+        print("    mean solving time per XCD", [int(sol[xcc == i].mean()) for i in range(8) if (xcc == i).any()])
         # waves per (CU, SIMD) as seen by this launch (XCC unknown: counts are summed over the 8 XCDs)
         key_s, key_f = cu(hs) * 4 + simd_s, cu(hf) * 4 + simd_f
         occ = torch.bincount(torch.cat([key_s, key_f]), minlength=1)
