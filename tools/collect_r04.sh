@@ -24,5 +24,14 @@ if [ "${SKIP_PROF:-0}" != "1" ]; then
   timeout 900 bash $R/tools/collect_profiles.sh pair_$TAG
   timeout 900 bash $R/tools/collect_stagew.sh $TAG
   timeout 600 bash $R/tools/collect_stagew.sh ${TAG}_b1024 f32 1024
+  # config 3: the narrow stage-wise kernel with the whole control period (kernel trace + instruction counters)
+  P3=$R/gpurun_out/prof_stage_$TAG; mkdir -p $P3
+  ( cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d $P3/trace -o t -- python $R/bench.py --config 3 --spinup 0 --no-extras --no-cpu-baseline > $P3/trace.log 2>&1
+    for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAVES SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_SMEM"; do
+      tag=$(echo $c | tr ' ' '+' | cut -c1-40)
+      rocprofv3 --kernel-trace --pmc $c --output-format csv -d $P3/pmc_$tag -o p -- python $R/bench.py --config 3 --steps 100 --no-extras --no-cpu-baseline > $P3/pmc_$tag.log 2>&1
+    done
+    find $P3 -name "*.db" -delete )
 fi
 du -sh $R/gpurun_out
