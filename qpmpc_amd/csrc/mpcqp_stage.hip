@@ -596,14 +596,18 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             // flight at once: ONE round trip for the image (a load -> LDS store loop paid one per turn of eight requests)
             typedef __attribute__((address_space(3))) void lds_void;
             typedef __attribute__((address_space(1))) const void glb_void;
-            const D2 *src = (const D2 *)img;
-            D2 *dst = (D2 *)Fl;
-            const int n2 = N * FS / 2;  // (FS is even)
-            const int nfull = n2 >> 6;
-            for (int c = 0; c < nfull; ++c)
-                __builtin_amdgcn_global_load_lds((glb_void *)(src + c * 64 + lane), (lds_void *)(dst + c * 64), 16, 0, 0);
-            if (nfull * 64 + lane < n2) dst[nfull * 64 + lane] = src[nfull * 64 + lane];
-            wsync();
+            // (a later period of a multi-period launch that REUSES the factor finds the image where the first one put it:
+            // nothing of a solve writes into it)
+            if (PIPE || per == 0) {
+                const D2 *src = (const D2 *)img;
+                D2 *dst = (D2 *)Fl;
+                const int n2 = N * FS / 2;  // (FS is even)
+                const int nfull = n2 >> 6;
+                for (int c = 0; c < nfull; ++c)
+                    __builtin_amdgcn_global_load_lds((glb_void *)(src + c * 64 + lane), (lds_void *)(dst + c * 64), 16, 0, 0);
+                if (nfull * 64 + lane < n2) dst[nfull * 64 + lane] = src[nfull * 64 + lane];
+                wsync();
+            }
             notpd = Fl[FSI] != Fl[FSI];
         } else if (keep) {
             for (int i = lane; i < N * FS; i += 64) img[i] = Fl[i];
@@ -1189,6 +1193,16 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
     tick(5);
     // ================================================================= active-set loop
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
+    // SERIAL cold start: whether ANY row is violated at the unconstrained minimiser is decided here, before the active-set loop's
+    // set-up code (its loop-invariant addresses, divisions and scalar spills: ~3 k cycles that most periods of a
+    // well-conditioned receding-horizon loop do not need)
+    bool early_plan = false;
+    if constexpr (late_fence) {
+        if (!notpd) {
+            wave_argmin(best, bi);  // (the loop's own reduction of the reduced pair changes nothing)
+            early_plan = !(best < INF);
+        }
+    }
     const int max_iter = ka.max_iter;
     const int nvar = N * NU;
     double *Vp = Vs + (int64_t)maxq * NP * NU, *Xp = XVs + (int64_t)maxq * NP * NX;  // the candidate's slot
@@ -1359,7 +1373,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             if (o) cold_start();  // the stored rows do not sit on their bounds with these vectors: not this problem's state
         }
     }
-    for (int round = 0; round < 4 && !fail && !notpd; ++round) {
+    for (int round = 0; round < 4 && !fail && !notpd && !early_plan; ++round) {
         for (;;) {
             // ---- selection: the violated row farthest from its hyperplane (the first one was made by the slack pass)
             if (!presel) {
@@ -1571,6 +1585,16 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
         }
         status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
     }
+    if (early_plan) {
+        // the slack pass evaluated exactly this point (no active row, u = u0): it is the plan, only the inputs are left to write
+        status = MPCQP_SOLVED;
+        tick(6);
+        for (int k = k0; k < k1; ++k) {
+            double *ou = (double *)ka.U + prob * (int64_t)(N * NU) + (int64_t)k * NU;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ou[i] = k == k0 ? u_first[i] : U0[wq(k) * NU + i];
+        }
+    }
     tick(7);
     if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
     if (slotsfull) status = MPCQP_SLOTS_FULL;
@@ -1620,8 +1644,10 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
         wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, ep_s0, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
                                 ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt));
         if (lane == 0 && ka.ep_loopstats) {
-            ka.ep_loopstats[2 * prob] += ok ? 0 : 1;
-            ka.ep_loopstats[2 * prob + 1] += iters;
+            // (atomics without a return value: fire and forget -- a load + add + store is a dependent round trip on the period's tail;
+            // this wavefront is the only writer of its loop's counters)
+            if (!ok) __hip_atomic_fetch_add(ka.ep_loopstats + 2 * prob, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (iters) __hip_atomic_fetch_add(ka.ep_loopstats + 2 * prob + 1, (long long)iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     tick(8);
