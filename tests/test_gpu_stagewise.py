@@ -534,3 +534,42 @@ def test_wide_systems_any_horizon_against_the_oracle(nx, nu, N, mk, dtype, tol):
         torch.cuda.synchronize()
         assert np.array_equal(again.status.cpu().numpy(), st)
         assert (np.abs(again.U.cpu().numpy()[ok] - U[ok]) / scale).max() <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,nu,N,mk", [(2, 1, 20, 2), (3, 2, 24, 3), (4, 2, 40, 2), (3, 1, 90, 1), (4, 1, 33, 4)])
+def test_factor_options_of_the_narrow_kernel_for_every_dimension(nx, nu, N, mk):
+    """MPCQP_OPT_KEEP_FACTOR / REUSE_FACTOR / PIPELINE_FACTOR of mpcqp_stage.hip for the dimensions the closed-loop tests do
+    not reach (they run nx = 4, nu = 1): the factor kept by one launch, reused by the next, and rebuilt by the second
+    wavefront of the pipelined instantiation (operands padded and transposed into LDS, round 4) must give the plans of the
+    plain launch -- same recursion, same sweeps: bitwise. Replaces qpmpc/solve_mpc.py:42-44 / mpc_qp.py:129-163 (build once,
+    update, re-solve) like the closed loops."""
+    import os, sys
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    from stress_stagewise import random_ltv
+    from qpmpc_amd import PreparedSolve, _capi
+    from qpmpc_amd.workloads import to_batch_problem
+
+    rng = np.random.default_rng(1000 * nx + 100 * nu + N)
+    w = random_ltv(rng, 24, nx, nu, N, mk, tight=1.0)
+    bp = to_batch_problem(w)
+    plain = PreparedSolve(bp, formulation="stagewise")
+    plain.launch()
+    torch.cuda.synchronize()
+    U0, st0 = plain.U.clone(), plain.status.clone()
+    assert int((st0 == 0).sum()) >= 12  # (a meaningful share of the batch is solvable)
+    run = PreparedSolve(bp, formulation="stagewise")
+    o = run._opts
+    base = o.flags & ~(_capi.OPT_KEEP_FACTOR | _capi.OPT_REUSE_FACTOR | _capi.OPT_PIPELINE_FACTOR)
+    # keep (image 0) -> reuse it -> pipelined: solve with image 0, the second wavefront factors into image 1 -> solve with image 1
+    for flags, slot in ((_capi.OPT_KEEP_FACTOR, 0), (_capi.OPT_REUSE_FACTOR, 0), (_capi.OPT_PIPELINE_FACTOR, 0),
+                        (_capi.OPT_PIPELINE_FACTOR, 1), (_capi.OPT_REUSE_FACTOR, 0)):
+        o.flags, o.factor_slot = base | flags, slot
+        run.U.zero_()
+        run.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(run.status, st0), (flags, slot)
+        assert torch.equal(run.U, U0), (flags, slot, float((run.U - U0).abs().max()))
