@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -2177,11 +2178,17 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
                        (FUSE ? (size_t)(RR + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) + (size_t)maxq * sizeof(T) : 0) +
                        (size_t)RR * sizeof(int);
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (developer knob: MPCQP_STAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
+    static const size_t lds_pad = [] {
+        const char *e = getenv("MPCQP_STAGEW_LDS_PAD");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    const size_t lds_req = lds + lds_pad;
+    if (lds_req > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64), lds, st, ka, wl, (T *)ws, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(64), lds_req, st, ka, wl, (T *)ws, batch);
     return (int)hipGetLastError();
 }
 
