@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     using T = double;
     __shared__ T Pm[NXM * NXM], PAm[NXM * NXM], Tm[NXM * NXM], Am[NXM * NXM], PBm[NXM * NUM], Bm[NXM * NUM], G1[NUM * NXM], Km[NUM * NXM];
     __shared__ T Sm[NUM * NUM], Sim[NUM * NUM], pv[NXM], pn[NXM], xv[NXM], xn[NXM], tv[NUM], uv[NUM], redv[BS / 64];
+    __shared__ T Ga[NUM * 2 * NUM];
     __shared__ int redi[BS / 64], flag;
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
@@ -144,6 +145,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
     const T wu = ka.wu, wx = stageP ? ka.wx : 0.0, wt = termP ? ka.wt : 0.0, tol = ka.tol;
 
+    const long long t_start = (long long)__builtin_readcyclecounter();
     // ================================================================= factor: Riccati recursion (oracle/stagewise_np.py::Riccati)
     for (int i = tid; i < nx * nx; i += BS) Pm[i] = (i / nx == i % nx) ? wt : 0.0;
     if (tid == 0) flag = 0;
@@ -179,31 +181,27 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             G1[e] = acc;
         }
         bsync();
-        if (tid == 0) {  // S^-1 by Gauss-Jordan (nu <= 8; S is a Schur complement of the condensed Hessian: pivots must be positive)
-            T a[NUM][2 * NUM];
-            for (int r = 0; r < nu; ++r)
-                for (int c = 0; c < nu; ++c) {
-                    a[r][c] = Sm[r * nu + c];
-                    a[r][nu + c] = (r == c) ? 1.0 : 0.0;
-                }
+        // S^-1 by Gauss-Jordan on [S | I] in LDS, one thread per entry (nu <= 8; S is a Schur complement of the condensed
+        // Hessian: pivots must be positive). (Round 4: it was ONE thread on a private array -- 70 us per step in scratch memory.)
+        {
+            const int gr_ = tid / (2 * NUM), gc_ = tid - gr_ * 2 * NUM;  // entry (gr_, gc_) of the nu x 2 nu tableau, tid < 128
+            const bool mine = tid < 2 * NUM * NUM && gr_ < nu && gc_ < 2 * nu;
+            if (mine) Ga[gr_ * 2 * NUM + gc_] = gc_ < nu ? Sm[gr_ * nu + gc_] : (gc_ - nu == gr_ ? 1.0 : 0.0);
+            bsync();
             bool bad = false;
             for (int c = 0; c < nu; ++c) {
-                const T piv = a[c][c];
+                const T piv = Ga[c * 2 * NUM + c];
                 if (!(piv > 0.0)) {
-                    bad = true;
+                    bad = true;  // (uniform: every thread reads the same pivot)
                     break;
                 }
-                const T ip = 1.0 / piv;
-                for (int j = 0; j < 2 * nu; ++j) a[c][j] *= ip;
-                for (int r = 0; r < nu; ++r)
-                    if (r != c) {
-                        const T f = a[r][c];
-                        for (int j = 0; j < 2 * nu; ++j) a[r][j] -= f * a[c][j];
-                    }
+                const T prow = mine ? Ga[c * 2 * NUM + gc_] / piv : 0.0, fcol = mine ? Ga[gr_ * 2 * NUM + c] : 0.0;
+                bsync();
+                if (mine) Ga[gr_ * 2 * NUM + gc_] = gr_ == c ? prow : Ga[gr_ * 2 * NUM + gc_] - fcol * prow;
+                bsync();
             }
-            if (bad) flag = 1;
-            for (int r = 0; r < nu; ++r)
-                for (int c = 0; c < nu; ++c) Sim[r * nu + c] = bad ? 0.0 : a[r][nu + c];
+            if (bad && tid == 0) flag = 1;
+            if (tid < nu * nu) Sim[tid] = bad ? 0.0 : Ga[(tid / nu) * 2 * NUM + nu + tid % nu];
         }
         bsync();
         for (int e = tid; e < nu * nu; e += BS) Si[(int64_t)k * nu * nu + e] = Sim[e];
@@ -240,6 +238,10 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
         bsync();
     }
     const bool notpd = flag != 0;
+    // (developer probe, MpcqpSolveOpts.probe: cycles of the whole problem [0], of the recursion [1], of the sweeps [2], their number [3])
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
+    const long long t_ric = (long long)__builtin_readcyclecounter();
+    long long t_sweeps = 0, n_sweeps = 0;
 
     // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
     //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
@@ -443,7 +445,12 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     };
     if (!notpd) {
         // unconstrained minimiser and its slacks (tracking terms as linear costs: q of mpc_qp.py:129-149)
-        sweep(0, 0, true, gx0, U0, sl);
+        {
+            const long long t0 = (long long)__builtin_readcyclecounter();
+            sweep(0, 0, true, gx0, U0, sl);
+            t_sweeps += (long long)__builtin_readcyclecounter() - t0;
+            ++n_sweeps;
+        }
         for (int i = tid; i < M; i += BS) {
             const int k = i / mk, r = i - k * mk;
             const T ev = ge[k * sE + r];
@@ -499,7 +506,12 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                     }
                     ++iters;
                     T *Vp = Vs + (int64_t)phys[nq] * n, *Hp = Hs + (int64_t)phys[nq] * M;
-                    sweep(kp, rp, false, nullptr, Vp, Hp);
+                    {
+                        const long long t0 = (long long)__builtin_readcyclecounter();
+                        sweep(kp, rp, false, nullptr, Vp, Hp);
+                        t_sweeps += (long long)__builtin_readcyclecounter() - t0;
+                        ++n_sweeps;
+                    }
                     // V_p = -P^-1 (-g_p') ... the sweep solved with ql = -C, rl = -D: its result IS P^-1 g_p'
                     for (int a = tid; a < nq; a += BS) cv[a] = Hp[actrow[a]];
                     bsync();
@@ -691,6 +703,12 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
         for (int i = tid; i < M; i += BS) ol[i] = (ok && !notpd && pos[i] >= 0) ? lamv[pos[i]] : 0.0;
     }
     if (tid == 0) {
+        if (stamp) {
+            stamp[0] = (long long)__builtin_readcyclecounter() - t_start;
+            stamp[1] = t_ric - t_start;
+            stamp[2] = t_sweeps;
+            stamp[3] = n_sweeps;
+        }
         if (ka.status) ka.status[prob] = status;
         if (ka.iters) ka.iters[prob] = iters;
     }
