@@ -12,10 +12,12 @@
 // W = (G_A P^-1 G_A')^-1 bordered / deflated by rank-one updates; per active row the slot keeps V_a = P^-1 g_a' (inputs) and
 // h_a = G V_a (all m rows), so an iteration is one sweep pair plus AXPYs over m-long arrays.
 //
-// Written for GENERALITY, not speed: float64 only (float32 launches are converted, mpcqp_capi.hip), one workgroup of 256
-// threads per problem, every per-problem array in a caller-owned HBM workspace, the per-step matrices of the recursion
-// (at most 32 x 32) in LDS, one barrier between the dependent pieces of a step. nx <= 32, nu <= 8, any N, any mk.
-// What bounds it: the 2 N serial steps of a sweep pair at ~3 barriers each (latency), then the m-row passes (HBM).
+// Written for GENERALITY first: float64 only (float32 launches are converted, mpcqp_capi.hip), one workgroup of 256 threads per
+// problem, every per-problem array in a caller-owned HBM workspace, the per-step matrices of the recursion (at most 32 x 32)
+// in LDS. nx <= 32, nu <= 8, any N, any mk. The 2 N serial steps of a sweep pair are run by ONE wavefront on scalars
+// (v_readlane) while the other three stream the factor's per-step blocks into an LDS ring ahead of it (round 4, second
+// version: 2.9x the first one on nx = 20, nu = 6, N = 40); what is left per iteration besides the sweeps are the m-row passes
+// and the updates of W, handed from thread to thread through the workspace (a barrier and a round trip each).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -29,9 +31,11 @@ namespace stageg {
 constexpr int NXM = 32, NUM = 8, BS = 256;
 
 struct Ws {  // per-problem workspace carve in doubles (host-computed, passed by value)
-    int64_t Acl, Kt, Si, U0, ff, s0, s, invn, thr, V, H, W, lam, cv, rv, ints, total;
+    int64_t Blk, U0, ff, Xt, s0, s, invn, thr, V, H, W, lam, cv, rv, ints, total;
     int maxq;
 };
+
+__host__ __device__ inline int block_doubles(int nx, int nu) { return (nx * nx + 2 * nx * nu + nu * nu + 1) & ~1; }
 
 inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
 {
@@ -43,11 +47,12 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
         return at;
     };
     const int64_t n = (int64_t)N * nu, m = (int64_t)N * mk;
-    w.Acl = take((int64_t)N * nx * nx);
-    w.Kt = take((int64_t)N * nu * nx);
-    w.Si = take((int64_t)N * nu * nu);
+    // the factor, one packed block per step: [Acl' nx x nx | B nx x nu | S^-1 nu x nu | K nu x nx] -- what a sweep step reads, in the
+    // order in which the sweeps' loaders copy whole runs of steps into LDS
+    w.Blk = take((int64_t)N * block_doubles(nx, nu));
     w.U0 = take(n);
     w.ff = take(n);
+    w.Xt = take((int64_t)N * nx);  // state trajectory of the latest forward sweep (the rows of G are applied to it afterwards)
     w.s0 = take(m);
     w.s = take(m);
     w.invn = take(m);
@@ -115,7 +120,7 @@ __device__ __forceinline__ bool block_any(bool p, int *redi, int tid)
 
 using namespace stageg;
 
-__global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase)
+__global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, int ring_doubles)
 {
     using T = double;
     __shared__ T Pm[NXM * NXM], PAm[NXM * NXM], Tm[NXM * NXM], Am[NXM * NXM], PBm[NXM * NUM], Bm[NXM * NUM], G1[NUM * NXM], Km[NUM * NXM];
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     const int n = N * nu, M = N * mk;
     const T INF = HUGE_VAL;
     T *ws = wsbase + prob * wl.total;
-    T *Acl = ws + wl.Acl, *Kt = ws + wl.Kt, *Si = ws + wl.Si, *U0 = ws + wl.U0, *ffv = ws + wl.ff, *s0 = ws + wl.s0, *sl = ws + wl.s;
+    T *Blk = ws + wl.Blk, *U0 = ws + wl.U0, *ffv = ws + wl.ff, *Xt = ws + wl.Xt, *s0 = ws + wl.s0, *sl = ws + wl.s;
     T *invn = ws + wl.invn, *thr = ws + wl.thr, *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W, *lamv = ws + wl.lam;
     T *cv = ws + wl.cv, *rv = ws + wl.rv;
     int *pos = (int *)(ws + wl.ints), *actrow = pos + M, *phys = actrow + maxq + 1;
@@ -145,6 +150,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
     const T wu = ka.wu, wx = stageP ? ka.wx : 0.0, wt = termP ? ka.wt : 0.0, tol = ka.tol;
 
+    const int oB = nx * nx, oS = oB + nx * nu, oK = oS + nu * nu, PSW = block_doubles(nx, nu);  // a step's block (make_ws)
     const long long t_start = (long long)__builtin_readcyclecounter();
     // ================================================================= factor: Riccati recursion (oracle/stagewise_np.py::Riccati)
     for (int i = tid; i < nx * nx; i += BS) Pm[i] = (i / nx == i % nx) ? wt : 0.0;
@@ -204,13 +210,15 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             if (tid < nu * nu) Sim[tid] = bad ? 0.0 : Ga[(tid / nu) * 2 * NUM + nu + tid % nu];
         }
         bsync();
-        for (int e = tid; e < nu * nu; e += BS) Si[(int64_t)k * nu * nu + e] = Sim[e];
+        T *blkk = Blk + (int64_t)k * PSW;
+        for (int e = tid; e < nu * nu; e += BS) blkk[oS + e] = Sim[e];
+        for (int e = tid; e < nx * nu; e += BS) blkk[oB + e] = Bm[e];
         for (int e = tid; e < nu * nx; e += BS) {  // K = S^-1 B' P A
             const int a = e / nx, j = e - a * nx;
             T acc = 0.0;
             for (int b = 0; b < nu; ++b) acc += Sim[a * nu + b] * G1[b * nx + j];
             Km[e] = acc;
-            Kt[(int64_t)k * nu * nx + e] = acc;
+            blkk[oK + e] = acc;
         }
         bsync();
         for (int e = tid; e < nx * nx; e += BS) {  // Acl = A - B K ; T = P Acl = PA - PB K
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                 a1 -= Bm[i * nu + a] * Km[a * nx + j];
                 a2 -= PBm[i * nu + a] * Km[a * nx + j];
             }
-            Acl[(int64_t)k * nx * nx + j * nx + i] = a1;  // (transposed: the backward sweep reads columns)
+            blkk[j * nx + i] = a1;  // (transposed: the backward sweep reads columns)
             Tm[e] = a2;
         }
         bsync();
@@ -241,145 +249,168 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     // (developer probe, MpcqpSolveOpts.probe: cycles of the whole problem [0], of the recursion [1], of the sweeps [2], their number [3])
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     const long long t_ric = (long long)__builtin_readcyclecounter();
-    long long t_sweeps = 0, n_sweeps = 0;
+    long long t_sweeps = 0, n_sweeps = 0, t_bwd = 0, t_fwd = 0, t_rows = 0;
 
     // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
     //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
-    // Every step's matrices come from HBM (N nx^2 doubles do not fit a CU), and a step is too short to hide that round trip:
-    // each thread therefore requests the entries of step k -+ 1 it will use -- one role per thread: tid < nu the input-sized
-    // rows, 64 <= tid < 64 + nx the state rows, 128 <= tid the rows of G -- into registers while step k computes.
+    // (round 4, second version) The 2 N serial steps are run by ONE wavefront, without a barrier per step: lane l < nx owns
+    // component l of the running vector and the row of the step's state matrix that produces it, lanes 32 .. 32 + nu - 1 own
+    // the input-sized rows; the vector reaches every lane as scalars (v_readlane of the register that holds it, one component
+    // at a time, feeding FMAs with a scalar operand). The step's matrices do not fit a CU for a whole horizon (N nx^2 doubles),
+    // and a step is shorter than a round trip to HBM: the OTHER three wavefronts stream the next RG steps' blocks
+    // ([Acl' | B | S^-1 | K | targets | ff], as they lie in memory) into one half of an LDS ring while the first wavefront works
+    // through the half loaded before -- one workgroup barrier per RG steps. The rows of G are applied afterwards, by all
+    // 256 threads, to the stored trajectory. Rows are read with CLAMPED indices instead of being zero-padded: an entry beyond
+    // nx / nu multiplies a component that is zero. (First version: 256 threads, one role per wavefront, 2-3 barriers and one
+    // exposed memory round trip per step: 4.7 k cycles per step; this one: ~1 k.)
+    extern __shared__ __attribute__((aligned(16))) unsigned char stageg_dyn[];
+    T *ring = (T *)stageg_dyn;
+    // a half of the ring: RG blocks as they lie in the workspace (one flat copy), then RG x (nx targets + nu feed-forward terms)
+    const int XS = nx + nu, oT = 0, oF = nx;
+    const int RG = ring_doubles / (2 * (PSW + XS)) < 1 ? 1 : (ring_doubles / (2 * (PSW + XS)) > 16 ? 16 : ring_doubles / (2 * (PSW + XS)));
+    const int HALF = RG * (PSW + XS);
+    auto rlane = [&](T x, int l) {  // (l: compile-time after unrolling)
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+    };
+    // sum_l row[l rs] v_l over the (clamped) 32 components of the vector held one per lane in `v`: every LDS read issued before
+    // the first use, four partial sums (a dependent float64 FMA issues every 8 cycles, an independent one every 4)
+    auto dot32 = [&](const T *row, int rs, T v) {
+        T rv_[NXM];
+#pragma unroll
+        for (int l = 0; l < NXM; ++l) rv_[l] = row[(l < nx ? l : 0) * rs];
+        T a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int l = 0; l < NXM; l += 4) {
+            a0 += rv_[l] * rlane(v, l);
+            a1 += rv_[l + 1] * rlane(v, l + 1);
+            a2 += rv_[l + 2] * rlane(v, l + 2);
+            a3 += rv_[l + 3] * rlane(v, l + 3);
+        }
+        return (a0 + a1) + (a2 + a3);
+    };
     auto sweep = [&](int kp, int rp, bool tracking, const T *xstart, T *Vout, T *Hout) {
-        for (int i = tid; i < nx; i += BS) pv[i] = (tracking && termQ) ? -ka.wt * ggoal[i] : 0.0;
         const int ktop = tracking ? N - 1 : kp;
         for (int i = tid; i < n; i += BS)
             if (i >= (ktop + 1) * nu) ffv[i] = 0.0;
-        const bool roleT = tid < nu, roleP = tid >= 64 && tid < 64 + nx, roleG = tid >= 128 && tid - 128 < mk;
-        const int pi = tid - 64, gr = tid - 128;
-        T cur[NXM], cur2[NUM], nxt[NXM], nxt2[NUM], curs = 0.0, nxts = 0.0;
+        // steps kfirst, kfirst + dir, ... (RG of them, inside the horizon) into half `half` of the ring, by threads t, t + nth, ...:
+        // the blocks are one contiguous run of the workspace (eight loads in flight per thread), slot sidx <-> step kfirst + dir sidx
+        auto load_chunk = [&](int half, int kfirst, int dir, int t, int nth, bool fwd) {
+            int cnt = 0;
+            for (int sidx = 0; sidx < RG; ++sidx) cnt += (kfirst + dir * sidx >= 0 && kfirst + dir * sidx < N) ? 1 : 0;
+            if (cnt == 0) return;
+            const int klo = dir > 0 ? kfirst : kfirst - (cnt - 1);  // lowest step of the run
+            const T *src = Blk + (int64_t)klo * PSW;
+            T *dst = ring + (size_t)half * HALF;  // (block of step k at (k - klo) PSW)
+            typedef T T2 __attribute__((ext_vector_type(2)));
+            const int total = cnt * PSW / 2;  // (16-byte pairs: PSW is even, the blocks and the ring are 16-byte aligned)
+            const T2 *src2 = (const T2 *)src;
+            T2 *dst2 = (T2 *)dst;
+            for (int j0 = t; j0 < total; j0 += nth * 8) {
+                T2 v[8];
 #pragma unroll
-        for (int l = 0; l < NXM; ++l) cur[l] = nxt[l] = 0.0;
+                for (int u = 0; u < 8; ++u) v[u] = src2[j0 + u * nth < total ? j0 + u * nth : total - 1];
 #pragma unroll
-        for (int a = 0; a < NUM; ++a) cur2[a] = nxt2[a] = 0.0;
-        auto req_b = [&](int k) {  // backward operands of step k
-            if (roleT) {
-                const T *B = gB + k * sB, *Sk = Si + (int64_t)k * nu * nu;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? B[l * nu + tid] : 0.0;
-#pragma unroll
-                for (int a = 0; a < NUM; ++a) nxt2[a] = a < nu ? Sk[tid * nu + a] : 0.0;
-            } else if (roleP) {
-                const T *Ak = Acl + (int64_t)k * nx * nx + pi * nx;  // (stored transposed: row i = column i of Acl)
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? Ak[l] : 0.0;
-                nxts = (tracking && stageQ && k >= 1) ? gtgt[(int64_t)k * nx + pi] : 0.0;
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u * nth < total) dst2[j0 + u * nth] = v[u];
+            }
+            T *ext = dst + RG * PSW;
+            for (int j = t; j < cnt * XS; j += nth) {
+                const int kk = j / XS, i = j - kk * XS, k = klo + kk;
+                ext[j] = i < nx ? ((!fwd && tracking && stageQ && k >= 1) ? gtgt[(int64_t)k * nx + i] : 0.0) : (fwd ? ffv[k * nu + (i - nx)] : 0.0);
             }
         };
-        auto rotate = [&]() {
-#pragma unroll
-            for (int l = 0; l < NXM; ++l) cur[l] = nxt[l];
-#pragma unroll
-            for (int a = 0; a < NUM; ++a) cur2[a] = nxt2[a];
-            curs = nxts;
-        };
-        req_b(ktop);
-        rotate();
+        const int lane = tid & 63, ti = lane - 32;
+        const bool w0 = tid < 64, roleP = w0 && lane < nx, roleT = w0 && ti >= 0 && ti < nu;
+        const int lp = lane < nx ? lane : 0, tq = (ti >= 0 && ti < nu) ? ti : 0;  // (clamped: every lane reads SOME row)
+        // ---- backward: p_k = ql + Acl' p - K' rl, t = B' p + rl, ff = -S^-1 t  (ql = -C[kp, rp], rl = -D[kp, rp] at the row's stage)
+        T pc = (roleP && tracking && termQ) ? -ka.wt * ggoal[lane] : 0.0;  // p (lane l: component l)
+        const long long tb0 = (long long)__builtin_readcyclecounter();
         bsync();
-        for (int k = ktop; k >= 0; --k) {
-            if (k > 0) req_b(k - 1);
-            const bool here = !tracking && k == kp;
-            const T *Dr = (here && gD) ? gD + k * sD + rp * nu : nullptr;
-            const T *Cr = (here && gC) ? gC + k * sC + rp * nx : nullptr;
-            if (roleT) {  // t = B' p + rl  (rl = -D[kp, rp] at the row's stage)
-                T acc = Dr ? -Dr[tid] : 0.0;
+        load_chunk(0, ktop, -1, tid, BS, false);
+        bsync();
+        for (int c = 0, kc = ktop; kc >= 0; ++c, kc -= RG) {
+            if (!w0) {
+                load_chunk((c + 1) & 1, kc - RG, -1, tid - 64, BS - 64, false);
+            } else {
+                const int cntb = kc + 1 < RG ? kc + 1 : RG, klo = kc - (cntb - 1);
+                for (int sidx = 0; sidx < RG && kc - sidx >= 0; ++sidx) {
+                    const int k = kc - sidx;
+                    const T *blk = ring + (size_t)(c & 1) * HALF + (size_t)(k - klo) * PSW;
+                    const T *ext = ring + (size_t)(c & 1) * HALF + (size_t)RG * PSW + (size_t)(k - klo) * XS;
+                    const bool here = !tracking && k == kp;
+                    const T *Dr = (here && gD) ? gD + k * sD + rp * nu : nullptr;
+                    const T *Cr = (here && gC) ? gC + k * sC + rp * nx : nullptr;
+                    // this lane's row: state lanes a column of Acl (row lp of the stored transpose), input lanes a column of B
+                    const T *row = ti >= 0 ? blk + oB + tq : blk + lp * nx;
+                    const int rs = ti >= 0 ? nu : 1;
+                    T acc = 0.0;
+                    if (roleP) acc = (Cr ? -Cr[lane] : 0.0) - ka.wx * ext[oT + lp];
+                    if (roleT) acc = Dr ? -Dr[ti] : 0.0;
+                    acc += dot32(row, rs, pc);
+                    if (Dr && roleP) {
+                        const T *Kk = blk + oK;
+                        for (int a = 0; a < nu; ++a) acc += Kk[a * nx + lane] * Dr[a];
+                    }
+                    T f = 0.0;  // (input lanes: ff = -S^-1 t, t = acc of those lanes)
+                    const T *srow = blk + oS + tq * nu;
 #pragma unroll
-                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? pv[l] : 0.0);
-                tv[tid] = acc;
-            }
-            if (roleP) {  // p_k = ql + Acl' p - K' rl
-                T acc = Cr ? -Cr[pi] : 0.0;
-                acc -= ka.wx * curs;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? pv[l] : 0.0);
-                if (Dr) {
-                    const T *Kk = Kt + (int64_t)k * nu * nx;
-                    for (int a = 0; a < nu; ++a) acc += Kk[a * nx + pi] * Dr[a];
+                    for (int bb = 0; bb < NUM; ++bb) f -= srow[bb < nu ? bb : 0] * (bb < nu ? rlane(acc, 32 + bb) : 0.0);
+                    if (roleT) ffv[k * nu + ti] = f;
+                    pc = roleP ? acc : 0.0;
                 }
-                pn[pi] = acc;
             }
-            bsync();
-            if (roleT) {  // ff = -S^-1 t
-                T acc = 0.0;
-#pragma unroll
-                for (int b = 0; b < NUM; ++b) acc -= cur2[b] * (b < nu ? tv[b] : 0.0);
-                ffv[k * nu + tid] = acc;
-            }
-            if (roleP) pv[pi] = pn[pi];
-            rotate();
             bsync();
         }
-        for (int i = tid; i < nx; i += BS) xv[i] = xstart ? xstart[i] : 0.0;
-        auto req_f = [&](int k) {  // forward operands of step k
-            if (roleT) {
-                const T *Kk = Kt + (int64_t)k * nu * nx + tid * nx;
+        // ---- forward: u = ff - K x, x+ = Acl x + B ff  (= A x + B u)
+        const long long tf0 = (long long)__builtin_readcyclecounter();
+        t_bwd += tf0 - tb0;
+        T xc = (roleP && xstart) ? xstart[lane] : 0.0;  // x (lane l: component l)
+        load_chunk(0, 0, 1, tid, BS, true);  // (the barrier above made the feed-forward terms visible)
+        bsync();
+        for (int c = 0, kc = 0; kc < N; ++c, kc += RG) {
+            if (!w0) {
+                load_chunk((c + 1) & 1, kc + RG, 1, tid - 64, BS - 64, true);
+            } else {
+                for (int sidx = 0; sidx < RG && kc + sidx < N; ++sidx) {
+                    const int k = kc + sidx;
+                    const T *blk = ring + (size_t)(c & 1) * HALF + (size_t)sidx * PSW;
+                    const T *ext = ring + (size_t)(c & 1) * HALF + (size_t)RG * PSW + (size_t)sidx * XS;
+                    if (roleP) Xt[k * nx + lane] = xc;
+                    // state lanes: row lp of Acl (a column of the stored transpose) and of B; input lanes: row tq of K, negated below
+                    const T *row = ti >= 0 ? blk + oK + tq * nx : blk + lp;
+                    const int rs = ti >= 0 ? 1 : nx;
+                    const T sg = ti >= 0 ? -1.0 : 1.0;
+                    T acc = sg * dot32(row, rs, xc);
+                    const T ffown = ext[oF + tq];  // (input lanes: their feed-forward term)
+                    if (roleT) acc += ffown;
+                    const T *brow = blk + oB + lp * nu;
+                    T bf = 0.0;
 #pragma unroll
-                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? Kk[l] : 0.0;
-                nxts = ffv[k * nu + tid];
-            } else if (roleP) {
-                const T *A = gA + k * sA + pi * nx, *B = gB + k * sB + pi * nu;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) nxt[l] = l < nx ? A[l] : 0.0;
-#pragma unroll
-                for (int a = 0; a < NUM; ++a) nxt2[a] = a < nu ? B[a] : 0.0;
-            } else if (roleG) {
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) nxt[l] = (gC && l < nx) ? gC[k * sC + gr * nx + l] : 0.0;
-#pragma unroll
-                for (int a = 0; a < NUM; ++a) nxt2[a] = (gD && a < nu) ? gD[k * sD + gr * nu + a] : 0.0;
+                    for (int a = 0; a < NUM; ++a) bf += brow[a < nu ? a : 0] * (a < nu ? rlane(ffown, 32 + a) : 0.0);  // B ff
+                    if (roleP) acc += bf;
+                    if (roleT) Vout[k * nu + ti] = acc;
+                    xc = roleP ? acc : 0.0;
+                }
             }
-        };
-        bsync();  // (ffv of the backward sweep is complete)
-        req_f(0);
-        rotate();
-        for (int k = 0; k < N; ++k) {
-            if (k + 1 < N) req_f(k + 1);
-            if (roleT) {  // u = -K x + ff
-                T acc = curs;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) acc -= cur[l] * (l < nx ? xv[l] : 0.0);
-                uv[tid] = acc;
-                Vout[k * nu + tid] = acc;
-            }
-            bsync();
-            if (roleG) {  // rows of G at this stage
-                T acc = 0.0;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? xv[l] : 0.0);
-#pragma unroll
-                for (int a = 0; a < NUM; ++a) acc += cur2[a] * (a < nu ? uv[a] : 0.0);
-                Hout[k * mk + gr] = acc;
-            }
-            for (int r = tid; r + 128 < mk; r += BS) {  // (more than 128 rows per stage: the rest, without the read-ahead)
-                const int rr = r + 128;
-                T acc = 0.0;
-                if (gC)
-                    for (int i = 0; i < nx; ++i) acc += gC[k * sC + rr * nx + i] * xv[i];
-                if (gD)
-                    for (int a = 0; a < nu; ++a) acc += gD[k * sD + rr * nu + a] * uv[a];
-                Hout[k * mk + rr] = acc;
-            }
-            if (roleP) {  // x+ = A x + B u
-                T acc = 0.0;
-#pragma unroll
-                for (int l = 0; l < NXM; ++l) acc += cur[l] * (l < nx ? xv[l] : 0.0);
-#pragma unroll
-                for (int a = 0; a < NUM; ++a) acc += cur2[a] * (a < nu ? uv[a] : 0.0);
-                xn[pi] = acc;
-            }
-            bsync();
-            if (tid < nx) xv[tid] = xn[tid];
-            rotate();
             bsync();
         }
+        const long long tr0 = (long long)__builtin_readcyclecounter();
+        t_fwd += tr0 - tf0;
+        for (int i = tid; i < M; i += BS) {  // h = G (x, u), one row per thread (the barrier above made the trajectory visible)
+            const int k = i / mk, r = i - k * mk;
+            T acc = 0.0;
+            if (gC) {
+                const T *c = gC + k * sC + r * nx, *x = Xt + k * nx;
+                for (int l = 0; l < nx; ++l) acc += c[l] * x[l];
+            }
+            if (gD) {
+                const T *d = gD + k * sD + r * nu, *u = Vout + k * nu;
+                for (int a = 0; a < nu; ++a) acc += d[a] * u[a];
+            }
+            Hout[i] = acc;
+        }
+        bsync();
+        t_rows += (long long)__builtin_readcyclecounter() - tr0;
     };
 
     int status = notpd ? (int)MPCQP_NOT_PD : (int)MPCQP_MAX_ITER, iters = 0, nq = 0;
@@ -708,6 +739,9 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             stamp[1] = t_ric - t_start;
             stamp[2] = t_sweeps;
             stamp[3] = n_sweeps;
+            stamp[4] = t_bwd;
+            stamp[5] = t_fwd;
+            stamp[6] = t_rows;
         }
         if (ka.status) ka.status[prob] = status;
         if (ka.iters) ka.iters[prob] = iters;
@@ -729,7 +763,13 @@ size_t stageg_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_w
 int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
-    hipLaunchKernelGGL(mpcqp_stageg_kernel, dim3((unsigned)batch), dim3(BS), 0, st, ka, wl, (double *)ws);
+    // the sweeps' LDS ring: two halves of RG steps each (96 KB next to the kernel's 43 KB of static LDS; one workgroup per CU)
+    constexpr int ring_doubles = 12288;
+    static const bool attr_ok = hipFuncSetAttribute((const void *)mpcqp_stageg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    ring_doubles * (int)sizeof(double)) == hipSuccess;
+    if (!attr_ok) return MPCQP_EUNSUPPORTED;
+    hipLaunchKernelGGL(mpcqp_stageg_kernel, dim3((unsigned)batch), dim3(BS), ring_doubles * sizeof(double), st, ka, wl, (double *)ws,
+                       ring_doubles);
     return (int)hipGetLastError();
 }
 
