@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     // (developer probe, MpcqpSolveOpts.probe: cycles of the whole problem [0], of the recursion [1], of the sweeps [2], their number [3])
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     const long long t_ric = (long long)__builtin_readcyclecounter();
-    long long t_sweeps = 0, n_sweeps = 0, t_bwd = 0, t_fwd = 0, t_rows = 0;
+    long long t_sweeps = 0, n_sweeps = 0, t_bwd = 0, t_fwd = 0, t_rows = 0, t_w0 = 0;
 
     // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
     //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             if (!w0) {
                 load_chunk((c + 1) & 1, kc - RG, -1, tid - 64, BS - 64, false);
             } else {
+                const long long tc0 = (long long)__builtin_readcyclecounter();
                 const int cntb = kc + 1 < RG ? kc + 1 : RG, klo = kc - (cntb - 1);
                 for (int sidx = 0; sidx < RG && kc - sidx >= 0; ++sidx) {
                     const int k = kc - sidx;
@@ -358,6 +359,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                     if (roleT) ffv[k * nu + ti] = f;
                     pc = roleP ? acc : 0.0;
                 }
+                t_w0 += (long long)__builtin_readcyclecounter() - tc0;
             }
             bsync();
         }
@@ -371,6 +373,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             if (!w0) {
                 load_chunk((c + 1) & 1, kc + RG, 1, tid - 64, BS - 64, true);
             } else {
+                const long long tc0 = (long long)__builtin_readcyclecounter();
                 for (int sidx = 0; sidx < RG && kc + sidx < N; ++sidx) {
                     const int k = kc + sidx;
                     const T *blk = ring + (size_t)(c & 1) * HALF + (size_t)sidx * PSW;
@@ -391,6 +394,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                     if (roleT) Vout[k * nu + ti] = acc;
                     xc = roleP ? acc : 0.0;
                 }
+                t_w0 += (long long)__builtin_readcyclecounter() - tc0;
             }
             bsync();
         }
@@ -742,6 +746,7 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
             stamp[4] = t_bwd;
             stamp[5] = t_fwd;
             stamp[6] = t_rows;
+            stamp[7] = t_w0;
         }
         if (ka.status) ka.status[prob] = status;
         if (ka.iters) ka.iters[prob] = iters;
