@@ -126,6 +126,9 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     __shared__ T Pm[NXM * NXM], PAm[NXM * NXM], Tm[NXM * NXM], Am[NXM * NXM], PBm[NXM * NUM], Bm[NXM * NUM], G1[NUM * NXM], Km[NUM * NXM];
     __shared__ T Sm[NUM * NUM], Sim[NUM * NUM], pv[NXM], pn[NXM], xv[NXM], xn[NXM], tv[NUM], uv[NUM], redv[BS / 64];
     __shared__ T Ga[NUM * 2 * NUM];
+    constexpr int LQ = 256;  // slots whose coefficient / place are staged in LDS for the m-row passes
+    __shared__ T rvl[LQ];
+    __shared__ int physl[LQ];
     __shared__ int redi[BS / 64], flag;
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
@@ -600,10 +603,33 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                         stop = fail = true;
                         break;
                     }
-                    // s -= t G z with z = -(V_p - sum_a r_a V_a)
+                    // s -= t G z with z = -(V_p - sum_a r_a V_a). The coefficients and the slots' places are the same for every row:
+                    // staged in LDS once (they were re-read from the workspace per row and slot, the slot's place first: two
+                    // dependent round trips per term), four slots' entries requested together
+                    const bool staged = nq <= LQ;
+                    if (staged) {
+                        for (int a = tid; a < nq; a += BS) {
+                            rvl[a] = rv[a];
+                            physl[a] = phys[a];
+                        }
+                        bsync();
+                    }
                     for (int i = tid; i < M; i += BS) {
                         T gz = Hp[i];
-                        for (int a = 0; a < nq; ++a) gz -= rv[a] * Hs[(int64_t)phys[a] * M + i];
+                        if (staged) {
+                            int a = 0;
+                            for (; a + 4 <= nq; a += 4) {
+                                const T h0 = Hs[(int64_t)physl[a] * M + i], h1 = Hs[(int64_t)physl[a + 1] * M + i];
+                                const T h2 = Hs[(int64_t)physl[a + 2] * M + i], h3 = Hs[(int64_t)physl[a + 3] * M + i];
+                                gz -= rvl[a] * h0;
+                                gz -= rvl[a + 1] * h1;
+                                gz -= rvl[a + 2] * h2;
+                                gz -= rvl[a + 3] * h3;
+                            }
+                            for (; a < nq; ++a) gz -= rvl[a] * Hs[(int64_t)physl[a] * M + i];
+                        } else {
+                            for (int a = 0; a < nq; ++a) gz -= rv[a] * Hs[(int64_t)phys[a] * M + i];
+                        }
                         sl[i] = pos[i] >= 0 ? 0.0 : sl[i] + t * gz;
                     }
                     for (int a = tid; a < nq; a += BS) {
