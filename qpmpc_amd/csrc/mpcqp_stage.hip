@@ -1423,8 +1423,11 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                 forward_s(0.0, Vp, Xp);
             else
                 forward(nullptr, Vp, Xp);
-            wsync();
-            const double dpp = gdot(kp, wp, rp, Vp, Xp);
+            // SERIAL: the candidate's vectors are read where the sweep staged them, in LDS (step order) -- no wait for the workspace
+            // copy, which only the slot copy of a row that becomes active reads (each lane its own chunk)
+            const double *Vc = SERIAL ? ul : Vp, *Xc = SERIAL ? xl : Xp;
+            if constexpr (!serial) wsync();
+            const double dpp = gdot(kp, SERIAL ? (int64_t)kp : wp, rp, Vc, Xc);
             while (!added) {
                 if (iters >= max_iter) {
                     fail = true;
@@ -1432,8 +1435,11 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                 }
                 ++iters;
                 // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], wg(actk[a]), actr[a], Vp, Xp);
-                wsync();
+                for (int a = lane; a < nq; a += 64) cv[a] = gdot(actk[a], SERIAL ? (int64_t)actk[a] : wg(actk[a]), actr[a], Vc, Xc);
+                if constexpr (serial)
+                    lsync();  // (c goes from lane to lane through LDS)
+                else
+                    wsync();
                 double cr = 0.0;
                 for (int a = lane; a < nq; a += 64) {
                     double acc = 0.0;
@@ -1442,7 +1448,10 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                     cr += acc * cv[a];
                 }
                 cr = wave_sum(cr);
-                wsync();
+                if constexpr (serial)
+                    lsync();  // (r likewise)
+                else
+                    wsync();
                 const double d2 = dpp - cr;
                 const bool can_move = (nq < nvar) && (d2 > 1e-13 * dpp) && (d2 > 0.0);
                 // ---- ratio test on the multipliers
@@ -1477,9 +1486,9 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                 for (int k = k0; k < k1; ++k) {
                     double zu[NU], zx[NX];
 #pragma unroll
-                    for (int i = 0; i < NU; ++i) zu[i] = -Vp[wq(k) * NU + i];
+                    for (int i = 0; i < NU; ++i) zu[i] = -Vc[(SERIAL ? (int64_t)k : wq(k)) * NU + i];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) zx[i] = -Xp[wq(k) * NX + i];
+                    for (int i = 0; i < NX; ++i) zx[i] = -Xc[(SERIAL ? (int64_t)k : wq(k)) * NX + i];
                     for (int a = 0; a < nq; ++a) {
                         const double ra = rv[a];
                         const double *va = Vs + ((int64_t)a * NP + wq(k)) * NU, *xa = XVs + ((int64_t)a * NP + wq(k)) * NX;
