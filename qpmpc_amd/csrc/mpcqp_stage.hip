@@ -327,6 +327,18 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
     auto tick = [&](int slot) {
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();
     };
+    // (developer probe, launches of ONE period without the pipelined factor: slots 9, 10, 12, 13 are free there) time spent in the
+    // parts of an active-set iteration: sweeps [9], c and r = W c [10], ratio test [12], slack update [13]; the rest is the W update
+    long long tlast = 0;
+    const bool acc_on = stamp && !PIPE && !(ka.ep_on && ka.ep_periods > 1);
+    auto tacc = [&](int slot) {
+        if (acc_on) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0 && slot >= 0) stamp[slot] += now - tlast;
+            tlast = now;
+        }
+    };
+    if (acc_on && lane == 0) stamp[9] = stamp[10] = stamp[12] = stamp[13] = 0;
     // ================================================================= factor: Riccati recursion
     // Serial in k and nonlinear; the lane layout is described where the recursion starts (below).
     // MPCQP_OPT_REUSE_FACTOR: A, B and the weights are those of the launch that left its factor in this workspace
@@ -1411,6 +1423,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             double up = 0.0;
             bool added = false;
             // V_p = P^-1 g_p' and its trajectory do not change while p waits for room: solved once
+            tacc(-1);
             if constexpr (serial)
                 backward_s(kp, gC ? gC + kp * sC + rp * NX : nullptr, gD ? gD + kp * sD + rp * NU : nullptr, std::false_type{});
             else
@@ -1427,6 +1440,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             // copy, which only the slot copy of a row that becomes active reads (each lane its own chunk)
             const double *Vc = SERIAL ? ul : Vp, *Xc = SERIAL ? xl : Xp;
             if constexpr (!serial) wsync();
+            tacc(9);  // sweeps
             const double dpp = gdot(kp, SERIAL ? (int64_t)kp : wp, rp, Vc, Xc);
             while (!added) {
                 if (iters >= max_iter) {
@@ -1452,6 +1466,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                     lsync();  // (r likewise)
                 else
                     wsync();
+                tacc(10);  // c, r = W c
                 const double d2 = dpp - cr;
                 const bool can_move = (nq < nvar) && (d2 > 1e-13 * dpp) && (d2 > 0.0);
                 // ---- ratio test on the multipliers
@@ -1482,6 +1497,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                     slotsfull = true;
                     break;
                 }
+                tacc(12);  // ratio test, step
                 // ---- slacks: s_i -= t g_i . z ,  z = -(V_p - sum_a r_a V_a)  (this lane's chunk)
                 for (int k = k0; k < k1; ++k) {
                     double zu[NU], zx[NX];
@@ -1516,6 +1532,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                 }
                 up += t;
                 wsync();
+                tacc(13);  // slack update
                 if (full) {
                     // p becomes active in slot nq: W is bordered, the candidate's vectors move into the slot
                     const double id2 = 1.0 / d2;
@@ -1548,6 +1565,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                     --nq;
                 }
                 wsync();
+                tacc(-1);  // (W update, slot copy: the rest)
             }
             if (fail) break;
         }

@@ -8,6 +8,13 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "wip"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 if kind == "wip":
     bp = W.to_batch_problem(W.wip_batch(batch))
+elif kind == "sat":  # config 3's problems with states that saturate the input box (tools/probe_saturating.py)
+    w = W.wip_batch(batch, seed=9)
+    w["x0"][:, 1] += 0.3
+    w["x0"][:, 3] += 1.0
+    ts = np.stack([w["pendulum"].target_states(x, 0.5) for x in w["x0"]])
+    w["goal"], w["targets"] = ts[:, -4:], ts[:, :-4]
+    bp = W.to_batch_problem(w)
 elif kind in ("c5", "c5f64"):
     bp = W.to_batch_problem(W.synthetic_ltv_batch_slice(0, batch), dtype=torch.float32 if kind == "c5" else torch.float64)
 else:
@@ -25,6 +32,9 @@ for i, nme in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print(f"  {nme:16s} mean {d.mean().item():10.0f} cyc   max {d.max().item():10.0f}")
 print(f"  total            mean {(t[:,7]-t[:,0]).mean().item():10.0f} cyc   max {(t[:,7]-t[:,0]).max().item():10.0f}")
+if kind == "wip" or kind == "sat":
+    for i, nme in zip((9, 10, 12, 13), ["sweeps", "c, r = W c", "ratio test", "slack update"]):
+        print(f"    in loop: {nme:14s} mean {t[:, i].mean().item():10.0f} cyc   per iteration {t[:, i].sum().item() / max(1.0, plan.iters.float().sum().item()):8.0f}")
 if kind in ("c5", "c5f64"):
     for i, nme in zip(range(8, 15), ["selection", "backward", "forward", "gmul", "step calc", "slack update", "W update"]):
         print(f"    in loop: {nme:14s} mean {t[:, i].mean().item():10.0f} cyc")
