@@ -38,6 +38,7 @@ def _campaign(tool, args, seed, extra_env=None):
     ("stress_stagewise.py", (20, 64, "narrow"), 3, 1e-6),  # narrow stage-wise kernel (nx <= 4, nu <= 2)
     ("stress_f32.py", (24, 64), 41, 1e-3),              # float32 through the default dispatch vs the float64 oracle
     ("stress_f32.py", (24, 64), 46, 1e-3),
+    ("stress_general.py", (12, 8), 2, 1e-7),            # wide systems (17 <= nx <= 32, nu <= 8): the general stage-wise kernel
 ])
 def test_stress_campaign(tool, args, seed, bound):
     worst, nflag, flagged = _campaign(tool, args, seed)
