@@ -123,9 +123,13 @@ using namespace stageg;
 __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, int ring_doubles)
 {
     using T = double;
-    __shared__ T Pm[NXM * NXM], PAm[NXM * NXM], Tm[NXM * NXM], Am[NXM * NXM], PBm[NXM * NUM], Bm[NXM * NUM], G1[NUM * NXM], Km[NUM * NXM];
-    __shared__ T Sm[NUM * NUM], Sim[NUM * NUM], pv[NXM], pn[NXM], xv[NXM], xn[NXM], tv[NUM], uv[NUM], redv[BS / 64];
-    __shared__ T Ga[NUM * 2 * NUM];
+    // The matrices of the recursion and the sweeps' ring are never alive together: both are carved from the SAME dynamic LDS
+    // (64 KB; a workgroup's own 4 KB of static LDS next to it -- two workgroups per CU at the kernel's 235 VGPRs)
+    extern __shared__ __attribute__((aligned(16))) unsigned char stageg_dyn[];
+    T *Pm = (T *)stageg_dyn, *PAm = Pm + NXM * NXM, *Tm = PAm + NXM * NXM, *Am = Tm + NXM * NXM, *PBm = Am + NXM * NXM;
+    T *Bm = PBm + NXM * NUM, *G1 = Bm + NXM * NUM, *Km = G1 + NUM * NXM, *Sm = Km + NUM * NXM, *Sim = Sm + NUM * NUM, *Ga = Sim + NUM * NUM;
+    static_assert(4 * NXM * NXM + 4 * NXM * NUM + 2 * NUM * NUM + NUM * 2 * NUM <= 6144, "the recursion's matrices fit the ring");
+    __shared__ T redv[BS / 64];
     constexpr int LQ = 256;  // slots whose coefficient / place are staged in LDS for the m-row passes
     __shared__ T rvl[LQ];
     __shared__ int physl[LQ];
@@ -266,7 +270,6 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     // 256 threads, to the stored trajectory. Rows are read with CLAMPED indices instead of being zero-padded: an entry beyond
     // nx / nu multiplies a component that is zero. (First version: 256 threads, one role per wavefront, 2-3 barriers and one
     // exposed memory round trip per step: 4.7 k cycles per step; this one: ~1 k.)
-    extern __shared__ __attribute__((aligned(16))) unsigned char stageg_dyn[];
     T *ring = (T *)stageg_dyn;
     // a half of the ring: RG blocks as they lie in the workspace (one flat copy), then RG x (nx targets + nu feed-forward terms)
     const int XS = nx + nu, oT = 0, oF = nx;
@@ -794,8 +797,8 @@ size_t stageg_ws_doubles(const KernelArgs &ka, int maxq) { return (size_t)make_w
 int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipStream_t st)
 {
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
-    // the sweeps' LDS ring: two halves of RG steps each (96 KB next to the kernel's 43 KB of static LDS; one workgroup per CU)
-    constexpr int ring_doubles = 12288;
+    // the sweeps' LDS ring: two halves of RG steps each (the recursion's matrices live in the same 64 KB before the first sweep)
+    constexpr int ring_doubles = 8192;
     static const bool attr_ok = hipFuncSetAttribute((const void *)mpcqp_stageg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     ring_doubles * (int)sizeof(double)) == hipSuccess;
     if (!attr_ok) return MPCQP_EUNSUPPORTED;
