@@ -104,6 +104,17 @@ bool force_dense_g(int fl) { return fl & MPCQP_OPT_FORCE_DENSE_G; }
 // largest amount any of them needs
 const int kFlagVariants[] = {0, MPCQP_OPT_FORCE_LDS, MPCQP_OPT_FORCE_GWS, MPCQP_OPT_FORCE_DENSE_G, MPCQP_OPT_FORCE_CONDENSED};
 
+// float64 problems that would take the dense HBM-resident path (nx <= 16, nu > 4, n <= 256: condense + one QP per workgroup)
+// go to the general stage-wise kernel instead, unless an override flag asks for the dense solvers: since its second version
+// (round 4) it is 15-20x faster there (512 problems of nx = 12, nu = 6, N = 40: 124 against 8.4 ms). float32 keeps the dense
+// path (MFMA Gram, float32 solver), which is what makes that size affordable in float32.
+static bool prefer_general(const KernelArgs &ka, int dtype)
+{
+    const int override_bits = MPCQP_OPT_FORCE_LDS | MPCQP_OPT_FORCE_GWS | MPCQP_OPT_FORCE_DENSE_G | MPCQP_OPT_FORCE_CONDENSED |
+                              MPCQP_OPT_ONE_PER_WAVE;
+    return dtype == MPCQP_F64 && !(ka.opt_flags & override_bits) && !ka.warm_state && stageg_supported(ka, MPCQP_F64);
+}
+
 // Fused build+solve of mid-size problems of small systems goes to the stage-wise kernel (mpcqp_stage.hip): same
 // minimiser (tests), 1.5-1.9x the mid-size condensed kernel on config 3. Its slots hold min(n, m) <= 128 active rows, i.e.
 // every row that can be active at once, so nothing is lost against the condensed kernels.
@@ -424,6 +435,10 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
                 const BigPlan b = big_plan(ka, dims->dtype, true, for_solve != 0);
                 const size_t big = b.total(for_solve != 0) * elem_size(dims->dtype) * (size_t)batch;
                 if (big > v) v = big;
+                if (for_solve && prefer_general(ka, dims->dtype)) {  // (the launch takes the general kernel: the larger of the two)
+                    const size_t sg = stageg_ws_doubles(ka, stageg_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+                    if (sg > v) v = sg;
+                }
                 served = true;
             } else if (for_solve && stageg_supported(ka, dims->dtype)) {
                 const size_t sg = stageg_ws_doubles(ka, stageg_default_maxq(ka)) * sizeof(double) * (size_t)batch;
@@ -695,9 +710,9 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         return run_solver<MODE_FUSED>(ka, stepA, stepB, dims->dtype, batch, st);
     // HBM-resident path: propagate + Gram (MFMA for f32) into the workspace, then the
     // general solver with its arrays in the workspace as well
-    if (!big_supported(ka) || ka.n > 256) {
-        // wide systems on horizons the dense path cannot hold: the general stage-wise kernel (float64; float32 launches of
-        // these dimensions arrive here converted, promote_f32)
+    if (!big_supported(ka) || ka.n > 256 || prefer_general(ka, dims->dtype)) {
+        // wide systems on horizons the dense path cannot hold -- and every float64 problem it could hold (prefer_general): the
+        // general stage-wise kernel (float64; float32 launches of these dimensions arrive here converted, promote_f32)
         if (!stageg_supported(ka, dims->dtype) || ka.warm_state) return MPCQP_ETOOLARGE;
         const int maxq = stageg_default_maxq(ka);
         const size_t need = stageg_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;

@@ -8,10 +8,11 @@ from qpmpc_amd import solve_mpc_batch, workloads as W
 from stress_stagewise import random_ltv
 nx, nu, N, mk = (int(a) for a in sys.argv[1:5])
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+dt = torch.float32 if (len(sys.argv) > 6 and sys.argv[6] == "f32") else torch.float64
 rng = np.random.default_rng(7)
 w = random_ltv(rng, batch, nx, nu, N, mk, 1.0)
 w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
-bp = W.to_batch_problem(w)
+bp = W.to_batch_problem(w, dtype=dt)
 def timed(**kw):
     p = solve_mpc_batch(bp, **kw); torch.cuda.synchronize()
     t0 = time.perf_counter(); p = solve_mpc_batch(bp, **kw); torch.cuda.synchronize()
