@@ -25,6 +25,10 @@
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
+#ifndef STAGEG_DBG
+#define STAGEG_DBG 0 /* timing experiments only (wrong results) */
+#endif
+
 namespace mpcqp {
 namespace stageg {
 
@@ -120,7 +124,7 @@ __device__ __forceinline__ bool block_any(bool p, int *redi, int tid)
 
 using namespace stageg;
 
-__global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, int ring_doubles)
+__global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka, const Ws wl, double *__restrict__ wsbase, int ring_doubles)
 {
     using T = double;
     // The matrices of the recursion and the sweeps' ring are never alive together: both are carved from the SAME dynamic LDS
@@ -281,6 +285,26 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
     // sum_l row[l rs] v_l over the (clamped) 32 components of the vector held one per lane in `v`: every LDS read issued before
     // the first use, four partial sums (a dependent float64 FMA issues every 8 cycles, an independent one every 4)
     auto dot32 = [&](const T *row, int rs, T v) {
+#if STAGEG_DBG & 1
+        return row[0] * v;  // (timing experiment: no dot product)
+#endif
+#if STAGEG_DBG & 2
+        {  // (timing experiment: the LDS reads without the lane reads)
+            T a = 0.0;
+#pragma unroll
+            for (int l = 0; l < NXM; ++l) a += row[(l < nx ? l : 0) * rs] * v;
+            return a;
+        }
+#endif
+#if STAGEG_DBG & 4
+        {  // (timing experiment: the lane reads without the LDS reads)
+            T a = 0.0;
+            const T r0 = row[0];
+#pragma unroll
+            for (int l = 0; l < NXM; ++l) a += r0 * rlane(v, l);
+            return a;
+        }
+#endif
         T rv_[NXM];
 #pragma unroll
         for (int l = 0; l < NXM; ++l) rv_[l] = row[(l < nx ? l : 0) * rs];
@@ -330,6 +354,11 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
         const int lp = lane < nx ? lane : 0, tq = (ti >= 0 && ti < nu) ? ti : 0;  // (clamped: every lane reads SOME row)
         // ---- backward: p_k = ql + Acl' p - K' rl, t = B' p + rl, ff = -S^-1 t  (ql = -C[kp, rp], rl = -D[kp, rp] at the row's stage)
         T pc = (roleP && tracking && termQ) ? -ka.wt * ggoal[lane] : 0.0;  // p (lane l: component l)
+        // (what a step needs besides its slot is formed once per sweep: a kernel argument or a 64-bit address formed per step is
+        // a scalar load / a chain of integer operations in the serial wavefront's path)
+        const T wxs = ka.wx;
+        const T *DrK = (!tracking && gD) ? gD + kp * sD + rp * nu : nullptr, *CrK = (!tracking && gC) ? gC + kp * sC + rp * nx : nullptr;
+        const T crl = (CrK && roleP) ? -CrK[lane] : 0.0, drl = (DrK && roleT) ? -DrK[ti] : 0.0;  // the row's own entries, by lane
         const long long tb0 = (long long)__builtin_readcyclecounter();
         bsync();
         load_chunk(0, ktop, -1, tid, BS, false);
@@ -345,23 +374,27 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                     const T *blk = ring + (size_t)(c & 1) * HALF + (size_t)(k - klo) * PSW;
                     const T *ext = ring + (size_t)(c & 1) * HALF + (size_t)RG * PSW + (size_t)(k - klo) * XS;
                     const bool here = !tracking && k == kp;
-                    const T *Dr = (here && gD) ? gD + k * sD + rp * nu : nullptr;
-                    const T *Cr = (here && gC) ? gC + k * sC + rp * nx : nullptr;
                     // this lane's row: state lanes a column of Acl (row lp of the stored transpose), input lanes a column of B
                     const T *row = ti >= 0 ? blk + oB + tq : blk + lp * nx;
                     const int rs = ti >= 0 ? nu : 1;
-                    T acc = 0.0;
-                    if (roleP) acc = (Cr ? -Cr[lane] : 0.0) - ka.wx * ext[oT + lp];
-                    if (roleT) acc = Dr ? -Dr[ti] : 0.0;
+                    T acc = here ? crl + drl : 0.0;
+                    if (roleP) acc -= wxs * ext[oT + lp];
                     acc += dot32(row, rs, pc);
-                    if (Dr && roleP) {
+                    if (here && DrK && roleP) {
                         const T *Kk = blk + oK;
-                        for (int a = 0; a < nu; ++a) acc += Kk[a * nx + lane] * Dr[a];
+                        for (int a = 0; a < nu; ++a) acc += Kk[a * nx + lane] * DrK[a];
                     }
-                    T f = 0.0;  // (input lanes: ff = -S^-1 t, t = acc of those lanes)
+                    // (input lanes: ff = -S^-1 t, t = acc of those lanes. No branch per term -- a taken or untaken branch costs a lone
+                    // wavefront more than the term: lanes that are no input lane hold a zero, the clamped entry of S^-1 is a number)
+                    const T tm = roleT ? acc : 0.0;
                     const T *srow = blk + oS + tq * nu;
+                    T f0 = 0.0, f1 = 0.0;
 #pragma unroll
-                    for (int bb = 0; bb < NUM; ++bb) f -= srow[bb < nu ? bb : 0] * (bb < nu ? rlane(acc, 32 + bb) : 0.0);
+                    for (int bb = 0; bb < NUM; bb += 2) {
+                        f0 -= srow[bb < nu ? bb : 0] * rlane(tm, 32 + bb);
+                        f1 -= srow[bb + 1 < nu ? bb + 1 : 0] * rlane(tm, 32 + bb + 1);
+                    }
+                    const T f = f0 + f1;
                     if (roleT) ffv[k * nu + ti] = f;
                     pc = roleP ? acc : 0.0;
                 }
@@ -390,13 +423,16 @@ __global__ void __launch_bounds__(BS) mpcqp_stageg_kernel(const KernelArgs ka, c
                     const int rs = ti >= 0 ? 1 : nx;
                     const T sg = ti >= 0 ? -1.0 : 1.0;
                     T acc = sg * dot32(row, rs, xc);
-                    const T ffown = ext[oF + tq];  // (input lanes: their feed-forward term)
-                    if (roleT) acc += ffown;
+                    const T ffown = roleT ? ext[oF + tq] : 0.0;  // (input lanes: their feed-forward term; zero elsewhere)
+                    acc += ffown;
                     const T *brow = blk + oB + lp * nu;
-                    T bf = 0.0;
+                    T b0 = 0.0, b1 = 0.0;  // B ff (no branch per term: see the backward sweep)
 #pragma unroll
-                    for (int a = 0; a < NUM; ++a) bf += brow[a < nu ? a : 0] * (a < nu ? rlane(ffown, 32 + a) : 0.0);  // B ff
-                    if (roleP) acc += bf;
+                    for (int a = 0; a < NUM; a += 2) {
+                        b0 += brow[a < nu ? a : 0] * rlane(ffown, 32 + a);
+                        b1 += brow[a + 1 < nu ? a + 1 : 0] * rlane(ffown, 32 + a + 1);
+                    }
+                    if (roleP) acc += b0 + b1;
                     if (roleT) Vout[k * nu + ti] = acc;
                     xc = roleP ? acc : 0.0;
                 }
