@@ -6,3 +6,5 @@ for s in 21 22 23 24 25 26; do echo "stress_pair 40x256 seed $s: $(STRESS_SEED=$
 for s in 21 22 23 24; do echo "stress_pair SEEDED 40x256 seed $s: $(STRESS_SEEDED=1 STRESS_SEED=$s python tools/stress_pair.py 40 256 2>&1 | tail -1)"; done
 for s in 6 7 8 9; do echo "stress_stagewise wide 20x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 20 128 2>&1 | tail -1)"; echo "stress_stagewise narrow 20x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 20 128 narrow 2>&1 | tail -1)"; done
 for s in 56 57 58 59 60 61 62 63; do echo "stress_f32 60x128 seed $s: $(STRESS_SEED=$s python tools/stress_f32.py 60 128 2>&1 | grep -E 'CHECK|worst' | tr '\n' ' ')"; done
+for s in 6 7 8 9 10 11 12 13 14 15 16 17; do echo "stress_stagewise narrow 30x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 30 128 narrow 2>&1 | tail -1)"; done
+for s in 1 2 3 4 5 6 7 8; do echo "stress_general 12x8 seed $s: $(STRESS_SEED=$s python tools/stress_general.py 12 8 2>&1 | tail -1)"; done
