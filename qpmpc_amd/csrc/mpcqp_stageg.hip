@@ -25,6 +25,9 @@
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
+#ifndef STAGEG_REFRESH
+#define STAGEG_REFRESH 64 /* iterations between rebuilds of W, the multipliers and the slacks from scratch */
+#endif
 #ifndef STAGEG_DBG
 #define STAGEG_DBG 0 /* timing experiments only (wrong results) */
 #endif
@@ -547,12 +550,12 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         bsync();
         const int max_iter = ka.max_iter;
         bool fail = false, slotsfull = false;
-        int fails = 0, next_refresh = 64, rescues = 0;
+        int fails = 0, next_refresh = STAGEG_REFRESH, rescues = 0;
         for (;;) {
             // ---- active-set loop (oracle/stagewise_np.py::solve_stagewise)
             for (;;) {
                 if (nq > 0 && iters >= next_refresh) {  // every 64 iterations: W, lam and the slacks from scratch
-                    next_refresh = iters + 64;
+                    next_refresh = iters + STAGEG_REFRESH;
                     refresh_state();  // (a failed refresh leaves W as it was rebuilt so far: the verification below decides)
                 }
                 T best = INF;
