@@ -25,8 +25,17 @@
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
+#ifndef STAGEG_NREF
+#define STAGEG_NREF 1 /* refinement steps of r = W c for a nearly dependent row */
+#endif
 #ifndef STAGEG_REFRESH
-#define STAGEG_REFRESH 64 /* iterations between rebuilds of W, the multipliers and the slacks from scratch */
+// iterations between rebuilds of W, the multipliers and the slacks from scratch. 64 until the refinement of r (below) existed;
+// with it a rebuild every 64 iterations HURTS on the one nearly fully active problem of tools/stress_general.py (seed 7: the
+// rebuilt W -- Gauss-Jordan without pivoting on an ill-conditioned Gram matrix -- and the re-derived multipliers send it
+// wandering: MAX_ITER / INFEASIBLE after 1.3-3.5 k iterations), never rebuilding loses the detection of truly infeasible
+// problems (they wander to the iteration limit); at 1024 that batch comes out like the oracle's (solved in 523 iterations,
+// three infeasible ones reported) and the hyperactive test problems still pass.
+#define STAGEG_REFRESH 1024
 #endif
 #ifndef STAGEG_DBG
 #define STAGEG_DBG 0 /* timing experiments only (wrong results) */
@@ -554,7 +563,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         for (;;) {
             // ---- active-set loop (oracle/stagewise_np.py::solve_stagewise)
             for (;;) {
-                if (nq > 0 && iters >= next_refresh) {  // every 64 iterations: W, lam and the slacks from scratch
+                if (nq > 0 && iters >= next_refresh) {  // every STAGEG_REFRESH iterations: W, lam and the slacks from scratch
                     next_refresh = iters + STAGEG_REFRESH;
                     refresh_state();  // (a failed refresh leaves W as it was rebuilt so far: the verification below decides)
                 }
@@ -604,8 +613,35 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                     bsync();
                     T part = 0.0;
                     for (int a = tid; a < nq; a += BS) part += cv[a] * rv[a];
-                    const T cr = block_sum(part, redv, tid);
-                    const T d2 = dpp - cr;
+                    T cr = block_sum(part, redv, tid);
+                    T d2 = dpp - cr;
+                    // A row that looks (nearly) DEPENDENT on the active ones -- |z|^2 = g_p V_p - c' W c below 1e-3 of g_p V_p -- is
+                    // judged on a refined r: one step of iterative refinement with the Gram matrix of the active rows, read off
+                    // the slots (entry (a, b) = row a of h_b). W is an explicit inverse kept by rank-one updates (and rebuilt
+                    // without pivoting): near a full active set its error turns a row that can enter into one that cannot, and
+                    // with no multiplier to drop the problem was reported infeasible (tools/stress_general.py seed 7: a problem
+                    // with u = 0 strictly feasible; the oracle solves it in 515 iterations, this kernel now in 519).
+                    for (int pass = 0; pass < STAGEG_NREF && nq > 0 && nq <= LQ && !(d2 > 1e-3 * dpp); ++pass) {
+                        for (int a = tid; a < nq; a += BS) physl[a] = phys[a];
+                        bsync();
+                        for (int a = tid; a < nq; a += BS) {
+                            T acc = cv[a];
+                            const int ra = actrow[a];
+                            for (int b = 0; b < nq; ++b) acc -= Hs[(int64_t)physl[b] * M + ra] * rv[b];
+                            rvl[a] = acc;  // c - Gram r
+                        }
+                        bsync();
+                        part = 0.0;
+                        for (int a = tid; a < nq; a += BS) {
+                            T acc = rv[a];
+                            for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * rvl[b];
+                            rv[a] = acc;
+                            part += cv[a] * acc;
+                        }
+                        bsync();
+                        cr = block_sum(part, redv, tid);
+                        d2 = dpp - cr;
+                    }
                     const bool can_move = nq < n && d2 > 1e-13 * dpp && d2 > 0.0;
                     if (can_move && nq >= maxq) {  // the step would need one more slot than this launch holds
                         slotsfull = stop = fail = true;
