@@ -164,6 +164,15 @@ def solve_stagewise(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-12)
             dpp = gdot(kp, rp, Vp, Xp)
             r_ = W @ c if len(act) else np.zeros(0)
             d2 = dpp - float(c @ r_) if len(act) else dpp
+            if len(act) and not d2 > 1e-3 * dpp:
+                # A row that looks nearly dependent on the active ones is judged on a refined r: one step of iterative
+                # refinement with the Gram matrix of the active rows (entry (a, b) = g_a . V_b). |z|^2 = dpp - c' W c is a
+                # difference of two nearly equal numbers there, and W is an explicit inverse kept by rank-one updates: without
+                # this a feasible, nearly fully active problem (tools/stress_general.py, seed 7) came back 'infeasible'
+                # after 389 iterations; with it, solved in 519 like the dense oracle (515). mpcqp_stageg.hip does the same.
+                Gm = np.array([[gdot(ka_, ra_, V[b_], XV[b_]) for b_ in range(len(act))] for (ka_, ra_) in act])
+                r_ = r_ + W @ (c - Gm @ r_)
+                d2 = dpp - float(c @ r_)
             can_move = len(act) < n and d2 > 1e-13 * dpp and d2 > 0.0
             cand = [a for a in range(len(act)) if r_[a] > 0.0]
             t1, l = (np.inf, -1)
