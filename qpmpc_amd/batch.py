@@ -510,7 +510,8 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     synchronisation, only for problems with more than 128 variables and rows).
 
     ``retry_unsolved``: problems that come back ``MPCQP_MAX_ITER`` are solved once more through the OTHER formulations of the
-    same solver on the GPU (the LDS workgroup kernel -- Householder-based, the sturdiest of them --, then the stage-wise one):
+    same solver on the GPU (the LDS workgroup kernel -- Householder-based, the sturdiest of them --, the condensed kernels where a
+    wide system went to the general stage-wise kernel, then the stage-wise one):
     a handful of degenerate problems in 10^4 (hundreds of iterations, rows nearly conflicting) end the mid-size dense kernel's
     verification rounds unsolved while the others -- and the reference's backends -- solve them. It reads the statuses (a
     synchronisation), hence off by default here and on in ``solve_mpc``.
@@ -572,7 +573,8 @@ def _retry_unsolved(plan: "BatchPlan", max_iter, feas_tol, opt_kw) -> None:
     """``MPCQP_MAX_ITER`` items of a default-dispatch solve, once more through the other formulations (see solve_mpc_batch)."""
     problem = plan.problem
     kw = {k: v for k, v in opt_kw.items() if k not in ("warm_state", "warm_start", "probe", "flags")}
-    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"formulation": "stagewise"}):
+    # (FORCE_CONDENSED: wide systems take the general stage-wise kernel by default, the condensed kernels are their other formulation)
+    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"flags": _capi.OPT_FORCE_CONDENSED}, {"formulation": "stagewise"}):
         left = plan.status == _capi.MAX_ITER
         if not bool(left.any().item()):
             return

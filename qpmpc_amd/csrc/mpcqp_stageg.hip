@@ -25,6 +25,12 @@
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
 
+#ifndef STAGEG_VPASS
+// passes of the final verification: each one re-evaluates every slack from scratch and, while an active row is off its bound,
+// corrects the multipliers by W times the residuals (a Richardson iteration preconditioned by the inexact W: two passes were
+// not enough near a full active set -- tools/stress_tight.py general, seed 8)
+#define STAGEG_VPASS 6
+#endif
 #ifndef STAGEG_NREF
 #define STAGEG_NREF 1 /* refinement steps of r = W c for a nearly dependent row */
 #endif
@@ -589,6 +595,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                 bool added = false, stop = false, rescued = false;
                 while (!added) {
                     if (iters >= max_iter) {
+                        if (stamp && tid == 0) stamp[8] = 1;  // (developer probe: why the problem stopped)
                         status = MPCQP_MAX_ITER;
                         stop = fail = true;
                         break;
@@ -678,6 +685,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                             if (refresh_state()) break;  // (select again)
                         }
                         status = MPCQP_INFEASIBLE;
+                        if (stamp && tid == 0) stamp[8] = 5;  // (developer probe: why the problem stopped)
                         stop = fail = true;
                         break;
                     }
@@ -781,7 +789,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
             if (fail) break;
             // ---- verification from scratch: s = s0 + sum_a lam_a h_a ; active rows on their bounds, inactive rows feasible
             bool dirty = false, offa = false;
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < STAGEG_VPASS; ++pass) {
                 dirty = offa = false;
                 for (int a = tid; a < nq; a += BS) offa |= !(lamv[a] >= 0.0);
                 for (int i = tid; i < M; i += BS) {
@@ -798,9 +806,34 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                 }
                 offa = block_any(offa, redi, tid);
                 if (!offa) break;
-                if (pass == 1) {
+                if (pass == STAGEG_VPASS - 1) {
+                    if (stamp && tid == 0) {
+                        stamp[8] = 2;  // (developer probe: why the problem stopped)
+                        stamp[9] = nq;
+                        long long worst = 0, neg = 0;
+                        for (int a = 0; a < nq; ++a) {
+                            const long long r_ = (long long)(fabs(cv[a]) / thr[actrow[a]]);
+                            worst = r_ > worst ? r_ : worst;
+                            neg += lamv[a] == 0.0;
+                        }
+                        stamp[10] = worst;
+                        stamp[11] = neg;
+                    }
                     fail = true;
                     break;
+                }
+                // (from the second correction on with W rebuilt from the slots' Gram matrix: the rank-one-updated inverse may be too
+                // far off for the correction to contract)
+                if (pass >= 1 && nq > 0) {
+                    for (int a = tid; a < nq; a += BS) sl[actrow[a]] = cv[a];  // (the rebuild uses cv; sl is rewritten by the next pass)
+                    bsync();
+                    if (!refresh_W()) {
+                        if (stamp && tid == 0) stamp[9] = 100 + pass;
+                        fail = true;
+                        break;
+                    }
+                    for (int a = tid; a < nq; a += BS) cv[a] = sl[actrow[a]];
+                    bsync();
                 }
                 for (int a = tid; a < nq; a += BS) {  // lam -= W rho_A
                     T acc = 0.0;
@@ -815,6 +848,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                 bsync();
             }
             if (fail) {
+                if (stamp && tid == 0) stamp[8] = 3;  // (developer probe: why the problem stopped)
                 status = MPCQP_MAX_ITER;
                 break;
             }
@@ -824,6 +858,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                 break;
             }
             if (++fails >= 4) {
+                if (stamp && tid == 0) stamp[8] = 4;  // (developer probe: why the problem stopped)
                 status = MPCQP_MAX_ITER;
                 break;
             }

@@ -8,3 +8,6 @@ for s in 6 7 8 9; do echo "stress_stagewise wide 20x128 seed $s: $(STRESS_SEED=$
 for s in 56 57 58 59 60 61 62 63; do echo "stress_f32 60x128 seed $s: $(STRESS_SEED=$s python tools/stress_f32.py 60 128 2>&1 | grep -E 'CHECK|worst' | tr '\n' ' ')"; done
 for s in 6 7 8 9 10 11 12 13 14 15 16 17; do echo "stress_stagewise narrow 30x128 seed $s: $(STRESS_SEED=$s python tools/stress_stagewise.py 30 128 narrow 2>&1 | tail -1)"; done
 for s in 1 2 3 4 5 6 7 8; do echo "stress_general 12x8 seed $s: $(STRESS_SEED=$s python tools/stress_general.py 12 8 2>&1 | tail -1)"; done
+# nearly fully active problems (tools/stress_tight.py): the general kernel's known limit shows here
+for s in 1 2 3 4 5 6 7 8 9; do echo "stress_tight general 8x8 seed $s: $(STRESS_SEED=$s python tools/stress_tight.py general 8 8 2>&1 | tail -1)"; done
+for s in 1 2 3; do echo "stress_tight wide 8x8 seed $s: $(STRESS_SEED=$s python tools/stress_tight.py wide 8 8 2>&1 | tail -1)"; echo "stress_tight narrow 8x8 seed $s: $(STRESS_SEED=$s python tools/stress_tight.py narrow 8 8 2>&1 | tail -1)"; done
