@@ -327,6 +327,8 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
             # the dense path (qpmpc/mpc_qp.py:99-105) is timed by itself, in this run, on this workload's problems
             out["roofline"]["gram_mfma"] = _gram_mfma_block(w)
         out["accuracy"] = _accuracy(args, w, run)
+        if args.config == 4 and world == 1:
+            out["paired_by_last_counts"] = _paired_block(run, local_per_step)
         if not args.no_extras and world == 1 and args.config == 2:
             try:
                 out["other_workloads"] = other_workloads()
@@ -337,6 +339,44 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores_value"]
     return out
+
+
+def _paired_block(run, problems, reps: int = 50):
+    """Not the headline: the same launch with MpcqpSolveOpts.order = the batch sorted by the PREVIOUS launch's iteration counts
+    (mpcqp_order_by_count: what a receding-horizon loop has at hand -- here the previous launch solved the same problems, so the
+    counts are exact and this is the ceiling of the technique), the device-side sort timed with it."""
+    import torch
+
+    from qpmpc_amd import pairing_order
+
+    def timed(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    solver = run.solver
+    order = torch.empty_like(solver.iters)
+    natural = timed(solver.launch)
+    pairing_order(solver.iters, out=order)
+    solver.set_order(order)
+    paired = timed(solver.launch)
+
+    def period():
+        solver.launch()
+        pairing_order(solver.iters, out=order)
+
+    with_sort = timed(period)
+    solver.set_order(None)
+    return {"ms_natural": natural, "ms_paired": paired, "ms_paired_plus_sort": with_sort,
+            "value_paired_plus_sort": problems / (with_sort * 1e-3), "unit": "problems/s",
+            "note": "order = mpcqp_order_by_count(last launch's iters), re-sorted every launch; statuses and iteration counts are those "
+                    "of the natural order, plans equal to rounding (tests/test_gpu_pairing.py); not the headline value"}
 
 
 def _overlap_two_streams(args, run, rank, world, barrier, allreduce, dev):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 8
+#define MPCQP_ABI_VERSION 9
 
 /* element type of every floating-point buffer of a call. It is the STORAGE type: mpcqp_build_solve_batch computes
  * MPCQP_F32 problems of at most 160 variables (and every float32 problem only the general stage-wise kernel serves) in
@@ -206,6 +206,17 @@ typedef struct MpcqpSolveOpts {
      * fall off the horizon's start (or name a padded row) are dropped. 0: the rows kept their places. */
     int32_t warm_shift;
     int32_t reserved_;
+    /* Pairing order (ABI 9), NULL = natural: DEVICE array of `batch` int32, a permutation of 0 .. batch-1. The small-problem
+     * fused kernel (n <= 16, m <= 32) puts TWO problems on a wavefront, which then runs max(trips_a, trips_b) active-set trips --
+     * 13.1 against 10.75 per problem on BASELINE config 4 (examples/humanoid_one_step.py:42-80 times 65,536). With an order,
+     * half-wavefront i takes problem order[i]; outputs stay where they were (U, lam, status, iters are indexed by problem), every
+     * problem's iterations are the same (the two halves of a wavefront sum in different orders: plans equal to rounding). A receding-horizon loop passes mpcqp_order_by_count() of last period's iteration counts
+     * (qpmpc/solve_mpc.py:43 is called once per period, examples/lipm_walking_controller.py:307-335): launches of several rounds
+     * get up to 12 % shorter, a launch that fills the machine once gains nothing. Cold launches of mpcqp_build_solve_batch that
+     * the small-problem fused kernel serves only: MPCQP_EUNSUPPORTED with warm_state, with a dispatch override, for other
+     * dimensions and from every other entry point. The array is read during the launch (keep it alive until the stream has
+     * passed it) and NOT validated: an index outside the batch reads and writes out of bounds. */
+    const int32_t *order;
 } MpcqpSolveOpts;
 
 /* ABI version of the loaded library (== MPCQP_ABI_VERSION of its build). */
@@ -403,6 +414,14 @@ int mpcqp_wip_periods_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
 /* Bookkeeping of closed loops (the reference's loops count nothing; ours report failures and iterations):
  * stats[0] += number of problems with status != 0, stats[1] += sum of iters. stats: two int64 in DEVICE memory. */
 int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t batch, int64_t *stats, void *stream);
+
+/* A pairing order for MpcqpSolveOpts.order (ABI 9): order = the problems sorted by counts[] (last period's `iters`, clamped to
+ * 0 .. 1023), longest first, by a counting sort on the device (three small launches, ~10 us for 65,536). Equal counts come out in
+ * an unspecified order. counts, order: DEVICE int32 [batch]; workspace: mpcqp_order_workspace_bytes(batch) bytes of DEVICE memory
+ * (MPCQP_EWORKSPACE if smaller). The reference has no counterpart: its solver is called per problem (qpmpc/solve_mpc.py:43). */
+size_t mpcqp_order_workspace_bytes(int64_t batch);
+int mpcqp_order_by_count(const int32_t *counts, int64_t batch, int32_t *order, void *workspace, size_t workspace_bytes,
+                         void *stream);
 
 /* One period of `batch` LIPM walking controllers, fused (examples/lipm_walking_controller.py:304-333):
  * if U is not NULL, apply the first jerk of each plan (U[b*u_stride], zero when status[b] != 0) to

@@ -18,6 +18,7 @@ from .batch import (  # noqa: F401
     WarmState,
     SharedModel,
     rollout_batch,
+    pairing_order,
     solve_mpc_batch,
     solve_qp_batch,
 )
@@ -45,6 +46,7 @@ __all__ = [
     "WarmState",
     "SharedModel",
     "PreparedModelSolve",
+    "pairing_order",
     "solve_mpc_batch",
     "solve_qp_batch",
     "rollout_batch",

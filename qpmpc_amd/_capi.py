@@ -13,8 +13,8 @@ from .exceptions import BackendError
 F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
-EINVAL, EUNSUPPORTED = -1, -6
-ABI_VERSION = 8
+EINVAL, EWORKSPACE, EUNSUPPORTED = -1, -5, -6
+ABI_VERSION = 9
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED, OPT_EXACT_SELECTION = 64, 128, 256, 512, 1024
 WARM_OPERATOR, WARM_ACTIVE_SET = 1, 2
@@ -42,6 +42,8 @@ EXPORTS = (
     "mpcqp_solve_model_batch",
     "mpcqp_solve_model_bounds_batch",
     "mpcqp_accumulate_stats",
+    "mpcqp_order_workspace_bytes",
+    "mpcqp_order_by_count",
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
     "mpcqp_wip_period_batch",
@@ -72,6 +74,7 @@ class SolveOpts(C.Structure):
         ("max_iter", C.c_int32), ("flags", C.c_int32), ("feas_tol", C.c_double),
         ("warm_state", C.c_void_p), ("warm_start", C.c_int32), ("factor_slot", C.c_int32),
         ("probe", C.c_void_p), ("warm_state_bytes", C.c_size_t), ("warm_shift", C.c_int32), ("reserved_", C.c_int32),
+        ("order", C.c_void_p),
     ]
 
 
@@ -141,6 +144,10 @@ def load():
                                                    vp, vp, vp, vp, vp]
     lib.mpcqp_accumulate_stats.restype = C.c_int
     lib.mpcqp_accumulate_stats.argtypes = [vp, vp, i64, vp, vp]
+    lib.mpcqp_order_workspace_bytes.restype = C.c_size_t
+    lib.mpcqp_order_workspace_bytes.argtypes = [i64]
+    lib.mpcqp_order_by_count.restype = C.c_int
+    lib.mpcqp_order_by_count.argtypes = [vp, i64, vp, vp, C.c_size_t, vp]
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]

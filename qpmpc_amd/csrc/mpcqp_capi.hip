@@ -69,7 +69,7 @@ void fill_args(KernelArgs &ka, const MpcqpDims *d, const MpcqpProblem *p)
     }
 }
 
-int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
+int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype, bool order_ok = false)
 {
     ka.max_iter = (o && o->max_iter > 0) ? o->max_iter : 10 * (ka.n + ka.m) + 10;
     ka.tol = (o && o->feas_tol > 0.0) ? o->feas_tol : (dtype == MPCQP_F64 ? 1e-12 : 1e-5);
@@ -82,6 +82,8 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype)
     if (ka.warm_start < 0 || ka.warm_start > MPCQP_WARM_ACTIVE_SET) return MPCQP_EINVAL;
     ka.warm_state_bytes = o->warm_state ? o->warm_state_bytes : 0;
     ka.factor_slot = o->factor_slot & 1;
+    if (o->order && !order_ok) return MPCQP_EUNSUPPORTED;  // (only mpcqp_build_solve_batch's small-problem kernel takes one)
+    ka.order = o->order;
     return 0;
 }
 
@@ -628,7 +630,11 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     ka.lam = lam;
     ka.status = status;
     ka.iters = iters;
-    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+    if ((rc = fill_opts(ka, opts, dims->dtype, true))) return rc;
+    // a pairing order: cold launches of the small-problem fused kernel (float32 launches of its size arrive here converted)
+    if (ka.order && (ka.warm_state || (ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_SEED_VIOLATED)) ||
+                     !pair_eligible(ka, MODE_FUSED, MPCQP_F64)))
+        return MPCQP_EUNSUPPORTED;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (promote_f32(ka, dims->dtype)) {
@@ -980,6 +986,82 @@ int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t 
     if (!status || !iters || !stats || batch < 0) return MPCQP_EINVAL;
     if (batch == 0) return 0;
     return launch_stats(status, iters, batch, stats, (hipStream_t)stream);
+}
+
+// ---- mpcqp_order_by_count: a counting sort of the batch by (clamped) count, longest first. Three small launches: per-chunk
+// histograms, one workgroup that turns them into start offsets (bucket-major, chunk-minor), the scatter. Inside one (bucket, chunk)
+// cell the places are handed out by an LDS atomic, so the order of equal counts within a chunk is not reproducible -- it is a
+// pairing hint, every order is a valid one.
+namespace {
+constexpr int kOrdBuckets = 1024, kOrdChunk = 4096, kOrdThreads = 256;
+__device__ __forceinline__ int ord_bucket(int c) { return kOrdBuckets - 1 - (c < 0 ? 0 : (c > kOrdBuckets - 1 ? kOrdBuckets - 1 : c)); }
+
+__global__ void __launch_bounds__(kOrdThreads) order_hist_kernel(const int32_t *__restrict__ counts, int64_t batch, int32_t *__restrict__ hist, int chunks)
+{
+    __shared__ int h[kOrdBuckets];
+    for (int b = threadIdx.x; b < kOrdBuckets; b += kOrdThreads) h[b] = 0;
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * kOrdChunk;
+    for (int i = threadIdx.x; i < kOrdChunk && first + i < batch; i += kOrdThreads) atomicAdd(&h[ord_bucket(counts[first + i])], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < kOrdBuckets; b += kOrdThreads) hist[(int64_t)blockIdx.x * kOrdBuckets + b] = h[b];
+}
+
+__global__ void __launch_bounds__(kOrdBuckets) order_scan_kernel(int32_t *__restrict__ hist, int chunks)
+{
+    __shared__ int tot[kOrdBuckets];
+    const int b = threadIdx.x;
+    int sum = 0;
+#pragma unroll 8
+    for (int g = 0; g < chunks; ++g) sum += hist[(int64_t)g * kOrdBuckets + b];  // (independent, coalesced loads)
+    tot[b] = sum;
+    __syncthreads();
+    for (int d = 1; d < kOrdBuckets; d <<= 1) {  // inclusive scan over the buckets
+        const int v = b >= d ? tot[b - d] : 0;
+        __syncthreads();
+        tot[b] += v;
+        __syncthreads();
+    }
+    int run = tot[b] - sum;
+#pragma unroll 8
+    for (int g = 0; g < chunks; ++g) {
+        const int c = hist[(int64_t)g * kOrdBuckets + b];
+        hist[(int64_t)g * kOrdBuckets + b] = run;
+        run += c;
+    }
+}
+
+__global__ void __launch_bounds__(kOrdThreads) order_scatter_kernel(const int32_t *__restrict__ counts, int64_t batch, const int32_t *__restrict__ hist,
+                                                                     int chunks, int32_t *__restrict__ order)
+{
+    __shared__ int off[kOrdBuckets];
+    for (int b = threadIdx.x; b < kOrdBuckets; b += kOrdThreads) off[b] = hist[(int64_t)blockIdx.x * kOrdBuckets + b];
+    __syncthreads();
+    const int64_t first = (int64_t)blockIdx.x * kOrdChunk;
+    for (int i = threadIdx.x; i < kOrdChunk && first + i < batch; i += kOrdThreads) {
+        const int at = atomicAdd(&off[ord_bucket(counts[first + i])], 1);
+        order[at] = (int32_t)(first + i);
+    }
+}
+}  // namespace
+
+size_t mpcqp_order_workspace_bytes(int64_t batch)
+{
+    return batch <= 0 ? 0 : (size_t)kOrdBuckets * sizeof(int32_t) * (size_t)((batch + kOrdChunk - 1) / kOrdChunk);
+}
+
+int mpcqp_order_by_count(const int32_t *counts, int64_t batch, int32_t *order, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!counts || !order || batch < 0 || batch > INT32_MAX) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    if (!workspace || workspace_bytes < mpcqp_order_workspace_bytes(batch)) return MPCQP_EWORKSPACE;
+    const int chunks = (int)((batch + kOrdChunk - 1) / kOrdChunk);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *hist = (int32_t *)workspace;
+    hipLaunchKernelGGL(order_hist_kernel, dim3(chunks), dim3(kOrdThreads), 0, st, counts, batch, hist, chunks);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(kOrdBuckets), 0, st, hist, chunks);
+    hipLaunchKernelGGL(order_scatter_kernel, dim3(chunks), dim3(kOrdThreads), 0, st, counts, batch, hist, chunks, order);
+    return (int)hipGetLastError();
 }
 
 int mpcqp_lipm_advance_stats_batch(int32_t dtype, void *states, const void *U, int64_t u_stride, const int32_t *status,

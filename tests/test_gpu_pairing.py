@@ -1,0 +1,84 @@
+"""GPU tests (-m gpu): the pairing order of the small-problem fused kernel (MpcqpSolveOpts.order, ABI 9) and the device-side
+counting sort that makes one from last period's iteration counts (mpcqp_order_by_count). The reference solves one problem per
+call (qpmpc/solve_mpc.py:43), so WHICH two problems share a wavefront must never show in the results: statuses and iteration
+counts are compared exactly with the natural order's, plans to rounding (1e-8); the launch time is what changes (BASELINE config 4 =
+examples/humanoid_one_step.py:42-80 over 65,536 initial states)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("batch", [1, 5, 1023, 1025, 70001])
+def test_order_by_count_is_a_permutation_sorted_longest_first(batch):
+    from qpmpc_amd import pairing_order
+
+    g = torch.Generator().manual_seed(batch)
+    counts = torch.randint(-3, 1500, (batch,), generator=g, dtype=torch.int32).cuda()
+    order = pairing_order(counts)
+    torch.cuda.synchronize()
+    o = order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(batch))
+    clamped = np.clip(counts.cpu().numpy(), 0, 1023)[o]
+    assert np.all(np.diff(clamped) <= 0)
+
+
+@pytest.mark.parametrize("kind,batch", [("triple", 777), ("triple", 9000), ("humanoid", 5001)])
+def test_results_do_not_depend_on_the_pairing_order(kind, batch):
+    from qpmpc_amd import pairing_order, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(batch, seed=5) if kind == "triple" else W.humanoid_batch(batch, seed=7)
+    bp = W.to_batch_problem(w)
+    ref = solve_mpc_batch(bp, return_multipliers=True)
+    torch.cuda.synchronize()
+    assert int((ref.status == 0).sum()) > batch // 2
+    g = torch.Generator().manual_seed(1)
+    for order in (pairing_order(ref.iters), torch.randperm(batch, generator=g).to(torch.int32).cuda()):
+        got = solve_mpc_batch(bp, return_multipliers=True, order=order)
+        torch.cuda.synchronize()
+        assert torch.equal(got.status, ref.status) and torch.equal(got.iters, ref.iters)
+        # (a problem that moves to the other half of a wavefront sees that half's order of summation: rounding only -- 1e-15 on
+        # the triple integrator, amplified to 1.3e-10 by the conditioning of the humanoid problem; the contract is 1e-6)
+        ok = ref.status == 0  # (unsolved items carry no plan)
+        scale = ref.U[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert float(((got.U[ok] - ref.U[ok]).abs() / scale).max()) <= 1e-8
+        lscale = ref.multipliers[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert float(((got.multipliers[ok] - ref.multipliers[ok]).abs() / lscale).max()) <= 1e-8
+
+
+def test_prepared_solve_takes_a_new_order_every_period():
+    from qpmpc_amd import PreparedSolve, pairing_order
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(W.triple_integrator_batch(3000, seed=9))
+    prep = PreparedSolve(bp)
+    prep.launch()
+    torch.cuda.synchronize()
+    U0, it0 = prep.U.clone(), prep.iters.clone()
+    prep.set_order(pairing_order(prep.iters))
+    prep.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(prep.iters, it0) and float((prep.U - U0).abs().max()) <= 1e-11 * max(1.0, float(U0.abs().max()))
+    prep.set_order(None)
+    prep.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(prep.U, U0)
+
+
+def test_order_is_refused_where_no_kernel_takes_it():
+    from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(W.triple_integrator_batch(64, seed=5))
+    order = torch.arange(64, dtype=torch.int32, device="cuda")
+    for kw in ({"flags": _capi.OPT_FORCE_LDS}, {"flags": _capi.OPT_ONE_PER_WAVE}, {"warm_state": WarmState(bp)},
+               {"formulation": "stagewise"}):
+        with pytest.raises(BackendError):
+            solve_mpc_batch(bp, order=order, **kw)
+    wide = W.to_batch_problem(W.wip_batch(8))  # n = 50: the stage-wise kernel's size
+    with pytest.raises(BackendError):
+        solve_mpc_batch(wide, order=torch.arange(8, dtype=torch.int32, device="cuda"))
+    with pytest.raises(BackendError):
+        solve_mpc_batch(bp, order=order.to(torch.int64))

@@ -160,6 +160,12 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.mpcqp_wip_periods_batch(*args, 0, None) == _capi.EINVAL
     assert lib.mpcqp_wip_periods_batch(*args, 20, None) == _capi.EINVAL  # (NULL problem)
     assert lib.mpcqp_wip_period_batch(*args, None) == _capi.EINVAL
+    # (ABI 9) the pairing order's counting sort: scratch of 1024 int32 per chunk of 4096 problems; arguments checked first
+    assert lib.mpcqp_order_workspace_bytes(65536) == 16 * 1024 * 4 and lib.mpcqp_order_workspace_bytes(1) == 4096
+    assert lib.mpcqp_order_workspace_bytes(0) == 0
+    assert lib.mpcqp_order_by_count(None, 8, None, None, 0, None) == _capi.EINVAL
+    assert lib.mpcqp_order_by_count(8, 8, 8, None, 0, None) == _capi.EWORKSPACE  # (non-NULL dummies: refused before any launch)
+    assert C.sizeof(_capi.SolveOpts) == 64  # (the header's struct: 2 x int32, double, ptr, 2 x int32, ptr, size_t, 2 x int32, ptr)
     # workspace queries are host-only: config 2 needs none, config 5 (n=256, m=1024, f32) does
     d = _capi.Dims(3, 1, 16, 2, _capi.F64, 5, 1.0, 0.0, 1e-6)
     assert lib.mpcqp_workspace_bytes(C.byref(d), 4096, 1, C.byref(b)) == 0 and b.value == 0
