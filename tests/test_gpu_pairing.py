@@ -82,3 +82,23 @@ def test_order_is_refused_where_no_kernel_takes_it():
         solve_mpc_batch(wide, order=torch.arange(8, dtype=torch.int32, device="cuda"))
     with pytest.raises(BackendError):
         solve_mpc_batch(bp, order=order.to(torch.int64))
+
+
+def test_walking_loops_repaired_every_period_walk_the_same_way():
+    """examples/lipm_walking_controller.py:307-335 for 3000 walkers, 40 periods: re-pairing by last period's counts (in place,
+    behind the launch that still reads the old order) must leave every trajectory where it was, to rounding."""
+    from qpmpc_amd.closed_loop import LIPMWalkingLoop
+
+    rng = np.random.default_rng(3)
+    B = 3000
+    kw = dict(strides=np.stack([-rng.uniform(0.12, 0.2, B), rng.uniform(0.12, 0.2, B)], axis=1),
+              foot_size=rng.uniform(0.05, 0.08, B), index=rng.integers(0, 8, B))
+    ref, got = LIPMWalkingLoop(B, **kw), LIPMWalkingLoop(B, pair_every=1, **kw)
+    ref.step(40)
+    got.step(40)
+    torch.cuda.synchronize()
+    assert ref.stats()["failed"] == got.stats()["failed"] and ref.stats()["mean_iters"] == got.stats()["mean_iters"]
+    assert float((ref.states - got.states).abs().max()) <= 1e-9
+    assert torch.equal(ref.index, got.index)
+    with pytest.raises(ValueError):
+        LIPMWalkingLoop(8, pair_every=1, shared_model=True)
