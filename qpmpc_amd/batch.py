@@ -465,6 +465,13 @@ class WarmState:
         return torch.where(live, rows, torch.full_like(rows, -1))
 
 
+def _check_order(problem, opt_kw) -> None:
+    """The kernel indexes by ``order[i]`` unchecked (MpcqpSolveOpts.order): at least the length is checked here."""
+    order = opt_kw.get("order")
+    if order is not None and order.numel() != problem.batch_size:
+        raise BackendError(f"order holds {order.numel()} indices, the batch {problem.batch_size} problems")
+
+
 def _check_warm(problem: "BatchMPCProblem", opt_kw) -> None:
     """Host-side check of ``warm_state=`` against the launch (batch, dimensions, device); raw uint8 tensors are
     checked for size and device (the C ABI checks the size again: ``MpcqpSolveOpts.warm_state_bytes``)."""
@@ -555,6 +562,7 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
     _check_warm(problem, opt_kw)
+    _check_order(problem, opt_kw)
     ws_ = opt_kw.get("warm_state")
     if isinstance(ws_, WarmState) and ws_.kind == "stage" and opt_kw.get("warm_start"):
         # the stage-wise kernel's warm start continues from the vectors its previous launch left in the SAME workspace;
@@ -674,6 +682,7 @@ class PreparedSolve:
         self.status = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         self.iters = torch.empty((Bn,), dtype=torch.int32, device=problem.device)
         _check_warm(problem, opt_kw)
+        _check_order(problem, opt_kw)
         self._opts = _opts(max_iter, feas_tol, **opt_kw)
         ws_ = opt_kw.get("warm_state")
         # the stage-wise kernel's warm start continues from the vectors its previous launch left in THIS object's
@@ -719,8 +728,10 @@ class PreparedSolve:
 
     def set_order(self, order) -> None:
         """Pairing order of the next launches (:func:`pairing_order`; ``None``: natural). The tensor is kept alive here."""
+        _check_order(self.problem, {"order": order})
+        probe = _opts(order=order)  # (dtype / device / layout checks)
         self._opt_kw["order"] = order
-        self._opts.order = None if order is None else order.data_ptr()
+        self._opts.order = probe.order
 
     def launch(self, stream=None) -> None:
         """Enqueue one fused build+solve of the whole batch on ``stream``

@@ -82,6 +82,8 @@ def test_order_is_refused_where_no_kernel_takes_it():
         solve_mpc_batch(wide, order=torch.arange(8, dtype=torch.int32, device="cuda"))
     with pytest.raises(BackendError):
         solve_mpc_batch(bp, order=order.to(torch.int64))
+    with pytest.raises(BackendError):  # (the kernel indexes unchecked: the host refuses an order of another length)
+        solve_mpc_batch(bp, order=order[:32].contiguous())
 
 
 def test_walking_loops_repaired_every_period_walk_the_same_way():
