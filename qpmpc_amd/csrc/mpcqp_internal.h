@@ -37,13 +37,14 @@ struct KernelArgs {
     int factor_slot;              // which of the two factor images of the stage-wise kernel this launch keeps / reuses
     size_t warm_state_bytes;      // size of the buffer behind warm_state (checked on the host before the launch)
     void *probe;                  // developer probe: int64 stamps per problem, or null
-    const int32_t *order;         // pairing order of the small-problem fused kernel (a permutation of the batch), or null
     // closed-loop epilogue of the stage-wise kernel (mpcqp_wip_period_batch): after its solve every wavefront applies
     // the first input of its plan to the wheeled-inverted-pendulum plant and writes its loop's NEXT problem in place
     int ep_on, ep_nsub, ep_periods;  // (ep_periods: control periods per launch, mpcqp_wip_periods_batch; 0 / 1 = one)
     double ep_Tp, ep_vel, ep_omega2, ep_g;
     void *ep_states;              // [batch, 4], updated in place
     long long *ep_loopstats;      // [batch, 2]: += (failed, iterations), or null
+    // (last: the fields above keep the offsets the stage-wise kernels' hand-placed kernel-argument loads were measured with)
+    const int32_t *order;         // pairing order of the small-problem fused kernel (a permutation of the batch), or null
 };
 
 // LDS carve, in elements of T. Matrices are row-major with odd row stride ld.
