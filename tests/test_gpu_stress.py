@@ -39,6 +39,11 @@ def _campaign(tool, args, seed, extra_env=None):
     ("stress_f32.py", (24, 64), 41, 1e-3),              # float32 through the default dispatch vs the float64 oracle
     ("stress_f32.py", (24, 64), 46, 1e-3),
     ("stress_general.py", (12, 8), 2, 1e-7),            # wide systems (17 <= nx <= 32, nu <= 8): the general stage-wise kernel
+    # nearly fully active problems (4-6 tight rows per step, most variables pinned): the three stage-wise kernels. (Seeds 2, 3, 8
+    # of the general kernel's campaign each hold a problem that ends MAX_ITER where the oracle solves it: DESIGN 3.9.4 vii.)
+    ("stress_tight.py", ("narrow", 8, 8), 1, 1e-7),
+    ("stress_tight.py", ("wide", 8, 8), 1, 1e-7),
+    ("stress_tight.py", ("general", 8, 8), 1, 1e-7),
 ])
 def test_stress_campaign(tool, args, seed, bound):
     worst, nflag, flagged = _campaign(tool, args, seed)
