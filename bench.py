@@ -683,7 +683,19 @@ def other_workloads():
     w = W.humanoid_batch(65536)
     bp = W.to_batch_problem(w)
     out["config4_humanoid_sweep_65536_fused"] = rate(PreparedSolve(bp).launch, 65536, 10)
-    out["config4_humanoid_sweep_65536_shared_model"] = rate(SharedModel(bp).prepare(bp).launch, 65536, 10)
+    shared = SharedModel(bp).prepare(bp)
+    out["config4_humanoid_sweep_65536_shared_model"] = rate(shared.launch, 65536, 10)
+    # ... and with the problems paired by the previous launch's iteration counts, the sort re-run every launch
+    from qpmpc_amd import pairing_order
+
+    order = torch.empty_like(shared.iters)
+    shared.set_order(pairing_order(shared.iters, out=order))
+
+    def shared_period():
+        shared.launch()
+        pairing_order(shared.iters, out=order)
+
+    out["config4_humanoid_sweep_65536_shared_model_paired_by_last_counts"] = rate(shared_period, 65536, 10)
     w = W.synthetic_ltv_batch(1024)
     out["config5_synthetic_ltv_n256_m1024_f32_batch1024"] = rate(
         PreparedSolve(W.to_batch_problem(w, dtype=torch.float32)).launch, 1024, 5)

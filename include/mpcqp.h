@@ -212,9 +212,9 @@ typedef struct MpcqpSolveOpts {
      * half-wavefront i takes problem order[i]; outputs stay where they were (U, lam, status, iters are indexed by problem), every
      * problem's iterations are the same (the two halves of a wavefront sum in different orders: plans equal to rounding). A receding-horizon loop passes mpcqp_order_by_count() of last period's iteration counts
      * (qpmpc/solve_mpc.py:43 is called once per period, examples/lipm_walking_controller.py:307-335): launches of several rounds
-     * get up to 12 % shorter, a launch that fills the machine once gains nothing. Cold launches of mpcqp_build_solve_batch that
-     * the small-problem fused kernel serves only: MPCQP_EUNSUPPORTED with warm_state, with a dispatch override, for other
-     * dimensions and from every other entry point. The array is read during the launch (keep it alive until the stream has
+     * get up to 12 % shorter, a launch that fills the machine once gains nothing. Cold launches of mpcqp_build_solve_batch and launches
+     * of mpcqp_solve_model_batch / mpcqp_solve_model_bounds_batch that the small-problem kernel serves only: MPCQP_EUNSUPPORTED
+     * with warm_state, with a dispatch override, for other dimensions and from every other entry point. The array is read during the launch (keep it alive until the stream has
      * passed it) and NOT validated: an index outside the batch reads and writes out of bounds. */
     const int32_t *order;
 } MpcqpSolveOpts;

@@ -852,6 +852,13 @@ class PreparedModelSolve:
         head = (C.byref(self.model.dims), self.model.model.data_ptr())
         self._args = head + ((C.byref(self._ops[3]),) if self._own_e else ()) + tail
 
+    def set_order(self, order) -> None:
+        """Pairing order of the next launches (:func:`pairing_order`; ``None``: natural), as ``PreparedSolve.set_order``."""
+        _check_order(self.problem, {"order": order})
+        probe = _opts(order=order)
+        self._opt_kw["order"] = order
+        self._opts.order = probe.order
+
     def launch(self, stream=None) -> None:
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
         if self._own_e:

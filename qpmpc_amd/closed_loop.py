@@ -232,9 +232,9 @@ class LIPMWalkingLoop:
         # pair_every = K > 0: every K periods the walkers are re-paired by the iteration counts of the period just solved
         # (MpcqpSolveOpts.order, mpcqp_order_by_count: a wavefront of the small-problem kernel runs max(trips) of its two
         # problems, and a walker's count moves slowly with its phase); same plans to rounding, shorter launches for batches
-        # of several rounds. Not with warm_start / shared_model (those launches take no order).
-        if pair_every and (warm_start or shared_model):
-            raise ValueError("LIPMWalkingLoop: pair_every needs the cold rebuilding loop (no warm_start, no shared_model)")
+        # of several rounds where the counts spread. Not with warm_start (that launch takes no order).
+        if pair_every and warm_start:
+            raise ValueError("LIPMWalkingLoop: pair_every and warm_start are exclusive (a warm launch takes no order)")
         self.pair_every, self._order = int(pair_every), None
         dev, f64 = torch.device("cuda", torch.cuda.current_device()), torch.float64
         T, N = float(sampling_period), int(nb_timesteps)

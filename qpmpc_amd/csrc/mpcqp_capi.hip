@@ -869,8 +869,11 @@ int mpcqp_solve_model_bounds_batch(const MpcqpDims *dims, const void *model, con
     ka.lam = lam;
     ka.status = status;
     ka.iters = iters;
-    if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
+    if ((rc = fill_opts(ka, opts, dims->dtype, true))) return rc;
     if (ka.warm_state) return MPCQP_EUNSUPPORTED;
+    // (a pairing order: the pair kernel's model mode only)
+    if (ka.order && ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE)) || !pair_eligible(ka, MODE_MODEL, dims->dtype)))
+        return MPCQP_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const bool own_e = e && e->ptr;  // per-problem bounds: the pair kernel's model mode only
     if (own_e) {

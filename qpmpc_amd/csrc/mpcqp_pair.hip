@@ -1600,7 +1600,9 @@ int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
                            (const double *)ka.goal.ptr, (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status,
                            ka.iters, ka, L, batch);
     };
-    if (waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024)
+    if (ka.order)
+        go(mpcqp_pair_kernel<3, 0, true, false, 1, false, true>, 1);
+    else if (waves >= 2 && one_round(waves) && (size_t)L.per * 4 * sizeof(double) <= 64 * 1024)
         go(mpcqp_pair_kernel<3, 0, true, false, 2>, 2);
     else
         go(mpcqp_pair_kernel<3, 0, true, false, 1>, 1);

@@ -103,4 +103,30 @@ def test_walking_loops_repaired_every_period_walk_the_same_way():
     assert float((ref.states - got.states).abs().max()) <= 1e-9
     assert torch.equal(ref.index, got.index)
     with pytest.raises(ValueError):
-        LIPMWalkingLoop(8, pair_every=1, shared_model=True)
+        LIPMWalkingLoop(8, pair_every=1, warm_start=True)
+    # the same with the model factored once (mpcqp_solve_model_bounds_batch takes the order too)
+    refm, gotm = LIPMWalkingLoop(B, shared_model=True, **kw), LIPMWalkingLoop(B, shared_model=True, pair_every=2, **kw)
+    refm.step(40)
+    gotm.step(40)
+    torch.cuda.synchronize()
+    assert refm.stats() == gotm.stats() and float((refm.states - gotm.states).abs().max()) <= 1e-9
+
+
+def test_shared_model_solve_takes_the_order():
+    """Config 4 the way the reference would run it -- MPCQP built once, update_cost_vector / update_constraint_vector per state
+    (qpmpc/mpc_qp.py:129-163) --: the model-mode launch with an order gives the natural order's results."""
+    from qpmpc_amd import SharedModel, pairing_order
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(W.humanoid_batch(6001, seed=11))
+    run = SharedModel(bp).prepare(bp, return_multipliers=True)
+    run.launch()
+    torch.cuda.synchronize()
+    U0, st0, it0 = run.U.clone(), run.status.clone(), run.iters.clone()
+    run.set_order(pairing_order(run.iters))
+    run.launch()
+    torch.cuda.synchronize()
+    ok = st0 == 0
+    assert torch.equal(run.status, st0) and torch.equal(run.iters, it0)
+    scale = U0[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+    assert float(((run.U[ok] - U0[ok]).abs() / scale).max()) <= 1e-8
