@@ -420,6 +420,18 @@ int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t 
  * an unspecified order. counts, order: DEVICE int32 [batch]; workspace: mpcqp_order_workspace_bytes(batch) bytes of DEVICE memory
  * (MPCQP_EWORKSPACE if smaller). The reference has no counterpart: its solver is called per problem (qpmpc/solve_mpc.py:43). */
 size_t mpcqp_order_workspace_bytes(int64_t batch);
+
+/* Counts for a launch that has no previous period (ABI 9): what mpcqp_solve_model_batch / _bounds_batch would see first for every
+ * problem -- the slacks h + M w at the unconstrained minimiser, from the model's linear maps (update_cost_vector /
+ * update_constraint_vector, qpmpc/mpc_qp.py:129-163, without the solve) -- as a sort key: 31 x (rows violated) + a bucket (0..30) of
+ * their mean relative violation. Ordering by it keeps about half of what exact iteration counts give (on BASELINE config 4 the
+ * wavefronts' summed trips fall to 0.85 of the natural order's, to 0.74 with exact counts). Measured on 65,536 problems: 30 us for
+ * this call + 16 us for the sort against 17 us gained by the ordered launch -- worth it only when the order is reused. Same arguments as
+ * mpcqp_solve_model_bounds_batch (e may be NULL; opts only for feas_tol); counts: DEVICE int32 [batch]. Small-problem kernel's
+ * dimensions only (MPCQP_EUNSUPPORTED elsewhere). */
+int mpcqp_model_predict_counts(const MpcqpDims *dims, const void *model, const MpcqpOperand *e, const MpcqpOperand *x0,
+                               const MpcqpOperand *goal, const MpcqpOperand *targets, int64_t batch,
+                               const MpcqpSolveOpts *opts, int32_t *counts, void *stream);
 int mpcqp_order_by_count(const int32_t *counts, int64_t batch, int32_t *order, void *workspace, size_t workspace_bytes,
                          void *stream);
 

@@ -44,6 +44,7 @@ EXPORTS = (
     "mpcqp_accumulate_stats",
     "mpcqp_order_workspace_bytes",
     "mpcqp_order_by_count",
+    "mpcqp_model_predict_counts",
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
     "mpcqp_wip_period_batch",
@@ -148,6 +149,8 @@ def load():
     lib.mpcqp_order_workspace_bytes.argtypes = [i64]
     lib.mpcqp_order_by_count.restype = C.c_int
     lib.mpcqp_order_by_count.argtypes = [vp, i64, vp, vp, C.c_size_t, vp]
+    lib.mpcqp_model_predict_counts.restype = C.c_int
+    lib.mpcqp_model_predict_counts.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]

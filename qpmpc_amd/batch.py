@@ -859,6 +859,22 @@ class PreparedModelSolve:
         self._opt_kw["order"] = order
         self._opts.order = probe.order
 
+    def predict_order(self) -> None:
+        """For a launch with no previous period: order the problems by what the solve would see first -- the rows violated at
+        the unconstrained minimiser (``mpcqp_model_predict_counts`` + ``mpcqp_order_by_count``, two small launches on torch's
+        current stream) -- and use that order from the next launch on."""
+        torch = _torch()
+        if getattr(self, "_pred", None) is None:
+            self._pred = (torch.empty_like(self.iters), torch.empty_like(self.iters))
+        counts, order = self._pred
+        ops = self._ops
+        rc = self._lib.mpcqp_model_predict_counts(
+            C.byref(self.model.dims), self.model.model.data_ptr(), C.byref(ops[3]) if self._own_e else None, C.byref(ops[0]),
+            C.byref(ops[1]), C.byref(ops[2]), self.problem.batch_size, C.byref(self._opts), counts.data_ptr(), _stream_ptr())
+        _capi.check(rc, "mpcqp_model_predict_counts")
+        pairing_order(counts, out=order)
+        self.set_order(order)
+
     def launch(self, stream=None) -> None:
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
         if self._own_e:

@@ -1048,6 +1048,107 @@ __global__ void __launch_bounds__(kOrdThreads) order_scatter_kernel(const int32_
 }
 }  // namespace
 
+// ---- mpcqp_model_predict_counts: what the shared-model solve sees first -- the slacks at the unconstrained minimiser, s = h + M w
+// with h = e - Hx x0 and w = L^-1 q from the model's linear maps (the MODEL prologue of mpcqp_pair.hip) --, turned into a sort key
+// per problem: 31 x (rows violated) + a 31-level bucket of their mean relative violation. 32 lanes per problem (m <= 32 rows).
+namespace {
+constexpr int kPredPerBlock = 64;  // problems per workgroup: the model (4-12 KB, shared by the batch) is staged in LDS once for them
+__global__ void __launch_bounds__(256) model_counts_kernel(const double *__restrict__ model, const KernelArgs ka, const double *__restrict__ ge,
+                                                            double tol, int64_t batch, int32_t *__restrict__ counts)
+{
+    extern __shared__ double pm[];  // M [m][nc + 1] | Hx [m][nx] | e [m] | Wx [n][nx] | Wg [n][nx] | Wt [n][nT] (stage costs only)
+    const int n = ka.n, m = ka.m, nx = ka.nx, nT = ka.N * ka.nx;
+    const ModelLayout ml = make_model_layout(nx, ka.N, n, m);
+    const int ldm = ml.nc + 1;  // (odd row stride: the 32 rows of a column sit in 32 banks)
+    const bool stage = ka.flags & MPCQP_Q_STAGE;
+    double *sM = pm, *sHx = sM + m * ldm, *se = sHx + m * nx, *sWx = se + m, *sWg = sWx + n * nx, *sWt = sWg + n * nx;
+    for (int i = threadIdx.x; i < m * ml.nc; i += 256) sM[(i / ml.nc) * ldm + i % ml.nc] = model[ml.off_M + i];
+    for (int i = threadIdx.x; i < m * nx; i += 256) sHx[i] = model[ml.off_Hx + i];
+    for (int i = threadIdx.x; i < m; i += 256) se[i] = model[ml.off_e + i];
+    for (int i = threadIdx.x; i < n * nx; i += 256) {
+        sWx[i] = model[ml.off_Wx + i];
+        sWg[i] = model[ml.off_Wg + i];
+    }
+    if (stage)
+        for (int i = threadIdx.x; i < n * nT; i += 256) sWt[i] = model[ml.off_Wt + i];
+    __syncthreads();
+    const int hl = threadIdx.x & 31;
+    const bool row = hl < m;
+    const int kq = row ? hl / ka.mk : 0;
+    for (int it = 0; it < kPredPerBlock / 8; ++it) {
+        const int64_t prob = (int64_t)blockIdx.x * kPredPerBlock + it * 8 + (threadIdx.x >> 5);
+        if (prob >= batch) break;  // (whole 32-lane groups leave together; no barrier follows)
+        const double *x0 = (const double *)ka.x0.ptr + prob * ka.x0.batch_stride;
+        const double *goal = ka.goal.ptr ? (const double *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
+        const double *tgt = ka.targets.ptr ? (const double *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
+        double wk = 0.0;  // lane k < n: w_k
+        if (hl < n) {
+            for (int c = 0; c < nx; ++c) wk += sWx[hl * nx + c] * x0[c];
+            if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
+                for (int c = 0; c < nx; ++c) wk -= sWg[hl * nx + c] * goal[c];
+            if (stage && tgt)
+                for (int j = 0; j < nT; ++j) wk -= sWt[hl * nT + j] * tgt[j];
+        }
+        double hh = 0.0, sl = 0.0;
+        if (row) {
+            hh = ge ? ge[prob * ka.e.batch_stride + kq * ka.e.step_stride + (hl - kq * ka.mk)] : se[hl];
+            for (int c = 0; c < nx; ++c) hh -= sHx[hl * nx + c] * x0[c];
+            sl = hh;
+        }
+        for (int k = 0; k < n; ++k) {
+            const double w = __shfl(wk, k, 32);
+            if (row) sl += sM[hl * ldm + k] * w;
+        }
+        const double scale = 1.0 + fabs(hh);
+        const bool viol = row && sl < -tol * scale;
+        double rel = viol ? fmin(1.0, -sl / scale) : 0.0;
+        int rows = viol ? 1 : 0;
+        for (int d = 16; d >= 1; d >>= 1) {
+            rel += __shfl_xor(rel, d, 32);
+            rows += __shfl_xor(rows, d, 32);
+        }
+        if (hl == 0) {
+            int bucket = rows ? (int)(31.0 * rel / rows) : 0;
+            bucket = bucket > 30 ? 30 : bucket;
+            counts[prob] = rows * 31 + bucket;
+        }
+    }
+}
+}  // namespace
+
+int mpcqp_model_predict_counts(const MpcqpDims *dims, const void *model, const MpcqpOperand *e, const MpcqpOperand *x0,
+                               const MpcqpOperand *goal, const MpcqpOperand *targets, int64_t batch, const MpcqpSolveOpts *opts,
+                               int32_t *counts, void *stream)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!model || !x0 || !x0->ptr || !counts || batch < 0) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_TERMINAL) && !(goal && goal->ptr)) return MPCQP_EINVAL;
+    if ((dims->flags & MPCQP_Q_STAGE) && !(targets && targets->ptr)) return MPCQP_EINVAL;
+    if (batch == 0) return 0;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    ka.x0 = *x0;
+    if (goal) ka.goal = *goal;
+    if (targets) ka.targets = *targets;
+    ka.model = model;
+    if ((rc = fill_opts(ka, opts, dims->dtype, true))) return rc;
+    if (!pair_eligible(ka, MODE_MODEL, dims->dtype)) return MPCQP_EUNSUPPORTED;  // (the kernel the order is for)
+    const double *ge = nullptr;
+    if (e && e->ptr) {
+        ka.e = *e;
+        ge = (const double *)e->ptr;
+    }
+    const ModelLayout ml = make_model_layout(ka.nx, ka.N, ka.n, ka.m);
+    const size_t lds = sizeof(double) * ((size_t)ka.m * (ml.nc + 1) + (size_t)ka.m * ka.nx + ka.m + 2 * (size_t)ka.n * ka.nx +
+                                         ((ka.flags & MPCQP_Q_STAGE) ? (size_t)ka.n * ka.N * ka.nx : 0));
+    if (lds > 64 * 1024) return MPCQP_EUNSUPPORTED;
+    const unsigned grid = (unsigned)((batch + kPredPerBlock - 1) / kPredPerBlock);
+    hipLaunchKernelGGL(model_counts_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const double *)model, ka, ge, ka.tol, batch,
+                       counts);
+    return (int)hipGetLastError();
+}
+
 size_t mpcqp_order_workspace_bytes(int64_t batch)
 {
     return batch <= 0 ? 0 : (size_t)kOrdBuckets * sizeof(int32_t) * (size_t)((batch + kOrdChunk - 1) / kOrdChunk);
