@@ -160,3 +160,29 @@ def test_predicted_order_for_a_one_shot_shared_model_sweep():
         return int(np.maximum(v[0::2], v[1::2]).sum())
 
     assert trips(order) <= 0.92 * trips(np.arange(8192)), (trips(order), trips(np.arange(8192)))
+
+
+@pytest.mark.parametrize("nx,nu,N,mk,with_c,with_d,wx", [
+    (4, 2, 6, 3, True, True, 0.5),     # the kernel's <4, 0> instantiation: C and D, stage + terminal cost
+    (3, 4, 4, 8, True, True, 0.5),     # <3, 0>: n = 16, m = 32 exactly
+    (4, 1, 12, 2, True, False, None),  # <4, 2>: the register-pipelined chain
+])
+def test_every_instantiation_of_the_kernel_takes_the_order(nx, nu, N, mk, with_c, with_d, wx):
+    """Random LTV families of the small-problem kernel's other template instantiations, odd batch, reversed and sorted orders."""
+    from test_gpu_parity import _random_ltv_workload
+
+    from qpmpc_amd import pairing_order, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    batch = 1001
+    bp = W.to_batch_problem(_random_ltv_workload(np.random.default_rng(7 * nx + N), batch, nx, nu, N, mk, with_c, with_d, wx=wx))
+    ref = solve_mpc_batch(bp, return_multipliers=True)
+    torch.cuda.synchronize()
+    ok = ref.status == 0
+    assert int(ok.sum()) > 900
+    for order in (pairing_order(ref.iters), torch.arange(batch - 1, -1, -1, dtype=torch.int32, device="cuda")):
+        got = solve_mpc_batch(bp, return_multipliers=True, order=order)
+        torch.cuda.synchronize()
+        assert torch.equal(got.status, ref.status) and torch.equal(got.iters, ref.iters)
+        scale = ref.U[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
+        assert float(((got.U[ok] - ref.U[ok]).abs() / scale).max()) <= 1e-8
