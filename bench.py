@@ -697,13 +697,6 @@ def other_workloads():
 
     out["config4_humanoid_sweep_65536_shared_model_paired_by_last_counts"] = rate(shared_period, 65536, 10)
 
-    # ... and as a ONE-SHOT sweep: ordered by mpcqp_model_predict_counts (rows violated at the unconstrained minimiser), the
-    # prediction and the sort re-run with every launch
-    def shared_one_shot():
-        shared.predict_order()
-        shared.launch()
-
-    out["config4_humanoid_sweep_65536_shared_model_paired_by_prediction"] = rate(shared_one_shot, 65536, 10)
     shared.set_order(None)
     w = W.synthetic_ltv_batch(1024)
     out["config5_synthetic_ltv_n256_m1024_f32_batch1024"] = rate(

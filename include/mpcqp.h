@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 9
+#define MPCQP_ABI_VERSION 10
 
 /* element type of every floating-point buffer of a call. It is the STORAGE type: mpcqp_build_solve_batch computes
  * MPCQP_F32 problems of at most 160 variables (and every float32 problem only the general stage-wise kernel serves) in
@@ -69,7 +69,8 @@ extern "C" {
                                 kernel, float64 arithmetic, takes what the MFMA stage-wise kernels (nx <= 16, nu <= 4) and
                                 the dense path (n <= 256) do not: qpmpc/solve_mpc.py:42-44 accepts any dimension) */
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
-#define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size   */
+#define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size; or a float32 launch that is solved in float64
+                                (at most 160 variables) with a batch stride that is neither 0 nor the packed size */
 #define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */
 #define MPCQP_EUNSUPPORTED (-6) /* option not available for these dimensions / this dtype    */
 
@@ -156,6 +157,17 @@ typedef struct MpcqpProblem {
                                  preferring a violated row whose sweeps are already done and deferring the pass (lazy
                                  slacks, the default since ABI 8). Same minimiser; other iterates. */
 
+#define MPCQP_OPT_TWO_PER_WAVE 2048 /* small-problem fused kernel: keep TWO problems per wavefront (mpcqp_pair.hip) where the
+                                 dispatch would put FOUR on one (mpcqp_quad.hip: cold launches with terminal cost only and two
+                                 state rows per step -- BASELINE configs 1, 2, 4 -- of a size that fills the machine about
+                                 once, see MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check. */
+#define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
+                                 takes it between 2.25 and 16 problems per SIMD of the device: 2305 .. 16384 on an MI355X,
+                                 where a wavefront per SIMD with four problems beats two wavefronts with two; smaller batches
+                                 leave SIMDs idle either way and larger ones are bound by resident wavefronts per CU).
+                                 MPCQP_EUNSUPPORTED where the kernel does not apply (other cost / constraint layouts, warm
+                                 starts, seed steps). */
+
 /* MpcqpSolveOpts.warm_start */
 #define MPCQP_WARM_OPERATOR 1   /* begin from the stored active set AND operator N* (contract: matrices unchanged)          */
 #define MPCQP_WARM_ACTIVE_SET 2 /* begin from the stored active set's ROW IDS only, moved by warm_shift rows: the rows enter
@@ -215,7 +227,8 @@ typedef struct MpcqpSolveOpts {
      * get up to 12 % shorter, a launch that fills the machine once gains nothing. Cold launches of mpcqp_build_solve_batch and launches
      * of mpcqp_solve_model_batch / mpcqp_solve_model_bounds_batch that the small-problem kernel serves only: MPCQP_EUNSUPPORTED
      * with warm_state, with a dispatch override, for other dimensions and from every other entry point. The array is read during the launch (keep it alive until the stream has
-     * passed it) and NOT validated: an index outside the batch reads and writes out of bounds. */
+     * passed it). It is not checked for being a permutation (a problem named twice is solved twice, one left out keeps its old
+     * outputs); an index outside the batch is clamped into it. */
     const int32_t *order;
 } MpcqpSolveOpts;
 
@@ -243,6 +256,20 @@ int mpcqp_solve_workspace_bytes(int32_t n, int32_t m, int32_t dtype, int64_t bat
 
 /* Bytes per problem of MpcqpSolveOpts.warm_state for these dimensions (0: no warm start for them). */
 int mpcqp_warm_state_bytes(const MpcqpDims *dims, size_t *bytes);
+
+/* Whose record that buffer holds (ABI 10) -- the kernel mpcqp_build_solve_batch picks for these dimensions and this dtype (a
+ * float32 launch of at most 160 variables is solved by the float64 kernels and keeps THEIR record):
+ *   MPCQP_WARM_KIND_OPERATOR  small-problem fused kernel: the operator N* (16 x 16 float64, by slot), then 16 int32 constraint
+ *                             ids (-1 = empty slot). MPCQP_WARM_OPERATOR and MPCQP_WARM_ACTIVE_SET.
+ *   MPCQP_WARM_KIND_STAGE     narrow stage-wise kernel: int32 [count, slots, workspace tag (2), step of each row ..., index in its
+ *                             step ...]; the rows' vectors stay in the launch's workspace (MPCQP_OPT_REUSE_FACTOR contract).
+ *   MPCQP_WARM_KIND_ROWS      wide stage-wise kernel: int32 count, then the active rows' ids. MPCQP_WARM_ACTIVE_SET only.
+ * A binding reads the layout from here instead of re-deriving the dispatch. */
+#define MPCQP_WARM_KIND_NONE 0
+#define MPCQP_WARM_KIND_OPERATOR 1
+#define MPCQP_WARM_KIND_STAGE 2
+#define MPCQP_WARM_KIND_ROWS 3
+int mpcqp_warm_state_kind(const MpcqpDims *dims, int32_t *kind);
 
 /* Replaces MPCQP.__init__ (mpc_qp.py:39-122) for a batch: Phi/Psi propagation
  * (:53-54,:88-90), G_k/h_k (:62-78), P (:99-105), q (:129-149).
@@ -421,17 +448,6 @@ int mpcqp_accumulate_stats(const int32_t *status, const int32_t *iters, int64_t 
  * (MPCQP_EWORKSPACE if smaller). The reference has no counterpart: its solver is called per problem (qpmpc/solve_mpc.py:43). */
 size_t mpcqp_order_workspace_bytes(int64_t batch);
 
-/* Counts for a launch that has no previous period (ABI 9): what mpcqp_solve_model_batch / _bounds_batch would see first for every
- * problem -- the slacks h + M w at the unconstrained minimiser, from the model's linear maps (update_cost_vector /
- * update_constraint_vector, qpmpc/mpc_qp.py:129-163, without the solve) -- as a sort key: 31 x (rows violated) + a bucket (0..30) of
- * their mean relative violation. Ordering by it keeps about half of what exact iteration counts give (on BASELINE config 4 the
- * wavefronts' summed trips fall to 0.85 of the natural order's, to 0.74 with exact counts). Measured on 65,536 problems: 30 us for
- * this call + 16 us for the sort against 17 us gained by the ordered launch -- worth it only when the order is reused. Same arguments as
- * mpcqp_solve_model_bounds_batch (e may be NULL; opts only for feas_tol); counts: DEVICE int32 [batch]. Small-problem kernel's
- * dimensions only (MPCQP_EUNSUPPORTED elsewhere). */
-int mpcqp_model_predict_counts(const MpcqpDims *dims, const void *model, const MpcqpOperand *e, const MpcqpOperand *x0,
-                               const MpcqpOperand *goal, const MpcqpOperand *targets, int64_t batch,
-                               const MpcqpSolveOpts *opts, int32_t *counts, void *stream);
 int mpcqp_order_by_count(const int32_t *counts, int64_t batch, int32_t *order, void *workspace, size_t workspace_bytes,
                          void *stream);
 

@@ -14,9 +14,10 @@ F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EINVAL, EWORKSPACE, EUNSUPPORTED = -1, -5, -6
-ABI_VERSION = 9
+ABI_VERSION = 10
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED, OPT_EXACT_SELECTION = 64, 128, 256, 512, 1024
+OPT_TWO_PER_WAVE, OPT_FOUR_PER_WAVE = 2048, 4096
 WARM_OPERATOR, WARM_ACTIVE_SET = 1, 2
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.
@@ -28,6 +29,7 @@ EXPORTS = (
     "mpcqp_lds_bytes",
     "mpcqp_workspace_bytes",
     "mpcqp_warm_state_bytes",
+    "mpcqp_warm_state_kind",
     "mpcqp_solve_workspace_bytes",
     "mpcqp_condense_batch",
     "mpcqp_condense_phase_batch",
@@ -44,7 +46,6 @@ EXPORTS = (
     "mpcqp_accumulate_stats",
     "mpcqp_order_workspace_bytes",
     "mpcqp_order_by_count",
-    "mpcqp_model_predict_counts",
     "mpcqp_wip_advance_batch",
     "mpcqp_wip_advance_stats_batch",
     "mpcqp_wip_period_batch",
@@ -112,6 +113,8 @@ def load():
     lib.mpcqp_workspace_bytes.argtypes = [C.POINTER(Dims), i64, C.c_int32, C.POINTER(C.c_size_t)]
     lib.mpcqp_warm_state_bytes.restype = C.c_int
     lib.mpcqp_warm_state_bytes.argtypes = [C.POINTER(Dims), C.POINTER(C.c_size_t)]
+    lib.mpcqp_warm_state_kind.restype = C.c_int
+    lib.mpcqp_warm_state_kind.argtypes = [C.POINTER(Dims), C.POINTER(C.c_int32)]
     lib.mpcqp_solve_workspace_bytes.restype = C.c_int
     lib.mpcqp_solve_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, i64, C.POINTER(C.c_size_t)]
     lib.mpcqp_condense_phase_batch.restype = C.c_int
@@ -149,8 +152,6 @@ def load():
     lib.mpcqp_order_workspace_bytes.argtypes = [i64]
     lib.mpcqp_order_by_count.restype = C.c_int
     lib.mpcqp_order_by_count.argtypes = [vp, i64, vp, vp, C.c_size_t, vp]
-    lib.mpcqp_model_predict_counts.restype = C.c_int
-    lib.mpcqp_model_predict_counts.argtypes = [vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.mpcqp_wip_advance_batch.restype = C.c_int
     lib.mpcqp_wip_advance_batch.argtypes = [C.c_int32, vp, vp, i64, vp, C.c_int32, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int32, vp, vp, vp, i64, vp]
@@ -183,8 +184,8 @@ def check(code: int, what: str) -> None:
     if code != 0:
         msg = load().mpcqp_error_string(code).decode()
         if code == -2:  # MPCQP_ETOOLARGE: name the envelope instead of leaving the caller guessing
-            msg += (". Served: everything that fits 160 KiB of LDS; beyond that any horizon for systems with nx <= 16, "
-                    "nu <= 4 (stage-wise kernels) and n = N*nu <= 256 variables for wider systems (dense HBM-resident path)")
+            msg += (". Served: everything that fits 160 KiB of LDS; beyond that any horizon for systems with nx <= 32, "
+                    "nu <= 8 (stage-wise kernels)")
         raise BackendError(f"{what} failed with code {code}: {msg}")
 
 

@@ -412,8 +412,9 @@ class WarmState:
         _capi.check(lib.mpcqp_warm_state_bytes(C.byref(dims), C.byref(nbytes)), "mpcqp_warm_state_bytes")
         if nbytes.value == 0:
             raise BackendError(
-                "warm start is available for float64 problems with n = N*nu <= 16 variables and m <= 32 rows (the active-set "
-                "operator persists), for small systems (nx <= 4, nu <= 2) with 16 < n <= 128 (the active rows' vectors "
+                "warm start is available for problems with n = N*nu <= 16 variables and m <= 32 rows (the active-set "
+                "operator persists; float32 launches of that size are solved in float64), for small systems (nx <= 4, nu <= 2) with "
+                "16 < n <= 128 (the active rows' vectors "
                 "persist in the solver's workspace) and for what the wide stage-wise kernel takes (nx <= 16, nu <= 4: the active "
                 f"rows' ids); got n={problem.nb_variables}, m={problem.nb_constraints}, {problem.dtype}")
         self.bytes_per_problem = int(nbytes.value)
@@ -424,8 +425,11 @@ class WarmState:
         # the PreparedSolve that is re-launched (MPCQP_OPT_REUSE_FACTOR contract), so this kind only acts there
         # "stagew" (round 4): the wide stage-wise kernel -- int32 count, then the active rows' ids; started from with
         # warm_start="active_set" only (the rows' vectors ride along with the first sweeps)
-        narrow = problem.state_dim <= 4 and problem.input_dim <= 2 and problem.nb_variables <= 128 and problem.dtype == torch.float64
-        self.kind = "pair" if problem.nb_variables <= 16 else ("stage" if narrow else "stagew")
+        # (asked of the library: the dispatch is its business -- a float32 problem of at most 160 variables is solved by the
+        # float64 kernels and keeps their record)
+        kind = C.c_int32(0)
+        _capi.check(lib.mpcqp_warm_state_kind(C.byref(dims), C.byref(kind)), "mpcqp_warm_state_kind")
+        self.kind = {1: "pair", 2: "stage", 3: "stagew"}[kind.value]
         self._mk = problem.ineq_dim
         self._ids_at = 16 * 16 * 8 if self.kind == "pair" else 0
         self.buffer = torch.zeros((problem.batch_size, self.bytes_per_problem), dtype=torch.uint8, device=problem.device)
@@ -858,22 +862,6 @@ class PreparedModelSolve:
         probe = _opts(order=order)
         self._opt_kw["order"] = order
         self._opts.order = probe.order
-
-    def predict_order(self) -> None:
-        """For a launch with no previous period: order the problems by what the solve would see first -- the rows violated at
-        the unconstrained minimiser (``mpcqp_model_predict_counts`` + ``mpcqp_order_by_count``, two small launches on torch's
-        current stream) -- and use that order from the next launch on."""
-        torch = _torch()
-        if getattr(self, "_pred", None) is None:
-            self._pred = (torch.empty_like(self.iters), torch.empty_like(self.iters))
-        counts, order = self._pred
-        ops = self._ops
-        rc = self._lib.mpcqp_model_predict_counts(
-            C.byref(self.model.dims), self.model.model.data_ptr(), C.byref(ops[3]) if self._own_e else None, C.byref(ops[0]),
-            C.byref(ops[1]), C.byref(ops[2]), self.problem.batch_size, C.byref(self._opts), counts.data_ptr(), _stream_ptr())
-        _capi.check(rc, "mpcqp_model_predict_counts")
-        pairing_order(counts, out=order)
-        self.set_order(order)
 
     def launch(self, stream=None) -> None:
         sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)

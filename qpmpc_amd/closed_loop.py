@@ -225,17 +225,10 @@ class LIPMWalkingLoop:
                  state=None, com_height: float = 0.84, dsp_duration: float = 0.1, ssp_duration: float = 0.7,
                  gravity: float = 9.81, init_support_foot_pos: float = 0.09, nb_timesteps: int = 16,
                  sampling_period: float = 0.1, substeps: int = 15, max_iter: Optional[int] = None,
-                 warm_start=False, shared_model: bool = False, pair_every: int = 0):
+                 warm_start=False, shared_model: bool = False):
         import torch
 
         _capi.require_gpu()
-        # pair_every = K > 0: every K periods the walkers are re-paired by the iteration counts of the period just solved
-        # (MpcqpSolveOpts.order, mpcqp_order_by_count: a wavefront of the small-problem kernel runs max(trips) of its two
-        # problems, and a walker's count moves slowly with its phase); same plans to rounding, shorter launches for batches
-        # of several rounds where the counts spread. Not with warm_start (that launch takes no order).
-        if pair_every and warm_start:
-            raise ValueError("LIPMWalkingLoop: pair_every and warm_start are exclusive (a warm launch takes no order)")
-        self.pair_every, self._order = int(pair_every), None
         dev, f64 = torch.device("cuda", torch.cuda.current_device()), torch.float64
         T, N = float(sampling_period), int(nb_timesteps)
         self.nb_timesteps, self.sampling_period, self.substeps = N, T, int(substeps)
@@ -387,13 +380,6 @@ class LIPMWalkingLoop:
                 self.solver.launch()
                 if self.warm_state is not None and self.mpc_steps == 0:
                     self.solver.set_warm_start(self._warm_mode, warm_shift=2)  # from the second period on
-                if self.pair_every and self.mpc_steps % self.pair_every == 0:
-                    from .batch import pairing_order
-
-                    if self._order is None:
-                        self._order = torch.empty_like(self.solver.iters)
-                    pairing_order(self.solver.iters, out=self._order)  # (after the launch that reads the old order, in stream order)
-                    self.solver.set_order(self._order)
                 self._advance_fused(first=False)
                 self._problem_written = True
             else:

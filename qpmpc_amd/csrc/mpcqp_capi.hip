@@ -170,15 +170,26 @@ int stagew_auto_maxq(const KernelArgs &ka)
 // warm start: the small-problem pair kernel (operator + slot ids) and the narrow stage-wise kernel (row ids; the rows'
 // vectors stay in its workspace); 0 = not offered for these dimensions
 bool promote_f32(const KernelArgs &ka, int dtype);
-size_t warm_bytes_per_problem(KernelArgs ka, int dtype)
+// (kind: MPCQP_WARM_KIND_* -- whose record it is; the host side reads it instead of re-deriving the dispatch)
+size_t warm_bytes_per_problem(KernelArgs ka, int dtype, int *kind = nullptr)
 {
     ka.opt_flags = 0;
     ka.warm_state = nullptr;
+    int k = MPCQP_WARM_KIND_NONE;
+    size_t bytes = 0;
     if (dtype == MPCQP_F32 && promote_f32(ka, dtype)) dtype = MPCQP_F64;  // (the launch that is solved in float64: its kernel's record)
-    if (pair_eligible(ka, MODE_FUSED, dtype)) return kPairWarmDoubles * sizeof(double);
-    if (use_stage_auto(ka, dtype)) return stage_warm_bytes(stage_default_maxq(ka));
-    if (use_stagew_auto(ka, dtype)) return stagew_warm_bytes(stagew_auto_maxq(ka));  // row ids only (MPCQP_WARM_ACTIVE_SET)
-    return 0;
+    if (pair_eligible(ka, MODE_FUSED, dtype)) {
+        k = MPCQP_WARM_KIND_OPERATOR;
+        bytes = kPairWarmDoubles * sizeof(double);
+    } else if (use_stage_auto(ka, dtype)) {
+        k = MPCQP_WARM_KIND_STAGE;
+        bytes = stage_warm_bytes(stage_default_maxq(ka));
+    } else if (use_stagew_auto(ka, dtype)) {
+        k = MPCQP_WARM_KIND_ROWS;
+        bytes = stagew_warm_bytes(stagew_auto_maxq(ka));  // row ids only (MPCQP_WARM_ACTIVE_SET)
+    }
+    if (kind) *kind = k;
+    return bytes;
 }
 
 bool use_bigsolve(int n, int m, int dtype, int fl) { return !force_gws(fl) && m > 0 && bigsolve_supported(n, m, dtype); }
@@ -368,7 +379,7 @@ const char *mpcqp_error_string(int code)
     case MPCQP_EINVAL: return "invalid argument";
     case MPCQP_ETOOLARGE: return "no kernel for these dimensions (the stage-wise kernels serve nx <= 32, nu <= 8 at any horizon; the dense HBM-resident path any system with n <= 256)";
     case MPCQP_EDTYPE: return "dtype must be MPCQP_F64 or MPCQP_F32";
-    case MPCQP_ELAYOUT: return "step stride must be 0 or the block size";
+    case MPCQP_ELAYOUT: return "step stride must be 0 or the block size (float32 launches solved in float64: batch stride 0 or the packed size)";
     case MPCQP_EWORKSPACE: return "workspace missing or too small (see mpcqp_workspace_bytes)";
     case MPCQP_EUNSUPPORTED: return "option not available for these dimensions / this dtype (warm start: n <= 16, m <= 32, float64)";
     default: break;
@@ -397,6 +408,19 @@ int mpcqp_warm_state_bytes(const MpcqpDims *dims, size_t *bytes)
     KernelArgs ka;
     fill_args(ka, dims, nullptr);
     *bytes = warm_bytes_per_problem(ka, dims->dtype);
+    return 0;
+}
+
+int mpcqp_warm_state_kind(const MpcqpDims *dims, int32_t *kind)
+{
+    int rc = check_dims(dims);
+    if (rc) return rc;
+    if (!kind) return MPCQP_EINVAL;
+    KernelArgs ka;
+    fill_args(ka, dims, nullptr);
+    int k = MPCQP_WARM_KIND_NONE;
+    warm_bytes_per_problem(ka, dims->dtype, &k);
+    *kind = k;
     return 0;
 }
 
@@ -635,6 +659,10 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     if (ka.order && (ka.warm_state || (ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_SEED_VIOLATED)) ||
                      !pair_eligible(ka, MODE_FUSED, MPCQP_F64)))
         return MPCQP_EUNSUPPORTED;
+    // four problems per wavefront on request: only where that kernel applies (the dispatch picks it by batch size otherwise)
+    if ((ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) &&
+        ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_TWO_PER_WAVE)) || !pair_eligible(ka, MODE_FUSED, MPCQP_F64) || !quad_applies(ka)))
+        return MPCQP_EUNSUPPORTED;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;
     if (promote_f32(ka, dims->dtype)) {
@@ -652,6 +680,10 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         for (int i = 0; i < 8; ++i) {
             const int64_t cnt = operand_elems(*src[i], block[i], (int)N, batch, per_step[i]);
             if (!cnt) continue;
+            // (the copies keep the source's layout and mpcqp_workspace_bytes prices them densely packed: a padded batch stride
+            // is refused by name instead of as a workspace that looks too small)
+            const int64_t dense = (per_step[i] && src[i]->step_stride) ? N * block[i] : block[i];
+            if (src[i]->batch_stride != 0 && src[i]->batch_stride != dense) return MPCQP_ELAYOUT;
             if (w) dst[i]->ptr = w + off;
             in.seg[in.nseg++] = ConvSeg{src[i]->ptr, w ? w + off : nullptr, cnt};
             off += al256(cnt * 8);
@@ -1047,107 +1079,6 @@ __global__ void __launch_bounds__(kOrdThreads) order_scatter_kernel(const int32_
     }
 }
 }  // namespace
-
-// ---- mpcqp_model_predict_counts: what the shared-model solve sees first -- the slacks at the unconstrained minimiser, s = h + M w
-// with h = e - Hx x0 and w = L^-1 q from the model's linear maps (the MODEL prologue of mpcqp_pair.hip) --, turned into a sort key
-// per problem: 31 x (rows violated) + a 31-level bucket of their mean relative violation. 32 lanes per problem (m <= 32 rows).
-namespace {
-constexpr int kPredPerBlock = 64;  // problems per workgroup: the model (4-12 KB, shared by the batch) is staged in LDS once for them
-__global__ void __launch_bounds__(256) model_counts_kernel(const double *__restrict__ model, const KernelArgs ka, const double *__restrict__ ge,
-                                                            double tol, int64_t batch, int32_t *__restrict__ counts)
-{
-    extern __shared__ double pm[];  // M [m][nc + 1] | Hx [m][nx] | e [m] | Wx [n][nx] | Wg [n][nx] | Wt [n][nT] (stage costs only)
-    const int n = ka.n, m = ka.m, nx = ka.nx, nT = ka.N * ka.nx;
-    const ModelLayout ml = make_model_layout(nx, ka.N, n, m);
-    const int ldm = ml.nc + 1;  // (odd row stride: the 32 rows of a column sit in 32 banks)
-    const bool stage = ka.flags & MPCQP_Q_STAGE;
-    double *sM = pm, *sHx = sM + m * ldm, *se = sHx + m * nx, *sWx = se + m, *sWg = sWx + n * nx, *sWt = sWg + n * nx;
-    for (int i = threadIdx.x; i < m * ml.nc; i += 256) sM[(i / ml.nc) * ldm + i % ml.nc] = model[ml.off_M + i];
-    for (int i = threadIdx.x; i < m * nx; i += 256) sHx[i] = model[ml.off_Hx + i];
-    for (int i = threadIdx.x; i < m; i += 256) se[i] = model[ml.off_e + i];
-    for (int i = threadIdx.x; i < n * nx; i += 256) {
-        sWx[i] = model[ml.off_Wx + i];
-        sWg[i] = model[ml.off_Wg + i];
-    }
-    if (stage)
-        for (int i = threadIdx.x; i < n * nT; i += 256) sWt[i] = model[ml.off_Wt + i];
-    __syncthreads();
-    const int hl = threadIdx.x & 31;
-    const bool row = hl < m;
-    const int kq = row ? hl / ka.mk : 0;
-    for (int it = 0; it < kPredPerBlock / 8; ++it) {
-        const int64_t prob = (int64_t)blockIdx.x * kPredPerBlock + it * 8 + (threadIdx.x >> 5);
-        if (prob >= batch) break;  // (whole 32-lane groups leave together; no barrier follows)
-        const double *x0 = (const double *)ka.x0.ptr + prob * ka.x0.batch_stride;
-        const double *goal = ka.goal.ptr ? (const double *)ka.goal.ptr + prob * ka.goal.batch_stride : nullptr;
-        const double *tgt = ka.targets.ptr ? (const double *)ka.targets.ptr + prob * ka.targets.batch_stride : nullptr;
-        double wk = 0.0;  // lane k < n: w_k
-        if (hl < n) {
-            for (int c = 0; c < nx; ++c) wk += sWx[hl * nx + c] * x0[c];
-            if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
-                for (int c = 0; c < nx; ++c) wk -= sWg[hl * nx + c] * goal[c];
-            if (stage && tgt)
-                for (int j = 0; j < nT; ++j) wk -= sWt[hl * nT + j] * tgt[j];
-        }
-        double hh = 0.0, sl = 0.0;
-        if (row) {
-            hh = ge ? ge[prob * ka.e.batch_stride + kq * ka.e.step_stride + (hl - kq * ka.mk)] : se[hl];
-            for (int c = 0; c < nx; ++c) hh -= sHx[hl * nx + c] * x0[c];
-            sl = hh;
-        }
-        for (int k = 0; k < n; ++k) {
-            const double w = __shfl(wk, k, 32);
-            if (row) sl += sM[hl * ldm + k] * w;
-        }
-        const double scale = 1.0 + fabs(hh);
-        const bool viol = row && sl < -tol * scale;
-        double rel = viol ? fmin(1.0, -sl / scale) : 0.0;
-        int rows = viol ? 1 : 0;
-        for (int d = 16; d >= 1; d >>= 1) {
-            rel += __shfl_xor(rel, d, 32);
-            rows += __shfl_xor(rows, d, 32);
-        }
-        if (hl == 0) {
-            int bucket = rows ? (int)(31.0 * rel / rows) : 0;
-            bucket = bucket > 30 ? 30 : bucket;
-            counts[prob] = rows * 31 + bucket;
-        }
-    }
-}
-}  // namespace
-
-int mpcqp_model_predict_counts(const MpcqpDims *dims, const void *model, const MpcqpOperand *e, const MpcqpOperand *x0,
-                               const MpcqpOperand *goal, const MpcqpOperand *targets, int64_t batch, const MpcqpSolveOpts *opts,
-                               int32_t *counts, void *stream)
-{
-    int rc = check_dims(dims);
-    if (rc) return rc;
-    if (!model || !x0 || !x0->ptr || !counts || batch < 0) return MPCQP_EINVAL;
-    if ((dims->flags & MPCQP_Q_TERMINAL) && !(goal && goal->ptr)) return MPCQP_EINVAL;
-    if ((dims->flags & MPCQP_Q_STAGE) && !(targets && targets->ptr)) return MPCQP_EINVAL;
-    if (batch == 0) return 0;
-    KernelArgs ka;
-    fill_args(ka, dims, nullptr);
-    ka.x0 = *x0;
-    if (goal) ka.goal = *goal;
-    if (targets) ka.targets = *targets;
-    ka.model = model;
-    if ((rc = fill_opts(ka, opts, dims->dtype, true))) return rc;
-    if (!pair_eligible(ka, MODE_MODEL, dims->dtype)) return MPCQP_EUNSUPPORTED;  // (the kernel the order is for)
-    const double *ge = nullptr;
-    if (e && e->ptr) {
-        ka.e = *e;
-        ge = (const double *)e->ptr;
-    }
-    const ModelLayout ml = make_model_layout(ka.nx, ka.N, ka.n, ka.m);
-    const size_t lds = sizeof(double) * ((size_t)ka.m * (ml.nc + 1) + (size_t)ka.m * ka.nx + ka.m + 2 * (size_t)ka.n * ka.nx +
-                                         ((ka.flags & MPCQP_Q_STAGE) ? (size_t)ka.n * ka.N * ka.nx : 0));
-    if (lds > 64 * 1024) return MPCQP_EUNSUPPORTED;
-    const unsigned grid = (unsigned)((batch + kPredPerBlock - 1) / kPredPerBlock);
-    hipLaunchKernelGGL(model_counts_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const double *)model, ka, ge, ka.tol, batch,
-                       counts);
-    return (int)hipGetLastError();
-}
 
 size_t mpcqp_order_workspace_bytes(int64_t batch)
 {

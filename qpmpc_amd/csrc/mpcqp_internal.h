@@ -241,6 +241,10 @@ bool pair_eligible(const KernelArgs &ka, int mode, int dtype);
 constexpr size_t kPairWarmDoubles = 16 * 16 + 8;  // T (16 x 16), then 16 int32 constraint ids
 int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st);
 int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st);  // shared model (ka.model)
+// small-problem kernel (mpcqp_quad.hip): four problems per wavefront, cold lean fused build+solve
+bool quad_applies(const KernelArgs &ka);                  // the kernel serves this launch's layout
+bool quad_eligible(const KernelArgs &ka, int64_t batch);  // ... and the dispatch takes it (batch size, MPCQP_OPT_TWO / FOUR_PER_WAVE)
+int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

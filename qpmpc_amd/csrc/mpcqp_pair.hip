@@ -314,7 +314,10 @@ __global__ void __launch_bounds__(64 * WPB, 2)
     int64_t prob = 2 * ((int64_t)blockIdx.x * WPB + wv) + (hb >> 5);
     const bool valid = prob < batch;  // an odd batch leaves the last half idle: it repeats the last problem, stores nothing
     prob = valid ? prob : batch - 1;
-    if constexpr (ORD) prob = ka.order[prob];
+    if constexpr (ORD) {  // (an index outside the batch is clamped: a bad order costs wrong pairings, never an access out of bounds)
+        const int64_t o = ka.order[prob];
+        prob = o < 0 ? 0 : (o >= batch ? batch - 1 : o);
+    }
     T *sm = (T *)smem_raw + (2 * wv + (hb ? 1 : 0)) * L.per;
     const int vofs = low ? hl : 3 * NV + l15;  // element of an exchange vector (shadow copy for lanes >= 16)
     const int n = ka.n, m = ka.m;
@@ -1613,6 +1616,7 @@ int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     // the register-pipelined chain: terminal cost only, state constraints only, two rows per step
     const bool lean = ka.mk == 2 && ka.C.ptr && !ka.D.ptr && !(ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
+    if (quad_eligible(ka, batch)) return launch_quad(ka, batch, st);  // cold lean launches that fill the machine about once: four problems per wavefront
     if (ka.nx == 3) return lean ? launch_pair_t<3, 2>(ka, batch, st) : launch_pair_t<3, 0>(ka, batch, st);
     return lean ? launch_pair_t<4, 2>(ka, batch, st) : launch_pair_t<4, 0>(ka, batch, st);
 }

@@ -1,0 +1,890 @@
+// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {3, 4},
+// float64, terminal cost only, state rows only, two rows per step): FOUR PROBLEMS PER WAVEFRONT, one per 16-lane DPP row.
+//
+// Replaces the same reference code as mpcqp_pair.hip (qpmpc/mpc_qp.py:53-149 for the build, qpsolvers.solve_problem at
+// qpmpc/solve_mpc.py:43 for the solve) for the cold fused build+solve of BASELINE configs 1, 2 and 4 (nx = 3, nu = 1,
+// N = 16 -> n = 16, m = 32). Everything else the small-problem path serves (stage costs, input rows, shared models, warm
+// starts, seed steps) stays on mpcqp_pair.hip, which is also this kernel's cross-check (MPCQP_OPT_TWO_PER_WAVE).
+//
+// Why four per wavefront (round-4 counters on the pair kernel, profiles/r04_pair_m_rocprof_summary.txt): 8.17 M vector
+// instructions per 4096-problem launch of which 4.22 M are float64 arithmetic -- 48 % of vector issue is masks, selects,
+// lane moves and reductions that serve TWO problems per instruction, and half of every lane-crossing step exists only
+// because a problem straddles two DPP rows (v_permlane16_swap in every reduction, the copy of the factor into the second
+// row, the high row's -z copied over the low one). Here a problem owns ONE 16-lane row and each lane owns FOUR 16-register
+// rows, so the same overhead stream serves four problems and every lane-crossing step is a row-only DPP operation:
+//   lane l of a row (l = 0..15):
+//     RT  row l of T = N* (active-set slot l, its multiplier, its constraint id)
+//     RH  row l of the projector H = I - M_A' T
+//     K0  K_l = H M_l (constraint l, slack s0)        K1  K_{l+16} = H M_{l+16} (constraint l + 16, slack s1)
+//   build: lane l owns column l of Psi and row l of P -> L; EVERY lane carries the free response Phi_k x0 (there is no
+//   17th lane; the 15 extra FMAs per step are issue slots a lone wavefront leaves idle anyway), so h and q need no exchange.
+// 1024 wavefronts for the 4096 problems of config 2 -> ONE wavefront per SIMD (512-register budget), 35.6 KB of LDS each.
+//
+// Solver: the dual active-set method (Goldfarb-Idnani 1983) in the explicit-operator form of mpcqp_pair.hip, same pivots,
+// same tolerances; see that file for the derivation. What differs:
+//   * Cholesky and forward substitution are ONE right-looking pass: step j scales column j of L and immediately applies it
+//     to the trailing columns of P, of the two rows of G, of the identity row (-> L^-T) -- four independent FMA streams on
+//     the same DPP broadcasts -- and to q (-> w = L^-1 q, component k in lane k).
+//   * One loop serves every kind of trip. The update vector (z for a new row, T_l for a leaving slot) always sits in a
+//     register with component k in lane k and is applied by DPP row broadcasts at the top of the next trip; the rare
+//     parts (|K_p|^2 near dependence, ratio test on the multipliers, drop pass) sit behind wavefront-uniform ballots.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "mpcqp.h"
+#include "mpcqp_internal.h"
+
+namespace mpcqp {
+
+namespace quad {
+
+constexpr int NV = 16;    // padded number of variables / slots = lanes per problem
+constexpr int MMAX = 32;  // constraints a problem can hold (two per lane)
+constexpr int LDM = 18;   // row stride of the M image (144 B: rows start in distinct 16-B slots)
+constexpr int MK = 2;     // inequality rows per step
+
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+constexpr int ROR8 = 0x128, ROR4 = 0x124, ROR2 = 0x122, ROR1 = 0x121;  // rotate within a row of 16
+
+// all-reduce (min) over the 16 lanes of each row
+__device__ __forceinline__ unsigned row_min(unsigned v)
+{
+    v = min(v, dpp_u<ROR8>(v));
+    v = min(v, dpp_u<ROR4>(v));
+    v = min(v, dpp_u<ROR2>(v));
+    v = min(v, dpp_u<ROR1>(v));
+    return v;
+}
+// value of lane `idx` (0..15; per lane, usually uniform inside a row) of the caller's own row
+__device__ __forceinline__ int row_get(int x, int rb, int idx) { return __builtin_amdgcn_ds_bpermute((rb + idx) << 2, x); }
+__device__ __forceinline__ double row_get(double x, int rb, int idx)
+{
+    const int a = (rb + idx) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(a, __double2loint(x));
+    const int hi = __builtin_amdgcn_ds_bpermute(a, __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+// true in every lane of a row iff `pred` holds in one of its lanes
+__device__ __forceinline__ bool row_any(bool pred, int rb)
+{
+    const unsigned long long b = __ballot(pred);
+    return ((unsigned)(b >> rb) & 0xffffu) != 0u;
+}
+// order-preserving map of a double onto two unsigned words
+__device__ __forceinline__ void ordered(double x, unsigned &hi, unsigned &lo)
+{
+    const unsigned h = (unsigned)__double2hiint(x), l = (unsigned)__double2loint(x);
+    const bool neg = h & 0x80000000u;
+    hi = neg ? ~h : (h | 0x80000000u);
+    lo = neg ? ~l : l;
+}
+__device__ __forceinline__ void ld16(double (&d)[NV], const double *src)
+{
+    const double2 *p = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        const double2 t = p[i];
+        d[2 * i] = t.x;
+        d[2 * i + 1] = t.y;
+    }
+}
+__device__ __forceinline__ void st16(double *dst, const double (&s)[NV])
+{
+    double2 *p = reinterpret_cast<double2 *>(dst);
+#pragma unroll
+    for (int i = 0; i < NV / 2; ++i) {
+        double2 t;
+        t.x = s[2 * i];
+        t.y = s[2 * i + 1];
+        p[i] = t;
+    }
+}
+__device__ __forceinline__ double dot16(const double (&a)[NV], const double (&b)[NV])
+{
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) {
+        acc0 += a[k] * b[k];
+        acc1 += a[k + 1] * b[k + 1];
+        acc2 += a[k + 2] * b[k + 2];
+        acc3 += a[k + 3] * b[k + 3];
+    }
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+// two dot products with one vector, two chains each (a lone wavefront issues a dependent FMA every 8.5 cycles and an
+// independent one every 5.1: four chains in flight are enough, and accumulators are registers the loop does not have)
+__device__ __forceinline__ void dot16x2(const double (&a)[NV], const double (&b)[NV], const double (&x)[NV], double &ra, double &rb)
+{
+    double a0 = a[0] * x[0], a1 = a[1] * x[1], b0 = b[0] * x[0], b1 = b[1] * x[1];
+#pragma unroll
+    for (int k = 2; k < NV; k += 2) {
+        a0 = fma(a[k], x[k], a0);
+        b0 = fma(b[k], x[k], b0);
+        a1 = fma(a[k + 1], x[k + 1], a1);
+        b1 = fma(b[k + 1], x[k + 1], b1);
+    }
+    ra = a0 + a1;
+    rb = b0 + b1;
+}
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
+// The value held by lane N of the caller's 16-lane row, in every lane of that row (v_mov_b64_dpp row_newbcast:N).
+template <int N> __device__ __forceinline__ double row_bcast(double x) { return __builtin_amdgcn_mov_dpp(x, 0x150 + N, 0xf, 0xf, true); }
+// acc += (x of lane N of the caller's row) * m in ONE instruction (v_fmac_f64_dpp). The compiler cannot see inside the asm:
+// a register written by a VALU instruction needs two wait states before a DPP read, so every batch of these is preceded by
+// dpp_ready(x) on its broadcast source (tools/check_dpp_hazards.py verifies that on the assembly).
+template <int N> __device__ __forceinline__ void fmac_bcast(double &acc, double x, double m)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(N));
+}
+__device__ __forceinline__ void dpp_ready(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
+// Compile-time loop: f(integral_constant<int, I>) for I = B .. E-1. The DPP lane select is an immediate, so the loops over lanes
+// are unrolled by the front end (a `switch` on an unrolled loop's counter is only folded AFTER the unroller has priced the
+// body with all sixteen cases in it -- the fused factorisation then exceeds the unroller's budget and stays a loop of jump tables).
+template <int I> using ic = std::integral_constant<int, I>;
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+// sum_k (x_k of lane k of the caller's row) * m[k]: a dot product with a vector spread over the row's lanes, two chains
+__device__ __forceinline__ double dot_bcast(double x, const double (&m)[NV], double init)
+{
+    double a0 = init, a1 = 0.0;
+    dpp_ready(x);
+    static_for<0, NV / 2>([&](auto kk) {
+        constexpr int k = 2 * decltype(kk)::value;
+        fmac_bcast<k>(a0, x, m[k]);
+        fmac_bcast<k + 1>(a1, x, m[k + 1]);
+    });
+    return a0 + a1;
+}
+
+// 1/x from the hardware estimate plus two Newton steps (operands are never subnormal or zero when the result is used)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+// 1/sqrt(x) from the hardware estimate, one Newton step and one third-order step (x is a positive, normal number wherever the
+// result is used: a pivot of a positive definite matrix, a squared row norm; the library's rsqrt spends two thirds of its
+// instructions on subnormals and infinities)
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+// The wavefronts of a workgroup share nothing and a wavefront's LDS operations complete in order: only the COMPILER has
+// to keep the order of an exchange (no s_barrier, no queue drain).
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS carve of ONE problem, in doubles
+constexpr int OFF_M = 0;                      // build: G image by column, 16 x GS (GS = 33) | main: M image, 32 x LDM
+constexpr int OFF_LT = MMAX * LDM;            // rows of L^-T (read when a point is accepted)
+constexpr int OFF_T = OFF_LT + NV * NV;       // T by rows (refinement only)
+constexpr int OFF_KA = OFF_T + NV * NV;       // the row of a leaving slot
+constexpr int OFF_ACT = OFF_KA + NV;          // 16 int32: constraint held by each slot
+constexpr int PER = OFF_ACT + NV / 2;         // 1112 doubles = 8896 B per problem, 35.6 KB per wavefront
+static_assert(NV * 33 <= MMAX * LDM, "the G image must fit the M image's region");
+static_assert(PER % 2 == 0, "16-byte alignment of every problem's carve");
+
+constexpr double DEP = 1e-14;      // |z|^2 / |M_p|^2 below this: M_p depends on the active rows
+constexpr double DEP_FAST = 1e-6;  // K_p . M_p is trusted as |z|^2 only above this (mpcqp_pair.hip); |K_p|^2 otherwise
+
+}  // namespace quad
+
+using namespace quad;
+
+// ORD: the launch carries a pairing order (MpcqpSolveOpts.order): row i of the launch takes problem order[i].
+// WPB: wavefronts per workgroup (they share nothing).
+template <int NX, bool ORD, int WPB>
+__global__ void __launch_bounds__(64 * WPB, 1)
+    mpcqp_quad_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
+                      const double *__restrict__ ge, const double *__restrict__ gx0, const double *__restrict__ ggoal,
+                      double *__restrict__ oU, double *__restrict__ olam, int32_t *__restrict__ ostatus,
+                      int32_t *__restrict__ oiters, const KernelArgs ka, const int64_t batch)
+{
+    using T = double;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    {  // every kernel argument the operand addresses need, requested in ONE batch of scalar loads at the top (mpcqp_pair.hip)
+        const int64_t b0 = ka.A.batch_stride, b1 = ka.B.batch_stride, b2 = ka.C.batch_stride, b3 = ka.e.batch_stride,
+                      b4 = ka.x0.batch_stride, b5 = ka.goal.batch_stride;
+        const int64_t s0 = ka.A.step_stride, s1 = ka.B.step_stride, s2 = ka.C.step_stride, s3 = ka.e.step_stride;
+        asm volatile("" ::"s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(ka.N), "s"(ka.nu),
+                     "s"(ka.flags), "s"(ka.probe), "s"(gA), "s"(gB), "s"(gC), "s"(ge), "s"(gx0), "s"(ggoal), "s"(ka.n), "s"(ka.m),
+                     "s"(batch));
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int rb = lane & 48;  // first lane of this row
+    const int l = lane & 15;   // lane inside the row
+    int64_t prob = 4 * ((int64_t)blockIdx.x * WPB + wv) + (rb >> 4);
+    const bool valid = prob < batch;  // a batch that is no multiple of four leaves rows idle: they repeat the last problem, store nothing
+    prob = valid ? prob : batch - 1;
+    if constexpr (ORD) {  // (an index outside the batch is clamped: a bad order costs wrong pairings, never an access out of bounds)
+        const int64_t o = ka.order[prob];
+        prob = o < 0 ? 0 : (o >= batch ? batch - 1 : o);
+    }
+    T *sm = (T *)smem_raw + (4 * wv + (rb >> 4)) * PER;
+    const int n = ka.n, m = ka.m;
+    const int row0 = l, row1 = l + NV;                // the two constraints of this lane
+    const bool isc0 = row0 < m, isc1 = row1 < m;
+    const T INF = HUGE_VAL;
+    constexpr int GS = 33;  // the G image is stored by COLUMN with an odd stride
+    T *Gimg = sm + OFF_M, *Ml = sm + OFF_M, *LTimg = sm + OFF_LT, *Timg = sm + OFF_T, *kAv = sm + OFF_KA;
+    int *actv = reinterpret_cast<int *>(sm + OFF_ACT);
+
+    // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[16] per problem, slots as mpcqp_pair.hip
+    long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
+    auto tick = [&](int slot) {
+        if (stamp && l == 0 && valid) {
+            stamp[slot] = (long long)__builtin_readcyclecounter();
+            if (slot == 0 || slot == 6) stamp[slot ? 13 : 12] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    };
+    tick(0);
+
+    // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
+    T Pr[NV];  // row l of P, then of L
+    T hval0, hval1, qa;
+    {
+        constexpr int nx = NX;
+        const int nu = ka.nu, N = ka.N;
+        const T *A = gA + prob * ka.A.batch_stride;
+        const T *B = gB + prob * ka.B.batch_stride;
+        const T *Cm = gC + prob * ka.C.batch_stride;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0, sC = ka.C.step_stride ? MK * nx : 0;
+        const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
+        constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
+        const bool col = (l < n);
+        const int j = col ? (nu == 1 ? l : l / nu) : -1, ii = col ? l - j * nu : 0;  // (nu == 1: no division before the loads)
+        // every load is issued before the first use: the whole build costs ONE HBM latency
+        const int64_t eb = prob * ka.e.batch_stride;
+        const T eval0 = isc0 ? ge[eb + (row0 >> 1) * ka.e.step_stride + (row0 & 1)] : INF;
+        const T eval1 = isc1 ? ge[eb + (row1 >> 1) * ka.e.step_stride + (row1 & 1)] : INF;
+        T v[NX], x[NX], gref[NX], bcol[NX];
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            v[s] = T(0);
+            x[s] = x0[s];
+            gref[s] = termQ ? goal[s] : T(0);
+        }
+#pragma unroll
+        for (int r = 0; r < NX; ++r) bcol[r] = col ? B[j * sB + r * nu + ii] : T(0);
+        // lane e of the row keeps element e (and e + 16) of [A_k | C_k] for every step k, straight from HBM; the chain
+        // fetches an operand as a DPP row broadcast (lanes without an element load a valid address and are never read)
+        T opa[NV], opb[NV];
+        {
+            const int e0 = l, e1 = l + 16;
+            const bool ok0 = e0 < NEe, ok1 = e1 < NEe;
+            const T *p0 = (e0 < NAe) ? A + e0 : Cm + (ok0 ? e0 - NAe : 0);
+            const T *p1 = (e1 < NAe) ? A + e1 : Cm + (ok1 ? e1 - NAe : 0);
+            const int s0 = (e0 < NAe) ? sA : sC, s1 = (e1 < NAe) ? sA : sC;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int kc = (k < N) ? k : N - 1;
+                opa[k] = p0[kc * s0];
+                opb[k] = (NEe > 16) ? p1[kc * s1] : T(0);
+            }
+        }
+        tick(8);
+        const T wu = (T)ka.wu;
+#pragma unroll
+        for (int b = 0; b < NV; ++b) Pr[b] = (l == b) ? (col ? wu : T(1)) : T(0);
+        tick(9);
+        // acc += (element IDX of [A_k | C_k]) * xx
+        auto mac = [&](auto idx, T &acc, const T &oa, const T &ob, T xx) {
+            constexpr int IDX = decltype(idx)::value;
+            if constexpr (IDX < 16)
+                fmac_bcast<IDX>(acc, oa, xx);
+            else
+                fmac_bcast<IDX - 16>(acc, ob, xx);
+        };
+        // [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k (column l in lane l), [C_k Phi_k x0; Phi_{k+1} x0] alongside in every lane
+        T hp0 = T(0), hp1 = T(0);  // C_k Phi_k x0 of this lane's two rows
+        const int lk = l >> 1;
+        const bool lodd = l & 1;
+        static_for<0, NV>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            if (k < N) {
+                T g[MK], xg[MK];
+                static_for<0, MK>([&](auto i2c) {
+                    constexpr int i2 = decltype(i2c)::value;
+                    T acc = T(0), xacc = T(0);
+                    static_for<0, NX>([&](auto sc) {
+                        constexpr int s2 = decltype(sc)::value;
+                        mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                        mac(ic<NAe + i2 * NX + s2>{}, xacc, opa[k], opb[k], x[s2]);
+                    });
+                    g[i2] = acc;
+                    xg[i2] = xacc;
+                });
+#pragma unroll
+                for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
+                const T xs = lodd ? xg[1] : xg[0];
+                if constexpr (k < 8)
+                    hp0 = (lk == k) ? xs : hp0;
+                else
+                    hp1 = (lk == k - 8) ? xs : hp1;
+                // column j of Psi_k is zero up to step j, so B_j's column enters as the start value of lane j's sums
+                const T hk = (j == k) ? T(1) : T(0);
+                T w[NX], xw[NX];
+                static_for<0, NX>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    T acc = hk * bcol[r], xacc = T(0);
+                    static_for<0, NX>([&](auto sc) {
+                        constexpr int s2 = decltype(sc)::value;
+                        mac(ic<r * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                        mac(ic<r * NX + s2>{}, xacc, opa[k], opb[k], x[s2]);
+                    });
+                    w[r] = acc;
+                    xw[r] = xacc;
+                });
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    v[r] = w[r];
+                    x[r] = xw[r];
+                }
+            }
+        });
+        tick(10);
+        // P = wu I + wt psi_N' psi_N ; q = wt psi_N' (Phi_N x0 - goal)   (mpc_qp.py:99-105, 129-149)
+        qa = T(0);
+        const T wt = (T)ka.wt;
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            const T t = wt * v[s];
+            if (termQ) qa += t * (x[s] - gref[s]);
+            if (termP) {
+                T src = v[s];
+                dpp_ready(src);
+                static_for<0, NV>([&](auto bc) { fmac_bcast<decltype(bc)::value>(Pr[decltype(bc)::value], src, t); });
+            }
+        }
+        qa = col ? qa : T(0);
+        hval0 = isc0 ? eval0 - hp0 : INF;  // h_i = e_i - C_k Phi_k x0
+        hval1 = isc1 ? eval1 - hp1 : INF;
+        tick(11);
+        wsync();  // the G image is complete
+    }
+    tick(1);
+    // ------------------------------------------------------------ factorise + forward substitution, one pass
+    // Right-looking Cholesky; step j scales column j of L and applies it at once to everything that waits for it:
+    //   P[:, k] -= L[:, j] L[k][j]                       (trailing columns of P)
+    //   x[k]    -= (x[j] / L_jj) L[k][j], x[j] /= L_jj   for the rows x = G_l, G_{l+16}, e_l: -> M_l, M_{l+16}, (L^-T)_l
+    //   q_k     -= L[k][j] w_j, w_j = q_j / L_jj         (q_k in lane k: L[k][j] is local, w_j the broadcast)
+    // L[k][j] of lane k is a DPP row broadcast; the four FMA streams are independent of each other.
+    bool notpd = false;
+    T RM0[NV], RM1[NV], RLt[NV];
+    T wv_ = T(0);  // w = L^-1 q, component l
+    {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            RM0[k] = isc0 ? Gimg[k * GS + row0] : T(0);
+            RM1[k] = isc1 ? Gimg[k * GS + row1] : T(0);
+            RLt[k] = (l == k) ? T(1) : T(0);
+        }
+        static_for<0, NV>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const T pij = Pr[j];                 // P[l][j] of this lane's row, before scaling
+            const T piv = row_bcast<j>(pij);     // P[j][j]
+            if (!(piv > T(0))) notpd = true;
+            const T rinv = fast_rsqrt(piv);
+            const T nt2 = -(pij * rinv * rinv);  // -P[l][j] / piv
+            T nl = -(pij * rinv);                // -L[l][j] (column j of L is never read after this step: not kept)
+            RM0[j] *= rinv;
+            RM1[j] *= rinv;
+            RLt[j] *= rinv;
+            const T wj = qa * rinv;              // lane j: w_j
+            wv_ = (l == j) ? wj : wv_;
+            {
+                T src = pij, wsrc = wj;
+                asm volatile("s_nop 1" : "+v"(src), "+v"(nl), "+v"(wsrc) : "v"(RM0[j]), "v"(RM1[j]), "v"(RLt[j]));  // (the DPP wait states)
+                fmac_bcast<j>(qa, wsrc, nl);  // q_k -= L[k][j] w_j (lanes k <= j hold values nobody reads again)
+                static_for<j + 1, NV>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    fmac_bcast<k>(Pr[k], src, nt2);     // P[k][j] from lane k
+                    fmac_bcast<k>(RM0[k], nl, RM0[j]);  // -L[k][j] from lane k
+                    fmac_bcast<k>(RM1[k], nl, RM1[j]);
+                    fmac_bcast<k>(RLt[k], nl, RLt[j]);
+                });
+            }
+        });
+        wsync();  // the M image below reuses the G image
+    }
+    tick(2);
+    tick(3);
+    int status = MPCQP_MAX_ITER, iters = 0;
+    T xsol = T(0);
+    bool done = notpd;      // this row has left the active-set loop
+    bool finished = notpd;  // ... and needs no refinement any more (failed, or accepted)
+    if (notpd) status = MPCQP_NOT_PD;
+
+    if (isc0) st16(Ml + row0 * LDM, RM0);  // image of M: row-p broadcasts, the active rows in the refinement
+    if (isc1) st16(Ml + row1 * LDM, RM1);
+    st16(LTimg + l * NV, RLt);  // the rows of L^-T leave the registers
+    const T y0 = -wv_;          // y0 = -L^-1 q, component l
+    T s0, s1, invn0, invn1;
+    {
+        // (computed by EVERY lane: a DPP read from a lane that a branch has switched off returns zero)
+        const T d0 = dot_bcast(wv_, RM0, hval0), d1 = dot_bcast(wv_, RM1, hval1);  // h - M y0 = h + M w
+        s0 = isc0 ? d0 : INF;
+        s1 = isc1 ? d1 : INF;
+        const T nn0 = dot16(RM0, RM0), nn1 = dot16(RM1, RM1);
+        invn0 = (nn0 > T(0)) ? fast_rsqrt(nn0) : T(1);
+        invn1 = (nn1 > T(0)) ? fast_rsqrt(nn1) : T(1);
+    }
+    // Selection rule (the classic Goldfarb-Idnani one): among the rows violated beyond the tolerance, the one FARTHEST
+    // from its hyperplane in the P^-1 metric, s_i / |M_i|.
+    const bool sel0 = isc0 && (hval0 < T(1e29)), sel1 = isc1 && (hval1 < T(1e29));
+    const T tol = (T)ka.tol;
+    const T tolh0 = tol + tol * fabs(hval0), tolh1 = tol + tol * fabs(hval1);  // row i is violated when s_i < -tol (1 + |h_i|)
+    const int max_iter = ka.max_iter;
+    T RT[NV], RH[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        RT[k] = T(0);                      // T = N* starts empty
+        RH[k] = (l == k) ? T(1) : T(0);    // H = I
+    }
+    T lam = T(0);      // multiplier of slot l
+    int myact = 0;     // constraint held by slot l
+    bool occ = false;  // slot l occupied
+    bool e0 = sel0, e1 = sel1;  // this lane's constraints may be selected: they have a bound and are not active (the slack of an
+                                // active row is never read: it stays whatever the steps make of it, zero up to rounding)
+    // row-uniform state
+    int nq = 0, p = 0, ldrop = 0;
+    unsigned mask = 0;  // occupied slots
+    bool needp = true, dropping = false;
+    T up = T(0);
+    int fails = 0;
+    // ---- selection, for the rows that start a new constraint (straight-line selects: no divergent branches), and the
+    //      fetch of row p of M (a broadcast read inside the row). Called between the two halves of the (deferred) rank-one
+    //      update: the update's first FMAs cover the reduction's dependent chain, its last ones the LDS round trip.
+    T mp[NV];
+    auto select = [&]() {
+        // a violated row's scaled slack is negative: the order of the magnitudes is the order of the high words, so
+        // the most violated row has the smallest complement
+        const bool want = needp & !done & !dropping;
+        const unsigned h0 = ~(unsigned)__double2hiint(s0 * invn0), h1 = ~(unsigned)__double2hiint(s1 * invn1);
+        const bool v0 = want & e0 & (s0 < -tolh0), v1 = want & e1 & (s1 < -tolh1);
+        const unsigned k0 = v0 ? ((h0 & ~31u) | (unsigned)row0) : 0xffffffffu;
+        const unsigned k1 = v1 ? ((h1 & ~31u) | (unsigned)row1) : 0xffffffffu;
+        const unsigned mkey = row_min(min(k0, k1));
+        const bool none = want & (mkey == 0xffffffffu);
+        const bool got = want & !none;
+        done = done | none;
+        status = none ? (int)MPCQP_SOLVED : status;
+        p = got ? (int)(mkey & 31u) : p;
+        up = got ? T(0) : up;
+        needp = needp & !got;
+    };
+    // R += c v for the two maintained register rows, v spread over the row (component k in lane k), columns B .. E-1
+    auto update = [&](auto bc, auto ec, T zn, T cT, T cH) {
+        static_for<decltype(bc)::value, decltype(ec)::value>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            fmac_bcast<k>(RT[k], zn, cT);
+            fmac_bcast<k>(RH[k], zn, cH);
+        });
+    };
+    constexpr int USPLIT = 8;  // columns of the update issued before the selection's row fetch
+    // pending rank-one update R += c v, applied at the top of the next trip -- the ONE site that writes the register rows,
+    // selects and fetches
+    T zn = T(0), cT = T(0), cH = T(0);
+    wsync();
+    tick(4);
+    for (;;) {
+        // ===================================================== active-set loop
+        for (;;) {
+            // ---- the previous trip's rank-one update  T_a += (r_a/d2) z, T_new = -z/d2 ; H -= z z'/d2  (or the same with a
+            //      leaving slot's T_l), wrapped around this trip's selection and row fetch, which only read the slacks
+            dpp_ready(zn);
+            update(ic<0>{}, ic<USPLIT>{}, zn, cT, cH);
+            select();
+            ld16(mp, Ml + p * LDM);
+            update(ic<USPLIT>{}, ic<NV>{}, zn, cT, cH);
+            cT = cH = T(0);
+            if (__ballot(!done) == 0ull) break;
+            const bool st = !done & !dropping;  // this row steps
+            const bool drp = !done & dropping;  // ... or drops a slot
+            const bool phi = p >= NV;           // (row-uniform)
+            const int pl = p & 15;
+            // ---- r_a = T_a . M_p ; -z_l = H_l . M_p ; then -M_i . z = sum_k M_i[k] (-z_k) for this lane's two rows, with -z
+            //      spread over the row: the projected rows K_i = H M_i of mpcqp_pair.hip are NOT maintained (32 FMAs of update
+            //      and 32 of dot products per trip against the 32 of these two)
+            const T hd = dot16(RH, mp);
+            const T kd0 = dot_bcast(hd, RM0, T(0)), kd1 = dot_bcast(hd, RM1, T(0));
+            // ---- step length, by lane p from its own row: |z|^2 = -M_p . z (trusted well away from dependence, DEP_FAST),
+            //      1/|z|^2, t2 = -s_p/|z|^2; the two results go to the row (inv = -1: too close to dependence)
+            T inv, t2;
+            {
+                const T kp = phi ? kd1 : kd0, sq = phi ? s1 : s0, iq = phi ? invn1 : invn0;
+                const bool okf = kp * iq * iq > T(DEP_FAST);
+                const T iv = fast_rcp(kp);
+                inv = row_get(okf ? iv : T(-1), rb, pl);
+                t2 = row_get(-sq * iv, rb, pl);
+            }
+            T rd = dot16(RT, mp);  // (while the exchange is in flight)
+            pin(rd);
+            if (__ballot(st & !(inv > T(0))) != 0ull) {  // rare: |z|^2 as a sum of squares, robust near dependence
+                T z2 = hd * hd;
+                z2 += dpp_mov<ROR8>(z2);
+                z2 += dpp_mov<ROR4>(z2);
+                z2 += dpp_mov<ROR2>(z2);
+                z2 += dpp_mov<ROR1>(z2);
+                z2 = row_bcast<0>(z2);  // (the rotations sum in another order in every lane)
+                const T sq = row_get(phi ? s1 : s0, rb, pl), iq = row_get(phi ? invn1 : invn0, rb, pl);
+                const bool ok2 = (z2 * iq * iq > T(DEP)) & (z2 > T(0));
+                const T iv2 = fast_rcp(z2);
+                const bool nearp = !(inv > T(0));
+                t2 = nearp ? -sq * iv2 : t2;
+                inv = nearp ? (ok2 ? iv2 : T(0)) : inv;
+            }
+            const bool can_move = (nq < n) & (inv > T(0));
+            inv = (can_move & st) ? inv : T(0);
+            t2 = can_move ? t2 : INF;
+            const int sl = (int)__builtin_ctz(~mask);  // lowest free slot
+            const T r = (occ & st) ? rd : T(0);
+            // a blocking multiplier exists iff lam_a / r_a < t2 for some slot
+            const bool blk = (r > T(0)) & (lam < t2 * r);
+            if (__ballot(drp | (st & (!can_move | (iters >= max_iter) | blk))) == 0ull) {
+                // ---- PLAIN TRIP: every row still in the loop takes a full step. Coefficients of the (deferred) update with
+                //      -z: slot sl takes -z/d2, the occupied slots r_a/d2, H row l -z_l/d2
+                const T tt = st ? t2 : T(0);
+                const bool isnew = st & (l == sl), isp = st & (l == pl);
+                iters += st ? 1 : 0;
+                zn = hd;
+                cT = (l == sl) ? inv : -(r * inv);
+                cH = -(hd * inv);
+                s0 = fma(tt, kd0, s0);  // s_i -= t M_i . z
+                s1 = fma(tt, kd1, s1);
+                T ln = fma(-tt, r, lam);
+                ln = (occ & (ln < T(0))) ? T(0) : ln;
+                lam = isnew ? up + tt : ln;
+                myact = isnew ? p : myact;
+                occ = occ | isnew;
+                e0 = e0 & !(isp & !phi);
+                e1 = e1 & !(isp & phi);
+                mask |= st ? (1u << sl) : 0u;
+                nq += st ? 1 : 0;
+                needp = needp | st;
+                continue;
+            }
+            // ---- GENERAL TRIP: limits, partial steps, drops
+            bool stepping = st;
+            {
+                const bool lim = stepping & (iters >= max_iter);
+                done = done | lim;
+                finished = finished | lim;
+                status = lim ? (int)MPCQP_MAX_ITER : status;
+                stepping = stepping & !lim;
+            }
+            iters += stepping ? 1 : 0;
+            const bool cand = occ & stepping & (r > T(0));
+            T t1 = INF;
+            int lq = 0;
+            const unsigned long long bl = __ballot(stepping & blk);
+            if (bl != 0ull) {  // ratio test on the multipliers
+                const T ratio = cand ? lam * fast_rcp(r) : INF;
+                unsigned hi, lo;
+                ordered(ratio, hi, lo);
+                hi = cand ? hi : 0xffffffffu;
+                const unsigned mhi = row_min(hi);
+                const unsigned k2 = (cand && hi == mhi) ? ((lo & ~31u) | (unsigned)l) : 0xffffffffu;
+                const unsigned ml = row_min(k2);
+                lq = (int)(ml & 15u);
+                const T tl1 = row_get(ratio, rb, lq);
+                // (only for the rows that are blocked: a row's result must not depend on what its wavefront's other rows need)
+                const bool blocked = ((unsigned)(bl >> rb) & 0xffffu) != 0u;
+                t1 = (blocked && mhi != 0xffffffffu) ? tl1 : INF;
+            }
+            T t = t1 < t2 ? t1 : t2;
+            {
+                const bool inf = stepping & !(t < INF);  // no step possible: the constraints are inconsistent
+                done = done | inf;
+                finished = finished | inf;
+                status = inf ? (int)MPCQP_INFEASIBLE : status;
+                stepping = stepping & !inf;
+            }
+            t = stepping ? t : T(0);
+            const bool full = stepping & (t2 <= t1);
+            zn = hd;
+            cT = full ? ((l == sl) ? inv : -(r * inv)) : T(0);
+            cH = full ? -(hd * inv) : T(0);
+            if (__ballot(drp) != 0ull) {
+                // slot ldrop leaves (its row T_l is in kAv). With W = T T' implicit, T_a -= (T_a . T_l / T_l . T_l) T_l
+                // (row l becomes exactly zero); the null space of the active rows gains the direction T_l:
+                // H += T_l T_l' / T_l . T_l.
+                T vv[NV];
+                ld16(vv, kAv);
+                const T tl = dot16(RT, vv);
+                const T tld = row_get(tl, rb, ldrop);
+                const T itl = fast_rcp(tld);
+                const T vl = kAv[l];
+                if (drp) {
+                    zn = vl;
+                    cT = (l == ldrop) ? T(-1) : (occ ? -tl * itl : T(0));
+                    cH = vl * itl;
+                    if (l == ldrop) {
+                        lam = T(0);
+                        occ = false;
+                    }
+                    mask &= ~(1u << ldrop);
+                    --nq;
+                    dropping = false;
+                }
+            }
+            // ---- bookkeeping: the implied primal point moved by t z: s_i -= t M_i . z
+            if (stepping) {
+                s0 = fma(t, kd0, s0);
+                s1 = fma(t, kd1, s1);
+                lam -= t * r;
+                lam = (occ && lam < T(0)) ? T(0) : lam;
+                up += t;
+            }
+            if (full) {  // p takes slot sl
+                if (l == sl) {
+                    lam = up;
+                    myact = p;
+                    occ = true;
+                }
+                if (l == pl) {
+                    e0 = e0 & phi;
+                    e1 = e1 & !phi;
+                }
+                mask |= 1u << sl;
+                ++nq;
+                needp = true;
+            }
+            const bool partial = stepping & !full;
+            if (__ballot(partial) != 0ull) {
+                // partial step: the next trip removes slot lq from T (no update is pending for this row: RT is current)
+                const int cl = row_get(myact, rb, lq);
+                wsync();
+                if (partial && l == lq) st16(kAv, RT);
+                if (partial) {
+                    if (l == (cl & 15)) {  // the row that leaves may be selected again
+                        e0 = (cl < NV) ? sel0 : e0;
+                        e1 = (cl < NV) ? e1 : sel1;
+                    }
+                    dropping = true;
+                    ldrop = lq;
+                }
+                wsync();
+            }
+        }
+        tick(5);
+        if (__ballot(!finished) == 0ull) break;
+        // ================================== multipliers by refinement, slacks re-evaluated
+        // (rows that are already finished compute along and change nothing)
+        actv[l] = occ ? myact : 0;
+        wsync();
+        int aa[NV];
+        {
+            const int4 *ap = reinterpret_cast<const int4 *>(actv);
+#pragma unroll
+            for (int q = 0; q < NV / 4; ++q) {
+                const int4 t4 = ap[q];
+                aa[4 * q] = t4.x;
+                aa[4 * q + 1] = t4.y;
+                aa[4 * q + 2] = t4.z;
+                aa[4 * q + 3] = t4.w;
+            }
+        }
+        // (M_A' cf)_l, cf_a in lane a (an empty slot carries a zero coefficient)
+        auto ma_dot = [&](T cf) {
+            T ma[NV];
+#pragma unroll
+            for (int a = 0; a < NV; ++a) ma[a] = Ml[aa[a] * LDM + l];
+            return dot_bcast(cf, ma, T(0));
+        };
+        // slacks of this lane's two rows at the point y (component k in lane k)
+        T fresh0, fresh1;
+        auto slacks = [&](T yv) {
+            const T f0 = dot_bcast(yv, RM0, T(0)), f1 = dot_bcast(yv, RM1, T(0));
+            fresh0 = isc0 ? hval0 - f0 : INF;
+            fresh1 = isc1 ? hval1 - f1 : INF;
+        };
+        // value of this slot's own constraint row (x0 of rows 0..15, x1 of rows 16..31)
+        auto of_act = [&](T x0v, T x1v) {
+            const T a = row_get(x0v, rb, myact & 15), b = row_get(x1v, rb, myact & 15);
+            return (myact < NV) ? a : b;
+        };
+        T y = y0 - ma_dot(occ ? lam : T(0));  // y = y0 - M_A' lam
+        slacks(y);
+        // active residuals rho_a = h_a - M_a y should vanish. When they already do to REFTOL (1 + |h_a|) in every row --
+        // the usual case: a dozen rank-one updates of T in float64 -- the refinement step below would move y by less than
+        // that and is skipped.
+        T rho = of_act(fresh0, fresh1);  // (fetched by EVERY lane: an exchange only sees the lanes that take part in it)
+        rho = occ ? rho : T(0);
+        constexpr double REFTOL = 1e-11;
+        const T hact = of_act(hval0, hval1);
+        const bool needref = occ & !finished & !(fabs(rho) <= T(REFTOL) * (T(1) + fabs(hact)));
+        const unsigned long long nr = __ballot(needref);
+        if (nr != 0ull) {
+            rho = (((unsigned)(nr >> rb) & 0xffffu) != 0u) ? rho : T(0);  // (rows that need none take a zero step: see the ratio test)
+            // dlam = -W rho_A = -T (T' rho_A)
+            st16(Timg + l * NV, RT);
+            wsync();
+            T uk;
+            {
+                T tc[NV];
+#pragma unroll
+                for (int a = 0; a < NV; ++a) tc[a] = Timg[a * NV + l];
+                uk = dot_bcast(rho, tc, T(0));  // (T' rho)_l
+            }
+            T dl = -dot_bcast(uk, RT, T(0));
+            dl = occ ? dl : T(0);
+            if (!finished) {
+                const T lraw = lam + dl;
+                lam = (occ && lraw < T(0)) ? T(0) : lraw;
+            }
+            // with dl as it is (not clamped) y moves exactly onto the active hyperplanes: y - M_A' dl = y + M_A' T (T' rho)
+            // = y + T' rho, because T' rho lies in the range of M_A' where M_A' T = I - H is the identity
+            y += uk;
+            wsync();
+            slacks(y);
+        }
+        // ---- acceptance: no inactive row violated, every active row on its bound, lam >= 0 -- with stationarity by
+        //      construction these are the KKT conditions of the strictly convex QP
+        bool dirty = row_any((e0 && !(fresh0 >= -T(4) * tolh0)) || (e1 && !(fresh1 >= -T(4) * tolh1)), rb);
+        {
+            const T ra = of_act(fresh0, fresh1);
+            const T ta = of_act(tolh0, tolh1);
+            const bool off = row_any(occ && !(fabs(ra) <= T(1e3) * ta), rb);
+            const bool neg = row_any(occ && !(lam >= T(0)), rb);
+            if (stamp && l == 0 && valid && !finished && done) {  // developer probe: why the last acceptance test failed
+                T worst = T(0);
+                stamp[14] = (long long)(dirty ? 1 : 0) | (off ? 2 : 0) | (neg ? 4 : 0) | ((long long)fails << 8) | ((long long)nq << 16);
+                (void)worst;
+            }
+            dirty = dirty || off || neg;
+        }
+        // u = L^-T y (component l; the rows of L^-T come back from their image)
+        auto primal = [&]() {
+            T lt[NV];
+            ld16(lt, LTimg + l * NV);
+            return dot_bcast(y, lt, T(0));
+        };
+        if (!finished && done) {
+            if (!dirty) {
+                xsol = primal();
+                status = MPCQP_SOLVED;
+                finished = true;
+            } else if (++fails < 4) {
+                // continue the active-set loop from the re-evaluated slacks
+                s0 = fresh0;
+                s1 = fresh1;
+                status = MPCQP_MAX_ITER;
+                done = false;
+                needp = true;
+            } else {
+                xsol = primal();
+                status = MPCQP_MAX_ITER;
+                finished = true;
+            }
+        }
+        wsync();
+        if (__ballot(!finished) == 0ull) break;
+    }
+    tick(6);
+    const bool ok = (status == MPCQP_SOLVED);
+    T lo0 = T(0), lo1 = T(0);
+    if (olam) {  // multipliers by constraint: every occupied slot drops its multiplier at its row's place
+        T *lamv = Timg;
+        lamv[row0] = T(0);
+        lamv[row1] = T(0);
+        wsync();
+        if (occ) lamv[myact] = lam;
+        wsync();
+        lo0 = ok ? lamv[row0] : T(0);
+        lo1 = ok ? lamv[row1] : T(0);
+    }
+    if (valid) {
+        if (l < n) oU[prob * (int64_t)n + l] = ok ? xsol : T(0);
+        if (olam) {
+            if (isc0) olam[prob * (int64_t)m + row0] = lo0;
+            if (isc1) olam[prob * (int64_t)m + row1] = lo1;
+        }
+        if (l == 0) {
+            if (ostatus) ostatus[prob] = status;
+            if (oiters) oiters[prob] = iters;
+        }
+    }
+}
+
+// ------------------------------------------------------------ host side
+// true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from 2.25
+// problems per SIMD -- below that a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.1 against 20.6 us) -- to 16
+// per SIMD -- config 2: 4096 problems 22.5 against 24.8 us, 8192: 41.1 / 47.3, 16,384: 77.2 / 85.6; config 4: 4096: 29.7 / 33.9,
+// 8192: 53.2 / 56.6, 16,384: 91.9 / 91.0, 65,536: 324 / 305 (this kernel's 35.6 KB of LDS keep four wavefronts on a CU, the other's eight).
+static bool quad_pays(int64_t batch)
+{
+    static const int simds = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return 4 * cus;
+    }();
+    return 4 * batch > 9 * (int64_t)simds && batch <= 16 * (int64_t)simds;
+}
+
+bool quad_applies(const KernelArgs &ka)
+{
+    // the register-pipelined chain: terminal cost only, state rows only, two rows per step; cold launches
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || (ka.nx != 3 && ka.nx != 4)) return false;
+    if (!(ka.mk == MK && ka.C.ptr && !ka.D.ptr && !(ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE)))) return false;
+    if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
+    if (ka.warm_state || (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED)) return false;
+    return true;
+}
+
+bool quad_eligible(const KernelArgs &ka, int64_t batch)
+{
+    if (!quad_applies(ka) || (ka.opt_flags & MPCQP_OPT_TWO_PER_WAVE)) return false;
+    return (ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) || quad_pays(batch);
+}
+
+template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    const int64_t waves = (batch + 3) / 4;
+    auto go = [&](auto kern, int wpb) {
+        const size_t bytes = (size_t)PER * 4 * sizeof(double) * wpb;
+        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
+                           (const double *)ka.C.ptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
+                           (const double *)ka.goal.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, batch);
+    };
+#ifndef QUAD_WPB
+#define QUAD_WPB 1
+#endif
+    if (ka.order)
+        go(mpcqp_quad_kernel<NX, true, 1>, 1);
+    else
+        go(mpcqp_quad_kernel<NX, false, QUAD_WPB>, QUAD_WPB);
+    return (int)hipGetLastError();
+}
+
+int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    return ka.nx == 3 ? launch_quad_t<3>(ka, batch, st) : launch_quad_t<4>(ka, batch, st);
+}
+
+}  // namespace mpcqp

@@ -666,8 +666,10 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                             }
                         }
                     }
+                    const T slp = sl[rowp];  // (read BEFORE the reduction's barriers: the slack pass below rewrites it, and without the
+                                             // LDS staging -- nq > LQ -- no barrier separates that pass from a late wavefront's read)
                     block_argmin(t1, l, redv, redi, tid);
-                    const T t2 = can_move ? -sl[rowp] / d2 : INF;
+                    const T t2 = can_move ? -slp / d2 : INF;
                     const T t = t1 < t2 ? t1 : t2;
                     if (!(t < INF)) {
                         if (!rescued && nq > 0) {  // before the verdict: the same trip once more on a W rebuilt from scratch

@@ -1060,7 +1060,12 @@ __global__ void __launch_bounds__(64)
                 for (int u = 0; u < TU; ++u) {
                     const int i = i0 + 64 * u;
                     const T sc = sv[u] * iv[u];
-                    if (i < M && sv[u] < -th[u] && i != bi) {
+                    bool dup = false;  // a warm row that is violated as well must not take a second sweep slot
+                    if (jstart > 1) {  // (wave-uniform; only the launch's first selections carry warm rows)
+#pragma unroll
+                        for (int j = 1; j < R; ++j) dup = dup || (j < jstart && rows[j] == i);
+                    }
+                    if (i < M && sv[u] < -th[u] && i != bi && !dup) {
                         if (sc < b1) {
                             b2 = b1;
                             i2 = i1;

@@ -86,30 +86,29 @@ def test_order_is_refused_where_no_kernel_takes_it():
         solve_mpc_batch(bp, order=order[:32].contiguous())
 
 
-def test_walking_loops_repaired_every_period_walk_the_same_way():
-    """examples/lipm_walking_controller.py:307-335 for 3000 walkers, 40 periods: re-pairing by last period's counts (in place,
-    behind the launch that still reads the old order) must leave every trajectory where it was, to rounding."""
+def test_walking_loop_launches_take_an_order_set_from_outside():
+    """examples/lipm_walking_controller.py:307-335 for 3000 walkers, 40 periods: the loop's prepared solve re-paired by last
+    period's counts (in place, behind the launch that still reads the old order) must leave every trajectory where it was, to
+    rounding -- for the per-problem build and for the model factored once (mpcqp_solve_model_bounds_batch takes the order too)."""
+    from qpmpc_amd import pairing_order
     from qpmpc_amd.closed_loop import LIPMWalkingLoop
 
     rng = np.random.default_rng(3)
     B = 3000
     kw = dict(strides=np.stack([-rng.uniform(0.12, 0.2, B), rng.uniform(0.12, 0.2, B)], axis=1),
               foot_size=rng.uniform(0.05, 0.08, B), index=rng.integers(0, 8, B))
-    ref, got = LIPMWalkingLoop(B, **kw), LIPMWalkingLoop(B, pair_every=1, **kw)
-    ref.step(40)
-    got.step(40)
-    torch.cuda.synchronize()
-    assert ref.stats()["failed"] == got.stats()["failed"] and ref.stats()["mean_iters"] == got.stats()["mean_iters"]
-    assert float((ref.states - got.states).abs().max()) <= 1e-9
-    assert torch.equal(ref.index, got.index)
-    with pytest.raises(ValueError):
-        LIPMWalkingLoop(8, pair_every=1, warm_start=True)
-    # the same with the model factored once (mpcqp_solve_model_bounds_batch takes the order too)
-    refm, gotm = LIPMWalkingLoop(B, shared_model=True, **kw), LIPMWalkingLoop(B, shared_model=True, pair_every=2, **kw)
-    refm.step(40)
-    gotm.step(40)
-    torch.cuda.synchronize()
-    assert refm.stats() == gotm.stats() and float((refm.states - gotm.states).abs().max()) <= 1e-9
+    for shared in (False, True):
+        ref, got = LIPMWalkingLoop(B, shared_model=shared, **kw), LIPMWalkingLoop(B, shared_model=shared, **kw)
+        ref.step(40)
+        order = torch.empty_like(got.solver.iters)
+        for _ in range(40):
+            got.step(1)
+            pairing_order(got.solver.iters, out=order)  # (after the launch that reads the old order, in stream order)
+            got.solver.set_order(order)
+        torch.cuda.synchronize()
+        assert ref.stats()["failed"] == got.stats()["failed"] and ref.stats()["mean_iters"] == got.stats()["mean_iters"]
+        assert float((ref.states - got.states).abs().max()) <= 1e-9
+        assert torch.equal(ref.index, got.index)
 
 
 def test_shared_model_solve_takes_the_order():
@@ -130,36 +129,6 @@ def test_shared_model_solve_takes_the_order():
     assert torch.equal(run.status, st0) and torch.equal(run.iters, it0)
     scale = U0[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
     assert float(((run.U[ok] - U0[ok]).abs() / scale).max()) <= 1e-8
-
-
-def test_predicted_order_for_a_one_shot_shared_model_sweep():
-    """No previous period: mpcqp_model_predict_counts orders the sweep by the rows violated at the unconstrained minimiser. Same
-    results; and the order must be worth having -- the wavefronts' summed trips max(iters_a, iters_b), evaluated on the real
-    iteration counts, fall by more than 8 % against the natural order (offline estimate on the oracle's counts: 15 %)."""
-    from qpmpc_amd import SharedModel
-    from qpmpc_amd import workloads as W
-
-    bp = W.to_batch_problem(W.humanoid_batch(8192, seed=2))
-    run = SharedModel(bp).prepare(bp)
-    run.launch()
-    torch.cuda.synchronize()
-    U0, st0, it0 = run.U.clone(), run.status.clone(), run.iters.clone()
-    run.predict_order()
-    run.launch()
-    torch.cuda.synchronize()
-    assert torch.equal(run.status, st0) and torch.equal(run.iters, it0)
-    ok = st0 == 0
-    scale = U0[ok].abs().amax(dim=1, keepdim=True).clamp(min=1.0)
-    assert float(((run.U[ok] - U0[ok]).abs() / scale).max()) <= 1e-8
-    order = run._pred[1].cpu().numpy().astype(np.int64)
-    assert np.array_equal(np.sort(order), np.arange(8192))
-    it = it0.cpu().numpy()
-
-    def trips(o):
-        v = it[o]
-        return int(np.maximum(v[0::2], v[1::2]).sum())
-
-    assert trips(order) <= 0.92 * trips(np.arange(8192)), (trips(order), trips(np.arange(8192)))
 
 
 @pytest.mark.parametrize("nx,nu,N,mk,with_c,with_d,wx", [

@@ -814,18 +814,21 @@ def test_batch_size_edges_wavefront_kernel(batch):
     assert (status == 0).all() and err <= 1e-8
 
 
-def test_large_batch_sweep_shared_operands():
+@pytest.mark.parametrize("per_wave", ["two", "four"])
+def test_large_batch_sweep_shared_operands(per_wave):
     """262,144 problems in one launch (config-4 family, stride-0 operands): every item equals the
-    item of a 4096-batch with the same state (no cross-talk, no grid-size limit)."""
-    from qpmpc_amd import solve_mpc_batch
+    item of a 4096-batch with the same state (no cross-talk, no grid-size limit), for both small-problem fused kernels
+    (the dispatch would take the four-per-wavefront one at 4096 and the two-per-wavefront one at 262,144)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
     from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
 
     small = humanoid_batch(4096)
     big = dict(small)
     reps = 64
     big["x0"] = np.tile(small["x0"], (reps, 1))
-    a = solve_mpc_batch(to_batch_problem(small))
-    b = solve_mpc_batch(to_batch_problem(big))
+    fl = _capi.OPT_TWO_PER_WAVE if per_wave == "two" else _capi.OPT_FOUR_PER_WAVE
+    a = solve_mpc_batch(to_batch_problem(small), flags=fl)
+    b = solve_mpc_batch(to_batch_problem(big), flags=fl)
     torch.cuda.synchronize()
     Ua, Ub = a.U.cpu().numpy(), b.U.cpu().numpy().reshape(reps, 4096, -1)
     sa, sb = a.status.cpu().numpy(), b.status.cpu().numpy().reshape(reps, 4096)
@@ -1355,15 +1358,16 @@ def test_exactly_full_launch_of_the_pair_kernel_equals_the_other_launch_shapes()
     wavefronts. Same kernel body, same problem -> wavefront half mapping: the full launch must give bit for bit what the same
     problems give in a launch one problem longer (two rounds, single wavefronts) and in a half-size one, with multipliers, for
     the per-problem build and for the shared model."""
-    from qpmpc_amd import SharedModel, solve_mpc_batch
+    from qpmpc_amd import SharedModel, _capi, solve_mpc_batch
     from qpmpc_amd import workloads as W
 
     full = 16 * torch.cuda.get_device_properties(0).multi_processor_count
     w = W.triple_integrator_batch(full + 1)
     cut = lambda n: {k: (v[:n] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == full + 1 else v) for k, v in w.items()}
-    longer = solve_mpc_batch(W.to_batch_problem(w), return_multipliers=True)
-    exact = solve_mpc_batch(W.to_batch_problem(cut(full)), return_multipliers=True)
-    half = solve_mpc_batch(W.to_batch_problem(cut(full // 2)), return_multipliers=True)
+    two = _capi.OPT_TWO_PER_WAVE  # (at these sizes the dispatch would take the four-per-wavefront kernel for the lean family)
+    longer = solve_mpc_batch(W.to_batch_problem(w), return_multipliers=True, flags=two)
+    exact = solve_mpc_batch(W.to_batch_problem(cut(full)), return_multipliers=True, flags=two)
+    half = solve_mpc_batch(W.to_batch_problem(cut(full // 2)), return_multipliers=True, flags=two)
     torch.cuda.synchronize()
     assert torch.equal(exact.status, longer.status[:full]) and torch.equal(exact.iters, longer.iters[:full])
     assert torch.equal(exact.U, longer.U[:full]) and torch.equal(exact.multipliers, longer.multipliers[:full])

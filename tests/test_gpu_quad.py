@@ -1,0 +1,175 @@
+"""GPU tests (-m gpu): the four-problems-per-wavefront kernel (csrc/mpcqp_quad.hip) -- the cold fused build+solve of problems with
+terminal cost only and two state rows per step (BASELINE configs 1, 2, 4), replacing qpmpc/mpc_qp.py:53-149 and the
+qpsolvers call at qpmpc/solve_mpc.py:43 like the two-per-wavefront kernel it is dispatched next to. The dispatch takes it by
+batch size (2305 .. 16,384 problems on an MI355X); MPCQP_OPT_FOUR_PER_WAVE forces it, MPCQP_OPT_TWO_PER_WAVE keeps the other.
+
+Tolerances (float64): plans |u - u_ref|_inf <= 1e-7 max(1, |u_ref|_inf) against the C oracle (BASELINE.json: 1e-6), observed
+~1e-12; statuses equal; iteration counts equal to the two-per-wavefront kernel's (same method, same pivots)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TOOLS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+if TOOLS not in sys.path:
+    sys.path.insert(0, TOOLS)
+
+
+def _lean_family(rng, batch, nx, nu, N, tight, lti):
+    from stress_stagewise import random_ltv
+
+    w = random_ltv(rng, batch, nx, nu, N, 2, tight)
+    w["wx"] = w["targets"] = w["D"] = None
+    if lti:  # time-invariant A, C (stride 0 along the horizon)
+        w["A"] = np.ascontiguousarray(w["A"][:, :1])
+        w["C"] = np.ascontiguousarray(w["C"][:, :1])
+    return w
+
+
+def _check_against_oracle(w, plan, tol=1e-7):
+    U, st = plan.U.cpu().numpy(), plan.status.cpu().numpy()
+    Uo, lamo, sto, _ = oracle.solve_workload(w)
+    assert np.array_equal(st == 0, sto == 0), np.flatnonzero((st == 0) != (sto == 0))
+    ok = sto == 0
+    if ok.any():
+        scale = np.maximum(1.0, np.abs(Uo[ok]).max(axis=1, keepdims=True))
+        assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= tol
+    assert not np.isnan(U).any() and (U[~ok] == 0).all()  # (no plan: zeros, never NaN)
+    return ok
+
+
+def test_config2_at_the_benchmarked_size_takes_the_kernel_and_matches_the_oracle():
+    """4096 heterogeneous triple-integrator problems (BASELINE config 2): the default dispatch (four per wavefront at this size),
+    the forced one and the two-per-wavefront kernel give the oracle's plans, and each other's iteration counts."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    w = W.triple_integrator_batch(4096)
+    bp = W.to_batch_problem(w)
+    auto = solve_mpc_batch(bp, return_multipliers=True)
+    four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE, return_multipliers=True)
+    two = solve_mpc_batch(bp, flags=_capi.OPT_TWO_PER_WAVE, return_multipliers=True)
+    torch.cuda.synchronize()
+    assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters)  # (the same kernel ran)
+    assert torch.equal(four.status, two.status) and torch.equal(four.iters, two.iters)
+    assert float((four.U - two.U).abs().max()) <= 1e-9
+    assert float((four.multipliers - two.multipliers).abs().max()) <= 1e-9 * max(1.0, float(two.multipliers.abs().max()))
+    ok = _check_against_oracle(w, four, tol=1e-8)
+    assert ok.all()
+
+
+def test_config4_share_of_one_gpu_matches_the_oracle():
+    """8192 humanoid problems (BASELINE config 4's share of one of eight GPUs, examples/humanoid_one_step.py:42-80 with the sweep's
+    states): default dispatch = this kernel; statuses and plans against the oracle."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    w = W.humanoid_batch(8192, seed=2)
+    bp = W.to_batch_problem(w)
+    auto = solve_mpc_batch(bp)
+    four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+    torch.cuda.synchronize()
+    assert torch.equal(auto.U, four.U)
+    ok = _check_against_oracle(w, four, tol=1e-7)
+    assert ok.sum() > 6000 and set(np.unique(four.status.cpu().numpy())) <= {0, 2}  # (a state no plan exists for: status 2, zeros)
+
+
+@pytest.mark.parametrize("nx,nu", [(3, 1), (4, 1), (3, 2), (4, 2)])
+def test_every_horizon_and_tightness_against_the_oracle(nx, nu):
+    """Random LTV families over the kernel's envelope -- every horizon N = 2 .. 16 / nu (rows 16 .. 2 N - 1 sit in the lanes'
+    second register row: N = 9 .. 15 leaves that row partly empty), loose to very tight bounds (partial steps, drops), A and C per
+    step or time-invariant --: statuses and plans against the oracle, iteration counts against the two-per-wavefront kernel."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(100 * nx + nu)
+    drops = 0
+    for N in range(2, 16 // nu + 1):
+        for tight, lti in ((3.0, False), (0.2, True), (0.05, False), (0.05, True)):
+            w = _lean_family(rng, 61, nx, nu, N, tight, lti)  # (an odd batch: the last wavefront holds one problem)
+            bp = W.to_batch_problem(w)
+            four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+            two = solve_mpc_batch(bp, flags=_capi.OPT_TWO_PER_WAVE)
+            torch.cuda.synchronize()
+            ok = _check_against_oracle(w, four)
+            same = (four.iters == two.iters).cpu().numpy()[ok]
+            assert same.mean() >= 0.95, (N, tight, lti, same.mean())  # (ties between rows may break differently: rare)
+            drops += int((four.iters.cpu().numpy()[ok] > N * nu).sum())
+    assert drops > 0  # the partial-step / drop path really ran
+
+
+def test_inconsistent_rows_are_never_reported_solved():
+    """Problems whose rows are inconsistent with their bounds (generated consistent, then A and C replaced by their first step):
+    the kernel's statuses are the oracle's, and what it reports solved is the oracle's plan (qpsolvers reports found=False for the
+    others, qpmpc/plan.py:35-40)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(99)
+    unsolved = 0
+    for _ in range(16):
+        nx, N = int(rng.choice([3, 4])), int(rng.integers(4, 16))
+        w = _lean_family(rng, 128, nx, 1, N, float(rng.choice([0.05, 0.2])), True)
+        ok = _check_against_oracle(w, solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE), tol=1e-6)
+        unsolved += int((~ok).sum())
+    assert unsolved > 50
+
+
+def test_small_and_ragged_batches_and_a_pairing_order():
+    """Batches of 1, 2, 3, 5 and 4097 problems (idle rows of the last wavefront repeat its last problem and store nothing), and a
+    launch with MpcqpSolveOpts.order (row i of the launch takes problem order[i]; outputs stay indexed by problem)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    for batch in (1, 2, 3, 5, 4097):
+        w = W.triple_integrator_batch(batch, seed=batch)
+        plan = solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE)
+        torch.cuda.synchronize()
+        assert _check_against_oracle(w, plan, tol=1e-8).all()
+    w = W.humanoid_batch(1001, seed=4)
+    bp = W.to_batch_problem(w)
+    ref = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+    order = torch.randperm(1001, device="cuda").to(torch.int32)
+    got = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE, order=order)
+    torch.cuda.synchronize()
+    # (bit for bit: a row's arithmetic does not depend on which problems share its wavefront)
+    assert torch.equal(ref.status, got.status) and torch.equal(ref.iters, got.iters) and torch.equal(ref.U, got.U)
+
+
+def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
+    """MPCQP_OPT_FOUR_PER_WAVE with a stage cost, with input rows, with a warm state or next to another override:
+    MPCQP_EUNSUPPORTED before any launch."""
+    from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from stress_stagewise import random_ltv
+
+    rng = np.random.default_rng(1)
+    w = random_ltv(rng, 8, 3, 1, 8, 2, 1.0)  # stage cost, C and D
+    with pytest.raises(BackendError, match="-6"):
+        solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE)
+    w = W.triple_integrator_batch(8)
+    bp = W.to_batch_problem(w)
+    with pytest.raises(BackendError, match="-6"):
+        solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE | _capi.OPT_TWO_PER_WAVE)
+    with pytest.raises(BackendError, match="-6"):
+        solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE, warm_state=WarmState(bp))
+    wide = random_ltv(rng, 8, 6, 2, 10, 2, 1.0)  # another kernel's dimensions
+    with pytest.raises(BackendError, match="-6"):
+        solve_mpc_batch(W.to_batch_problem(wide), flags=_capi.OPT_FOUR_PER_WAVE)
+
+
+def test_stress_campaign_with_drops():
+    """tools/stress_pair.py's lean rounds forced through this kernel: statuses equal to the C oracle's and to the one-per-wavefront
+    and workgroup kernels', plans within 1e-7 relative."""
+    from stress_pair import run
+
+    worst, flagged, drops = run(24, 96, seed=20260930, verbose=False, lean_only=True, flags_lean=4096)
+    assert flagged == 0, (worst, flagged)
+    assert worst < 1e-7 and drops > 0

@@ -280,7 +280,7 @@ def test_hand_written_dpp_instructions_keep_their_wait_states():
     bad, _, _ = chk.check("f:\n\tv_add_f64 v[0:1], v[2:3], v[4:5]\n\ts_nop 1\n\tv_fmac_f64_dpp v[6:7], v[0:1], v[8:9] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
     assert not bad
     # (mpcqp_stage.hip: the serial sweeps of the narrow stage-wise kernel use the same instruction since round 4)
-    for unit in ("mpcqp_pair.hip", "mpcqp_stage.hip"):
+    for unit in ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_stage.hip"):
         src = os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", unit)
         bad, ndpp, nasm = chk.check(chk.device_asm(src))
         assert nasm > 1000 and not bad, (unit, bad[:3])

@@ -10,8 +10,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 rng = np.random.default_rng(1)
 strides = np.stack([-rng.uniform(0.12, 0.2, B), rng.uniform(0.12, 0.2, B)], axis=1)
 shared = len(sys.argv) > 3 and sys.argv[3] == "shared"  # matrices factored once, bounds per period
-pair = int(sys.argv[3][4:]) if len(sys.argv) > 3 and sys.argv[3].startswith("pair") else 0  # pairK: re-paired every K periods by last period's counts
-loop = LIPMWalkingLoop(B, strides=strides, foot_size=rng.uniform(0.05, 0.08, B), index=rng.integers(0, 8, B), shared_model=shared, pair_every=pair)
+loop = LIPMWalkingLoop(B, strides=strides, foot_size=rng.uniform(0.05, 0.08, B), index=rng.integers(0, 8, B), shared_model=shared)
 loop.step(5); torch.cuda.synchronize()
 t0 = time.perf_counter(); loop.step(steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 s = loop.stats()

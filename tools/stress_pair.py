@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from stress_stagewise import random_ltv  # noqa
 
 
-def run(rounds, batch, seed=4242, verbose=True):
+def run(rounds, batch, seed=4242, verbose=True, lean_only=False, flags_lean=0):
+    """lean_only: every round draws the lean family; flags_lean: MpcqpSolveOpts.flags for those rounds (MPCQP_OPT_FOUR_PER_WAVE forces
+    the four-per-wavefront kernel, which the dispatch would only take for thousands of problems)."""
     rng = np.random.default_rng(seed)
     worst, bad, drops = 0.0, 0, 0
     for it in range(rounds):
@@ -24,7 +26,7 @@ def run(rounds, batch, seed=4242, verbose=True):
         mk = int(rng.integers(1, min(4, 32 // N) + 1))
         tight = float(rng.choice([0.05, 0.2, 1.0, 3.0]))
         w = random_ltv(rng, batch, nx, nu, N, mk, tight)
-        mode = int(rng.integers(0, 4))
+        mode = 3 if lean_only else int(rng.integers(0, 4))
         if mode == 3:  # the lean instantiations <NX, 2>: terminal cost only, state rows only, two rows per step
             mk = 2
             N = min(N, 16)
@@ -41,7 +43,8 @@ def run(rounds, batch, seed=4242, verbose=True):
         if mode == 1 and rng.random() < 0.5:  # state rows only
             w["D"] = None
         bp = W.to_batch_problem(w)
-        plan = solve_mpc_batch(bp, flags=_capi.OPT_SEED_VIOLATED if os.environ.get("STRESS_SEEDED") else 0)  # (STRESS_SEEDED: the seeded start)
+        fl = _capi.OPT_SEED_VIOLATED if os.environ.get("STRESS_SEEDED") else (flags_lean if mode == 3 else 0)  # (STRESS_SEEDED: the seeded start)
+        plan = solve_mpc_batch(bp, flags=fl)
         one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
         lds = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
         torch.cuda.synchronize()
@@ -84,5 +87,6 @@ def run(rounds, batch, seed=4242, verbose=True):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    worst, bad, drops = run(rounds, batch, seed=int(os.environ.get("STRESS_SEED", "4242")))
+    worst, bad, drops = run(rounds, batch, seed=int(os.environ.get("STRESS_SEED", "4242")), lean_only=bool(os.environ.get("STRESS_LEAN")),
+                            flags_lean=_capi.OPT_FOUR_PER_WAVE if os.environ.get("STRESS_FOUR") else 0)
     print("worst rel diff", worst, "rounds flagged", bad, "problems with more trips than variables", drops)
