@@ -49,7 +49,7 @@ CONFIGS = {
     3: dict(batch=1024, scaling="weak", dtype="f64",
             workload="{b} wheeled-inverted-pendulum receding-horizon loops, N=50 T=0.024 s (nx=4 nu=1, n=50 m=100), LTV "
                      "lists, fp64; one step = one MPC period: fused build+solve rebuilt every step (the factor by a second "
-                     "wavefront one period ahead) + plant (15 sub-steps); up to 20 consecutive periods per launch"),
+                     "wavefront one period ahead) + plant (15 sub-steps); up to %d consecutive periods per launch" % PERIODS_PER_LAUNCH),
     4: dict(batch=65536, scaling="strong", dtype="f64",
             workload="humanoid one-step (LIPM) N=16 (n=16 m=32), {b}-state sweep strong-sharded over the GPUs, fp64, "
                      "fused build+solve; U/status all_gather timed separately"),
@@ -230,8 +230,13 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
         for _ in range(20):
             run.launch()
         clock.sync()
-    for _ in range(args.warmup):
-        run.launch()
+    # the W warm-up steps go through the same region code as the timed ones (events recorded around them, full
+    # synchronisation behind them): the timed region then meets no first-use cost of the event and synchronisation paths
+    if args.warmup > 0 and getattr(run, "launch_steps", None) is None:
+        clock.time(run.launch, args.warmup)
+    else:
+        for _ in range(args.warmup):
+            run.launch()
     clock.sync()
     barrier()
     # A real barrier (RCCL) keeps the host busy for a few hundred microseconds during which the GPU idles and its clocks
@@ -334,10 +339,46 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
                 out["other_workloads"] = other_workloads()
             except Exception as exc:  # never at the expense of the headline line
                 out["other_workloads"] = {"error": repr(exc)}
+            try:
+                out["predicted_strong_scaling"] = predicted_strong_scaling()
+            except Exception as exc:
+                out["predicted_strong_scaling"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config, w, args.cpu_seconds)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
             out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["all_cores_value"]
+    return out
+
+
+def predicted_strong_scaling():
+    """No 8-GPU node was available to this build: what one GPU measures at the per-GPU SHARE of the strong-split configurations
+    (config 4: 65,536 / 8 = 8192 problems; config 5: 8192 / 8 = 1024), against the full batch on one GPU. The ranks share nothing
+    on the data path (qpmpc_amd/distributed.py), so rate(share) x 8 is what eight GPUs deliver before the all_gather, and
+    rate(share) / rate(full) is the predicted strong-scaling efficiency. A PREDICTION from one GPU, not a measured curve."""
+    import torch
+
+    from qpmpc_amd import PreparedSolve
+    from qpmpc_amd import workloads as W
+
+    def rate(launch, problems, steps):
+        for _ in range(max(3, steps // 4)):
+            launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            launch()
+        torch.cuda.synchronize()
+        return problems * steps / (time.perf_counter() - t0)
+
+    out = {"note": "single-GPU rates at the per-GPU share of an 8-way strong split vs the full batch; efficiency = share rate / "
+                   "full rate; x8 = the eight-GPU aggregate this predicts (no data-path collective)"}
+    for name, make, full, steps in (("config4_humanoid", lambda b: W.to_batch_problem(W.humanoid_batch(b)), 65536, 40),
+                                    ("config5_synthetic_ltv_f32", lambda b: W.to_batch_problem(W.synthetic_ltv_batch(b), dtype=torch.float32), 8192, 5)):
+        share = full // 8
+        r_full = rate(PreparedSolve(make(full)).launch, full, steps)
+        r_share = rate(PreparedSolve(make(share)).launch, share, steps * 4)
+        out[name] = {"full_batch": full, "share_per_gpu": share, "rate_full_1gpu": r_full, "rate_share_1gpu": r_share,
+                     "predicted_efficiency_8gpu": r_share / r_full, "predicted_rate_8gpu": 8 * r_share}
     return out
 
 
@@ -420,9 +461,9 @@ def _traffic_from_profiles(config: int):
     """(HBM bytes per launch, source) from the rocprofv3 PMC passes stored under profiles/ for this round's kernels
     (separate --pmc runs of this same command: tools/collect_profiles.sh; FETCH_SIZE doubled as the microarchitecture
     guide prescribes for gfx950, WRITE_SIZE as reported). Newest round first; (None, None) when there is none."""
-    names = [f"r04_pmc_traffic_config{config}.json", f"r03_pmc_traffic_config{config}.json", f"r02_pmc_traffic_config{config}.json"]
+    names = [f"r0{r}_pmc_traffic_config{config}.json" for r in (5, 4, 3, 2)]
     if config == 2:
-        names += ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]
+        names = ["r05_pmc_traffic.json"] + names + ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
@@ -433,6 +474,17 @@ def _traffic_from_profiles(config: int):
                                                           "correction) + WRITE_SIZE per launch of the dominant kernel, collected "
                                                           "in separate counter passes of this command (not by this run)")
     return None, None
+
+
+def _small_kernel_name(problems: int) -> str:
+    """Which small-problem fused kernel a cold launch of `problems` lean problems gets (csrc/mpcqp_quad.hip, quad_pays: four per
+    wavefront between 2.25 and 16 problems per SIMD of the device) -- for the report only; the library decides."""
+    import torch
+
+    simds = 4 * torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    if 4 * problems > 9 * simds and problems <= 16 * simds:
+        return "mpcqp_quad_kernel<3> (fused build+solve, FOUR problems per wavefront, one per 16-lane DPP row)"
+    return "mpcqp_pair_kernel<3, 2> (fused build+solve, two problems per wavefront)"
 
 
 def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
@@ -460,7 +512,7 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
         common["traffic_over_algorithmic"] = common["traffic"] / (bytes_pp * local_per_step)
     if args.config in (2, 4):
         return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "kernel": "mpcqp_pair_kernel (fused build+solve, two problems per wavefront)",
+                "kernel": _small_kernel_name(local_per_step),
                 "achieved_tflops_f64": tfs, **common,
                 "note": "nominally HBM-bound (4 flop/B) but a launch moves only ~11 MB: the serial active-set chain of "
                         "each wavefront (instruction issue + dependent latency) sets the time, not HBM or FP64 throughput"}
@@ -562,7 +614,7 @@ def _accuracy(args, w, run):
 
     import oracle
 
-    lim = {2: None, 3: 64, 4: 4096, 5: 4}[args.config]
+    lim = {2: None, 3: 64, 4: 4096, 5: 64}[args.config]
     U = run.U.double().cpu().numpy()
     st = run.status.cpu().numpy()
     if args.config == 3:  # the loop has moved on: compare the LAST solved problems through the oracle
@@ -577,7 +629,15 @@ def _accuracy(args, w, run):
 
         torch.cuda.synchronize()
         U, st, w = run.U.cpu().numpy(), run.status.cpu().numpy(), ws
-    Uo, _, sto, _ = oracle.solve_workload(w, count=lim)
+    if args.config == 5:  # (seconds per problem on one core: the sample's problems go to the host cores, one shard each)
+        from oracle.parallel import solve_workload_parallel
+        from qpmpc_amd.distributed import shard_workload
+
+        batch = int(w["x0"].shape[0])
+        ws = shard_workload(w, 0, max(1, batch // lim)) if batch > lim else w
+        Uo, _, sto, _ = solve_workload_parallel(ws, shard_workload)
+    else:
+        Uo, _, sto, _ = oracle.solve_workload(w, count=lim)
     k = Uo.shape[0]
     ok = (sto == 0) & (st[:k] == 0)
     err = np.abs(U[:k][ok] - Uo[ok])
