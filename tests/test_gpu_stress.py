@@ -51,6 +51,23 @@ def test_stress_campaign(tool, args, seed, bound):
     assert worst <= bound, (tool, seed, worst)
 
 
+# Known failures of the general stage-wise kernel (17 <= nx <= 32 or nu > 4: the only kernel of those dimensions) on nearly fully
+# active problems, kept IN the suite so that it says what is broken (profiles/r04_stress_summary.txt): the active-set operator
+# W = (G_A P^-1 G_A')^-1 is an explicit inverse kept by rank-one updates, and once the active rows' Gram matrix is ill
+# conditioned |z|^2 = g_p V_p - c' W c loses its digits -- one plan 3.3e-6 off (stress_general seed 7), one or two problems per
+# campaign ending MPCQP_MAX_ITER where the oracle solves them (stress_tight general seeds 2, 3, 8). strict: a fix turns these red.
+@pytest.mark.parametrize("tool,args,seed,bound", [
+    pytest.param("stress_general.py", (12, 8), 7, 1e-7, marks=pytest.mark.xfail(strict=True, reason="plan 3.3e-6 off: W by rank-one updates")),
+    pytest.param("stress_tight.py", ("general", 8, 8), 2, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
+    pytest.param("stress_tight.py", ("general", 8, 8), 3, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
+    pytest.param("stress_tight.py", ("general", 8, 8), 8, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
+])
+def test_stress_campaign_known_failures_of_the_general_kernel(tool, args, seed, bound):
+    worst, nflag, flagged = _campaign(tool, args, seed)
+    assert nflag == 0, "\n".join(flagged)
+    assert worst <= bound, (tool, seed, worst)
+
+
 def test_stress_campaign_inconsistent_rows():
     """Rows made inconsistent with their bounds (infeasible and borderline problems): statuses must follow the oracle's.
     (On a few solvable-but-degenerate problems of this family ALL formulations, oracle included, only agree to 1e-3 in u --
