@@ -358,9 +358,11 @@ bool promote_f32(const KernelArgs &ka, int dtype)
     constexpr int kPromoteN = 160;
     if (use_stagew_auto(ka, MPCQP_F32)) return ka.n <= kPromoteN && use_stagew_auto(ka, MPCQP_F64);
     if (!fits_on_chip(ka, true, true, MODE_FUSED, MPCQP_F32) && !use_mid(ka, MPCQP_F32))
-        // the dense HBM-resident fallback stays in float32; what even that path cannot hold goes to the general stage-wise
-        // kernel, which is float64 only
-        return !(big_supported(ka) && ka.n <= 256) && stageg_supported(ka, MPCQP_F64);
+        // Round 5: whatever the general stage-wise kernel serves (nx <= 32, nu <= 8; float64 only) goes there, converted -- also
+        // the float32 launches the dense HBM-resident path could hold (nx <= 16, 4 < nu <= 8, n <= 256): that path solves 330 k
+        // problems/s where the general kernel, in float64, is an order of magnitude faster (tools/probe_dense_vs_general.py). The
+        // dense solvers are left with nu > 8, MPCQP_OPT_FORCE_CONDENSED / _GWS / _DENSE_G and mpcqp_condense_batch + mpcqp_solve_batch.
+        return stageg_supported(ka, MPCQP_F64);
     // ... and the float64 dispatch must have an on-chip / stage-wise kernel for it
     return pair_eligible(ka, MODE_FUSED, MPCQP_F64) || use_stage_auto(ka, MPCQP_F64) || use_stagew_auto(ka, MPCQP_F64) ||
            use_mid(ka, MPCQP_F64) || fits_on_chip(ka, true, true, MODE_FUSED, MPCQP_F64);

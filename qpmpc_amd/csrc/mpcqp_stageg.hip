@@ -9,8 +9,22 @@
 // Same method as mpcqp_stage.hip / mpcqp_stagew.hip (oracle/stagewise_np.py restates it): Riccati factor of the LQR problem
 // whose Hessian is the condensed P (once per problem), v -> P^-1 v as one backward and one forward sweep, a row of G applied
 // to a vector as a read of that vector's trajectory, Goldfarb-Idnani's dual active set in the metric of P with
-// W = (G_A P^-1 G_A')^-1 bordered / deflated by rank-one updates; per active row the slot keeps V_a = P^-1 g_a' (inputs) and
-// h_a = G V_a (all m rows), so an iteration is one sweep pair plus AXPYs over m-long arrays.
+// a thin QR FACTORISATION of the active rows' whitened vectors (round 5; rounds 2-4 kept W = (G_A P^-1 G_A')^-1 by rank-one updates,
+// see below); per active row the slot keeps V_a = P^-1 g_a' (inputs) and h_a = G V_a (all m rows), so an iteration is one sweep pair,
+// two passes over Q, one triangular solve and AXPYs over m-long arrays.
+//
+// The active-set operator. With c = G_A V_p and d = g_p V_p the step needs r = S^-1 c and |z|^2 = d - c' S^-1 c, S = G_A P^-1 G_A'.
+// An explicit inverse W = S^-1 kept by bordering / deflation computes the latter with an error of eps cond(S) d -- near a full
+// active set, cond(S) ~ 1e10 and more, a row that can enter looks dependent (or the other way round) and the loop wanders
+// (tools/stress_general.py seed 7, tools/stress_tight.py general seeds 2, 3, 8: MAX_ITER where the oracle solves); a Cholesky
+// factor of S gets eps sqrt(cond(S)) d, still a DIFFERENCE. Goldfarb and Idnani's own form has no difference in it: with
+// P = L L', y_a = L^-1 g_a' and Y_A = Q R (Q orthonormal), |z|^2 = |y_p - Q Q' y_p|^2 is a sum of squares, good to eps^2 |y_p|^2,
+// and r = R^-1 Q' y_p. The Riccati recursion IS a block Cholesky factorisation of P, and the backward sweep already produces the
+// whitened vector: with S_k = R + B' P_{k+1} B = Ls_k Ls_k' the stage Hessians and ff_k = -S_k^-1 t_k the feed-forward terms,
+// y = (Ls_k^-1 t_k)_k = (-Ls_k' ff_k)_k and g_a P^-1 g_b' = y_a . y_b. So: Q (n x slots, explicit, in the workspace) and R (upper
+// triangular) are kept; a candidate is orthogonalised against Q twice (classical Gram-Schmidt with re-orthogonalisation), a new
+// row appends a column to R and a vector to Q, a leaving row deletes its column of R and a sweep of Givens rotations over the
+// rows of R / the vectors of Q restores the triangle. The whitened vectors Y are kept too: Q, R can be rebuilt from them.
 //
 // Written for GENERALITY first: float64 only (float32 launches are converted, mpcqp_capi.hip), one workgroup of 256 threads per
 // problem, every per-problem array in a caller-owned HBM workspace, the per-step matrices of the recursion (at most 32 x 32)
@@ -27,20 +41,11 @@
 
 #ifndef STAGEG_VPASS
 // passes of the final verification: each one re-evaluates every slack from scratch and, while an active row is off its bound,
-// corrects the multipliers by W times the residuals (a Richardson iteration preconditioned by the inexact W: two passes were
-// not enough near a full active set -- tools/stress_tight.py general, seed 8)
+// corrects the multipliers by S^-1 times the residuals (iterative refinement through the factor)
 #define STAGEG_VPASS 6
 #endif
-#ifndef STAGEG_NREF
-#define STAGEG_NREF 1 /* refinement steps of r = W c for a nearly dependent row */
-#endif
 #ifndef STAGEG_REFRESH
-// iterations between rebuilds of W, the multipliers and the slacks from scratch. 64 until the refinement of r (below) existed;
-// with it a rebuild every 64 iterations HURTS on the one nearly fully active problem of tools/stress_general.py (seed 7: the
-// rebuilt W -- Gauss-Jordan without pivoting on an ill-conditioned Gram matrix -- and the re-derived multipliers send it
-// wandering: MAX_ITER / INFEASIBLE after 1.3-3.5 k iterations), never rebuilding loses the detection of truly infeasible
-// problems (they wander to the iteration limit); at 1024 that batch comes out like the oracle's (solved in 523 iterations,
-// three infeasible ones reported) and the hyperactive test problems still pass.
+// iterations between rebuilds of the factor (from the Gram matrix the slots hold), the multipliers and the slacks from scratch
 #define STAGEG_REFRESH 1024
 #endif
 #ifndef STAGEG_DBG
@@ -53,7 +58,7 @@ namespace stageg {
 constexpr int NXM = 32, NUM = 8, BS = 256;
 
 struct Ws {  // per-problem workspace carve in doubles (host-computed, passed by value)
-    int64_t Blk, U0, ff, Xt, s0, s, invn, thr, V, H, W, lam, cv, rv, ints, total;
+    int64_t Blk, U0, ff, Xt, s0, s, invn, thr, V, H, W, Q, Y, LS, lam, cv, rv, yv, dv, ev, ints, total;
     int maxq;
 };
 
@@ -75,16 +80,22 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq)
     w.U0 = take(n);
     w.ff = take(n);
     w.Xt = take((int64_t)N * nx);  // state trajectory of the latest forward sweep (the rows of G are applied to it afterwards)
-    w.s0 = take(m);
+    w.s0 = take(2);  // (unused since round 5)
     w.s = take(m);
     w.invn = take(m);
     w.thr = take(m);
-    w.V = take((int64_t)(maxq + 1) * n);
-    w.H = take((int64_t)(maxq + 1) * m);
-    w.W = take((int64_t)maxq * maxq);
+    w.V = take((int64_t)2 * n);  // the step in the inputs z_u, a roll-out's scratch inputs
+    w.H = take((int64_t)2 * m);  // G z of the step, a roll-out's rows
+    w.W = take((int64_t)(maxq + 1) * maxq);  // R (upper triangular) by rows: row j = basis vector j, column b = slot b
+    w.Q = take((int64_t)(maxq + 1) * n);     // Q by vectors: vector j at j n (vector nq: the candidate's projection)
+    w.Y = take(n);                           // the candidate's whitened vector y_p = L^-1 g_p'
+    w.LS = take((int64_t)N * nu * nu);       // Cholesky factors of the stage Hessians S_k (the recursion)
     w.lam = take(maxq + 1);
     w.cv = take(maxq + 1);
     w.rv = take(maxq + 1);
+    w.yv = take(maxq + 1);  // vectors of the triangular solves when the slots outgrow their LDS copies
+    w.dv = take(maxq + 1);
+    w.ev = take(maxq + 1);
     w.ints = take((m + 2 * (maxq + 2)) / 2 + 2);  // int32: pos[m], actrow[maxq + 1], phys[maxq + 1]
     w.total = (o + 15) & ~(int64_t)15;
     w.maxq = maxq;
@@ -156,6 +167,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
     __shared__ T rvl[LQ];
     __shared__ int physl[LQ];
     __shared__ int redi[BS / 64], flag;
+    __shared__ T yl_s[LQ], dl_s[LQ], el_s[LQ], cs_s[4];  // d = Q' y, 1 / R_jj, the re-orthogonalisation's correction, a rotation's (c, s)
     const int tid = threadIdx.x;
     const int64_t prob = blockIdx.x;
     const int nx = ka.nx, nu = ka.nu, N = ka.N, mk = ka.mk, maxq = wl.maxq;
@@ -165,6 +177,11 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
     T *Blk = ws + wl.Blk, *U0 = ws + wl.U0, *ffv = ws + wl.ff, *Xt = ws + wl.Xt, *s0 = ws + wl.s0, *sl = ws + wl.s;
     T *invn = ws + wl.invn, *thr = ws + wl.thr, *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W, *lamv = ws + wl.lam;
     T *cv = ws + wl.cv, *rv = ws + wl.rv;
+    T *Rm = Wm, *Qs = ws + wl.Q, *Ys = ws + wl.Y;  // Y_A = Q R: R by rows (row j at j maxq), Q by vectors (vector j at j n)
+    // the vectors over the slots: in LDS while the launch's slots fit there, in the workspace beyond (maxq <= NRM BS)
+    constexpr int NRM = 4;  // rows / columns of R per thread: maxq <= 1024 (launch_stageg)
+    const bool vlds = maxq <= LQ;
+    T *yv = vlds ? yl_s : ws + wl.yv, *dv = vlds ? dl_s : ws + wl.dv, *ev = vlds ? el_s : ws + wl.ev, *ro = vlds ? rvl : rv;
     int *pos = (int *)(ws + wl.ints), *actrow = pos + M, *phys = actrow + maxq + 1;
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
     const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
@@ -216,6 +233,23 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
             G1[e] = acc;
         }
         bsync();
+        // Ls_k with S_k = Ls Ls' (lower, nu <= 8: one thread; whitens the feed-forward terms of the sweeps, see the header)
+        if (tid == 64) {
+            T *ls = ws + wl.LS + (int64_t)k * nu * nu;
+            for (int j = 0; j < nu; ++j) {
+                T dsum = Sm[j * nu + j];
+                for (int c2 = 0; c2 < j; ++c2) dsum -= ls[j * nu + c2] * ls[j * nu + c2];
+                const T dj = dsum > 0.0 ? sqrt(dsum) : 0.0;  // (a non-positive pivot is reported by the inversion below)
+                ls[j * nu + j] = dj;
+                const T idj = dj > 0.0 ? 1.0 / dj : 0.0;
+                for (int i = j + 1; i < nu; ++i) {
+                    T v2 = Sm[i * nu + j];
+                    for (int c2 = 0; c2 < j; ++c2) v2 -= ls[i * nu + c2] * ls[j * nu + c2];
+                    ls[i * nu + j] = v2 * idj;
+                }
+                for (int i = 0; i < j; ++i) ls[i * nu + j] = 0.0;
+            }
+        }
         // S^-1 by Gauss-Jordan on [S | I] in LDS, one thread per entry (nu <= 8; S is a Schur complement of the condensed
         // Hessian: pivots must be positive). (Round 4: it was ONE thread on a private array -- 70 us per step in scratch memory.)
         {
@@ -336,10 +370,13 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         }
         return (a0 + a1) + (a2 + a3);
     };
-    auto sweep = [&](int kp, int rp, bool tracking, const T *xstart, T *Vout, T *Hout) {
+    // part: 1 = the backward sweep only (leaves the feed-forward terms in ffv), 2 = the forward sweep + the rows of G only (takes
+    // them from ffv), 3 = both. given_u: ffv holds the INPUTS themselves (a roll-out: u = ffv, x+ = A x + B u = Acl x + B (u + K x)).
+    auto sweep = [&](int kp, int rp, bool tracking, const T *xstart, T *Vout, T *Hout, int part, bool given_u) {
         const int ktop = tracking ? N - 1 : kp;
-        for (int i = tid; i < n; i += BS)
-            if (i >= (ktop + 1) * nu) ffv[i] = 0.0;
+        if (part & 1)
+            for (int i = tid; i < n; i += BS)
+                if (i >= (ktop + 1) * nu) ffv[i] = 0.0;
         // steps kfirst, kfirst + dir, ... (RG of them, inside the horizon) into half `half` of the ring, by threads t, t + nth, ...:
         // the blocks are one contiguous run of the workspace (eight loads in flight per thread), slot sidx <-> step kfirst + dir sidx
         auto load_chunk = [&](int half, int kfirst, int dir, int t, int nth, bool fwd) {
@@ -379,9 +416,9 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         const T crl = (CrK && roleP) ? -CrK[lane] : 0.0, drl = (DrK && roleT) ? -DrK[ti] : 0.0;  // the row's own entries, by lane
         const long long tb0 = (long long)__builtin_readcyclecounter();
         bsync();
-        load_chunk(0, ktop, -1, tid, BS, false);
+        if (part & 1) load_chunk(0, ktop, -1, tid, BS, false);
         bsync();
-        for (int c = 0, kc = ktop; kc >= 0; ++c, kc -= RG) {
+        for (int c = 0, kc = ktop; (part & 1) && kc >= 0; ++c, kc -= RG) {
             if (!w0) {
                 load_chunk((c + 1) & 1, kc - RG, -1, tid - 64, BS - 64, false);
             } else {
@@ -424,6 +461,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         const long long tf0 = (long long)__builtin_readcyclecounter();
         t_bwd += tf0 - tb0;
         T xc = (roleP && xstart) ? xstart[lane] : 0.0;  // x (lane l: component l)
+        if (!(part & 2)) return;
         load_chunk(0, 0, 1, tid, BS, true);  // (the barrier above made the feed-forward terms visible)
         bsync();
         for (int c = 0, kc = 0; kc < N; ++c, kc += RG) {
@@ -440,9 +478,10 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                     const T *row = ti >= 0 ? blk + oK + tq * nx : blk + lp;
                     const int rs = ti >= 0 ? 1 : nx;
                     const T sg = ti >= 0 ? -1.0 : 1.0;
-                    T acc = sg * dot32(row, rs, xc);
-                    const T ffown = roleT ? ext[oF + tq] : 0.0;  // (input lanes: their feed-forward term; zero elsewhere)
-                    acc += ffown;
+                    const T accd = sg * dot32(row, rs, xc);  // state lanes: Acl x ; input lanes: -K x
+                    const T gu = roleT ? ext[oF + tq] : 0.0;  // (input lanes: their feed-forward term, or their input; zero elsewhere)
+                    const T ffown = given_u ? (roleT ? gu - accd : 0.0) : gu;  // the feed-forward term in effect
+                    T acc = roleT ? (given_u ? gu : accd + gu) : accd;
                     const T *brow = blk + oB + lp * nu;
                     T b0 = 0.0, b1 = 0.0;  // B ff (no branch per term: see the backward sweep)
 #pragma unroll
@@ -478,100 +517,182 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
     };
 
     int status = notpd ? (int)MPCQP_NOT_PD : (int)MPCQP_MAX_ITER, iters = 0, nq = 0;
-    // ---- W = (G_A P^-1 G_A')^-1 FROM SCRATCH: the Gram matrix of the active rows is read off the slots (its entry (a, b) is
-    //      row a's entry of h_b = G V_b) and inverted in place by Gauss-Jordan (symmetric positive definite: no pivoting).
-    //      W is otherwise only ever bordered / deflated by rank-one updates, and after several hundred of them its error
-    //      makes |z|^2 = g_p V_p - c' W c of a perfectly addable row come out negative -- the problem would be reported
-    //      infeasible (the NumPy restatement, which has no refresh, does that after 948 iterations on one of the tests'
-    //      problems). Returns false when a pivot is not positive (the active rows have become dependent).
-    auto refresh_W = [&]() -> bool {
-        for (int e = tid; e < nq * nq; e += BS) {
-            const int a = e / nq, b = e - a * nq;
-            Wm[(int64_t)a * maxq + b] = Hs[(int64_t)phys[b] * M + actrow[a]];
-        }
+    // ---- the factorisation's routines (every thread of the workgroup calls them)
+    auto load_dinv = [&](int k) {
+        for (int a2 = tid; a2 < k; a2 += BS) dv[a2] = 1.0 / Rm[(int64_t)a2 * maxq + a2];
         bsync();
-        bool good = true;
-        for (int c = 0; c < nq; ++c) {
-            const T piv = Wm[(int64_t)c * maxq + c];
-            if (!(piv > 0.0)) {
-                good = false;
-                break;
-            }
-            for (int a = tid; a < nq; a += BS) {
-                cv[a] = Wm[(int64_t)a * maxq + c];  // column c
-                rv[a] = Wm[(int64_t)c * maxq + a];  // row c
-            }
-            bsync();
-            const T ip = 1.0 / piv;
-            for (int e = tid; e < nq * nq; e += BS) {
-                const int a = e / nq, b = e - a * nq;
-                T v;
-                if (a == c)
-                    v = b == c ? ip : rv[b] * ip;
-                else if (b == c)
-                    v = -cv[a] * ip;
-                else
-                    v = Wm[(int64_t)a * maxq + b] - cv[a] * rv[b] * ip;
-                Wm[(int64_t)a * maxq + b] = v;
-            }
-            bsync();
-        }
-        return good;
     };
-    // ... and with it the multipliers lam = -W s0_A and every slack s = s0 + sum_a lam_a h_a (between two selections, where
-    // (u, A) is an S-pair: the active rows sit on their bounds)
-    auto refresh_state = [&]() -> bool {
-        if (!refresh_W()) return false;
-        for (int a = tid; a < nq; a += BS) {
-            T acc = 0.0;
-            for (int b = 0; b < nq; ++b) acc -= Wm[(int64_t)a * maxq + b] * s0[actrow[b]];
-            rv[a] = acc < 0.0 ? 0.0 : acc;
+    // r = R^-1 d for the first k slots (d in yv), into ro. Thread j owns row j: the owner of row b publishes r_b, every row above
+    // takes its entry of column b times r_b off its own sum -- one barrier per step, the next entry of the thread's own row
+    // (contiguous along the row) requested before the barrier.
+    auto solveR = [&](int k) {
+        T acc[NRM], lnx[NRM];
+        const T *lr[NRM];
+#pragma unroll
+        for (int q2 = 0; q2 < NRM; ++q2) {
+            const int j = tid + q2 * BS;
+            acc[q2] = j < k ? yv[j] : 0.0;
+            lr[q2] = Rm + (int64_t)(j < k ? j : 0) * maxq;
+            lnx[q2] = (k > 0 && j < k - 1) ? lr[q2][k - 1] : 0.0;
+        }
+        for (int b2 = k - 1; b2 >= 0; --b2) {
+            T lcur[NRM];
+#pragma unroll
+            for (int q2 = 0; q2 < NRM; ++q2) {
+                const int j = tid + q2 * BS;
+                lcur[q2] = lnx[q2];
+                if (b2 > 0 && j < b2 - 1) lnx[q2] = lr[q2][b2 - 1];
+                if (j == b2) ro[b2] = acc[q2] * dv[b2];
+            }
+            bsync();
+            const T rb = ro[b2];
+#pragma unroll
+            for (int q2 = 0; q2 < NRM; ++q2) {
+                const int j = tid + q2 * BS;
+                if (j < b2) acc[q2] -= lcur[q2] * rb;
+            }
         }
         bsync();
-        for (int a = tid; a < nq; a += BS) lamv[a] = rv[a];
+    };
+    // The candidate y (n entries) against the first k vectors of Q: d = Q' y into yv, z = y - Q d into zout, once more on z
+    // (classical Gram-Schmidt with re-orthogonalisation: the second pass's coefficients e are added to d); returns |z|^2 as the
+    // sum of z's squares. A wavefront per vector for the dot products (coalesced, DPP reduction), a thread per entry for the AXPYs.
+    auto ortho = [&](const T *y, T *zout, int k) -> T {
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int pass = 0; pass < 2; ++pass) {
+            const T *src = pass == 0 ? y : zout;
+            T *co = pass == 0 ? yv : ev;
+            for (int a2 = wv; a2 < k; a2 += BS / 64) {
+                const T *qa = Qs + (int64_t)a2 * n;
+                T part = 0.0;
+                for (int i = ln; i < n; i += 64) part += qa[i] * src[i];
+                part = wave_sum_dpp(part);
+                if (ln == 0) co[a2] = part;
+            }
+            bsync();
+            for (int i = tid; i < n; i += BS) {
+                T a0 = src[i], a1 = 0.0;
+                int a2 = 0;
+                for (; a2 + 2 <= k; a2 += 2) {
+                    a0 -= co[a2] * Qs[(int64_t)a2 * n + i];
+                    a1 -= co[a2 + 1] * Qs[(int64_t)(a2 + 1) * n + i];
+                }
+                if (a2 < k) a0 -= co[a2] * Qs[(int64_t)a2 * n + i];
+                zout[i] = a0 + a1;
+            }
+            bsync();
+        }
+        T part = 0.0;
+        for (int i = tid; i < n; i += BS) part += zout[i] * zout[i];
+        for (int a2 = tid; a2 < k; a2 += BS) yv[a2] += ev[a2];
+        return block_sum(part, redv, tid);  // (its barriers also publish d)
+    };
+    // the candidate becomes basis vector k = slot k: Q gains z / |z|, R the column [d; |z|]
+    auto append = [&](int k, T zn2) {
+        const T zn = sqrt(zn2), izn = 1.0 / zn;
+        T *qk = Qs + (int64_t)k * n;
+        for (int i = tid; i < n; i += BS) qk[i] *= izn;
+        for (int j = tid; j < k; j += BS) Rm[(int64_t)j * maxq + k] = yv[j];
+        if (tid == 0) Rm[(int64_t)k * maxq + k] = zn;
+    };
+    // slot l leaves: its column of R goes (every thread closes the gap in its own rows; the small per-slot arrays move down by
+    // one), and one Givens rotation per column behind it -- on two rows of R and two vectors of Q -- restores the triangle
+    auto drop_slot = [&](int l) {
+        const int k = nq - 1;  // slots after the drop
+        int na[NRM];
+        T nl[NRM];
+        const int rowl = actrow[l];
+#pragma unroll
+        for (int q2 = 0; q2 < NRM; ++q2) {
+            const int j = tid + q2 * BS;
+            na[q2] = 0;
+            nl[q2] = 0.0;
+            if (j < nq) {
+                T *row = Rm + (int64_t)j * maxq;
+                for (int b2 = (j > l ? j - 1 : l); b2 < k; ++b2) row[b2] = row[b2 + 1];  // (own row, ascending; row j > l gains entry j - 1)
+            }
+            if (j > l && j < nq) {
+                na[q2] = actrow[j];
+                nl[q2] = lamv[j];
+            }
+        }
         bsync();
+#pragma unroll
+        for (int q2 = 0; q2 < NRM; ++q2) {
+            const int j = tid + q2 * BS;
+            if (j > l && j < nq) {
+                actrow[j - 1] = na[q2];
+                lamv[j - 1] = nl[q2];
+                pos[na[q2]] = j - 1;
+            }
+        }
+        if (tid == 0) pos[rowl] = -1;  // (its slack is zero now and moves with the next steps)
+        bsync();
+        for (int j = l; j < k; ++j) {  // zero R[j + 1][j] against R[j][j]
+            T *r0 = Rm + (int64_t)j * maxq, *r1 = r0 + maxq, *q0 = Qs + (int64_t)j * n, *q1 = q0 + n;
+            const T a0 = r0[j], b0 = r1[j];
+            const T hh = sqrt(a0 * a0 + b0 * b0);
+            const T cc = hh > 0.0 ? a0 / hh : 1.0, ss = hh > 0.0 ? b0 / hh : 0.0;  // (every thread: two broadcast reads)
+            bsync();  // (before anybody rewrites r0[j], r1[j])
+            for (int b2 = j + tid; b2 < k; b2 += BS) {
+                const T t1 = r0[b2], t2 = r1[b2];
+                r0[b2] = cc * t1 + ss * t2;
+                r1[b2] = cc * t2 - ss * t1;
+            }
+            for (int i = tid; i < n; i += BS) {
+                const T t1 = q0[i], t2 = q1[i];
+                q0[i] = cc * t1 + ss * t2;
+                q1[i] = cc * t2 - ss * t1;
+            }
+            bsync();
+        }
+    };
+    // every slack from scratch, at the point the loop has reached: a roll-out of the inputs Ucur through the dynamics (the forward
+    // sweep with the inputs given) and the rows of G on it -- what the oracle does after a full step (sp = h_p - G_p x)
+    T *Ucur = U0, *Zu = Vs, *Usc = Vs + n, *gz = Hs, *Hsc = Hs + M, *Yp = Ys;
+    auto eval_slacks = [&](T *out) {
+        for (int i = tid; i < n; i += BS) ffv[i] = Ucur[i];
+        bsync();
+        sweep(0, 0, true, gx0, Usc, out, 2, true);
         for (int i = tid; i < M; i += BS) {
-            T fr = s0[i];
-            for (int a = 0; a < nq; ++a) fr += lamv[a] * Hs[(int64_t)phys[a] * M + i];
-            sl[i] = pos[i] >= 0 ? 0.0 : fr;
+            const int k = i / mk, r = i - k * mk;
+            out[i] = ge[k * sE + r] - out[i];
         }
         bsync();
-        return true;
     };
     if (!notpd) {
         // unconstrained minimiser and its slacks (tracking terms as linear costs: q of mpc_qp.py:129-149)
         {
             const long long t0 = (long long)__builtin_readcyclecounter();
-            sweep(0, 0, true, gx0, U0, sl);
+            sweep(0, 0, true, gx0, Ucur, sl, 3, false);
             t_sweeps += (long long)__builtin_readcyclecounter() - t0;
             ++n_sweeps;
         }
         for (int i = tid; i < M; i += BS) {
             const int k = i / mk, r = i - k * mk;
-            const T ev = ge[k * sE + r];
-            const T sv = ev - sl[i];
-            s0[i] = sv;
-            sl[i] = sv;
-            thr[i] = tol + tol * fabs(ev);
+            const T ev2 = ge[k * sE + r];
+            sl[i] = ev2 - sl[i];
+            thr[i] = tol + tol * fabs(ev2);
             T nn = 0.0;
             if (gC)
                 for (int j = 0; j < nx; ++j) nn += gC[k * sC + r * nx + j] * gC[k * sC + r * nx + j];
             if (gD)
                 for (int a = 0; a < nu; ++a) nn += gD[k * sD + r * nu + a] * gD[k * sD + r * nu + a];
             invn[i] = nn > 0.0 ? rsqrt(nn) : 1.0;
-            pos[i] = ev < 1e29 ? -1 : -2;  // -2: padded row, never selectable
+            pos[i] = ev2 < 1e29 ? -1 : -2;  // -2: padded row, never selectable
         }
-        for (int a = tid; a <= maxq; a += BS) phys[a] = a;
         bsync();
         const int max_iter = ka.max_iter;
         bool fail = false, slotsfull = false;
-        int fails = 0, next_refresh = STAGEG_REFRESH, rescues = 0;
+        int fails = 0, next_refresh = STAGEG_REFRESH;
         for (;;) {
-            // ---- active-set loop (oracle/stagewise_np.py::solve_stagewise)
+            // ---- active-set loop (Goldfarb-Idnani with the thin QR of the whitened active rows; oracle/mpc_oracle.c is the dense form)
             for (;;) {
-                if (nq > 0 && iters >= next_refresh) {  // every STAGEG_REFRESH iterations: W, lam and the slacks from scratch
+                if (nq > 0 && iters >= next_refresh) {  // every STAGEG_REFRESH iterations: the slacks from scratch (rounding drift)
                     next_refresh = iters + STAGEG_REFRESH;
-                    refresh_state();  // (a failed refresh leaves W as it was rebuilt so far: the verification below decides)
+                    eval_slacks(Hsc);
+                    for (int i = tid; i < M; i += BS) sl[i] = pos[i] >= 0 ? 0.0 : Hsc[i];
+                    bsync();
                 }
                 T best = INF;
                 int bi = 0x7fffffff;
@@ -592,7 +713,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                 }
                 const int rowp = bi, kp = rowp / mk, rp = rowp - kp * mk;
                 T up = 0.0;
-                bool added = false, stop = false, rescued = false;
+                bool added = false, stop = false;
                 while (!added) {
                     if (iters >= max_iter) {
                         if (stamp && tid == 0) stamp[8] = 1;  // (developer probe: why the problem stopped)
@@ -601,55 +722,34 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                         break;
                     }
                     ++iters;
-                    T *Vp = Vs + (int64_t)phys[nq] * n, *Hp = Hs + (int64_t)phys[nq] * M;
-                    {
+                    {  // backward sweep on the row: ffv = -S_k^-1 t_k, the feed-forward terms of P^-1 g_p'
                         const long long t0 = (long long)__builtin_readcyclecounter();
-                        sweep(kp, rp, false, nullptr, Vp, Hp);
+                        sweep(kp, rp, false, nullptr, nullptr, nullptr, 1, false);
                         t_sweeps += (long long)__builtin_readcyclecounter() - t0;
                         ++n_sweeps;
                     }
-                    // V_p = -P^-1 (-g_p') ... the sweep solved with ql = -C, rl = -D: its result IS P^-1 g_p'
-                    for (int a = tid; a < nq; a += BS) cv[a] = Hp[actrow[a]];
-                    bsync();
-                    const T dpp = Hp[rowp];
-                    for (int a = tid; a < nq; a += BS) {
-                        T acc = 0.0;
-                        for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * cv[b];
-                        rv[a] = acc;
-                    }
-                    bsync();
+                    // the row's whitened vector y_p = L^-1 g_p' = (-Ls_k' ff_k)_k (header); d = Q' y_p, z = y_p - Q d into Q's next
+                    // vector, |z|^2 as a sum of squares; r = R^-1 d
+                    T *Zw = Qs + (int64_t)nq * n;
                     T part = 0.0;
-                    for (int a = tid; a < nq; a += BS) part += cv[a] * rv[a];
-                    T cr = block_sum(part, redv, tid);
-                    T d2 = dpp - cr;
-                    // A row that looks (nearly) DEPENDENT on the active ones -- |z|^2 = g_p V_p - c' W c below 1e-3 of g_p V_p -- is
-                    // judged on a refined r: one step of iterative refinement with the Gram matrix of the active rows, read off
-                    // the slots (entry (a, b) = row a of h_b). W is an explicit inverse kept by rank-one updates (and rebuilt
-                    // without pivoting): near a full active set its error turns a row that can enter into one that cannot, and
-                    // with no multiplier to drop the problem was reported infeasible (tools/stress_general.py seed 7: a problem
-                    // with u = 0 strictly feasible; the oracle solves it in 515 iterations, this kernel now in 519).
-                    for (int pass = 0; pass < STAGEG_NREF && nq > 0 && nq <= LQ && !(d2 > 1e-3 * dpp); ++pass) {
-                        for (int a = tid; a < nq; a += BS) physl[a] = phys[a];
-                        bsync();
-                        for (int a = tid; a < nq; a += BS) {
-                            T acc = cv[a];
-                            const int ra = actrow[a];
-                            for (int b = 0; b < nq; ++b) acc -= Hs[(int64_t)physl[b] * M + ra] * rv[b];
-                            rvl[a] = acc;  // c - Gram r
-                        }
-                        bsync();
-                        part = 0.0;
-                        for (int a = tid; a < nq; a += BS) {
-                            T acc = rv[a];
-                            for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * rvl[b];
-                            rv[a] = acc;
-                            part += cv[a] * acc;
-                        }
-                        bsync();
-                        cr = block_sum(part, redv, tid);
-                        d2 = dpp - cr;
+                    for (int i = tid; i < n; i += BS) {
+                        const int k2 = i / nu, a2 = i - k2 * nu;
+                        const T *ls = ws + wl.LS + (int64_t)k2 * nu * nu;
+                        T acc = 0.0;
+                        for (int b2 = a2; b2 < nu; ++b2) acc -= ls[b2 * nu + a2] * ffv[k2 * nu + b2];
+                        Yp[i] = acc;
+                        part += acc * acc;
                     }
-                    const bool can_move = nq < n && d2 > 1e-13 * dpp && d2 > 0.0;
+                    const T dpp = block_sum(part, redv, tid);  // |y_p|^2 = g_p P^-1 g_p'  (its barriers publish y_p)
+                    const T d2 = ortho(Yp, Zw, nq);
+                    load_dinv(nq);
+                    solveR(nq);
+                    if (vlds) {
+                        for (int a = tid; a < nq; a += BS) rv[a] = ro[a];
+                        bsync();
+                    }
+                    // (the oracle's pivot test: |z|^2 > 1e-28 |y_p|^2, oracle/mpc_oracle.c; two orders above it here)
+                    const bool can_move = nq < n && d2 > 1e-26 * dpp && d2 > 0.0;
                     if (can_move && nq >= maxq) {  // the step would need one more slot than this launch holds
                         slotsfull = stop = fail = true;
                         break;
@@ -666,59 +766,38 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                             }
                         }
                     }
-                    const T slp = sl[rowp];  // (read BEFORE the reduction's barriers: the slack pass below rewrites it, and without the
-                                             // LDS staging -- nq > LQ -- no barrier separates that pass from a late wavefront's read)
+                    const T slp = sl[rowp];
                     block_argmin(t1, l, redv, redi, tid);
                     const T t2 = can_move ? -slp / d2 : INF;
                     const T t = t1 < t2 ? t1 : t2;
-                    if (!(t < INF)) {
-                        if (!rescued && nq > 0) {  // before the verdict: the same trip once more on a W rebuilt from scratch
-                            rescued = true;
-                            if (refresh_W()) {
-                                --iters;
-                                continue;
-                            }
-                        }
-                        if (rescues < 3 && nq > 0) {
-                            // ... and once more from a state rebuilt from scratch (W, multipliers, every slack): after a
-                            // thousand iterations the carried slacks can show a row violated by 1e-11 that sits ON its
-                            // bound and depends on the active rows -- there is no step for such a row, and no need for one
-                            ++rescues;
-                            if (refresh_state()) break;  // (select again)
-                        }
+                    if (!(t < INF)) {  // no step possible: the row depends on the active ones and no multiplier blocks
                         status = MPCQP_INFEASIBLE;
                         if (stamp && tid == 0) stamp[8] = 5;  // (developer probe: why the problem stopped)
                         stop = fail = true;
                         break;
                     }
-                    // s -= t G z with z = -(V_p - sum_a r_a V_a). The coefficients and the slots' places are the same for every row:
-                    // staged in LDS once (they were re-read from the workspace per row and slot, the slot's place first: two
-                    // dependent round trips per term), four slots' entries requested together
-                    const bool staged = nq <= LQ;
-                    if (staged) {
-                        for (int a = tid; a < nq; a += BS) {
-                            rvl[a] = rv[a];
-                            physl[a] = phys[a];
+                    if (can_move) {
+                        // the step in the inputs: z_u = L'^-1 z = the forward sweep on the feed-forward terms -Ls_k'^-1 z_k (the
+                        // PROJECTED vector goes through the sweep: no difference of large vectors anywhere), and G z with it
+                        for (int k2 = tid; k2 < N; k2 += BS) {
+                            const T *ls = ws + wl.LS + (int64_t)k2 * nu * nu;
+                            T f[NUM];
+                            for (int a2 = nu - 1; a2 >= 0; --a2) {  // Ls' f = -z_k (upper triangular: back substitution)
+                                T acc = -Zw[k2 * nu + a2];
+                                for (int b2 = a2 + 1; b2 < nu; ++b2) acc -= ls[b2 * nu + a2] * f[b2 < NUM ? b2 : 0];
+                                f[a2 < NUM ? a2 : 0] = acc / ls[a2 * nu + a2];
+                            }
+                            for (int a2 = 0; a2 < nu; ++a2) ffv[k2 * nu + a2] = f[a2 < NUM ? a2 : 0];
                         }
                         bsync();
-                    }
-                    for (int i = tid; i < M; i += BS) {
-                        T gz = Hp[i];
-                        if (staged) {
-                            int a = 0;
-                            for (; a + 4 <= nq; a += 4) {
-                                const T h0 = Hs[(int64_t)physl[a] * M + i], h1 = Hs[(int64_t)physl[a + 1] * M + i];
-                                const T h2 = Hs[(int64_t)physl[a + 2] * M + i], h3 = Hs[(int64_t)physl[a + 3] * M + i];
-                                gz -= rvl[a] * h0;
-                                gz -= rvl[a + 1] * h1;
-                                gz -= rvl[a + 2] * h2;
-                                gz -= rvl[a + 3] * h3;
-                            }
-                            for (; a < nq; ++a) gz -= rvl[a] * Hs[(int64_t)physl[a] * M + i];
-                        } else {
-                            for (int a = 0; a < nq; ++a) gz -= rv[a] * Hs[(int64_t)phys[a] * M + i];
+                        {
+                            const long long t0 = (long long)__builtin_readcyclecounter();
+                            sweep(0, 0, false, nullptr, Zu, gz, 2, false);
+                            t_sweeps += (long long)__builtin_readcyclecounter() - t0;
                         }
-                        sl[i] = pos[i] >= 0 ? 0.0 : sl[i] + t * gz;
+                        // z_u = P^-1 (g_p' - G_A' r): the point moves against it, u -= t z_u ; s = e - G u gains t G z_u
+                        for (int i = tid; i < n; i += BS) Ucur[i] -= t * Zu[i];
+                        for (int i = tid; i < M; i += BS) sl[i] = pos[i] >= 0 ? 0.0 : sl[i] + t * gz[i];
                     }
                     for (int a = tid; a < nq; a += BS) {
                         const T v = lamv[a] - t * rv[a];
@@ -726,18 +805,9 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                     }
                     up += t;
                     bsync();
-                    if (t2 <= t1) {  // full step: p takes slot nq (its vectors are already there)
-                        const T id2 = 1.0 / d2;
-                        for (int e = tid; e < nq * nq; e += BS) {
-                            const int a = e / nq, b = e - a * nq;
-                            Wm[(int64_t)a * maxq + b] += rv[a] * rv[b] * id2;
-                        }
-                        for (int a = tid; a < nq; a += BS) {
-                            Wm[(int64_t)a * maxq + nq] = -rv[a] * id2;
-                            Wm[(int64_t)nq * maxq + a] = -rv[a] * id2;
-                        }
+                    if (t2 <= t1) {  // full step: p takes slot nq: Q gains z / |z|, R the column [d; |z|]
+                        append(nq, d2);
                         if (tid == 0) {
-                            Wm[(int64_t)nq * maxq + nq] = id2;
                             lamv[nq] = up;
                             actrow[nq] = rowp;
                             pos[rowp] = nq;
@@ -746,115 +816,36 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                         ++nq;
                         added = true;
                         bsync();
-                    } else {  // partial step: slot l leaves; the last slot takes its place
-                        const T wll = Wm[(int64_t)l * maxq + l];
-                        for (int a = tid; a < nq; a += BS) cv[a] = Wm[(int64_t)a * maxq + l];
-                        bsync();
-                        const T iw = 1.0 / wll;
-                        for (int e = tid; e < nq * nq; e += BS) {
-                            const int a = e / nq, b = e - a * nq;
-                            Wm[(int64_t)a * maxq + b] -= cv[a] * cv[b] * iw;
-                        }
-                        bsync();
-                        const int last = nq - 1;
-                        // the leaving row's slack is no longer pinned: it is zero now and moves with the next steps
-                        if (l != last) {
-                            for (int a = tid; a < nq; a += BS) {  // column `last` -> column l, then row
-                                Wm[(int64_t)a * maxq + l] = Wm[(int64_t)a * maxq + last];
-                            }
-                            bsync();
-                            for (int b = tid; b < nq; b += BS) Wm[(int64_t)l * maxq + b] = Wm[(int64_t)last * maxq + b];
-                            bsync();
-                            if (tid == 0) Wm[(int64_t)l * maxq + l] = Wm[(int64_t)last * maxq + last];
-                        }
-                        bsync();
-                        if (tid == 0) {
-                            const int rl_ = actrow[l];
-                            pos[rl_] = -1;
-                            const int pl = phys[l];
-                            if (l != last) {
-                                phys[l] = phys[last];
-                                actrow[l] = actrow[last];
-                                lamv[l] = lamv[last];
-                                pos[actrow[l]] = l;
-                            }
-                            // the candidate's buffer follows the shrinking slot count
-                            phys[last] = phys[nq];
-                            phys[nq] = pl;
-                        }
+                    } else {  // partial step: slot l leaves, the slots behind it close the gap
+                        drop_slot(l);
                         --nq;
-                        bsync();
                     }
                 }
                 if (stop) break;
             }
             if (fail) break;
-            // ---- verification from scratch: s = s0 + sum_a lam_a h_a ; active rows on their bounds, inactive rows feasible
+            // ---- acceptance, from scratch (the oracle's: oracle/mpc_oracle.c): every multiplier >= 0, every active row on its bound
+            //      to 1e-6 (1 + |e_i|), no inactive row violated -- evaluated on the roll-out of the inputs that are returned
+            eval_slacks(Hsc);
             bool dirty = false, offa = false;
-            for (int pass = 0; pass < STAGEG_VPASS; ++pass) {
-                dirty = offa = false;
-                for (int a = tid; a < nq; a += BS) offa |= !(lamv[a] >= 0.0);
-                for (int i = tid; i < M; i += BS) {
-                    T fr = s0[i];
-                    for (int a = 0; a < nq; ++a) fr += lamv[a] * Hs[(int64_t)phys[a] * M + i];
-                    const bool act = pos[i] >= 0;
-                    const T fac = pass == 0 ? 1000.0 : (1000.0 > 1e-6 / tol ? 1000.0 : 1e-6 / tol);
-                    if (act)
-                        offa |= !(fabs(fr) <= fac * thr[i]);
-                    else if (pos[i] == -1 && !(fr >= -4.0 * thr[i]))
-                        dirty = true;
-                    sl[i] = act ? 0.0 : fr;
-                    if (act) cv[pos[i]] = fr;
-                }
-                offa = block_any(offa, redi, tid);
-                if (!offa) break;
-                if (pass == STAGEG_VPASS - 1) {
-                    if (stamp && tid == 0) {
-                        stamp[8] = 2;  // (developer probe: why the problem stopped)
-                        stamp[9] = nq;
-                        long long worst = 0, neg = 0;
-                        for (int a = 0; a < nq; ++a) {
-                            const long long r_ = (long long)(fabs(cv[a]) / thr[actrow[a]]);
-                            worst = r_ > worst ? r_ : worst;
-                            neg += lamv[a] == 0.0;
-                        }
-                        stamp[10] = worst;
-                        stamp[11] = neg;
-                    }
-                    fail = true;
-                    break;
-                }
-                // (from the second correction on with W rebuilt from the slots' Gram matrix: the rank-one-updated inverse may be too
-                // far off for the correction to contract)
-                if (pass >= 1 && nq > 0) {
-                    for (int a = tid; a < nq; a += BS) sl[actrow[a]] = cv[a];  // (the rebuild uses cv; sl is rewritten by the next pass)
-                    bsync();
-                    if (!refresh_W()) {
-                        if (stamp && tid == 0) stamp[9] = 100 + pass;
-                        fail = true;
-                        break;
-                    }
-                    for (int a = tid; a < nq; a += BS) cv[a] = sl[actrow[a]];
-                    bsync();
-                }
-                for (int a = tid; a < nq; a += BS) {  // lam -= W rho_A
-                    T acc = 0.0;
-                    for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)a * maxq + b] * cv[b];
-                    rv[a] = acc;
-                }
-                bsync();
-                for (int a = tid; a < nq; a += BS) {
-                    const T v = lamv[a] - rv[a];
-                    lamv[a] = v < 0.0 ? 0.0 : v;
-                }
-                bsync();
+            for (int a = tid; a < nq; a += BS) offa |= !(lamv[a] >= 0.0);
+            for (int i = tid; i < M; i += BS) {
+                const T fr = Hsc[i];
+                const bool act = pos[i] >= 0;
+                const T fac = 1000.0 > 1e-6 / tol ? 1000.0 : 1e-6 / tol;
+                if (act)
+                    offa |= !(fabs(fr) <= fac * thr[i]);
+                else if (pos[i] == -1 && !(fr >= -4.0 * thr[i]))
+                    dirty = true;
+                sl[i] = act ? 0.0 : fr;
             }
-            if (fail) {
+            offa = block_any(offa, redi, tid);
+            dirty = block_any(dirty, redi, tid);
+            if (offa) {
                 if (stamp && tid == 0) stamp[8] = 3;  // (developer probe: why the problem stopped)
                 status = MPCQP_MAX_ITER;
                 break;
             }
-            dirty = block_any(dirty, redi, tid);
             if (!dirty) {
                 status = MPCQP_SOLVED;
                 break;
@@ -869,11 +860,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
     }
     const bool ok = status == MPCQP_SOLVED;
     T *ou = (T *)ka.U + prob * (int64_t)n;
-    for (int i = tid; i < n; i += BS) {
-        T u = ok ? U0[i] : 0.0;
-        for (int a = 0; ok && a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * n + i];
-        ou[i] = u;
-    }
+    for (int i = tid; i < n; i += BS) ou[i] = ok ? U0[i] : 0.0;  // (U0 holds the point the loop reached)
     if (ka.lam) {
         T *ol = (T *)ka.lam + prob * (int64_t)M;
         for (int i = tid; i < M; i += BS) ol[i] = (ok && !notpd && pos[i] >= 0) ? lamv[pos[i]] : 0.0;
@@ -913,7 +900,7 @@ int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipSt
     constexpr int ring_doubles = 8192;
     static const bool attr_ok = hipFuncSetAttribute((const void *)mpcqp_stageg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     ring_doubles * (int)sizeof(double)) == hipSuccess;
-    if (!attr_ok) return MPCQP_EUNSUPPORTED;
+    if (!attr_ok || maxq > 4 * BS) return MPCQP_EUNSUPPORTED;  // (a thread owns at most four rows of the active rows' factor)
     hipLaunchKernelGGL(mpcqp_stageg_kernel, dim3((unsigned)batch), dim3(BS), ring_doubles * sizeof(double), st, ka, wl, (double *)ws,
                        ring_doubles);
     return (int)hipGetLastError();

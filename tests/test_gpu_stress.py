@@ -39,8 +39,7 @@ def _campaign(tool, args, seed, extra_env=None):
     ("stress_f32.py", (24, 64), 41, 1e-3),              # float32 through the default dispatch vs the float64 oracle
     ("stress_f32.py", (24, 64), 46, 1e-3),
     ("stress_general.py", (12, 8), 2, 1e-7),            # wide systems (17 <= nx <= 32, nu <= 8): the general stage-wise kernel
-    # nearly fully active problems (4-6 tight rows per step, most variables pinned): the three stage-wise kernels. (Seeds 2, 3, 8
-    # of the general kernel's campaign each hold a problem that ends MAX_ITER where the oracle solves it: DESIGN 3.9.4 vii.)
+    # nearly fully active problems (4-6 tight rows per step, most variables pinned): the three stage-wise kernels
     ("stress_tight.py", ("narrow", 8, 8), 1, 1e-7),
     ("stress_tight.py", ("wide", 8, 8), 1, 1e-7),
     ("stress_tight.py", ("general", 8, 8), 1, 1e-7),
@@ -51,18 +50,20 @@ def test_stress_campaign(tool, args, seed, bound):
     assert worst <= bound, (tool, seed, worst)
 
 
-# Known failures of the general stage-wise kernel (17 <= nx <= 32 or nu > 4: the only kernel of those dimensions) on nearly fully
-# active problems, kept IN the suite so that it says what is broken (profiles/r04_stress_summary.txt): the active-set operator
-# W = (G_A P^-1 G_A')^-1 is an explicit inverse kept by rank-one updates, and once the active rows' Gram matrix is ill
-# conditioned |z|^2 = g_p V_p - c' W c loses its digits -- one plan 3.3e-6 off (stress_general seed 7), one or two problems per
-# campaign ending MPCQP_MAX_ITER where the oracle solves them (stress_tight general seeds 2, 3, 8). strict: a fix turns these red.
+# Round 4's known failures of the general stage-wise kernel (17 <= nx <= 32 or nu > 4: the only kernel of those dimensions) on nearly
+# fully active problems -- one plan 3.3e-6 off (stress_general seed 7), one or two problems per campaign ending MPCQP_MAX_ITER where
+# the oracle solves them (stress_tight general seeds 2, 3, 8), profiles/r04_stress_summary.txt -- were strict xfails here until the
+# kernel's active-set operator became a thin QR factorisation of the whitened active rows with the projected direction sent through
+# the forward sweep (round 5, csrc/mpcqp_stageg.hip): all four are ordinary cases now, next to more seeds of the same families.
 @pytest.mark.parametrize("tool,args,seed,bound", [
-    pytest.param("stress_general.py", (12, 8), 7, 1e-7, marks=pytest.mark.xfail(strict=True, reason="plan 3.3e-6 off: W by rank-one updates")),
-    pytest.param("stress_tight.py", ("general", 8, 8), 2, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
-    pytest.param("stress_tight.py", ("general", 8, 8), 3, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
-    pytest.param("stress_tight.py", ("general", 8, 8), 8, 1e-7, marks=pytest.mark.xfail(strict=True, reason="MAX_ITER where the oracle solves")),
+    ("stress_general.py", (12, 8), 7, 1e-7),
+    ("stress_general.py", (12, 8), 11, 1e-7),
+    ("stress_tight.py", ("general", 8, 8), 2, 1e-7),
+    ("stress_tight.py", ("general", 8, 8), 3, 1e-7),
+    ("stress_tight.py", ("general", 8, 8), 8, 1e-7),
+    ("stress_tight.py", ("general", 8, 8), 5, 1e-7),
 ])
-def test_stress_campaign_known_failures_of_the_general_kernel(tool, args, seed, bound):
+def test_stress_campaign_nearly_full_active_sets_of_the_general_kernel(tool, args, seed, bound):
     worst, nflag, flagged = _campaign(tool, args, seed)
     assert nflag == 0, "\n".join(flagged)
     assert worst <= bound, (tool, seed, worst)
