@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "mpcqp.h"
 #include "mpcqp_internal.h"
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
     // (developer probe, MpcqpSolveOpts.probe: cycles of the whole problem [0], of the recursion [1], of the sweeps [2], their number [3])
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     const long long t_ric = (long long)__builtin_readcyclecounter();
-    long long t_sweeps = 0, n_sweeps = 0, t_bwd = 0, t_fwd = 0, t_rows = 0, t_w0 = 0;
+    long long t_sweeps = 0, n_sweeps = 0, t_bwd = 0, t_fwd = 0, t_rows = 0, t_w0 = 0, t_ortho = 0, t_solve = 0, t_drop = 0, t_whiten = 0;
 
     // ---- one LQR solve: backward sweep from stage kp (row right-hand side) or from N (tracking terms), forward sweep from
     //      x_start; writes the inputs to Vout [n] and G (x, u) to Hout [M]
@@ -523,69 +524,108 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         bsync();
     };
     // r = R^-1 d for the first k slots (d in yv), into ro. Thread j owns row j: the owner of row b publishes r_b, every row above
-    // takes its entry of column b times r_b off its own sum -- one barrier per step, the next entry of the thread's own row
-    // (contiguous along the row) requested before the barrier.
-    auto solveR = [&](int k) {
-        T acc[NRM], lnx[NRM];
-        const T *lr[NRM];
+    // takes its entry of column b times r_b off its own sum -- one barrier per step; the thread's own row is fetched eight entries
+    // (contiguous along the row) per round trip to the workspace.
+    auto solveR_n = [&](int k, auto nrc) {  // (NR rows per thread: 1 while the slots fit one row per thread)
+        constexpr int NR = decltype(nrc)::value;
+        T acc[NR];
+        const T *lr[NR];
 #pragma unroll
-        for (int q2 = 0; q2 < NRM; ++q2) {
+        for (int q2 = 0; q2 < NR; ++q2) {
             const int j = tid + q2 * BS;
             acc[q2] = j < k ? yv[j] : 0.0;
             lr[q2] = Rm + (int64_t)(j < k ? j : 0) * maxq;
-            lnx[q2] = (k > 0 && j < k - 1) ? lr[q2][k - 1] : 0.0;
         }
-        for (int b2 = k - 1; b2 >= 0; --b2) {
-            T lcur[NRM];
+        for (int hi = k - 1; hi >= 0; hi -= 8) {  // columns hi, hi - 1, ..., hi - 7
+            T ent[NR][8];
 #pragma unroll
-            for (int q2 = 0; q2 < NRM; ++q2) {
+            for (int q2 = 0; q2 < NR; ++q2) {
                 const int j = tid + q2 * BS;
-                lcur[q2] = lnx[q2];
-                if (b2 > 0 && j < b2 - 1) lnx[q2] = lr[q2][b2 - 1];
-                if (j == b2) ro[b2] = acc[q2] * dv[b2];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ent[q2][u] = (hi - u >= 0 && j < hi - u) ? lr[q2][hi - u] : 0.0;
             }
-            bsync();
-            const T rb = ro[b2];
 #pragma unroll
-            for (int q2 = 0; q2 < NRM; ++q2) {
-                const int j = tid + q2 * BS;
-                if (j < b2) acc[q2] -= lcur[q2] * rb;
+            for (int u = 0; u < 8; ++u) {
+                const int b2 = hi - u;
+                if (b2 < 0) break;  // (uniform)
+#pragma unroll
+                for (int q2 = 0; q2 < NR; ++q2)
+                    if (tid + q2 * BS == b2) ro[b2] = acc[q2] * dv[b2];
+                bsync();
+                const T rb = ro[b2];
+#pragma unroll
+                for (int q2 = 0; q2 < NR; ++q2) acc[q2] -= ent[q2][u] * rb;  // (zero for the rows at and below b2)
             }
         }
         bsync();
     };
-    // The candidate y (n entries) against the first k vectors of Q: d = Q' y into yv, z = y - Q d into zout, once more on z
-    // (classical Gram-Schmidt with re-orthogonalisation: the second pass's coefficients e are added to d); returns |z|^2 as the
-    // sum of z's squares. A wavefront per vector for the dot products (coalesced, DPP reduction), a thread per entry for the AXPYs.
-    auto ortho = [&](const T *y, T *zout, int k) -> T {
+    auto solveR = [&](int k) {
+        if (maxq <= BS)
+            solveR_n(k, std::integral_constant<int, 1>{});
+        else
+            solveR_n(k, std::integral_constant<int, NRM>{});
+    };
+    // The candidate y (n entries, |y|^2 = yy) against the first k vectors of Q: d = Q' y into yv, z = y - Q d into zout; when that
+    // cancelled (|z|^2 < |y|^2 / 4) once more on z, the second pass's coefficients added to d (classical Gram-Schmidt with
+    // re-orthogonalisation on demand, "twice is enough"); returns |z|^2 as the sum of z's squares. A wavefront per four vectors for
+    // the dot products (coalesced, DPP reduction), a thread per entry for the AXPYs, eight loads in flight per thread: the passes are
+    // bound by the round trips to Q in the workspace.
+    auto ortho = [&](const T *y, T *zout, int k, T yy) -> T {
         const int wv = tid >> 6, ln = tid & 63;
+        T zz = yy;
         for (int pass = 0; pass < 2; ++pass) {
             const T *src = pass == 0 ? y : zout;
             T *co = pass == 0 ? yv : ev;
-            for (int a2 = wv; a2 < k; a2 += BS / 64) {
-                const T *qa = Qs + (int64_t)a2 * n;
-                T part = 0.0;
-                for (int i = ln; i < n; i += 64) part += qa[i] * src[i];
-                part = wave_sum_dpp(part);
-                if (ln == 0) co[a2] = part;
+            for (int a0i = 4 * wv; a0i < k; a0i += 4 * (BS / 64)) {  // four vectors per wavefront and round: their loads overlap
+                const T *qa = Qs + (int64_t)a0i * n;
+                const int64_t s1 = a0i + 1 < k ? n : 0, s2 = a0i + 2 < k ? 2 * (int64_t)n : 0, s3 = a0i + 3 < k ? 3 * (int64_t)n : 0;
+                T p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll 2
+                for (int i = ln; i < n; i += 64) {
+                    const T sv = src[i];
+                    p0 += qa[i] * sv;
+                    p1 += qa[s1 + i] * sv;
+                    p2 += qa[s2 + i] * sv;
+                    p3 += qa[s3 + i] * sv;
+                }
+                p0 = wave_sum_dpp(p0);
+                p1 = wave_sum_dpp(p1);
+                p2 = wave_sum_dpp(p2);
+                p3 = wave_sum_dpp(p3);
+                if (ln == 0) {
+                    co[a0i] = p0;
+                    if (a0i + 1 < k) co[a0i + 1] = p1;
+                    if (a0i + 2 < k) co[a0i + 2] = p2;
+                    if (a0i + 3 < k) co[a0i + 3] = p3;
+                }
             }
             bsync();
+            T part = 0.0;
             for (int i = tid; i < n; i += BS) {
                 T a0 = src[i], a1 = 0.0;
                 int a2 = 0;
-                for (; a2 + 2 <= k; a2 += 2) {
-                    a0 -= co[a2] * Qs[(int64_t)a2 * n + i];
-                    a1 -= co[a2 + 1] * Qs[(int64_t)(a2 + 1) * n + i];
+                for (; a2 + 8 <= k; a2 += 8) {
+                    T qv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) qv[u] = Qs[(int64_t)(a2 + u) * n + i];
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        a0 -= co[a2 + u] * qv[u];
+                        a1 -= co[a2 + u + 1] * qv[u + 1];
+                    }
                 }
-                if (a2 < k) a0 -= co[a2] * Qs[(int64_t)a2 * n + i];
-                zout[i] = a0 + a1;
+                for (; a2 < k; ++a2) a0 -= co[a2] * Qs[(int64_t)a2 * n + i];
+                const T zi = a0 + a1;
+                zout[i] = zi;
+                part += zi * zi;
             }
-            bsync();
+            if (pass == 1)
+                for (int a2 = tid; a2 < k; a2 += BS) yv[a2] += ev[a2];
+            const T prev = zz;
+            zz = block_sum(part, redv, tid);  // (its barriers publish z and d)
+            if (pass == 0 && (k == 0 || zz >= 0.25 * prev)) break;  // no cancellation: Q' z is at rounding level already
         }
-        T part = 0.0;
-        for (int i = tid; i < n; i += BS) part += zout[i] * zout[i];
-        for (int a2 = tid; a2 < k; a2 += BS) yv[a2] += ev[a2];
-        return block_sum(part, redv, tid);  // (its barriers also publish d)
+        return zz;
     };
     // the candidate becomes basis vector k = slot k: Q gains z / |z|, R the column [d; |z|]
     auto append = [&](int k, T zn2) {
@@ -628,24 +668,55 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
         }
         if (tid == 0) pos[rowl] = -1;  // (its slack is zero now and moves with the next steps)
         bsync();
+        // The rotation of step j mixes rows j, j + 1 of R and vectors j, j + 1 of Q. Thread b carries column b's entry of the
+        // MOVING row (row j after the rotations before it) in a register, so what a step reads from memory -- row j + 1 -- no earlier
+        // step has written: one barrier per rotation (the owner of column j publishes (c, s)). The rotations are recorded and Q
+        // takes them afterwards in one pass, every thread walking the chain for its own entries without any barrier.
+        T *cr = vlds ? yl_s : ws + wl.yv, *sr = vlds ? el_s : ws + wl.ev;  // (c_j, s_j), j = l .. k - 1
+        T carry[NRM], nxt[NRM];
+#pragma unroll
+        for (int q2 = 0; q2 < NRM; ++q2) {
+            const int b2 = tid + q2 * BS;
+            carry[q2] = (b2 >= l && b2 < k) ? Rm[(int64_t)l * maxq + b2] : 0.0;
+            nxt[q2] = (b2 >= l && b2 < k && l < k) ? Rm[(int64_t)(l + 1) * maxq + b2] : 0.0;
+        }
         for (int j = l; j < k; ++j) {  // zero R[j + 1][j] against R[j][j]
-            T *r0 = Rm + (int64_t)j * maxq, *r1 = r0 + maxq, *q0 = Qs + (int64_t)j * n, *q1 = q0 + n;
-            const T a0 = r0[j], b0 = r1[j];
-            const T hh = sqrt(a0 * a0 + b0 * b0);
-            const T cc = hh > 0.0 ? a0 / hh : 1.0, ss = hh > 0.0 ? b0 / hh : 0.0;  // (every thread: two broadcast reads)
-            bsync();  // (before anybody rewrites r0[j], r1[j])
-            for (int b2 = j + tid; b2 < k; b2 += BS) {
-                const T t1 = r0[b2], t2 = r1[b2];
-                r0[b2] = cc * t1 + ss * t2;
-                r1[b2] = cc * t2 - ss * t1;
-            }
-            for (int i = tid; i < n; i += BS) {
-                const T t1 = q0[i], t2 = q1[i];
-                q0[i] = cc * t1 + ss * t2;
-                q1[i] = cc * t2 - ss * t1;
+            T u[NRM];
+#pragma unroll
+            for (int q2 = 0; q2 < NRM; ++q2) {
+                const int b2 = tid + q2 * BS;
+                u[q2] = nxt[q2];
+                if (j + 1 < k && b2 > j && b2 < k) nxt[q2] = Rm[(int64_t)(j + 2) * maxq + b2];  // (row j + 2: next step's)
+                if (b2 == j) {
+                    const T hh = sqrt(carry[q2] * carry[q2] + u[q2] * u[q2]);
+                    cr[j] = hh > 0.0 ? carry[q2] / hh : 1.0;
+                    sr[j] = hh > 0.0 ? u[q2] / hh : 0.0;
+                }
             }
             bsync();
+            const T cc = cr[j], ss = sr[j];
+#pragma unroll
+            for (int q2 = 0; q2 < NRM; ++q2) {
+                const int b2 = tid + q2 * BS;
+                if (b2 >= j && b2 < k) {
+                    Rm[(int64_t)j * maxq + b2] = cc * carry[q2] + ss * u[q2];
+                    carry[q2] = cc * u[q2] - ss * carry[q2];
+                }
+            }
         }
+        bsync();
+        for (int i = tid; i < n; i += BS) {
+            T t1 = Qs[(int64_t)l * n + i];
+            T un = l < k ? Qs[(int64_t)(l + 1) * n + i] : 0.0;
+            for (int j = l; j < k; ++j) {
+                const T u2 = un;
+                if (j + 1 < k) un = Qs[(int64_t)(j + 2) * n + i];
+                const T cc = cr[j], ss = sr[j];
+                Qs[(int64_t)j * n + i] = cc * t1 + ss * u2;
+                t1 = cc * u2 - ss * t1;
+            }
+        }
+        bsync();
     };
     // every slack from scratch, at the point the loop has reached: a roll-out of the inputs Ucur through the dynamics (the forward
     // sweep with the inputs given) and the rows of G on it -- what the oracle does after a full step (sp = h_p - G_p x)
@@ -732,6 +803,7 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                     // vector, |z|^2 as a sum of squares; r = R^-1 d
                     T *Zw = Qs + (int64_t)nq * n;
                     T part = 0.0;
+                    const long long tw0 = (long long)__builtin_readcyclecounter();
                     for (int i = tid; i < n; i += BS) {
                         const int k2 = i / nu, a2 = i - k2 * nu;
                         const T *ls = ws + wl.LS + (int64_t)k2 * nu * nu;
@@ -741,9 +813,14 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                         part += acc * acc;
                     }
                     const T dpp = block_sum(part, redv, tid);  // |y_p|^2 = g_p P^-1 g_p'  (its barriers publish y_p)
-                    const T d2 = ortho(Yp, Zw, nq);
+                    const long long to0 = (long long)__builtin_readcyclecounter();
+                    t_whiten += to0 - tw0;
+                    const T d2 = ortho(Yp, Zw, nq, dpp);
+                    const long long to1 = (long long)__builtin_readcyclecounter();
+                    t_ortho += to1 - to0;
                     load_dinv(nq);
                     solveR(nq);
+                    t_solve += (long long)__builtin_readcyclecounter() - to1;
                     if (vlds) {
                         for (int a = tid; a < nq; a += BS) rv[a] = ro[a];
                         bsync();
@@ -781,13 +858,18 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                         // PROJECTED vector goes through the sweep: no difference of large vectors anywhere), and G z with it
                         for (int k2 = tid; k2 < N; k2 += BS) {
                             const T *ls = ws + wl.LS + (int64_t)k2 * nu * nu;
-                            T f[NUM];
-                            for (int a2 = nu - 1; a2 >= 0; --a2) {  // Ls' f = -z_k (upper triangular: back substitution)
-                                T acc = -Zw[k2 * nu + a2];
-                                for (int b2 = a2 + 1; b2 < nu; ++b2) acc -= ls[b2 * nu + a2] * f[b2 < NUM ? b2 : 0];
-                                f[a2 < NUM ? a2 : 0] = acc / ls[a2 * nu + a2];
+                            T f[NUM];  // (fully unrolled below: registers)
+#pragma unroll
+                            for (int a2 = NUM - 1; a2 >= 0; --a2) {  // Ls' f = -z_k (upper triangular: back substitution)
+                                T acc = a2 < nu ? -Zw[k2 * nu + a2] : 0.0;
+#pragma unroll
+                                for (int b2 = a2 + 1; b2 < NUM; ++b2)
+                                    if (b2 < nu) acc -= ls[b2 * nu + (a2 < nu ? a2 : 0)] * f[b2];
+                                f[a2] = a2 < nu ? acc / ls[a2 * nu + a2] : 0.0;
                             }
-                            for (int a2 = 0; a2 < nu; ++a2) ffv[k2 * nu + a2] = f[a2 < NUM ? a2 : 0];
+#pragma unroll
+                            for (int a2 = 0; a2 < NUM; ++a2)
+                                if (a2 < nu) ffv[k2 * nu + a2] = f[a2];
                         }
                         bsync();
                         {
@@ -817,7 +899,9 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
                         added = true;
                         bsync();
                     } else {  // partial step: slot l leaves, the slots behind it close the gap
+                        const long long td0 = (long long)__builtin_readcyclecounter();
                         drop_slot(l);
+                        t_drop += (long long)__builtin_readcyclecounter() - td0;
                         --nq;
                     }
                 }
@@ -875,6 +959,10 @@ __global__ void __launch_bounds__(BS, 2) mpcqp_stageg_kernel(const KernelArgs ka
             stamp[5] = t_fwd;
             stamp[6] = t_rows;
             stamp[7] = t_w0;
+            stamp[12] = t_ortho;
+            stamp[13] = t_solve;
+            stamp[14] = t_drop;
+            stamp[15] = t_whiten;
         }
         if (ka.status) ka.status[prob] = status;
         if (ka.iters) ka.iters[prob] = iters;

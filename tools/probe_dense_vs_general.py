@@ -25,5 +25,6 @@ buf = torch.zeros(batch * 16, dtype=torch.int64, device="cuda")
 solve_mpc_batch(bp, formulation="stagewise", probe=buf); torch.cuda.synchronize()
 t = buf.view(batch, 16).cpu().double()
 print(f"  general kernel, cycles per problem: total {t[:,0].mean():.0f}, recursion {t[:,1].mean():.0f}, sweeps {t[:,2].mean():.0f} in {t[:,3].mean():.1f} sweep pairs = {(t[:,2]/t[:,3].clamp(min=1)).mean():.0f} each (backward {(t[:,4]/t[:,3].clamp(min=1)).mean():.0f}, forward {(t[:,5]/t[:,3].clamp(min=1)).mean():.0f}, rows of G {(t[:,6]/t[:,3].clamp(min=1)).mean():.0f}; first wavefront computing {(t[:,7]/t[:,3].clamp(min=1)).mean():.0f})")
+print(f"  active-set operator, cycles per problem: orthogonalisation {t[:,12].mean():.0f}, R solve {t[:,13].mean():.0f}, drops {t[:,14].mean():.0f}, whitening {t[:,15].mean():.0f}")
 print(f"nx={nx} nu={nu} N={N} mk={mk} batch {batch}: default {td:.2f} ms (solved {float((pd.status==0).float().mean()):.2f}, iters {pd.iters.float().mean().item():.1f}) | stage-wise {ts:.2f} ms"
       f" (solved {float((ps.status==0).float().mean()):.2f}, iters {ps.iters.float().mean().item():.1f}) | max rel diff {err:.1e}")
