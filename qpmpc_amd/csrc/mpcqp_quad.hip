@@ -505,7 +505,10 @@ __global__ void __launch_bounds__(64 * WPB, 1)
             fmac_bcast<k>(RH[k], zn, cH);
         });
     };
-    constexpr int USPLIT = 8;  // columns of the update issued before the selection's row fetch
+#ifndef QUAD_USPLIT
+#define QUAD_USPLIT 8
+#endif
+    constexpr int USPLIT = QUAD_USPLIT;  // columns of the update issued before the selection's row fetch
     // pending rank-one update R += c v, applied at the top of the next trip -- the ONE site that writes the register rows,
     // selects and fetches
     T zn = T(0), cT = T(0), cH = T(0);
