@@ -478,12 +478,14 @@ def _traffic_from_profiles(config: int):
 
 def _small_kernel_name(problems: int) -> str:
     """Which small-problem fused kernel a cold launch of `problems` lean problems gets (csrc/mpcqp_quad.hip, quad_pays: four per
-    wavefront between 2.25 and 16 problems per SIMD of the device) -- for the report only; the library decides."""
+    wavefront from 2.25 problems per SIMD of the device up; one round: the roomy LDS carve, several rounds: the slim one, two
+    wavefronts per SIMD) -- for the report only; the library decides."""
     import torch
 
     simds = 4 * torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    if 4 * problems > 9 * simds and problems <= 16 * simds:
-        return "mpcqp_quad_kernel<3> (fused build+solve, FOUR problems per wavefront, one per 16-lane DPP row)"
+    if 4 * problems > 9 * simds:
+        carve = "35.6 KB of LDS, one wavefront per SIMD" if (problems + 3) // 4 <= simds else "20 KB of LDS, two wavefronts per SIMD"
+        return f"mpcqp_quad_kernel<3> (fused build+solve, FOUR problems per wavefront, one per 16-lane DPP row; {carve})"
     return "mpcqp_pair_kernel<3, 2> (fused build+solve, two problems per wavefront)"
 
 

@@ -159,12 +159,12 @@ typedef struct MpcqpProblem {
 
 #define MPCQP_OPT_TWO_PER_WAVE 2048 /* small-problem fused kernel: keep TWO problems per wavefront (mpcqp_pair.hip) where the
                                  dispatch would put FOUR on one (mpcqp_quad.hip: cold launches with terminal cost only and two
-                                 state rows per step -- BASELINE configs 1, 2, 4 -- of a size that fills the machine about
-                                 once, see MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check. */
+                                 state rows per step -- BASELINE configs 1, 2, 4 -- from a few thousand problems up, see
+                                 MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check. */
 #define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
-                                 takes it between 2.25 and 16 problems per SIMD of the device: 2305 .. 16384 on an MI355X,
-                                 where a wavefront per SIMD with four problems beats two wavefronts with two; smaller batches
-                                 leave SIMDs idle either way and larger ones are bound by resident wavefronts per CU).
+                                 takes it from 2.25 problems per SIMD of the device up: 2305 and more on an MI355X, where a
+                                 wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
+                                 rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way).
                                  MPCQP_EUNSUPPORTED where the kernel does not apply (other cost / constraint layouts, warm
                                  starts, seed steps). */
 

@@ -18,7 +18,8 @@
 //     K0  K_l = H M_l (constraint l, slack s0)        K1  K_{l+16} = H M_{l+16} (constraint l + 16, slack s1)
 //   build: lane l owns column l of Psi and row l of P -> L; EVERY lane carries the free response Phi_k x0 (there is no
 //   17th lane; the 15 extra FMAs per step are issue slots a lone wavefront leaves idle anyway), so h and q need no exchange.
-// 1024 wavefronts for the 4096 problems of config 2 -> ONE wavefront per SIMD (512-register budget), 35.6 KB of LDS each.
+// 1024 wavefronts for the 4096 problems of config 2 -> one wavefront per SIMD; 254 registers and 20 KB of LDS each, so that launches
+// of several rounds keep two on every SIMD.
 //
 // Solver: the dual active-set method (Goldfarb-Idnani 1983) in the explicit-operator form of mpcqp_pair.hip, same pivots,
 // same tolerances; see that file for the derivation. What differs:
@@ -42,7 +43,7 @@ namespace quad {
 
 constexpr int NV = 16;    // padded number of variables / slots = lanes per problem
 constexpr int MMAX = 32;  // constraints a problem can hold (two per lane)
-constexpr int LDM = 18;   // row stride of the M image (144 B: rows start in distinct 16-B slots)
+// row stride of the M image: 18 (144 B: rows start in distinct 16-B slots, conflict-free stores) in the roomy carve, 16 in the slim one
 constexpr int MK = 2;     // inequality rows per step
 
 template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned x)
@@ -195,15 +196,29 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS carve of ONE problem, in doubles
-constexpr int OFF_M = 0;                      // build: G image by column, 16 x GS (GS = 33) | main: M image, 32 x LDM
-constexpr int OFF_LT = MMAX * LDM;            // rows of L^-T (read when a point is accepted)
-constexpr int OFF_T = OFF_LT + NV * NV;       // T by rows (refinement only)
-constexpr int OFF_KA = OFF_T + NV * NV;       // the row of a leaving slot
-constexpr int OFF_ACT = OFF_KA + NV;          // 16 int32: constraint held by each slot
-constexpr int PER = OFF_ACT + NV / 2;         // 1112 doubles = 8896 B per problem, 35.6 KB per wavefront
-static_assert(NV * 33 <= MMAX * LDM, "the G image must fit the M image's region");
-static_assert(PER % 2 == 0, "16-byte alignment of every problem's carve");
+// LDS carve of ONE problem, in doubles. Two of them:
+//  * ROOMY (launches of one round: at most one wavefront per SIMD, so LDS is free): M image 32 x 18, the full L^-T image, a T image
+//    for the rare refinement, the leaving slot's row, the slots' constraint ids: 1112 doubles = 35.6 KB per wavefront, four on a CU.
+//  * SLIM (launches of several rounds): 640 doubles = 5120 B, 20 KB per wavefront -- EIGHT wavefronts on a CU's 160 KB, two per SIMD
+//    (256-register budget), which is what those launches live on: 65,536 config-4 problems 231 us against 324 us roomy and 305 us
+//    for the two-per-wavefront kernel (tools/ab_quad_c4.py). Kept in LDS: M (32 x 16: its stores conflict, +2.6 k cycles once)
+//    and the strict upper triangle of L^-T, packed (the diagonal stays in a register). Gone: the T image (T' rho by row sums over
+//    the lanes), the leaving slot's row (fetched from its lane by ds_bpermute in the rare drop trip), the slots' ids (DPP). On a
+//    one-round launch the slim carve costs 3.8 us (its prologue and epilogue are longer): hence both.
+template <bool SLIM> struct Carve {
+    static constexpr int LDM = SLIM ? 16 : 18;
+    static constexpr int OFF_M = 0;  // build: G image by column, 16 x GS (GS = 33: 528 doubles; slim: over the start of the region
+                                     // behind it, which is not alive yet) | main: M image, 32 x LDM
+    static constexpr int OFF_LT = MMAX * LDM;  // roomy: rows of L^-T, 16 x 16 | slim: strict upper triangle by rows, packed: row l at
+                                               // l (31 - l) / 2, 15 - l entries
+    static constexpr int NLT = SLIM ? NV * (NV - 1) / 2 + 8 : NV * NV;  // (slim: eight spare doubles keep the G image inside the carve)
+    static constexpr int OFF_T = OFF_LT + NLT;                    // roomy only from here on: T by rows (refinement)
+    static constexpr int OFF_KA = OFF_T + NV * NV;                // the row of a leaving slot
+    static constexpr int OFF_ACT = OFF_KA + NV;                   // 16 int32: constraint held by each slot
+    static constexpr int PER = SLIM ? OFF_LT + NLT : OFF_ACT + NV / 2;  // 640 | 1112 doubles per problem
+    static_assert(NV * 33 <= PER, "the G image must fit the problem's carve");
+    static_assert(PER % 2 == 0 && (!SLIM || PER * 4 * 8 <= 20 * 1024), "16-byte alignment; slim: 20 KB per wavefront");
+};
 
 constexpr double DEP = 1e-14;      // |z|^2 / |M_p|^2 below this: M_p depends on the active rows
 constexpr double DEP_FAST = 1e-6;  // K_p . M_p is trusted as |z|^2 only above this (mpcqp_pair.hip); |K_p|^2 otherwise
@@ -214,8 +229,8 @@ using namespace quad;
 
 // ORD: the launch carries a pairing order (MpcqpSolveOpts.order): row i of the launch takes problem order[i].
 // WPB: wavefronts per workgroup (they share nothing).
-template <int NX, bool ORD, int WPB>
-__global__ void __launch_bounds__(64 * WPB, 1)
+template <int NX, bool ORD, int WPB, bool SLIM>
+__global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     mpcqp_quad_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ ge, const double *__restrict__ gx0, const double *__restrict__ ggoal,
                       double *__restrict__ oU, double *__restrict__ olam, int32_t *__restrict__ ostatus,
@@ -242,14 +257,18 @@ __global__ void __launch_bounds__(64 * WPB, 1)
         const int64_t o = ka.order[prob];
         prob = o < 0 ? 0 : (o >= batch ? batch - 1 : o);
     }
+    using CV = Carve<SLIM>;
+    constexpr int LDM = CV::LDM, PER = CV::PER;
     T *sm = (T *)smem_raw + (4 * wv + (rb >> 4)) * PER;
     const int n = ka.n, m = ka.m;
     const int row0 = l, row1 = l + NV;                // the two constraints of this lane
     const bool isc0 = row0 < m, isc1 = row1 < m;
     const T INF = HUGE_VAL;
     constexpr int GS = 33;  // the G image is stored by COLUMN with an odd stride
-    T *Gimg = sm + OFF_M, *Ml = sm + OFF_M, *LTimg = sm + OFF_LT, *Timg = sm + OFF_T, *kAv = sm + OFF_KA;
-    int *actv = reinterpret_cast<int *>(sm + OFF_ACT);
+    T *Gimg = sm + CV::OFF_M, *Ml = sm + CV::OFF_M;
+    T *LTp = sm + CV::OFF_LT + (l * (31 - l)) / 2 - (l + 1);  // slim: LTp[k] = entry (l, k) of L^-T, k > l
+    T *LTimg = sm + CV::OFF_LT, *Timg = sm + CV::OFF_T, *kAv = sm + CV::OFF_KA;  // roomy
+    int *actv = reinterpret_cast<int *>(sm + CV::OFF_ACT);
 
     // optional phase timestamps (developer probe, MpcqpSolveOpts.probe): long long[16] per problem, slots as mpcqp_pair.hip
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
@@ -441,7 +460,18 @@ __global__ void __launch_bounds__(64 * WPB, 1)
 
     if (isc0) st16(Ml + row0 * LDM, RM0);  // image of M: row-p broadcasts, the active rows in the refinement
     if (isc1) st16(Ml + row1 * LDM, RM1);
-    st16(LTimg + l * NV, RLt);  // the rows of L^-T leave the registers
+    // the rows of L^-T leave the registers. Slim: L^-T is upper triangular (the identity pushed through a forward substitution with a
+    // lower triangular factor): the strict upper part packed in LDS, the diagonal in a register
+    T ltd = T(0);
+    if constexpr (SLIM) {
+        static_for<0, NV>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            ltd = (l == k) ? RLt[k] : ltd;
+            if (k > l) LTp[k] = RLt[k];
+        });
+    } else {
+        st16(LTimg + l * NV, RLt);
+    }
     const T y0 = -wv_;          // y0 = -L^-1 q, component l
     T s0, s1, invn0, invn1;
     {
@@ -633,15 +663,25 @@ __global__ void __launch_bounds__(64 * WPB, 1)
             cT = full ? ((l == sl) ? inv : -(r * inv)) : T(0);
             cH = full ? -(hd * inv) : T(0);
             if (__ballot(drp) != 0ull) {
-                // slot ldrop leaves (its row T_l is in kAv). With W = T T' implicit, T_a -= (T_a . T_l / T_l . T_l) T_l
+                // slot ldrop leaves (its row T_l still sits in lane ldrop -- a partial step has no update of its own --, roomy: and in kAv).
+                // With W = T T' implicit, T_a -= (T_a . T_l / T_l . T_l) T_l
                 // (row l becomes exactly zero); the null space of the active rows gains the direction T_l:
                 // H += T_l T_l' / T_l . T_l.
                 T vv[NV];
-                ld16(vv, kAv);
+                T vl = T(0);
+                if constexpr (SLIM) {
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {  // (fetched from its lane: a rare trip, and LDS has no room for the row)
+                        vv[k] = row_get(RT[k], rb, ldrop);
+                        vl = (l == k) ? vv[k] : vl;
+                    }
+                } else {
+                    ld16(vv, kAv);
+                    vl = kAv[l];
+                }
                 const T tl = dot16(RT, vv);
                 const T tld = row_get(tl, rb, ldrop);
                 const T itl = fast_rcp(tld);
-                const T vl = kAv[l];
                 if (drp) {
                     zn = vl;
                     cT = (l == ldrop) ? T(-1) : (occ ? -tl * itl : T(0));
@@ -681,8 +721,10 @@ __global__ void __launch_bounds__(64 * WPB, 1)
             if (__ballot(partial) != 0ull) {
                 // partial step: the next trip removes slot lq from T (no update is pending for this row: RT is current)
                 const int cl = row_get(myact, rb, lq);
-                wsync();
-                if (partial && l == lq) st16(kAv, RT);
+                if constexpr (!SLIM) {
+                    wsync();
+                    if (partial && l == lq) st16(kAv, RT);
+                }
                 if (partial) {
                     if (l == (cl & 15)) {  // the row that leaves may be selected again
                         e0 = (cl < NV) ? sel0 : e0;
@@ -691,17 +733,20 @@ __global__ void __launch_bounds__(64 * WPB, 1)
                     dropping = true;
                     ldrop = lq;
                 }
-                wsync();
+                if constexpr (!SLIM) wsync();
             }
         }
         tick(5);
         if (__ballot(!finished) == 0ull) break;
         // ================================== multipliers by refinement, slacks re-evaluated
         // (rows that are already finished compute along and change nothing)
-        actv[l] = occ ? myact : 0;
-        wsync();
-        int aa[NV];
-        {
+        int aa[NV];  // constraint held by each slot (an empty one: row 0 with a zero coefficient)
+        if constexpr (SLIM) {
+            const int mine = occ ? myact : 0;
+            static_for<0, NV>([&](auto ac) { aa[decltype(ac)::value] = __builtin_amdgcn_update_dpp(0, mine, 0x150 + decltype(ac)::value, 0xf, 0xf, false); });
+        } else {
+            actv[l] = occ ? myact : 0;
+            wsync();
             const int4 *ap = reinterpret_cast<const int4 *>(actv);
 #pragma unroll
             for (int q = 0; q < NV / 4; ++q) {
@@ -744,11 +789,22 @@ __global__ void __launch_bounds__(64 * WPB, 1)
         const unsigned long long nr = __ballot(needref);
         if (nr != 0ull) {
             rho = (((unsigned)(nr >> rb) & 0xffffu) != 0u) ? rho : T(0);  // (rows that need none take a zero step: see the ratio test)
-            // dlam = -W rho_A = -T (T' rho_A)
-            st16(Timg + l * NV, RT);
-            wsync();
-            T uk;
-            {
+            // dlam = -W rho_A = -T (T' rho_A). (T' rho)_k = sum_a T_a[k] rho_a: lane a holds row a of T, so the sum runs over the
+            // lanes -- slim: sixteen row reductions, lane k keeps the k-th (a rare path); roomy: through an image of T in LDS
+            T uk = T(0);
+            if constexpr (SLIM) {
+                static_for<0, NV>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    T v = RT[k] * rho;
+                    v += dpp_mov<ROR8>(v);
+                    v += dpp_mov<ROR4>(v);
+                    v += dpp_mov<ROR2>(v);
+                    v += dpp_mov<ROR1>(v);
+                    uk = (l == k) ? v : uk;
+                });
+            } else {
+                st16(Timg + l * NV, RT);
+                wsync();
                 T tc[NV];
 #pragma unroll
                 for (int a = 0; a < NV; ++a) tc[a] = Timg[a * NV + l];
@@ -781,10 +837,17 @@ __global__ void __launch_bounds__(64 * WPB, 1)
             }
             dirty = dirty || off || neg;
         }
-        // u = L^-T y (component l; the rows of L^-T come back from their image)
+        // u = L^-T y (component l). Slim: the diagonal from its register, the strict upper triangle from its packed image
         auto primal = [&]() {
             T lt[NV];
-            ld16(lt, LTimg + l * NV);
+            if constexpr (SLIM) {
+                static_for<0, NV>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    lt[k] = (k > l) ? LTp[k > l ? k : l + 1] : ((k == l) ? ltd : T(0));
+                });
+            } else {
+                ld16(lt, LTimg + l * NV);
+            }
             return dot_bcast(y, lt, T(0));
         };
         if (!finished && done) {
@@ -812,7 +875,7 @@ __global__ void __launch_bounds__(64 * WPB, 1)
     const bool ok = (status == MPCQP_SOLVED);
     T lo0 = T(0), lo1 = T(0);
     if (olam) {  // multipliers by constraint: every occupied slot drops its multiplier at its row's place
-        T *lamv = Timg;
+        T *lamv = Ml;  // (the M image is dead: every row has finished; 32 doubles)
         lamv[row0] = T(0);
         lamv[row1] = T(0);
         wsync();
@@ -835,19 +898,21 @@ __global__ void __launch_bounds__(64 * WPB, 1)
 }
 
 // ------------------------------------------------------------ host side
-// true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from 2.25
-// problems per SIMD -- below that a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.1 against 20.6 us) -- to 16
-// per SIMD -- config 2: 4096 problems 22.5 against 24.8 us, 8192: 41.1 / 47.3, 16,384: 77.2 / 85.6; config 4: 4096: 29.7 / 33.9,
-// 8192: 53.2 / 56.6, 16,384: 91.9 / 91.0, 65,536: 324 / 305 (this kernel's 35.6 KB of LDS keep four wavefronts on a CU, the other's eight).
-static bool quad_pays(int64_t batch)
+static int device_simds()
 {
     static const int simds = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         return 4 * cus;
     }();
-    return 4 * batch > 9 * (int64_t)simds && batch <= 16 * (int64_t)simds;
+    return simds;
 }
+// true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from 2.25
+// problems per SIMD up -- below that a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.1 against 20.6 us). One
+// round (up to four problems per SIMD) runs the roomy carve: config 2 at 4096: 22.4 against 24.8 us; anything larger the slim one,
+// two wavefronts per SIMD: config 2 at 8192 / 16,384: 37.8 / 65.0 against 47.3 / 85.6 us; config 4 at 8192 / 16,384 / 65,536:
+// 45.5 / 74.0 / 231 against 56.9 / 90.9 / 305 us.
+static bool quad_pays(int64_t batch) { return 4 * batch > 9 * (int64_t)device_simds(); }
 
 bool quad_applies(const KernelArgs &ka)
 {
@@ -868,20 +933,24 @@ bool quad_eligible(const KernelArgs &ka, int64_t batch)
 template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     const int64_t waves = (batch + 3) / 4;
-    auto go = [&](auto kern, int wpb) {
-        const size_t bytes = (size_t)PER * 4 * sizeof(double) * wpb;
-        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpb), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
+    auto go = [&](auto kern, size_t per) {
+        const size_t bytes = per * 4 * sizeof(double);
+        hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
                            (const double *)ka.C.ptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
                            (const double *)ka.goal.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, batch);
     };
-#ifndef QUAD_WPB
-#define QUAD_WPB 1
-#endif
-    if (ka.order)
-        go(mpcqp_quad_kernel<NX, true, 1>, 1);
-    else
-        go(mpcqp_quad_kernel<NX, false, QUAD_WPB>, QUAD_WPB);
+    // one round (at most one wavefront per SIMD): the roomy carve; several rounds: the slim one, two wavefronts per SIMD
+    const bool slim = waves > device_simds();
+    if (ka.order) {
+        if (slim)
+            go(mpcqp_quad_kernel<NX, true, 1, true>, Carve<true>::PER);
+        else
+            go(mpcqp_quad_kernel<NX, true, 1, false>, Carve<false>::PER);
+    } else if (slim) {
+        go(mpcqp_quad_kernel<NX, false, 1, true>, Carve<true>::PER);
+    } else {
+        go(mpcqp_quad_kernel<NX, false, 1, false>, Carve<false>::PER);
+    }
     return (int)hipGetLastError();
 }
 

@@ -105,6 +105,37 @@ def test_every_horizon_and_tightness_against_the_oracle(nx, nu):
     assert drops > 0  # the partial-step / drop path really ran
 
 
+def test_launches_of_several_rounds_take_the_slim_carve():
+    """More than four problems per SIMD of the device (4097 and more on an MI355X): the kernel's instantiation with the 20-KB LDS
+    carve -- packed L^-T, T' rho by row sums, the leaving slot's row fetched by ds_bpermute -- two wavefronts per SIMD. Same
+    families as above at 4400 problems each (drops, partly empty second rows, inconsistent rows), against the oracle and, bit for
+    bit in the statuses and iteration counts, against the one-round instantiation on the same problems in chunks."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    batch = 4 * simds + 304
+    rng = np.random.default_rng(77)
+    drops = 0
+    for nx, nu, N, tight, lti in ((3, 1, 16, 0.05, False), (4, 1, 11, 0.05, True), (3, 2, 8, 0.2, False), (4, 1, 13, 0.2, True), (3, 1, 5, 3.0, False)):
+        w = _lean_family(rng, batch, nx, nu, N, tight, lti)
+        slim = solve_mpc_batch(W.to_batch_problem(w), return_multipliers=True)  # (default dispatch at this size)
+        torch.cuda.synchronize()
+        ok = _check_against_oracle(w, slim)
+        drops += int((slim.iters.cpu().numpy()[ok] > N * nu).sum())
+        # the same problems in two launches of one round each (the roomy carve)
+        parts = [solve_mpc_batch(W.to_batch_problem(shard_workload(w, r, 2)), flags=_capi.OPT_FOUR_PER_WAVE, return_multipliers=True) for r in range(2)]
+        torch.cuda.synchronize()
+        st = torch.cat([p.status for p in parts])
+        it = torch.cat([p.iters for p in parts])
+        U = torch.cat([p.U for p in parts])
+        assert torch.equal(st, slim.status) and torch.equal(it, slim.iters)
+        good = st == 0
+        assert float((U[good] - slim.U[good]).abs().max()) <= 1e-9 * max(1.0, float(U[good].abs().max()))
+    assert drops > 0
+
+
 def test_inconsistent_rows_are_never_reported_solved():
     """Problems whose rows are inconsistent with their bounds (generated consistent, then A and C replaced by their first step):
     the kernel's statuses are the oracle's, and what it reports solved is the oracle's plan (qpsolvers reports found=False for the
