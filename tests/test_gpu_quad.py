@@ -1,7 +1,8 @@
 """GPU tests (-m gpu): the four-problems-per-wavefront kernel (csrc/mpcqp_quad.hip) -- the cold fused build+solve of problems with
 terminal cost only and two state rows per step (BASELINE configs 1, 2, 4), replacing qpmpc/mpc_qp.py:53-149 and the
 qpsolvers call at qpmpc/solve_mpc.py:43 like the two-per-wavefront kernel it is dispatched next to. The dispatch takes it by
-batch size (2305 .. 16,384 problems on an MI355X); MPCQP_OPT_FOUR_PER_WAVE forces it, MPCQP_OPT_TWO_PER_WAVE keeps the other.
+batch size (2305 problems and more on an MI355X; beyond 4096 its slim LDS carve, two wavefronts per SIMD); MPCQP_OPT_FOUR_PER_WAVE
+forces it, MPCQP_OPT_TWO_PER_WAVE keeps the other.
 
 Tolerances (float64): plans |u - u_ref|_inf <= 1e-7 max(1, |u_ref|_inf) against the C oracle (BASELINE.json: 1e-6), observed
 ~1e-12; statuses equal; iteration counts equal to the two-per-wavefront kernel's (same method, same pivots)."""
