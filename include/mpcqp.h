@@ -166,7 +166,8 @@ typedef struct MpcqpProblem {
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
                                  rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way).
                                  MPCQP_EUNSUPPORTED where the kernel does not apply (other cost / constraint layouts, warm
-                                 starts, seed steps). */
+                                 starts, seed steps). The shared-model solves (mpcqp_solve_model_batch / _bounds_batch) take
+                                 it too, with the same batch-size rule, for every model with n <= 16, m <= 32. */
 
 /* MpcqpSolveOpts.warm_start */
 #define MPCQP_WARM_OPERATOR 1   /* begin from the stored active set AND operator N* (contract: matrices unchanged)          */

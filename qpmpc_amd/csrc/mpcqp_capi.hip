@@ -908,16 +908,20 @@ int mpcqp_solve_model_bounds_batch(const MpcqpDims *dims, const void *model, con
     // (a pairing order: the pair kernel's model mode only)
     if (ka.order && ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE)) || !pair_eligible(ka, MODE_MODEL, dims->dtype)))
         return MPCQP_EUNSUPPORTED;
+    const bool small = pair_eligible(ka, MODE_MODEL, dims->dtype);
+    if ((ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) &&
+        ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_TWO_PER_WAVE)) || !small))
+        return MPCQP_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const bool own_e = e && e->ptr;  // per-problem bounds: the pair kernel's model mode only
+    const bool own_e = e && e->ptr;  // per-problem bounds: the small-problem kernels' model mode only
     if (own_e) {
         if (ka.m < 1) return MPCQP_EINVAL;
         ka.e = *e;
-        if (!pair_eligible(ka, MODE_MODEL, dims->dtype)) return MPCQP_EUNSUPPORTED;
-        return launch_pair_model(ka, batch, st);
+        if (!small) return MPCQP_EUNSUPPORTED;
+        return quad_model_eligible(ka, batch) ? launch_quad_model(ka, batch, st) : launch_pair_model(ka, batch, st);
     }
-    if (!force_lds(ka.opt_flags) && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE_MODEL, dims->dtype))
-        return launch_pair_model(ka, batch, st);
+    if (!force_lds(ka.opt_flags) && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && small)
+        return quad_model_eligible(ka, batch) ? launch_quad_model(ka, batch, st) : launch_pair_model(ka, batch, st);
     if (!force_lds(ka.opt_flags) && w64_eligible(ka, MODE_MODEL, dims->dtype)) return launch_w64(ka, MODE_MODEL, dims->dtype, batch, st);
     Layout L;
     if ((rc = layout_for(ka, false, false, MODE_SOLVE, dims->dtype, L))) return rc;

@@ -243,6 +243,8 @@ int launch_pair(const KernelArgs &ka, int64_t batch, hipStream_t st);
 int launch_pair_model(const KernelArgs &ka, int64_t batch, hipStream_t st);  // shared model (ka.model)
 // small-problem kernel (mpcqp_quad.hip): four problems per wavefront, cold lean fused build+solve
 bool quad_applies(const KernelArgs &ka);                  // the kernel serves this launch's layout
+bool quad_model_eligible(const KernelArgs &ka, int64_t batch);  // shared-model launches of that layout
+int launch_quad_model(const KernelArgs &ka, int64_t batch, hipStream_t st);
 bool quad_eligible(const KernelArgs &ka, int64_t batch);  // ... and the dispatch takes it (batch size, MPCQP_OPT_TWO / FOUR_PER_WAVE)
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront

@@ -229,11 +229,13 @@ using namespace quad;
 
 // ORD: the launch carries a pairing order (MpcqpSolveOpts.order): row i of the launch takes problem order[i].
 // WPB: wavefronts per workgroup (they share nothing).
-template <int NX, bool ORD, int WPB, bool SLIM>
+// MODEL: the launch shares one factored model (mpcqp_factor_model: gA points at it); the per-problem vectors are x0, goal, targets and,
+//        optionally, the bounds e. No build, no factorisation: M, L^-T and the linear maps of h and w are read from the model.
+template <int NX, bool ORD, int WPB, bool SLIM, bool MODEL = false>
 __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     mpcqp_quad_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ ge, const double *__restrict__ gx0, const double *__restrict__ ggoal,
-                      double *__restrict__ oU, double *__restrict__ olam, int32_t *__restrict__ ostatus,
+                      const double *__restrict__ gtgt, double *__restrict__ oU, double *__restrict__ olam, int32_t *__restrict__ ostatus,
                       int32_t *__restrict__ oiters, const KernelArgs ka, const int64_t batch)
 {
     using T = double;
@@ -280,9 +282,51 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     };
     tick(0);
 
+    T hval0, hval1;
+    bool notpd = false;
+    T RM0[NV], RM1[NV], RLt[NV];
+    T wv_ = T(0);  // w = L^-1 q, component l
+    if constexpr (MODEL) {
+        // rows of M and of L^-T straight from the model (4 KB, read by every wavefront of the launch: L1/L2), h = e - Hx x0 and
+        // w = L^-1 q = Wx x0 - Wg goal - Wt targets from the model's linear maps (mpcqp_pair.hip's model mode, four to a wavefront)
+        const T *model = gA;
+        const ModelLayout ml = make_model_layout(ka.nx, ka.N, n, m);
+        const int nxr = ka.nx, nT = ka.N * ka.nx;
+        const T *x0 = gx0 + prob * ka.x0.batch_stride;
+        const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
+        const T *tgt = gtgt ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        notpd = model[ml.total] != T(0);
+        {
+            T r0[NV], r1[NV];
+            ld16(r0, model + ml.off_M + (size_t)(isc0 ? row0 : 0) * NV);
+            ld16(r1, model + ml.off_M + (size_t)(isc1 ? row1 : 0) * NV);
+            ld16(RLt, model + ml.off_LinvT + (size_t)l * NV);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                RM0[k] = isc0 ? r0[k] : T(0);
+                RM1[k] = isc1 ? r1[k] : T(0);
+            }
+        }
+        // the bounds come with the model, or per problem (mpcqp_solve_model_bounds_batch: matrices shared, e moving)
+        auto bound = [&](int row, bool isc) {
+            if (!isc) return INF;
+            const int mkr = ka.mk, kq = mkr == 2 ? row >> 1 : row / mkr;
+            T hh = ge ? ge[prob * ka.e.batch_stride + kq * ka.e.step_stride + (row - kq * mkr)] : model[ml.off_e + row];
+            for (int c = 0; c < nxr; ++c) hh -= model[ml.off_Hx + (size_t)row * nxr + c] * x0[c];
+            return hh;
+        };
+        hval0 = bound(row0, isc0);
+        hval1 = bound(row1, isc1);
+        for (int c = 0; c < nxr; ++c) wv_ += model[ml.off_Wx + (size_t)l * nxr + c] * x0[c];
+        if ((ka.flags & MPCQP_Q_TERMINAL) && goal)
+            for (int c = 0; c < nxr; ++c) wv_ -= model[ml.off_Wg + (size_t)l * nxr + c] * goal[c];
+        if ((ka.flags & MPCQP_Q_STAGE) && tgt)
+            for (int j2 = 0; j2 < nT; ++j2) wv_ -= model[ml.off_Wt + (size_t)l * nT + j2] * tgt[j2];
+        tick(1);
+    } else {
     // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
     T Pr[NV];  // row l of P, then of L
-    T hval0, hval1, qa;
+    T qa;
     {
         constexpr int nx = NX;
         const int nu = ka.nu, N = ka.N;
@@ -412,9 +456,6 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     //   x[k]    -= (x[j] / L_jj) L[k][j], x[j] /= L_jj   for the rows x = G_l, G_{l+16}, e_l: -> M_l, M_{l+16}, (L^-T)_l
     //   q_k     -= L[k][j] w_j, w_j = q_j / L_jj         (q_k in lane k: L[k][j] is local, w_j the broadcast)
     // L[k][j] of lane k is a DPP row broadcast; the four FMA streams are independent of each other.
-    bool notpd = false;
-    T RM0[NV], RM1[NV], RLt[NV];
-    T wv_ = T(0);  // w = L^-1 q, component l
     {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -450,6 +491,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         });
         wsync();  // the M image below reuses the G image
     }
+    }  // (!MODEL)
     tick(2);
     tick(3);
     int status = MPCQP_MAX_ITER, iters = 0;
@@ -937,7 +979,8 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
         const size_t bytes = per * 4 * sizeof(double);
         hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), bytes, st, (const double *)ka.A.ptr, (const double *)ka.B.ptr,
                            (const double *)ka.C.ptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
-                           (const double *)ka.goal.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, batch);
+                           (const double *)ka.goal.ptr, (const double *)nullptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters,
+                           ka, batch);
     };
     // one round (at most one wavefront per SIMD): the roomy carve; several rounds: the slim one, two wavefronts per SIMD
     const bool slim = waves > device_simds();
@@ -957,6 +1000,38 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     return ka.nx == 3 ? launch_quad_t<3>(ka, batch, st) : launch_quad_t<4>(ka, batch, st);
+}
+
+// Shared-model launches (mpcqp_solve_model_batch / _bounds_batch): any cost and constraint layout the model was factored from, as
+// long as the condensed problem fits the rows (the caller has checked pair_eligible(ka, MODE_MODEL)).
+bool quad_model_eligible(const KernelArgs &ka, int64_t batch)
+{
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.warm_state || (ka.opt_flags & (MPCQP_OPT_TWO_PER_WAVE | MPCQP_OPT_SEED_VIOLATED)))
+        return false;
+    return (ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) || quad_pays(batch);
+}
+
+int launch_quad_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    const int64_t waves = (batch + 3) / 4;
+    auto go = [&](auto kern, size_t per) {
+        const size_t bytes = per * 4 * sizeof(double);
+        hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), bytes, st, (const double *)ka.model, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr, (const double *)ka.goal.ptr,
+                           (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, batch);
+    };
+    const bool slim = waves > device_simds();
+    if (ka.order) {
+        if (slim)
+            go(mpcqp_quad_kernel<3, true, 1, true, true>, Carve<true>::PER);
+        else
+            go(mpcqp_quad_kernel<3, true, 1, false, true>, Carve<false>::PER);
+    } else if (slim) {
+        go(mpcqp_quad_kernel<3, false, 1, true, true>, Carve<true>::PER);
+    } else {
+        go(mpcqp_quad_kernel<3, false, 1, false, true>, Carve<false>::PER);
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace mpcqp

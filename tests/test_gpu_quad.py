@@ -175,6 +175,86 @@ def test_small_and_ragged_batches_and_a_pairing_order():
     assert torch.equal(ref.status, got.status) and torch.equal(ref.iters, got.iters) and torch.equal(ref.U, got.U)
 
 
+@pytest.mark.parametrize("family", ["humanoid_4096", "humanoid_9000", "wip12", "triple"])
+def test_shared_model_launches_four_per_wavefront(family):
+    """mpcqp_solve_model_batch on a model factored once (mpc_qp.py:129-163 taken to its end): the dispatch takes this layout from
+    2305 problems (forced below); it agrees with the two-per-wavefront launch of the same model and with the C oracle. wip12 has
+    a stage cost and input rows: the model mode takes every layout whose condensed problem fits the rows."""
+    from qpmpc_amd import SharedModel, _capi
+    from qpmpc_amd import workloads as W
+
+    if family.startswith("humanoid"):
+        w = W.humanoid_batch(int(family.split("_")[1]))
+    elif family == "triple":
+        w = W.triple_integrator_batch(777, heterogeneous=False)
+    else:
+        w = W.wip_batch(515, N=12, sampling_period=0.1)
+        w["x0"][:64, 1] += 0.25  # some loops hit the input box
+        ts = np.stack([w["pendulum"].target_states(x, 0.5) for x in w["x0"]])
+        w["goal"], w["targets"] = ts[:, -4:], ts[:, :-4]
+    bp = W.to_batch_problem(w)
+    model = SharedModel(bp)
+    args = (bp.initial_state, bp.goal_state, bp.target_states)
+    four = model.solve(*args, return_multipliers=True, flags=_capi.OPT_FOUR_PER_WAVE)
+    two = model.solve(*args, return_multipliers=True, flags=_capi.OPT_TWO_PER_WAVE)
+    torch.cuda.synchronize()
+    assert torch.equal(four.status, two.status) and torch.equal(four.iters, two.iters)
+    ok = two.status.cpu().numpy() == 0
+    assert ok.mean() > 0.9
+    Uf, Ut = four.U.cpu().numpy()[ok], two.U.cpu().numpy()[ok]
+    assert (np.abs(Uf - Ut) / np.maximum(1.0, np.abs(Ut).max(axis=1, keepdims=True))).max() < 1e-9
+    lf, lt = four.multipliers.cpu().numpy()[ok], two.multipliers.cpu().numpy()[ok]
+    assert np.abs(lf - lt).max() <= 1e-6 * max(1.0, np.abs(lt).max())
+    if family.startswith("humanoid"):  # large enough for the default rule
+        dflt = model.solve(*args)
+        torch.cuda.synchronize()
+        assert torch.equal(dflt.U, four.U) and torch.equal(dflt.status, four.status)
+    Uo, _, sto, _ = oracle.solve_workload(w, count=64)
+    okc = sto == 0
+    assert np.array_equal(okc, four.status.cpu().numpy()[:64] == 0)
+    scale = np.maximum(1.0, np.abs(Uo[okc]).max(axis=1, keepdims=True))
+    assert (np.abs(four.U.cpu().numpy()[:64][okc] - Uo[okc]) / scale).max() <= 1e-6
+
+
+def test_shared_model_with_bounds_per_problem_and_an_order():
+    """mpcqp_solve_model_bounds_batch (matrices shared, inequality vectors per problem: update_constraint_vector, mpc_qp.py:151-163)
+    through this layout: equal to the fused build of every problem, ragged batch, and bit for bit under a pairing order."""
+    from qpmpc_amd import BatchMPCProblem, SharedModel, _capi, solve_mpc_batch
+
+    rng = np.random.default_rng(15)
+    B, N, T = 2999, 16, 0.1
+    A = np.array([[1.0, T, T**2 / 2.0], [0.0, 1.0, T], [0.0, 0.0, 1.0]])
+    Bm = np.array([T**3 / 6.0, T**2 / 2.0, T]).reshape((3, 1))
+    Cm = np.array([[1.0, 0.0, -0.0856], [-1.0, 0.0, 0.0856]])
+    centre = rng.uniform(-0.2, 0.2, (B, N, 1))
+    e = np.concatenate([centre + rng.uniform(0.03, 0.2, (B, N, 1)), -centre + rng.uniform(0.03, 0.2, (B, N, 1))], axis=2)
+    x0 = np.concatenate([rng.uniform(-0.05, 0.05, (B, 1)), rng.uniform(-0.1, 0.1, (B, 1)), rng.uniform(-0.2, 0.2, (B, 1))], axis=1)
+    goal = np.concatenate([rng.uniform(-0.3, 0.3, (B, 1)), np.zeros((B, 2))], axis=1)
+    prob = BatchMPCProblem(A, Bm, Cm, None, e, N, 1.0, None, 1e-3, x0, goal_state=goal)
+    fused = solve_mpc_batch(prob, flags=_capi.OPT_TWO_PER_WAVE)
+    model = SharedModel(prob)
+    assert model.per_problem_bounds
+    run = model.prepare(prob)  # 2999 problems: the default rule takes four per wavefront
+    run.launch()
+    forced = model.prepare(prob, flags=_capi.OPT_FOUR_PER_WAVE)
+    forced.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(run.U, forced.U) and torch.equal(run.status, forced.status)
+    st = fused.status.cpu().numpy()
+    assert (run.status.cpu().numpy() == st).all()
+    ok = st == 0
+    assert ok.sum() > B // 2
+    Uf, Um = fused.U.cpu().numpy()[ok], run.U.cpu().numpy()[ok]
+    assert (np.abs(Uf - Um) / np.maximum(1.0, np.abs(Uf).max(axis=1, keepdims=True))).max() < 1e-8
+    order = torch.randperm(B, device="cuda").to(torch.int32)
+    perm = model.prepare(prob, flags=_capi.OPT_FOUR_PER_WAVE, order=order)
+    perm.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(perm.status, run.status) and torch.equal(perm.iters, run.iters) and torch.equal(perm.U, run.U)
+    with pytest.raises(Exception, match="-6"):  # next to another override
+        model.prepare(prob, flags=_capi.OPT_FOUR_PER_WAVE | _capi.OPT_ONE_PER_WAVE).launch()
+
+
 def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
     """MPCQP_OPT_FOUR_PER_WAVE with a stage cost, with input rows, with a warm state or next to another override:
     MPCQP_EUNSUPPORTED before any launch."""
