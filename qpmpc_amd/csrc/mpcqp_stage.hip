@@ -379,25 +379,27 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
     // still make P indefinite). A pivot that is not positive -> MPCQP_NOT_PD, like the condensed kernels' Cholesky.
     bool notpd = false;
     if (!reuse) {
-        // (round 4) Every 4 x 4 matrix is spread over ALL 64 lanes by COLUMN: the 16-lane row rho = lane / 16 holds column rho, its
-        // quad q = (lane / 4) % 4 element [q][rho] (four copies) -- the layout of a serial sweep's vector, once per column. A
-        // product M' v of a matrix known by its coefficients (A, B: from memory; A_cl: formed in registers) with a column held
-        // this way is four v_fmac_f64_dpp row_newbcast (sweep_chain), all four columns at once:
-        //   rows of P A and P B from P's columns (P is symmetric) -> the four P B through v_readlane into scalars -> S, B'PA, K
-        //   by FMAs with a scalar operand, identical in every lane -> K_rho by four row-masked DPP moves -> A_cl ->
-        //   P_k = Q + A_cl' (P A), whose right factor is needed by column: ONE 8-byte LDS write + five reads per lane, issued
-        //   right after the first product and hidden behind everything up to the last. ~85 instructions per step, no exec masking
-        //   (every store is unmasked: the copies of a value are bitwise equal), against ~140 with DPP rotations, quad
-        //   broadcasts, masked stores and register copies before.
-        const int rho = lane >> 4, q = (lane >> 2) & 3;
-        const bool inq = q < NX, inr = rho < NX, in = inq && inr;
-        double P = (in && q == rho) ? wt : 0.0;  // P[q][rho]
+        // (round 5) The recursion runs on the MATRIX CORES: v_mfma_f64_4x4x4 multiplies 4 x 4 float64 matrices held ONE ELEMENT PER
+        // LANE -- operand A[i][k] in lane i + 16 k, operand B[k][j] in lane j + 16 k, result D[i][j] in lane j + 16 i, the same in
+        // each of the four lane quads b = (lane / 4) % 4 of a 16-lane row (four independent products; here four copies of one).
+        // (tools/ubench/mfma_f64_4x4.hip prints that layout; 17 cycles per instruction, 28 from a result to its dependent product.)
+        // A result is already in B-operand order, and read as an A operand it is its own TRANSPOSE, so a step is a chain of
+        // products with no lane exchange at all (element [r][c] of every matrix in lane 16 r + c, r = lane / 16, c = lane % 4):
+        //   T = P A, PB = P B (P symmetric: P as the A operand)   BPA = (PB)' A, S = w_u I + (PB)' B   K = S^-1 BPA
+        //   A_cl = A - B K   P_k = Q + (A_cl' T + T' A_cl) / 2  (the two products are exact mirrors: P stays exactly symmetric)
+        // B is held with its columns repeated (B[r][c % NU]), which repeats the rows of BPA, S and K the same way: every lane
+        // has the entries it needs. ~30 instructions per step (six or eight on the matrix pipe, which runs beside the vector
+        // pipe the solving wavefront of the same SIMD lives on) against ~85 of float64 DPP arithmetic in round 4.
+        const int r = lane >> 4, c = lane & 3;
+        const bool in = r < NX && c < NX;
+        auto mm = [](double a, double b, double cc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, cc, 0, 0, 0); };
+        double P = (in && r == c) ? wt : 0.0;  // P[r][c]
         // operands are requested RD steps ahead into a register ring (a step is shorter than an HBM round trip)
         constexpr int RD = 3;
-        double Acn[RD][4], Ann[RD], Bln[RD][4 * NU], Bqn[RD][NU];  // A[l][q]; A[q][rho]; B[l][u] at l NU + u; B[q][u]
+        double Amn[RD], Brn[RD][NU], Bik[RD];  // A[r][c]; B[r][u]; (NU = 2) -B[c][r], r < NU: the A operand of B K
         // PIPE: the factor wavefront writes its factor to the WORKSPACE, and a load issued behind those stores would wait for
         // them (vector memory operations retire in order): the operands come through LDS instead, one bulk copy up front --
-        // A transposed and both padded to four rows (zeros), so that a lane's values are two 16-byte reads
+        // A transposed and both padded to four rows (zeros)
         const double *la = rsc + 32, *lb = la;
         const int sAl = sA ? 16 : 0, sBl = sB ? 4 * NU : 0;
         if constexpr (PIPE) {
@@ -434,33 +436,16 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
         auto request = [&](int d, int k) {
             if constexpr (PIPE) {
                 const double *A = la + k * sAl, *B = lb + k * sBl;
-                const D2 *a2 = (const D2 *)(A + q * 4), *b2 = (const D2 *)B;
+                Amn[d] = A[c * 4 + r];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const D2 v = a2[h];
-                    Acn[d][2 * h] = v[0];
-                    Acn[d][2 * h + 1] = v[1];
-                }
-                Ann[d] = A[rho * 4 + q];
-#pragma unroll
-                for (int h = 0; h < 2 * NU; ++h) {
-                    const D2 v = b2[h];
-                    Bln[d][2 * h] = v[0];
-                    Bln[d][2 * h + 1] = v[1];
-                }
-#pragma unroll
-                for (int u = 0; u < NU; ++u) Bqn[d][u] = B[q * NU + u];
+                for (int u = 0; u < NU; ++u) Brn[d][u] = B[r * NU + u];
+                Bik[d] = (NU > 1 && r < NU) ? -B[c * NU + (r < NU ? r : 0)] : 0.0;
             } else {
                 const double *A = gA + k * sA, *B = gB + k * sB;
+                Amn[d] = in ? A[r * NX + c] : 0.0;
 #pragma unroll
-                for (int l = 0; l < 4; ++l) Acn[d][l] = (l < NX && inq) ? A[l * NX + q] : 0.0;
-                Ann[d] = in ? A[q * NX + rho] : 0.0;
-#pragma unroll
-                for (int l = 0; l < 4; ++l)
-#pragma unroll
-                    for (int u = 0; u < NU; ++u) Bln[d][l * NU + u] = l < NX ? B[l * NU + u] : 0.0;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) Bqn[d][u] = inq ? B[q * NU + u] : 0.0;
+                for (int u = 0; u < NU; ++u) Brn[d][u] = r < NX ? B[r * NU + u] : 0.0;
+                Bik[d] = (NU > 1 && r < NU && c < NX) ? -B[c * NU + (r < NU ? r : 0)] : 0.0;
             }
         };
 #pragma unroll
@@ -468,110 +453,59 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             request(d, N - 1 - d >= 0 ? N - 1 - d : 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        const int cu = c & (NU - 1), ru = r & (NU - 1);
         auto step = [&](int d, int k) {
-            // rows of P A and of P B: T[q] = (P A)[rho][q], PBr[u] = (P B)[rho][u]
-            double T = 0.0, PBr[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) PBr[u] = 0.0;
-            sweep_chain(T, PBr, P, Acn[d], Bln[d]);
-            // ... P A again by column, for the last product: through LDS, the read comes back while the rest runs
-            rsc[rho * 4 + q] = T;
-            lsync();
-            const double Tq = rsc[q * 4 + rho];  // (P A)[q][rho]
-            double Tc[4];                        // (P A)[l][q]: column q, for the mirrored sum below
-#pragma unroll
-            for (int l = 0; l < 4; ++l) Tc[l] = rsc[l * 4 + q];
-            double PBs[4][NU];  // P B, every entry in every lane (scalars)
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) PBs[l][u] = rl(PBr[u], 16 * l);
-            // S[u][v] = w_u delta + sum_l B[l][u] PB[l][v] ; BPA[u] = (B' P A)[u][q] = sum_l PB[l][u] A[l][q]
-            double BPA[NU], S[NU * NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                BPA[u] = 0.0;
-#pragma unroll
-                for (int v = 0; v < NU; ++v) S[u * NU + v] = (u == v) ? wu : 0.0;
-            }
-#pragma unroll
-            for (int l = 0; l < 4; ++l)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    BPA[u] += PBs[l][u] * Acn[d][l];
-#pragma unroll
-                    for (int v = 0; v < NU; ++v) S[u * NU + v] += Bln[d][l * NU + u] * PBs[l][v];
-                }
-            double Si[NU * NU];
+            const double Am = Amn[d];
+            const double Bk = (NU == 1 || cu == 0) ? Brn[d][0] : Brn[d][NU - 1];  // B[r][c % NU]
+            const double T = mm(P, Am, 0.0);    // (P A)[r][c]
+            const double PB = mm(P, Bk, 0.0);   // (P B)[r][c % NU]
+            const double BPA = mm(PB, Am, 0.0); // (B' P A)[r % NU][c]
+            const double Sm = mm(PB, Bk, 0.0);  // (B' P B)[r % NU][c % NU]
+            double Si[NU * NU], Kd, Aclo;       // K[r % NU][c], Acl[r][c]
+            auto si = [&](int i) { return Si[i < NU * NU ? i : 0]; };  // (an index the NU = 1 instantiation never takes stays in range)
             if constexpr (NU == 1) {
-                notpd |= !(S[0] > 0.0);
-                Si[0] = frcp(S[0]);
+                const double S = Sm + wu;
+                notpd |= !(S > 0.0);
+                Si[0] = frcp(S);
+                Kd = Si[0] * BPA;
+                Aclo = Am - Bk * Kd;
             } else {
-                const double det = S[0] * S[3] - S[1] * S[2], id = frcp(det);
-                notpd |= !(S[0] > 0.0) | !(det > 0.0);
-                Si[0] = S[3] * id;
-                Si[1] = -S[1] * id;
-                Si[2] = -S[2] * id;
-                Si[3] = S[0] * id;
+                const double s00 = rl(Sm, 0) + wu, s01 = rl(Sm, 1), s10 = rl(Sm, 16), s11 = rl(Sm, 17) + wu;
+                const double det = s00 * s11 - s01 * s10, id = frcp(det);
+                notpd |= !(s00 > 0.0) | !(det > 0.0);
+                Si[0] = s11 * id;
+                Si[1] = -s01 * id;
+                Si[2] = -s10 * id;
+                Si[3] = s00 * id;
+                // K = S^-1 BPA and A_cl = A - B K as two more products: A operand [i][k] in lane i + 16 k
+                const double SiA = r < NU ? (cu == 0 ? (r == 0 ? si(0) : si(1)) : (r == 0 ? si(2) : si(3))) : 0.0;  // Si[c % 2][r]
+                Kd = mm(SiA, BPA, 0.0);
+                Aclo = mm(Bik[d], Kd, Am);
             }
-            // K[u] = K[u][q] in quad q of every row; Kr[u] = K[u][rho] in every lane of row rho
-            double Kk[NU], Kr[NU];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                double a = 0.0;
-#pragma unroll
-                for (int v = 0; v < NU; ++v) a += Si[u * NU + v] * BPA[v];
-                Kk[u] = a;
-                Kr[u] = 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < NU; ++u) row_gather(Kr[u], Kk[u]);
-            // Acl[q][rho] (this lane's element) and column q of Acl (the coefficients of the last product)
-            double Aclo = Ann[d], Acc[4];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) Aclo -= Bqn[d][u] * Kr[u];
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                double a = Acn[d][l];
-#pragma unroll
-                for (int u = 0; u < NU; ++u) a -= Bln[d][l * NU + u] * Kk[u];
-                Acc[l] = a;
-            }
-            // P_k[q][rho] = Q_k + sum_l Acl[l][q] (P A)[l][rho]   (x_0 is data: Q_0 = 0), symmetrised: the lane forms the sum of
-            // [q][rho] AND that of [rho][q] (the same products in the same order as its mirror lane: exactly symmetric without a
-            // second exchange) -- without it the antisymmetric rounding error is multiplied by ~|Acl| |A| per step (1e-6 after 40)
-            double s1 = 0.0, s2 = 0.0;
-            sweep_chain2(s1, s2, Tq, Aclo, Acc, Tc);
-            const double Pn = 0.5 * (s1 + s2) + ((in && q == rho && k >= 1) ? wx : 0.0);
+            // P_k = Q_k + A_cl' (P A), symmetrised (x_0 is data: Q_0 = 0): the mirrored product forms the same sums in the same
+            // order, so the mean is exactly symmetric -- without it the antisymmetric rounding error is multiplied by ~|Acl| |A|
+            // per step (1e-6 after 40)
+            const double s1 = mm(Aclo, T, 0.0), s2 = mm(T, Aclo, 0.0);
+            const double Pn = 0.5 * (s1 + s2) + ((in && r == c && k >= 1) ? wx : 0.0);
             if constexpr (SERIAL) {
-                // every lane stores (the copies of a value are bitwise equal; zero outside NX x NX); PIPE: straight into the next
+                // every lane stores (the four quads hold bitwise equal copies; zero outside NX x NX); PIPE: straight into the next
                 // launch's image in the workspace (the LDS image belongs to the solving wavefront)
                 double *f = (PIPE ? img_next : Fl) + k * FS;
-                f[FA + q * 4 + rho] = Aclo;
-                f[FAT + rho * 4 + q] = Aclo;
+                f[FA + r * 4 + c] = Aclo;
+                f[FAT + c * 4 + r] = Aclo;
+                double bsv = 0.0;  // -(S^-1 B')[u][r], u = c % NU: the backward sweep's feed-forward row, S^-1 folded in here
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    double bsv = 0.0;  // -(S^-1 B')[u][q]: the backward sweep's feed-forward row, S^-1 folded in here
-#pragma unroll
-                    for (int v = 0; v < NU; ++v) bsv -= Si[u * NU + v] * Bqn[d][v];
-                    f[FKN + q * NU + u] = -Kk[u];
-                    f[FBS + q * NU + u] = bsv;
-                    f[FBO + q * NU + u] = Bqn[d][u];
-                }
-#pragma unroll
-                for (int i = 0; i < NU * NU; ++i) f[FSI + i] = Si[i];
+                for (int v = 0; v < NU; ++v) bsv -= ((NU == 1 || cu == 0) ? si(v) : si(NU + v)) * Brn[d][v];
+                f[FKN + c * NU + ru] = -Kd;
+                f[FBS + r * NU + cu] = bsv;
+                f[FBO + r * NU + cu] = Bk;
+                f[FSI + ru * NU + cu] = ru == 0 ? (cu == 0 ? si(0) : si(1)) : (cu == 0 ? si(2) : si(3));
             } else {
                 const int64_t w = wg(k);
-                if ((lane & 3) == 0) {
-                    if (in) Acl[w * NX * NX + q * NX + rho] = Aclo;
-                    if (rho == 0 && inq) {
-#pragma unroll
-                        for (int u = 0; u < NU; ++u) Kg[w * NU * NX + u * NX + q] = Kk[u];
-                    }
-                    if (lane == 0) {
-#pragma unroll
-                        for (int i = 0; i < NU * NU; ++i) Sinv[w * NU * NU + i] = Si[i];
-                    }
+                if ((lane & 12) == 0) {  // the first quad of every row
+                    if (in) Acl[w * NX * NX + r * NX + c] = Aclo;
+                    if (r < NU && c < NX) Kg[w * NU * NX + r * NX + c] = Kd;
+                    if (r < NU && c < NU) Sinv[w * NU * NU + r * NU + c] = r == 0 ? (c == 0 ? si(0) : si(1)) : (c == 0 ? si(2) : si(3));
                 }
             }
             P = Pn;
