@@ -43,6 +43,9 @@
 namespace mpcqp {
 
 // (developer knob: tools/ab_unit.sh builds variants)
+#ifndef STAGE_PRIO
+#define STAGE_PRIO 3
+#endif
 #ifndef STAGE_SRD
 #define STAGE_SRD 4
 #endif
@@ -53,15 +56,16 @@ namespace mpcqp {
 #define STAGE_SROWL (PIPE ? 16 : 64)
 #endif
 #ifndef STAGE_PW
-// problems per workgroup of the pipelined instantiation (when four of them fit the CU's LDS; else 1). 4: eight wavefronts, the
-// solving wavefront of problem j is wavefront j, its factor wavefront j + 4 -- the dispatcher deals a workgroup's wavefronts
-// round-robin over the four SIMDs, so the two wavefronts of a problem SHARE a SIMD and each SIMD is a closed system. 1: two
-// wavefronts per workgroup on neighbouring SIMDs, every SIMD hosting the solving wavefront of one problem and the factor
-// wavefront of another. Measured on config 3 (tools/probe_config3_loop.py 1024 50): with 1 the workgroups of a CU split into
-// fast and slow ones (solving wavefront 36 k ... 51 k cycles, factor wavefront 34 k), with 4 all take the same 46 k -- and
-// the period is 22.5 against 22.0 us: either way a SIMD issues one solving and one factor wavefront's instructions per
-// period (~10 k instructions), which is what the period costs. Default 1 (no lock step between problems, a quarter of the LDS).
-#define STAGE_PW 1
+// problems per workgroup of the pipelined instantiation (4 when four of them fit the CU's LDS; else 1).
+// 1: two wavefronts per workgroup, the problem's solving wavefront and its factor wavefront, on neighbouring SIMDs: every SIMD
+//    hosts the solving wavefront of one problem and the factor wavefront of another.
+// 4 (round 5): FIVE wavefronts -- four solving ones and ONE factor wavefront for all four problems: v_mfma_f64_4x4x4 carries four
+//    independent products, one per lane quad of a 16-lane row, so quad b of the factor wavefront runs the recursion of problem b
+//    on the instruction stream that served one problem before. The chip issues a quarter of the factor instructions, three of
+//    four solving wavefronts have their SIMD to themselves, and the one that shares issues first (s_setprio).
+//    (Round 4's variant of 4 -- eight wavefronts, a problem's two on ONE SIMD -- made every workgroup as slow as the slow ones
+//    of 1: a SIMD issued one solving and one factor wavefront's instructions per period either way.)
+#define STAGE_PW 4
 #endif
 #ifndef STAGE_DBG
 #define STAGE_DBG 0 /* timing experiments only (wrong results): 1 no re-requests, 2 no stores, 4 no arithmetic in the serial sweeps */
@@ -243,7 +247,7 @@ struct StageArgs {
 static_assert(offsetof(StageArgs, ka) == 0, "the kernel argument block starts with KernelArgs");
 
 template <int NX, int NU, bool SERIAL, bool PIPE, bool WARM, int PWT = 1>
-__global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 2) mpcqp_stage_kernel(const StageArgs sa_)
+__global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PWT == 4 ? 1 : 2) mpcqp_stage_kernel(const StageArgs sa_)
 {
     const KernelArgs &ka_ = sa_.ka;
     // ONE PERIOD = one build + solve (+ the fused plant epilogue). A launch runs ka.ep_periods of them back to back
@@ -272,9 +276,19 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
     extern __shared__ __attribute__((aligned(16))) unsigned char stage_smem_all[];
     unsigned char *stage_smem = stage_smem_all + (PW > 1 ? (size_t)(wvi % PW) * (size_t)sa_.lds_problem : 0);
     const int lane = tid & 63;
-    const int sq = (lane >> 2) & 3;  // (serial sweeps: the quad of a 16-lane row that owns component sq of the running vector)
+    // serial sweeps: the running vector sits the way the matrix cores take a B operand (and return a result): component sq in
+    // every lane of the 16-lane row sq; sc: the column of a matrix element this lane fetches as an A operand
+    const int sq = lane >> 4, sc = lane & 3;
     const bool sqin = sq < NX;
+    auto mm44 = [](double a, double b, double cc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, cc, 0, 0, 0); };
     const bool factor_wave = PIPE && wvi >= PW;
+    if constexpr (PIPE && PW == 4) {  // the solving wavefronts are the period's critical path: the one that shares its SIMD with the
+                                      // factor wavefront issues first, the factor wavefront fills the gaps
+        if (factor_wave)
+            __builtin_amdgcn_s_setprio(0);
+        else
+            __builtin_amdgcn_s_setprio(STAGE_PRIO);
+    }
     const int N = ka.N, mk = ka.mk, maxq = wl.maxq;
     const int L = (N + 63) / 64;                    // steps per chunk
     const int k0 = lane * L < N ? lane * L : N;     // this lane's chunk [k0, k1)
@@ -393,6 +407,18 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
         const int r = lane >> 4, c = lane & 3;
         const bool in = r < NX && c < NX;
         auto mm = [](double a, double b, double cc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, cc, 0, 0, 0); };
+        // SF: ONE factor wavefront for the workgroup's four problems -- quad b = (lane / 4) % 4 of every row runs problem b (the
+        // products of the four quads are independent; every other instruction of a step is per lane): per-lane pointers
+        constexpr bool SF = PIPE && PW == 4;
+        const int quad = (lane >> 2) & 3;
+        const int64_t lds_pd = sa_.lds_problem / (int64_t)sizeof(double);
+        double *imgq = img_next;                              // where this lane's problem takes its next factor
+        const double *laq = rsc + 32 + (SF ? quad * lds_pd : 0);  // ... and finds its operands (PIPE)
+        if constexpr (SF) {
+            int64_t pq = (int64_t)blockIdx.x * PW + quad;
+            pq = pq < sa_.batch ? pq : sa_.batch - 1;  // (the last workgroup may hold fewer than four problems: a quad repeats the last)
+            imgq = wsbase + pq * wl.total + wl.Fimg + (int64_t)(slot ^ 1) * N * FS;
+        }
         double P = (in && r == c) ? wt : 0.0;  // P[r][c]
         // operands are requested RD steps ahead into a register ring (a step is shorter than an HBM round trip)
         constexpr int RD = 3;
@@ -400,38 +426,58 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
         // PIPE: the factor wavefront writes its factor to the WORKSPACE, and a load issued behind those stores would wait for
         // them (vector memory operations retire in order): the operands come through LDS instead, one bulk copy up front --
         // A transposed and both padded to four rows (zeros)
-        const double *la = rsc + 32, *lb = la;
         const int sAl = sA ? 16 : 0, sBl = sB ? 4 * NU : 0;
-        if constexpr (PIPE) {
-            double *wa = rsc + 32;
-            const int na = (sA ? N : 1) * 16, nb = (sB ? N : 1) * 4 * NU;
-            double *wb = wa + na;
-            lb = wb;
+        const int na = (sA ? N : 1) * 16, nb = (sB ? N : 1) * 4 * NU;
+        const double *la = laq, *lb = laq + na;
+        // (SF: the loads of all four problems are in flight together -- one round trip per turn, not one per problem)
+        // (A LATER period of a multi-period launch finds the copy of the first one: the launch's operands are its arguments, nothing
+        // writes them while it runs, and nothing else lives in that part of LDS.)
+        constexpr int NPQ = SF ? PW : 1;
+        if (PIPE && per == 0) {
+            const double *srcA[NPQ], *srcB[NPQ];
+            double *dst[NPQ];
+#pragma unroll
+            for (int j = 0; j < NPQ; ++j) {
+                int64_t pj = SF ? (int64_t)blockIdx.x * PW + j : prob;
+                pj = pj < sa_.batch ? pj : sa_.batch - 1;
+                srcA[j] = (const double *)ka.A.ptr + pj * ka.A.batch_stride;
+                srcB[j] = (const double *)ka.B.ptr + pj * ka.B.batch_stride;
+                dst[j] = rsc + 32 + j * lds_pd;
+            }
             for (int i0 = lane; i0 < na; i0 += 64 * 8) {
-                double v[8];
+                double v[NPQ][8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + 64 * u < na ? i0 + 64 * u : na - 1;
                     const int kk = i >> 4, cc = (i >> 2) & 3, rr = i & 3;  // la[k][c][r] = A_k[r][c]
-                    v[u] = (rr < NX && cc < NX) ? gA[(int64_t)kk * sA + rr * NX + cc] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NPQ; ++j) v[j][u] = (rr < NX && cc < NX) ? srcA[j][(int64_t)kk * sA + rr * NX + cc] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (i0 + 64 * u < na) wa[i0 + 64 * u] = v[u];
+                    if (i0 + 64 * u < na)
+#pragma unroll
+                        for (int j = 0; j < NPQ; ++j) dst[j][i0 + 64 * u] = v[j][u];
             }
             for (int i0 = lane; i0 < nb; i0 += 64 * 4) {
-                double v[4];
+                double v[NPQ][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int i = i0 + 64 * u < nb ? i0 + 64 * u : nb - 1;
                     const int kk = i / (4 * NU), e = i - kk * 4 * NU;  // lb[k][l][u] = B_k[l][u], l < 4
-                    v[u] = e < NX * NU ? gB[(int64_t)kk * sB + e] : 0.0;
+#pragma unroll
+                    for (int j = 0; j < NPQ; ++j) v[j][u] = e < NX * NU ? srcB[j][(int64_t)kk * sB + e] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i0 + 64 * u < nb) wb[i0 + 64 * u] = v[u];
+                    if (i0 + 64 * u < nb)
+#pragma unroll
+                        for (int j = 0; j < NPQ; ++j) dst[j][na + i0 + 64 * u] = v[j][u];
             }
             wsync();
+#ifdef STAGE_DBG_COPY
+            tick(10);
+#endif
         }
         auto request = [&](int d, int k) {
             if constexpr (PIPE) {
@@ -470,7 +516,17 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
                 Kd = Si[0] * BPA;
                 Aclo = Am - Bk * Kd;
             } else {
-                const double s00 = rl(Sm, 0) + wu, s01 = rl(Sm, 1), s10 = rl(Sm, 16), s11 = rl(Sm, 17) + wu;
+                // (SF: the entries of this lane's own quad, by ds_bpermute)
+                auto sget = [&](int rr, int cc) {
+                    if constexpr (SF) {
+                        const int src = 4 * (16 * rr + 4 * quad + cc);
+                        return __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(Sm)),
+                                                __builtin_amdgcn_ds_bpermute(src, __double2loint(Sm)));
+                    } else {
+                        return rl(Sm, 16 * rr + cc);
+                    }
+                };
+                const double s00 = sget(0, 0) + wu, s01 = sget(0, 1), s10 = sget(1, 0), s11 = sget(1, 1) + wu;
                 const double det = s00 * s11 - s01 * s10, id = frcp(det);
                 notpd |= !(s00 > 0.0) | !(det > 0.0);
                 Si[0] = s11 * id;
@@ -490,7 +546,7 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             if constexpr (SERIAL) {
                 // every lane stores (the four quads hold bitwise equal copies; zero outside NX x NX); PIPE: straight into the next
                 // launch's image in the workspace (the LDS image belongs to the solving wavefront)
-                double *f = (PIPE ? img_next : Fl) + k * FS;
+                double *f = (PIPE ? imgq : Fl) + k * FS;
                 f[FA + r * 4 + c] = Aclo;
                 f[FAT + c * 4 + r] = Aclo;
                 double bsv = 0.0;  // -(S^-1 B')[u][r], u = c % NU: the backward sweep's feed-forward row, S^-1 folded in here
@@ -522,6 +578,20 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
 #pragma unroll
         for (int d = 0; d < RD - 1; ++d)
             if (k - d >= 0) step(d, k - d);
+    }
+    if constexpr (PIPE && PW == 4) {
+        if (factor_wave) {  // this wavefront's work is done: mark the factors that do not exist (per quad), like KEEP does
+            if (notpd) {
+                int64_t pq = (int64_t)blockIdx.x * PW + ((lane >> 2) & 3);
+                pq = pq < sa_.batch ? pq : sa_.batch - 1;
+                (wsbase + pq * wl.total + wl.Fimg + (int64_t)(slot ^ 1) * N * FS)[FSI] = __builtin_nan("");
+            }
+            wsync();
+#ifndef STAGE_DBG_COPY
+            tick(10);
+#endif
+            return;
+        }
     }
     notpd = __ballot(notpd) != 0ull;
     wsync();
@@ -864,15 +934,15 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             for (int i = 0; i < NX; ++i) x[i] = nx_[i];
         }
     };
-    // ---- the same two sweeps, serial in k (N <= kSerialMaxN). Quad q = (lane / 4) % 4 of every 16-lane row owns component q of
-    // the running vector (the four rows run the same stream), so "component j" is the value of lane 4 j of the row, and a term
-    // of the step's dot products is ONE instruction: v_fmac_f64_dpp row_newbcast:4j (the broadcast folded into the FMA; no
-    // rotations, nothing of the vector in LDS). The step's coefficients come from the LDS image, requested STAGE_SRD steps
-    // ahead through running pointers (no clamping: the image has that many steps of slack on either side); S^-1 is folded
-    // into the feed-forward rows by the factor; nothing is stored under an exec mask. 22 instructions per step, ~165 cycles
-    // (one wavefront per SIMD: a step costs what its instructions issue, 56 of them the eight dependent FMAs --
-    // tools/ubench/dpp_rate.hip). Round 4; before: the vector in rotated order in every lane, three DPP rotations and two
-    // masked stores per step, ~55 instructions, 370-540 cycles.
+    // ---- the same two sweeps, serial in k (N <= kSerialMaxN), on the matrix cores (round 5). The running vector sits in B-operand
+    // order -- component sq in the lanes of 16-lane row sq, which is also where a result lands --, the step's matrix is fetched
+    // from the LDS image one ELEMENT per lane in A-operand order, the affine term enters as the C operand: a step of the serial
+    // chain is ONE v_mfma_f64_4x4x4 whose result is the next step's operand (28 cycles from result to dependent product,
+    // tools/ubench/mfma_f64_4x4.hip); a second product off the chain gives the feed-forward term (backward) or the input
+    // (forward). The operands are requested STAGE_SRD steps ahead through running pointers (no clamping: the image has that
+    // many steps of slack on either side); S^-1 is folded into the feed-forward rows by the factor; nothing is stored under an
+    // exec mask. ~12 instructions per step. Round 4: component q in quad q of a row, eight dependent v_fmac_f64_dpp per step,
+    // 22 instructions, ~165 cycles.
     constexpr int SRD = STAGE_SRD;  // request distance of the serial sweeps, in steps (their operands sit in LDS: ~100+ cycles, a step is ~80)
     // A value that only one lane (or one lane per quad) has to store is stored by EVERY lane, each to an address of its own:
     // the wanted lanes walk the array, the others hit their cell of `junkl` (a masked store costs the wavefront two exec
@@ -918,47 +988,39 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
             own = sqin ? pn : 0.0;
             kstart = kq - 1;
         }
-        double at[SRD][4], bs[SRD][4 * NU], tg[SRD];
-        const double *fq = Fl + FAT + sq * 4 + kstart * FS, *tq = tgl + ((NX == 4 || sqin) ? sq : 0) + kstart * NX;
-        double *fw = lane == 0 ? ffl + kstart * NU : junkl;  // where this lane stores the step's feed-forward term
-        const int fws = lane == 0 ? -NU : 0;
-        auto req = [&](int d, const double *f, const double *t) {
-            const D2 *a2 = (const D2 *)f, *b2 = (const D2 *)(f + (FBS - FAT - sq * 4));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const D2 v = a2[h];  // Acl[j][q], j = 2h, 2h + 1
-                at[d][2 * h] = v[0];
-                at[d][2 * h + 1] = v[1];
-            }
-#pragma unroll
-            for (int h = 0; h < 2 * NU; ++h) {
-                const D2 v = b2[h];  // -(S^-1 B')[i][j] at index j NU + i
-                bs[d][2 * h] = v[0];
-                bs[d][2 * h + 1] = v[1];
-            }
-            if constexpr (track) tg[d] = *t;
+        // element [sq][sc] of the step's matrices, as the matrix cores take an A operand (A[i][k] in lane i + 16 k): Acl[r][c] read
+        // that way is Acl' (p_k = Acl' p_{k+1}), the row-major -(S^-1 B')[u][j] at j NU + u gives the feed-forward rows u < NU
+        double at[SRD], bs[SRD], tg[SRD];
+        const double *fa = Fl + FA + sq * 4 + sc + kstart * FS, *fb = Fl + FBS + sq * NU + (sc < NU ? sc : 0) + kstart * FS;
+        const double *tq = tgl + ((NX == 4 || sqin) ? sq : 0) + kstart * NX;
+        const bool ffw = (lane & 15) == 0 && sq < NU;
+        double *fw = ffw ? ffl + kstart * NU + sq : junkl;  // where this lane stores the step's feed-forward term
+        const int fws = ffw ? -NU : 0;
+        auto req = [&](int d, int off, int offt) {
+            at[d] = fa[off];
+            bs[d] = fb[off];
+            if constexpr (track) tg[d] = tq[offt];
         };
-        if (lane >= STAGE_SROWL) return;  // (the four 16-lane rows would run the same stream)
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
-            req(d, fq - d * FS, tq - d * NX);
+            req(d, -d * FS, -d * NX);
             __builtin_amdgcn_sched_barrier(0);
         }
-        fq -= SRD * FS;  // (the pointers run SRD steps ahead of the step that computes)
+        fa -= SRD * FS;  // (the pointers run SRD steps ahead of the step that computes)
+        fb -= SRD * FS;
         tq -= SRD * NX;
         auto step = [&](int d, bool again) {
-            double pn = track ? tg[d] : 0.0, fn[NU];
-#pragma unroll
-            for (int i = 0; i < NU; ++i) fn[i] = 0.0;
-            if (!(STAGE_DBG & 4)) sweep_chain(pn, fn, own, at[d], bs[d]);
+            const double c0 = track ? ((NX == 4 || sqin) ? tg[d] : 0.0) : 0.0;
+            const double pn = mm44(at[d], own, c0);   // p_k = (-w_x target_k) + Acl' p_{k+1}: the only product on the chain
+            const double fn = mm44(bs[d], own, 0.0);  // ff_k = -(S^-1 B') p_{k+1}, rows u < NU
             if (!(STAGE_DBG & 2)) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) fw[i] = fn[i];
+                *fw = fn;
                 fw += fws;
             }
-            own = (NX == 4 || sqin) ? pn : 0.0;
-            if (again && !(STAGE_DBG & 1)) req(d, fq, tq);
-            fq -= FS;
+            own = pn;
+            if (again && !(STAGE_DBG & 1)) req(d, 0, 0);
+            fa -= FS;
+            fb -= FS;
             tq -= NX;
         };
         int k = kstart;
@@ -977,61 +1039,52 @@ __global__ void __launch_bounds__(PIPE ? 128 * PWT : 64, PIPE && PWT == 4 ? 1 : 
     double *xl = tgl, *ul = ffl;
     auto forward_s = [&](double x0q, double *Uo, double *Xo) {  // x0q: this lane's component of the initial state
         double own = x0q;
-        double ar[SRD][4], kn[SRD][4 * NU], bo[SRD][NU], ff[SRD][NU];
-        const double *fq = Fl + FA + sq * 4, *fk = ffl;
-        const bool xwl = lane < 16 && (lane & 3) == 0 && sqin;
-        double *xw = xwl ? xl + sq : junkl, *uw = lane == 0 ? ul : junkl;
-        const int xws = xwl ? NX : 0, uws = lane == 0 ? NU : 0;
-        auto req = [&](int d, const double *f, const double *fkk) {
-            const D2 *a2 = (const D2 *)f, *k2 = (const D2 *)(f + (FKN - FA - sq * 4));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const D2 v = a2[h];  // Acl[q][j]
-                ar[d][2 * h] = v[0];
-                ar[d][2 * h + 1] = v[1];
-            }
-#pragma unroll
-            for (int h = 0; h < 2 * NU; ++h) {
-                const D2 v = k2[h];  // -K[i][j] at index j NU + i
-                kn[d][2 * h] = v[0];
-                kn[d][2 * h + 1] = v[1];
-            }
+        // A operands by element: Acl[c][r] (= FAT at r 4 + c) -> x_{k+1} = Acl x_k + (B ff_k), -K[c][r] -> u_k = ff_k - K x_k
+        double ar[SRD], kn[SRD], bo[SRD][NU], ff[SRD][NU];
+        const double *fa = Fl + FAT + sq * 4 + sc, *fk = Fl + FKN + sq * NU + (sc < NU ? sc : 0), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
+        const bool xwl = (lane & 15) == 0 && sqin, uwl = (lane & 15) == 0 && sq < NU;
+        double *xw = xwl ? xl + sq : junkl, *uw = uwl ? ul + sq : junkl;
+        const int xws = xwl ? NX : 0, uws = uwl ? NU : 0;
+        auto req = [&](int d, int off, int offf) {
+            ar[d] = fa[off];
+            kn[d] = fk[off];
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                bo[d][i] = f[FBO - FA - sq * 4 + sq * NU + i];
-                ff[d][i] = fkk[i];
+                bo[d][i] = fbo[off + i];
+                ff[d][i] = ffp[offf + i];
             }
         };
         auto run = [&]() {
-        if (lane >= STAGE_SROWL) return;  // (the four 16-lane rows would run the same stream)
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
-            req(d, fq + d * FS, fk + d * NU);
+            req(d, d * FS, d * NU);
             __builtin_amdgcn_sched_barrier(0);
         }
-        fq += SRD * FS;
-        fk += SRD * NU;
+        fa += SRD * FS;
+        fk += SRD * FS;
+        fbo += SRD * FS;
+        ffp += SRD * NU;
         auto step = [&](int d, bool again) {
             if (!(STAGE_DBG & 2)) {
                 *xw = own;
                 xw += xws;
             }
-            double xn = 0.0, u[NU];
+            double cx = 0.0;
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                u[i] = ff[d][i];
-                xn += bo[d][i] * u[i];
-            }
-            if (!(STAGE_DBG & 4)) sweep_chain(xn, u, own, ar[d], kn[d]);
+            for (int i = 0; i < NU; ++i) cx += bo[d][i] * ff[d][i];
+            const double ffr = (NU == 1 || sq == 0) ? ff[d][0] : ff[d][NU - 1];
+            const double xn = mm44(ar[d], own, cx);   // the only product on the chain
+            const double un = mm44(kn[d], own, ffr);  // rows u < NU
             if (!(STAGE_DBG & 2)) {
-#pragma unroll
-                for (int i = 0; i < NU; ++i) uw[i] = u[i];
+                *uw = un;
                 uw += uws;
             }
             own = (NX == 4 || sqin) ? xn : 0.0;
-            if (again && !(STAGE_DBG & 1)) req(d, fq, fk);
-            fq += FS;
-            fk += NU;
+            if (again && !(STAGE_DBG & 1)) req(d, 0, 0);
+            fa += FS;
+            fk += FS;
+            fbo += FS;
+            ffp += NU;
         };
         int k = 0;
         for (int g = N / SRD; g > 0; --g) {
@@ -1667,7 +1720,7 @@ static int launch_stage_p(const KernelArgs &ka, const Ws &wl, size_t lds_problem
         if (e != hipSuccess) return (int)e;
     }
     const StageArgs sa{ka, wl, (double *)ws, batch, (int64_t)lds_problem};
-    hipLaunchKernelGGL(kern, dim3((unsigned)((batch + PW - 1) / PW)), dim3(PIPE ? 128 * PW : 64), lds, st, sa);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((batch + PW - 1) / PW)), dim3(PIPE ? (PW == 4 ? 320 : 128) : 64), lds, st, sa);
     return (int)hipGetLastError();
 }
 
@@ -1680,7 +1733,7 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
     if (PIPE) lds += (32 + (size_t)ka.N * (16 + 4 * NU)) * sizeof(double);  // the factor wavefront's exchange cells + operands (padded)
     lds = (lds + 15) & ~(size_t)15;
     if constexpr (PIPE && STAGE_PW == 4) {
-        // four problems per workgroup -- the two wavefronts of a problem on ONE SIMD -- when they fit the CU's 160 KB
+        // four problems per workgroup and ONE factor wavefront for them, when they fit the CU's 160 KB
         if (4 * lds <= 160 * 1024) return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 4>(ka, wl, lds, batch, ws, st);
     }
     return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 1>(ka, wl, lds, batch, ws, st);

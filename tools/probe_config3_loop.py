@@ -38,7 +38,19 @@ for name, kw in (("rebuild", {}), ("pipeline_factor", {"pipeline_factor": True})
         for sd in range(4):
             print(f"    solver on SIMD {sd}: {int((simd_s == sd).sum())} workgroups, mean solving {int(sol[simd_s == sd].mean()) if (simd_s == sd).any() else -1};"
                   f" factor on SIMD {sd}: {int((simd_f == sd).sum())}")
-        slow = sol > 44000
+        slow = sol > torch.quantile(sol, torch.tensor(0.8, dtype=torch.float64))
+        joint = torch.zeros(4, 4, dtype=torch.int64); jslow = torch.zeros(4, 4, dtype=torch.int64)
+        for a, b2, sl_ in zip(simd_s.tolist(), simd_f.tolist(), slow.tolist()):
+            joint[a, b2] += 1; jslow[a, b2] += int(sl_)
+        print("    (solver SIMD, factor SIMD) counts", joint.tolist(), "slow among them", jslow.tolist())
+        # what shares a SIMD with each solving wavefront: per (XCC, CU, SIMD) the kinds of wavefronts
+        xs, xf = (hs >> 32) & 15, (hf >> 32) & 15
+        ks, kf = (xs * 512 + cu(hs)) * 4 + simd_s, (xf * 512 + cu(hf)) * 4 + simd_f
+        ns, nf = torch.bincount(ks, minlength=8 * 512 * 4), torch.bincount(kf, minlength=8 * 512 * 4)
+        for a in range(0, 3):
+            for b2 in range(0, 3):
+                sel = (ns[ks] == a + 1) & (nf[ks] == b2)
+                if sel.any(): print(f"    solving wavefronts on a SIMD with {a + 1} solving and {b2} factor wavefronts: {int(sel.sum())}, mean solving time {int(sol[sel].mean())}, slow {int(slow[sel].sum())}")
         print("    slow workgroups:", int(slow.sum()), "; their solver SIMDs", torch.bincount(simd_s[slow], minlength=4).tolist(), "factor SIMDs", torch.bincount(simd_f[slow], minlength=4).tolist())
         cuid = (cu(hs) | ((hs >> 32) & 15) << 8)  # (XCC, SE, SH, CU)
         ids, inv = torch.unique(cuid, return_inverse=True)

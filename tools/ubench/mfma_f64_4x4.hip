@@ -26,6 +26,24 @@ template <int MODE> __global__ void rate(double *out, long long *cyc, double x)
         } else if (MODE == 2) {  // dependent through A (result feeds the next A operand)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(acc[0], b, 0.0, 0, 0, 0);
+        } else if (MODE == 4) {  // dependent through B
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, acc[0], 0.0, 0, 0, 0);
+        } else if (MODE == 5) {  // a sweep step: the chain through B, an independent product on the same operand between two links
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, acc[0], 0.0, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, acc[0], b, 0, 0, 0);
+                asm volatile("" : "+v"(acc[1]));
+            }
+        } else if (MODE == 6) {  // ... and the side product stored to LDS
+            __shared__ double buf[64 * 8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(b, acc[0], 0.0, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, acc[0], b, 0, 0, 0);
+                buf[threadIdx.x + 64 * i] = acc[1];
+            }
         } else {  // MFMA -> VALU -> MFMA
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -63,17 +81,21 @@ int main()
     double *out;
     long long *cyc, hc;
     hipMalloc(&out, 64 * 8), hipMalloc(&cyc, 8);
-    const char *names[] = {"independent", "dependent via C", "dependent via A", "MFMA -> v_mul -> MFMA"};
-    for (int m = 0; m < 4; ++m) {
+    const char *names[] = {"independent", "dependent via C", "dependent via A", "MFMA -> v_mul -> MFMA", "dependent via B",
+                           "chain via B + side product", "chain via B + side product + ds_write"};
+    for (int m = 0; m < 7; ++m) {
         for (int r = 0; r < 2; ++r) {
             if (m == 0) hipLaunchKernelGGL(rate<0>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
             if (m == 1) hipLaunchKernelGGL(rate<1>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
             if (m == 2) hipLaunchKernelGGL(rate<2>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
             if (m == 3) hipLaunchKernelGGL(rate<3>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
+            if (m == 4) hipLaunchKernelGGL(rate<4>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
+            if (m == 5) hipLaunchKernelGGL(rate<5>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
+            if (m == 6) hipLaunchKernelGGL(rate<6>, dim3(1), dim3(64), 0, 0, out, cyc, 0.5);
             hipDeviceSynchronize();
         }
         hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
-        printf("%-24s %.1f cycles per MFMA%s\n", names[m], hc / (256.0 * 8), m == 3 ? " + mul" : "");
+        printf("%-40s %.1f cycles per %s\n", names[m], hc / (256.0 * 8), m == 3 ? "MFMA + mul" : m >= 5 ? "step (two MFMAs)" : "MFMA");
     }
     return 0;
 }
