@@ -524,16 +524,18 @@ def _roofline(args, w, local_per_step, kernel_ms, mean_iters):
         etf = ex * local_per_step / kernel_s / 1e12
         common["algorithmic_flops_per_problem"] = ex
         return {"bound": "mfma", "achieved": etf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": etf / FP64_PEAK_TFLOPS,
-                "kernel": "mpcqp_stage_kernel<4, 1, serial, pipelined> (stage-wise Riccati active set; two wavefronts per loop: "
-                          "one solves this period, the other rebuilds the factor for the next one) with the plant step, next "
-                          "references and bookkeeping as its epilogue; up to periods_per_launch consecutive periods per launch "
-                          "(the episode's first period is a launch of its own), kernel_ms is per period",
+                "kernel": "mpcqp_stage_kernel<4, 1, serial, pipelined, 4> (stage-wise Riccati active set on v_mfma_f64_4x4x4; "
+                          "workgroups of four loops: four solving wavefronts and ONE factor wavefront that rebuilds the four "
+                          "factors of the next period, one per lane quad of its matrix-core products, into the loops' second LDS "
+                          "image) with the plant step, next references and bookkeeping as its epilogue; up to periods_per_launch "
+                          "consecutive periods per launch (the episode's first period is a launch of its own), kernel_ms is per "
+                          "period",
                 "periods_per_launch": PERIODS_PER_LAUNCH, "pipeline_factor": True,
                 "achieved_gbs": gbs, "dense_equivalent_tflops": tfs, **common,
                 "note": "achieved = float64 operations the kernel executes per period (Riccati recursion, sweeps, slack "
                         "passes: ~3e4 per loop) over the period; dense_equivalent_tflops prices the reference's dense "
-                        "condense + solve flops, which this path does not execute. With 1024 loops there are two wavefronts "
-                        "per SIMD and the period is the latency of one problem's serial chain (dependent float64 "
+                        "condense + solve flops, which this path does not execute. With 1024 loops there are five wavefronts "
+                        "per CU and the period is the latency of one problem's serial chain (dependent float64 "
                         "operations, LDS round trips), nowhere near a throughput roof. Peak = AMD's fp64 vector=matrix figure"}
     return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             "kernel": "mpcqp_stagew_kernel<float, 12> (one launch per step: Riccati factor, LQR sweeps and the dual "

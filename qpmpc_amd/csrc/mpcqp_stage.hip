@@ -74,7 +74,7 @@ namespace mpcqp {
 namespace stage {
 
 constexpr int kSerialMaxN = 128;  // horizons up to here take the serial sweeps of the LQR solve (if their factor fits LDS)
-constexpr int serial_fs(int nu) { return (32 + 12 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
+constexpr int serial_fs(int nu) { return (16 + 12 * nu + nu * nu + 1) & ~1; }  // doubles per step of the LDS factor image
 // LDS doubles of a serial instantiation behind the active-set vectors: exchange cells, the image (STAGE_SRD steps of slack on
 // either side: the sweeps request that far ahead without clamping), the feed-forward terms, the targets / the staged trajectory
 // ... and one cell of nu doubles per lane that takes the stores of the lanes whose value is not wanted (no exec masking)
@@ -307,10 +307,11 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     int *actk = (int *)(lamv + maxq), *actr = actk + maxq;
     // SERIAL: the factor of every step stays in LDS -- the serial sweeps read nothing else, and nothing of it goes to the
     // workspace -- in the order in which quad q of a 16-lane row consumes it (16-byte reads):
-    //   FA  Acl[q][j]     FAT Acl[j][q]     (row q / column q: four values per quad)
+    //   FA  Acl[q][j] at q 4 + j   (the sweeps on the matrix cores fetch it by element: as it is for the backward sweep's Acl', transposed
+    //       for the forward one -- round 4 kept a second, transposed copy for its 16-byte row reads)
     //   FKN -K[i][j] at j NU + i     FBS -(S^-1 B')[i][j] at j NU + i     (the same 4 NU values for every lane)
     //   FBO B[q][i]      FSI S^-1
-    constexpr int FA = 0, FAT = 16, FKN = 32, FBS = FKN + 4 * NU, FBO = FBS + 4 * NU, FSI = FBO + 4 * NU;
+    constexpr int FA = 0, FKN = 16, FBS = FKN + 4 * NU, FBO = FBS + 4 * NU, FSI = FBO + 4 * NU;
     constexpr int FS = serial_fs(NU);
     static_assert(FS >= FSI + NU * NU && (FS & 1) == 0, "factor image");
     typedef double D2 __attribute__((ext_vector_type(2)));
@@ -318,6 +319,13 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     double *Fl = rsc + 32 + STAGE_SRD * FS;  // (SRD steps of slack below the image and above the targets: serial_lds_doubles)
     double *ffl = Fl + N * FS;             // ... and the feed-forward terms of the latest backward sweep (N x NU)
     double *tgl = ffl + N * NU;            // ... and the targets of the tracking sweep (N x NX)
+    // LDSIMG (four problems per workgroup, one factor wavefront): a SECOND image behind that wavefront's operand copies. The factor
+    // wavefront writes the next period's factor straight into the image the solving wavefront is not reading, and the two swap
+    // from period to period: inside a multi-period launch the factor never travels through the workspace (only the launch's
+    // first period loads one from there, only its last period leaves one there).
+    constexpr bool LDSIMG = PIPE && PW == 4;
+    double *const Fl0 = Fl, *const Fl1 = rsc + serial_lds_doubles(N, NX, NU) + 32 + (int64_t)N * (16 + 4 * NU);
+    if constexpr (LDSIMG) Fl = (per & 1) ? Fl1 : Fl0;
     // ---- workspace
     double *ws = wsbase + prob * wl.total;
     double *Acl = ws + wl.Acl, *Kg = ws + wl.Kg, *Sinv = ws + wl.Sinv, *ffv = ws + wl.ff, *U0 = ws + wl.U0, *X0 = ws + wl.X0;
@@ -412,7 +420,10 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         constexpr bool SF = PIPE && PW == 4;
         const int quad = (lane >> 2) & 3;
         const int64_t lds_pd = sa_.lds_problem / (int64_t)sizeof(double);
-        double *imgq = img_next;                              // where this lane's problem takes its next factor
+        double *imgq = img_next;                              // where this lane's problem takes its next factor: the workspace ...
+        const int nper_ = (ka.ep_on && ka.ep_periods > 1) ? ka.ep_periods : 1;
+        const bool to_lds = LDSIMG && per + 1 < nper_;        // ... or (LDSIMG, not the launch's last period) its other LDS image
+        double *lq = (((per + 1) & 1) ? Fl1 : Fl0) + (SF ? quad * lds_pd : 0);
         const double *laq = rsc + 32 + (SF ? quad * lds_pd : 0);  // ... and finds its operands (PIPE)
         if constexpr (SF) {
             int64_t pq = (int64_t)blockIdx.x * PW + quad;
@@ -546,16 +557,25 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             if constexpr (SERIAL) {
                 // every lane stores (the four quads hold bitwise equal copies; zero outside NX x NX); PIPE: straight into the next
                 // launch's image in the workspace (the LDS image belongs to the solving wavefront)
-                double *f = (PIPE ? imgq : Fl) + k * FS;
-                f[FA + r * 4 + c] = Aclo;
-                f[FAT + c * 4 + r] = Aclo;
                 double bsv = 0.0;  // -(S^-1 B')[u][r], u = c % NU: the backward sweep's feed-forward row, S^-1 folded in here
 #pragma unroll
                 for (int v = 0; v < NU; ++v) bsv -= ((NU == 1 || cu == 0) ? si(v) : si(NU + v)) * Brn[d][v];
-                f[FKN + c * NU + ru] = -Kd;
-                f[FBS + r * NU + cu] = bsv;
-                f[FBO + r * NU + cu] = Bk;
-                f[FSI + ru * NU + cu] = ru == 0 ? (cu == 0 ? si(0) : si(1)) : (cu == 0 ? si(2) : si(3));
+                const double siv = ru == 0 ? (cu == 0 ? si(0) : si(1)) : (cu == 0 ? si(2) : si(3));
+                auto put = [&](double *f) {
+                    f[FA + r * 4 + c] = Aclo;
+                    f[FKN + c * NU + ru] = -Kd;
+                    f[FBS + r * NU + cu] = bsv;
+                    f[FBO + r * NU + cu] = Bk;
+                    f[FSI + ru * NU + cu] = siv;
+                };
+                if constexpr (LDSIMG) {
+                    if (to_lds)
+                        put(lq + k * FS);
+                    else
+                        put(imgq + k * FS);
+                } else {
+                    put((PIPE ? imgq : Fl) + k * FS);
+                }
             } else {
                 const int64_t w = wg(k);
                 if ((lane & 12) == 0) {  // the first quad of every row
@@ -582,9 +602,14 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     if constexpr (PIPE && PW == 4) {
         if (factor_wave) {  // this wavefront's work is done: mark the factors that do not exist (per quad), like KEEP does
             if (notpd) {
-                int64_t pq = (int64_t)blockIdx.x * PW + ((lane >> 2) & 3);
+                const int quad = (lane >> 2) & 3;
+                int64_t pq = (int64_t)blockIdx.x * PW + quad;
                 pq = pq < sa_.batch ? pq : sa_.batch - 1;
-                (wsbase + pq * wl.total + wl.Fimg + (int64_t)(slot ^ 1) * N * FS)[FSI] = __builtin_nan("");
+                const int nper_ = (ka.ep_on && ka.ep_periods > 1) ? ka.ep_periods : 1;
+                if (per + 1 < nper_)
+                    ((((per + 1) & 1) ? Fl1 : Fl0) + quad * (sa_.lds_problem / (int64_t)sizeof(double)))[FSI] = __builtin_nan("");
+                else
+                    (wsbase + pq * wl.total + wl.Fimg + (int64_t)(slot ^ 1) * N * FS)[FSI] = __builtin_nan("");
             }
             wsync();
 #ifndef STAGE_DBG_COPY
@@ -614,7 +639,7 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             typedef __attribute__((address_space(1))) const void glb_void;
             // (a later period of a multi-period launch that REUSES the factor finds the image where the first one put it:
             // nothing of a solve writes into it)
-            if (PIPE || per == 0) {
+            if ((PIPE && !LDSIMG) || per == 0) {
                 const D2 *src = (const D2 *)img;
                 D2 *dst = (D2 *)Fl;
                 const int n2 = N * FS / 2;  // (FS is even)
@@ -1039,9 +1064,9 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     double *xl = tgl, *ul = ffl;
     auto forward_s = [&](double x0q, double *Uo, double *Xo) {  // x0q: this lane's component of the initial state
         double own = x0q;
-        // A operands by element: Acl[c][r] (= FAT at r 4 + c) -> x_{k+1} = Acl x_k + (B ff_k), -K[c][r] -> u_k = ff_k - K x_k
+        // A operands by element: Acl[c][r] -> x_{k+1} = Acl x_k + (B ff_k), -K[c][r] -> u_k = ff_k - K x_k
         double ar[SRD], kn[SRD], bo[SRD][NU], ff[SRD][NU];
-        const double *fa = Fl + FAT + sq * 4 + sc, *fk = Fl + FKN + sq * NU + (sc < NU ? sc : 0), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
+        const double *fa = Fl + FA + sc * 4 + sq, *fk = Fl + FKN + sq * NU + (sc < NU ? sc : 0), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
         const bool xwl = (lane & 15) == 0 && sqin, uwl = (lane & 15) == 0 && sq < NU;
         double *xw = xwl ? xl + sq : junkl, *uw = uwl ? ul + sq : junkl;
         const int xws = xwl ? NX : 0, uws = uwl ? NU : 0;
@@ -1734,7 +1759,9 @@ static int launch_stage_s(const KernelArgs &ka, int maxq, int64_t batch, void *w
     lds = (lds + 15) & ~(size_t)15;
     if constexpr (PIPE && STAGE_PW == 4) {
         // four problems per workgroup and ONE factor wavefront for them, when they fit the CU's 160 KB
-        if (4 * lds <= 160 * 1024) return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 4>(ka, wl, lds, batch, ws, st);
+        // (... with the second LDS image of every problem, and the sweeps' request distance of slack behind it)
+        const size_t lds4 = lds + (size_t)(ka.N + STAGE_SRD) * serial_fs(NU) * sizeof(double);
+        if (4 * lds4 <= 160 * 1024) return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 4>(ka, wl, lds4, batch, ws, st);
     }
     return launch_stage_p<NX, NU, SERIAL, PIPE, WARM, 1>(ka, wl, lds, batch, ws, st);
 }
