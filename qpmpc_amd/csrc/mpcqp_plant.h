@@ -47,7 +47,7 @@ __device__ __forceinline__ void sincos_t(float x, float *s, float *c) { sincosf(
 // round trip is not on the period's tail)
 template <typename T>
 __device__ __forceinline__ void wip_period_wave(int lane, T *st, const T (&s0)[4], T a, int N, T Tp, T vel, T omega2, T g, int nsub,
-                                                T *x0, T *goal, T *tg)
+                                                T *x0, T *goal, T *tg, T (&s1)[4])  // s1: the state after the period, in every lane
 {
     T r = s0[0], th = s0[1], rd = s0[2], thd = s0[3];
     const T dt = Tp / (T)nsub, ag = a / g;
@@ -62,6 +62,10 @@ __device__ __forceinline__ void wip_period_wave(int lane, T *st, const T (&s0)[4
         r = r2;
         th = th2;
     }
+    s1[0] = r;
+    s1[1] = th;
+    s1[2] = rd;
+    s1[3] = thd;
     __builtin_amdgcn_wave_barrier();  // (every lane has read the state before any lane overwrites it)
     if (lane < 4) {
         const T v = lane == 0 ? r : lane == 1 ? th : lane == 2 ? rd : thd;
@@ -81,7 +85,8 @@ __device__ __forceinline__ void wip_period_wave(int lane, T *st, T a, int N, T T
                                                 T *tg)
 {
     const T s0[4] = {st[0], st[1], st[2], st[3]};
-    wip_period_wave<T>(lane, st, s0, a, N, Tp, vel, omega2, g, nsub, x0, goal, tg);
+    T s1[4];
+    wip_period_wave<T>(lane, st, s0, a, N, Tp, vel, omega2, g, nsub, x0, goal, tg, s1);
 }
 
 }  // namespace mpcqp

@@ -254,6 +254,10 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     // (mpcqp_wip_periods_batch: the loop's next problem is written by the epilogue, so the wavefront carries on with it --
     // no launch boundary, no dispatch gap between the periods); every other entry point runs one. (Everything, the
     // address arithmetic included, is inside the period: nothing but the kernel's arguments stays live across periods.)
+    // (the one thing a period hands to the next: the loop's plant state after its epilogue -- the next problem's x0, goal and
+    // targets are functions of it, so a later period of a launch forms them in registers instead of reading back what the
+    // epilogue has just stored: one global round trip less at the top of every period but the first)
+    double carry[4] = {0.0, 0.0, 0.0, 0.0};
     auto period = [&](const int per) {
     const long long t_entry = (long long)__builtin_readcyclecounter();  // (developer probe: slot 11)
     // (the lane and problem indices pass through an empty asm: the optimiser must not hoist the period's address
@@ -374,9 +378,11 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         stamp[factor_wave ? 15 : 14] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32);
     // the fused period's plant state (epilogue): requested now, used ~70 k cycles later
     double ep_s0[4] = {0.0, 0.0, 0.0, 0.0};
-    if (ka.ep_on && !factor_wave)
+    const bool carried = SERIAL && NX == 4 && NU == 1 && ka.ep_on && per > 0;
+    if (ka.ep_on && !factor_wave) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ep_s0[i] = ((const double *)ka.ep_states)[prob * 4 + i];
+        for (int i = 0; i < 4; ++i) ep_s0[i] = carried ? carry[i] : ((const double *)ka.ep_states)[prob * 4 + i];
+    }
     // (serial sweeps) the problem's own data, requested now and used once the factor is in place: x0 and the goal (this
     // lane's component), the targets (64 consecutive values per register; they go to LDS in the tracking sweep)
     constexpr int TGV = SERIAL ? (kSerialMaxN * NX + 63) / 64 : 1;
@@ -384,7 +390,17 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
 #pragma unroll
     for (int u = 0; u < TGV; ++u) tgv[u] = 0.0;
     if constexpr (SERIAL) {
-        if (!factor_wave) {
+        if (!factor_wave && carried) {
+            // the problem the last epilogue wrote (wip_period_wave, mpcqp_plant.h: the same expressions, bit for bit)
+            const double rr = carry[0], vel = ka.ep_vel, Tp = ka.ep_Tp;
+            x0own = sq == 0 ? carry[0] : sq == 1 ? carry[1] : sq == 2 ? carry[2] : carry[3];
+            goalown = termQ ? (sq == 0 ? rr + ((double)N * Tp) * vel : sq == 2 ? vel : 0.0) : 0.0;
+#pragma unroll
+            for (int u = 0; u < TGV; ++u) {
+                const int i = lane + 64 * u, kk = i >> 2, j = i & 3;
+                tgv[u] = (stageQ && i < N * NX) ? (j == 0 ? rr + ((double)kk * Tp) * vel : j == 2 ? vel : 0.0) : 0.0;
+            }
+        } else if (!factor_wave) {
             x0own = sqin ? gx0[sq] : 0.0;
             goalown = (termQ && sqin) ? ggoal[sq] : 0.0;
 #pragma unroll
@@ -1681,7 +1697,7 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             a = ok ? ((const double *)ka.U)[prob * (int64_t)N * NU] : 0.0;
         }
         wip_period_wave<double>(lane, (double *)ka.ep_states + prob * 4, ep_s0, a, N, ka.ep_Tp, ka.ep_vel, ka.ep_omega2, ka.ep_g,
-                                ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt));
+                                ka.ep_nsub, const_cast<double *>(gx0), const_cast<double *>(ggoal), const_cast<double *>(gtgt), carry);
         if (lane == 0 && ka.ep_loopstats) {
             // (atomics without a return value: fire and forget -- a load + add + store is a dependent round trip on the period's tail;
             // this wavefront is the only writer of its loop's counters)
