@@ -42,18 +42,13 @@
 
 namespace mpcqp {
 
-// (developer knob: tools/ab_unit.sh builds variants)
+// (developer knobs: tools/ab_unit.sh builds variants)
+// priority of a solving wavefront of the five-wavefront workgroups (the factor wavefront runs at 0): worth 1-2 % on config 3
 #ifndef STAGE_PRIO
 #define STAGE_PRIO 3
 #endif
 #ifndef STAGE_SRD
 #define STAGE_SRD 4
-#endif
-#ifndef STAGE_SROWL
-// lanes that run the serial sweeps: 16 = one 16-lane row, 64 = all four rows redundantly. Same cycle count either way; with
-// the factor wavefronts running next to the solving ones (PIPE: two busy wavefronts on every SIMD of the chip, shader clock
-// ~1.8 GHz instead of ~2.25) three idle rows are worth 2.5 % of the period, alone on its SIMD the exec mask costs 2 %.
-#define STAGE_SROWL (PIPE ? 16 : 64)
 #endif
 #ifndef STAGE_PW
 // problems per workgroup of the pipelined instantiation (4 when four of them fit the CU's LDS; else 1).
@@ -138,68 +133,6 @@ __device__ __forceinline__ double frcp(double x)
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
     return fma(fma(-x, y, 1.0), y, y);
-}
-// a DPP move of a double (two dwords); CTRL: quad_perm 0x00..0xff, row_ror:n = 0x120 + n
-template <int CTRL> __device__ __forceinline__ double dpp64(double x)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-// acc += (x of lane N of the caller's 16-lane row) * m in ONE instruction (the row broadcast folded into the FMA; the compiler
-// does not do that itself). A register written by a VALU instruction needs two wait states before a DPP read: dpp_ready(x)
-// goes in front of every batch (tools/check_dpp_hazards.py verifies the assembly).
-template <int LANE> __device__ __forceinline__ void fmac_bcast(double &acc, double x, double m)
-{
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(LANE));
-}
-__device__ __forceinline__ void dpp_ready(double &x) { asm volatile("s_nop 1" : "+v"(x)); }
-// One step of a serial sweep in ONE asm block (nothing is scheduled into it): with x_j = the value of lane 4 j of the row,
-//   a += sum_j x_j ca[j] ;  b[i] += sum_j x_j cb[j NU + i]      (the two or three sums interleaved: dependent FMAs apart)
-#define STAGE_FB(acc, c, n) "v_fmac_f64_dpp " acc ", %[x], " c " row_newbcast:" n " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void sweep_chain(double &a, double (&b)[1], double x, const double (&ca)[4], const double (&cb)[4])
-{
-    asm volatile("s_nop 1\n\t" STAGE_FB("%[a]", "%[a0]", "0") STAGE_FB("%[b]", "%[b0]", "0") STAGE_FB("%[a]", "%[a1]", "4")
-                     STAGE_FB("%[b]", "%[b1]", "4") STAGE_FB("%[a]", "%[a2]", "8") STAGE_FB("%[b]", "%[b2]", "8")
-                         STAGE_FB("%[a]", "%[a3]", "12") STAGE_FB("%[b]", "%[b3]", "12")
-                 : [a] "+v"(a), [b] "+v"(b[0])
-                 : [x] "v"(x), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]), [b1] "v"(cb[1]),
-                   [b2] "v"(cb[2]), [b3] "v"(cb[3]));
-}
-__device__ __forceinline__ void sweep_chain(double &a, double (&b)[2], double x, const double (&ca)[4], const double (&cb)[8])
-{
-    asm volatile("s_nop 1\n\t" STAGE_FB("%[a]", "%[a0]", "0") STAGE_FB("%[b]", "%[b0]", "0") STAGE_FB("%[c]", "%[c0]", "0")
-                     STAGE_FB("%[a]", "%[a1]", "4") STAGE_FB("%[b]", "%[b1]", "4") STAGE_FB("%[c]", "%[c1]", "4")
-                         STAGE_FB("%[a]", "%[a2]", "8") STAGE_FB("%[b]", "%[b2]", "8") STAGE_FB("%[c]", "%[c2]", "8")
-                             STAGE_FB("%[a]", "%[a3]", "12") STAGE_FB("%[b]", "%[b3]", "12") STAGE_FB("%[c]", "%[c3]", "12")
-                 : [a] "+v"(a), [b] "+v"(b[0]), [c] "+v"(b[1])
-                 : [x] "v"(x), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]), [b1] "v"(cb[2]),
-                   [b2] "v"(cb[4]), [b3] "v"(cb[6]), [c0] "v"(cb[1]), [c1] "v"(cb[3]), [c2] "v"(cb[5]), [c3] "v"(cb[7]));
-}
-#undef STAGE_FB
-// a += sum_j x_j ca[j] ; b += sum_j y_j cb[j]   (two vectors x, y: value of lane 4 j of the row)
-#define STAGE_FB2(acc, src, c, n) "v_fmac_f64_dpp " acc ", " src ", " c " row_newbcast:" n " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void sweep_chain2(double &a, double &b, double x, double y, const double (&ca)[4], const double (&cb)[4])
-{
-    asm volatile("s_nop 1\n\t" STAGE_FB2("%[a]", "%[x]", "%[a0]", "0") STAGE_FB2("%[b]", "%[y]", "%[b0]", "0")
-                     STAGE_FB2("%[a]", "%[x]", "%[a1]", "4") STAGE_FB2("%[b]", "%[y]", "%[b1]", "4")
-                         STAGE_FB2("%[a]", "%[x]", "%[a2]", "8") STAGE_FB2("%[b]", "%[y]", "%[b2]", "8")
-                             STAGE_FB2("%[a]", "%[x]", "%[a3]", "12") STAGE_FB2("%[b]", "%[y]", "%[b3]", "12")
-                 : [a] "+v"(a), [b] "+v"(b)
-                 : [x] "v"(x), [y] "v"(y), [a0] "v"(ca[0]), [a1] "v"(ca[1]), [a2] "v"(ca[2]), [a3] "v"(ca[3]), [b0] "v"(cb[0]),
-                   [b1] "v"(cb[1]), [b2] "v"(cb[2]), [b3] "v"(cb[3]));
-}
-#undef STAGE_FB2
-// dst of every lane of the 16-lane row rho <- src of lane 4 rho of that row: four row-masked broadcasts
-__device__ __forceinline__ void row_gather(double &dst, double src)
-{
-    asm volatile("s_nop 1\n\t"
-                 "v_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0x1 bank_mask:0xf\n\t"
-                 "v_mov_b64_dpp %0, %1 row_newbcast:4 row_mask:0x2 bank_mask:0xf\n\t"
-                 "v_mov_b64_dpp %0, %1 row_newbcast:8 row_mask:0x4 bank_mask:0xf\n\t"
-                 "v_mov_b64_dpp %0, %1 row_newbcast:12 row_mask:0x8 bank_mask:0xf"
-                 : "+v"(dst)
-                 : "v"(src));
 }
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // (value, index) arg-min over the wavefront; ties -> lowest index; every lane gets the result
