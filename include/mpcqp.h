@@ -395,7 +395,8 @@ int mpcqp_rollout_batch(const MpcqpDims *dims, const MpcqpOperand *A,
  * examples/wheeled_inverted_pendulum.py:110-111), then write the next MPC problem's
  * x0 [4], goal [4] and targets [N*4] reference ramp (get_target_states, same example
  * :65-83,:101-108). states [batch*4] is updated in place; a loop whose plan was not
- * found (status[b] != 0, may be NULL) applies a zero input. */
+ * found (status[b] != 0, may be NULL) applies a zero input. nsub = 0 leaves the plant where
+ * it is and writes the problem of the CURRENT state (the first problem of an episode). */
 int mpcqp_wip_advance_batch(int32_t dtype, void *states, const void *U, int64_t u_stride,
                             const int32_t *status, int32_t N, double sampling_period,
                             double target_vel, double length, double gravity, int32_t nsub,

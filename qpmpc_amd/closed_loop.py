@@ -91,7 +91,17 @@ class WIPClosedLoop:
             self.solver._opts.flags |= _capi.OPT_KEEP_FACTOR
 
     def _write_references(self) -> None:
-        """target_states / goal_state of every loop, in place (so the bound pointers stay valid)."""
+        """target_states / goal_state / initial_state of every loop from its current state, in place (so the bound
+        pointers stay valid): one launch of the plant kernel with zero sub-steps (``mpcqp_wip_advance_batch``, nsub = 0)."""
+        p, pend = self.problem, self.pendulum
+        rc = _capi.load().mpcqp_wip_advance_batch(
+            _dtype_code(p.dtype), self.states.data_ptr(), self.solver.U.data_ptr(), p.nb_variables, None, pend.nb_timesteps,
+            pend.sampling_period, self.target_vel, pend.length, pend.GRAVITY, 0, p.initial_state.data_ptr(),
+            p.goal_state.data_ptr(), p.target_states.data_ptr(), p.batch_size, _stream_ptr())
+        _capi.check(rc, "mpcqp_wip_advance_batch")
+
+    def _write_references_torch(self) -> None:
+        """The same with torch operations (kept as a cross-check of the kernel: tests/)."""
         p, N = self.problem, self.pendulum.nb_timesteps
         pos = self.states[:, 0:1] + self._ramp[None, :]  # [B, N+1]
         tgt = p.target_states.view(-1, N, 4)

@@ -1006,7 +1006,7 @@ int mpcqp_wip_advance_stats_batch(int32_t dtype, void *states, const void *U, in
                                   void *targets, int64_t batch, void *stream)
 {
     if (dtype != MPCQP_F64 && dtype != MPCQP_F32) return MPCQP_EDTYPE;
-    if (!states || !U || !x0 || !goal || !targets || N <= 0 || nsub <= 0 || batch < 0 || !(length > 0) || !(gravity > 0))
+    if (!states || !U || !x0 || !goal || !targets || N <= 0 || nsub < 0 || batch < 0 || !(length > 0) || !(gravity > 0))
         return MPCQP_EINVAL;
     if (stats && !status) return MPCQP_EINVAL;
     if (batch == 0) return 0;

@@ -50,7 +50,7 @@ __device__ __forceinline__ void wip_period_wave(int lane, T *st, const T (&s0)[4
                                                 T *x0, T *goal, T *tg, T (&s1)[4])  // s1: the state after the period, in every lane
 {
     T r = s0[0], th = s0[1], rd = s0[2], thd = s0[3];
-    const T dt = Tp / (T)nsub, ag = a / g;
+    const T dt = nsub > 0 ? Tp / (T)nsub : T(0), ag = a / g;  // (nsub = 0: the state stays, the problem of that state is written)
     for (int i = 0; i < nsub; ++i) {
         T sn, cs;
         sincos_t(th, &sn, &cs);  // (one argument reduction for both)

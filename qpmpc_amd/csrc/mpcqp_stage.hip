@@ -62,9 +62,6 @@ namespace mpcqp {
 //    of 1: a SIMD issued one solving and one factor wavefront's instructions per period either way.)
 #define STAGE_PW 4
 #endif
-#ifndef STAGE_DBG
-#define STAGE_DBG 0 /* timing experiments only (wrong results): 1 no re-requests, 2 no stores, 4 no arithmetic in the serial sweeps */
-#endif
 
 namespace stage {
 
@@ -965,11 +962,11 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         // element [sq][sc] of the step's matrices, as the matrix cores take an A operand (A[i][k] in lane i + 16 k): Acl[r][c] read
         // that way is Acl' (p_k = Acl' p_{k+1}), the row-major -(S^-1 B')[u][j] at j NU + u gives the feed-forward rows u < NU
         double at[SRD], bs[SRD], tg[SRD];
-        const double *fa = Fl + FA + sq * 4 + sc + kstart * FS, *fb = Fl + FBS + sq * NU + (sc < NU ? sc : 0) + kstart * FS;
+        // (the rows of the feed-forward product repeat with period NU -- A-operand row i reads row i % NU --, so EVERY lane holds
+        // a wanted value, component sq % NU, and all of them store it: one stride for all lanes, no spare cells)
+        const double *fa = Fl + FA + sq * 4 + sc + kstart * FS, *fb = Fl + FBS + sq * NU + (sc & (NU - 1)) + kstart * FS;
         const double *tq = tgl + ((NX == 4 || sqin) ? sq : 0) + kstart * NX;
-        const bool ffw = (lane & 15) == 0 && sq < NU;
-        double *fw = ffw ? ffl + kstart * NU + sq : junkl;  // where this lane stores the step's feed-forward term
-        const int fws = ffw ? -NU : 0;
+        double *fw = ffl + kstart * NU + (sq & (NU - 1));  // where this lane stores a step's feed-forward term
         auto req = [&](int d, int off, int offt) {
             at[d] = fa[off];
             bs[d] = fb[off];
@@ -983,29 +980,37 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         fa -= SRD * FS;  // (the pointers run SRD steps ahead of the step that computes)
         fb -= SRD * FS;
         tq -= SRD * NX;
-        auto step = [&](int d, bool again) {
+        // (a step stores the feed-forward term of the step BEFORE it: the store of a product's result right behind the product
+        // stalls the wavefront until the matrix pipe delivers it)
+        double fprev = 0.0;
+        auto step = [&](int d, bool again, bool store_prev) {
             const double c0 = track ? ((NX == 4 || sqin) ? tg[d] : 0.0) : 0.0;
             const double pn = mm44(at[d], own, c0);   // p_k = (-w_x target_k) + Acl' p_{k+1}: the only product on the chain
-            const double fn = mm44(bs[d], own, 0.0);  // ff_k = -(S^-1 B') p_{k+1}, rows u < NU
-            if (!(STAGE_DBG & 2)) {
-                *fw = fn;
-                fw += fws;
+            const double fn = mm44(bs[d], own, 0.0);  // ff_k = -(S^-1 B') p_{k+1}, rows u < NU (repeated)
+            if (store_prev) {
+                *fw = fprev;
+                fw -= NU;
             }
+            fprev = fn;
             own = pn;
-            if (again && !(STAGE_DBG & 1)) req(d, 0, 0);
+            if (again) req(d, 0, 0);
             fa -= FS;
             fb -= FS;
             tq -= NX;
         };
-        int k = kstart;
-        for (int g = (kstart + 1) / SRD; g > 0; --g) {
+        if (kstart >= 0) {
+            step(0, true, false);
+            int k = kstart - 1;  // steps left: k + 1, ring slots 1, 2, ..., SRD - 1, 0, 1, ...
+            for (int g = (k + 1) / SRD; g > 0; --g) {
 #pragma unroll
-            for (int d = 0; d < SRD; ++d) step(d, true);
-            k -= SRD;
+                for (int d = 0; d < SRD; ++d) step((d + 1) % SRD, true, true);
+                k -= SRD;
+            }
+#pragma unroll
+            for (int d = 0; d < SRD - 1; ++d)
+                if (k - d >= 0) step((d + 1) % SRD, false, true);
+            *fw = fprev;
         }
-#pragma unroll
-        for (int d = 0; d < SRD - 1; ++d)
-            if (k - d >= 0) step(d, false);
     };
     // The trajectory is staged in LDS while the sweep runs (x_k over the targets, u_k over the feed-forward term it was formed
     // from: both are dead by then); the lanes copy their chunks to the workspace arrays (Uo, Xo) in one coalesced pass
@@ -1015,10 +1020,11 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         double own = x0q;
         // A operands by element: Acl[c][r] -> x_{k+1} = Acl x_k + (B ff_k), -K[c][r] -> u_k = ff_k - K x_k
         double ar[SRD], kn[SRD], bo[SRD][NU], ff[SRD][NU];
-        const double *fa = Fl + FA + sc * 4 + sq, *fk = Fl + FKN + sq * NU + (sc < NU ? sc : 0), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
-        const bool xwl = (lane & 15) == 0 && sqin, uwl = (lane & 15) == 0 && sq < NU;
-        double *xw = xwl ? xl + sq : junkl, *uw = uwl ? ul + sq : junkl;
-        const int xws = xwl ? NX : 0, uws = uwl ? NU : 0;
+        // (the input product's rows repeat with period NU like the feed-forward rows of the backward sweep: every lane stores
+        // component sq % NU; the state is stored by every lane of its row -- NX < 4: the rows without a component hit a spare cell)
+        const double *fa = Fl + FA + sc * 4 + sq, *fk = Fl + FKN + sq * NU + (sc & (NU - 1)), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
+        double *xw = (NX == 4 || sqin) ? xl + sq : junkl, *uw = ul + (sq & (NU - 1));
+        const int xws = (NX == 4 || sqin) ? NX : 0;
         auto req = [&](int d, int off, int offf) {
             ar[d] = fa[off];
             kn[d] = fk[off];
@@ -1038,37 +1044,41 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
         fk += SRD * FS;
         fbo += SRD * FS;
         ffp += SRD * NU;
-        auto step = [&](int d, bool again) {
-            if (!(STAGE_DBG & 2)) {
-                *xw = own;
-                xw += xws;
-            }
+        double uprev = 0.0;  // (the input of the step before: stored one step late, like the backward sweep's feed-forward terms)
+        auto step = [&](int d, bool again, bool store_prev) {
+            *xw = own;
+            xw += xws;
             double cx = 0.0;
 #pragma unroll
             for (int i = 0; i < NU; ++i) cx += bo[d][i] * ff[d][i];
-            const double ffr = (NU == 1 || sq == 0) ? ff[d][0] : ff[d][NU - 1];
+            const double ffr = (NU == 1 || (sq & (NU - 1)) == 0) ? ff[d][0] : ff[d][NU - 1];
             const double xn = mm44(ar[d], own, cx);   // the only product on the chain
-            const double un = mm44(kn[d], own, ffr);  // rows u < NU
-            if (!(STAGE_DBG & 2)) {
-                *uw = un;
-                uw += uws;
+            const double un = mm44(kn[d], own, ffr);  // rows u < NU (repeated)
+            if (store_prev) {
+                *uw = uprev;
+                uw += NU;
             }
+            uprev = un;
             own = (NX == 4 || sqin) ? xn : 0.0;
-            if (again && !(STAGE_DBG & 1)) req(d, 0, 0);
+            if (again) req(d, 0, 0);
             fa += FS;
             fk += FS;
             fbo += FS;
             ffp += NU;
         };
-        int k = 0;
-        for (int g = N / SRD; g > 0; --g) {
+        if (N >= 1) {
+            step(0, true, false);
+            int k = 1;
+            for (int g = (N - 1) / SRD; g > 0; --g) {
 #pragma unroll
-            for (int d = 0; d < SRD; ++d) step(d, true);
-            k += SRD;
+                for (int d = 0; d < SRD; ++d) step((d + 1) % SRD, true, true);
+                k += SRD;
+            }
+#pragma unroll
+            for (int d = 0; d < SRD - 1; ++d)
+                if (k + d < N) step((d + 1) % SRD, false, true);
+            *uw = uprev;
         }
-#pragma unroll
-        for (int d = 0; d < SRD - 1; ++d)
-            if (k + d < N) step(d, false);
         };
         run();
         lsync();
@@ -1659,9 +1669,17 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             // the next period's x0 / goal / targets / state were written by this wavefront, its factor image by the other
             // one (PIPE): same CU, same L1 -- the stores have to be complete, nothing has to be invalidated but the
             // scalar cache
-            wsync();
-            __builtin_amdgcn_s_dcache_inv();
-            if constexpr (PIPE) __syncthreads();
+            if constexpr (PIPE && PWT == 4) {
+                // four loops per workgroup: the next period reads NOTHING this one stored to global memory -- its factor is in the
+                // other LDS image, its problem comes from the carried plant state, the factor wavefront's operands from their LDS
+                // copy, and a wavefront's own workspace arrays are written before they are read in every period -- so only the LDS
+                // writes have to be complete at the barrier: the global stores (plan, next problem, counters) drain behind it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                wsync();
+                __builtin_amdgcn_s_dcache_inv();
+                if constexpr (PIPE) __syncthreads();
+            }
             if (stamper)  // (developer probe: the end of the hand-over to the next period)
                 ((long long *)ka_.probe)[probo * 16 + 12] = (long long)__builtin_readcyclecounter();
             // (no vector-L1 invalidate: the two wavefronts of a workgroup share their CU's L1, which its own stores keep

@@ -641,6 +641,26 @@ def test_shared_model_equals_fused_path(family):
     assert np.abs(one.multipliers.cpu().numpy()[ok] - got.multipliers.cpu().numpy()[ok]).max() <= 1e-6 * max(1.0, float(got.multipliers.abs().max()))
 
 
+def test_first_problem_of_an_episode_from_the_plant_kernel():
+    """mpcqp_wip_advance_batch with nsub = 0 writes the problem of the CURRENT state (x0, goal, the reference ramp of
+    examples/wheeled_inverted_pendulum.py:65-83) and leaves the plant alone: equal to the torch expressions it replaces at the
+    start of an episode, to rounding (k T v is formed in another order)."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(3)
+    x0 = rng.standard_normal((37, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    loop = WIPClosedLoop(x0.copy())
+    before = loop.states.clone()
+    loop._write_references()
+    torch.cuda.synchronize()
+    got = [t.clone() for t in (loop.problem.initial_state, loop.problem.goal_state, loop.problem.target_states)]
+    assert torch.equal(loop.states, before)
+    loop._write_references_torch()
+    torch.cuda.synchronize()
+    for a, b in zip(got, (loop.problem.initial_state, loop.problem.goal_state, loop.problem.target_states)):
+        assert float((a - b).abs().max()) <= 1e-15 * max(1.0, float(b.abs().max()))
+
+
 def test_closed_loop_with_shared_model_matches_rebuild_every_step():
     from qpmpc_amd.closed_loop import WIPClosedLoop
 
