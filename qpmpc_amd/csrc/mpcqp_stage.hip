@@ -47,6 +47,9 @@ namespace mpcqp {
 #ifndef STAGE_PRIO
 #define STAGE_PRIO 3
 #endif
+#ifndef STAGE_FPRIO
+#define STAGE_FPRIO 0
+#endif
 #ifndef STAGE_SRD
 #define STAGE_SRD 4
 #endif
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     if constexpr (PIPE && PW == 4) {  // the solving wavefronts are the period's critical path: the one that shares its SIMD with the
                                       // factor wavefront issues first, the factor wavefront fills the gaps
         if (factor_wave)
-            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(STAGE_FPRIO);
         else
             __builtin_amdgcn_s_setprio(STAGE_PRIO);
     }
@@ -959,17 +962,16 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             own = sqin ? pn : 0.0;
             kstart = kq - 1;
         }
-        // element [sq][sc] of the step's matrices, as the matrix cores take an A operand (A[i][k] in lane i + 16 k): Acl[r][c] read
-        // that way is Acl' (p_k = Acl' p_{k+1}), the row-major -(S^-1 B')[u][j] at j NU + u gives the feed-forward rows u < NU
-        double at[SRD], bs[SRD], tg[SRD];
-        // (the rows of the feed-forward product repeat with period NU -- A-operand row i reads row i % NU --, so EVERY lane holds
-        // a wanted value, component sq % NU, and all of them store it: one stride for all lanes, no spare cells)
-        const double *fa = Fl + FA + sq * 4 + sc + kstart * FS, *fb = Fl + FBS + sq * NU + (sc & (NU - 1)) + kstart * FS;
+        // element [sq][sc] of the step's matrix, as the matrix cores take an A operand (A[i][k] in lane i + 16 k): Acl[r][c] read that
+        // way is Acl' (p_k = Acl' p_{k+1}). The step stores its operand p_{k+1} into cell k + 1 of the target array (that target
+        // was consumed a step earlier; cell N lies in the slack behind the array), one step late -- nothing waits for a product.
+        double at[SRD], tg[SRD];
+        const double *fa = Fl + FA + sq * 4 + sc + kstart * FS;
         const double *tq = tgl + ((NX == 4 || sqin) ? sq : 0) + kstart * NX;
-        double *fw = ffl + kstart * NU + (sq & (NU - 1));  // where this lane stores a step's feed-forward term
+        double *pw = (NX == 4 || sqin) ? tgl + (kstart + 1) * NX + sq : junkl;  // cell of p_{kstart+1}
+        const int pws = (NX == 4 || sqin) ? NX : 0;
         auto req = [&](int d, int off, int offt) {
             at[d] = fa[off];
-            bs[d] = fb[off];
             if constexpr (track) tg[d] = tq[offt];
         };
 #pragma unroll
@@ -978,38 +980,41 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
             __builtin_amdgcn_sched_barrier(0);
         }
         fa -= SRD * FS;  // (the pointers run SRD steps ahead of the step that computes)
-        fb -= SRD * FS;
         tq -= SRD * NX;
-        // (a step stores the feed-forward term of the step BEFORE it: the store of a product's result right behind the product
-        // stalls the wavefront until the matrix pipe delivers it)
-        double fprev = 0.0;
-        auto step = [&](int d, bool again, bool store_prev) {
+        auto step = [&](int d, bool again) {
             const double c0 = track ? ((NX == 4 || sqin) ? tg[d] : 0.0) : 0.0;
-            const double pn = mm44(at[d], own, c0);   // p_k = (-w_x target_k) + Acl' p_{k+1}: the only product on the chain
-            const double fn = mm44(bs[d], own, 0.0);  // ff_k = -(S^-1 B') p_{k+1}, rows u < NU (repeated)
-            if (store_prev) {
-                *fw = fprev;
-                fw -= NU;
-            }
-            fprev = fn;
-            own = pn;
+            *pw = own;
+            pw -= pws;
+            own = mm44(at[d], own, c0);  // p_k = (-w_x target_k) + Acl' p_{k+1}: ONE product per step
             if (again) req(d, 0, 0);
             fa -= FS;
-            fb -= FS;
             tq -= NX;
         };
-        if (kstart >= 0) {
-            step(0, true, false);
-            int k = kstart - 1;  // steps left: k + 1, ring slots 1, 2, ..., SRD - 1, 0, 1, ...
-            for (int g = (k + 1) / SRD; g > 0; --g) {
+        int k = kstart;
+        for (int g = (kstart + 1) / SRD; g > 0; --g) {
 #pragma unroll
-                for (int d = 0; d < SRD; ++d) step((d + 1) % SRD, true, true);
-                k -= SRD;
+            for (int d = 0; d < SRD; ++d) step(d, true);
+            k -= SRD;
+        }
+#pragma unroll
+        for (int d = 0; d < SRD - 1; ++d)
+            if (k - d >= 0) step(d, false);
+        lsync();
+        // the feed-forward terms ff_k = -(S^-1 B') p_{k+1} of all the steps at once, lane <-> step (they were a second product in
+        // every step of the chain; a lone wavefront pays ~16 cycles of issue for each)
+        for (int kk = lane; kk <= kstart; kk += 64) {
+            const double *f = Fl + kk * FS + FBS, *pc = tgl + (kk + 1) * NX;
+            double a[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) a[u] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const double pj = pc[j];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) a[u] += f[j * NU + u] * pj;
             }
 #pragma unroll
-            for (int d = 0; d < SRD - 1; ++d)
-                if (k - d >= 0) step((d + 1) % SRD, false, true);
-            *fw = fprev;
+            for (int u = 0; u < NU; ++u) ffl[kk * NU + u] = a[u];
         }
     };
     // The trajectory is staged in LDS while the sweep runs (x_k over the targets, u_k over the feed-forward term it was formed
@@ -1018,69 +1023,76 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
     double *xl = tgl, *ul = ffl;
     auto forward_s = [&](double x0q, double *Uo, double *Xo) {  // x0q: this lane's component of the initial state
         double own = x0q;
-        // A operands by element: Acl[c][r] -> x_{k+1} = Acl x_k + (B ff_k), -K[c][r] -> u_k = ff_k - K x_k
-        double ar[SRD], kn[SRD], bo[SRD][NU], ff[SRD][NU];
-        // (the input product's rows repeat with period NU like the feed-forward rows of the backward sweep: every lane stores
-        // component sq % NU; the state is stored by every lane of its row -- NX < 4: the rows without a component hit a spare cell)
-        const double *fa = Fl + FA + sc * 4 + sq, *fk = Fl + FKN + sq * NU + (sc & (NU - 1)), *fbo = Fl + FBO + sq * NU, *ffp = ffl;
-        double *xw = (NX == 4 || sqin) ? xl + sq : junkl, *uw = ul + (sq & (NU - 1));
-        const int xws = (NX == 4 || sqin) ? NX : 0;
-        auto req = [&](int d, int off, int offf) {
-            ar[d] = fa[off];
-            kn[d] = fk[off];
+        // c_k = B_k ff_k of all the steps at once (lane <-> step) into cell k + 1 of the trajectory array, where the step that forms
+        // x_{k+1} = Acl x_k + c_k reads it as its C operand and a step later x_{k+1} itself lands (x_k is stored one step late)
+        lsync();
+        for (int kk = lane; kk < N; kk += 64) {
+            const double *f = Fl + kk * FS + FBO;
+            double fk[NU];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                bo[d][i] = fbo[off + i];
-                ff[d][i] = ffp[offf + i];
+            for (int u = 0; u < NU; ++u) fk[u] = ffl[kk * NU + u];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double a = 0.0;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) a += f[j * NU + u] * fk[u];
+                xl[(kk + 1) * NX + j] = a;
             }
+        }
+        lsync();
+        // A operand by element: Acl[c][r] -> x_{k+1} = Acl x_k + c_k: ONE product per step
+        double ar[SRD], cx[SRD];
+        const double *fa = Fl + FA + sc * 4 + sq, *cq = xl + NX + ((NX == 4 || sqin) ? sq : 0);
+        double *xw = (NX == 4 || sqin) ? xl + sq : junkl;
+        const int xws = (NX == 4 || sqin) ? NX : 0;
+        auto req = [&](int d, int off, int offc) {
+            ar[d] = fa[off];
+            cx[d] = cq[offc];
         };
         auto run = [&]() {
 #pragma unroll
         for (int d = 0; d < SRD; ++d) {
-            req(d, d * FS, d * NU);
+            req(d, d * FS, d * NX);
             __builtin_amdgcn_sched_barrier(0);
         }
         fa += SRD * FS;
-        fk += SRD * FS;
-        fbo += SRD * FS;
-        ffp += SRD * NU;
-        double uprev = 0.0;  // (the input of the step before: stored one step late, like the backward sweep's feed-forward terms)
-        auto step = [&](int d, bool again, bool store_prev) {
+        cq += SRD * NX;
+        auto step = [&](int d, bool again) {
             *xw = own;
             xw += xws;
-            double cx = 0.0;
-#pragma unroll
-            for (int i = 0; i < NU; ++i) cx += bo[d][i] * ff[d][i];
-            const double ffr = (NU == 1 || (sq & (NU - 1)) == 0) ? ff[d][0] : ff[d][NU - 1];
-            const double xn = mm44(ar[d], own, cx);   // the only product on the chain
-            const double un = mm44(kn[d], own, ffr);  // rows u < NU (repeated)
-            if (store_prev) {
-                *uw = uprev;
-                uw += NU;
-            }
-            uprev = un;
+            const double xn = mm44(ar[d], own, (NX == 4 || sqin) ? cx[d] : 0.0);
             own = (NX == 4 || sqin) ? xn : 0.0;
             if (again) req(d, 0, 0);
             fa += FS;
-            fk += FS;
-            fbo += FS;
-            ffp += NU;
+            cq += NX;
         };
-        if (N >= 1) {
-            step(0, true, false);
-            int k = 1;
-            for (int g = (N - 1) / SRD; g > 0; --g) {
+        int k = 0;
+        for (int g = N / SRD; g > 0; --g) {
 #pragma unroll
-                for (int d = 0; d < SRD; ++d) step((d + 1) % SRD, true, true);
-                k += SRD;
-            }
-#pragma unroll
-            for (int d = 0; d < SRD - 1; ++d)
-                if (k + d < N) step((d + 1) % SRD, false, true);
-            *uw = uprev;
+            for (int d = 0; d < SRD; ++d) step(d, true);
+            k += SRD;
         }
+#pragma unroll
+        for (int d = 0; d < SRD - 1; ++d)
+            if (k + d < N) step(d, false);
         };
         run();
+        lsync();
+        // the inputs u_k = ff_k - K_k x_k of all the steps at once (over the feed-forward terms they are formed from)
+        for (int kk = lane; kk < N; kk += 64) {
+            const double *f = Fl + kk * FS + FKN, *xc = xl + kk * NX;
+            double a[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) a[u] = ffl[kk * NU + u];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const double xj = xc[j];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) a[u] += f[j * NU + u] * xj;  // (FKN holds -K[u][j] at j NU + u)
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) ul[kk * NU + u] = a[u];
+        }
         lsync();
         for (int kk = k0; kk < k1; ++kk) {
 #pragma unroll
