@@ -710,8 +710,15 @@ def other_workloads():
     from qpmpc_amd.closed_loop import LIPMWalkingLoop, WIPClosedLoop
 
     def rate(run, batch, reps):
-        for _ in range(3):
+        # (spin-up: the clocks of a GPU that has just idled through a host-side set-up ramp for tens of milliseconds -- a short
+        # timed region right behind it once read 13 M/s for a 175 M/s launch)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 0.1:
             run()
+            n += 1
+            if n % 8 == 0:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
