@@ -661,6 +661,34 @@ def test_first_problem_of_an_episode_from_the_plant_kernel():
         assert float((a - b).abs().max()) <= 1e-15 * max(1.0, float(b.abs().max()))
 
 
+def test_pipelined_periods_report_an_indefinite_hessian_in_every_period():
+    """A negative terminal weight makes the condensed Hessian indefinite (mpc_problem.py:104-107 only checks w_u > 0). In the
+    pipelined multi-period launch the factor of the next period is written -- by the ONE factor wavefront of a four-loop
+    workgroup, quad by quad -- into the loop's other LDS image, and a factor that does not exist is marked there: every period of
+    every loop must count as failed (the plant runs on with a zero input), exactly like the plain loop, and nothing sticks when
+    the weight is restored. Seven loops: the last workgroup holds three."""
+    from qpmpc_amd.closed_loop import WIPClosedLoop
+
+    rng = np.random.default_rng(11)
+    x0 = rng.standard_normal((7, 4)) * np.array([0.05, 0.05, 0.1, 0.1])
+    loops = [WIPClosedLoop(x0.copy()), WIPClosedLoop(x0.copy(), pipeline_factor=True, periods_per_launch=5)]
+    for lp in loops:
+        lp.solver._dims.w_terminal = -50.0
+        lp.step(12)
+    torch.cuda.synchronize()
+    for lp in loops:
+        assert int(lp.failed.item()) == 7 * 12, lp.stats()
+    assert torch.equal(loops[0].states, loops[1].states)
+    for lp in loops:  # the weight restored: the loops solve again (the kept / pipelined factor is rebuilt from the operands)
+        lp.solver._dims.w_terminal = 10.0
+        lp.reset(x0)
+        lp.step(12)
+    torch.cuda.synchronize()
+    for lp in loops:
+        assert int(lp.failed.item()) == 0, lp.stats()
+    assert torch.equal(loops[0].states, loops[1].states)
+
+
 def test_closed_loop_with_shared_model_matches_rebuild_every_step():
     from qpmpc_amd.closed_loop import WIPClosedLoop
 
