@@ -32,5 +32,14 @@ def run(rounds, batch, seed, verbose=True):
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    worst, bad = run(rounds, batch, int(os.environ.get("STRESS_SEED", "2026")))
+    # STRESS_SEEDS="1,2,3": several campaigns in one process (tests/test_gpu_stress.py), one line per seed and the total
+    seeds = os.environ.get("STRESS_SEEDS")
+    if seeds:
+        worst, bad = 0.0, 0
+        for sd in (int(x) for x in seeds.split(",")):
+            w1, b1 = run(rounds, batch, sd, verbose=False)
+            print(f"seed {sd}: worst rel diff {w1} rounds flagged {b1}")
+            worst, bad = max(worst, w1), bad + b1
+    else:
+        worst, bad = run(rounds, batch, int(os.environ.get("STRESS_SEED", "2026")))
     print(f"worst rel diff {worst} rounds flagged {bad}")
