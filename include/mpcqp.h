@@ -161,6 +161,11 @@ typedef struct MpcqpProblem {
                                  dispatch would put FOUR on one (mpcqp_quad.hip: cold launches with terminal cost only and two
                                  state rows per step -- BASELINE configs 1, 2, 4 -- from a few thousand problems up, see
                                  MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check. */
+#define MPCQP_OPT_STAGE_GENERAL 8192 /* mpcqp_stagewise_solve_batch: take the general stage-wise kernel (float64, nx <= 32, nu <= 8) also
+                                 where the narrow or the wide one applies: the formulation the host side re-solves through when one
+                                 of those reports MPCQP_INFEASIBLE or MPCQP_MAX_ITER (their active-set operator is the explicit
+                                 inverse of a Gram matrix; the general kernel keeps a thin QR factor). MPCQP_EUNSUPPORTED for
+                                 float32 and wider systems. */
 #define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
                                  takes it from 2.25 problems per SIMD of the device up: 2305 and more on an MI355X, where a
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
@@ -332,7 +337,9 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
  * nu <= 4 (matrix-core sweeps; MPCQP_EUNSUPPORTED otherwise). `max_active` bounds the number of simultaneously active
  * rows (<= 0: min(n, m, 128)); a problem that needs more returns status MPCQP_SLOTS_FULL. The workspace is caller-owned
  * (mpcqp_stagewise_workspace_bytes). mpcqp_build_solve_batch reaches the same kernels by itself for every problem that
- * does not fit the on-chip condensed kernels (any n = N nu). */
+ * does not fit the on-chip condensed kernels (any n = N nu). MPCQP_OPT_STAGE_GENERAL asks for the general kernel (float64,
+ * nx <= 32, nu <= 8: thin-QR active-set operator, the sturdiest of the three on nearly fully active problems) whatever
+ * the width; its workspace is sized by the query with max_active = -1 (default slots) or -k (k slots). */
 int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes);
 int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
                                 const MpcqpSolveOpts *opts, int32_t max_active, void *U, void *lam,

@@ -18,6 +18,7 @@ ABI_VERSION = 10
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED, OPT_EXACT_SELECTION = 64, 128, 256, 512, 1024
 OPT_TWO_PER_WAVE, OPT_FOUR_PER_WAVE = 2048, 4096
+OPT_STAGE_GENERAL = 8192
 WARM_OPERATOR, WARM_ACTIVE_SET = 1, 2
 
 # MPCQP_LIB (dev only) points at another build of the same sources for A/B timing.

@@ -576,7 +576,10 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
     dims, cp, opts = problem.dims(), problem.c_problem(), _opts(max_iter, feas_tol, **opt_kw)
     if formulation == "stagewise":
         nbytes = C.c_size_t(0)
-        _capi.check(lib.mpcqp_stagewise_workspace_bytes(C.byref(dims), Bn, int(max_active or 0), C.byref(nbytes)),
+        # (MPCQP_OPT_STAGE_GENERAL: the general kernel's workspace is asked for with a negative slot count, include/mpcqp.h)
+        general = bool((opt_kw.get("flags") or 0) & _capi.OPT_STAGE_GENERAL)
+        ask = (-max(int(max_active or 0), 1)) if general else int(max_active or 0)
+        _capi.check(lib.mpcqp_stagewise_workspace_bytes(C.byref(dims), Bn, ask, C.byref(nbytes)),
                     "mpcqp_stagewise_workspace_bytes")
         ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=problem.device)
         rc = lib.mpcqp_stagewise_solve_batch(
@@ -587,7 +590,7 @@ def solve_mpc_batch(problem: BatchMPCProblem, solver: str = "hip_gi", return_mul
         plan = BatchPlan(problem, U, status, iters, lam)
         plan._workspace = (ws, opt_kw)
         if retry_slots:
-            _retry_slots_full(plan, int(max_active or 128), max_iter, feas_tol, opt_kw)
+            _retry_slots_full(plan, int(max_active or (256 if general else 128)), max_iter, feas_tol, opt_kw)
         return plan
     if formulation != "condensed":
         raise ProblemDefinitionError(f"formulation must be 'condensed' or 'stagewise', not {formulation!r}")
@@ -612,8 +615,19 @@ def _retry_unsolved(plan: "BatchPlan", max_iter, feas_tol, opt_kw) -> None:
     problem = plan.problem
     kw = {k: v for k, v in opt_kw.items() if k not in ("warm_state", "warm_start", "probe", "flags", "order")}
     # (FORCE_CONDENSED: wide systems take the general stage-wise kernel by default, the condensed kernels are their other formulation)
-    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"flags": _capi.OPT_FORCE_CONDENSED}, {"formulation": "stagewise"}):
+    # ... and an INFEASIBLE verdict of a stage-wise kernel is confirmed by another formulation before it stands: the narrow and the
+    # wide stage-wise kernel keep the explicit inverse of the active rows' Gram matrix, and on nearly fully active problems (most
+    # variables pinned) its error can turn the signs of the step in the multipliers -- tools/stress_tight.py with STRESS_TIGHT <= 0.3
+    # finds a handful per thousand that the oracle, and every exact backend of the reference, solves. Problems of the
+    # small-problem kernels' size (n <= 16) never go there.
+    recheck = problem.nb_variables > 16
+    # (last: the general stage-wise kernel -- thin QR of the whitened active rows, the formulation that stays accurate when nearly
+    # every variable is pinned; float64, nx <= 32, nu <= 8)
+    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"flags": _capi.OPT_FORCE_CONDENSED}, {"formulation": "stagewise"},
+                    {"formulation": "stagewise", "flags": _capi.OPT_STAGE_GENERAL}):
         left = plan.status == _capi.MAX_ITER
+        if recheck:
+            left = left | (plan.status == _capi.INFEASIBLE)
         if not bool(left.any().item()):
             return
         index = left.nonzero().flatten()

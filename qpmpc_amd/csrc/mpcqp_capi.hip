@@ -795,6 +795,11 @@ int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_
     if (!bytes || batch < 0) return MPCQP_EINVAL;
     KernelArgs ka;
     fill_args(ka, dims, nullptr);
+    if (max_active < 0) {  // the general kernel's workspace (MPCQP_OPT_STAGE_GENERAL): -1 default slots, -k: k slots
+        if (!stageg_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;
+        *bytes = stageg_ws_doubles(ka, max_active < -1 ? -max_active : stageg_default_maxq(ka)) * sizeof(double) * (size_t)batch;
+        return 0;
+    }
     const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
     // (the query does not see MpcqpSolveOpts.flags: where both kernels apply it reports the larger workspace)
     size_t a = 0, b = 0;
@@ -822,7 +827,8 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     KernelArgs ka;
     fill_args(ka, dims, problem);
     bool narrow = stage_supported(ka, dims->dtype);
-    if (!narrow && !stagew_supported(ka, dims->dtype)) {
+    const bool general = opts && (opts->flags & MPCQP_OPT_STAGE_GENERAL);
+    if (general || (!narrow && !stagew_supported(ka, dims->dtype))) {
         if (!stageg_supported(ka, dims->dtype)) return MPCQP_EUNSUPPORTED;  // (float32: through mpcqp_build_solve_batch, which converts)
         ka.U = U;
         ka.lam = lam;

@@ -269,12 +269,17 @@ __global__ void __launch_bounds__(64)
     using MV = typename Mfma<T>::V;
     constexpr int D = sizeof(T) == 4 ? (LOW ? D_LOW : STAGEW_D) : 4;  // the sweeps request their records this many steps ahead
     // passes of the final verification: every pass but the last one triggers a refinement step of the multipliers when an
-    // active row is off its bound by more than 1e3 tol (1 + |e|) (float64) / STAGEW_VTRIG32 tol (1 + |e|) (float32: 8, was 64
+    // active row is off its bound by more than 10 tol (1 + |e|) (float64; see below) / STAGEW_VTRIG32 tol (1 + |e|) (float32: 8, was 64
     // -- a stress run in float32 left rows 6e-4 off their bounds and plans 1.5e-3 off the oracle's). Round 4: float32 makes
     // up to two refinement steps and then ACCEPTS only at STAGEW_VACC32 = 16 tol (1 + |e|) plus the rounding noise of the
     // evaluation itself (it was 1000 tol: plans 3e-3 from the float64 one came back SOLVED when W had drifted; such a
     // problem is now MPCQP_MAX_ITER and the host side retries it through the other formulations: tools/stress_f32.py)
-    constexpr int VPASS = sizeof(T) == 4 ? STAGEW_VPASS32 : 2;
+    // Round 5, float64: an active row 1e-6 (1 + |e|) off its bound used to be accepted -- the oracle's own rule, but the oracle's
+    // rows sit 1e-12 off theirs -- and on a nearly fully active problem that is a plan 6e-6 from the minimiser reported SOLVED
+    // (tools/stress_tight.py wide, STRESS_TIGHT=0.3, seed 11). Now 10 tol (1 + |e|) triggers a refinement step, up to two of them,
+    // and 100 tol (1 + |e|) = 1e-7 is what is accepted; what still fails is MPCQP_MAX_ITER and the host side re-solves it through
+    // the other formulations (the general stage-wise kernel last).
+    constexpr int VPASS = sizeof(T) == 4 ? STAGEW_VPASS32 : 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char stagew_smem[];
     const int lane = threadIdx.x, pg = lane >> 4, c16 = lane & 15;
     const int64_t prob = blockIdx.x;
@@ -1638,9 +1643,9 @@ __global__ void __launch_bounds__(64)
                             const bool act = th[u] == INF;
                             if (act) {  // (rare) the row's own threshold is gone: from its bound
                                 const int k = stepof(i), r = i - k * mk;
-                                // first pass: 1e3 tol (1 + |e|) TRIGGERS the refinement; second pass: what is acceptable after it
-                                // (the contract's 1e-6 in float64)
-                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(1000) > T(1e-6) / tol) ? T(1000) : T(1e-6) / tol);
+                                // the first passes: 10 tol (1 + |e|) TRIGGERS a refinement step; the last one: what is acceptable after
+                                // them (1e-7 in float64: a tenth of the contract's 1e-6)
+                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(100) > T(1e-7) / tol) ? T(100) : T(1e-7) / tol);
                                 // (float32: ... plus what the evaluation itself cannot resolve -- a healthy n = 192 problem sits
                                 // 3e-4 off in THIS sum while its plan is 1e-6 from the float64 one: STAGEW_VNOISE32 ulps of the
                                 // terms' magnitudes)
@@ -2008,7 +2013,7 @@ __global__ void __launch_bounds__(64)
             bool offa = false;
             dirty = false;
             for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
-            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 1000) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : T(1000) > T(1e-6) / tol ? T(1000) : T(1e-6) / tol);
+            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : T(100) > T(1e-7) / tol ? T(100) : T(1e-7) / tol);
             for (int i0 = lane; i0 < M; i0 += 64 * SU) {
                 T fr[SU], nz[SU];
 #pragma unroll

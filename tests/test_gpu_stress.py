@@ -85,6 +85,38 @@ def test_stress_campaign_every_seed_of_the_review_list(tool, args, seeds):
     assert worst <= 1e-7, (tool, args, worst)
 
 
+# Beyond the review's list: TIGHTER rows (STRESS_TIGHT 0.3 / 0.15 / 0.05 instead of 0.5: 60-78 of ~80 variables pinned). Here the wide
+# stage-wise kernel ALONE does report MPCQP_INFEASIBLE / MPCQP_MAX_ITER for a handful of problems per thousand that the oracle -- and an
+# exact backend of the reference (qpmpc/solve_mpc.py:43) -- solves: its active-set operator is the explicit inverse of the active rows'
+# Gram matrix. What the product path delivers is the answer AFTER the host side's re-solve of those items through the other
+# formulations, the general stage-wise kernel (thin QR) last (solve_mpc's setting, retry_unsolved=True; STRESS_RETRY=1): statuses
+# equal to the oracle's everywhere, plans within 1e-7.
+@pytest.mark.parametrize("kind,tight,bound", [("wide", "0.3", 1e-7), ("wide", "0.15", 1e-7), ("narrow", "0.05", 1e-7)])
+def test_stress_campaign_nearly_fully_active_with_the_host_side_re_solve(kind, tight, bound):
+    worst, nflag, flagged = _campaign("stress_tight.py", (kind, 8, 8), 0,
+                                      {"STRESS_SEEDS": ",".join(str(sd) for sd in range(1, 17)), "STRESS_TIGHT": tight, "STRESS_RETRY": "1"})
+    assert nflag == 0, "\n".join(flagged)
+    assert worst <= bound, (kind, tight, worst)
+
+
+# Known red, kept in the suite so that it says what is not exact yet (strict: a fix turns these into errors until they are moved up):
+#  * the wide kernel on its own (no re-solve) on the tight family: wrong MPCQP_INFEASIBLE / MPCQP_MAX_ITER verdicts (seeds 1, 5, 11, 14,
+#    16 of STRESS_TIGHT=0.3) -- the thin-QR operator of mpcqp_stageg.hip is not in mpcqp_stagew.hip yet;
+#  * vertices of the tightest family (STRESS_TIGHT=0.05: every variable pinned): three SOLVED plans of 128 rounds are 1.6e-6 .. 2.1e-6
+#    from the oracle's, the general kernel's answers among them (both sides accept active rows 1e-6 (1 + |e|) off their bounds there).
+@pytest.mark.xfail(strict=True, reason="wide stage-wise kernel without the host side's re-solve: explicit inverse of the Gram matrix")
+def test_known_red_wide_kernel_alone_on_the_tight_family():
+    worst, nflag, flagged = _campaign("stress_tight.py", ("wide", 8, 8), 0, {"STRESS_SEEDS": "1,5,11", "STRESS_TIGHT": "0.3"})
+    assert nflag == 0, "\n".join(flagged)
+
+
+@pytest.mark.xfail(strict=True, reason="fully pinned vertices: plans 1.6e-6 .. 2.1e-6 from the oracle's (contract 1e-6)")
+def test_known_red_vertices_of_the_tightest_family():
+    worst, nflag, flagged = _campaign("stress_tight.py", ("wide", 8, 8), 0,
+                                      {"STRESS_SEEDS": "5,12,14", "STRESS_TIGHT": "0.05", "STRESS_RETRY": "1"})
+    assert nflag == 0, "\n".join(flagged)
+
+
 def test_stress_campaign_inconsistent_rows():
     """Rows made inconsistent with their bounds (infeasible and borderline problems): statuses must follow the oracle's.
     (On a few solvable-but-degenerate problems of this family ALL formulations, oracle included, only agree to 1e-3 in u --

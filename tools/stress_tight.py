@@ -22,7 +22,7 @@ def run(kind, rounds, batch, seed, verbose=True):
         else:
             nx, nu = int(rng.integers(17, 33)), int(rng.integers(1, 9))
         N = int(rng.integers(20, 41)); mk = int(rng.integers(4, 7))
-        w = random_ltv(rng, batch, nx, nu, N, mk, 0.5)
+        w = random_ltv(rng, batch, nx, nu, N, mk, float(os.environ.get("STRESS_TIGHT", "0.5")))  # (smaller: tighter rows, more of them active)
         w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
         plan = solve_mpc_batch(W.to_batch_problem(w), retry_unsolved=os.environ.get("STRESS_RETRY", "0") == "1"); torch.cuda.synchronize()
         st = plan.status.cpu().numpy()
