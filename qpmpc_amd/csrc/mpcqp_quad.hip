@@ -344,11 +344,16 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         const int64_t eb = prob * ka.e.batch_stride;
         const T eval0 = isc0 ? ge[eb + (row0 >> 1) * ka.e.step_stride + (row0 & 1)] : INF;
         const T eval1 = isc1 ? ge[eb + (row1 >> 1) * ka.e.step_stride + (row1 & 1)] : INF;
-        T v[NX], x[NX], gref[NX], bcol[NX];
+        // The free response Phi_k x0 rides in LANE 15 of the row: that lane's own column belongs to the horizon's last step (or to
+        // no variable at all), so it is zero in every G_k and enters Psi_N only as B's column itself -- its registers are idle for the
+        // whole chain. The lane starts from x0 instead of zero, the chain's FMAs propagate it with everyone else's columns, and a row's
+        // C_k Phi_k x0 is a row broadcast of what lane 15 computes as "its G entry" (round 5; before: a second chain of 15 FMAs per step
+        // in every lane).
+        const bool xl15 = (l == NV - 1);
+        T v[NX], gref[NX], bcol[NX];
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
-            v[s] = T(0);
-            x[s] = x0[s];
+            v[s] = xl15 ? x0[s] : T(0);
             gref[s] = termQ ? goal[s] : T(0);
         }
 #pragma unroll
@@ -389,50 +394,54 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         static_for<0, NV>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             if (k < N) {
-                T g[MK], xg[MK];
+                T g[MK];
                 static_for<0, MK>([&](auto i2c) {
                     constexpr int i2 = decltype(i2c)::value;
-                    T acc = T(0), xacc = T(0);
+                    T acc = T(0);
                     static_for<0, NX>([&](auto sc) {
                         constexpr int s2 = decltype(sc)::value;
                         mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
-                        mac(ic<NAe + i2 * NX + s2>{}, xacc, opa[k], opb[k], x[s2]);
                     });
                     g[i2] = acc;
-                    xg[i2] = xacc;
                 });
+                // (lane 15 stores C_k Phi_k x0 into column 15 of the image: that column is never read -- it is zero by construction)
 #pragma unroll
                 for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
-                const T xs = lodd ? xg[1] : xg[0];
+                // (both broadcasts in EVERY lane, then the select: a DPP read from a lane that a branch has switched off returns zero)
+                const T xg0 = row_bcast<NV - 1>(g[0]), xg1 = row_bcast<NV - 1>(g[1]);
+                const T xs = lodd ? xg1 : xg0;
                 if constexpr (k < 8)
                     hp0 = (lk == k) ? xs : hp0;
                 else
                     hp1 = (lk == k - 8) ? xs : hp1;
-                // column j of Psi_k is zero up to step j, so B_j's column enters as the start value of lane j's sums
-                const T hk = (j == k) ? T(1) : T(0);
-                T w[NX], xw[NX];
+                // column j of Psi_k is zero up to step j, so B_j's column enters as the start value of lane j's sums (lane 15 carries
+                // the free response: its own column is put in place behind the chain)
+                const T hk = (j == k && !xl15) ? T(1) : T(0);
+                T w[NX];
                 static_for<0, NX>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    T acc = hk * bcol[r], xacc = T(0);
+                    T acc = hk * bcol[r];
                     static_for<0, NX>([&](auto sc) {
                         constexpr int s2 = decltype(sc)::value;
                         mac(ic<r * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
-                        mac(ic<r * NX + s2>{}, xacc, opa[k], opb[k], x[s2]);
                     });
                     w[r] = acc;
-                    xw[r] = xacc;
                 });
 #pragma unroll
-                for (int r = 0; r < NX; ++r) {
-                    v[r] = w[r];
-                    x[r] = xw[r];
-                }
+                for (int r = 0; r < NX; ++r) v[r] = w[r];
             }
         });
         tick(10);
         // P = wu I + wt psi_N' psi_N ; q = wt psi_N' (Phi_N x0 - goal)   (mpc_qp.py:99-105, 129-149)
         qa = T(0);
         const T wt = (T)ka.wt;
+        // Phi_N x0 from lane 15, whose own column of Psi_N is B's column of the last step (or nothing)
+        T x[NX];
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            x[s] = row_bcast<NV - 1>(v[s]);
+            v[s] = xl15 ? bcol[s] : v[s];
+        }
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
             const T t = wt * v[s];
@@ -459,8 +468,9 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            RM0[k] = isc0 ? Gimg[k * GS + row0] : T(0);
-            RM1[k] = isc1 ? Gimg[k * GS + row1] : T(0);
+            // (column 15 of G is zero: the column of the horizon's last step, or of no variable -- its cells hold the free response)
+            RM0[k] = (isc0 && k < NV - 1) ? Gimg[k * GS + row0] : T(0);
+            RM1[k] = (isc1 && k < NV - 1) ? Gimg[k * GS + row1] : T(0);
             RLt[k] = (l == k) ? T(1) : T(0);
         }
         static_for<0, NV>([&](auto jc) {
