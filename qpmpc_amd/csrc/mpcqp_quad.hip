@@ -387,10 +387,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
             else
                 fmac_bcast<IDX - 16>(acc, ob, xx);
         };
-        // [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k (column l in lane l), [C_k Phi_k x0; Phi_{k+1} x0] alongside in every lane
-        T hp0 = T(0), hp1 = T(0);  // C_k Phi_k x0 of this lane's two rows
-        const int lk = l >> 1;
-        const bool lodd = l & 1;
+        // [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k (column l in lane l; lane 15: [C_k Phi_k x0; Phi_{k+1} x0])
         static_for<0, NV>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             if (k < N) {
@@ -404,16 +401,10 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                     });
                     g[i2] = acc;
                 });
-                // (lane 15 stores C_k Phi_k x0 into column 15 of the image: that column is never read -- it is zero by construction)
+                // (lane 15 stores C_k Phi_k x0 into column 15 of the image -- zero in G by construction --: the rows read their
+                // entry of it behind the chain)
 #pragma unroll
                 for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
-                // (both broadcasts in EVERY lane, then the select: a DPP read from a lane that a branch has switched off returns zero)
-                const T xg0 = row_bcast<NV - 1>(g[0]), xg1 = row_bcast<NV - 1>(g[1]);
-                const T xs = lodd ? xg1 : xg0;
-                if constexpr (k < 8)
-                    hp0 = (lk == k) ? xs : hp0;
-                else
-                    hp1 = (lk == k - 8) ? xs : hp1;
                 // column j of Psi_k is zero up to step j, so B_j's column enters as the start value of lane j's sums (lane 15 carries
                 // the free response: its own column is put in place behind the chain)
                 const T hk = (j == k && !xl15) ? T(1) : T(0);
@@ -453,10 +444,10 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
             }
         }
         qa = col ? qa : T(0);
-        hval0 = isc0 ? eval0 - hp0 : INF;  // h_i = e_i - C_k Phi_k x0
-        hval1 = isc1 ? eval1 - hp1 : INF;
         tick(11);
         wsync();  // the G image is complete
+        hval0 = isc0 ? eval0 - Gimg[(NV - 1) * GS + row0] : INF;  // h_i = e_i - C_k Phi_k x0 (column 15 of the image)
+        hval1 = isc1 ? eval1 - Gimg[(NV - 1) * GS + row1] : INF;
     }
     tick(1);
     // ------------------------------------------------------------ factorise + forward substitution, one pass
