@@ -478,7 +478,7 @@ def _traffic_from_profiles(config: int):
 
 def _small_kernel_name(problems: int) -> str:
     """Which small-problem fused kernel a cold launch of `problems` lean problems gets (csrc/mpcqp_quad.hip, quad_pays: four per
-    wavefront from 2.25 problems per SIMD of the device up; one round: the roomy LDS carve, several rounds: the slim one, two
+    wavefront from more than two problems per SIMD of the device up; one round: the roomy LDS carve, several rounds: the slim one, two
     wavefronts per SIMD) -- for the report only; the library decides."""
     import torch
 

@@ -167,7 +167,7 @@ typedef struct MpcqpProblem {
                                  inverse of a Gram matrix; the general kernel keeps a thin QR factor). MPCQP_EUNSUPPORTED for
                                  float32 and wider systems. */
 #define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
-                                 takes it from 2.25 problems per SIMD of the device up: 2305 and more on an MI355X, where a
+                                 takes it from more than two problems per SIMD of the device up: 2049 and more on an MI355X, where a
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
                                  rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way).
                                  MPCQP_EUNSUPPORTED where the kernel does not apply (other cost / constraint layouts, warm

@@ -950,12 +950,13 @@ static int device_simds()
     }();
     return simds;
 }
-// true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from 2.25
-// problems per SIMD up -- below that a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.1 against 20.6 us). One
+// true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from MORE THAN TWO
+// problems per SIMD up -- up to there a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.2 against 19.3 us), one
+// problem more and some SIMD runs two of them (2304: 23.5 against 19.1 us; the rule read 2.25 per SIMD until that was measured). One
 // round (up to four problems per SIMD) runs the roomy carve: config 2 at 4096: 22.4 against 24.8 us; anything larger the slim one,
 // two wavefronts per SIMD: config 2 at 8192 / 16,384: 37.8 / 65.0 against 47.3 / 85.6 us; config 4 at 8192 / 16,384 / 65,536:
 // 45.5 / 74.0 / 231 against 56.9 / 90.9 / 305 us.
-static bool quad_pays(int64_t batch) { return 4 * batch > 9 * (int64_t)device_simds(); }
+static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds(); }
 
 bool quad_applies(const KernelArgs &ka)
 {

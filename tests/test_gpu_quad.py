@@ -1,7 +1,7 @@
 """GPU tests (-m gpu): the four-problems-per-wavefront kernel (csrc/mpcqp_quad.hip) -- the cold fused build+solve of problems with
 terminal cost only and two state rows per step (BASELINE configs 1, 2, 4), replacing qpmpc/mpc_qp.py:53-149 and the
 qpsolvers call at qpmpc/solve_mpc.py:43 like the two-per-wavefront kernel it is dispatched next to. The dispatch takes it by
-batch size (2305 problems and more on an MI355X; beyond 4096 its slim LDS carve, two wavefronts per SIMD); MPCQP_OPT_FOUR_PER_WAVE
+batch size (2049 problems and more on an MI355X; beyond 4096 its slim LDS carve, two wavefronts per SIMD); MPCQP_OPT_FOUR_PER_WAVE
 forces it, MPCQP_OPT_TWO_PER_WAVE keeps the other.
 
 Tolerances (float64): plans |u - u_ref|_inf <= 1e-7 max(1, |u_ref|_inf) against the C oracle (BASELINE.json: 1e-6), observed
@@ -178,7 +178,7 @@ def test_small_and_ragged_batches_and_a_pairing_order():
 @pytest.mark.parametrize("family", ["humanoid_4096", "humanoid_9000", "wip12", "triple"])
 def test_shared_model_launches_four_per_wavefront(family):
     """mpcqp_solve_model_batch on a model factored once (mpc_qp.py:129-163 taken to its end): the dispatch takes this layout from
-    2305 problems (forced below); it agrees with the two-per-wavefront launch of the same model and with the C oracle. wip12 has
+    2049 problems (forced below); it agrees with the two-per-wavefront launch of the same model and with the C oracle. wip12 has
     a stage cost and input rows: the model mode takes every layout whose condensed problem fits the rows."""
     from qpmpc_amd import SharedModel, _capi
     from qpmpc_amd import workloads as W
