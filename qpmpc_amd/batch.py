@@ -621,10 +621,11 @@ def _retry_unsolved(plan: "BatchPlan", max_iter, feas_tol, opt_kw) -> None:
     # finds a handful per thousand that the oracle, and every exact backend of the reference, solves. Problems of the
     # small-problem kernels' size (n <= 16) never go there.
     recheck = problem.nb_variables > 16
-    # (last: the general stage-wise kernel -- thin QR of the whitened active rows, the formulation that stays accurate when nearly
-    # every variable is pinned; float64, nx <= 32, nu <= 8)
-    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"flags": _capi.OPT_FORCE_CONDENSED}, {"formulation": "stagewise"},
-                    {"formulation": "stagewise", "flags": _capi.OPT_STAGE_GENERAL}):
+    # (second, behind the workgroup kernel, which is quick where it applies: the general stage-wise kernel -- thin QR of the whitened
+    # active rows, the formulation that stays accurate when nearly every variable is pinned; float64, nx <= 32, nu <= 8. It is the one
+    # that settles the tight families of tools/stress_tight.py, so it goes before the dense path and the other stage-wise kernels.)
+    for attempt in ({"flags": _capi.OPT_FORCE_LDS}, {"formulation": "stagewise", "flags": _capi.OPT_STAGE_GENERAL},
+                    {"flags": _capi.OPT_FORCE_CONDENSED}, {"formulation": "stagewise"}):
         left = plan.status == _capi.MAX_ITER
         if recheck:
             left = left | (plan.status == _capi.INFEASIBLE)
