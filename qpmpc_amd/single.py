@@ -215,8 +215,9 @@ def solve_single(problem, max_iter=None, feas_tol=None):
     stream.synchronize()
     out = r.h_out_np
     status, iters = int(r.h_out_i32[0]), int(r.h_out_i32[1])
-    if status in (_capi.SLOTS_FULL, _capi.MAX_ITER):
-        # the stage-wise kernel's slots were too few, or the kernel gave up on a degenerate problem: the batch path solves
+    if status in (_capi.SLOTS_FULL, _capi.MAX_ITER) or (status == _capi.INFEASIBLE and r.n > 16):
+        # the stage-wise kernel's slots were too few, the kernel gave up on a degenerate problem, or a stage-wise kernel says
+        # "infeasible" (re-checked by another formulation before it stands: batch._retry_unsolved): the batch path solves
         # again (more slots / the other formulations of the solver)
         return None
     if status != 0:

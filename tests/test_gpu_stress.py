@@ -120,6 +120,41 @@ def test_vertices_of_the_tightest_family_sit_on_their_active_rows():
     assert worst <= 1e-5, worst
 
 
+def test_solve_mpc_delivers_what_an_exact_backend_would_on_known_hard_problems():
+    """The problems of stress_tight's wide family at STRESS_TIGHT=0.3 (seeds 1 and 5) that the wide stage-wise kernel alone gives up on or
+    calls infeasible although the oracle solves them (60-78 of ~80 variables pinned), through the reference's own entry point, solve_mpc
+    (qpmpc/solve_mpc.py:16-44): it re-solves such an item through the other formulations -- an `infeasible` verdict is re-checked too -- and
+    returns the oracle's plan."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle
+    from qpmpc_amd import solve_mpc, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from stress_stagewise import random_ltv
+
+    hard = 0
+    for seed in (1, 5):
+        rng = np.random.default_rng(seed)
+        for it in range(8):  # (the generator of tools/stress_tight.py, wide family)
+            nx, nu = int(rng.integers(5, 17)), int(rng.integers(1, 5))
+            N, mk = int(rng.integers(20, 41)), int(rng.integers(4, 7))
+            w = random_ltv(rng, 8, nx, nu, N, mk, 0.3)
+            w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
+            raw = solve_mpc_batch(W.to_batch_problem(w))
+            torch.cuda.synchronize()
+            st = raw.status.cpu().numpy()
+            Uo, _, sto, _ = oracle.solve_workload(w)
+            for b in np.flatnonzero((st != 0) & (sto == 0)):
+                hard += 1
+                plan = solve_mpc(W.problem_from_workload(w, int(b)), solver="hip_gi")
+                assert not plan.is_empty, (seed, it, int(b), int(st[b]))
+                U = np.asarray(plan.inputs).reshape(-1)
+                assert np.abs(U - Uo[b]).max() <= 1e-7 * max(1.0, np.abs(Uo[b]).max()), (seed, it, int(b))
+    assert hard >= 2  # (the kernel on its own: the strict xfail above)
+
+
 def test_stress_campaign_inconsistent_rows():
     """Rows made inconsistent with their bounds (infeasible and borderline problems): statuses must follow the oracle's.
     (On a few solvable-but-degenerate problems of this family ALL formulations, oracle included, only agree to 1e-3 in u --
