@@ -435,9 +435,6 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
                         for (int j = 0; j < NPQ; ++j) dst[j][na + i0 + 64 * u] = v[j][u];
             }
             wsync();
-#ifdef STAGE_DBG_COPY
-            tick(10);
-#endif
         }
         auto request = [&](int d, int k) {
             if constexpr (PIPE) {
@@ -561,9 +558,7 @@ __global__ void __launch_bounds__(PIPE ? (PWT == 4 ? 320 : 128) : 64, PIPE && PW
                     (wsbase + pq * wl.total + wl.Fimg + (int64_t)(slot ^ 1) * N * FS)[FSI] = __builtin_nan("");
             }
             wsync();
-#ifndef STAGE_DBG_COPY
             tick(10);
-#endif
             return;
         }
     }
