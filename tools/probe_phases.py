@@ -32,5 +32,11 @@ print("  iterations: max", int(it.max().item()), " 99%", torch.quantile(it, 0.99
 pm = torch.maximum(it[0::2], it[1::2]) if not one else it
 print("  per-wavefront max(iterations of the pair): mean", pm.mean().item(), "max", pm.max().item())
 if not one:
-    rt = t[:, 12:14]
-    print(f"  real time (100 MHz): first start -> last end {(rt[:,0].max()-rt[:,1].min()).item()/100:.2f} us ; wavefront mean {(rt[:,0]-rt[:,1]).mean().item()/100:.2f} us max {(rt[:,0]-rt[:,1]).max().item()/100:.2f} us ; start spread {(rt[:,1].max()-rt[:,1].min()).item()/100:.2f} us")
+    rt = t[:, 12:14]  # s_memrealtime (100 MHz) at the first and the last stamp of a wavefront
+    st, en = rt[:, 0], rt[:, 1]
+    if float((en - st).mean()) < 0:  # (the two-per-wavefront kernel stamps them the other way round)
+        st, en = en, st
+    q = torch.tensor([0.5, 0.9, 0.99, 1.0], dtype=torch.float64)
+    print(f"  real time (100 MHz): first start -> last end {(en.max()-st.min()).item()/100:.2f} us ; wavefront mean {(en-st).mean().item()/100:.2f} us max {(en-st).max().item()/100:.2f} us")
+    print("    starts after the first (50/90/99/100 %, us):", [round(v / 100, 2) for v in torch.quantile(st - st.min(), q).tolist()],
+          "; ends before the last:", [round(v / 100, 2) for v in torch.quantile(en.max() - en, q).tolist()])
