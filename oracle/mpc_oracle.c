@@ -178,6 +178,72 @@ void oracle_rollout_one(int nx, int nu, int N, const double *A, int64_t sA,
  */
 static double hyp(double a, double b) { return hypot(a, b); }
 
+/* Iterative refinement of the final active set's KKT system at (x, u): see the comment at the end of oracle_gi_solve.
+ * r: scratch of iq + 1 doubles. */
+static void refine_active(int n, int iq, const int *act, const double *P, const double *qv, const double *G, const double *h,
+                          const double *J, const double *R, double *x, double *u, double *r)
+{
+    long double *r1 = (long double *)calloc((size_t)n, sizeof(long double));
+    long double *r2 = (long double *)calloc((size_t)(iq > 0 ? iq : 1), sizeof(long double));
+    double *w = (double *)calloc((size_t)n, sizeof(double));
+    double *v = (double *)calloc((size_t)(iq > 0 ? iq : 1), sizeof(double));
+    double *xs = (double *)calloc((size_t)n, sizeof(double));
+    double *us = (double *)calloc((size_t)(iq > 0 ? iq : 1), sizeof(double));
+    long double best = INFINITY;
+    for (int pass = 0; pass < 4 && iq > 0; ++pass) {
+        /* residuals of the active set's KKT system at (x, u), extended precision */
+        long double worst = 0.0L;
+        for (int k = 0; k < n; ++k) {
+            long double acc = (long double)qv[k];
+            for (int j = 0; j < n; ++j) acc += (long double)P[(size_t)k * n + j] * (long double)x[j];
+            for (int i = 0; i < iq; ++i) acc += (long double)G[(size_t)act[i] * n + k] * (long double)u[i];
+            r1[k] = -acc;
+        }
+        for (int i = 0; i < iq; ++i) {
+            const int a = act[i];
+            long double acc = (long double)h[a];
+            for (int k = 0; k < n; ++k) acc -= (long double)G[(size_t)a * n + k] * (long double)x[k];
+            r2[i] = acc;
+            const long double rel = fabsl(acc) / (1.0L + fabsl((long double)h[a]));
+            if (rel > worst) worst = rel;
+        }
+        if (!(worst < best)) {  /* no longer improving (or not a number): keep the better point */
+            if (pass > 0) {
+                for (int k = 0; k < n; ++k) x[k] = xs[k];
+                for (int i = 0; i < iq; ++i) u[i] = us[i];
+            }
+            break;
+        }
+        best = worst;
+        if (pass == 3 || worst == 0.0L) break;
+        for (int k = 0; k < n; ++k) xs[k] = x[k];
+        for (int i = 0; i < iq; ++i) us[i] = u[i];
+        for (int j = 0; j < n; ++j) {  /* w = J' r1 */
+            long double acc = 0.0L;
+            for (int k = 0; k < n; ++k) acc += (long double)J[k * n + j] * r1[k];
+            w[j] = (double)acc;
+        }
+        for (int i = 0; i < iq; ++i) {  /* R' v = r2 */
+            long double acc = r2[i];
+            for (int j = 0; j < i; ++j) acc -= (long double)R[j * n + i] * (long double)v[j];
+            v[i] = (double)(acc / (long double)R[i * n + i]);
+        }
+        for (int k = 0; k < n; ++k) {  /* dx = J2 w2 - J1 v */
+            long double acc = 0.0L;
+            for (int j = 0; j < iq; ++j) acc -= (long double)J[k * n + j] * (long double)v[j];
+            for (int j = iq; j < n; ++j) acc += (long double)J[k * n + j] * (long double)w[j];
+            x[k] = (double)((long double)x[k] + acc);
+        }
+        for (int i = iq - 1; i >= 0; --i) {  /* du = -R^-1 (w1 + v), into r (free now) */
+            long double acc = -((long double)w[i] + (long double)v[i]);
+            for (int j = i + 1; j < iq; ++j) acc -= (long double)R[i * n + j] * (long double)r[j];
+            r[i] = (double)(acc / (long double)R[i * n + i]);
+        }
+        for (int i = 0; i < iq; ++i) u[i] += r[i];
+    }
+    free(r1); free(r2); free(w); free(v); free(xs); free(us);
+}
+
 int oracle_gi_solve(int n, int m, const double *P, const double *qv,
                     const double *G, const double *h, int max_iter, double tol,
                     double *x, double *lam, int *iters_out)
@@ -193,7 +259,7 @@ int oracle_gi_solve(int n, int m, const double *P, const double *qv,
     double *np = (double *)calloc(n, sizeof(double));
     int *act = (int *)calloc(n + 1, sizeof(int));
     char *is_active = (char *)calloc(m > 0 ? m : 1, 1);
-    int iq = 0;
+    int iq = 0, refined = 0;
 
     /* Step 0a: Cholesky P = L L' (lower) */
     for (int j = 0; j < n; ++j) {
@@ -237,7 +303,20 @@ int oracle_gi_solve(int n, int m, const double *P, const double *qv,
             double key = s / (1.0 + fabs(h[i]));
             if (key < worst) { worst = key; p = i; sp = s; }
         }
-        if (p < 0) { status = 0; break; }
+        if (p < 0) {
+            /* no inactive row is violated: refine the point on its active set once (round 6, see the end of this function) and look
+               again -- a row that was feasible by less than the refinement moved the point is taken up like any other */
+            if (iq > 0 && !refined) {
+                refine_active(n, iq, act, P, qv, G, h, J, R, x, u, r);
+                for (int i = 0; i < iq; ++i)
+                    if (u[i] < 0.0) u[i] = 0.0; /* (rounding level: a weakly active row) */
+                refined = 1;
+                continue;
+            }
+            status = 0;
+            break;
+        }
+        refined = 0;
         for (int k = 0; k < n; ++k) np[k] = -G[(size_t)p * n + k];
         u[iq] = 0.0;
 
@@ -342,20 +421,32 @@ int oracle_gi_solve(int n, int m, const double *P, const double *qv,
             }
         }
     }
-    /* Acceptance, from scratch (round 3): a point is reported solved only if it is finite, every multiplier is >= 0
-       and every ACTIVE row sits on its bound to 1e-6 (1 + |h_i|) -- inactive rows were just checked by step 1. A failure
-       means a dependent row of an inconsistent problem slipped through the pivot test above: no feasible point was
-       found -> status 2, what qpsolvers reports as found=False (plan.py:35-40). Accepted points are returned
-       untouched, so everything the certified fixtures pin stays bit for bit. */
+    /* Refinement + acceptance (round 6). The loop above ends with every inactive row feasible to tol (1 + |h|), but the point it
+       carries is the SUM of its steps: on a nearly fully active problem (a vertex: as many active rows as variables) the active
+       rows end 1e-8 off their bounds, and that is 2e-6 in the plan -- looser than the 1e-6 contract this oracle checks (SURVEY 2.1
+       asks a "quadprog-class" KKT residual of 1e-9). So the final active set's KKT system
+           P dx + G_A' du = r1 = -(P x + q + G_A' u),     G_A dx = r2 = h_A - G_A x
+       is solved once more -- up to three steps of iterative refinement with the factors the method holds (J J' = P^-1,
+       J' N = [R; 0] with N = -G_A'), the residuals formed in extended precision:
+           w = J' r1,  v = R^-T r2,  dx = J2 w2 - J1 v,  du = -R^-1 (w1 + v).
+       Acceptance, from scratch: the point is finite, every multiplier is >= 0 (to rounding) and every ACTIVE row sits on its bound
+       to 1e-9 (1 + |h_i|) (it was 1e-6 until round 5) -- inactive rows were just checked by step 1. A failure means a dependent row
+       of an inconsistent problem slipped through the pivot test above: no feasible point was found -> status 2, what qpsolvers
+       reports as found=False (plan.py:35-40). */
     if (status == 0) {
         int bad = 0;
+        double umax = 0.0;
+        for (int i = 0; i < iq; ++i)
+            if (u[i] > umax) umax = u[i];
         for (int k = 0; k < n; ++k)
             if (!isfinite(x[k])) bad = 1;
         for (int i = 0; i < iq && !bad; ++i) {
             const int a = act[i];
-            double s = h[a];
-            for (int k = 0; k < n; ++k) s -= G[(size_t)a * n + k] * x[k];
-            if (!(fabs(s) <= 1e-6 * (1.0 + fabs(h[a]))) || !(u[i] >= 0.0)) bad = 1;
+            long double s = (long double)h[a];
+            for (int k = 0; k < n; ++k) s -= (long double)G[(size_t)a * n + k] * (long double)x[k];
+            if (!(fabsl(s) <= 1e-9L * (1.0L + fabsl((long double)h[a])))) bad = 1;
+            if (u[i] < 0.0 && u[i] >= -1e-12 * (1.0 + umax)) u[i] = 0.0;  /* a weakly active row's multiplier, at rounding level */
+            if (!(u[i] >= 0.0)) bad = 1;
         }
         if (bad) status = 2;
     }

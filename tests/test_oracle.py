@@ -46,7 +46,7 @@ def test_gi_matches_certified_solution(name):
     x, lam, status, iters = oracle.gi_solve(P, q, G, h)
     assert status == 0
     scale = max(1.0, np.abs(z["U_star"]).max())
-    assert np.abs(x - z["U_star"]).max() <= 1e-8 * scale
+    assert np.abs(x - z["U_star"]).max() <= 1e-10 * scale  # (round 6: 1e-8 until the oracle refined its final active set)
     stat, prim, dual, comp = kkt_residuals(P, q, G, h, x, lam)
     qs = 1.0 + np.abs(q).max()
     assert stat <= 1e-9 * qs and prim <= 1e-9 and dual <= 1e-12 and comp <= 1e-8 * qs
