@@ -53,12 +53,6 @@ namespace mpcqp {
 #ifndef STAGEW_WPE32
 #define STAGEW_WPE32 3
 #endif
-#ifndef STAGEW_SU32
-#define STAGEW_SU32 8
-#endif
-#ifndef STAGEW_SG
-#define STAGEW_SG 2
-#endif
 #ifndef STAGEW_RF
 #define STAGEW_RF 7 /* (round 4, with the lazy slacks: 7 -> 1.183 ms, 6 -> 1.198, 8 -> 1.215, 10 -> 1.238, 16 -> 1.309 per 8192 config-5 problems) */
 #endif
@@ -67,20 +61,18 @@ namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
-// right-hand sides per sweep pair (columns of the MFMA B operand): the candidate + R - 1 speculated rows. The matrix cores
-// compute all 16 columns whatever their number; what a column costs is its stores (inputs, and h = G V in the FUSE layout,
-// where they go straight into free slots). Measured on config 5: 8 beats 4 by 3 %, 16 loses (later candidates are rarely among
-// the rows that were violated when the sweep ran, and the sweep starts at the latest of its rows' steps).
-constexpr int R_PLAIN = 4, R_FUSE = STAGEW_RF;
+// right-hand sides per BACKWARD sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows. The matrix cores
+// compute all 16 columns whatever their number; a column costs its share of the selection that picks the rows, and the sweep
+// starts at the latest of its rows' steps. (The forward sweeps carry ONE vector since round 6: the projected one.)
+constexpr int R_PLAIN = 8, R_FUSE = STAGEW_RF;
 // LOW (float32, FUSE layout): the instantiation for batches that do not fill the SIMDs -- a launch of at most one wavefront per
 // SIMD (the 8-GPU share of config 5: 1024 problems) is bounded by the LATENCY of its longest problem, and the registers of
-// the empty wavefront slots buy some of it back: one wavefront per SIMD (512 VGPRs), twelve right-hand sides per sweep
-// pair, a six-step request ring, sixteen rows per lane and four slots in flight in the slack passes. Measured on config 5 at
-// batch 1024: 0.325 -> 0.303 ms; at two wavefronts per SIMD and beyond the default instantiation wins.
-constexpr int R_FUSE_LOW = 12, D_LOW = 6, SU_LOW = 16, SG_LOW = 4;
+// the empty wavefront slots buy some of it back: one wavefront per SIMD (512 VGPRs), twelve right-hand sides per backward
+// sweep, a six-step request ring.
+constexpr int R_FUSE_LOW = 12, D_LOW = 6;
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Mb, Mf, KS, ff, U0, Zs, Vc, Hc, Gp, s0, s, invn, thr, rowslot, V, H, W, total;  // (Hc unused)
+    int64_t Mb, Mf, KS, ff, Zs, Gp, s0, s, invn, thr, vpt, Q, W, total;
     int maxq, mg;
 };
 
@@ -93,7 +85,8 @@ inline int64_t rec_elems(int nv) { return nv < 4 ? 64 * nv : (int64_t)((nv + 3) 
 
 // FUSE: the constraint matrices C, D do not change along the horizon and have at most 16 rows per step (a multiple of
 // four): h = G (x_k, u_k) of a forward sweep is then formed by the sweep itself, on the matrix cores, with [C | D] as a
-// constant operand held in registers -- no trajectory (Zs) is written and no pass over the m rows reads it back.
+// constant operand held in registers, and the sweep's own lanes own the rows (slack update, selection): no trajectory is
+// written and no pass over the m rows reads it back.
 inline bool fuse_ok(int mk, bool ginv) { return ginv && mk <= 16 && (mk & 3) == 0; }
 
 // nxc: nx rounded up to a multiple of 4 (the kernel's compile-time row length)
@@ -102,6 +95,8 @@ inline int nxc_of(int nx) { return (nx + 3) & ~3; }
 // ginv: C and D do not change along the horizon (their packed copy holds mk rows instead of N mk)
 inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz, bool low = false)
 {
+    (void)esz;
+    (void)nu;
     Ws w{};
     int64_t o = 0;
     auto take = [&](int64_t cnt) {
@@ -117,26 +112,20 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
     w.Mb = take((int64_t)N * rec_elems(na * nq));
     w.Mf = take((int64_t)N * rec_elems(na * (nq + 1)));
-    w.KS = take((int64_t)N * (nx * nu + 16));  // K' and S^-1 of every step (read at the candidate row's step)
-    w.U0 = take((int64_t)N * 4);               // input trajectories in rows of 4, zero-padded
+    w.KS = take((int64_t)N * (nx * nu + 16));  // K' and the factor of S of every step (read at a candidate row's step)
     const bool fuse = fuse_ok(mk, ginv);
     const int R = fuse ? (low ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
-    w.ff = take((int64_t)R * N * 4);           // feed-forward terms of the latest backward sweep, per right-hand side
-    w.Zs = take(fuse ? 0 : (int64_t)R * N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order, per rhs
-    w.Vc = take(fuse ? 0 : (int64_t)R * N * 4);  // ... and its inputs alone (they move into a slot when the row is taken)
-    w.Hc = 0;
+    w.ff = take((int64_t)R * N * 4);           // whitened vectors y_a of the latest backward sweep's rows, per right-hand side
+    w.Zs = take(fuse ? 0 : (int64_t)N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order
     w.mg = ginv ? mk : (int)m;
-    w.Gp = take(fuse ? 0 : (int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zp's rows, as four-vectors: Gp[j][row], j <= nxc / 4
-    w.s0 = take(m);
+    w.Gp = take(fuse ? 0 : (int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zs's rows, as four-vectors: Gp[j][row], j <= nxc / 4
+    w.s0 = take(m);    // rows of the latest evaluation of the point (the active rows' residuals)
     w.s = take(m);
     w.invn = take(m);
     w.thr = take(m);
-    w.rowslot = take(fuse ? 0 : (m * 4 + esz - 1) / esz);  // int32 per row
-    // slots of V_a = P^-1 g_a' (inputs only) and h_a = G V_a: maxq active rows + the candidate; FUSE: + the R right-hand
-    // sides of a sweep pair, which are written straight into free slots
-    w.V = take((int64_t)(maxq + (fuse ? R : 1)) * N * 4);
-    w.H = take((int64_t)(maxq + (fuse ? R : 1)) * m);
-    w.W = take((int64_t)maxq * maxq);
+    w.vpt = take((int64_t)N * 4);                   // the point in whitened coordinates
+    w.Q = take((int64_t)(maxq + 1) * N * 4);        // Q by vectors (vector nq: the candidate's projection)
+    w.W = take((int64_t)maxq * maxq);               // R by columns, once it has outgrown its LDS tile
     o = (o + 127) & ~(int64_t)127;  // odd multiple of 512 B / 1 KB between problems (memory channels)
     if (((o >> 7) & 1) == 0) o += 128;
     w.total = o;
@@ -234,6 +223,15 @@ template <typename T> struct Ldl4 {
         id[3] = frcp(d3);
         return (d0 > T(0)) & (d1 > T(0)) & (d2 > T(0)) & (d3 > T(0));
     }
+    // b <- Ls^-1 b with S = Ls Ls', Ls = L D^1/2 (sid[i] = 1 / sqrt(d_i)): the WHITENING of a stage's input-sized vector
+    __device__ __forceinline__ void wsolve(T (&b)[4], const T (&sid)[4]) const
+    {
+        b[1] -= l[0] * b[0];
+        b[2] -= l[1] * b[0] + l[3] * b[1];
+        b[3] -= l[2] * b[0] + l[4] * b[1] + l[5] * b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] *= sid[i];
+    }
     __device__ __forceinline__ void solve(T (&b)[4]) const  // b <- S^-1 b
     {
         b[1] -= l[0] * b[0];
@@ -309,21 +307,16 @@ __global__ void __launch_bounds__(64)
     // (the stacked instantiations, nx <= 12, run the recursion in registers and carve no tiles: kTileElems below)
     T *Pm = (T *)stagew_smem, *PAm = Pm + 16 * LD, *Mm = PAm + 16 * LD, *Am = Mm + 16 * LD, *Atm = Am + 16 * LD;
     T *Acm = Atm + 16 * LD, *PBm = Acm + 16 * LD, *Bm = PBm + 16 * 4, *Btm = Bm + 16 * 4, *BPAm = Btm + 4 * LD;
-    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD;
+    T *Km = BPAm + 4 * LD, *Fm = Km + 4 * LD, *Sm = Fm + 4 * LD, *Lim = Sm + 16;  // (Lim: Ls^-1 of the step, 4 x 4)
     T *cst = STACK ? (T *)stagew_smem : Sm + 32;  // cst: 0, 1, spare cells
-    T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq;
-    int *actrow = (int *)(lamv + maxq), *phys = actrow + maxq;  // active row ids; slot permutation (maxq + 1)
-    int *crow = phys + maxq + 1;                                // rows whose P^-1 g' the latest sweeps left in Zs / Vc
+    // (the active set's LDS -- d, r, multipliers, row ids, the tile of R -- is carved behind cst + 8 where the loop starts)
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
     T *Mb = ws + wl.Mb, *Mf = ws + wl.Mf, *KS = ws + wl.KS, *ffv = ws + wl.ff;
-    T *U0 = ws + wl.U0, *Zs = ws + wl.Zs, *Vc = ws + wl.Vc, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn;
-    T *thr = ws + wl.thr;
+    T *Zs = ws + wl.Zs, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn, *thr = ws + wl.thr;
     V4 *Gp = (V4 *)(ws + wl.Gp);
     const int Mg = wl.mg;
     const bool ginv = Mg != M;
-    T *Vs = ws + wl.V, *Hs = ws + wl.H, *Wm = ws + wl.W;
-    int *rowslot = (int *)(ws + wl.rowslot);
     // ---- operands
     const T *gA = (const T *)ka.A.ptr + prob * ka.A.batch_stride;
     const T *gB = (const T *)ka.B.ptr + prob * ka.B.batch_stride;
@@ -468,10 +461,26 @@ __global__ void __launch_bounds__(64)
                 const T v = pg == 0 ? eb[0] : pg == 1 ? eb[1] : pg == 2 ? eb[2] : eb[3];
                 sfull = ucol ? v : T(0);
             }
+            // Ls^-T spread over the input block the same way: lane (pg, input column b) holds Ls^-T[pg][b] = Ls^-1[b][pg]
+            // (S = Ls Ls', Ls = L D^1/2). The records are kept in WHITENED coordinates (round 6): the backward sweep then yields
+            // y_k = Ls_k' ff_k directly and g_a P^-1 g_b' = y_a . y_b (the Riccati recursion is a block Cholesky factorisation of
+            // the condensed Hessian), the forward sweep takes y_k as its input.
+            T sid[4], swh;
+            {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sid[i] = (T)sqrt((double)ldl.id[i]);
+                T eb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) eb[i] = (pg == i) ? T(1) : T(0);
+                ldl.wsolve(eb, sid);
+                const T v = ic == 0 ? eb[0] : ic == 1 ? eb[1] : ic == 2 ? eb[2] : eb[3];
+                swh = ucol ? v : T(0);
+            }
             const MV K3 = Mfma<T>::run(sfull, H[TI], zero4);  // rows of the inputs: S^-1 [H_ux, H_uu]
             const T kfull = scol ? K3[TI] : T(0);              // K = S^-1 H_ux
-            const T ks3 = scol ? K3[TI] : sfull;               // [K, S^-1]
-            const MV E = Mfma<T>::run(mB, ks3, Wz);            // [[Acl, F'], [-K, -S^-1]]
+            const T ks3 = scol ? K3[TI] : swh;                 // [K, Ls^-T]
+            const MV E = Mfma<T>::run(mB, ks3, Wz);            // [[Acl, -B Ls^-T], [-K, -Ls^-T]]
+            const MV RW = Mfma<T>::run(swh, -mB, zero4);       // rows of the inputs: Ls^-1 [B', I]
             MV Hq = H;
 #pragma unroll
             for (int t = 0; t < NQ; ++t) Hq[t] += (4 * t + pg == lcol && lcol < nx && k >= 1) ? wx : T(0);  // (x_0 is data: Q_0 = 0)
@@ -501,7 +510,7 @@ __global__ void __launch_bounds__(64)
                     rb.v[e] = E[e];
                     rf.v[e] = M2[e];
                 }
-                rf.v[NQ] = -mB;
+                rf.v[NQ] = RW[TI];
                 *(RecB *)(Mb + (int64_t)k * SB + lane * LB) = rb;
                 *(RecF *)(Mf + (int64_t)k * SF + lane * LF) = rf;
                 T *ks = KS + (int64_t)k * (nx * nu + 16);
@@ -509,7 +518,7 @@ __global__ void __launch_bounds__(64)
                 if (lane == 0) {
                     T *kf = ks + nx * nu;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
+                    for (int i = 0; i < 4; ++i) kf[i] = sid[i];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
                 }
@@ -540,7 +549,7 @@ __global__ void __launch_bounds__(64)
         int srcb[NB], srcf[NF];
         T sgnf[NF];
         {
-            const int zero = (int)(cst - Pm), one = zero + 1, mrow = Mfma<T>::rowmap(c16);
+            const int zero = (int)(cst - Pm), mrow = Mfma<T>::rowmap(c16);
 #pragma unroll
             for (int blk = 0; blk < NA; ++blk) {
 #pragma unroll
@@ -548,22 +557,29 @@ __global__ void __launch_bounds__(64)
                     const int col = 4 * kk + pg;
                     // the input-sized row this (block, row) is, or -1
                     const int irow = (blk == 0) ? ((STACK && mrow >= NXC && mrow < NXC + 4) ? mrow - NXC : -1) : (mrow < 4 ? mrow : -1);
-                    if (kk < NQ) {  // backward: [Acl' ; F], F = -S^-1 B'
+                    if (kk < NQ) {  // backward: [Acl' ; F], F = -Ls^-1 B'
                         int o = zero;
                         if (blk == 0 && mrow < NXC) o = (int)(Acm - Pm) + col * LD + mrow;
                         if (irow >= 0) o = (int)(Fm - Pm) + irow * LD + col;
                         srcb[blk * NQ + kk] = o;
                     }
-                    {  // forward: [[Acl, B], [-K, I]]
+                    {  // forward: [[Acl, B Ls^-T], [-K, Ls^-T]]  (B Ls^-T = -F' with F = -Ls^-1 B', whitened records: round 6)
                         int o = zero;
                         T sg = T(1);
-                        if (blk == 0 && mrow < NXC) o = col < NXC ? (int)(Acm - Pm) + mrow * LD + col : (int)(Bm - Pm) + mrow * 4 + (col - NXC);
+                        if (blk == 0 && mrow < NXC) {
+                            if (col < NXC) {
+                                o = (int)(Acm - Pm) + mrow * LD + col;
+                            } else {
+                                o = (int)(Fm - Pm) + (col - NXC) * LD + mrow;
+                                sg = T(-1);
+                            }
+                        }
                         if (irow >= 0) {
                             if (col < NXC) {
                                 o = (int)(Km - Pm) + irow * LD + col;
                                 sg = T(-1);
                             } else {
-                                o = (col - NXC == irow) ? one : zero;
+                                o = (int)(Lim - Pm) + (col - NXC) * 4 + irow;  // Ls^-T[irow][j] = Ls^-1[j][irow]
                             }
                         }
                         srcf[blk * (NQ + 1) + kk] = o;
@@ -628,18 +644,25 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                     for (int j = 0; j <= i; ++j, ++e) sv[e] = Sm[i * 4 + j] + ((i == j) ? (i < nu ? wu : T(1)) : T(0));
                 notpd |= !ldl.factor(sv);
-                T kc[4], fc[4];
+                T kc[4], fc[4], ec[4], sid[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     kc[i] = BPAm[i * LD + c16];
                     fc[i] = Bm[c16 * 4 + i];
+                    ec[i] = (c16 == i) ? T(1) : T(0);
+                    sid[i] = (T)sqrt((double)ldl.id[i]);
                 }
                 ldl.solve(kc);
-                ldl.solve(fc);
+                ldl.wsolve(fc, sid);  // Ls^-1 B' (column c16): the WHITENED feed-forward row block
+                ldl.wsolve(ec, sid);  // Ls^-1 (column c16 < 4)
                 const T kv = pg == 0 ? kc[0] : pg == 1 ? kc[1] : pg == 2 ? kc[2] : kc[3];
                 const T fv = pg == 0 ? fc[0] : pg == 1 ? fc[1] : pg == 2 ? fc[2] : fc[3];
+                const T lv = pg == 0 ? ec[0] : pg == 1 ? ec[1] : pg == 2 ? ec[2] : ec[3];
                 Km[pg * LD + c16] = kv;
                 Fm[pg * LD + c16] = -fv;
+                if (c16 < 4) Lim[pg * 4 + c16] = lv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ldl.id[i] = sid[i];  // (what the workspace keeps: 1 / sqrt(d_i))
             }
             wsync();
             mm_t<T, 4, LD, LD, 16, 16, 4, true>(Acm, Bm, Km, Am, pg, c16);           // Acl = A - B K
@@ -793,9 +816,8 @@ __global__ void __launch_bounds__(64)
         for (int d = 0; d < D - 1; ++d)
             if (k - d >= 0) step(d, k - d, false);
     };
-    // forward: (x_{k+1}, u_k) = [[Acl_k, B_k], [-K_k, I]] (x_k, ff_k) from x_0 = xs (ff_k = 0 for k > kff); writes the
-    // inputs to Uo[k][0..3] and (x_k, u_k) to Zp[k]
-    // per column: ff_k = 0 for k > kff; inputs to Uo[k][0..3], (x_k, u_k) to Zo[k] (lanes with `on`)
+    // forward: (x_{k+1}, u_k) = [[Acl_k, B_k Ls_k^-T], [-K_k, Ls_k^-T]] (x_k, y_k) from x_0 = xs, y = the WHITENED feed-forward
+    // terms yin[k][0..3] (what the backward sweep left, or a projected vector of the active set).
     // FUSE: [C | D]' as a constant MFMA operand: chunk q of lane (c16, pg) is G[r][4 q + pg] of the row r that lane c16 stands
     // for (chosen so that row group pg' of the RESULT holds rows 4 pg' .. 4 pg' + 3 in both precisions); the last chunk is D
     constexpr int NG = NQ + 1;
@@ -811,18 +833,99 @@ __global__ void __launch_bounds__(64)
     bool gnz[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) gnz[q] = FUSE && __ballot(gT[q] != T(0)) != 0ull;
-    // ... Ho (FUSE): h = G (x_k, u_k) of every step goes to Ho[k mk + r] (lanes with `on`; per column through hoff)
-    auto forward = [&](const T *xs, int kff, T *Uo, unsigned uoff, T *Zo, unsigned zoff, bool on, T *Ho, unsigned hoff) {
+    const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
+    auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
+    const T tol = ka.tol;
+
+    // ---- what happens to a row of G once h_i = g_i . (x_k, u_k) of a forward sweep is known (round 6: the sweeps own the rows).
+    // INIT: the sweep of the unconstrained minimiser -- slack, threshold, selection metric; DIR: a step of length tstep along a
+    // projected vector z (s += t G z_u; active rows stay on their bounds; on a FULL step the candidate lands on its bound and
+    // becomes active: infinite threshold); EVAL: the point from scratch (s = e - G (x, u), active rows checked against their bounds,
+    // inactive ones against feasibility). Every mode also looks for the most violated inactive row (sel*).
+    enum { FW_INIT = 0, FW_DIR = 1, FW_EVAL = 2 };
+    T selb = INF, selv = T(0), spnew = T(0);
+    int seli = 0x7fffffff;
+    bool offa = false, dirty = false;
+    auto rowlogic = [&](int mode, int i, T hs, T hsa, T ra, T rb, T iv, T tstep, int bi, bool full, T fac) {
+        T v, th;
+        bool skip = false;
+        if (mode == FW_INIT) {
+            v = ra - hs;
+            th = tol + tol * (T)fabs((double)ra);
+            sl[i] = v;
+            thr[i] = th;
+            invn[i] = iv;
+        } else if (mode == FW_DIR) {
+            th = rb;
+            const bool me = i == bi;
+            skip = (th == INF) || (full && me);
+            v = skip ? T(0) : ra + tstep * hs;
+            sl[i] = v;
+            if (full && me) thr[i] = INF;
+            if (me) spnew = v;
+        } else {
+            th = rb;
+            const T st = ra - hs;
+            const bool act = th == INF;
+            s0[i] = st;
+            sl[i] = act ? T(0) : st;
+            if (act) {
+                // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the terms' magnitudes)
+                const T lim = fac * (tol + tol * (T)fabs((double)ra)) +
+                              (sizeof(T) == 4 ? T(STAGEW_VNOISE32) * T(6e-8) * ((T)fabs((double)ra) + hsa) : T(0));
+                offa |= !((T)fabs((double)st) <= lim);
+            } else if (!(st >= T(-4) * th)) {
+                dirty = true;
+            }
+            skip = act;
+            v = st;
+        }
+        const T sc = v * iv;
+        if (!skip && v < -th && sc < selb) {  // (ties: a lane meets its rows in ascending order; across lanes wave_argmin)
+            selb = sc;
+            seli = i;
+            selv = v;
+        }
+    };
+    // the lane that owns row i in the sweeps (FUSE) / the m-row passes
+    auto owner = [&](int i) {
+        if constexpr (FUSE) {
+            const int r = i - stepof(i) * mk;
+            return 16 * (r >> 2) + (r & 3);
+        } else {
+            return i & 63;
+        }
+    };
+    auto sel_reduce = [&]() {
+        wave_argmin(selb, seli);
+        selv = __shfl(selv, owner(seli < M ? seli : 0));
+    };
+    T myinvn = T(1);  // FUSE: 1 / |g_r| of the row this lane owns in the sweeps (r = 4 pg + c16, c16 < 4)
+    if constexpr (FUSE) {
+        T nnv = T(0);  // |g_r|^2 of the row this lane's column stands for in gT (summed over the four row groups)
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) nnv += gT[q] * gT[q];
+        nnv += __shfl_xor(nnv, 16);
+        nnv += __shfl_xor(nnv, 32);
+        const int r = (4 * pg + (c16 & 3)) & 15;
+        const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
+        myinvn = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+    }
+    T *ou = (T *)ka.U + prob * (int64_t)nvar;
+    auto forward = [&](int mode, const T *xs, const T *yin, T tstep, int bi, bool full, T fac) {
+        // FUSE: the vector rides in columns 0..3 (the matrix cores compute sixteen whatever their number), so that the SIXTEEN
+        // lanes (pg, c16 < 4) each hold the rows 4 pg .. 4 pg + 3 of the step and each owns ONE of them: row 4 pg + c16
+        const bool cuse = FUSE ? c16 < 4 : col0;
+        const bool hl = FUSE && c16 < 4 && 4 * pg < mk;
+        const int rr = hl ? 4 * pg + c16 : 0;
         T z[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) z[q] = (xs && col0 && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
-        const unsigned ffo = (unsigned)(cn * N * 4 + pg);
-        uoff += (unsigned)pg;
-        zoff += (unsigned)(pg * (NQ + 1));
-        T rec[D][NF], ffr[D];
+        for (int q = 0; q < NQ; ++q) z[q] = (xs && cuse && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
+        const unsigned zoff = (unsigned)(pg * (NQ + 1));
+        T rec[D][NF], ffr[D], ra[D], rb[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            ffr[d] = T(0);
+            ffr[d] = ra[d] = rb[d] = T(0);
 #pragma unroll
             for (int e = 0; e < NF; ++e) rec[d][e] = T(0);
         }
@@ -835,7 +938,12 @@ __global__ void __launch_bounds__(64)
                 for (int j = 0; j < LF; ++j)
                     if (LF * g + j < NF) rec[d][LF * g + j] = v.v[j];
             }
-            ffr[d] = ffv[ffo + (unsigned)(k * 4)];
+            ffr[d] = yin[(unsigned)(k * 4 + pg)];
+            if constexpr (FUSE) {
+                const unsigned ri = (unsigned)(k * mk + rr);
+                ra[d] = mode == FW_DIR ? sl[ri] : ge[k * sE + rr];
+                rb[d] = mode == FW_INIT ? T(0) : thr[ri];
+            }
         };
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -843,7 +951,7 @@ __global__ void __launch_bounds__(64)
             __builtin_amdgcn_sched_barrier(0);
         }
         auto step = [&](int d, int k, bool again) {
-            const T ffd = (k <= kff && on) ? ffr[d] : T(0);
+            const T ffd = cuse ? ffr[d] : T(0);
             MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int kk = 0; kk <= NQ; ++kk) {
@@ -852,22 +960,29 @@ __global__ void __launch_bounds__(64)
                 if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
             }
             const T u = STACK ? a0[NQ] : a1[0];
+            if (mode != FW_DIR && col0 && pg < nu) ou[k * nu + pg] = u;  // (the point itself: the unconstrained minimiser / the evaluated one)
             if constexpr (FUSE) {
-                MV hk = {T(0), T(0), T(0), T(0)};
+                MV hk = {T(0), T(0), T(0), T(0)}, ha = {T(0), T(0), T(0), T(0)};
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
                     if (gnz[q]) hk = Mfma<T>::run(gT[q], z[q], hk);
                 if (gnz[NQ]) hk = Mfma<T>::run(gT[NQ], u, hk);
-                if (on) {
-                    Uo[uoff + (unsigned)(k * 4)] = u;
-                    if (4 * pg < mk) *(V4 *)(Ho + (hoff + (unsigned)(k * mk + 4 * pg))) = hk;
+                if (sizeof(T) == 4 && mode == FW_EVAL) {  // sum |g_ij| |x_j|: the magnitude of the row's terms
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (gnz[q]) ha = Mfma<T>::run((T)fabs((double)gT[q]), (T)fabs((double)z[q]), ha);
+                    if (gnz[NQ]) ha = Mfma<T>::run((T)fabs((double)gT[NQ]), (T)fabs((double)u), ha);
                 }
-            } else if (on) {
+                if (hl) {
+                    const T hs = c16 == 0 ? hk[0] : c16 == 1 ? hk[1] : c16 == 2 ? hk[2] : hk[3];
+                    const T hsa = c16 == 0 ? ha[0] : c16 == 1 ? ha[1] : c16 == 2 ? ha[2] : ha[3];
+                    rowlogic(mode, k * mk + rr, hs, hsa, ra[d], rb[d], myinvn, tstep, bi, full, fac);
+                }
+            } else if (col0) {
                 const unsigned zr = zoff + (unsigned)(k * ZL);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) Zo[zr + q] = z[q];
-                Zo[zr + NQ] = u;
-                Uo[uoff + (unsigned)(k * 4)] = u;
+                for (int q = 0; q < NQ; ++q) Zs[zr + q] = z[q];
+                Zs[zr + NQ] = u;
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) z[q] = a0[q];
@@ -883,13 +998,10 @@ __global__ void __launch_bounds__(64)
         for (int d = 0; d < D - 1; ++d)
             if (k + d < N) step(d, k + d, false);
     };
-    // ---- the m-row passes: lane <-> row i = k mk + r, GU rows per lane in flight
-    constexpr int GU = sizeof(T) == 4 ? 2 : 1;                       // rows of G per lane in flight (2 (NQ + 1) four-vectors each)
-    constexpr int SU = sizeof(T) == 4 ? (LOW ? SU_LOW : STAGEW_SU32) : 4;  // rows per lane in flight in the slack passes
-    const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
-    auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
-    // [C | D] packed once: row i (or r, when they do not change along the horizon) in the order of Zp's rows, as NQ + 1
-    // four-vectors, zero-padded, vector-major so that the lanes of a pass read side by side
+    // ---- the general constraint layout: [C | D] packed once -- row i (or r, when they do not change along the horizon) in the
+    // order of Zs's rows, as NQ + 1 four-vectors, zero-padded, vector-major so that the lanes of a pass read side by side -- and
+    // ONE pass over the m rows behind every forward sweep: lane <-> row i = k mk + r, GU rows per lane in flight
+    constexpr int GU = sizeof(T) == 4 ? 2 : 1;
     for (int i = lane; i < (FUSE ? 0 : Mg); i += 64) {
         const int k = stepof(i), r = i - k * mk;
         V4 g[NQ + 1];
@@ -907,110 +1019,62 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int q = 0; q <= NQ; ++q) Gp[(int64_t)q * Mg + i] = g[q];
     }
-    // hd[i] = g_i . (x_k, u_k) of the latest forward sweep (Zp): the four-vectors of GU rows are requested together
-    // (when C, D are fixed along the horizon and mk divides 64, a lane meets the same row of [C | D] in every pass: it
-    // is loaded once and the passes only fetch the (x_k, u_k) rows, four of them in flight)
-    const bool ghoist = ginv && (64 % mk == 0);
-    auto gdot = [&](const V4 (&g)[NQ + 1], const V4 (&zq)[NQ + 1]) {
-        T acc = T(0);
+    auto rowpass = [&](int mode, T tstep, int bi, bool full, T fac) {
+        for (int i0 = lane; i0 < M; i0 += 64 * GU) {
+            V4 g[GU][NQ + 1], zq[GU][NQ + 1];
+            T ra[GU], rb[GU], rc[GU];
 #pragma unroll
-        for (int q = 0; q <= NQ; ++q) acc += g[q][0] * zq[q][0] + g[q][1] * zq[q][1] + g[q][2] * zq[q][2] + g[q][3] * zq[q][3];
-        return acc;
-    };
-    // cap >= 0: also leaves c_a = h[row a] of the active rows in cv[] and returns h[cap]
-    auto gmul = [&](T *hd, const T *Zp, int cap) {
-        T capv = T(0);
-        auto keep = [&](int i, int rs, T v) {  // rs: the row's active index (requested with the row's operands)
-            if (rs >= 0) cv[rs] = v;
-            if (i == cap) capv = v;
-        };
-        if (ghoist) {
-            constexpr int ZU = sizeof(T) == 4 ? 4 : 2;
-            V4 gfix[NQ + 1];
-            const int r = lane - (lane / mk) * mk;
+            for (int u = 0; u < GU; ++u) {
+                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
+                const int k = stepof(i);
+                const int gi = ginv ? i - k * mk : i;
+                const V4 *zr = (const V4 *)(Zs + (unsigned)(k * ZL));
 #pragma unroll
-            for (int q = 0; q <= NQ; ++q) gfix[q] = Gp[(unsigned)(q * Mg + r)];
-            for (int i0 = lane; i0 < M; i0 += 64 * ZU) {
-                V4 zq[ZU][NQ + 1];
-                int rs[ZU];
-#pragma unroll
-                for (int u = 0; u < ZU; ++u) {
-                    const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
-                    const V4 *zr = (const V4 *)(Zp + (unsigned)(stepof(i) * ZL));
-#pragma unroll
-                    for (int q = 0; q <= NQ; ++q) zq[u][q] = zr[q];
-                    rs[u] = cap >= 0 ? rowslot[(unsigned)i] : -1;
+                for (int q = 0; q <= NQ; ++q) {
+                    g[u][q] = Gp[(unsigned)(q * Mg + gi)];
+                    zq[u][q] = zr[q];
                 }
-#pragma unroll
-                for (int u = 0; u < ZU; ++u)
-                    if (i0 + 64 * u < M) {
-                        const T v = gdot(gfix, zq[u]);
-                        hd[i0 + 64 * u] = v;
-                        keep(i0 + 64 * u, rs[u], v);
-                    }
+                ra[u] = mode == FW_DIR ? sl[i] : ge[k * sE + (i - k * mk)];
+                rb[u] = mode == FW_INIT ? T(0) : thr[i];
+                rc[u] = mode == FW_INIT ? T(0) : invn[i];
             }
-        } else {
-            for (int i0 = lane; i0 < M; i0 += 64 * GU) {
-                V4 g[GU][NQ + 1], zq[GU][NQ + 1];
-                int rs[GU];
 #pragma unroll
-                for (int u = 0; u < GU; ++u) {
-                    const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
-                    const int k = stepof(i);
-                    const int gi = ginv ? i - k * mk : i;
-                    const V4 *zr = (const V4 *)(Zp + (unsigned)(k * ZL));
+            for (int u = 0; u < GU; ++u)
+                if (i0 + 64 * u < M) {
+                    T hs = T(0), hsa = T(0), nn = T(0);
 #pragma unroll
-                    for (int q = 0; q <= NQ; ++q) {
-                        g[u][q] = Gp[(unsigned)(q * Mg + gi)];
-                        zq[u][q] = zr[q];
-                    }
-                    rs[u] = cap >= 0 ? rowslot[(unsigned)i] : -1;
+                    for (int q = 0; q <= NQ; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            hs += g[u][q][j] * zq[u][q][j];
+                            if (sizeof(T) == 4) hsa += (T)fabs((double)(g[u][q][j] * zq[u][q][j]));
+                            nn += g[u][q][j] * g[u][q][j];
+                        }
+                    const T iv = mode == FW_INIT ? (nn > T(0) ? (T)rsqrt((double)nn) : T(1)) : rc[u];
+                    rowlogic(mode, i0 + 64 * u, hs, hsa, ra[u], rb[u], iv, tstep, bi, full, fac);
                 }
-#pragma unroll
-                for (int u = 0; u < GU; ++u)
-                    if (i0 + 64 * u < M) {
-                        const T v = gdot(g[u], zq[u]);
-                        hd[i0 + 64 * u] = v;
-                        keep(i0 + 64 * u, rs[u], v);
-                    }
-            }
         }
-        return cap >= 0 ? __shfl(capv, cap & 63) : T(0);
     };
-    // the violated row farthest from its hyperplane (active rows sit at s = 0 exactly, rows without a bound at ~1e30:
-    // neither can be selected); ties go to the lowest row id, like the restatement
-    // (TU rows per lane are requested together; `sp` returns the winner's slack)
-    constexpr int TU = sizeof(T) == 4 ? 8 : 4;
-    auto select = [&](T &best, int &bi, T &sp) {
-        best = INF;
-        bi = 0x7fffffff;
-        T bsv = T(0);
-        for (int i0 = lane; i0 < M; i0 += 64 * TU) {
-            T sv[TU], iv[TU], th[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                sv[u] = sl[i];
-                iv[u] = invn[i];
-                th[u] = thr[i];
-            }
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const T sc = sv[u] * iv[u];
-                if (i0 + 64 * u < M && sv[u] < -th[u] && sc < best) {
-                    best = sc;
-                    bi = i0 + 64 * u;
-                    bsv = sv[u];
-                }
-            }
+    // a forward sweep and what follows it: the rows, the reduction of the selection
+    auto fsweep = [&](int mode, const T *xs, const T *yin, T tstep, int bi, bool full, T fac) {
+        selb = INF;
+        seli = 0x7fffffff;
+        selv = T(0);
+        offa = dirty = false;
+        forward(mode, xs, yin, tstep, bi, full, fac);
+        if constexpr (!FUSE) {
+            wsync();  // (the trajectory is read by other lanes)
+            rowpass(mode, tstep, bi, full, fac);
         }
-        wave_argmin(best, bi);
-        sp = __shfl(bsv, bi & 63);  // (row i lives in lane i % 64)
+        sel_reduce();
+        if (mode == FW_DIR) spnew = __shfl(spnew, owner(bi));
+        offa = __ballot(offa) != 0ull;
+        dirty = __ballot(dirty) != 0ull;
     };
 
-    // the right-hand sides of a sweep pair: column 0 carries the candidate row bi, columns 1 .. R - 1 the next most violated
-    // rows (V_a = P^-1 g_a' does not depend on the active set: a row found among them later costs no sweep; which rows ride
-    // along has no influence on the iterates). Per lane: its column's row, the row's step, (p_kq, ff_kq) to inject there;
+    // the right-hand sides of a backward sweep: column 0 carries the candidate row bi, columns 1 .. R - 1 the next most violated
+    // rows (the whitened vector y_a of a row does not depend on the active set: a row found among them later costs no sweep; which
+    // rows ride along has no influence on the iterates). Per lane: its column's row, the row's step, (p_kq, y_kq) to inject there;
     // kmax = the latest of the steps.
     // warm-state record (MpcqpSolveOpts.warm_state): int32 count, then the rows that were active when the last solve ended
     int *wrec = ka.warm_state ? (int *)((char *)ka.warm_state + prob * (int64_t)stagew_warm_bytes(maxq)) : nullptr;
@@ -1019,6 +1083,7 @@ __global__ void __launch_bounds__(64)
         wcnt = __builtin_amdgcn_readfirstlane(wrec[0]);  // (wave-uniform: scalar registers)
         wcnt = (wcnt < 0 || wcnt > maxq) ? 0 : wcnt;     // (a record that is not one: no warm rows)
     }
+    constexpr int TU = sizeof(T) == 4 ? 8 : 4;  // rows per lane requested together
     auto candidates = [&](int bi, int &myrow, int &mykq, int &kmax, MV &st, T &ffs) {
         // rows[0] = the candidate; then the next most violated rows (per-lane top two, R - 1 wave minima)
         int rows[R];
@@ -1026,13 +1091,13 @@ __global__ void __launch_bounds__(64)
         int jstart = 1;  // rows[1 .. jstart - 1] come from the warm list
         if (wpos < wcnt) {
             // MPCQP_WARM_ACTIVE_SET: the rows that were active at the end of the previous solve (moved with the horizon) ride
-            // along FIRST -- V_a = P^-1 g_a' does not depend on the active set, so when the iterations ask for one of them
-            // its sweeps are already done. Sixteen ids are examined per call (one round trip): in range, not the candidate,
+            // along FIRST -- y_a does not depend on the active set, so when the iterations ask for one of them
+            // its sweep is already done. Sixteen ids are examined per call (one round trip): in range, not the candidate,
             // not active now.
             const int t = lane & 15;
             const int id = wpos + t < wcnt ? wrec[1 + wpos + t] - ka.warm_shift : -1;
             bool okr = id >= 0 && id < M && id != bi && lane < 16;
-            if (okr) okr = FUSE ? !(thr[id] == INF) : rowslot[id] < 0;
+            if (okr) okr = !(thr[id] == INF);
             unsigned okm = (unsigned)__ballot(okr) & 0xffffu;
             int last = -1;
 #pragma unroll
@@ -1070,7 +1135,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                         for (int j = 1; j < R; ++j) dup = dup || (j < jstart && rows[j] == i);
                     }
-                    if (i < M && sv[u] < -th[u] && i != bi && !dup) {
+                    if (i < M && sv[u] < -th[u] && i != bi && !dup) {  // (an active row's threshold is infinite)
                         if (sc < b1) {
                             b2 = b1;
                             i2 = i1;
@@ -1102,8 +1167,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int j = 0; j < R; ++j)
             if (c16 == j) myrow = rows[j];
-        // (p_kq, ff_kq) of this lane's row (kq, rq): p = -C' + K' D', ff = S^-1 D'  (r = -D'; the costate above
-        // kq is zero)
+        // (p_kq, y_kq) of this lane's row (kq, rq): p = -C' + K' D', y = Ls^-1 D'  (r = -D'; the costate above kq is zero)
         st = MV{T(0), T(0), T(0), T(0)};
         ffs = T(0);
         mykq = -1;
@@ -1111,12 +1175,13 @@ __global__ void __launch_bounds__(64)
             const int kq = stepof(myrow), rq = myrow - kq * mk;
             mykq = kq;
             const T *ks = KS + (int64_t)kq * (nx * nu + 16);
-            T dd[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
+            T dd[NU], sid[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
             Ldl4<T> ldl;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
-                ldl.id[i] = ks[nx * nu + i];
+                sid[i] = ks[nx * nu + i];
+                ldl.id[i] = T(0);
             }
 #pragma unroll
             for (int i = 0; i < 6; ++i) ldl.l[i] = ks[nx * nu + 4 + i];
@@ -1134,7 +1199,7 @@ __global__ void __launch_bounds__(64)
                 for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
                 st[q] = v;
             }
-            ldl.solve(dd);  // S^-1 D'
+            ldl.wsolve(dd, sid);  // Ls^-1 D'
             ffs = pg == 0 ? dd[0] : pg == 1 ? dd[1] : pg == 2 ? dd[2] : dd[3];
         }
         kmax = -1;
@@ -1145,7 +1210,7 @@ __global__ void __launch_bounds__(64)
         }
     };
 
-    // ================================================================= unconstrained minimiser, slacks
+    // ================================================================= unconstrained minimiser, slacks, first selection
     tick(2);
     {
         MV pN = {T(0), T(0), T(0), T(0)};
@@ -1158,975 +1223,382 @@ __global__ void __launch_bounds__(64)
     }
     wsync();
     tick(3);
-    if constexpr (FUSE) {
-        // ================================================================= FUSE: constraint matrices fixed along the horizon
-        // What an iteration costs here is not arithmetic but DEPENDENT ROUND TRIPS to HBM (~1 us each under load, and a
-        // wavefront-wide hand-over through global memory needs the stores drained first). So:
-        //   * everything the lanes hand to each other inside an iteration lives in LDS -- c, r, the multipliers, the slot
-        //     bookkeeping and W = (G_A P^-1 G_A')^-1 itself while it has at most WL rows (it moves to the workspace when
-        //     the 33rd row arrives); LDS operations of ONE wavefront execute in order, so those hand-overs need no wait;
-        //   * per-row arrays (slacks, thresholds, h_a) are only ever touched by the lane that owns the row (row i <-> lane
-        //     i % 64, also for the single-row updates when a row enters or leaves): same-lane accesses need no fence;
-        //   * the sweeps write V_a and h_a = G V_a (formed by the forward sweep itself) straight into free SLOTS; taking
-        //     a candidate is bookkeeping, nothing is copied; an active row is marked by an infinite threshold;
-        //   * the feed-forward terms go from the backward to the forward sweep through the same lane.
-        // One store drain per sweep pair is left (its slots are read by every lane).
-        constexpr int WL = 32, WLD = 33;
-        int *cslot = crow + R, *freel = cslot + R;
-        T *Wl = (T *)(((uintptr_t)(freel + maxq) + 15) & ~(uintptr_t)15);
-        // LAZY SLACKS (round 4). A full step moves every slack by t (h_p - sum_a r_a h_a): one pass over the m rows that reads
-        // |A| + 1 slot arrays -- a quarter of an iteration's time at batch 8192 (HBM) and most of its dependent round trips
-        // at batch 1024 -- although the next iteration only needs the slack of ONE row when that row's vectors are already
-        // in a candidate slot. The pass is therefore DEFERRED: the step is folded into pending coefficients pcv[a] (true
-        // slack = sl + sum_a pcv[a] h_a), the next candidate is looked for among the cached rows first, each evaluated
-        // exactly from its own entries of the h_a (|A| loads per row, one round trip), and the pending sum is applied in one
-        // pass only when none of them is violated (then the most violated row of ALL is selected, as before), before a row
-        // leaves, and before the verification. On config 5 that is 2.1 full passes per problem instead of 6.4
-        // (tools/sim_lazy.py; measured: 1.215 against 1.278 ms per 8192 problems); the price is the selection rule -- a violated cached row is preferred to a more violated row
-        // that would need a sweep -- i.e. other iterates (4 % more iterations), the same minimiser. MPCQP_OPT_EXACT_SELECTION
-        // keeps the old rule (the tests that compare iteration counts across instantiations).
-        T *pcv = Wl + WL * WLD;
-        // (not in the small-batch instantiation: one wavefront per SIMD is bound by the longest problem's dependent round
-        // trips, and there the extra evaluation and the 4 % more iterations cost 9 % -- 0.318 against 0.292 ms per 1024)
-        const bool lazy = !LOW && !(ka.opt_flags & MPCQP_OPT_EXACT_SELECTION);
-        bool pend = false;
-        for (int a = lane; a < maxq; a += 64) pcv[a] = T(0);
-        forward(gx0, N, U0, 0u, nullptr, 0u, col0, sl, 0u);  // h = G (x, u) of the unconstrained minimiser into sl
-        wsync();
-        tick(4);
-        const T tol = ka.tol;
-        T nnv = T(0);  // |g_r|^2 of the row this lane's column stands for in gT (summed over the four row groups)
-#pragma unroll
-        for (int q = 0; q <= NQ; ++q) nnv += gT[q] * gT[q];
-        nnv += __shfl_xor(nnv, 16);
-        nnv += __shfl_xor(nnv, 32);
-        for (int i0 = lane; i0 < M; i0 += 64 * SU) {  // (SU rows per lane with their loads in flight together)
-            T ev[SU], hv[SU];
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
-                const int k = stepof(i), r = i - k * mk;
-                ev[u] = ge[k * sE + r];
-                hv[u] = sl[i];
-            }
-#pragma unroll
-            for (int u = 0; u < SU; ++u) {
-                const int i = i0 + 64 * u < M ? i0 + 64 * u : M - 1;
-                const int r = i - stepof(i) * mk;
-                const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
-                if (i0 + 64 * u < M) {
-                    const T sv = ev[u] - hv[u];
-                    s0[i] = sv;
-                    sl[i] = sv;
-                    thr[i] = tol + tol * (T)fabs((double)ev[u]);
-                    invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
+    // ---- LDS of the active set (round 6): the thin QR factorisation Y_A = Q R of the active rows' whitened vectors. R (upper
+    // triangular, by COLUMNS through a permutation: nothing is copied when a row leaves) sits in a WL x WL tile of LDS and
+    // moves to the workspace when the 33rd row arrives; Q (vectors of nv4 entries) lives in the workspace, every pass over it
+    // with the same lane <-> step mapping: no exchange through memory between its passes. d = Q' y (cv), r = R^-1 d (rv), the
+    // multipliers, the rows' ids, a scratch vector (ev: re-orthogonalisation, rotations), the rows cached by the backward sweeps.
+    constexpr int WL = 32, WLD = 33;
+    T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq, *ev = lamv + maxq;
+    int *actrow = (int *)(ev + maxq), *colp = actrow + maxq, *crow = colp + maxq;
+    T *Rl = (T *)(((uintptr_t)(crow + R) + 15) & ~(uintptr_t)15);
+    T *vpt = ws + wl.vpt, *Qs = ws + wl.Q, *Wm = ws + wl.W;
+    for (int a = lane; a < maxq; a += 64) colp[a] = a;
+    if (lane < R) crow[lane] = -1;
+    // the point in whitened coordinates: v = y0 (the sweeps' lane <-> step mapping of the vector passes: lane k % 64 owns step k)
+    for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] = ((const V4 *)ffv)[k];
+    lsync();
+    fsweep(FW_INIT, gx0, ffv, T(0), -1, false, T(0));
+    tick(4);
+    tick(5);
+
+    int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
+    const int max_iter = ka.max_iter;
+    bool fail = false, slotsfull = false, wglob = false;
+    const T DEP = sizeof(T) == 4 ? T(1e-10) : T(1e-26);  // |z|^2 <= DEP |y|^2: the row depends on the active ones
+    auto dot4 = [](V4 a, V4 b) { return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]); };
+    auto Q4 = [&](int a) { return (V4 *)(Qs + (int64_t)a * nv4); };
+    // d = Q' y into cv, z = y - Q d into zq; when that cancelled (|z|^2 < |y|^2 / 4) once more on z, the second pass's coefficients
+    // added to d (classical Gram-Schmidt with re-orthogonalisation on demand); returns |z|^2 as the SUM of z's squares.
+    // y: a cached row's vector, zero behind its step kq (the array holds stale values there).
+    auto ortho = [&](const T *yp, int kq, T *zq, T &yy) -> T {
+        T zz = T(0);
+        for (int pass = 0; pass < 2; ++pass) {
+            const V4 *src = (const V4 *)(pass == 0 ? yp : zq);
+            const int klim = pass == 0 ? kq : N - 1;
+            T *co = pass == 0 ? cv : ev;
+            const V4 zero4v = {T(0), T(0), T(0), T(0)};
+            for (int a0 = 0; a0 < nq; a0 += 4) {  // four vectors per round: their loads overlap
+                T p0 = T(0), p1 = T(0), p2 = T(0), p3 = T(0);
+                const V4 *q0 = Q4(a0), *q1 = Q4(a0 + 1 < nq ? a0 + 1 : a0), *q2 = Q4(a0 + 2 < nq ? a0 + 2 : a0), *q3 = Q4(a0 + 3 < nq ? a0 + 3 : a0);
+                for (int k = lane; k < N; k += 64) {
+                    const V4 sv = k <= klim ? src[k] : zero4v;
+                    const V4 v0 = q0[k], v1 = q1[k], v2 = q2[k], v3 = q3[k];
+                    p0 += dot4(v0, sv);
+                    p1 += dot4(v1, sv);
+                    p2 += dot4(v2, sv);
+                    p3 += dot4(v3, sv);
+                }
+                p0 = wave_sum(p0);
+                p1 = wave_sum(p1);
+                p2 = wave_sum(p2);
+                p3 = wave_sum(p3);
+                if (lane == 0) {
+                    co[a0] = p0;
+                    if (a0 + 1 < nq) co[a0 + 1] = p1;
+                    if (a0 + 2 < nq) co[a0 + 2] = p2;
+                    if (a0 + 3 < nq) co[a0 + 3] = p3;
                 }
             }
+            lsync();
+            T part = T(0), ypart = T(0);
+            for (int k = lane; k < N; k += 64) {
+                V4 acc = k <= klim ? src[k] : zero4v;
+                ypart += dot4(acc, acc);
+                int a = 0;
+                for (; a + 4 <= nq; a += 4) {
+                    const V4 v0 = Q4(a)[k], v1 = Q4(a + 1)[k], v2 = Q4(a + 2)[k], v3 = Q4(a + 3)[k];
+                    const T c0 = co[a], c1 = co[a + 1], c2 = co[a + 2], c3 = co[a + 3];
+                    acc -= c0 * v0 + c1 * v1;
+                    acc -= c2 * v2 + c3 * v3;
+                }
+                for (; a < nq; ++a) acc -= co[a] * Q4(a)[k];
+                ((V4 *)zq)[k] = acc;
+                part += dot4(acc, acc);
+            }
+            const T prev = pass == 0 ? wave_sum(ypart) : zz;
+            if (pass == 0) yy = prev;
+            zz = wave_sum(part);
+            if (pass == 1) {
+                for (int a = lane; a < nq; a += 64) cv[a] += ev[a];
+                lsync();
+            }
+            if (pass == 0 && (nq == 0 || zz >= T(0.25) * prev)) break;  // no cancellation: Q' z is at rounding level already
         }
-        for (int a = lane; a < maxq; a += 64) freel[a] = maxq + R - 1 - a;  // (popped from the end: slots R, R + 1, ...)
-        if (lane < R) {
-            crow[lane] = -1;
-            cslot[lane] = lane;
-        }
+        return zz;
+    };
+    // r = R^-1 d (d in cv) into rv: back substitution, column b of R read by the lanes of the rows above it
+    auto rsolve = [&](const T *Rp, int ld) {
+        for (int a = lane; a < nq; a += 64) rv[a] = cv[a];
         lsync();
-        tick(5);
-        int nq = 0, nfree = maxq, iters = 0, status = MPCQP_MAX_ITER;
-        const int max_iter = ka.max_iter;
-        bool fail = false, havesel = false, wglob = false, slotsfull = false;
-        T nbest = INF, nsp = T(0);
-        int nbi = 0x7fffffff;
-        // lazy mode's pass over the m rows: sl += cP hp + sum_a pcv[a] h_a (active rows stay on their bounds), the pending
-        // coefficients are cleared, and the most violated row other than `excl` is selected on the way (ob, oi, osv);
-        // returns the new slack of row `excl`
-        auto gpass = [&](const T *hp, T cP, int excl, T &ob, int &oi, T &osp) -> T {
-            constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
-            ob = INF;
-            oi = 0x7fffffff;
-            T osv = T(0), cap = T(0);
-            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                T z[SU], so[SU], iv[SU], th[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                    z[u] = hp ? cP * hp[i] : T(0);
-                    so[u] = sl[i];
-                    iv[u] = invn[i];
-                    th[u] = thr[i];
-                }
-                for (int a = 0; a < nq; a += SG) {
-                    T ca[SG], va[SG][SU];
-#pragma unroll
-                    for (int j = 0; j < SG; ++j) {
-                        const int aj = a + j < nq ? a + j : a;
-                        ca[j] = a + j < nq ? pcv[aj] : T(0);
-                        const T *ha = Hs + (int64_t)phys[aj] * M;
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                    }
-#pragma unroll
-                    for (int j = 0; j < SG; ++j)
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] += ca[j] * va[j][u];
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int i = i0 + 64 * u;
-                    const T v = (th[u] == INF) ? T(0) : so[u] + z[u];
-                    const T sc = v * iv[u];
-                    if (i < M) {
-                        sl[i] = v;
-                        if (i == excl) cap = v;
-                        if (v < -th[u] && i != excl && sc < ob) {
-                            ob = sc;
-                            oi = i;
-                            osv = v;
-                        }
-                    }
-                }
+        for (int b = nq - 1; b >= 0; --b) {
+            const T *col = Rp + (int64_t)colp[b] * ld;
+            const T rb = rv[b] / col[b];
+            for (int j = lane; j < b; j += 64) rv[j] -= col[j] * rb;
+            if (lane == 0) rv[b] = rb;
+            lsync();
+        }
+    };
+    // w = R^-T rho (rho in cv) into ev: forward substitution, a dot product along column b per step
+    auto rtsolve = [&](const T *Rp, int ld) {
+        for (int b = 0; b < nq; ++b) {
+            const T *col = Rp + (int64_t)colp[b] * ld;
+            T part = T(0);
+            for (int j = lane; j < b; j += 64) part += col[j] * ev[j];
+            const T wb = (cv[b] - wave_sum(part)) / col[b];
+            if (lane == 0) ev[b] = wb;
+            lsync();
+        }
+    };
+    // the candidate becomes basis vector nq: Q gains z / |z|, R the column [d; |z|]
+    auto append = [&](T *Rp, int ld, T *zq, T zz, T up, int bi) {
+        const T zn = (T)sqrt((double)zz), izn = T(1) / zn;
+        for (int k = lane; k < N; k += 64) ((V4 *)zq)[k] *= izn;
+        T *col = Rp + (int64_t)colp[nq] * ld;
+        for (int a = lane; a < nq; a += 64) col[a] = cv[a];
+        if (lane == 0) {
+            col[nq] = zn;
+            lamv[nq] = up;
+            actrow[nq] = bi;
+        }
+    };
+    // slot l leaves: its column of R goes (the permutation closes the gap, the small per-slot arrays move down by one), and one
+    // Givens rotation per column behind it -- on two rows of R and two vectors of Q -- restores the triangle. Lane b carries
+    // column b's entry of the MOVING row in cv[b]; what a step reads of R no earlier step of this drop has written.
+    auto drop = [&](int l, T *Rp, int ld) {
+        const int k = nq - 1, rowl = actrow[l], saved = colp[l];
+        for (int a0 = l; a0 < k; a0 += 64) {  // (chunks ascending: a chunk reads before any lane writes it)
+            const int a = a0 + lane;
+            int c = 0, ar = 0;
+            T lv = T(0);
+            if (a < k) {
+                c = colp[a + 1];
+                ar = actrow[a + 1];
+                lv = lamv[a + 1];
             }
             lsync();
-            for (int a = lane; a < nq; a += 64) pcv[a] = T(0);
+            if (a < k) {
+                colp[a] = c;
+                actrow[a] = ar;
+                lamv[a] = lv;
+            }
             lsync();
-            wave_argmin(ob, oi);
-            osp = __shfl(osv, oi & 63);
-            return excl >= 0 ? __shfl(cap, excl & 63) : T(0);
-        };
-        for (int round = 0; round < 4 && !fail; ++round) {
-            for (;;) {
-                tacc(-1);
-                T best = nbest, sp = nsp;
-                int bi = nbi;
-                int hit = -1;
-                if (lazy && !havesel) {
-                    // the cached rows first, each with its exact slack
-                    // (PER lanes per cached row share its |A| loads: one round trip for all of them)
-                    constexpr int PER = R <= 8 ? 8 : 4;
-                    const int cj = lane / PER, ai = lane % PER;
-                    const int rj = cj < R ? crow[cj] : -1;
-                    T sc = INF, sv = T(0);
-                    {
-                        const unsigned ri = (unsigned)(rj >= 0 ? rj : 0);
-                        T part = T(0);
-                        if (pend && rj >= 0) {
-                            for (int a0 = ai; a0 < nq; a0 += 4 * PER) {
-                                T hv[4], cf[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int a = a0 + u * PER < nq ? a0 + u * PER : a0;
-                                    cf[u] = a0 + u * PER < nq ? pcv[a] : T(0);
-                                    hv[u] = Hs[(int64_t)phys[a] * M + ri];
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) part += cf[u] * hv[u];
-                            }
-                        }
-                        const T s_own = sl[ri], th_own = thr[ri], iv_own = invn[ri];
-#pragma unroll
-                        for (int d = 1; d < PER; d <<= 1) part += __shfl_xor(part, d);
-                        const T v = s_own + part;
-                        if (rj >= 0 && ai == 0 && v < -th_own) {
-                            sc = v * iv_own;
-                            sv = v;
-                        }
-                    }
-                    int jl = lane;
-                    wave_argmin(sc, jl);
-                    if (sc < INF) {
-                        best = sc;
-                        hit = jl / PER;
-                        bi = __shfl(rj, jl);
-                        sp = __shfl(sv, jl);
-                        havesel = true;
-                    } else if (pend) {
-                        gpass(nullptr, T(0), -1, nbest, nbi, nsp);  // none of them is violated: the pending sum is applied, all rows looked at
-                        pend = false;
-                        best = nbest;
-                        bi = nbi;
-                        sp = nsp;
-                        havesel = true;
-                    }
-                }
-                if (!havesel) select(best, bi, sp);
-                havesel = false;
-                if (!(best < INF)) {
-                    status = MPCQP_SOLVED;
-                    break;
-                }
-                tacc(8);
-                if (hit < 0) {
-                    const unsigned long long hm = __ballot(lane < R && crow[lane < R ? lane : 0] == bi);
-                    hit = hm ? (int)__builtin_ctzll(hm) : -1;
-                }
-                if (hit < 0) {
-                    int myrow, mykq, kmax;
-                    MV st;
-                    T ffs;
-                    candidates(bi, myrow, mykq, kmax, st, ffs);
-                    backward(std::false_type{}, kmax, st, ffs, mykq);
-                    tacc(9);
-                    const unsigned cs = (unsigned)cslot[cn];
-                    forward(nullptr, mykq, Vs, cs * (unsigned)nv4, nullptr, 0u, myrow >= 0, Hs, cs * (unsigned)M);
-                    if (lane < R) crow[lane] = myrow;
-                    wsync();
-                    tacc(10);
-                    hit = 0;
-                }
-                // h_p = G V_p sits in the candidate's slot: c_a = h_p[row a], g_p . V_p = h_p[p]
-                const T *hp = Hs + (int64_t)cslot[hit] * M;
-                for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
-                const T dpp = hp[bi];
-                lsync();
-                tacc(11);
-                T up = T(0);
-                bool added = false, fresh = true;
-                while (!added) {
-                    if (iters >= max_iter) {
-                        fail = true;
-                        break;
-                    }
-                    ++iters;
-                    if (!fresh) {
-                        for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
-                        lsync();
-                    }
-                    fresh = false;
-                    // ---- r = W c ; d2 = g_p . V_p - c . r
-                    T cr = T(0);
-                    auto matvec = [&](const T *Wp, int ld) {
-                        for (int a = lane; a < nq; a += 64) {
-                            T acc = T(0);
-                            for (int b = 0; b < nq; ++b) acc += Wp[b * ld + a] * cv[b];  // W is symmetric
-                            rv[a] = acc;
-                            cr += acc * cv[a];
-                        }
-                    };
-                    if (wglob)
-                        matvec(Wm, maxq);
-                    else
-                        matvec(Wl, WLD);
-                    cr = wave_sum(cr);
-                    lsync();
-                    const T d2 = dpp - cr;
-                    const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
-                    // ---- ratio test on the multipliers
-                    T t1 = INF;
-                    int l = 0x7fffffff;
-                    for (int a = lane; a < nq; a += 64) {
-                        const T ra = rv[a];
-                        if (ra > T(0)) {
-                            const T q = lamv[a] / ra;
-                            if (q < t1) {
-                                t1 = q;
-                                l = a;
-                            }
-                        }
-                    }
-                    wave_argmin(t1, l);
-                    const T t2 = can_move ? -sp / d2 : INF;
-                    const T t = t1 < t2 ? t1 : t2;
-                    if (!(t < INF)) {
-                        status = MPCQP_INFEASIBLE;
-                        fail = true;
-                        break;
-                    }
-                    const bool full = (t2 <= t1);
-                    if (full && nq >= maxq) {  // every slot is taken (max_active < min(n, m)) -> MPCQP_SLOTS_FULL
-                        fail = true;
-                        slotsfull = true;
-                        break;
-                    }
-                    tacc(12);
-                    T nbsv = T(0), spcap = T(0);
-                    nbest = INF;
-                    nbi = 0x7fffffff;
-                    if (lazy) {
-                        // the step folded into the pending coefficients; a FULL step leaves it at that, a partial one (a row
-                        // is about to leave, and its h_a with it) applies everything now
-                        for (int a = lane; a < nq; a += 64) pcv[a] -= t * rv[a];
-                        lsync();
-                        if (full) {
-                            pend = true;
-                        } else {
-                            T db;
-                            int di;
-                            T ds;
-                            spcap = gpass(hp, t, bi, db, di, ds);
-                            pend = false;
-                        }
-                    } else
-                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
-                    for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                        // every load of the rows' own arrays first (they are needed last), then the slots in groups of
-                        // SG with all their loads in flight together: what a pass costs is its dependent round trips
-                        constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
-                        T z[SU], so[SU], iv[SU], th[SU];
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) {
-                            const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                            z[u] = hp[i];
-                            so[u] = sl[i];
-                            iv[u] = invn[i];
-                            th[u] = thr[i];
-                        }
-                        for (int a = 0; a < nq; a += SG) {
-                            T ra[SG], va[SG][SU];
-#pragma unroll
-                            for (int j = 0; j < SG; ++j) {
-                                const int aj = a + j < nq ? a + j : a;
-                                ra[j] = a + j < nq ? rv[aj] : T(0);
-                                const T *ha = Hs + (int64_t)phys[aj] * M;
-#pragma unroll
-                                for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                            }
-#pragma unroll
-                            for (int j = 0; j < SG; ++j)
-#pragma unroll
-                                for (int u = 0; u < SU; ++u) z[u] -= ra[j] * va[j][u];
-                        }
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) {
-                            const int i = i0 + 64 * u;
-                            const T v = (th[u] == INF) ? T(0) : so[u] + t * z[u];  // (active rows stay on their bounds)
-                            const T sc = v * iv[u];
-                            if (i < M) {
-                                sl[i] = v;
-                                if (i == bi) spcap = v;
-                                if (v < -th[u] && i != bi && sc < nbest) {
-                                    nbest = sc;
-                                    nbi = i;
-                                    nbsv = v;
-                                }
-                            }
-                        }
-                    }
-                    sp = lazy ? spcap : __shfl(spcap, bi & 63);  // the candidate's slack after the step
-                    // ---- multipliers
-                    for (int a = lane; a < nq; a += 64) {
-                        const T v = lamv[a] - t * rv[a];
-                        lamv[a] = v < T(0) ? T(0) : v;
-                    }
-                    up += t;
-                    tacc(13);
-                    if (full) {
-                        // p becomes active at index nq, in the slot its vectors already occupy: W is bordered
-                        const T id2 = T(1) / d2;
-                        if (!wglob && nq >= WL) {  // W outgrows its LDS tile: it moves to the workspace
-                            for (int b = 0; b < nq; ++b)
-                                for (int a = lane; a < nq; a += 64) Wm[(int64_t)b * maxq + a] = Wl[b * WLD + a];
-                            wglob = true;
-                            wsync();
-                        }
-                        auto border = [&](T *Wp, int ld) {
-                            for (int a = lane; a < nq; a += 64) {
-                                const T ra = rv[a];
-                                for (int b = 0; b < nq; ++b) Wp[b * ld + a] += rv[b] * ra * id2;
-                                Wp[nq * ld + a] = -ra * id2;
-                                Wp[a * ld + nq] = -ra * id2;
-                            }
-                            if (lane == 0) Wp[nq * ld + nq] = id2;
-                        };
-                        if (wglob)
-                            border(Wm, maxq);
-                        else
-                            border(Wl, WLD);
-                        if (lane == 0) {
-                            lamv[nq] = up;
-                            actrow[nq] = bi;
-                            phys[nq] = cslot[hit];
-                            cslot[hit] = freel[nfree - 1];
-                            crow[hit] = -1;
-                            pcv[nq] = lazy ? t : T(0);  // (lazy: this step's own move along h_p is pending as well)
-                        }
-                        if (lane == (bi & 63)) {  // (the row's owner)
-                            thr[bi] = INF;
-                            sl[bi] = T(0);
-                        }
-                        ++nq;
-                        --nfree;
-                        added = true;
-                        if (!lazy) {
-                            wave_argmin(nbest, nbi);
-                            nsp = __shfl(nbsv, nbi & 63);
-                            havesel = true;
-                        }
-                    } else {
-                        // partial step: index l leaves; W is deflated, the last index moves into the hole, its slot is free
-                        const int last = nq - 1, rowl = actrow[l];
-                        auto deflate = [&](T *Wp, int ld, auto sync) {
-                            const T iw = T(1) / Wp[l * ld + l];
-                            for (int a = lane; a < nq; a += 64) cv[a] = Wp[l * ld + a];  // row l before the update
-                            sync();
-                            for (int a = lane; a < nq; a += 64) {
-                                const T wa = cv[a];
-                                for (int b = 0; b < nq; ++b) Wp[b * ld + a] -= cv[b] * wa * iw;
-                            }
-                            sync();
-                            if (l != last) {
-                                for (int a = lane; a < nq; a += 64) Wp[l * ld + a] = Wp[last * ld + a];
-                                sync();
-                                for (int b = lane; b < nq; b += 64) Wp[b * ld + l] = Wp[b * ld + last];
-                                sync();
-                            }
-                        };
-                        if (wglob)
-                            deflate(Wm, maxq, [&] { wsync(); });
-                        else
-                            deflate(Wl, WLD, [&] { lsync(); });
-                        if (lane == (rowl & 63)) {  // (the row's owner) the row can be selected again
-                            const int k = stepof(rowl), r = rowl - k * mk;
-                            thr[rowl] = tol + tol * (T)fabs((double)ge[k * sE + r]);
-                        }
-                        if (lane == 0) {
-                            freel[nfree] = phys[l];
-                            if (l != last) {
-                                lamv[l] = lamv[last];
-                                actrow[l] = actrow[last];
-                                phys[l] = phys[last];
-                            }
-                        }
-                        --nq;
-                        ++nfree;
-                    }
-                    if (wglob)
-                        wsync();
-                    else
-                        lsync();
-                    tacc(14);
-                }
-                if (fail) break;
+        }
+        if (lane == 0) colp[k] = saved;
+        lsync();
+        for (int b = l + lane; b < k; b += 64) cv[b] = Rp[(int64_t)colp[b] * ld + l];
+        lsync();
+        for (int j = l; j < k; ++j) {  // zero R[j + 1][j] against R[j][j]
+            const T aj = cv[j], bj = Rp[(int64_t)colp[j] * ld + j + 1];
+            const T hh = (T)sqrt((double)(aj * aj + bj * bj));
+            const T cc = hh > T(0) ? aj / hh : T(1), ss = hh > T(0) ? bj / hh : T(0);
+            for (int b = j + lane; b < k; b += 64) {
+                T *cb = Rp + (int64_t)colp[b] * ld;
+                const T u = cb[j + 1], mv = cv[b];
+                cb[j] = cc * mv + ss * u;
+                cv[b] = cc * u - ss * mv;
             }
-            if (fail) break;
-            tick(6);
-            // ================================================================= primal point, verification
-            // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a. Inactive rows must be feasible;
-            // ACTIVE rows must sit on their bounds (W is only ever updated, never refactored: if it drifted, one step of
-            // refinement lam -= W rho_A puts them back, and a point that still fails is not reported solved)
-            bool dirty = false;
-            for (int pass = 0; pass < VPASS; ++pass) {
-                // ONE pass over the rows: s = s0 + sum_a lam_a h_a with the slots' loads in flight in groups
-                constexpr int SG = LOW ? SG_LOW : STAGEW_SG;
-                bool offa = false;
-                dirty = false;
-                for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
-                for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                    T fr[SU], th[SU], nz[SU];  // nz (float32): |s0| + sum |lam_a h_a|, the scale of this sum's rounding noise
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                        fr[u] = s0[i];
-                        th[u] = thr[i];
-                        nz[u] = (T)fabs((double)fr[u]);
-                    }
-                    for (int a = 0; a < nq; a += SG) {
-                        T la[SG], va[SG][SU];
-#pragma unroll
-                        for (int j = 0; j < SG; ++j) {
-                            const int aj = a + j < nq ? a + j : a;
-                            la[j] = a + j < nq ? lamv[aj] : T(0);
-                            const T *ha = Hs + (int64_t)phys[aj] * M;
-#pragma unroll
-                            for (int u = 0; u < SU; ++u) va[j][u] = ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                        }
-#pragma unroll
-                        for (int j = 0; j < SG; ++j)
-#pragma unroll
-                            for (int u = 0; u < SU; ++u) {
-                                const T pr = la[j] * va[j][u];
-                                fr[u] += pr;
-                                if constexpr (sizeof(T) == 4) nz[u] += (T)fabs((double)pr);
-                            }
-                    }
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const int i = i0 + 64 * u;
-                        if (i < M) {
-                            const bool act = th[u] == INF;
-                            if (act) {  // (rare) the row's own threshold is gone: from its bound
-                                const int k = stepof(i), r = i - k * mk;
-                                // the first passes: 10 tol (1 + |e|) TRIGGERS a refinement step; the last one: what is acceptable after
-                                // them (1e-7 in float64: a tenth of the contract's 1e-6)
-                                const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(100) > T(1e-7) / tol) ? T(100) : T(1e-7) / tol);
-                                // (float32: ... plus what the evaluation itself cannot resolve -- a healthy n = 192 problem sits
-                                // 3e-4 off in THIS sum while its plan is 1e-6 from the float64 one: STAGEW_VNOISE32 ulps of the
-                                // terms' magnitudes)
-                                const T lim = fac * (tol + tol * (T)fabs((double)ge[k * sE + r])) +
-                                              (sizeof(T) == 4 ? T(STAGEW_VNOISE32) * T(6e-8) * nz[u] : T(0));
-                                offa |= !((T)fabs((double)fr[u]) <= lim);
-                            } else if (!(fr[u] >= T(-4) * th[u])) {
-                                dirty = true;
-                            }
-                            sl[i] = act ? T(0) : fr[u];
-                        }
-                    }
-                }
-                if (__ballot(offa) == 0ull) break;
-                if (pass == VPASS - 1) {
-                    fail = true;
-                    break;
-                }
-                // (rare) an active row sits off its bound or a multiplier is not >= 0: residuals of the active rows through
-                // their own entries of the h_b, then lam -= W rho_A, and the pass again
-                for (int a = lane; a < nq; a += 64) {
-                    const int ra = actrow[a];
-                    T acc = s0[ra];
-                    for (int b = 0; b < nq; ++b) acc += lamv[b] * Hs[(int64_t)phys[b] * M + ra];
-                    cv[a] = acc;
-                }
-                lsync();
-                auto refine = [&](const T *Wp, int ld) {
-                    for (int a = lane; a < nq; a += 64) {
-                        T acc = T(0);
-                        for (int b = 0; b < nq; ++b) acc += Wp[b * ld + a] * cv[b];
-                        const T v = lamv[a] - acc;
-                        lamv[a] = v < T(0) ? T(0) : v;
-                    }
-                };
-                if (wglob)
-                    refine(Wm, maxq);
-                else
-                    refine(Wl, WLD);
-                lsync();
+            if (lane == 0) {
+                rv[j] = cc;
+                ev[j] = ss;
             }
-            if (fail) break;
-            dirty = __ballot(dirty) != 0ull;
-            if (!dirty) {
+            lsync();
+        }
+        for (int kk = lane; kk < N; kk += 64) {  // Q takes the rotations in one pass (lane <-> steps: no exchange)
+            V4 t1 = Q4(l)[kk];
+            V4 un = l < k ? Q4(l + 1)[kk] : t1;
+            for (int j = l; j < k; ++j) {
+                const V4 u2 = un;
+                if (j + 1 < k) un = Q4(j + 2)[kk];
+                const T cc = rv[j], ss = ev[j];
+                Q4(j)[kk] = cc * t1 + ss * u2;
+                t1 = cc * u2 - ss * t1;
+            }
+        }
+        if (lane == owner(rowl)) {  // (the row's owner) the row can be selected again
+            const int kr = stepof(rowl), r = rowl - kr * mk;
+            thr[rowl] = tol + tol * (T)fabs((double)ge[kr * sE + r]);
+        }
+    };
+
+    // ================================================================= active-set loop (Goldfarb-Idnani; oracle/stagewise_qr_np.py)
+    T best = selb, sp = selv;
+    int bi = seli;
+    for (int round = 0; round < 4 && !fail; ++round) {
+        for (;;) {
+            tacc(-1);
+            if (!(best < INF)) {
                 status = MPCQP_SOLVED;
                 break;
             }
-            status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
-        }
-        tick(7);
-        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
-        if (slotsfull) status = MPCQP_SLOTS_FULL;
-        const bool ok = status == MPCQP_SOLVED;
-        {
-            // u = u0 - sum_a lam_a V_a (zero when there is no plan), four slots' loads in flight
-            T *ou = (T *)ka.U + prob * (int64_t)nvar;
-            for (int i = lane; i < nv4; i += 64) {
-                T u = ok ? U0[i] : T(0);
-                for (int a = 0; ok && a < nq; a += 4) {
-                    T la[4], va[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int aj = a + j < nq ? a + j : a;
-                        la[j] = a + j < nq ? lamv[aj] : T(0);
-                        va[j] = Vs[(int64_t)phys[aj] * nv4 + i];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) u -= la[j] * va[j];
-                }
-                if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
+            // the candidate's whitened vector y_p: cached by an earlier backward sweep, or a sweep now (R right-hand sides)
+            int hit = -1;
+            {
+                const unsigned long long hm = __ballot(lane < R && crow[lane < R ? lane : 0] == bi);
+                hit = hm ? (int)__builtin_ctzll(hm) : -1;
             }
-        }
-        if (ka.lam) {
-            T *ol = (T *)ka.lam + prob * (int64_t)M;
-            for (int i = lane; i < M; i += 64) ol[i] = T(0);
-            wsync();
-            if (ok)
-                for (int a = lane; a < nq; a += 64) ol[actrow[a]] = lamv[a];
-        }
-        if (wrec) {  // the rows that are active now: the next solve's warm rows (MPCQP_WARM_ACTIVE_SET)
-            if (lane == 0) wrec[0] = ok ? nq : 0;
-            for (int a = lane; ok && a < nq; a += 64) wrec[1 + a] = actrow[a];
-        }
-        if (lane == 0) {
-            if (ka.status) ka.status[prob] = status;
-            if (ka.iters) ka.iters[prob] = iters;
-        }
-    } else {
-        forward(gx0, N, U0, 0u, Zs, 0u, col0, nullptr, 0u);
-        wsync();
-        tick(4);
-        const T tol = ka.tol;
-        gmul(sl, Zs, -1);
-        for (int i = lane; i < M; i += 64) {
-            const int k = stepof(i), r = i - k * mk;
-            const T ev = ge[k * sE + r], sv = ev - sl[i];
-            s0[i] = sv;
-            sl[i] = sv;
-            thr[i] = tol + tol * (T)fabs((double)ev);
-            const int gi = ginv ? r : i;
-            T nn = T(0);
-#pragma unroll
-            for (int q = 0; q <= NQ; ++q) {
-                const V4 g = Gp[(unsigned)(q * Mg + gi)];
-                nn += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+            tacc(8);
+            if (hit < 0) {
+                int myrow, mykq, kmax;
+                MV st;
+                T ffs;
+                wsync();  // (the sweeps' rows are read by other lanes)
+                candidates(bi, myrow, mykq, kmax, st, ffs);
+                backward(std::false_type{}, kmax, st, ffs, mykq);
+                if (lane < R) crow[lane] = myrow;
+                wsync();
+                hit = 0;
             }
-            invn[i] = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
-            rowslot[i] = -1;
-        }
-        for (int a = lane; a <= maxq; a += 64) phys[a] = a;
-        if (lane < R) crow[lane] = -1;
-        wsync();
-
-        tick(5);
-        if (stamp) {  // (developer probe) slot 15: violated rows at the unconstrained minimiser, and their summed scaled violation
-            int nv = 0;
-            T tv = T(0);
-            for (int i = lane; i < M; i += 64)
-                if (sl[i] < -thr[i]) {
-                    ++nv;
-                    tv -= sl[i] * invn[i];
-                }
-            nv = (int)wave_sum((T)nv);
-            tv = wave_sum(tv);
-            if (lane == 0) stamp[15] = (long long)nv + ((long long)(tv * T(1000)) << 16);
-        }
-        // ================================================================= active-set loop
-        int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
-        const int max_iter = ka.max_iter;
-        bool fail = false, havesel = false, slotsfull = false;
-        T nbest = INF, nsp = T(0);
-        int nbi = 0x7fffffff;
-        for (int round = 0; round < 4 && !fail; ++round) {
-            for (;;) {
-                // ---- selection (already made by the slack pass of the step that just ended, if there was one)
-                tacc(-1);
-                T best = nbest, sp = nsp;
-                int bi = nbi;
-                if (!havesel) select(best, bi, sp);
-                havesel = false;
-                if (!(best < INF)) {
-                    status = MPCQP_SOLVED;
+            tacc(9);
+            const T *yp = ffv + (int64_t)hit * nv4;
+            const int kq = stepof(bi);
+            T up = T(0);
+            bool added = false;
+            while (!added) {
+                if (iters >= max_iter) {
+                    fail = true;
                     break;
                 }
-                tacc(8);
-                // the candidate's slot: V_p = P^-1 g_p' (two sweeps), h_p = G V_p; unchanged while p waits for room. The
-                // sweeps carry R right-hand sides at the price of one, so the rows most likely to be taken next ride along
-                // (V_a does not depend on the active set: a row found in crow[] later costs no sweep; which rows ride along
-                // has no influence on the iterates).
-                const int ps = phys[nq];
-                T *Vp = Vs + (int64_t)ps * nv4, *hp = Hs + (int64_t)ps * M;
-                int hit = -1;
-#pragma unroll
-                for (int j = 0; j < R; ++j)
-                    if (crow[j] == bi) hit = j;
-                if (hit < 0) {
-                    int myrow, mykq, kmax;
-                    MV st;
-                    T ffs;
-                    candidates(bi, myrow, mykq, kmax, st, ffs);
-                    backward(std::false_type{}, kmax, st, ffs, mykq);
-                    wsync();
-                    tacc(9);
-                    forward(nullptr, mykq, Vc, (unsigned)(cn * nv4), Zs, (unsigned)(cn * N * ZL), myrow >= 0, nullptr, 0u);
-                    if (lane < R) crow[lane] = myrow;
-                    wsync();
-                    tacc(10);
-                    hit = 0;
+                ++iters;
+                T *zq = Qs + (int64_t)nq * nv4;
+                T yy;
+                const T zz = ortho(yp, kq, zq, yy);
+                tacc(10);
+                if (wglob)
+                    rsolve(Wm, maxq);
+                else
+                    rsolve(Rl, WLD);
+                const bool can_move = (nq < nvar) && (zz > DEP * yy) && (zz > T(0));
+                // ---- ratio test on the multipliers
+                T t1 = INF;
+                int l = 0x7fffffff;
+                for (int a = lane; a < nq; a += 64) {
+                    const T ra = rv[a];
+                    if (ra > T(0)) {
+                        const T q = lamv[a] / ra;
+                        if (q < t1) {
+                            t1 = q;
+                            l = a;
+                        }
+                    }
                 }
-                // the row's vectors move into the slot: inputs copied, h_p = G V_p from its trajectory
-                for (int i = lane; i < nv4; i += 64) Vp[i] = Vc[(int64_t)hit * nv4 + i];
-                const T dpp = gmul(hp, Zs + (int64_t)hit * N * ZL, bi);
-                if (lane == 0) crow[hit] = -1;
-                wsync();
+                wave_argmin(t1, l);
+                const T t2 = can_move ? -sp / zz : INF;
+                const T t = t1 < t2 ? t1 : t2;
+                if (!(t < INF)) {
+                    status = MPCQP_INFEASIBLE;
+                    fail = true;
+                    break;
+                }
+                const bool full = (t2 <= t1);
+                if (full && nq >= maxq) {  // every slot is taken (max_active < min(n, m)) -> MPCQP_SLOTS_FULL
+                    fail = true;
+                    slotsfull = true;
+                    break;
+                }
                 tacc(11);
-                T up = T(0);
-                bool added = false, fresh = true;  // fresh: cv[] still holds the c_a the pass above left
-                while (!added) {
-                    if (iters >= max_iter) {
-                        fail = true;
-                        break;
-                    }
-                    ++iters;
-                    // ---- c_a = g_a . V_p ; r = W c ; d2 = g_p . V_p - c . r
-                    if (!fresh) {
-                        for (int a = lane; a < nq; a += 64) cv[a] = hp[actrow[a]];
-                        wsync();
-                    }
-                    fresh = false;
-                    T cr = T(0);
-                    for (int a = lane; a < nq; a += 64) {
-                        T acc = T(0);
-                        for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];  // W is symmetric
-                        rv[a] = acc;
-                        cr += acc * cv[a];
-                    }
-                    cr = wave_sum(cr);
-                    wsync();
-                    const T d2 = dpp - cr;
-                    const bool can_move = (nq < nvar) && (d2 > DEPTOL * dpp) && (d2 > T(0));
-                    // ---- ratio test on the multipliers
-                    T t1 = INF;
-                    int l = 0x7fffffff;
-                    for (int a = lane; a < nq; a += 64) {
-                        const T ra = rv[a];
-                        if (ra > T(0)) {
-                            const T q = lamv[a] / ra;
-                            if (q < t1) {
-                                t1 = q;
-                                l = a;
-                            }
-                        }
-                    }
-                    wave_argmin(t1, l);
-                    const T t2 = can_move ? -sp / d2 : INF;
-                    const T t = t1 < t2 ? t1 : t2;
-                    if (!(t < INF)) {
-                        status = MPCQP_INFEASIBLE;
-                        fail = true;
-                        break;
-                    }
-                    const bool full = (t2 <= t1);
-                    if (full && nq >= maxq) {  // the row would enter, but every slot is taken (max_active < min(n, m)): a
-                        fail = true;           // drop can go on with full slots, an addition cannot -> MPCQP_SLOTS_FULL
-                        slotsfull = true;
-                        break;
-                    }
-                    tacc(12);
-                    // ---- slacks: s_i += t (h_p - sum_a r_a h_a)_i ; a full step also selects the next candidate here
-                    nbest = INF;
-                    nbi = 0x7fffffff;
-                    T nbsv = T(0), spcap = T(0);
-                    for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                        // SU rows per lane in one go: first z = h_p - sum r_a h_a (only z and the slots' values live), then
-                        // the rows' own arrays in halves
-                        T z[SU];
-#pragma unroll
-                        for (int u = 0; u < SU; ++u) z[u] = hp[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                        int a = 0;
-                        for (; a + 1 < nq; a += 2) {  // two slots per turn: their loads overlap
-                            const T ra = rv[a], rb = rv[a + 1];
-                            const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                            T va[SU], vb[SU];
-#pragma unroll
-                            for (int u = 0; u < SU; ++u) {
-                                const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                                va[u] = ha[i];
-                                vb[u] = hb[i];
-                            }
-#pragma unroll
-                            for (int u = 0; u < SU; ++u) z[u] -= ra * va[u] + rb * vb[u];
-                        }
-                        if (a < nq) {
-                            const T ra = rv[a];
-                            const T *ha = Hs + (int64_t)phys[a] * M;
-#pragma unroll
-                            for (int u = 0; u < SU; ++u) z[u] -= ra * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                        }
-#pragma unroll
-                        for (int h = 0; h < SU; h += SU / 2) {
-                            int rs[SU / 2];
-                            T so[SU / 2], iv[SU / 2], th[SU / 2];
-#pragma unroll
-                            for (int u = 0; u < SU / 2; ++u) {
-                                const unsigned i = (unsigned)(i0 + 64 * (h + u) < M ? i0 + 64 * (h + u) : M - 1);
-                                so[u] = sl[i];
-                                iv[u] = invn[i];
-                                th[u] = thr[i];
-                                rs[u] = rowslot[i];
-                            }
-#pragma unroll
-                            for (int u = 0; u < SU / 2; ++u) {
-                                const int i = i0 + 64 * (h + u);
-                                const T v = (rs[u] >= 0) ? T(0) : so[u] + t * z[h + u];
-                                const T sc = v * iv[u];
-                                if (i < M) {
-                                    sl[i] = v;
-                                    if (i == bi) spcap = v;
-                                    if (v < -th[u] && i != bi && sc < nbest) {
-                                        nbest = sc;
-                                        nbi = i;
-                                        nbsv = v;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    sp = __shfl(spcap, bi & 63);  // the candidate's slack after the step
-                    // ---- multipliers
-                    for (int a = lane; a < nq; a += 64) {
-                        const T v = lamv[a] - t * rv[a];
-                        lamv[a] = v < T(0) ? T(0) : v;
-                    }
-                    up += t;
-                    wsync();
-                    tacc(13);
-                    if (full) {
-                        // p becomes active at index nq (its slot is already phys[nq]): W is bordered
-                        const T id2 = T(1) / d2;
-                        for (int a = lane; a < nq; a += 64) {
-                            const T ra = rv[a];
-                            for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] += rv[b] * ra * id2;
-                            Wm[(int64_t)nq * maxq + a] = -ra * id2;
-                            Wm[(int64_t)a * maxq + nq] = -ra * id2;
-                        }
-                        if (lane == 0) {
-                            Wm[(int64_t)nq * maxq + nq] = id2;
-                            lamv[nq] = up;
-                            actrow[nq] = bi;
-                            rowslot[bi] = nq;
-                            sl[bi] = T(0);
-                        }
-                        ++nq;
-                        added = true;
-                        wave_argmin(nbest, nbi);
-                        nsp = __shfl(nbsv, nbi & 63);
-                        havesel = true;
-                    } else {
-                        // partial step: index l leaves; W is deflated, the last index moves into the hole; the slots follow
-                        // through the permutation (the candidate's stays where it is)
-                        const T wll = Wm[(int64_t)l * maxq + l];
-                        const T iw = T(1) / wll;
-                        for (int a = lane; a < nq; a += 64) cv[a] = Wm[(int64_t)l * maxq + a];  // row l before the update
-                        wsync();
-                        for (int a = lane; a < nq; a += 64) {
-                            const T wa = cv[a];
-                            for (int b = 0; b < nq; ++b) Wm[(int64_t)b * maxq + a] -= cv[b] * wa * iw;
-                        }
-                        wsync();
-                        const int last = nq - 1;
-                        if (l != last) {
-                            for (int a = lane; a < nq; a += 64) Wm[(int64_t)l * maxq + a] = Wm[(int64_t)last * maxq + a];
-                            wsync();
-                            for (int b = lane; b < nq; b += 64) Wm[(int64_t)b * maxq + l] = Wm[(int64_t)b * maxq + last];
-                            wsync();
-                        }
-                        if (lane == 0) {
-                            rowslot[actrow[l]] = -1;
-                            const int freed = phys[l];
-                            if (l != last) {
-                                lamv[l] = lamv[last];
-                                actrow[l] = actrow[last];
-                                rowslot[actrow[last]] = l;
-                                phys[l] = phys[last];
-                            }
-                            phys[last] = phys[nq];
-                            phys[nq] = freed;
-                        }
-                        --nq;
-                    }
-                    wsync();
-                    tacc(14);
+                if (can_move) {
+                    // the step: the point moves against z (v -= t z; in the inputs u -= t z_u), the slacks gain t G z_u -- the
+                    // PROJECTED vector goes through the forward sweep, whose rows also select the next candidate
+                    for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] -= t * ((const V4 *)zq)[k];
+                    wsync();  // (z is read by the sweep's lanes)
+                    fsweep(FW_DIR, nullptr, zq, t, bi, full, T(0));
                 }
-                if (fail) break;
+                tacc(12);
+                // ---- multipliers
+                for (int a = lane; a < nq; a += 64) {
+                    const T v = lamv[a] - t * rv[a];
+                    lamv[a] = v < T(0) ? T(0) : v;
+                }
+                up += t;
+                if (full) {
+                    if (!wglob && nq >= WL) {  // R outgrows its LDS tile: it moves to the workspace
+                        for (int b = 0; b < WL; ++b)
+                            for (int a = lane; a < WL; a += 64) Wm[(int64_t)b * maxq + a] = Rl[b * WLD + a];
+                        wglob = true;
+                    }
+                    if (wglob)
+                        append(Wm, maxq, zq, zz, up, bi);
+                    else
+                        append(Rl, WLD, zq, zz, up, bi);
+                    ++nq;
+                    added = true;
+                    best = selb;
+                    bi = seli;
+                    sp = selv;
+                } else {
+                    if (wglob)
+                        drop(l, Wm, maxq);
+                    else
+                        drop(l, Rl, WLD);
+                    --nq;
+                    if (can_move) sp = spnew;
+                }
+                if (wglob)
+                    wsync();
+                else
+                    lsync();
+                tacc(13);
             }
             if (fail) break;
-            tick(6);
-            // ================================================================= primal point, verification
-            // u = u0 - sum_a lam_a V_a ; slacks from scratch: s = s0 + sum_a lam_a h_a
-            // ACTIVE rows must sit on their bounds (W is only ever updated, never refactored: a stress run found plans with rows
-            // 5e-7 off after 450 iterations): beyond 1e3 tol (1 + |e|) one step of refinement lam -= W rho_A puts them back, and a
-            // point that still fails the contract's bound is not reported solved -- as in the layout above.
-            bool dirty = false;
-            for (int pass = 0; pass < VPASS; ++pass) {
-            bool offa = false;
-            dirty = false;
-            for (int a = lane; a < nq; a += 64) offa |= !(lamv[a] >= T(0));
-            const T afac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10) : (sizeof(T) == 4 ? T(STAGEW_VACC32) : T(100) > T(1e-7) / tol ? T(100) : T(1e-7) / tol);
-            for (int i0 = lane; i0 < M; i0 += 64 * SU) {
-                T fr[SU], nz[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    fr[u] = s0[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                    nz[u] = (T)fabs((double)fr[u]);
-                }
-                int a = 0;
-                for (; a + 1 < nq; a += 2) {
-                    const T la = lamv[a], lb = lamv[a + 1];
-                    const T *ha = Hs + (int64_t)phys[a] * M, *hb = Hs + (int64_t)phys[a + 1] * M;
-                    T va[SU], vb[SU];
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                        va[u] = ha[i];
-                        vb[u] = hb[i];
-                    }
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        fr[u] += la * va[u] + lb * vb[u];
-                        if constexpr (sizeof(T) == 4) nz[u] += (T)fabs((double)(la * va[u])) + (T)fabs((double)(lb * vb[u]));
-                    }
-                }
-                if (a < nq) {
-                    const T la = lamv[a];
-                    const T *ha = Hs + (int64_t)phys[a] * M;
-#pragma unroll
-                    for (int u = 0; u < SU; ++u) {
-                        const T pr = la * ha[(unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1)];
-                        fr[u] += pr;
-                        if constexpr (sizeof(T) == 4) nz[u] += (T)fabs((double)pr);
-                    }
-                }
-                T th[SU];
-                int rs[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
-                    th[u] = thr[i];
-                    rs[u] = rowslot[i];
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const bool act = rs[u] >= 0;
-                    if (!act && !(fr[u] >= T(-4) * th[u])) dirty = true;
-                    if (act && i0 + 64 * u < M &&
-                        !((T)fabs((double)fr[u]) <= afac * th[u] + (sizeof(T) == 4 ? T(STAGEW_VNOISE32) * T(6e-8) * nz[u] : T(0))))
-                        offa = true;
-                    if (i0 + 64 * u < M) sl[i0 + 64 * u] = act ? T(0) : fr[u];
-                }
-            }
-            if (__ballot(offa) == 0ull) break;
+        }
+        if (fail) break;
+        tick(6);
+        if (iters == 0) break;  // the unconstrained minimiser is feasible: its inputs are written already
+        // ================================================================= the point from scratch, acceptance
+        // One forward sweep of the whitened point v from x0 gives the inputs that are returned and their rows (closed loop: stable
+        // whatever the spectrum of A). Inactive rows must be feasible; ACTIVE rows must sit on their bounds: beyond the trigger a
+        // polish step -- S dlam = rho with S = R' R, the point moves along Q R^-T rho -- and the evaluation again; a point that still
+        // fails the acceptance bound is not reported solved.
+        constexpr int VPASS = sizeof(T) == 4 ? STAGEW_VPASS32 : 3;
+        for (int pass = 0; pass < VPASS; ++pass) {
+            const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10)
+                                           : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(100) > T(1e-7) / tol ? T(100) : T(1e-7) / tol));
+            wsync();  // (v is read by the sweep's lanes)
+            fsweep(FW_EVAL, gx0, vpt, T(0), -1, false, fac);
+            bool neg = false;
+            for (int a = lane; a < nq; a += 64) neg |= !(lamv[a] >= T(0));
+            if (!offa && __ballot(neg) == 0ull) break;
             if (pass == VPASS - 1) {
                 fail = true;
                 break;
             }
-            wsync();
-            for (int a = lane; a < nq; a += 64) {  // residuals of the active rows, then lam -= W rho_A
-                const int ra = actrow[a];
-                T acc = s0[ra];
-                for (int b = 0; b < nq; ++b) acc += lamv[b] * Hs[(int64_t)phys[b] * M + ra];
-                cv[a] = acc;
+            wsync();  // (the rows' residuals are read by other lanes)
+            for (int a = lane; a < nq; a += 64) cv[a] = s0[actrow[a]];
+            lsync();
+            if (wglob) {
+                rtsolve(Wm, maxq);
+            } else {
+                rtsolve(Rl, WLD);
             }
-            wsync();
+            for (int k = lane; k < N; k += 64) {  // v += Q w
+                V4 acc = ((const V4 *)vpt)[k];
+                for (int a = 0; a < nq; ++a) acc += ev[a] * Q4(a)[k];
+                ((V4 *)vpt)[k] = acc;
+            }
+            for (int a = lane; a < nq; a += 64) cv[a] = ev[a];
+            lsync();
+            if (wglob)
+                rsolve(Wm, maxq);
+            else
+                rsolve(Rl, WLD);
             for (int a = lane; a < nq; a += 64) {
-                T acc = T(0);
-                for (int b = 0; b < nq; ++b) acc += Wm[(int64_t)b * maxq + a] * cv[b];
-                const T v = lamv[a] - acc;
+                const T v = lamv[a] - rv[a];
                 lamv[a] = v < T(0) ? T(0) : v;
             }
-            wsync();
-            }
-            if (fail) break;
-            {
-                T *ou = (T *)ka.U + prob * (int64_t)nvar;
-                for (int i = lane; i < nv4; i += 64) {
-                    T u = U0[i];
-                    for (int a = 0; a < nq; ++a) u -= lamv[a] * Vs[(int64_t)phys[a] * nv4 + i];
-                    if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = u;
-                }
-            }
-            dirty = __ballot(dirty) != 0ull;
-            wsync();
-            if (!dirty) {
-                status = MPCQP_SOLVED;
-                break;
-            }
-            status = MPCQP_MAX_ITER;  // continue from the re-evaluated slacks
+            lsync();
         }
-        tick(7);
-        if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
-        if (slotsfull) status = MPCQP_SLOTS_FULL;
-        const bool ok = status == MPCQP_SOLVED;
-        if (!ok) {
-            T *ou = (T *)ka.U + prob * (int64_t)nvar;
-            for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+        if (fail) break;
+        if (!dirty) {
+            status = MPCQP_SOLVED;
+            break;
         }
-        if (ka.lam) {
-            T *ol = (T *)ka.lam + prob * (int64_t)M;
-            for (int i = lane; i < M; i += 64) {
-                const int sidx = rowslot[i];
-                ol[i] = (ok && sidx >= 0) ? lamv[sidx] : T(0);
-            }
-        }
-        if (wrec) {  // the rows that are active now: the next solve's warm rows (MPCQP_WARM_ACTIVE_SET)
-            if (lane == 0) wrec[0] = ok ? nq : 0;
-            for (int a = lane; ok && a < nq; a += 64) wrec[1 + a] = actrow[a];
-        }
-        if (lane == 0) {
-            if (ka.status) ka.status[prob] = status;
-            if (ka.iters) ka.iters[prob] = iters;
-        }
+        status = MPCQP_MAX_ITER;  // an inactive row came out violated: continue from the re-evaluated slacks
+        best = selb;
+        bi = seli;
+        sp = selv;
+    }
+    tick(7);
+    if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
+    if (slotsfull) status = MPCQP_SLOTS_FULL;
+    const bool ok = status == MPCQP_SOLVED;
+    wsync();
+    if (!ok)
+        for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+    if (ka.lam) {
+        T *ol = (T *)ka.lam + prob * (int64_t)M;
+        for (int i = lane; i < M; i += 64) ol[i] = T(0);
+        wsync();
+        if (ok)
+            for (int a = lane; a < nq; a += 64) ol[actrow[a]] = lamv[a];
+    }
+    if (wrec) {  // the rows that are active now: the next solve's warm rows (MPCQP_WARM_ACTIVE_SET)
+        if (lane == 0) wrec[0] = ok ? nq : 0;
+        for (int a = lane; ok && a < nq; a += 64) wrec[1 + a] = actrow[a];
+    }
+    if (lane == 0) {
+        if (ka.status) ka.status[prob] = status;
+        if (ka.iters) ka.iters[prob] = iters;
     }
 }
 
@@ -2182,11 +1654,9 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T), LOW);
     // the matrix tiles of the LDS Riccati recursion only exist for nx > 12; then 8 constant / spare cells
     const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
-    // + c, r, multipliers, active rows, slot permutation, the sweeps' rows; FUSE: + the candidates' slots, the free list
-    // and the 32 x 33 tile of W
-    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (3 * sizeof(T) + 2 * sizeof(int)) + 64 +
-                       (FUSE ? (size_t)(RR + maxq) * sizeof(int) + 16 + (size_t)32 * 33 * sizeof(T) + (size_t)maxq * sizeof(T) : 0) +
-                       (size_t)RR * sizeof(int);
+    // + d, r, multipliers, a scratch vector; active rows, column permutation of R, the backward sweeps' rows; the 32 x 33 tile of R
+    const size_t lds = tiles * sizeof(T) + (size_t)maxq * (4 * sizeof(T) + 2 * sizeof(int)) + (size_t)RR * sizeof(int) + 16 +
+                       (size_t)32 * 33 * sizeof(T);
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     // (developer knob: MPCQP_STAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
     static const size_t lds_pad = [] {
