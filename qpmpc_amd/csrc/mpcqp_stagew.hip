@@ -60,6 +60,7 @@ namespace mpcqp {
 namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
+constexpr int KSS = 80;  // a step's entry of the array KS: K' padded to 16 x 4, then 16 cells for the factor of S
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
 // right-hand sides per BACKWARD sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows. The matrix cores
 // compute all 16 columns whatever their number; a column costs its share of the selection that picks the rows, and the sweep
@@ -69,11 +70,12 @@ constexpr int R_PLAIN = 8, R_FUSE = STAGEW_RF;
 // SIMD (the 8-GPU share of config 5: 1024 problems) is bounded by the LATENCY of its longest problem, and the registers of
 // the empty wavefront slots buy some of it back: one wavefront per SIMD (512 VGPRs), twelve right-hand sides per backward
 // sweep, a six-step request ring.
-constexpr int R_FUSE_LOW = 12, D_LOW = 6;
+constexpr int R_FUSE_LOW = 12, D_LOW = 12;
 
-struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value)
-    int64_t Mb, Mf, KS, ff, Zs, Gp, s0, s, invn, thr, vpt, Q, W, total;
+struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value; 32-bit: scalar registers are short)
+    int Mb, Mf, KS, ff, Zs, Gp, s0, s, invn, thr, vpt, ust, junk, Q, W;
     int maxq, mg;
+    int64_t total;
 };
 
 // a lane's group of L record values (L < 4: packed, so that a step's record has no padding -- 12-byte loads for L = 3)
@@ -102,7 +104,7 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     auto take = [&](int64_t cnt) {
         const int64_t at = o;
         o += (cnt + 3) & ~(int64_t)3;
-        return at;
+        return (int)at;
     };
     const int nxc = nxc_of(nx);
     const int64_t m = (int64_t)N * mk;
@@ -112,10 +114,11 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
     w.Mb = take((int64_t)N * rec_elems(na * nq));
     w.Mf = take((int64_t)N * rec_elems(na * (nq + 1)));
-    w.KS = take((int64_t)N * (nx * nu + 16));  // K' and the factor of S of every step (read at a candidate row's step)
+    w.KS = take((int64_t)N * KSS);             // K' (16 x 4) and the factor of S of every step (read at a candidate row's step)
     const bool fuse = fuse_ok(mk, ginv);
     const int R = fuse ? (low ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
-    w.ff = take((int64_t)R * N * 4);           // whitened vectors y_a of the latest backward sweep's rows, per right-hand side
+    (void)R;
+    w.ff = take((int64_t)16 * N * 4);          // whitened vectors y_a of the latest backward sweep's rows, per column of the operand
     w.Zs = take(fuse ? 0 : (int64_t)N * (nxc + 4));  // (x_k, u_k) of the latest forward sweep, in B-operand order
     w.mg = ginv ? mk : (int)m;
     w.Gp = take(fuse ? 0 : (int64_t)(nxc + 4) * w.mg);  // [C | D] in the order of Zs's rows, as four-vectors: Gp[j][row], j <= nxc / 4
@@ -124,6 +127,8 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     w.invn = take(m);
     w.thr = take(m);
     w.vpt = take((int64_t)N * 4);                   // the point in whitened coordinates
+    w.ust = take((int64_t)N * 4);                   // its inputs, as the latest forward sweep left them (rows of 4)
+    w.junk = take(64);                              // a cell per lane for the stores of lanes without a row
     w.Q = take((int64_t)(maxq + 1) * N * 4);        // Q by vectors (vector nq: the candidate's projection)
     w.W = take((int64_t)maxq * maxq);               // R by columns, once it has outgrown its LDS tile
     o = (o + 127) & ~(int64_t)127;  // odd multiple of 512 B / 1 KB between problems (memory channels)
@@ -199,9 +204,21 @@ __device__ __forceinline__ double frcp(double x)
     r = fma(fma(-x, r, 1.0), r, r);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// reciprocal square root: hardware estimate + Newton steps
+__device__ __forceinline__ float frsq(float x)
+{
+    const float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x * r, r, 1.5f);
+}
+__device__ __forceinline__ double frsq(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r * fma(-0.5 * x * r, r, 1.5);
+}
 // S = L D L' of a symmetric positive definite 4 x 4 (unit lower L): id[i] = 1 / d_i, l = (l10, l20, l30, l21, l31, l32)
 template <typename T> struct Ldl4 {
-    T id[4], l[6];
+    T id[4], l[6], sd[4];  // (sd[i] = 1 / sqrt(d_i): the whitening scale, S = Ls Ls' with Ls = L D^1/2)
     // returns false when a pivot is not positive (or not a number): S, hence the condensed Hessian, is not positive definite
     __device__ __forceinline__ bool factor(const T (&s)[10])  // s = (s00, s10, s11, s20, s21, s22, s30, s31, s32, s33)
     {
@@ -221,6 +238,10 @@ template <typename T> struct Ldl4 {
         l[5] = t32 * id[2];
         const T d3 = s[9] - l[2] * s[6] - l[4] * t31 - l[5] * t32;
         id[3] = frcp(d3);
+        sd[0] = frsq(d0);
+        sd[1] = frsq(d1);
+        sd[2] = frsq(d2);
+        sd[3] = frsq(d3);
         return (d0 > T(0)) & (d1 > T(0)) & (d2 > T(0)) & (d3 > T(0));
     }
     // b <- Ls^-1 b with S = Ls Ls', Ls = L D^1/2 (sid[i] = 1 / sqrt(d_i)): the WHITENING of a stage's input-sized vector
@@ -245,6 +266,16 @@ template <typename T> struct Ldl4 {
     }
 };
 
+// entry i of the stored factor of S: 1 / sqrt(d_0..3), l10, l20, l30, l21, l31, l32 (selected per lane: the store is one instruction)
+template <typename T> __device__ __forceinline__ T ldl_entry(const Ldl4<T> &f, const T (&sid)[4], int i)
+{
+    T v = T(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v = i == j ? sid[j] : v;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v = i == 4 + j ? f.l[j] : v;
+    return v;
+}
 // lane j's value as a wave-uniform scalar (v_readlane)
 __device__ __forceinline__ float rl(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 __device__ __forceinline__ double rl(double v, int j)
@@ -405,7 +436,7 @@ __global__ void __launch_bounds__(64)
                 if (4 * q + pg < nx) pst[q] = -(T)ka.wt * ggoal[4 * q + pg];
         }
         const T *tp0 = stageQ ? gtgt : gA;  // (a readable address when there are no targets)
-        constexpr int PD = 2;  // operands are requested this many steps ahead
+        constexpr int PD = LOW ? 4 : 2;  // operands are requested this many steps ahead (a lone wavefront: deeper)
         T pw[PD][NQ], pa[PD][NQ], pb[PD], ptg[PD][NQ];
         auto request = [&](int d, int k) {
             const T *w = baseW + k * stW, *a = gA + k * sA, *b = gB + k * sB;
@@ -468,7 +499,7 @@ __global__ void __launch_bounds__(64)
             T sid[4], swh;
             {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sid[i] = (T)sqrt((double)ldl.id[i]);
+                for (int i = 0; i < 4; ++i) sid[i] = ldl.sd[i];
                 T eb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) eb[i] = (pg == i) ? T(1) : T(0);
@@ -488,7 +519,7 @@ __global__ void __launch_bounds__(64)
                 MV a0 = zero4;
 #pragma unroll
                 for (int t = 0; t < NQ; ++t) a0 = Mfma<T>::run(E[t], pst[t], a0);
-                if (col0) ffv[(unsigned)(k * 4 + pg)] = a0[NQ];
+                ffv[(unsigned)(c16 * N * 4 + k * 4 + pg)] = a0[NQ];  // (column 0 carries the tracking terms, the others zero)
 #pragma unroll
                 for (int t = 0; t < NQ; ++t)
                     pst[t] = a0[t] - ((tgtq && k >= 1 && col0 && 4 * t + pg < nx) ? wxq * tgk[t] : T(0));
@@ -513,15 +544,11 @@ __global__ void __launch_bounds__(64)
                 rf.v[NQ] = RW[TI];
                 *(RecB *)(Mb + (int64_t)k * SB + lane * LB) = rb;
                 *(RecF *)(Mf + (int64_t)k * SF + lane * LF) = rf;
-                T *ks = KS + (int64_t)k * (nx * nu + 16);
-                if (scol && lcol < nx && pg < nu) ks[lcol * nu + pg] = -E[TI];
-                if (lane == 0) {
-                    T *kf = ks + nx * nu;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) kf[i] = sid[i];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
-                }
+                // K' (padded to 16 x 4) and the factor of S (1 / sqrt(d_i), then l10, l20, l30, l21, l31, l32), one value per lane and
+                // NO condition: a store behind a branch costs the loop its request ring (see the forward sweep)
+                T *ks = KS + (unsigned)(k * KSS);
+                ks[lcol * 4 + pg] = -E[TI];
+                ks[64 + c16] = ldl_entry(ldl, sid, c16);
             }
 #pragma unroll
             for (int t = 0; t < NQ; ++t) P[t] = T(0.5) * (Pk[t] + PT[t]);
@@ -650,7 +677,7 @@ __global__ void __launch_bounds__(64)
                     kc[i] = BPAm[i * LD + c16];
                     fc[i] = Bm[c16 * 4 + i];
                     ec[i] = (c16 == i) ? T(1) : T(0);
-                    sid[i] = (T)sqrt((double)ldl.id[i]);
+                    sid[i] = ldl.sd[i];
                 }
                 ldl.solve(kc);
                 ldl.wsolve(fc, sid);  // Ls^-1 B' (column c16): the WHITENED feed-forward row block
@@ -688,15 +715,12 @@ __global__ void __launch_bounds__(64)
                         v.v[j] = (LF * g + j < NF) ? sgnf[LF * g + j < NF ? LF * g + j : 0] * Pm[srcf[LF * g + j < NF ? LF * g + j : 0]] : T(0);
                     *(RecF *)(mf + g * 64 * LF) = v;
                 }
-                T *ks = KS + (int64_t)k * (nx * nu + 16);
-                if (offK >= 0) ks[lane] = Km[offK];
-                if (lane == 0) {  // the factor of S: 1 / d, then l10, l20, l30, l21, l31, l32
-                    T *kf = ks + nx * nu;
+                T *ks = KS + (unsigned)(k * KSS);
+                ks[lane] = Km[(lane & 3) * LD + (lane >> 2)];  // K' padded to 16 x 4 (the tile is zero outside nu x nx)
+                T sid[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) kf[i] = ldl.id[i];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) kf[4 + i] = ldl.l[i];
-                }
+                for (int i = 0; i < 4; ++i) sid[i] = ldl.id[i];  // (1 / sqrt(d_i) by now)
+                ks[64 + c16] = ldl_entry(ldl, sid, c16);
             }
             wsync();
             // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
@@ -746,7 +770,7 @@ __global__ void __launch_bounds__(64)
         constexpr bool track = decltype(trackc)::value;
         const bool tgt = track && stageQ;
         const T wxq = (T)ka.wx;
-        const unsigned ffo = (unsigned)(cn * N * 4 + pg);  // this lane's entries of the feed-forward array
+        const unsigned ffo = (unsigned)(c16 * N * 4 + pg);  // this lane's entries of the array of whitened vectors (sixteen columns)
         MV st = start;
         const int kstart = track ? N - 1 : kq - 1;
         if (!track) {
@@ -801,7 +825,7 @@ __global__ void __launch_bounds__(64)
                 a0 = start;
                 ffk = ffstart;
             }
-            if (colr) ffv[ffo + (unsigned)(k * 4)] = ffk;
+            ffv[ffo + (unsigned)(k * 4)] = ffk;  // (unconditional: a store behind a branch shortens the request ring, see the forward sweep)
             st = a0;
             if (again) req(d, k - D >= 0 ? k - D : 0);
         };
@@ -828,60 +852,40 @@ __global__ void __launch_bounds__(64)
         for (int q = 0; q < NQ; ++q) gT[q] = (gC && r < mk && 4 * q + pg < nx) ? gC[r * nx + 4 * q + pg] : T(0);
         gT[NQ] = (gD && r < mk && pg < nu) ? gD[r * nu + pg] : T(0);
     }
-    // chunks of [C | D] that are zero in every lane cost no instruction (box constraints touch few states; under load the
-    // forward sweep is bound by the matrix pipe, three wavefronts sharing it)
-    bool gnz[NG];
-#pragma unroll
-    for (int q = 0; q < NG; ++q) gnz[q] = FUSE && __ballot(gT[q] != T(0)) != 0ull;
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     const T tol = ka.tol;
 
     // ---- what happens to a row of G once h_i = g_i . (x_k, u_k) of a forward sweep is known (round 6: the sweeps own the rows).
-    // INIT: the sweep of the unconstrained minimiser -- slack, threshold, selection metric; DIR: a step of length tstep along a
-    // projected vector z (s += t G z_u; active rows stay on their bounds; on a FULL step the candidate lands on its bound and
-    // becomes active: infinite threshold); EVAL: the point from scratch (s = e - G (x, u), active rows checked against their bounds,
-    // inactive ones against feasibility). Every mode also looks for the most violated inactive row (sel*).
-    enum { FW_INIT = 0, FW_DIR = 1, FW_EVAL = 2 };
-    T selb = INF, selv = T(0), spnew = T(0);
+    // INIT: the sweep of the unconstrained minimiser -- slack, threshold, selection metric; EVAL: the point from scratch
+    // (s = e - G (x, u); active rows -- infinite threshold -- checked against their bounds, inactive ones against feasibility).
+    // Both also look for the most violated inactive row (sel*). There is no incremental slack update: between two evaluations the
+    // iterations only track the rows whose whitened vectors are cached (s_c += t y_c . z, a dot product).
+    enum { FW_INIT = 0, FW_EVAL = 2 };
+    T selb = INF, selv = T(0);
     int seli = 0x7fffffff;
-    bool offa = false, dirty = false;
-    auto rowlogic = [&](int mode, int i, T hs, T hsa, T ra, T rb, T iv, T tstep, int bi, bool full, T fac) {
-        T v, th;
-        bool skip = false;
+    bool offa = false;
+    auto rowlogic = [&](int mode, int i, T hs, T hsa, T ra, T rb, T iv, T fac) {
+        const T v = ra - hs;
+        T th;
+        bool act = false;
         if (mode == FW_INIT) {
-            v = ra - hs;
             th = tol + tol * (T)fabs((double)ra);
-            sl[i] = v;
             thr[i] = th;
             invn[i] = iv;
-        } else if (mode == FW_DIR) {
-            th = rb;
-            const bool me = i == bi;
-            skip = (th == INF) || (full && me);
-            v = skip ? T(0) : ra + tstep * hs;
             sl[i] = v;
-            if (full && me) thr[i] = INF;
-            if (me) spnew = v;
         } else {
             th = rb;
-            const T st = ra - hs;
-            const bool act = th == INF;
-            s0[i] = st;
-            sl[i] = act ? T(0) : st;
-            if (act) {
-                // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the terms' magnitudes)
-                const T lim = fac * (tol + tol * (T)fabs((double)ra)) +
-                              (sizeof(T) == 4 ? T(STAGEW_VNOISE32) * T(6e-8) * ((T)fabs((double)ra) + hsa) : T(0));
-                offa |= !((T)fabs((double)st) <= lim);
-            } else if (!(st >= T(-4) * th)) {
-                dirty = true;
-            }
-            skip = act;
-            v = st;
+            act = th == INF;
+            s0[i] = v;
+            sl[i] = act ? T(0) : v;
+            // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the terms' magnitudes)
+            const T lim = fac * (tol + tol * (T)fabs((double)ra)) +
+                          (sizeof(T) == 4 ? T(STAGEW_VNOISE32) * T(6e-8) * ((T)fabs((double)ra) + hsa) : T(0));
+            offa |= act && !((T)fabs((double)v) <= lim);
         }
         const T sc = v * iv;
-        if (!skip && v < -th && sc < selb) {  // (ties: a lane meets its rows in ascending order; across lanes wave_argmin)
+        if (!act && v < -th && sc < selb) {  // (ties: a lane meets its rows in ascending order; across lanes wave_argmin)
             selb = sc;
             seli = i;
             selv = v;
@@ -889,9 +893,9 @@ __global__ void __launch_bounds__(64)
     };
     // the lane that owns row i in the sweeps (FUSE) / the m-row passes
     auto owner = [&](int i) {
-        if constexpr (FUSE) {
-            const int r = i - stepof(i) * mk;
-            return 16 * (r >> 2) + (r & 3);
+        if constexpr (FUSE) {  // (row r of step k: row group r / 4, column 4 (k % 4) + r % 4)
+            const int k = stepof(i), r = i - k * mk;
+            return 16 * (r >> 2) + 4 * (k & 3) + (r & 3);
         } else {
             return i & 63;
         }
@@ -911,38 +915,72 @@ __global__ void __launch_bounds__(64)
         const T nn = __shfl(nnv, sizeof(T) == 4 ? r : 4 * (r & 3) + (r >> 2));
         myinvn = nn > T(0) ? (T)rsqrt((double)nn) : T(1);
     }
+    T myl1 = T(0);    // FUSE, float32: sum_j |g_rj| of that row (bounds the magnitude of the row's terms: the evaluation's noise allowance)
+    if constexpr (FUSE && sizeof(T) == 4) {
+        T l1 = T(0);
+#pragma unroll
+        for (int q = 0; q <= NQ; ++q) l1 += (T)fabs((double)gT[q]);
+        l1 += __shfl_xor(l1, 16);
+        l1 += __shfl_xor(l1, 32);
+        const int r = (4 * pg + (c16 & 3)) & 15;
+        myl1 = __shfl(l1, r);
+    }
+    unsigned sE32;  // (an independent scalar register: the 64-bit stride sits in a 16-register tuple of the kernel arguments that was reloaded whole)
+    asm volatile("s_mov_b32 %0, %1" : "=s"(sE32) : "s"((unsigned)sE));
+    T xmax = T(0);  // max |x_k|, |u_k| over the latest forward sweep's trajectory (float32: the noise allowance of the NEXT evaluation)
     T *ou = (T *)ka.U + prob * (int64_t)nvar;
-    auto forward = [&](int mode, const T *xs, const T *yin, T tstep, int bi, bool full, T fac) {
-        // FUSE: the vector rides in columns 0..3 (the matrix cores compute sixteen whatever their number), so that the SIXTEEN
-        // lanes (pg, c16 < 4) each hold the rows 4 pg .. 4 pg + 3 of the step and each owns ONE of them: row 4 pg + c16
-        const bool cuse = FUSE ? c16 < 4 : col0;
-        const bool hl = FUSE && c16 < 4 && 4 * pg < mk;
-        const int rr = hl ? 4 * pg + c16 : 0;
+    // What bounds a sweep step (round 6, measured): (i) instruction ISSUE -- a lone wavefront spent ~1000 cycles per step on ~130
+    // instructions, a third of them reloads of spilled scalar registers (base pointers, masks, 64-bit strides): every array of the
+    // workspace is now addressed from ONE base with 32-bit per-lane offsets, the mode is a compile-time constant, zero chunks of
+    // [C | D] are multiplied like the others; (ii) the memory counter: a store inside a lane-divergent `if` sits behind a branch, the
+    // compiler must assume the path WITHOUT it when it counts the operations issued since a load (vmcnt is in order), and a ring
+    // of D requests degenerates to a wait for the step before. So NO memory operation of the loop is conditional: the vector rides
+    // in all sixteen columns, a lane owns the row 4 pg + (c16 & 3) of ONE step in four (phase c16 >> 2), keeps that step's h and u
+    // in a register and does its row's work -- bound, threshold, slack, selection, stores -- once per group of four steps, with all
+    // 64 lanes busy; lanes without a row (mk < 16, the horizon's last partial group) aim at a junk cell of their own. The vector's
+    // entries and the rows' operands are requested per group, D / 4 groups ahead, and a step takes its entry from the lane of its
+    // phase by a row broadcast (DPP).
+    constexpr int DG = D / 4;  // the groups' request ring
+    static_assert(D % 4 == 0, "the forward sweep works in groups of four steps");
+    auto forward = [&](auto modec, const T *xs, unsigned yoff, T fac) {
+        constexpr int mode = decltype(modec)::value;
+        const int ph = c16 >> 2;
+        const unsigned r = (unsigned)(4 * pg + (c16 & 3));
+        const bool valid = FUSE && r < (unsigned)mk;
         T z[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) z[q] = (xs && cuse && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
-        const unsigned zoff = (unsigned)(pg * (NQ + 1));
-        T rec[D][NF], ffr[D], ra[D], rb[D];
+        for (int q = 0; q < NQ; ++q) z[q] = (xs && 4 * q + pg < nx) ? xs[4 * q + pg] : T(0);
+        const unsigned lo_rec = (unsigned)wl.Mf + (unsigned)(lane * LF), lo_z = (unsigned)wl.Zs + (unsigned)(pg * (NQ + 1));
+        const unsigned junk = (unsigned)wl.junk + (unsigned)lane;
+        const unsigned mku = (unsigned)mk;
+        const T c_noise = T(STAGEW_VNOISE32) * T(6e-8), xprev = xmax;
+        const int NGall = (N + 3) >> 2;
+        T xm = T(0), hacc = T(0), uacc = T(0);
+        T rec[D][NF], yv[DG], ev[DG], thv[DG];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            ffr[d] = ra[d] = rb[d] = T(0);
+        for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int e = 0; e < NF; ++e) rec[d][e] = T(0);
-        }
+#pragma unroll
+        for (int g = 0; g < DG; ++g) yv[g] = ev[g] = thv[g] = T(0);
         auto req = [&](int d, int k) {
-            const T *mf = Mf + (int64_t)k * SF + lane * LF;
+            const unsigned ku = (unsigned)k;
 #pragma unroll
             for (int g = 0; g < GF; ++g) {
-                const RecF v = *(const RecF *)(mf + g * 64 * LF);
+                const RecF v = *(const RecF *)(ws + (lo_rec + ku * (unsigned)SF + (unsigned)(g * 64 * LF)));
 #pragma unroll
                 for (int j = 0; j < LF; ++j)
                     if (LF * g + j < NF) rec[d][LF * g + j] = v.v[j];
             }
-            ffr[d] = yin[(unsigned)(k * 4 + pg)];
+        };
+        // a group's operands: this lane's entry of the vector at ITS step of the group, its row's bound (and threshold)
+        auto greq = [&](int gs, int gi) {
+            const int st0 = 4 * gi + ph;
+            const unsigned stp = (unsigned)(st0 < N ? st0 : N - 1);
+            yv[gs] = ws[yoff + 4u * stp + (unsigned)pg];
             if constexpr (FUSE) {
-                const unsigned ri = (unsigned)(k * mk + rr);
-                ra[d] = mode == FW_DIR ? sl[ri] : ge[k * sE + rr];
-                rb[d] = mode == FW_INIT ? T(0) : thr[ri];
+                ev[gs] = ge[valid ? stp * sE32 + r : 0u];
+                if (mode == FW_EVAL) thv[gs] = ws[valid ? (unsigned)wl.thr + stp * mku + r : junk];
             }
         };
 #pragma unroll
@@ -950,8 +988,12 @@ __global__ void __launch_bounds__(64)
             req(d, d < N ? d : N - 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        auto step = [&](int d, int k, bool again) {
-            const T ffd = cuse ? ffr[d] : T(0);
+#pragma unroll
+        for (int g = 0; g < DG; ++g) greq(g, g < NGall ? g : NGall - 1);
+        auto step = [&](int d, int gs, int k, auto sc_, bool again) {
+            constexpr int sph = decltype(sc_)::value;  // the step's phase in its group
+            const unsigned ku = (unsigned)k;
+            const T ffd = dpp_mov<0x150 + 4 * sph>(yv[gs]);  // (row_newbcast: the entry held by the lane of phase sph of this row)
             MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int kk = 0; kk <= NQ; ++kk) {
@@ -960,43 +1002,104 @@ __global__ void __launch_bounds__(64)
                 if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
             }
             const T u = STACK ? a0[NQ] : a1[0];
-            if (mode != FW_DIR && col0 && pg < nu) ou[k * nu + pg] = u;  // (the point itself: the unconstrained minimiser / the evaluated one)
+            const bool mine = ph == sph;
+            uacc = mine ? u : uacc;
             if constexpr (FUSE) {
-                MV hk = {T(0), T(0), T(0), T(0)}, ha = {T(0), T(0), T(0), T(0)};
+                MV hk = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (gnz[q]) hk = Mfma<T>::run(gT[q], z[q], hk);
-                if (gnz[NQ]) hk = Mfma<T>::run(gT[NQ], u, hk);
-                if (sizeof(T) == 4 && mode == FW_EVAL) {  // sum |g_ij| |x_j|: the magnitude of the row's terms
+                for (int q = 0; q < NQ; ++q) hk = Mfma<T>::run(gT[q], z[q], hk);
+                hk = Mfma<T>::run(gT[NQ], u, hk);
+                if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (gnz[q]) ha = Mfma<T>::run((T)fabs((double)gT[q]), (T)fabs((double)z[q]), ha);
-                    if (gnz[NQ]) ha = Mfma<T>::run((T)fabs((double)gT[NQ]), (T)fabs((double)u), ha);
+                    for (int q = 0; q < NQ; ++q) xm = fmaxf(xm, fabsf(z[q]));
+                    xm = fmaxf(xm, fabsf(u));
                 }
-                if (hl) {
-                    const T hs = c16 == 0 ? hk[0] : c16 == 1 ? hk[1] : c16 == 2 ? hk[2] : hk[3];
-                    const T hsa = c16 == 0 ? ha[0] : c16 == 1 ? ha[1] : c16 == 2 ? ha[2] : ha[3];
-                    rowlogic(mode, k * mk + rr, hs, hsa, ra[d], rb[d], myinvn, tstep, bi, full, fac);
-                }
-            } else if (col0) {
-                const unsigned zr = zoff + (unsigned)(k * ZL);
+                T hs = hk[0];
+                hs = (c16 & 3) == 1 ? hk[1] : hs;
+                hs = (c16 & 3) == 2 ? hk[2] : hs;
+                hs = (c16 & 3) == 3 ? hk[3] : hs;
+                hacc = mine ? hs : hacc;
+            } else {
+                const unsigned zr = lo_z + ku * (unsigned)ZL;  // (every column writes the same values)
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) Zs[zr + q] = z[q];
-                Zs[zr + NQ] = u;
+                for (int q = 0; q < NQ; ++q) ws[zr + q] = z[q];
+                ws[zr + NQ] = u;
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) z[q] = a0[q];
             if (again) req(d, k + D < N ? k + D : N - 1);
         };
+        // the end of group gi: every lane's row of ITS step of the group
+        auto gend = [&](int gs, int gi) {
+            const int st0 = 4 * gi + ph;
+            const bool liveu = st0 < N;
+            const unsigned stp = (unsigned)(liveu ? st0 : N - 1);
+            ws[liveu ? (unsigned)wl.ust + 4u * stp + (unsigned)pg : junk] = uacc;  // (the point itself; the columns of a phase write the same value)
+            if constexpr (FUSE) {
+                const bool live = valid && liveu;
+                const unsigned irow = stp * mku + r;
+                const T e_ = ev[gs], v = e_ - hacc;
+                const T th0 = tol + tol * (T)fabs((double)e_);  // tol (1 + |e|)
+                T th = th0;
+                bool act = false;
+                if constexpr (mode == FW_EVAL) {
+                    th = thv[gs];
+                    act = th == INF;
+                    // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the magnitude of the
+                    // row's terms, bounded by |e| + |g_r|_1 max |x|)
+                    const T lim = fac * th0 + (sizeof(T) == 4 ? c_noise * ((T)fabs((double)e_) + myl1 * xprev) : T(0));
+                    offa |= live && act && !((T)fabs((double)v) <= lim);
+                }
+                const T sc = v * myinvn;
+                const bool take = live && !act && v < -th && sc < selb;  // (a lane meets its rows in ascending order; across lanes wave_argmin)
+                selb = take ? sc : selb;
+                selv = take ? v : selv;
+                seli = take ? (int)irow : seli;
+                if constexpr (mode == FW_INIT) {
+                    ws[live ? (unsigned)wl.thr + irow : junk] = th0;
+                    ws[live ? (unsigned)wl.invn + irow : junk] = myinvn;
+                    ws[live ? (unsigned)wl.s + irow : junk] = v;
+                } else {
+                    ws[live ? (unsigned)wl.s0 + irow : junk] = v;
+                    ws[live ? (unsigned)wl.s + irow : junk] = act ? T(0) : v;
+                }
+            }
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using P2 = std::integral_constant<int, 2>;
+        using P3 = std::integral_constant<int, 3>;
         int k = 0;
-        for (int g = N / D; g > 0; --g) {
+        for (int it = N / D; it > 0; --it) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) step(d, k + d, true);
+            for (int gs = 0; gs < DG; ++gs) {
+                const int kg = k + 4 * gs, gi = kg >> 2;
+                step(4 * gs + 0, gs, kg + 0, P0{}, true);
+                step(4 * gs + 1, gs, kg + 1, P1{}, true);
+                step(4 * gs + 2, gs, kg + 2, P2{}, true);
+                step(4 * gs + 3, gs, kg + 3, P3{}, true);
+                gend(gs, gi);
+                greq(gs, gi + DG < NGall ? gi + DG : NGall - 1);
+            }
             k += D;
         }
 #pragma unroll
-        for (int d = 0; d < D - 1; ++d)
-            if (k + d < N) step(d, k + d, false);
+        for (int gs = 0; gs < DG; ++gs) {  // the remainder: up to D - 1 steps, the last group possibly partial
+            const int kg = k + 4 * gs;
+            if (kg < N) {
+                step(4 * gs + 0, gs, kg + 0, P0{}, false);
+                if (kg + 1 < N) step(4 * gs + 1, gs, kg + 1, P1{}, false);
+                if (kg + 2 < N) step(4 * gs + 2, gs, kg + 2, P2{}, false);
+                if (kg + 3 < N) step(4 * gs + 3, gs, kg + 3, P3{}, false);
+                gend(gs, kg >> 2);
+            }
+        }
+        if constexpr (FUSE && sizeof(T) == 4) {
+            int dummy = 0;
+            T neg = -xm;
+            wave_argmin(neg, dummy);
+            xmax = -neg;
+        }
     };
     // ---- the general constraint layout: [C | D] packed once -- row i (or r, when they do not change along the horizon) in the
     // order of Zs's rows, as NQ + 1 four-vectors, zero-padded, vector-major so that the lanes of a pass read side by side -- and
@@ -1019,7 +1122,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int q = 0; q <= NQ; ++q) Gp[(int64_t)q * Mg + i] = g[q];
     }
-    auto rowpass = [&](int mode, T tstep, int bi, bool full, T fac) {
+    auto rowpass = [&](int mode, T fac) {
         for (int i0 = lane; i0 < M; i0 += 64 * GU) {
             V4 g[GU][NQ + 1], zq[GU][NQ + 1];
             T ra[GU], rb[GU], rc[GU];
@@ -1034,7 +1137,7 @@ __global__ void __launch_bounds__(64)
                     g[u][q] = Gp[(unsigned)(q * Mg + gi)];
                     zq[u][q] = zr[q];
                 }
-                ra[u] = mode == FW_DIR ? sl[i] : ge[k * sE + (i - k * mk)];
+                ra[u] = ge[k * sE + (i - k * mk)];
                 rb[u] = mode == FW_INIT ? T(0) : thr[i];
                 rc[u] = mode == FW_INIT ? T(0) : invn[i];
             }
@@ -1051,26 +1154,27 @@ __global__ void __launch_bounds__(64)
                             nn += g[u][q][j] * g[u][q][j];
                         }
                     const T iv = mode == FW_INIT ? (nn > T(0) ? (T)rsqrt((double)nn) : T(1)) : rc[u];
-                    rowlogic(mode, i0 + 64 * u, hs, hsa, ra[u], rb[u], iv, tstep, bi, full, fac);
+                    rowlogic(mode, i0 + 64 * u, hs, hsa, ra[u], rb[u], iv, fac);
                 }
         }
     };
     // a forward sweep and what follows it: the rows, the reduction of the selection
-    auto fsweep = [&](int mode, const T *xs, const T *yin, T tstep, int bi, bool full, T fac) {
+    auto fsweep = [&](auto modec, const T *xs, unsigned yoff, T fac) {
+        constexpr int mode = decltype(modec)::value;
         selb = INF;
         seli = 0x7fffffff;
         selv = T(0);
-        offa = dirty = false;
-        forward(mode, xs, yin, tstep, bi, full, fac);
+        offa = false;
+        forward(modec, xs, yoff, fac);
         if constexpr (!FUSE) {
             wsync();  // (the trajectory is read by other lanes)
-            rowpass(mode, tstep, bi, full, fac);
+            rowpass(mode, fac);
         }
         sel_reduce();
-        if (mode == FW_DIR) spnew = __shfl(spnew, owner(bi));
         offa = __ballot(offa) != 0ull;
-        dirty = __ballot(dirty) != 0ull;
     };
+    using FwInit = std::integral_constant<int, FW_INIT>;
+    using FwEval = std::integral_constant<int, FW_EVAL>;
 
     // the right-hand sides of a backward sweep: column 0 carries the candidate row bi, columns 1 .. R - 1 the next most violated
     // rows (the whitened vector y_a of a row does not depend on the active set: a row found among them later costs no sweep; which
@@ -1174,23 +1278,23 @@ __global__ void __launch_bounds__(64)
         if (myrow >= 0) {
             const int kq = stepof(myrow), rq = myrow - kq * mk;
             mykq = kq;
-            const T *ks = KS + (int64_t)kq * (nx * nu + 16);
+            const T *ks = KS + (unsigned)(kq * KSS);
             T dd[NU], sid[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
             Ldl4<T> ldl;
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
-                sid[i] = ks[nx * nu + i];
+                sid[i] = ks[64 + i];
                 ldl.id[i] = T(0);
             }
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ldl.l[i] = ks[nx * nu + 4 + i];
+            for (int i = 0; i < 6; ++i) ldl.l[i] = ks[64 + 4 + i];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = 4 * q + pg;
                 cq[q] = (gC && c < nx) ? gC[kq * sC + rq * nx + c] : T(0);
 #pragma unroll
-                for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * nu + i] : T(0);
+                for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * 4 + i] : T(0);
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -1232,13 +1336,16 @@ __global__ void __launch_bounds__(64)
     T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq, *ev = lamv + maxq;
     int *actrow = (int *)(ev + maxq), *colp = actrow + maxq, *crow = colp + maxq;
     T *Rl = (T *)(((uintptr_t)(crow + R) + 15) & ~(uintptr_t)15);
+    T *crs = (T *)(Rl + WL * WLD), *cth = crs + R, *civ = cth + R;  // the cached rows' slacks, thresholds, selection metric
+    T *cg = civ + R;                                                // ... what their slacks gain per unit step (y_c . z)
+    int *cact = (int *)(cg + R);                                    // ... and whether they are active now
     T *vpt = ws + wl.vpt, *Qs = ws + wl.Q, *Wm = ws + wl.W;
     for (int a = lane; a < maxq; a += 64) colp[a] = a;
     if (lane < R) crow[lane] = -1;
     // the point in whitened coordinates: v = y0 (the sweeps' lane <-> step mapping of the vector passes: lane k % 64 owns step k)
     for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] = ((const V4 *)ffv)[k];
     lsync();
-    fsweep(FW_INIT, gx0, ffv, T(0), -1, false, T(0));
+    fsweep(FwInit{}, gx0, (unsigned)wl.ff, T(0));
     tick(4);
     tick(5);
 
@@ -1305,6 +1412,91 @@ __global__ void __launch_bounds__(64)
             }
             if (pass == 0 && (nq == 0 || zz >= T(0.25) * prev)) break;  // no cancellation: Q' z is at rounding level already
         }
+        return zz;
+    };
+    // g_c = y_c . z of the cached rows (what their slacks gain per unit step along z) into cg[]
+    auto cached_dots = [&](const T *zq) {
+        for (int j0 = 0; j0 < R; j0 += 4) {
+            T p[4] = {T(0), T(0), T(0), T(0)};
+            int kj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kj[u] = (j0 + u < R && crow[j0 + u < R ? j0 + u : 0] >= 0) ? stepof(crow[j0 + u]) : -1;
+            for (int k = lane; k < N; k += 64) {
+                const V4 zv = ((const V4 *)zq)[k];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const V4 yv = ((const V4 *)(ffv + (int64_t)(j0 + u < R ? j0 + u : 0) * nv4))[k];
+                    if (k <= kj[u]) p[u] += dot4(yv, zv);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const T g = wave_sum(p[u]);
+                if (lane == 0 && j0 + u < R) cg[j0 + u] = g;
+            }
+        }
+        lsync();
+    };
+    // The same for horizons of at most 64 steps with at most QF active rows (a lane holds ONE four-vector of every vector): every
+    // load of the iteration -- the candidate's vector, Q, the cached rows' vectors -- is issued up front (one round trip), Q is
+    // read once. Leaves d in cv, z in zq, g_c in cg[]; returns |z|^2.
+    constexpr int QF = LOW ? 8 : 4;  // (registers: the default instantiations run three / two wavefronts per SIMD)
+    auto ortho_small = [&](const T *yp, int kq, T *zq, T &yy) -> T {
+        const V4 zero4v = {T(0), T(0), T(0), T(0)};
+        const int k = lane < N ? lane : N - 1;
+        const bool kin = lane < N;
+        const V4 yv0 = ((const V4 *)yp)[k];
+        V4 qv[QF];
+#pragma unroll
+        for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
+        // (the cached rows' vectors: with the candidate's in the small-batch instantiation, behind z in groups of four otherwise)
+        constexpr int RU = LOW ? R : 4;
+        V4 yc[RU];
+        int kj[RU];
+        auto load_yc = [&](int j0) {
+#pragma unroll
+            for (int j = 0; j < RU; ++j) {
+                const int jj = j0 + j < R ? j0 + j : R - 1;
+                yc[j] = ((const V4 *)(ffv + (int64_t)jj * nv4))[k];
+                const int rj = crow[jj];
+                kj[j] = rj >= 0 ? stepof(rj) : -1;
+            }
+        };
+        if constexpr (LOW) load_yc(0);
+        const V4 yv = (kin && k <= kq) ? yv0 : zero4v;
+        T dd[QF];
+#pragma unroll
+        for (int u = 0; u < QF; ++u) {
+            if (!kin || u >= nq) qv[u] = zero4v;
+            dd[u] = u < nq ? wave_sum(dot4(qv[u], yv)) : T(0);  // (u < nq: wave-uniform)
+        }
+        yy = wave_sum(dot4(yv, yv));
+        V4 zv = yv;
+#pragma unroll
+        for (int u = 0; u < QF; ++u) zv -= dd[u] * qv[u];
+        T zz = wave_sum(dot4(zv, zv));
+        if (nq > 0 && zz < T(0.25) * yy) {  // cancellation: once more on z
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                const T e2 = u < nq ? wave_sum(dot4(qv[u], zv)) : T(0);
+                dd[u] += e2;
+                zv -= e2 * qv[u];
+            }
+            zz = wave_sum(dot4(zv, zv));
+        }
+        if (kin) ((V4 *)zq)[k] = zv;
+#pragma unroll
+        for (int u = 0; u < QF; ++u)
+            if (lane == 0 && u < nq) cv[u] = dd[u];
+        for (int j0 = 0; j0 < R; j0 += RU) {
+            if constexpr (!LOW) load_yc(j0);
+#pragma unroll
+            for (int j = 0; j < RU; ++j) {
+                const T g = wave_sum((kin && k <= kj[j]) ? dot4(yc[j], zv) : T(0));
+                if (lane == 0 && j0 + j < R) cg[j0 + j] = g;
+            }
+        }
+        lsync();
         return zz;
     };
     // r = R^-1 d (d in cv) into rv: back substitution, column b of R read by the lanes of the rows above it
@@ -1402,34 +1594,54 @@ __global__ void __launch_bounds__(64)
     };
 
     // ================================================================= active-set loop (Goldfarb-Idnani; oracle/stagewise_qr_np.py)
+    // Between two evaluations of the point the loop works on the rows whose whitened vectors the latest backward sweep cached
+    // (the most violated row and the R - 1 next ones): a row's slack moves by t y_c . z with a step -- a dot product, no sweep --,
+    // the most violated CACHED row is taken next (any violated row is a valid Goldfarb-Idnani choice: the dual objective grows
+    // with every full step), and when none of them is violated the point is evaluated from scratch: ONE forward sweep of v from
+    // x0 gives every row's slack, the inputs, the check of the active rows and the most violated row of all, with which the
+    // next backward sweep starts. No slack is ever updated incrementally across evaluations.
     T best = selb, sp = selv;
     int bi = seli;
-    for (int round = 0; round < 4 && !fail; ++round) {
+    int polish = 0;
+    for (;;) {
+        tacc(-1);
+        if (!(best < INF)) {
+            status = MPCQP_SOLVED;
+            break;
+        }
+        {   // ---- the next R rows: the most violated one and the next ones; their whitened vectors (one backward sweep)
+            int myrow, mykq, kmax;
+            MV st;
+            T ffs;
+            wsync();  // (the sweeps' rows are read by other lanes)
+            if (stamp && lane == 0) stamp[15] += 1;
+            candidates(bi, myrow, mykq, kmax, st, ffs);
+            backward(std::false_type{}, kmax, st, ffs, mykq);
+            const int rj = __shfl(myrow, lane & 15);  // (column j's row sits in the lanes with c16 == j)
+            if (lane < R) {
+                crow[lane] = rj;
+                const unsigned ri = (unsigned)(rj >= 0 ? rj : 0);
+                crs[lane] = sl[ri];
+                cth[lane] = thr[ri];
+                civ[lane] = invn[ri];
+                cact[lane] = 0;
+            }
+            wsync();
+        }
+        tacc(9);
         for (;;) {
-            tacc(-1);
-            if (!(best < INF)) {
-                status = MPCQP_SOLVED;
-                break;
+            // ---- the most violated cached row
+            int hit = lane;
+            T sc = INF;
+            if (lane < R && crow[lane < R ? lane : 0] >= 0 && !cact[lane < R ? lane : 0]) {
+                const T v = crs[lane];
+                if (v < -cth[lane]) sc = v * civ[lane];
             }
-            // the candidate's whitened vector y_p: cached by an earlier backward sweep, or a sweep now (R right-hand sides)
-            int hit = -1;
-            {
-                const unsigned long long hm = __ballot(lane < R && crow[lane < R ? lane : 0] == bi);
-                hit = hm ? (int)__builtin_ctzll(hm) : -1;
-            }
+            wave_argmin(sc, hit);
+            if (!(sc < INF)) break;  // none: the point is evaluated from scratch
             tacc(8);
-            if (hit < 0) {
-                int myrow, mykq, kmax;
-                MV st;
-                T ffs;
-                wsync();  // (the sweeps' rows are read by other lanes)
-                candidates(bi, myrow, mykq, kmax, st, ffs);
-                backward(std::false_type{}, kmax, st, ffs, mykq);
-                if (lane < R) crow[lane] = myrow;
-                wsync();
-                hit = 0;
-            }
-            tacc(9);
+            bi = crow[hit];
+            sp = crs[hit];
             const T *yp = ffv + (int64_t)hit * nv4;
             const int kq = stepof(bi);
             T up = T(0);
@@ -1442,7 +1654,13 @@ __global__ void __launch_bounds__(64)
                 ++iters;
                 T *zq = Qs + (int64_t)nq * nv4;
                 T yy;
-                const T zz = ortho(yp, kq, zq, yy);
+                T zz;
+                if (N <= 64 && nq <= QF) {
+                    zz = ortho_small(yp, kq, zq, yy);
+                } else {
+                    zz = ortho(yp, kq, zq, yy);
+                    cached_dots(zq);
+                }
                 tacc(10);
                 if (wglob)
                     rsolve(Wm, maxq);
@@ -1478,11 +1696,12 @@ __global__ void __launch_bounds__(64)
                 }
                 tacc(11);
                 if (can_move) {
-                    // the step: the point moves against z (v -= t z; in the inputs u -= t z_u), the slacks gain t G z_u -- the
-                    // PROJECTED vector goes through the forward sweep, whose rows also select the next candidate
+                    // the step: the point moves against z (v -= t z), the slack of a cached row c gains t y_c . z (active rows stay on
+                    // their bounds, the candidate's own gain is t |z|^2: it lands on its bound exactly with a full step)
                     for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] -= t * ((const V4 *)zq)[k];
-                    wsync();  // (z is read by the sweep's lanes)
-                    fsweep(FW_DIR, nullptr, zq, t, bi, full, T(0));
+                    if (lane < R && !cact[lane < R ? lane : 0]) crs[lane] += t * cg[lane];
+                    sp += t * zz;
+                    lsync();
                 }
                 tacc(12);
                 // ---- multipliers
@@ -1503,16 +1722,23 @@ __global__ void __launch_bounds__(64)
                         append(Rl, WLD, zq, zz, up, bi);
                     ++nq;
                     added = true;
-                    best = selb;
-                    bi = seli;
-                    sp = selv;
+                    if (lane == owner(bi)) thr[bi] = INF;  // (the row's owner) active: infinite threshold
+                    if (lane == 0) {
+                        cact[hit] = 1;
+                        crs[hit] = T(0);
+                    }
                 } else {
+                    const int rowl = actrow[l];
                     if (wglob)
                         drop(l, Wm, maxq);
                     else
                         drop(l, Rl, WLD);
                     --nq;
-                    if (can_move) sp = spnew;
+                    // (a cached row that leaves is tracked again, from its bound)
+                    if (lane < R && crow[lane < R ? lane : 0] == rowl) {
+                        cact[lane] = 0;
+                        crs[lane] = T(0);
+                    }
                 }
                 if (wglob)
                     wsync();
@@ -1523,23 +1749,22 @@ __global__ void __launch_bounds__(64)
             if (fail) break;
         }
         if (fail) break;
-        tick(6);
-        if (iters == 0) break;  // the unconstrained minimiser is feasible: its inputs are written already
-        // ================================================================= the point from scratch, acceptance
-        // One forward sweep of the whitened point v from x0 gives the inputs that are returned and their rows (closed loop: stable
-        // whatever the spectrum of A). Inactive rows must be feasible; ACTIVE rows must sit on their bounds: beyond the trigger a
-        // polish step -- S dlam = rho with S = R' R, the point moves along Q R^-T rho -- and the evaluation again; a point that still
-        // fails the acceptance bound is not reported solved.
-        constexpr int VPASS = sizeof(T) == 4 ? STAGEW_VPASS32 : 3;
-        for (int pass = 0; pass < VPASS; ++pass) {
-            const T fac = pass < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10)
-                                           : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(100) > T(1e-7) / tol ? T(100) : T(1e-7) / tol));
+        tacc(-1);
+        // ================================================================= the point from scratch
+        // One forward sweep of the whitened point v from x0 gives the inputs that are returned and every row (closed loop: stable
+        // whatever the spectrum of A). The most violated inactive row, if there is one, starts the next round of the loop. If there
+        // is none the point is the answer -- once its ACTIVE rows sit on their bounds: beyond the trigger a polish step
+        // (S dlam = rho with S = R' R, the point moves along Q R^-T rho) and the evaluation again; a point that still fails the
+        // acceptance bound is not reported solved.
+        for (;;) {
+            const T fac = polish < VPASS - 1 ? T(sizeof(T) == 4 ? STAGEW_VTRIG32 : 10)
+                                             : (sizeof(T) == 4 ? T(STAGEW_VACC32) : (T(100) > T(1e-7) / tol ? T(100) : T(1e-7) / tol));
             wsync();  // (v is read by the sweep's lanes)
-            fsweep(FW_EVAL, gx0, vpt, T(0), -1, false, fac);
-            bool neg = false;
-            for (int a = lane; a < nq; a += 64) neg |= !(lamv[a] >= T(0));
-            if (!offa && __ballot(neg) == 0ull) break;
-            if (pass == VPASS - 1) {
+            fsweep(FwEval{}, gx0, (unsigned)wl.vpt, fac);
+            if (stamp && lane == 0) stamp[15] += 256;
+            if (selb < INF || !offa) break;
+            if (stamp && lane == 0) stamp[15] += 65536;
+            if (++polish >= VPASS) {
                 fail = true;
                 break;
             }
@@ -1569,22 +1794,22 @@ __global__ void __launch_bounds__(64)
             lsync();
         }
         if (fail) break;
-        if (!dirty) {
-            status = MPCQP_SOLVED;
-            break;
-        }
-        status = MPCQP_MAX_ITER;  // an inactive row came out violated: continue from the re-evaluated slacks
+        tacc(14);
         best = selb;
         bi = seli;
         sp = selv;
     }
+    tick(6);
     tick(7);
     if (fail && status == MPCQP_SOLVED) status = MPCQP_MAX_ITER;
     if (slotsfull) status = MPCQP_SLOTS_FULL;
     const bool ok = status == MPCQP_SOLVED;
     wsync();
-    if (!ok)
-        for (int i = lane; i < nvar; i += 64) ou[i] = T(0);
+    {   // the inputs of the latest evaluation (rows of 4), or zeros when there is no plan
+        const T *ust = ws + wl.ust;
+        for (int i = lane; i < nv4; i += 64)
+            if ((i & 3) < nu) ou[(i >> 2) * nu + (i & 3)] = ok ? ust[i] : T(0);
+    }
     if (ka.lam) {
         T *ol = (T *)ka.lam + prob * (int64_t)M;
         for (int i = lane; i < M; i += 64) ol[i] = T(0);
@@ -1652,11 +1877,12 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     }
     constexpr int RR = FUSE ? (LOW ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq, g_invariant(ka), sizeof(T), LOW);
+    if (wl.total >= ((int64_t)1 << 31)) return MPCQP_ETOOLARGE;  // (the kernel addresses a problem's arrays with 32-bit offsets)
     // the matrix tiles of the LDS Riccati recursion only exist for nx > 12; then 8 constant / spare cells
     const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
     // + d, r, multipliers, a scratch vector; active rows, column permutation of R, the backward sweeps' rows; the 32 x 33 tile of R
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (4 * sizeof(T) + 2 * sizeof(int)) + (size_t)RR * sizeof(int) + 16 +
-                       (size_t)32 * 33 * sizeof(T);
+                       (size_t)32 * 33 * sizeof(T) + (size_t)RR * (4 * sizeof(T) + sizeof(int));
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     // (developer knob: MPCQP_STAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
     static const size_t lds_pad = [] {

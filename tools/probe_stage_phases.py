@@ -26,7 +26,7 @@ buf = torch.zeros(batch * 16, dtype=torch.int64, device="cuda")
 for _ in range(2): plan = solve_mpc_batch(bp, formulation="stagewise", probe=buf)
 torch.cuda.synchronize()
 t = buf.view(batch, 16).cpu().double()
-names = ["riccati", "chunk matrices", "u0 backward", "u0 forward", "slacks", "active set", "verification"]
+names = ["riccati", "chunk matrices", "u0 backward", "u0 forward + rows", "-", "active set", "evaluation"]
 print(kind, "batch", batch, "N", bp.nb_timesteps, "mean iters", plan.iters.float().mean().item())
 for i, nme in enumerate(names):
     d = t[:, i + 1] - t[:, i]
@@ -35,24 +35,10 @@ print(f"  total            mean {(t[:,7]-t[:,0]).mean().item():10.0f} cyc   max 
 if kind == "wip" or kind == "sat":
     for i, nme in zip((9, 10, 12, 13), ["sweeps", "c, r = W c", "ratio test", "slack update"]):
         print(f"    in loop: {nme:14s} mean {t[:, i].mean().item():10.0f} cyc   per iteration {t[:, i].sum().item() / max(1.0, plan.iters.float().sum().item()):8.0f}")
-if kind in ("c5", "c5f64"):
-    for i, nme in zip(range(8, 15), ["selection", "backward", "forward", "gmul", "step calc", "slack update", "W update"]):
-        print(f"    in loop: {nme:14s} mean {t[:, i].mean().item():10.0f} cyc")
-if kind in ("c5", "c5f64"):
-    code = buf.view(batch, 16)[:, 15].cpu()
-    nv0, tv0 = (code & 0xffff).double(), (code >> 16).double() / 1000.0
-    it = plan.iters.cpu().double()
-    work = (t[:, 7] - t[:, 5])
-    def corr(a, b): return float(torch.corrcoef(torch.stack([a, b]))[0, 1])
-    print(f"    predictors of the active-set work: corr(nv0, iters) {corr(nv0, it):.3f}  corr(tv0, iters) {corr(tv0, it):.3f}  corr(nv0, cycles) {corr(nv0, work):.3f}  corr(tv0, cycles) {corr(tv0, work):.3f}")
-    # what longest-first would give: list scheduling on 3072 slots by descending key vs natural order
-    import heapq
-    def makespan(order, slots=3072):
-        h = [0.0] * slots; heapq.heapify(h)
-        for i in order: heapq.heappush(h, heapq.heappop(h) + float(work[i]))
-        return max(h)
-    nat = makespan(range(batch)); ideal = float(work.sum()) / 3072
-    print(f"    active-set makespan on 3072 slots (cycles): natural order {nat:.0f}, by nv0 desc {makespan(torch.argsort(nv0, descending=True).tolist()):.0f}, by tv0 desc {makespan(torch.argsort(tv0, descending=True).tolist()):.0f}, oracle LPT {makespan(torch.argsort(work, descending=True).tolist()):.0f}, sum/slots {ideal:.0f}")
+if kind in ("c5", "c5f64"):  # (round 6: the loop's parts of the thin-QR kernel)
+    its = max(1.0, plan.iters.float().sum().item())
+    for i, nme in zip(range(8, 15), ["cache lookup", "candidates+bwd", "orthogonalise", "R solve+ratio", "step: v, cached rows", "append / drop", "evaluations"]):
+        print(f"    in loop: {nme:16s} mean {t[:, i].mean().item():10.0f} cyc   per iteration {t[:, i].sum().item() / its:8.0f}")
 print(f"  makespan {(t[:,7].max()-t[:,0].min()).item():.0f} cyc; start spread {(t[:,0].max()-t[:,0].min()).item():.0f}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):
