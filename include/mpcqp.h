@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPCQP_ABI_VERSION 10
+#define MPCQP_ABI_VERSION 11
 
 /* element type of every floating-point buffer of a call. It is the STORAGE type: mpcqp_build_solve_batch computes
  * MPCQP_F32 problems of at most 160 variables (and every float32 problem only the general stage-wise kernel serves) in
@@ -152,10 +152,11 @@ typedef struct MpcqpProblem {
                                  minimiser; measured 5 % SLOWER than the plain iterations on BASELINE config 2,
                                  hence opt-in: the seed steps are what MPCQP_WARM_ACTIVE_SET starts from. */
 
-#define MPCQP_OPT_EXACT_SELECTION 1024 /* wide stage-wise kernel, constraint matrices fixed along the horizon: every iteration
-                                 selects the most violated row of ALL rows (a pass over the m slacks per step) instead of
-                                 preferring a violated row whose sweeps are already done and deferring the pass (lazy
-                                 slacks, the default since ABI 8). Same minimiser; other iterates. */
+#define MPCQP_OPT_EXACT_SELECTION 1024 /* accepted, no effect (ABI 11). Until ABI 10 it switched the wide stage-wise kernel from "lazy
+                                 slacks" to a pass over the m slacks per step. Since round 6 that kernel never updates slacks
+                                 incrementally: between two evaluations of the point it takes the most violated row among those
+                                 whose whitened vectors the latest backward sweep cached (a valid Goldfarb-Idnani choice:
+                                 same minimiser), see csrc/mpcqp_stagew.hip. */
 
 #define MPCQP_OPT_TWO_PER_WAVE 2048 /* small-problem fused kernel: keep TWO problems per wavefront (mpcqp_pair.hip) where the
                                  dispatch would put FOUR on one (mpcqp_quad.hip: cold launches with terminal cost only and two

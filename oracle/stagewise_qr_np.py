@@ -13,13 +13,15 @@ active problems. Here:
   (backward [Acl' ; -Ls^-1 B'], forward [[Acl, B Ls^-T], [-K, Ls^-T]]), so a sweep works on y directly.
 * Thin QR of the active rows' whitened vectors, Y_A = Q R: a candidate is orthogonalised against Q (classical
   Gram-Schmidt, a second pass when the first one cancelled), |z|^2 is a SUM OF SQUARES, r = R^-1 Q' y_p.
-* The projected vector z goes through the forward sweep, which returns the step in the inputs and G z: the primal
-  point and the slacks are carried explicitly (u -= t z_u, s += t G z_u). No per-row V_a / h_a storage.
+* No per-row V_a / h_a storage and NO incremental slack update: the point is carried in whitened coordinates (v -= t z) and
+  evaluated FROM SCRATCH when needed -- one forward sweep of v from x0 gives the inputs, every row's slack and the most
+  violated row. In between the loop works on the rows whose whitened vectors the latest backward sweep cached (the most
+  violated row and the next ones): such a row's slack gains t y_c . z with a step, a dot product; the most violated cached row
+  is taken next (any violated row is a valid Goldfarb-Idnani choice), and when none is violated the point is evaluated again.
 * A leaving row deletes its column of R; Givens rotations on rows of R / vectors of Q restore the triangle.
-* The point is carried in whitened coordinates as well (v = y0 - sum t z). Acceptance evaluates it FROM SCRATCH: one forward
-  sweep of v from x0 (closed loop: stable whatever the spectrum of A, unlike a roll-out of rounded inputs) gives the inputs
-  that are returned and their rows; while an active row sits off its bound, a polish step (z = Q R^-T rho,
-  lam -= R^-1 R^-T rho).
+* Acceptance is such an evaluation (closed loop: stable whatever the spectrum of A, unlike a roll-out of rounded inputs)
+  with no inactive row violated; while an active row sits off its bound, a polish step (z = Q R^-T rho,
+  lam -= R^-1 R^-T rho) and the evaluation again.
 
 ``dtype=np.float32`` runs every operation in float32 (what config 5's instantiation computes).
 """
@@ -101,8 +103,12 @@ def _rollout(sp, U, dt):
 
 
 def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-12, dtype=np.float64, stats=None,
-                       evaluate: str = "closed"):
-    """(U [N*nu], lam [N*mk], status, iters): status 0 solved, 1 iteration limit, 2 infeasible, 3 P not PD."""
+                       cached_rows: int = 8):
+    """(U [N*nu], lam [N*mk], status, iters): status 0 solved, 1 iteration limit, 2 infeasible, 3 P not PD.
+
+    ``cached_rows``: right-hand sides of a backward sweep (the kernels' R: 8 in the general constraint layout, 7 / 12 when the
+    constraint matrices are fixed along the horizon). It shapes the iterates: between two evaluations the loop only takes rows whose
+    whitened vectors the latest backward sweep cached."""
     dt = dtype
     f32 = dt == np.float32
     N, nx, nu, mk = sp.N, sp.nx, sp.nu, sp.mk
@@ -117,21 +123,24 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
     if s_on:
         qlin[1:] = -dt(sp.wx) * sp.targets[1:].astype(dt)
     pN = (-dt(sp.wt) * sp.goal).astype(dt) if t_on else np.zeros(nx, dt)
-    y0 = ric.backward(qlin, np.zeros((N, nu), dt), pN=pN)
-    U, X = ric.forward(y0, x0=sp.x0.astype(dt))
-    v = y0.reshape(-1).copy()          # the point in whitened coordinates: u = forward(v, x0)
     gmul = lambda Xv, Uv: np.einsum("kri,ki->kr", C, Xv[:N]) + np.einsum("kri,ki->kr", D, Uv)  # noqa: E731
-    s = e - gmul(X, U)
     selectable = sp.e < 1e29
     tolh = (dt(tol) * (1 + np.abs(e))).astype(dt)
     invn = _row_inv_norms(sp).astype(dt)
     dep = dt(1e-10 if f32 else 1e-26)   # |z|^2 <= dep |y|^2: the row depends on the active ones
+    x0 = sp.x0.astype(dt)
 
     act, lam = [], []
     Q = np.zeros((0, n), dt)            # vectors of Q by rows
     R = np.zeros((0, 0), dt)
     active = np.zeros((N, mk), bool)
-    iters, status = 0, 1
+    iters = 0
+    v = ric.backward(qlin, np.zeros((N, nu), dt), pN=pN).reshape(-1)  # the point in whitened coordinates: u = forward(v, x0)
+
+    def evaluate():
+        """the point from scratch: inputs, every row's slack (active rows: their residual)"""
+        U, X = ric.forward(v.reshape(N, nu), x0=x0)
+        return U, e - gmul(X, U)
 
     def row_y(kp, rp):
         ql = np.zeros((N, nx), dt)
@@ -140,21 +149,13 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
         rl[kp] = -D[kp, rp]
         return ric.backward(ql, rl, ktop=kp).reshape(-1)
 
-    def move(z, t):
-        """the step along the whitened vector z: u -= t z_u, s += t G z_u (active rows stay on their bounds)"""
-        nonlocal U, s, v
-        Zu, Zx = ric.forward(z.reshape(N, nu))
-        U = U - dt(t) * Zu
-        v = v - dt(t) * z
-        s = np.where(active, dt(0), s + dt(t) * gmul(Zx, Zu))
-
     def drop(l):
         nonlocal Q, R
         k = len(act) - 1
         R = np.delete(R, l, axis=1)          # rows 0..k, columns 0..k-1: upper Hessenberg behind column l
         for j in range(l, k):
             a, b = R[j, j], R[j + 1, j]
-            hh = dt(np.hypot(a, b))
+            hh = dt(np.sqrt(a * a + b * b))
             c, sn = (a / hh, b / hh) if hh > 0 else (dt(1), dt(0))
             rj, rj1 = R[j].copy(), R[j + 1].copy()
             R[j], R[j + 1] = c * rj + sn * rj1, c * rj1 - sn * rj
@@ -165,16 +166,55 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
         active[act[l]] = False
         del act[l], lam[l]
 
-    for rnd in range(4):
-        fail = False
-        while True:
-            viol = selectable & ~active & (s < -tolh)
-            if not viol.any():
-                status = 0
+    U, s = evaluate()
+    polish, vpass = 0, 3
+    while True:
+        viol = selectable & ~active & (s < -tolh)
+        if not viol.any():
+            # ---- no inactive row is violated: the point is the answer once its ACTIVE rows sit on their bounds
+            rho = np.array([s[a] for a in act], dt)
+            trig = (8 if f32 else 10) if polish < vpass - 1 else (16 if f32 else max(100.0, 1e-7 / tol))
+            lim = np.array([trig * tolh[a] for a in act])
+            if f32 and len(act):  # plus what a float32 evaluation cannot resolve
+                xmax = max(float(np.abs(U).max()), 1.0)
+                lim = lim + 16 * 6e-8 * np.array([abs(e[a]) + (np.abs(C[a[0], a[1]]).sum() + np.abs(D[a[0], a[1]]).sum()) * xmax for a in act])
+            if stats is not None:
+                stats.setdefault("rho", []).append(float(np.abs(rho).max()) if len(act) else 0.0)
+            if not (len(act) and bool((np.abs(rho) > lim).any())):
                 break
-            score = np.where(viol, s * invn, np.inf)
-            kp, rp = np.unravel_index(np.argmin(score), score.shape)
-            y = row_y(kp, rp)
+            polish += 1
+            if polish >= vpass:
+                return np.zeros(n), np.zeros(N * mk), 1, iters
+            # polish: S dlam = rho with S = R'R; the point moves along Q R^-T rho (whitened)
+            nq = len(act)
+            w = np.zeros(nq, dt)
+            for i in range(nq):
+                w[i] = (rho[i] - R[:i, i] @ w[:i]) / R[i, i]
+            dl = np.zeros(nq, dt)
+            for b in range(nq - 1, -1, -1):
+                dl[b] = (w[b] - R[b, b + 1:] @ dl[b + 1:]) / R[b, b]
+            v = v + w @ Q
+            for a in range(nq):
+                lam[a] = max(lam[a] - dl[a], dt(0))
+            U, s = evaluate()
+            continue
+        # ---- the most violated row and the next ones: their whitened vectors (one backward sweep), their slacks
+        score = np.where(viol, s * invn, np.inf).reshape(-1)
+        order = np.argsort(score, kind="stable")
+        rows = [int(i) for i in order[:cached_rows] if np.isfinite(score[i])]
+        ys = [row_y(i // mk, i % mk) for i in rows]
+        crs = [s.reshape(-1)[i] for i in rows]
+        cact = [False] * len(rows)
+        while True:
+            # the most violated cached row (ties: the lowest cache slot)
+            best, hit = np.inf, -1
+            for j, i in enumerate(rows):
+                if not cact[j] and crs[j] < -tolh.reshape(-1)[i] and crs[j] * invn.reshape(-1)[i] < best:
+                    best, hit = crs[j] * invn.reshape(-1)[i], j
+            if hit < 0:
+                break
+            kp, rp = rows[hit] // mk, rows[hit] % mk
+            y = ys[hit]
             yy = dt(y @ y)
             up = dt(0)
             added = False
@@ -199,15 +239,16 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
                 for a in range(nq):
                     if r[a] > 0 and lam[a] / r[a] < t1:
                         t1, l = lam[a] / r[a], a
-                t2 = -s[kp, rp] / zz if can_move else np.inf
+                t2 = -crs[hit] / zz if can_move else np.inf
                 t = min(t1, t2)
                 if not np.isfinite(t):
                     return np.zeros(n), np.zeros(N * mk), 2, iters
                 full = t2 <= t1
-                if can_move:
-                    if full:
-                        active[kp, rp] = True  # (lands on its bound exactly)
-                    move(z, t)
+                if can_move:  # the point moves against z; a cached row's slack gains t y_c . z
+                    v = v - dt(t) * z
+                    for j in range(len(rows)):
+                        if not cact[j]:
+                            crs[j] = crs[j] + dt(t) * dt(ys[j] @ z)
                 for a in range(nq):
                     lam[a] = max(lam[a] - dt(t) * r[a], dt(0))
                 up = up + dt(t)
@@ -220,57 +261,18 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
                     Rn[nq, nq] = zn
                     R = Rn
                     act.append((kp, rp))
+                    active[kp, rp] = True
                     lam.append(up)
+                    cact[hit], crs[hit] = True, dt(0)
                     added = True
                 else:
+                    rowl = act[l][0] * mk + act[l][1]
                     drop(l)
-        # ---- acceptance on a roll-out of the inputs through the original dynamics; polish while an active row is off its bound
-        vpass = 3
-        for vp in range(vpass):
-            if evaluate == "closed":   # the point from scratch through the closed-loop sweep (what the kernels do)
-                U, Xr = ric.forward(v.reshape(N, nu), x0=sp.x0.astype(dt))
-            else:                      # a roll-out of the carried inputs through the original dynamics
-                Xr = _rollout(sp, U, dt)
-            sr = e - gmul(Xr, U)
-            rho = np.array([sr[a] for a in act], dt)
-            offa = any(not (lv >= 0) for lv in lam)
-            trig = (8 if f32 else 10) if vp < vpass - 1 else (16 if f32 else max(100.0, 1e-7 / tol))
-            lim = np.array([trig * tolh[a] for a in act])
-            if f32:  # plus what a float32 evaluation cannot resolve
-                lim = lim + 16 * 6e-8 * np.array([np.abs(C[a[0], a[1]]) @ np.abs(Xr[a[0]]) + np.abs(D[a[0], a[1]]) @ np.abs(U[a[0]]) + abs(e[a]) for a in act])
-            if len(act):
-                offa = offa or bool((np.abs(rho) > lim).any())
-            if stats is not None:
-                stats.setdefault("rho", []).append(float(np.abs(rho).max()) if len(act) else 0.0)
-            if not offa:
-                break
-            if vp == vpass - 1:
-                fail = True
-                break
-            # polish: S dlam = rho with S = R'R; the point moves along z = Q R^-T rho (whitened), t = 1 in the loop's sign
-            nq = len(act)
-            w = np.zeros(nq, dt)
-            for i in range(nq):
-                w[i] = (rho[i] - R[:i, i] @ w[:i]) / R[i, i]
-            dl = np.zeros(nq, dt)
-            for b in range(nq - 1, -1, -1):
-                dl[b] = (w[b] - R[b, b + 1:] @ dl[b + 1:]) / R[b, b]
-            Zu, Zx = ric.forward((w @ Q).reshape(N, nu))
-            U = U + Zu                      # s = e - G u must drop by rho on the active rows: G_A dU = rho
-            v = v + w @ Q
-            for a in range(nq):
-                lam[a] = max(lam[a] - dl[a], dt(0))
-        if fail:
-            status = 1
-            break
-        s = np.where(active, dt(0), sr)
-        if not (selectable & ~active & (sr < -4 * tolh)).any():
-            status = 0
-            break
-        status = 1  # an inactive row came out violated: continue from the re-evaluated slacks
+                    if rowl in rows:  # a cached row that leaves is tracked again, from its bound
+                        j = rows.index(rowl)
+                        cact[j], crs[j] = False, dt(0)
+        U, s = evaluate()
     lam_full = np.zeros((N, mk))
     for a, (k, r_) in enumerate(act):
         lam_full[k, r_] = lam[a]
-    if status != 0:
-        return np.zeros(n), np.zeros(N * mk), status, iters
-    return U.astype(np.float64).reshape(-1), lam_full.reshape(-1), status, iters
+    return U.astype(np.float64).reshape(-1), lam_full.reshape(-1), 0, iters

@@ -14,7 +14,7 @@ F64, F32 = 0, 1
 P_TERMINAL, P_STAGE, Q_TERMINAL, Q_STAGE = 1, 2, 4, 8
 SOLVED, MAX_ITER, INFEASIBLE, NOT_PD, SLOTS_FULL = 0, 1, 2, 3, 4
 EINVAL, EWORKSPACE, EUNSUPPORTED = -1, -5, -6
-ABI_VERSION = 10
+ABI_VERSION = 11
 OPT_FORCE_LDS, OPT_FORCE_GWS, OPT_FORCE_DENSE_G, OPT_ONE_PER_WAVE, OPT_FORCE_CONDENSED, OPT_STAGE_WIDE = 1, 2, 4, 8, 16, 32
 OPT_KEEP_FACTOR, OPT_REUSE_FACTOR, OPT_PIPELINE_FACTOR, OPT_SEED_VIOLATED, OPT_EXACT_SELECTION = 64, 128, 256, 512, 1024
 OPT_TWO_PER_WAVE, OPT_FOUR_PER_WAVE = 2048, 4096

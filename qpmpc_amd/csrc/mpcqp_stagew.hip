@@ -53,6 +53,15 @@ namespace mpcqp {
 #ifndef STAGEW_WPE32
 #define STAGEW_WPE32 3
 #endif
+#ifndef STAGEW_DBG
+#define STAGEW_DBG 0 /* timing experiments only (wrong results): 1 no rows' products in the forward sweep, 2 no record loads in its loop, 4 no group work */
+#endif
+#ifndef STAGEW_DLOW
+#define STAGEW_DLOW 12
+#endif
+#ifndef STAGEW_RLOW
+#define STAGEW_RLOW 12
+#endif
 #ifndef STAGEW_RF
 #define STAGEW_RF 7 /* (round 4, with the lazy slacks: 7 -> 1.183 ms, 6 -> 1.198, 8 -> 1.215, 10 -> 1.238, 16 -> 1.309 per 8192 config-5 problems) */
 #endif
@@ -70,7 +79,7 @@ constexpr int R_PLAIN = 8, R_FUSE = STAGEW_RF;
 // SIMD (the 8-GPU share of config 5: 1024 problems) is bounded by the LATENCY of its longest problem, and the registers of
 // the empty wavefront slots buy some of it back: one wavefront per SIMD (512 VGPRs), twelve right-hand sides per backward
 // sweep, a six-step request ring.
-constexpr int R_FUSE_LOW = 12, D_LOW = 12;
+constexpr int R_FUSE_LOW = STAGEW_RLOW, D_LOW = STAGEW_DLOW;
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value; 32-bit: scalar registers are short)
     int Mb, Mf, KS, ff, Zs, Gp, s0, s, invn, thr, vpt, ust, junk, Q, W;
@@ -172,6 +181,35 @@ template <> struct Mfma<double> {
     static __device__ __forceinline__ int row(int pg, int t) { return pg + 4 * t; }
     static __device__ __forceinline__ int rowmap(int i) { return i; }
 };
+
+// sum_c a[c] (x) b[c] (+ init): a chain of products accumulating into one another, or (STAGEW_CHAIN 0) INDEPENDENT products summed
+// on the vector pipe. Round 6 measured a sweep step's bare chain of four float32 16x16x4 products at 358 cycles for a lone
+// wavefront and tried the independent form: slower everywhere (the sums' twelve vector instructions and the registers cost more
+// than the chain's waits).
+#ifndef STAGEW_CHAIN
+#define STAGEW_CHAIN 1 /* 0: independent products summed on the vector pipe -- measured SLOWER (config 5: 6.35 against 6.61 M/s, Riccati 183 k against 167 k cycles), kept for A/B runs */
+#endif
+template <typename T, int NCH> __device__ __forceinline__ typename Mfma<T>::V mfma_sum(const T (&a)[NCH], const T (&b)[NCH], typename Mfma<T>::V init)
+{
+    using MV = typename Mfma<T>::V;
+    if constexpr (STAGEW_CHAIN || NCH == 1) {
+        MV acc = init;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc = Mfma<T>::run(a[c], b[c], acc);
+        return acc;
+    } else {
+        const MV zero = {T(0), T(0), T(0), T(0)};
+        MV m[NCH];
+        m[0] = Mfma<T>::run(a[0], b[0], init);
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) m[c] = Mfma<T>::run(a[c], b[c], zero);
+#pragma unroll
+        for (int st = 1; st < NCH; st *= 2)
+#pragma unroll
+            for (int c = 0; c + st < NCH; c += 2 * st) m[c] += m[c + st];
+        return m[0];
+    }
+}
 
 // C[r][c] = alpha sum_k A[r][k] B[k][c] (+ beta Add[r][c]) on the matrix cores: one MFMA per chunk of 4 along k,
 // operands read from LDS tiles with compile-time strides. Tiles are 16 or 4 rows / columns (NR, NC) and ZERO outside
@@ -466,11 +504,19 @@ __global__ void __launch_bounds__(64)
             }
             const T mB = okBt ? -pb[d] : cBt;
             request(d, k - PD >= 0 ? k - PD : 0);
-            MV Z = zero4, H = zero4;
+            MV Z, H;
+            {   // Z = P W, H = W' P W
+                T pa_[NQ], wa_[NQ], za_[NQ];
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) Z = Mfma<T>::run(P[t], W[t], Z);  // Z = P W
+                for (int t = 0; t < NQ; ++t) {
+                    pa_[t] = P[t];
+                    wa_[t] = W[t];
+                }
+                Z = mfma_sum<T, NQ>(pa_, wa_, zero4);
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) H = Mfma<T>::run(W[t], Z[t], H);  // H = W' P W
+                for (int t = 0; t < NQ; ++t) za_[t] = Z[t];
+                H = mfma_sum<T, NQ>(wa_, za_, zero4);
+            }
             // S = w_u I + H_uu (identity on the padding), the same in every lane
             Ldl4<T> ldl;
             {
@@ -518,7 +564,16 @@ __global__ void __launch_bounds__(64)
             {  // (p_k, ff_k) = [Acl' ; F] p_{k+1} (+ the tracking cost of step k)
                 MV a0 = zero4;
 #pragma unroll
-                for (int t = 0; t < NQ; ++t) a0 = Mfma<T>::run(E[t], pst[t], a0);
+                for (int t = 0; t < NQ; ++t) a0[t] = T(0);
+                {
+                    T ea_[NQ], pp_[NQ];
+#pragma unroll
+                    for (int t = 0; t < NQ; ++t) {
+                        ea_[t] = E[t];
+                        pp_[t] = pst[t];
+                    }
+                    a0 = mfma_sum<T, NQ>(ea_, pp_, zero4);
+                }
                 ffv[(unsigned)(c16 * N * 4 + k * 4 + pg)] = a0[NQ];  // (column 0 carries the tracking terms, the others zero)
 #pragma unroll
                 for (int t = 0; t < NQ; ++t)
@@ -529,7 +584,16 @@ __global__ void __launch_bounds__(64)
             for (int t = 0; t < 4; ++t) Pk[t] = (t < NQ && scol) ? Pk[t] : T(0);
             MV PT = zero4;
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) PT = Mfma<T>::run(Pk[t], Id[t], PT);  // P_k'
+            for (int t = 0; t < NQ; ++t) PT[t] = T(0);  // P_k' = P_k' I
+            {
+                T pk_[NQ], id_[NQ];
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) {
+                    pk_[t] = Pk[t];
+                    id_[t] = Id[t];
+                }
+                PT = mfma_sum<T, NQ>(pk_, id_, zero4);
+            }
             const MV M2 = Mfma<T>::run(kfull, mB, WA);  // [Acl', -K']
             // factors to the workspace: the sweeps' records (one MFMA operand = 64 consecutive values), K' and the factor
             // of S (read at the candidate row's step)
@@ -810,10 +874,16 @@ __global__ void __launch_bounds__(64)
         }
         auto step = [&](int d, int k, bool again) {
             MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
+            {
+                T ra_[NQ], rb_[NQ], sb_[NQ];
 #pragma unroll
-            for (int kk = 0; kk < NQ; ++kk) {
-                a0 = Mfma<T>::run(rec[d][kk], st[kk], a0);
-                if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + kk], st[kk], a1);
+                for (int kk = 0; kk < NQ; ++kk) {
+                    ra_[kk] = rec[d][kk];
+                    rb_[kk] = rec[d][NA == 2 ? NQ + kk : kk];
+                    sb_[kk] = st[kk];
+                }
+                a0 = mfma_sum<T, NQ>(ra_, sb_, a0);
+                if (NA == 2) a1 = mfma_sum<T, NQ>(rb_, sb_, a1);
             }
             if (tgt && k >= 1 && col0) {
 #pragma unroll
@@ -852,6 +922,10 @@ __global__ void __launch_bounds__(64)
         for (int q = 0; q < NQ; ++q) gT[q] = (gC && r < mk && 4 * q + pg < nx) ? gC[r * nx + 4 * q + pg] : T(0);
         gT[NQ] = (gD && r < mk && pg < nu) ? gD[r * nu + pg] : T(0);
     }
+    // chunks of [C | D] that are zero in every lane cost no product (box constraints touch few states): one bit per chunk
+    unsigned gnz = 0u;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) gnz |= (FUSE && __ballot(gT[q] != T(0)) != 0ull) ? (1u << q) : 0u;
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     const T tol = ka.tol;
@@ -995,20 +1069,26 @@ __global__ void __launch_bounds__(64)
             const unsigned ku = (unsigned)k;
             const T ffd = dpp_mov<0x150 + 4 * sph>(yv[gs]);  // (row_newbcast: the entry held by the lane of phase sph of this row)
             MV a0 = {T(0), T(0), T(0), T(0)}, a1 = {T(0), T(0), T(0), T(0)};
+            {
+                T ra_[NQ + 1], rb_[NQ + 1], zb_[NQ + 1];
 #pragma unroll
-            for (int kk = 0; kk <= NQ; ++kk) {
-                const T b = kk < NQ ? z[kk < NQ ? kk : 0] : ffd;
-                a0 = Mfma<T>::run(rec[d][kk], b, a0);
-                if (NA == 2) a1 = Mfma<T>::run(rec[d][NQ + 1 + kk], b, a1);
+                for (int kk = 0; kk <= NQ; ++kk) {
+                    ra_[kk] = rec[d][kk];
+                    rb_[kk] = rec[d][NA == 2 ? NQ + 1 + kk : kk];
+                    zb_[kk] = kk < NQ ? z[kk < NQ ? kk : 0] : ffd;
+                }
+                a0 = mfma_sum<T, NQ + 1>(ra_, zb_, a0);
+                if (NA == 2) a1 = mfma_sum<T, NQ + 1>(rb_, zb_, a1);
             }
             const T u = STACK ? a0[NQ] : a1[0];
             const bool mine = ph == sph;
             uacc = mine ? u : uacc;
-            if constexpr (FUSE) {
+            if constexpr (FUSE && !(STAGEW_DBG & 1)) {
                 MV hk = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) hk = Mfma<T>::run(gT[q], z[q], hk);
-                hk = Mfma<T>::run(gT[NQ], u, hk);
+                for (int q = 0; q < NQ; ++q)
+                    if (gnz & (1u << q)) hk = Mfma<T>::run(gT[q], z[q], hk);
+                if (gnz & (1u << NQ)) hk = Mfma<T>::run(gT[NQ], u, hk);
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) xm = fmaxf(xm, fabsf(z[q]));
@@ -1019,7 +1099,7 @@ __global__ void __launch_bounds__(64)
                 hs = (c16 & 3) == 2 ? hk[2] : hs;
                 hs = (c16 & 3) == 3 ? hk[3] : hs;
                 hacc = mine ? hs : hacc;
-            } else {
+            } else if constexpr (!FUSE) {
                 const unsigned zr = lo_z + ku * (unsigned)ZL;  // (every column writes the same values)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) ws[zr + q] = z[q];
@@ -1027,7 +1107,7 @@ __global__ void __launch_bounds__(64)
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) z[q] = a0[q];
-            if (again) req(d, k + D < N ? k + D : N - 1);
+            if (again && !(STAGEW_DBG & 2)) req(d, k + D < N ? k + D : N - 1);
         };
         // the end of group gi: every lane's row of ITS step of the group
         auto gend = [&](int gs, int gi) {
@@ -1078,8 +1158,10 @@ __global__ void __launch_bounds__(64)
                 step(4 * gs + 1, gs, kg + 1, P1{}, true);
                 step(4 * gs + 2, gs, kg + 2, P2{}, true);
                 step(4 * gs + 3, gs, kg + 3, P3{}, true);
-                gend(gs, gi);
-                greq(gs, gi + DG < NGall ? gi + DG : NGall - 1);
+                if (!(STAGEW_DBG & 4)) {
+                    gend(gs, gi);
+                    greq(gs, gi + DG < NGall ? gi + DG : NGall - 1);
+                }
             }
             k += D;
         }
@@ -1441,15 +1523,43 @@ __global__ void __launch_bounds__(64)
     // load of the iteration -- the candidate's vector, Q, the cached rows' vectors -- is issued up front (one round trip), Q is
     // read once. Leaves d in cv, z in zq, g_c in cg[]; returns |z|^2.
     constexpr int QF = LOW ? 8 : 4;  // (registers: the default instantiations run three / two wavefronts per SIMD)
+    // Small-batch instantiation (one wavefront per SIMD: what an iteration costs is its round trips): the cached rows' vectors
+    // and the first QF vectors of Q stay in REGISTERS between the iterations (loaded behind the backward sweep / written by the
+    // step that appends them; a leaving row invalidates the vectors from its slot on, which are read again).
+    constexpr int QR_N = LOW ? QF : 1, YR_N = LOW ? R : 1;
+    V4 qreg[QR_N], ycreg[YR_N];
+    int qvalid = 0;  // vectors of Q valid in qreg
+    auto load_ycreg = [&]() {  // (behind a backward sweep) the cached rows' vectors, zero behind their steps
+        if constexpr (LOW) {
+            const V4 zero4v = {T(0), T(0), T(0), T(0)};
+            const int k = lane < N ? lane : N - 1;
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const V4 v = ((const V4 *)(ffv + (int64_t)j * nv4))[k];
+                const int rj = crow[j];
+                ycreg[j] = (lane < N && rj >= 0 && k <= stepof(rj)) ? v : zero4v;
+            }
+        }
+    };
+    V4 zlast = {T(0), T(0), T(0), T(0)};  // z of the latest ortho_small (this lane's four-vector)
     auto ortho_small = [&](const T *yp, int kq, T *zq, T &yy) -> T {
         const V4 zero4v = {T(0), T(0), T(0), T(0)};
         const int k = lane < N ? lane : N - 1;
         const bool kin = lane < N;
         const V4 yv0 = ((const V4 *)yp)[k];
         V4 qv[QF];
+        if constexpr (LOW) {
 #pragma unroll
-        for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
-        // (the cached rows' vectors: with the candidate's in the small-batch instantiation, behind z in groups of four otherwise)
+            for (int u = 0; u < QF; ++u) {
+                if (u < nq && u >= qvalid) qreg[u] = Q4(u)[k];  // (wave-uniform)
+                qv[u] = qreg[u];
+            }
+            qvalid = nq;
+        } else {
+#pragma unroll
+            for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
+        }
+        // (the cached rows' vectors: in registers in the small-batch instantiation, behind z in groups of four otherwise)
         constexpr int RU = LOW ? R : 4;
         V4 yc[RU];
         int kj[RU];
@@ -1462,7 +1572,6 @@ __global__ void __launch_bounds__(64)
                 kj[j] = rj >= 0 ? stepof(rj) : -1;
             }
         };
-        if constexpr (LOW) load_yc(0);
         const V4 yv = (kin && k <= kq) ? yv0 : zero4v;
         T dd[QF];
 #pragma unroll
@@ -1485,15 +1594,24 @@ __global__ void __launch_bounds__(64)
             zz = wave_sum(dot4(zv, zv));
         }
         if (kin) ((V4 *)zq)[k] = zv;
+        zlast = zv;
 #pragma unroll
         for (int u = 0; u < QF; ++u)
             if (lane == 0 && u < nq) cv[u] = dd[u];
-        for (int j0 = 0; j0 < R; j0 += RU) {
-            if constexpr (!LOW) load_yc(j0);
+        if constexpr (LOW) {
 #pragma unroll
-            for (int j = 0; j < RU; ++j) {
-                const T g = wave_sum((kin && k <= kj[j]) ? dot4(yc[j], zv) : T(0));
-                if (lane == 0 && j0 + j < R) cg[j0 + j] = g;
+            for (int j = 0; j < R; ++j) {
+                const T g = wave_sum(dot4(ycreg[j], zv));
+                if (lane == 0) cg[j] = g;
+            }
+        } else {
+            for (int j0 = 0; j0 < R; j0 += RU) {
+                load_yc(j0);
+#pragma unroll
+                for (int j = 0; j < RU; ++j) {
+                    const T g = wave_sum((kin && k <= kj[j]) ? dot4(yc[j], zv) : T(0));
+                    if (lane == 0 && j0 + j < R) cg[j0 + j] = g;
+                }
             }
         }
         lsync();
@@ -1627,6 +1745,7 @@ __global__ void __launch_bounds__(64)
                 cact[lane] = 0;
             }
             wsync();
+            load_ycreg();
         }
         tacc(9);
         for (;;) {
@@ -1655,7 +1774,8 @@ __global__ void __launch_bounds__(64)
                 T *zq = Qs + (int64_t)nq * nv4;
                 T yy;
                 T zz;
-                if (N <= 64 && nq <= QF) {
+                const bool small = N <= 64 && nq <= QF;
+                if (small) {
                     zz = ortho_small(yp, kq, zq, yy);
                 } else {
                     zz = ortho(yp, kq, zq, yy);
@@ -1720,6 +1840,15 @@ __global__ void __launch_bounds__(64)
                         append(Wm, maxq, zq, zz, up, bi);
                     else
                         append(Rl, WLD, zq, zz, up, bi);
+                    if constexpr (LOW) {
+                        if (small && nq < QF && qvalid == nq) {  // (the vector just written to Q's slot nq: z / |z|)
+                            const T izn = T(1) / (T)sqrt((double)zz);
+#pragma unroll
+                            for (int u = 0; u < QF; ++u)
+                                if (u == nq) qreg[u] = zlast * izn;
+                            qvalid = nq + 1;
+                        }
+                    }
                     ++nq;
                     added = true;
                     if (lane == owner(bi)) thr[bi] = INF;  // (the row's owner) active: infinite threshold
@@ -1734,6 +1863,7 @@ __global__ void __launch_bounds__(64)
                     else
                         drop(l, Rl, WLD);
                     --nq;
+                    qvalid = qvalid < l ? qvalid : l;  // (the vectors from slot l on were rotated)
                     // (a cached row that leaves is tracked again, from its bound)
                     if (lane < R && crow[lane < R ? lane : 0] == rowl) {
                         cact[lane] = 0;

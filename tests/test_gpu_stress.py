@@ -70,8 +70,7 @@ def test_stress_campaign_nearly_full_active_sets_of_the_general_kernel(tool, arg
 
 
 # The review's full list (round 4, "next round" item 2): stress_general seeds 1-12 and stress_tight general | wide | narrow seeds 1-9 --
-# nearly fully active problems through all three stage-wise kernels (the wide and the narrow one still keep the explicit inverse W of
-# the active rows' Gram matrix; these families are where that would show) -- every seed unflagged, plans within 1e-7 of the oracle's.
+# nearly fully active problems through all three stage-wise kernels -- every seed unflagged, plans within 1e-7 of the oracle's.
 # One process per family (STRESS_SEEDS: the tool loops over the seeds).
 @pytest.mark.parametrize("tool,args,seeds", [
     ("stress_general.py", (12, 8), range(1, 13)),
@@ -85,46 +84,27 @@ def test_stress_campaign_every_seed_of_the_review_list(tool, args, seeds):
     assert worst <= 1e-7, (tool, args, worst)
 
 
-# Beyond the review's list: TIGHTER rows (STRESS_TIGHT 0.3 / 0.15 / 0.05 instead of 0.5: 60-78 of ~80 variables pinned). Here the wide
-# stage-wise kernel ALONE does report MPCQP_INFEASIBLE / MPCQP_MAX_ITER for a handful of problems per thousand that the oracle -- and an
-# exact backend of the reference (qpmpc/solve_mpc.py:43) -- solves: its active-set operator is the explicit inverse of the active rows'
-# Gram matrix. What the product path delivers is the answer AFTER the host side's re-solve of those items through the other
-# formulations, the general stage-wise kernel (thin QR) last (solve_mpc's setting, retry_unsolved=True; STRESS_RETRY=1): statuses
-# equal to the oracle's everywhere, plans within 1e-7.
-@pytest.mark.parametrize("kind,tight,bound", [("wide", "0.3", 1e-7), ("wide", "0.15", 1e-7), ("narrow", "0.05", 1e-7)])
-def test_stress_campaign_nearly_fully_active_with_the_host_side_re_solve(kind, tight, bound):
+# Beyond the review's list: TIGHTER rows (STRESS_TIGHT 0.3 / 0.15 / 0.05 instead of 0.5: 60-78 of ~80 variables pinned, every variable at
+# 0.05). Until round 5 the wide stage-wise kernel ALONE reported MPCQP_INFEASIBLE / MPCQP_MAX_ITER for a handful of these problems per
+# thousand that the oracle -- and an exact backend of the reference (qpmpc/solve_mpc.py:43) -- solves: its active-set operator was the
+# explicit inverse of the active rows' Gram matrix, and only solve_mpc's host-side re-solve delivered the right answer (a strict xfail
+# stood here). Round 6: the kernel keeps a thin QR factorisation of the whitened active rows (csrc/mpcqp_stagew.hip,
+# oracle/stagewise_qr_np.py) -- every family below runs through the DEFAULT dispatch WITHOUT any re-solve (retry_unsolved=False: what
+# solve_mpc_batch, PreparedSolve, the closed loops and the C ABI deliver), sixteen seeds each, statuses equal to the oracle's, plans
+# within 1e-7.
+@pytest.mark.parametrize("kind,tight", [("wide", "0.5"), ("wide", "0.3"), ("wide", "0.15"), ("wide", "0.05"),
+                                        ("narrow", "0.5"), ("narrow", "0.3"), ("narrow", "0.15"), ("narrow", "0.05")])
+def test_stress_campaign_nearly_fully_active_without_any_re_solve(kind, tight):
     worst, nflag, flagged = _campaign("stress_tight.py", (kind, 8, 8), 0,
-                                      {"STRESS_SEEDS": ",".join(str(sd) for sd in range(1, 17)), "STRESS_TIGHT": tight, "STRESS_RETRY": "1"})
+                                      {"STRESS_SEEDS": ",".join(str(sd) for sd in range(1, 17)), "STRESS_TIGHT": tight, "STRESS_RETRY": "0"})
     assert nflag == 0, "\n".join(flagged)
-    assert worst <= bound, (kind, tight, worst)
-
-
-# Known red, kept in the suite so that it says what is not exact yet (strict: a fix turns it into an error until it is moved up):
-#  * the wide kernel on its own (no re-solve) on the tight family: wrong MPCQP_INFEASIBLE / MPCQP_MAX_ITER verdicts (seeds 1, 5, 11, 14,
-#    16 of STRESS_TIGHT=0.3) -- the thin-QR operator of mpcqp_stageg.hip is not in mpcqp_stagew.hip yet;
-@pytest.mark.xfail(strict=True, reason="wide stage-wise kernel without the host side's re-solve: explicit inverse of the Gram matrix")
-def test_known_red_wide_kernel_alone_on_the_tight_family():
-    worst, nflag, flagged = _campaign("stress_tight.py", ("wide", 8, 8), 0, {"STRESS_SEEDS": "1,5,11", "STRESS_TIGHT": "0.3"})
-    assert nflag == 0, "\n".join(flagged)
-
-
-def test_vertices_of_the_tightest_family_sit_on_their_active_rows():
-    """STRESS_TIGHT=0.05 (every variable pinned): three SOLVED plans of 128 rounds are 1.6e-6 .. 2.1e-6 from the oracle's although the
-    statuses agree. A roll-out in extended precision (no solver involved) says whose rows are off: the ORACLE's, up to 1.5e-8 (its rule
-    accepts 1e-6 (1 + |e|), and on such a vertex that is 2e-6 in the plan); the GPU plans -- the general stage-wise kernel's -- sit 60
-    times closer. The rounds count as red only if the GPU plan's active rows are worse than 1e-9 AND worse
-    than the oracle's (STRESS_RESIDUALS=1)."""
-    worst, nflag, flagged = _campaign("stress_tight.py", ("wide", 8, 8), 0,
-                                      {"STRESS_SEEDS": "5,12,14", "STRESS_TIGHT": "0.05", "STRESS_RETRY": "1", "STRESS_RESIDUALS": "1"})
-    assert nflag == 0, "\n".join(flagged)
-    assert worst <= 1e-5, worst
+    assert worst <= 1e-7, (kind, tight, worst)
 
 
 def test_solve_mpc_delivers_what_an_exact_backend_would_on_known_hard_problems():
-    """The problems of stress_tight's wide family at STRESS_TIGHT=0.3 (seeds 1 and 5) that the wide stage-wise kernel alone gives up on or
-    calls infeasible although the oracle solves them (60-78 of ~80 variables pinned), through the reference's own entry point, solve_mpc
-    (qpmpc/solve_mpc.py:16-44): it re-solves such an item through the other formulations -- an `infeasible` verdict is re-checked too -- and
-    returns the oracle's plan."""
+    """The problems of stress_tight's wide family at STRESS_TIGHT=0.3 (seeds 1 and 5; 60-78 of ~80 variables pinned) on which the wide
+    stage-wise kernel of rounds 2-5 gave up or said `infeasible` although the oracle solves them: the batched entry point on its own
+    (no re-solve) and the reference's own entry point, solve_mpc (qpmpc/solve_mpc.py:16-44), both return the oracle's plan."""
     import numpy as np
     import torch
 
@@ -134,7 +114,7 @@ def test_solve_mpc_delivers_what_an_exact_backend_would_on_known_hard_problems()
     from qpmpc_amd import workloads as W
     from stress_stagewise import random_ltv
 
-    hard = 0
+    checked = 0
     for seed in (1, 5):
         rng = np.random.default_rng(seed)
         for it in range(8):  # (the generator of tools/stress_tight.py, wide family)
@@ -146,13 +126,16 @@ def test_solve_mpc_delivers_what_an_exact_backend_would_on_known_hard_problems()
             torch.cuda.synchronize()
             st = raw.status.cpu().numpy()
             Uo, _, sto, _ = oracle.solve_workload(w)
-            for b in np.flatnonzero((st != 0) & (sto == 0)):
-                hard += 1
-                plan = solve_mpc(W.problem_from_workload(w, int(b)), solver="hip_gi")
-                assert not plan.is_empty, (seed, it, int(b), int(st[b]))
-                U = np.asarray(plan.inputs).reshape(-1)
-                assert np.abs(U - Uo[b]).max() <= 1e-7 * max(1.0, np.abs(Uo[b]).max()), (seed, it, int(b))
-    assert hard >= 2  # (the kernel on its own: the strict xfail above)
+            assert np.array_equal(st == 0, sto == 0), (seed, it, st.tolist(), sto.tolist())
+            if it in (0, 5):  # (one problem per campaign through the single-problem entry point as well)
+                b = int(np.flatnonzero(sto == 0)[0]) if (sto == 0).any() else None
+                if b is not None:
+                    plan = solve_mpc(W.problem_from_workload(w, b), solver="hip_gi")
+                    assert not plan.is_empty, (seed, it, b)
+                    U = np.asarray(plan.inputs).reshape(-1)
+                    assert np.abs(U - Uo[b]).max() <= 1e-7 * max(1.0, np.abs(Uo[b]).max()), (seed, it, b)
+                    checked += 1
+    assert checked >= 2
 
 
 def test_stress_campaign_inconsistent_rows():

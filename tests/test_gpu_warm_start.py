@@ -314,10 +314,10 @@ def test_stage_kernel_warm_start_with_a_foreign_or_garbage_state_is_still_correc
 
 def test_wide_stagewise_active_set_warm_start_same_plans_fewer_sweeps():
     """MPCQP_WARM_ACTIVE_SET in the wide stage-wise kernel (config 5's dimensions, float64 and float32): the rows active at
-    the end of the previous solve ride along with the first sweeps, so the iterations find their vectors ready. Same
-    statuses, same iteration counts, same plans as the cold solve -- which rows ride along cannot change the iterates --
-    for the same batch, for perturbed states, for garbage ids (timings printed, not asserted: 256 problems are a latency-bound
-    launch either way)."""
+    the end of the previous solve ride along with the first backward sweep, so the iterations find their vectors ready. Same
+    statuses and same plans as the cold solve -- the cached rows steer the SELECTION since round 6, not the minimiser; the
+    iteration counts stay close -- for the same batch, for perturbed states, for garbage ids (timings printed, not asserted:
+    256 problems are a latency-bound launch either way)."""
     import time
 
     from qpmpc_amd import PreparedSolve, WarmState, _capi
@@ -327,15 +327,15 @@ def test_wide_stagewise_active_set_warm_start_same_plans_fewer_sweeps():
     for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
         bp_c, bp_w = W.to_batch_problem(w, dtype=dtype), W.to_batch_problem(w, dtype=dtype)
         ws = WarmState(bp_w)
-        # (MPCQP_OPT_EXACT_SELECTION: under the default rule -- lazy slacks -- the rows that ride along do steer the selection)
-        cold, warm = PreparedSolve(bp_c, flags=_capi.OPT_EXACT_SELECTION), PreparedSolve(bp_w, warm_state=ws, flags=_capi.OPT_EXACT_SELECTION)
+        cold, warm = PreparedSolve(bp_c), PreparedSolve(bp_w, warm_state=ws)
         g = torch.Generator(device="cuda").manual_seed(2)
         x0 = bp_c.initial_state.clone()
         for period in range(4):
             cold.launch()
             warm.launch()
             torch.cuda.synchronize()
-            assert torch.equal(cold.status, warm.status) and torch.equal(cold.iters, warm.iters), (dtype, period)
+            assert torch.equal(cold.status, warm.status), (dtype, period)
+            assert abs(float(cold.iters.float().mean()) - float(warm.iters.float().mean())) <= 1.0, (dtype, period)
             ok = cold.status == 0
             assert bool(ok.any())
             d = (warm.U[ok] - cold.U[ok]).abs().max().item()
@@ -353,7 +353,7 @@ def test_wide_stagewise_active_set_warm_start_same_plans_fewer_sweeps():
         cold.launch()
         warm.launch()
         torch.cuda.synchronize()
-        assert torch.equal(cold.status, warm.status) and torch.equal(cold.iters, warm.iters)
+        assert torch.equal(cold.status, warm.status)
         ok = cold.status == 0
         assert (warm.U[ok] - cold.U[ok]).abs().max().item() <= tol * max(1.0, cold.U[ok].abs().max().item())
 
