@@ -483,7 +483,7 @@ def _small_kernel_name(problems: int) -> str:
     import torch
 
     simds = 4 * torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    if 4 * problems > 9 * simds:
+    if problems > 2 * simds:  # (quad_pays, csrc/mpcqp_quad.hip: more than two problems per SIMD)
         carve = "35.6 KB of LDS, one wavefront per SIMD" if (problems + 3) // 4 <= simds else "20 KB of LDS, two wavefronts per SIMD"
         return f"mpcqp_quad_kernel<3> (fused build+solve, FOUR problems per wavefront, one per 16-lane DPP row; {carve})"
     return "mpcqp_pair_kernel<3, 2> (fused build+solve, two problems per wavefront)"

@@ -69,8 +69,9 @@ extern "C" {
                                 kernel, float64 arithmetic, takes what the MFMA stage-wise kernels (nx <= 16, nu <= 4) and
                                 the dense path (n <= 256) do not: qpmpc/solve_mpc.py:42-44 accepts any dimension) */
 #define MPCQP_EDTYPE (-3)    /* dtype not MPCQP_F64 / MPCQP_F32               */
-#define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size; or a float32 launch that is solved in float64
-                                (at most 160 variables) with a batch stride that is neither 0 nor the packed size */
+#define MPCQP_ELAYOUT (-4)   /* step stride is neither 0 nor the block size, or a batch stride smaller than a problem's block
+                                (a float32 launch that is solved in float64 -- at most 160 variables -- takes any larger batch
+                                stride since ABI 11: the conversion packs the operands) */
 #define MPCQP_EWORKSPACE (-5) /* workspace missing or too small (see *_workspace_bytes) */
 #define MPCQP_EUNSUPPORTED (-6) /* option not available for these dimensions / this dtype    */
 

@@ -615,11 +615,12 @@ def _retry_unsolved(plan: "BatchPlan", max_iter, feas_tol, opt_kw) -> None:
     problem = plan.problem
     kw = {k: v for k, v in opt_kw.items() if k not in ("warm_state", "warm_start", "probe", "flags", "order")}
     # (FORCE_CONDENSED: wide systems take the general stage-wise kernel by default, the condensed kernels are their other formulation)
-    # ... and an INFEASIBLE verdict of a stage-wise kernel is confirmed by another formulation before it stands: the narrow and the
-    # wide stage-wise kernel keep the explicit inverse of the active rows' Gram matrix, and on nearly fully active problems (most
-    # variables pinned) its error can turn the signs of the step in the multipliers -- tools/stress_tight.py with STRESS_TIGHT <= 0.3
-    # finds a handful per thousand that the oracle, and every exact backend of the reference, solves. Problems of the
-    # small-problem kernels' size (n <= 16) never go there.
+    # ... and an INFEASIBLE verdict of a stage-wise kernel is confirmed by another formulation before it stands. Since round 6 the wide
+    # stage-wise kernel keeps a thin QR factorisation of the whitened active rows and needs none of this (tools/stress_tight.py at
+    # STRESS_TIGHT 0.5 .. 0.05 without any re-solve: tests/test_gpu_stress.py); the NARROW one (nx <= 4, nu <= 2, 16 < n <= 128) still
+    # keeps the explicit inverse of the active rows' Gram matrix, and when every variable is pinned its error can turn the sign of a
+    # step in the multipliers: one wrong verdict in 384 rounds of that family at STRESS_TIGHT = 0.05. Problems of the small-problem
+    # kernels' size (n <= 16) never go there.
     recheck = problem.nb_variables > 16
     # (second, behind the workgroup kernel, which is quick where it applies: the general stage-wise kernel -- thin QR of the whitened
     # active rows, the formulation that stays accurate when nearly every variable is pinned; float64, nx <= 32, nu <= 8. It is the one
@@ -665,8 +666,11 @@ def _retry_slots_full(plan: "BatchPlan", held: int, max_iter, feas_tol, opt_kw) 
             return
         index = full.nonzero().flatten()
         held = min(2 * held, cap)
-        again = solve_mpc_batch(problem.select(index), return_multipliers=plan.multipliers is not None, max_iter=max_iter,
-                                feas_tol=feas_tol, formulation="stagewise", max_active=held, retry_slots=False, **kw)
+        try:
+            again = solve_mpc_batch(problem.select(index), return_multipliers=plan.multipliers is not None, max_iter=max_iter,
+                                    feas_tol=feas_tol, formulation="stagewise", max_active=held, retry_slots=False, **kw)
+        except BackendError:  # (more slots than the kernel of these dimensions holds -- the general one stops at 1024: the items keep
+            return            # their MPCQP_SLOTS_FULL status, an empty plan, instead of an exception out of a batch call)
         plan.U.index_copy_(0, index, again.U)
         plan.status.index_copy_(0, index, again.status)
         plan.iters.index_copy_(0, index, again.iters)

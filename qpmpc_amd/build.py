@@ -78,7 +78,24 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     return LIB_PATH
 
 
+def one_line_command() -> str:
+    """The single hipcc invocation that builds the library from its sources (INTEGRATION.md section 1 shows exactly this text;
+    tests/test_host_api.py compares the two, so a translation unit added here cannot be forgotten there)."""
+    srcs = [f"qpmpc_amd/csrc/{u}" for u in _UNITS]
+    lines, cur = [], "     "
+    for src in srcs:
+        if len(cur) + len(src) + 1 > 104:
+            lines.append(cur.rstrip() + " \\")
+            cur = "     "
+        cur += " " + src
+    lines.append(cur + " -o libmpcqp_hip.so")
+    return "hipcc " + " ".join(FLAGS) + " -shared -Iinclude -Iqpmpc_amd/csrc \\\n" + "\n".join(lines)
+
+
 if __name__ == "__main__":
     import sys
 
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--print-command" in sys.argv:
+        print(one_line_command())
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

@@ -303,7 +303,9 @@ int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t 
 struct ConvSeg {
     const void *src;
     void *dst;
-    int64_t count;
+    int64_t count;       // elements written (densely packed)
+    int64_t row = 0;     // > 0: the source is `count / row` runs of `row` elements, `src_stride` elements apart (a padded batch stride)
+    int64_t src_stride = 0;
 };
 struct ConvPlan {
     ConvSeg seg[10];
@@ -317,6 +319,13 @@ __global__ void __launch_bounds__(256) mpcqp_convert_kernel(const ConvPlan cp)
     if (cp.to_double) {
         const float *a = (const float *)sg.src;
         double *b = (double *)sg.dst;
+        if (sg.row > 0) {  // (rows of a padded source packed densely)
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sg.count; i += stride) {
+                const int64_t r = i / sg.row;
+                b[i] = (double)a[r * sg.src_stride + (i - r * sg.row)];
+            }
+            return;
+        }
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < sg.count; i += stride) b[i] = (double)a[i];
     } else {
         const double *a = (const double *)sg.src;
@@ -680,14 +689,22 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         char *w = (char *)workspace;
         int64_t off = 0;
         for (int i = 0; i < 8; ++i) {
-            const int64_t cnt = operand_elems(*src[i], block[i], (int)N, batch, per_step[i]);
-            if (!cnt) continue;
-            // (the copies keep the source's layout and mpcqp_workspace_bytes prices them densely packed: a padded batch stride
-            // is refused by name instead of as a workspace that looks too small)
+            if (!operand_elems(*src[i], block[i], (int)N, batch, per_step[i])) continue;
+            // (mpcqp_workspace_bytes prices the copies densely packed. A source with a PADDED batch stride is packed on the way --
+            // round 6; until then it was refused, MPCQP_ELAYOUT --; a padded step stride still is: no caller of this library makes one)
             const int64_t dense = (per_step[i] && src[i]->step_stride) ? N * block[i] : block[i];
-            if (src[i]->batch_stride != 0 && src[i]->batch_stride != dense) return MPCQP_ELAYOUT;
+            if (per_step[i] && src[i]->step_stride && src[i]->step_stride != block[i]) return MPCQP_ELAYOUT;
+            const bool padded = src[i]->batch_stride != 0 && src[i]->batch_stride != dense;
+            if (src[i]->batch_stride != 0 && src[i]->batch_stride < dense) return MPCQP_ELAYOUT;
+            const int64_t cnt = src[i]->batch_stride ? batch * dense : dense;
             if (w) dst[i]->ptr = w + off;
-            in.seg[in.nseg++] = ConvSeg{src[i]->ptr, w ? w + off : nullptr, cnt};
+            if (padded) dst[i]->batch_stride = dense;
+            ConvSeg sg{src[i]->ptr, w ? w + off : nullptr, cnt};
+            if (padded) {
+                sg.row = dense;
+                sg.src_stride = src[i]->batch_stride;
+            }
+            in.seg[in.nseg++] = sg;
             off += al256(cnt * 8);
         }
         const int64_t offU = off;
@@ -916,8 +933,8 @@ int mpcqp_solve_model_bounds_batch(const MpcqpDims *dims, const void *model, con
         return MPCQP_EUNSUPPORTED;
     const bool small = pair_eligible(ka, MODE_MODEL, dims->dtype);
     if ((ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) &&
-        ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_TWO_PER_WAVE)) || !small))
-        return MPCQP_EUNSUPPORTED;
+        ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_TWO_PER_WAVE | MPCQP_OPT_SEED_VIOLATED)) || !small))
+        return MPCQP_EUNSUPPORTED;  // (the four-per-wavefront kernel has no seed steps: asked for by name, it is refused by name)
     hipStream_t st = (hipStream_t)stream;
     const bool own_e = e && e->ptr;  // per-problem bounds: the small-problem kernels' model mode only
     if (own_e) {

@@ -13,6 +13,15 @@ enum { MODE_FUSED = 0, MODE_CONDENSE = 1, MODE_SOLVE = 2, MODE_MODEL = 3 };
 
 constexpr size_t kLdsBytesPerCU = 160 * 1024;  // gfx950: 160 KiB per CU
 
+// SIMDs of the device that is current for this call (4 per compute unit). Asked per call: the library keeps no state between
+// calls (include/mpcqp.h), and a process may drive several devices. 0 when the runtime cannot tell.
+inline int device_simds_now()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return 4 * cus;
+}
+
 // Everything a kernel needs, passed by value (kernarg segment, scalar loads).
 struct KernelArgs {
     int nx, nu, N, mk, n, m, flags, max_iter;

@@ -1552,11 +1552,7 @@ bool pair_eligible(const KernelArgs &ka, int mode, int dtype)
 // against 26.5; 3900: 26.7 against 27.5; 4000: 27.0 against 28.0; 4096: 26.4 against 25.6)
 static bool one_round(int64_t waves)
 {
-    static const int simds = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return 4 * cus;
-    }();
+    const int simds = device_simds_now();
     return waves <= 2 * (int64_t)simds && waves > 2 * (int64_t)simds - 8;
 }
 

@@ -941,22 +941,13 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
 }
 
 // ------------------------------------------------------------ host side
-static int device_simds()
-{
-    static const int simds = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return 4 * cus;
-    }();
-    return simds;
-}
 // true when four problems per wavefront beat two (tools/ab_quad.py, tools/ab_quad_c4.py on an MI355X, 1024 SIMDs): from MORE THAN TWO
 // problems per SIMD up -- up to there a lone two-problem wavefront per SIMD is shorter (2048 problems: 18.2 against 19.3 us), one
 // problem more and some SIMD runs two of them (2304: 23.5 against 19.1 us; the rule read 2.25 per SIMD until that was measured). One
 // round (up to four problems per SIMD) runs the roomy carve: config 2 at 4096: 22.4 against 24.8 us; anything larger the slim one,
 // two wavefronts per SIMD: config 2 at 8192 / 16,384: 37.8 / 65.0 against 47.3 / 85.6 us; config 4 at 8192 / 16,384 / 65,536:
 // 45.5 / 74.0 / 231 against 56.9 / 90.9 / 305 us.
-static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds(); }
+static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_now(); }
 
 bool quad_applies(const KernelArgs &ka)
 {
@@ -985,7 +976,7 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
                            ka, batch);
     };
     // one round (at most one wavefront per SIMD): the roomy carve; several rounds: the slim one, two wavefronts per SIMD
-    const bool slim = waves > device_simds();
+    const bool slim = waves > device_simds_now();
     if (ka.order) {
         if (slim)
             go(mpcqp_quad_kernel<NX, true, 1, true>, Carve<true>::PER);
@@ -1022,7 +1013,7 @@ int launch_quad_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
                            (const double *)nullptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr, (const double *)ka.goal.ptr,
                            (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status, ka.iters, ka, batch);
     };
-    const bool slim = waves > device_simds();
+    const bool slim = waves > device_simds_now();
     if (ka.order) {
         if (slim)
             go(mpcqp_quad_kernel<3, true, 1, true, true>, Carve<true>::PER);

@@ -986,8 +986,8 @@ int launch_stageg(const KernelArgs &ka, int maxq, int64_t batch, void *ws, hipSt
     const Ws wl = make_ws(ka.nx, ka.nu, ka.N, ka.mk, maxq);
     // the sweeps' LDS ring: two halves of RG steps each (the recursion's matrices live in the same 64 KB before the first sweep)
     constexpr int ring_doubles = 8192;
-    static const bool attr_ok = hipFuncSetAttribute((const void *)mpcqp_stageg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    ring_doubles * (int)sizeof(double)) == hipSuccess;
+    const bool attr_ok = hipFuncSetAttribute((const void *)mpcqp_stageg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             ring_doubles * (int)sizeof(double)) == hipSuccess;  // (per call: no state between calls)
     if (!attr_ok || maxq > 4 * BS) return MPCQP_EUNSUPPORTED;  // (a thread owns at most four rows of the active rows' factor)
     hipLaunchKernelGGL(mpcqp_stageg_kernel, dim3((unsigned)batch), dim3(BS), ring_doubles * sizeof(double), st, ka, wl, (double *)ws,
                        ring_doubles);

@@ -62,6 +62,9 @@ namespace mpcqp {
 #ifndef STAGEW_RLOW
 #define STAGEW_RLOW 12
 #endif
+#ifndef STAGEW_LDS_PAD
+#define STAGEW_LDS_PAD 0
+#endif
 #ifndef STAGEW_RF
 #define STAGEW_RF 7 /* (round 4, with the lazy slacks: 7 -> 1.183 ms, 6 -> 1.198, 8 -> 1.215, 10 -> 1.238, 16 -> 1.309 per 8192 config-5 problems) */
 #endif
@@ -1988,15 +1991,8 @@ size_t stagew_ws_elems(const KernelArgs &ka, int maxq, int dtype)
 // SIMDs of the current device (the small-batch instantiation serves launches of at most one wavefront per SIMD)
 static int64_t device_simds()
 {
-    static int64_t cached = 0;
-    if (cached == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            cached = 4 * (int64_t)cus;
-        else
-            cached = 1024;
-    }
-    return cached;
+    const int s = device_simds_now();
+    return s > 0 ? s : 1024;
 }
 
 template <typename T, int NXC, bool FUSE, bool LOW = false>
@@ -2014,12 +2010,8 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (4 * sizeof(T) + 2 * sizeof(int)) + (size_t)RR * sizeof(int) + 16 +
                        (size_t)32 * 33 * sizeof(T) + (size_t)RR * (4 * sizeof(T) + sizeof(int));
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
-    // (developer knob: MPCQP_STAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
-    static const size_t lds_pad = [] {
-        const char *e = getenv("MPCQP_STAGEW_LDS_PAD");
-        return e ? (size_t)atol(e) : (size_t)0;
-    }();
-    const size_t lds_req = lds + lds_pad;
+    // (developer knob: -DSTAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
+    const size_t lds_req = lds + (size_t)STAGEW_LDS_PAD;
     if (lds_req > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
         if (e != hipSuccess) return (int)e;

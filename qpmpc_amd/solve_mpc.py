@@ -40,14 +40,15 @@ def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) 
             to a dual active-set method -- qpsolvers' quadprog wrapper ignores it the same way, with a
             warning) and ``verbose``. Any other keyword raises ``TypeError``: nothing is dropped silently.
 
-    Supported sizes of the HIP path: any. Problems that fit one CU's LDS take the fused on-chip kernels; beyond
-    that the stage-wise kernels serve systems with ``nx <= 16``, ``nu <= 4`` for any horizon (n = N*nu of 1024 or
-    4096 included; a problem that wants more rows active at once than the kernel's slots hold is solved again
-    with more slots), and wider systems go to the dense HBM-resident path up to ``n = N*nu <= 256`` (a slow
-    fallback: DESIGN.md 3.3) and beyond that to the general stage-wise kernel (``nx <= 32``, ``nu <= 8``, any horizon;
-    float64 arithmetic, slower still: one workgroup per problem, everything in HBM). Only ``nx > 32`` or ``nu > 8``
-    together with ``n > 256`` has no kernel (``MPCQP_ETOOLARGE`` -> ``BackendError`` naming the envelope).
-    float32 problems with at most 160 variables are solved in float64 on converted operands (mpcqp_capi.hip).
+    Supported sizes of the HIP path (the dispatch table is DESIGN.md 3.0): problems of at most 16 variables and 32 rows take the
+    fused on-chip kernels (four or two problems per wavefront); beyond that the stage-wise kernels, which never form the
+    condensed QP, serve every horizon -- the narrow one (``nx <= 4``, ``nu <= 2``, up to 128 variables), the wide one
+    (``nx <= 16``, ``nu <= 4``; thin-QR active-set operator, float32 and float64) and the general one (``nx <= 32``,
+    ``nu <= 8``, float64, one workgroup per problem: slower). ``nu > 8`` is served by the dense HBM-resident path up to
+    ``n = N*nu <= 256``; only ``nx > 32`` or ``nu > 8`` together with ``n > 256`` has no kernel (``MPCQP_ETOOLARGE`` ->
+    ``BackendError`` naming the envelope). A problem that wants more rows active at once than a stage-wise kernel's slots
+    hold is solved again with more slots. float32 problems with at most 160 variables are solved in float64 on converted
+    operands (mpcqp_capi.hip).
 
     Returns:
         A ``Plan``; empty (``is_empty``) when no solution was found.
@@ -93,4 +94,4 @@ def solve_mpc(problem: MPCProblem, solver: str, sparse: bool = False, **kwargs) 
     return Plan(problem, qpsol)
 
 
-__all__ = ["solve_mpc", "available_solvers", "np"]
+__all__ = ["solve_mpc", "available_solvers"]

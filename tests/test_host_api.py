@@ -285,3 +285,17 @@ def test_hand_written_dpp_instructions_keep_their_wait_states():
         src = os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", unit)
         bad, ndpp, nasm = chk.check(chk.device_asm(src))
         assert nasm > 1000 and not bad, (unit, bad[:3])
+
+
+def test_integration_md_shows_the_build_command_of_the_build_script():
+    """INTEGRATION.md section 1 is the one-line hipcc command a maintainer copies. It once missed a translation unit (a library
+    that does not load). It is generated -- `python -m qpmpc_amd.build --print-command` -- and compared here."""
+    import os
+
+    from qpmpc_amd import build
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert build.one_line_command() in text
+    for unit in build._UNITS:
+        assert os.path.exists(os.path.join(root, "qpmpc_amd", "csrc", unit))
