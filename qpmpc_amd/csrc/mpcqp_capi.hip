@@ -74,7 +74,7 @@ int fill_opts(KernelArgs &ka, const MpcqpSolveOpts *o, int dtype, bool order_ok 
     ka.max_iter = (o && o->max_iter > 0) ? o->max_iter : 10 * (ka.n + ka.m) + 10;
     ka.tol = (o && o->feas_tol > 0.0) ? o->feas_tol : (dtype == MPCQP_F64 ? 1e-12 : 1e-5);
     if (!o) return 0;
-    ka.opt_flags = o->flags;
+    ka.opt_flags = o->flags & ~kOptSecondOpinion;
     ka.probe = o->probe;
     ka.warm_state = o->warm_state;
     ka.warm_start = o->warm_state ? o->warm_start : 0;
@@ -160,6 +160,14 @@ bool use_stage_long(const KernelArgs &ka, int dtype)
     (void)override_bits;
     (void)dtype;
     return false;
+}
+// the narrow stage-wise kernel's unsolved verdicts get a second opinion from the wide one (kOptSecondOpinion) in one-shot launches of
+// mpcqp_build_solve_batch: not when the launch keeps state in its workspace or its warm-state record for a later one
+bool second_opinion_applies(const KernelArgs &ka, int dtype, bool size_query = false)
+{
+    // (a size query carries neither outputs nor options: it prices the launch that takes the second opinion)
+    return stagew_supported(ka, dtype) && (size_query || ka.status) && !ka.warm_state &&
+           !(ka.opt_flags & (MPCQP_OPT_KEEP_FACTOR | MPCQP_OPT_REUSE_FACTOR | MPCQP_OPT_PIPELINE_FACTOR));
 }
 int stagew_auto_maxq(const KernelArgs &ka)
 {
@@ -457,6 +465,10 @@ int mpcqp_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t for_solv
         if (for_solve && use_stage_auto(ka, dims->dtype)) {
             const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
             if (sw > v) v = sw;
+            if (second_opinion_applies(ka, dims->dtype, true)) {  // (the wide kernel behind the narrow one, in the same buffer)
+                const size_t s2 = stagew_ws_elems(ka, stagew_auto_maxq(ka), dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+                if (s2 > v) v = s2;
+            }
         }
         if (for_solve && use_stage_long(ka, dims->dtype)) {
             const size_t sw = stage_ws_doubles(ka, stage_default_maxq(ka)) * sizeof(double) * (size_t)batch;
@@ -742,9 +754,20 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     if (ka.warm_state && ka.warm_state_bytes < (size_t)batch * warm_bytes_per_problem(ka, dims->dtype)) return MPCQP_EWORKSPACE;
     if (use_stage_auto(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);
-        const size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+        size_t need = stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch;
+        const bool second = second_opinion_applies(ka, dims->dtype);
+        const int maxq2 = stagew_auto_maxq(ka);
+        if (second) {
+            const size_t need2 = stagew_ws_elems(ka, maxq2, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+            need = need2 > need ? need2 : need;
+        }
         if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
-        return launch_stage(ka, maxq, batch, workspace, st);
+        if ((rc = launch_stage(ka, maxq, batch, workspace, st)) || !second) return rc;
+        // the second opinion (mpcqp_internal.h, kOptSecondOpinion): same stream, same workspace (the first launch is done with it)
+        KernelArgs kb = ka;
+        kb.opt_flags |= kOptSecondOpinion;
+        kb.probe = nullptr;
+        return launch_stagew(kb, dims->dtype, maxq2, batch, workspace, st);
     }
     if (use_stage_long(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);

@@ -22,6 +22,13 @@ inline int device_simds_now()
     return 4 * cus;
 }
 
+// INTERNAL bit of KernelArgs.opt_flags (never taken from MpcqpSolveOpts.flags: fill_opts clears it): the wide stage-wise kernel runs as
+// the SECOND OPINION behind the narrow one -- a wavefront whose problem the first launch settled (solved, not positive definite,
+// slots full) exits at once, the others (MPCQP_MAX_ITER, MPCQP_INFEASIBLE) are solved again from scratch. Round 6: the narrow kernel
+// still keeps the explicit inverse of the active rows' Gram matrix and, when every variable is pinned, gives a wrong verdict on one
+// problem in some hundreds; the wide kernel's thin-QR operator does not, for the price of a launch of wavefronts that exit.
+constexpr int kOptSecondOpinion = 1 << 30;
+
 // Everything a kernel needs, passed by value (kernarg segment, scalar loads).
 struct KernelArgs {
     int nx, nu, N, mk, n, m, flags, max_iter;

@@ -403,6 +403,10 @@ __global__ void __launch_bounds__(64)
     const bool stageQ = (ka.flags & MPCQP_Q_STAGE) && gtgt, termQ = (ka.flags & MPCQP_Q_TERMINAL) && ggoal;
     const T wu = (T)ka.wu, wx = stageP ? (T)ka.wx : T(0), wt = termP ? (T)ka.wt : T(0);
 
+    if (ka.opt_flags & kOptSecondOpinion) {  // (behind the narrow kernel: only what it left unsolved, mpcqp_internal.h)
+        const int st0 = ka.status[prob];
+        if (st0 != MPCQP_MAX_ITER && st0 != MPCQP_INFEASIBLE) return;
+    }
     long long *stamp = ka.probe ? (long long *)ka.probe + prob * 16 : nullptr;
     auto tick = [&](int slot) {
         if (stamp && lane == 0) stamp[slot] = (long long)__builtin_readcyclecounter();

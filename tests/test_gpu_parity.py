@@ -340,6 +340,27 @@ def test_float32_path_tolerance():
     assert (np.abs(U[ok] - Uo[ok]) / scale).max() <= 1e-3
 
 
+def test_float32_launch_with_a_padded_batch_stride_is_packed_by_the_conversion():
+    """A float32 launch of at most 160 variables is solved in float64 on converted copies of its operands. An operand whose
+    batch stride is larger than its block (a view into a wider buffer) was refused (MPCQP_ELAYOUT) until ABI 10; the conversion
+    packs it now: same plans as the contiguous batch."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd.workloads import humanoid_batch, to_batch_problem
+
+    w = humanoid_batch(64)
+    dense = to_batch_problem(w, dtype=torch.float32)
+    ref = solve_mpc_batch(dense)
+    padded = to_batch_problem(w, dtype=torch.float32)
+    wide = torch.zeros(64, 8, dtype=torch.float32, device="cuda")
+    wide[:, :3] = dense.initial_state
+    padded.initial_state = wide[:, :3]  # batch stride 8, block 3
+    assert padded.initial_state.stride(0) == 8
+    plan = solve_mpc_batch(padded)
+    torch.cuda.synchronize()
+    assert torch.equal(plan.status, ref.status)
+    assert torch.equal(plan.U, ref.U)
+
+
 def test_c_abi_argument_errors():
     from qpmpc_amd import _capi
 
