@@ -461,9 +461,9 @@ def _traffic_from_profiles(config: int):
     """(HBM bytes per launch, source) from the rocprofv3 PMC passes stored under profiles/ for this round's kernels
     (separate --pmc runs of this same command: tools/collect_profiles.sh; FETCH_SIZE doubled as the microarchitecture
     guide prescribes for gfx950, WRITE_SIZE as reported). Newest round first; (None, None) when there is none."""
-    names = [f"r0{r}_pmc_traffic_config{config}.json" for r in (5, 4, 3, 2)]
+    names = [f"r0{r}_pmc_traffic_config{config}.json" for r in (6, 5, 4, 3, 2)]
     if config == 2:
-        names = ["r05_pmc_traffic.json"] + names + ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]
+        names = ["r06_pmc_traffic.json", "r05_pmc_traffic.json"] + names + ["r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"]
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):

@@ -317,6 +317,59 @@ template <typename T> __device__ __forceinline__ T ldl_entry(const Ldl4<T> &f, c
     for (int j = 0; j < 6; ++j) v = i == 4 + j ? f.l[j] : v;
     return v;
 }
+// The sums over the wavefront of SIXTEEN per-lane values at once: lane l ends with the total of value l % 16. A wave_sum per value is
+// a chain of eight dependent cross-lane steps (~200 cycles for a lone wavefront) and an iteration of the wide kernel's active-set loop
+// needs ~20 of them; here every exchange step HALVES the number of live values -- a lane keeps the half whose index has its own bit
+// and hands the other half to its partner -- so sixteen sums cost 15 exchanges + 6 row / half steps instead of 128.
+template <int MASK> __device__ __forceinline__ float lane_xor(float v)
+{
+    if constexpr (MASK == 1) return dpp_mov<0xb1>(v);
+    else if constexpr (MASK == 2) return dpp_mov<0x4e>(v);
+    else if constexpr (MASK == 32) return __shfl_xor(v, 32);
+    else return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (MASK << 10) | 0x1f));  // (bit-mask mode: xor inside 32 lanes)
+}
+template <int MASK> __device__ __forceinline__ double lane_xor(double v)
+{
+    if constexpr (MASK == 1) return dpp_mov<0xb1>(v);
+    else if constexpr (MASK == 2) return dpp_mov<0x4e>(v);
+    else if constexpr (MASK == 32) return __shfl_xor(v, 32);
+    else {
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (MASK << 10) | 0x1f);
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (MASK << 10) | 0x1f);
+        return __hiloint2double(hi, lo);
+    }
+}
+// K = 4, 8 or 16 values: lane l ends with the total of value l % K
+template <typename T, int K> __device__ __forceinline__ T multi_sum(const T (&p)[K], int lane)
+{
+    static_assert(K == 4 || K == 8 || K == 16, "multi_sum: 4, 8 or 16 values");
+    T a[K / 2];
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < K / 2; ++i) a[i] = (b0 ? p[2 * i + 1] : p[2 * i]) + lane_xor<1>(b0 ? p[2 * i] : p[2 * i + 1]);
+    T b[K / 4];
+#pragma unroll
+    for (int i = 0; i < K / 4; ++i) b[i] = (b1 ? a[2 * i + 1] : a[2 * i]) + lane_xor<2>(b1 ? a[2 * i] : a[2 * i + 1]);
+    T d;
+    if constexpr (K == 4) {
+        d = b[0];
+        d += lane_xor<4>(d);
+        d += lane_xor<8>(d);
+    } else {
+        T c[K / 8];
+#pragma unroll
+        for (int i = 0; i < K / 8; ++i) c[i] = (b2 ? b[2 * i + 1] : b[2 * i]) + lane_xor<4>(b2 ? b[2 * i] : b[2 * i + 1]);
+        if constexpr (K == 8) {
+            d = c[0];
+            d += lane_xor<8>(d);
+        } else {
+            d = (b3 ? c[1] : c[0]) + lane_xor<8>(b3 ? c[0] : c[1]);
+        }
+    }
+    d += lane_xor<16>(d);
+    d += lane_xor<32>(d);
+    return d;
+}
 // lane j's value as a wave-uniform scalar (v_readlane)
 __device__ __forceinline__ float rl(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
 __device__ __forceinline__ double rl(double v, int j)
@@ -581,7 +634,7 @@ __global__ void __launch_bounds__(64)
                     }
                     a0 = mfma_sum<T, NQ>(ea_, pp_, zero4);
                 }
-                ffv[(unsigned)(c16 * N * 4 + k * 4 + pg)] = a0[NQ];  // (column 0 carries the tracking terms, the others zero)
+                ws[col0 ? (unsigned)wl.ff + (unsigned)(k * 4 + pg) : (unsigned)wl.junk + (unsigned)lane] = a0[NQ];  // (column 0 carries the tracking terms; the other lanes aim at their junk cell: no branch, no traffic)
 #pragma unroll
                 for (int t = 0; t < NQ; ++t)
                     pst[t] = a0[t] - ((tgtq && k >= 1 && col0 && 4 * t + pg < nx) ? wxq * tgk[t] : T(0));
@@ -902,7 +955,7 @@ __global__ void __launch_bounds__(64)
                 a0 = start;
                 ffk = ffstart;
             }
-            ffv[ffo + (unsigned)(k * 4)] = ffk;  // (unconditional: a store behind a branch shortens the request ring, see the forward sweep)
+            ws[colr ? (unsigned)wl.ff + ffo + (unsigned)(k * 4) : (unsigned)wl.junk + (unsigned)lane] = ffk;  // (no branch: a store behind one shortens the request ring, see the forward sweep; the lanes of unused columns aim at their junk cell)
             st = a0;
             if (again) req(d, k - D >= 0 ? k - D : 0);
         };
@@ -1059,7 +1112,7 @@ __global__ void __launch_bounds__(64)
             const int st0 = 4 * gi + ph;
             const unsigned stp = (unsigned)(st0 < N ? st0 : N - 1);
             yv[gs] = ws[yoff + 4u * stp + (unsigned)pg];
-            if constexpr (FUSE) {
+            if constexpr (FUSE && !(STAGEW_DBG & 16)) {
                 ev[gs] = ge[valid ? stp * sE32 + r : 0u];
                 if (mode == FW_EVAL) thv[gs] = ws[valid ? (unsigned)wl.thr + stp * mku + r : junk];
             }
@@ -1121,7 +1174,7 @@ __global__ void __launch_bounds__(64)
             const int st0 = 4 * gi + ph;
             const bool liveu = st0 < N;
             const unsigned stp = (unsigned)(liveu ? st0 : N - 1);
-            ws[liveu ? (unsigned)wl.ust + 4u * stp + (unsigned)pg : junk] = uacc;  // (the point itself; the columns of a phase write the same value)
+            if (!(STAGEW_DBG & 8)) ws[liveu ? (unsigned)wl.ust + 4u * stp + (unsigned)pg : junk] = uacc;  // (the point itself; the columns of a phase write the same value)
             if constexpr (FUSE) {
                 const bool live = valid && liveu;
                 const unsigned irow = stp * mku + r;
@@ -1142,7 +1195,9 @@ __global__ void __launch_bounds__(64)
                 selb = take ? sc : selb;
                 selv = take ? v : selv;
                 seli = take ? (int)irow : seli;
-                if constexpr (mode == FW_INIT) {
+                if constexpr (STAGEW_DBG & 8) {
+                    selv += th0 * T(1e-30);
+                } else if constexpr (mode == FW_INIT) {
                     ws[live ? (unsigned)wl.thr + irow : junk] = th0;
                     ws[live ? (unsigned)wl.invn + irow : junk] = myinvn;
                     ws[live ? (unsigned)wl.s + irow : junk] = v;
@@ -1428,6 +1483,7 @@ __global__ void __launch_bounds__(64)
     T *crs = (T *)(Rl + WL * WLD), *cth = crs + R, *civ = cth + R;  // the cached rows' slacks, thresholds, selection metric
     T *cg = civ + R;                                                // ... what their slacks gain per unit step (y_c . z)
     int *cact = (int *)(cg + R);                                    // ... and whether they are active now
+    T *Wl_end = (T *)(((uintptr_t)(cact + R) + 15) & ~(uintptr_t)15);  // (small-batch instantiation: copies of vectors behind this)
     T *vpt = ws + wl.vpt, *Qs = ws + wl.Q, *Wm = ws + wl.W;
     for (int a = lane; a < maxq; a += 64) colp[a] = a;
     if (lane < R) crow[lane] = -1;
@@ -1436,6 +1492,15 @@ __global__ void __launch_bounds__(64)
     lsync();
     fsweep(FwInit{}, gx0, (unsigned)wl.ff, T(0));
     tick(4);
+    if constexpr (STAGEW_DBG != 0) {  // (timing experiments: the state is garbage from here on -- stop)
+        if (lane == 0) {
+            if (stamp)
+                for (int i2 = 5; i2 < 8; ++i2) stamp[i2] = stamp[4];
+            if (ka.status) ka.status[prob] = MPCQP_MAX_ITER;
+            if (ka.iters) ka.iters[prob] = 0;
+        }
+        return;
+    }
     tick(5);
 
     int nq = 0, iters = 0, status = MPCQP_MAX_ITER;
@@ -1529,97 +1594,140 @@ __global__ void __launch_bounds__(64)
     // The same for horizons of at most 64 steps with at most QF active rows (a lane holds ONE four-vector of every vector): every
     // load of the iteration -- the candidate's vector, Q, the cached rows' vectors -- is issued up front (one round trip), Q is
     // read once. Leaves d in cv, z in zq, g_c in cg[]; returns |z|^2.
-    constexpr int QF = LOW ? 8 : 4;  // (registers: the default instantiations run three / two wavefronts per SIMD)
-    // Small-batch instantiation (one wavefront per SIMD: what an iteration costs is its round trips): the cached rows' vectors
-    // and the first QF vectors of Q stay in REGISTERS between the iterations (loaded behind the backward sweep / written by the
-    // step that appends them; a leaving row invalidates the vectors from its slot on, which are read again).
-    constexpr int QR_N = LOW ? QF : 1, YR_N = LOW ? R : 1;
-    V4 qreg[QR_N], ycreg[YR_N];
-    int qvalid = 0;  // vectors of Q valid in qreg
-    auto load_ycreg = [&]() {  // (behind a backward sweep) the cached rows' vectors, zero behind their steps
-        if constexpr (LOW) {
-            const V4 zero4v = {T(0), T(0), T(0), T(0)};
-            const int k = lane < N ? lane : N - 1;
+    // (registers: the default instantiations run three / two wavefronts per SIMD, and float64 four-vectors are eight registers)
+    constexpr int QF = (LOW && sizeof(T) == 4) ? 8 : 4;
+    // Small-batch instantiation (one wavefront per SIMD: what an iteration costs is its round trips): copies of the cached rows'
+    // vectors and of the first QF vectors of Q in LDS (written behind the backward sweep / by the step that appends a vector; a
+    // leaving row invalidates the copies from its slot on, which are read again from the workspace).
+    constexpr bool VLDS = LOW;
+    T *yl = Wl_end, *ql = yl + (VLDS ? R * 256 : 0);  // (horizons of at most 64 steps: a vector is 256 entries)
+    int qvalid = 0;  // vectors of Q valid in ql
+    auto stage_cached = [&]() {  // (behind a backward sweep) the cached rows' vectors into LDS, zero behind their steps
+        if constexpr (VLDS) {
+            if (N <= 64) {
+                const V4 zero4v = {T(0), T(0), T(0), T(0)};
+                const int k = lane < N ? lane : N - 1;
+                V4 v[R];
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const V4 v = ((const V4 *)(ffv + (int64_t)j * nv4))[k];
-                const int rj = crow[j];
-                ycreg[j] = (lane < N && rj >= 0 && k <= stepof(rj)) ? v : zero4v;
+                for (int j = 0; j < R; ++j) v[j] = ((const V4 *)(ffv + (int64_t)j * nv4))[k];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int rj = crow[j];
+                    ((V4 *)(yl + j * 256))[lane] = (lane < N && rj >= 0 && k <= stepof(rj)) ? v[j] : zero4v;
+                }
             }
         }
     };
     V4 zlast = {T(0), T(0), T(0), T(0)};  // z of the latest ortho_small (this lane's four-vector)
-    auto ortho_small = [&](const T *yp, int kq, T *zq, T &yy) -> T {
+    V4 vreg = {T(0), T(0), T(0), T(0)};   // the point v (this lane's four-vector) while the loop stays on the small path
+    bool vreg_ok = false;
+    // The whole vector work of an iteration for horizons of at most 64 steps with at most QF active rows (a lane holds ONE four-vector
+    // of every vector): Q is read once, and the ~20 sums over the wavefront -- d = Q' y, |y|^2, |z|^2, the cached rows' y_c . z -- are
+    // a few multi-reductions (multi_sum). Leaves d in cv, z in zq and zlast, g_c in cg[]; returns |z|^2.
+    constexpr int K1 = QF == 8 ? 16 : 8;            // first batch: d_0 .. d_{QF-1}, |y|^2
+    constexpr int RB = (LOW && sizeof(T) == 4) ? 16 : 4;  // the cached rows' dots per batch (|z|^2 rides in the first one's last cell)
+    auto ortho_small = [&](const T *yp, int hit, int kq, T *zq, T &yy) -> T {
         const V4 zero4v = {T(0), T(0), T(0), T(0)};
         const int k = lane < N ? lane : N - 1;
         const bool kin = lane < N;
-        const V4 yv0 = ((const V4 *)yp)[k];
-        V4 qv[QF];
-        if constexpr (LOW) {
-#pragma unroll
-            for (int u = 0; u < QF; ++u) {
-                if (u < nq && u >= qvalid) qreg[u] = Q4(u)[k];  // (wave-uniform)
-                qv[u] = qreg[u];
-            }
-            qvalid = nq;
-        } else {
-#pragma unroll
-            for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
-        }
-        // (the cached rows' vectors: in registers in the small-batch instantiation, behind z in groups of four otherwise)
-        constexpr int RU = LOW ? R : 4;
-        V4 yc[RU];
-        int kj[RU];
-        auto load_yc = [&](int j0) {
-#pragma unroll
-            for (int j = 0; j < RU; ++j) {
-                const int jj = j0 + j < R ? j0 + j : R - 1;
-                yc[j] = ((const V4 *)(ffv + (int64_t)jj * nv4))[k];
-                const int rj = crow[jj];
-                kj[j] = rj >= 0 ? stepof(rj) : -1;
+        V4 qv[QF], yv;
+        auto cached = [&](int j) -> V4 {  // the cached row's vector (this lane's four-vector), zero behind the row's step
+            if constexpr (VLDS) {
+                return ((const V4 *)(yl + j * 256))[lane];
+            } else {
+                const V4 v = ((const V4 *)(ffv + (int64_t)j * nv4))[k];
+                const int rj = crow[j];
+                return (kin && rj >= 0 && k <= stepof(rj)) ? v : zero4v;
             }
         };
-        const V4 yv = (kin && k <= kq) ? yv0 : zero4v;
-        T dd[QF];
+        if constexpr (VLDS) {
+            for (int u = qvalid; u < nq; ++u) ((V4 *)(ql + u * 256))[lane] = kin ? Q4(u)[k] : zero4v;  // (rare: behind a leaving row)
+            qvalid = nq;
+            lsync();
+            yv = ((const V4 *)(yl + hit * 256))[lane];
+#pragma unroll
+            for (int u = 0; u < QF; ++u) qv[u] = ((const V4 *)(ql + (u < nq ? u : 0) * 256))[lane];
+        } else {
+            const V4 yv0 = ((const V4 *)yp)[k];
+#pragma unroll
+            for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
+            yv = (kin && k <= kq) ? yv0 : zero4v;
+        }
+        T p1[K1], dd[QF];
+#pragma unroll
+        for (int u = 0; u < K1; ++u) p1[u] = T(0);
 #pragma unroll
         for (int u = 0; u < QF; ++u) {
             if (!kin || u >= nq) qv[u] = zero4v;
-            dd[u] = u < nq ? wave_sum(dot4(qv[u], yv)) : T(0);  // (u < nq: wave-uniform)
+            p1[u] = dot4(qv[u], yv);
         }
-        yy = wave_sum(dot4(yv, yv));
+        p1[QF] = dot4(yv, yv);
+        if constexpr (LOW) {
+            const T r1 = multi_sum<T, K1>(p1, lane);
+#pragma unroll
+            for (int u = 0; u < QF; ++u) dd[u] = lane_get(r1, u);
+            yy = lane_get(r1, QF);
+        } else {  // (three / two wavefronts per SIMD hide a wave_sum's chain, and the multi-reduction's registers spill there)
+#pragma unroll
+            for (int u = 0; u < QF; ++u) dd[u] = u < nq ? wave_sum(p1[u]) : T(0);
+            yy = wave_sum(p1[QF]);
+        }
         V4 zv = yv;
 #pragma unroll
         for (int u = 0; u < QF; ++u) zv -= dd[u] * qv[u];
-        T zz = wave_sum(dot4(zv, zv));
-        if (nq > 0 && zz < T(0.25) * yy) {  // cancellation: once more on z
+        T zz = T(0);
+        bool redo = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            if constexpr (RB == 16) {  // every cached row and |z|^2 in one reduction
+                T p2[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) p2[u] = T(0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) p2[j] = dot4(cached(j), zv);
+                p2[15] = dot4(zv, zv);
+                const T r2 = multi_sum<T, 16>(p2, lane);
+                zz = lane_get(r2, 15);
+                if (lane < R) cg[lane] = r2;
+            } else if constexpr (LOW) {  // groups of three cached rows; |z|^2 in cell 3 of the first group
+                for (int j0 = 0; j0 < R; j0 += 3) {
+                    T p2[4];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) p2[u] = j0 + u < R ? dot4(cached(j0 + u < R ? j0 + u : R - 1), zv) : T(0);
+                    p2[3] = dot4(zv, zv);
+                    const T r2 = multi_sum<T, 4>(p2, lane);
+                    zz = lane_get(r2, 3);
+                    if (lane < 3 && j0 + lane < R) cg[j0 + lane] = r2;
+                }
+            } else {  // groups of four cached rows, a wave_sum each
+                zz = wave_sum(dot4(zv, zv));
+                for (int j0 = 0; j0 < R; j0 += 4) {
+                    V4 yc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) yc[u] = cached(j0 + u < R ? j0 + u : R - 1);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const T g = wave_sum(dot4(yc[u], zv));
+                        if (lane == 0 && j0 + u < R) cg[j0 + u] = g;
+                    }
+                }
+            }
+            redo = pass == 0 && nq > 0 && zz < T(0.25) * yy;
+            if (!redo) break;
+            // cancellation (rare): once more on z
 #pragma unroll
             for (int u = 0; u < QF; ++u) {
                 const T e2 = u < nq ? wave_sum(dot4(qv[u], zv)) : T(0);
                 dd[u] += e2;
                 zv -= e2 * qv[u];
             }
-            zz = wave_sum(dot4(zv, zv));
         }
         if (kin) ((V4 *)zq)[k] = zv;
-        zlast = zv;
+        if constexpr (LOW) zlast = zv;
+        {
+            T mine = T(0);
 #pragma unroll
-        for (int u = 0; u < QF; ++u)
-            if (lane == 0 && u < nq) cv[u] = dd[u];
-        if constexpr (LOW) {
-#pragma unroll
-            for (int j = 0; j < R; ++j) {
-                const T g = wave_sum(dot4(ycreg[j], zv));
-                if (lane == 0) cg[j] = g;
-            }
-        } else {
-            for (int j0 = 0; j0 < R; j0 += RU) {
-                load_yc(j0);
-#pragma unroll
-                for (int j = 0; j < RU; ++j) {
-                    const T g = wave_sum((kin && k <= kj[j]) ? dot4(yc[j], zv) : T(0));
-                    if (lane == 0 && j0 + j < R) cg[j0 + j] = g;
-                }
-            }
+            for (int u = 0; u < QF; ++u) mine = lane == u ? dd[u] : mine;
+            if (lane < nq) cv[lane] = mine;
         }
         lsync();
         return zz;
@@ -1636,6 +1744,30 @@ __global__ void __launch_bounds__(64)
             lsync();
         }
     };
+    // ... the same for at most QF active rows whose factor sits in the LDS tile: lane j < nq takes row j of R into registers (one
+    // round trip for all entries), the substitution runs on lane reads -- no LDS hand-over per step. Leaves r in rv as well.
+    auto rsolve_small = [&]() {
+        const int cp = colp[lane < maxq ? lane : 0];  // (lane b holds the physical column of slot b)
+        T acc = lane < nq ? cv[lane] : T(0);
+        T row[QF], dg = T(1);
+#pragma unroll
+        for (int b = 0; b < QF; ++b) {
+            const int cb = __builtin_amdgcn_readlane(cp, b);
+            const T e_ = Rl[cb * WLD + (lane < QF ? lane : 0)];  // R[lane][b]
+            row[b] = (b < nq && lane < b) ? e_ : T(0);
+            dg = (lane == b && b < nq) ? e_ : dg;
+        }
+        const T idg = T(1) / dg;
+#pragma unroll
+        for (int b = QF - 1; b >= 0; --b) {
+            if (b < nq) {  // (wave-uniform)
+                const T rb = lane_get(acc * idg, b);
+                acc = lane == b ? rb : acc - row[b] * rb;
+            }
+        }
+        if (lane < nq) rv[lane] = acc;
+        lsync();
+    };
     // w = R^-T rho (rho in cv) into ev: forward substitution, a dot product along column b per step
     auto rtsolve = [&](const T *Rp, int ld) {
         for (int b = 0; b < nq; ++b) {
@@ -1648,9 +1780,20 @@ __global__ void __launch_bounds__(64)
         }
     };
     // the candidate becomes basis vector nq: Q gains z / |z|, R the column [d; |z|]
-    auto append = [&](T *Rp, int ld, T *zq, T zz, T up, int bi) {
+    auto append = [&](T *Rp, int ld, T *zq, T zz, T up, int bi, bool small) {
         const T zn = (T)sqrt((double)zz), izn = T(1) / zn;
-        for (int k = lane; k < N; k += 64) ((V4 *)zq)[k] *= izn;
+        if (small) {  // (z is in a register: no load; the small-batch instantiation's copy of Q takes the vector as well)
+            const V4 qn = zlast * izn;
+            if (lane < N) ((V4 *)zq)[lane] = qn;
+            if constexpr (VLDS) {
+                if (qvalid == nq && nq < QF) {
+                    ((V4 *)(ql + nq * 256))[lane] = lane < N ? qn : V4{T(0), T(0), T(0), T(0)};
+                    qvalid = nq + 1;
+                }
+            }
+        } else {
+            for (int k = lane; k < N; k += 64) ((V4 *)zq)[k] *= izn;
+        }
         T *col = Rp + (int64_t)colp[nq] * ld;
         for (int a = lane; a < nq; a += 64) col[a] = cv[a];
         if (lane == 0) {
@@ -1752,7 +1895,8 @@ __global__ void __launch_bounds__(64)
                 cact[lane] = 0;
             }
             wsync();
-            load_ycreg();
+            stage_cached();
+            lsync();
         }
         tacc(9);
         for (;;) {
@@ -1783,13 +1927,15 @@ __global__ void __launch_bounds__(64)
                 T zz;
                 const bool small = N <= 64 && nq <= QF;
                 if (small) {
-                    zz = ortho_small(yp, kq, zq, yy);
+                    zz = ortho_small(yp, hit, kq, zq, yy);
                 } else {
                     zz = ortho(yp, kq, zq, yy);
                     cached_dots(zq);
                 }
                 tacc(10);
-                if (wglob)
+                if (LOW && small && !wglob)
+                    rsolve_small();
+                else if (wglob)
                     rsolve(Wm, maxq);
                 else
                     rsolve(Rl, WLD);
@@ -1825,7 +1971,15 @@ __global__ void __launch_bounds__(64)
                 if (can_move) {
                     // the step: the point moves against z (v -= t z), the slack of a cached row c gains t y_c . z (active rows stay on
                     // their bounds, the candidate's own gain is t |z|^2: it lands on its bound exactly with a full step)
-                    for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] -= t * ((const V4 *)zq)[k];
+                    if (LOW && small) {  // (the point's four-vector stays in a register while the loop stays on this path: no load)
+                        if (!vreg_ok) vreg = ((const V4 *)vpt)[lane < N ? lane : N - 1];
+                        vreg_ok = true;
+                        vreg -= t * zlast;
+                        if (lane < N) ((V4 *)vpt)[lane] = vreg;
+                    } else {
+                        for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] -= t * ((const V4 *)zq)[k];
+                        vreg_ok = false;
+                    }
                     if (lane < R && !cact[lane < R ? lane : 0]) crs[lane] += t * cg[lane];
                     sp += t * zz;
                     lsync();
@@ -1844,18 +1998,9 @@ __global__ void __launch_bounds__(64)
                         wglob = true;
                     }
                     if (wglob)
-                        append(Wm, maxq, zq, zz, up, bi);
+                        append(Wm, maxq, zq, zz, up, bi, LOW && small);
                     else
-                        append(Rl, WLD, zq, zz, up, bi);
-                    if constexpr (LOW) {
-                        if (small && nq < QF && qvalid == nq) {  // (the vector just written to Q's slot nq: z / |z|)
-                            const T izn = T(1) / (T)sqrt((double)zz);
-#pragma unroll
-                            for (int u = 0; u < QF; ++u)
-                                if (u == nq) qreg[u] = zlast * izn;
-                            qvalid = nq + 1;
-                        }
-                    }
+                        append(Rl, WLD, zq, zz, up, bi, LOW && small);
                     ++nq;
                     added = true;
                     if (lane == owner(bi)) thr[bi] = INF;  // (the row's owner) active: infinite threshold
@@ -1913,6 +2058,7 @@ __global__ void __launch_bounds__(64)
             } else {
                 rtsolve(Rl, WLD);
             }
+            vreg_ok = false;
             for (int k = lane; k < N; k += 64) {  // v += Q w
                 V4 acc = ((const V4 *)vpt)[k];
                 for (int a = 0; a < nq; ++a) acc += ev[a] * Q4(a)[k];
@@ -2012,7 +2158,8 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
     // + d, r, multipliers, a scratch vector; active rows, column permutation of R, the backward sweeps' rows; the 32 x 33 tile of R
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (4 * sizeof(T) + 2 * sizeof(int)) + (size_t)RR * sizeof(int) + 16 +
-                       (size_t)32 * 33 * sizeof(T) + (size_t)RR * (4 * sizeof(T) + sizeof(int));
+                       (size_t)32 * 33 * sizeof(T) + (size_t)RR * (4 * sizeof(T) + sizeof(int)) + 16 +
+                       (LOW ? (size_t)(RR + 8) * 256 * sizeof(T) : 0);  // (LOW: copies of the cached rows' vectors and of up to eight vectors of Q)
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     // (developer knob: -DSTAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
     const size_t lds_req = lds + (size_t)STAGEW_LDS_PAD;

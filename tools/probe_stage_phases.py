@@ -39,6 +39,9 @@ if kind in ("c5", "c5f64"):  # (round 6: the loop's parts of the thin-QR kernel)
     its = max(1.0, plan.iters.float().sum().item())
     for i, nme in zip(range(8, 15), ["cache lookup", "candidates+bwd", "orthogonalise", "R solve+ratio", "step: v, cached rows", "append / drop", "evaluations"]):
         print(f"    in loop: {nme:16s} mean {t[:, i].mean().item():10.0f} cyc   per iteration {t[:, i].sum().item() / its:8.0f}")
+if kind in ("c5", "c5f64"):
+    code = buf.view(batch, 16)[:, 15].cpu()
+    print(f"    per problem: backward sweeps {(code & 255).double().mean().item():.2f}, evaluations {((code >> 8) & 255).double().mean().item():.2f}, polish steps {(code >> 16).double().mean().item():.3f}")
 print(f"  makespan {(t[:,7].max()-t[:,0].min()).item():.0f} cyc; start spread {(t[:,0].max()-t[:,0].min()).item():.0f}")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for _ in range(3):
