@@ -331,6 +331,7 @@ def run_bench(args, rank: int, world: int, dist=None, make_runner=_Runner, devic
             # north_star's "fraction of the dense-GEMM roofline": the benched path forms no Gram, so the MFMA Gram kernel of
             # the dense path (qpmpc/mpc_qp.py:99-105) is timed by itself, in this run, on this workload's problems
             out["roofline"]["gram_mfma"] = _gram_mfma_block(w)
+            out["sweeps_per_problem"] = _sweeps_per_problem(w)
         out["accuracy"] = _accuracy(args, w, run)
         if args.config == 4 and world == 1:
             out["paired_by_last_counts"] = _paired_block(run, local_per_step)
@@ -447,6 +448,28 @@ def _overlap_two_streams(args, run, rank, world, barrier, allreduce, dev):
     return {"streams": 2, "value": b * world * args.steps / float(t2.item()), "unit": "problems/s",
             "ms_per_step": float(t2.item()) / args.steps * 1e3,
             "note": "independent batches in flight on 2 HIP streams; not the headline value"}
+
+
+def _sweeps_per_problem(w, dtype=None):
+    """Config 5: how many serial sweeps over the horizon a problem makes in the wide stage-wise kernel (mpcqp_stagew.hip): counted BY
+    THE KERNEL (developer stamps, one extra launch outside the timed region) -- every forward sweep reads 64 KB of factor records per
+    problem, every backward sweep up to 48 KB: they are the launch's HBM traffic."""
+    import torch
+
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    bp = W.to_batch_problem(w, dtype=torch.float32)
+    buf = torch.zeros(bp.batch_size * 16, dtype=torch.int64, device="cuda")
+    plan = solve_mpc_batch(bp, probe=buf)
+    torch.cuda.synchronize()
+    code = buf.view(bp.batch_size, 16)[:, 15]
+    bwd = float((code & 255).double().mean().item())
+    ev = float(((code >> 8) & 255).double().mean().item())
+    pol = float((code >> 16).double().mean().item())
+    return {"riccati_recursion": 1.0, "forward_unconstrained_minimiser": 1.0, "backward_sweeps_of_cached_rows": bwd,
+            "forward_evaluations_of_the_point": ev, "polish_steps": pol, "iterations": float(plan.iters.float().mean().item()),
+            "note": "per problem, means over the batch; a forward sweep reads 64 KB of records, a backward sweep at most 48 KB"}
 
 
 def _dims_of(w):
@@ -749,6 +772,9 @@ def other_workloads():
     # config 2 in shared-LTI mode (reported separately and labelled): stride-0 operands, then the model
     # factored once (P, Cholesky, G L^-T hoisted out of the batch)
     bp2 = W.to_batch_problem(W.triple_integrator_batch(4096, heterogeneous=False))
+    # the headline launch over 2000 launches (the driver's contract times 20: ~1 us per step of launch pipeline is inside that region)
+    bph = W.to_batch_problem(W.triple_integrator_batch(4096))
+    out["config2_headline_batch4096_2000_launches"] = rate(PreparedSolve(bph).launch, 4096, 2000)
     out["config2_shared_lti_operands_fused_batch4096"] = rate(PreparedSolve(bp2).launch, 4096, 200)
     out["config2_shared_lti_model_factored_once_batch4096"] = rate(SharedModel(bp2).prepare(bp2).launch, 4096, 200)
     w = W.humanoid_batch(65536)

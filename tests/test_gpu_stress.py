@@ -92,7 +92,10 @@ def test_stress_campaign_every_seed_of_the_review_list(tool, args, seeds):
 # oracle/stagewise_qr_np.py) -- every family below runs through the DEFAULT dispatch WITHOUT any re-solve (retry_unsolved=False: what
 # solve_mpc_batch, PreparedSolve, the closed loops and the C ABI deliver), sixteen seeds each, statuses equal to the oracle's, plans
 # within 1e-7.
+# ("widef": the same family with constraint matrices FIXED along the horizon, 4 / 8 / 12 / 16 rows per step -- the layout in which the
+# wide kernel's forward sweep forms the rows itself, config 5's.)
 @pytest.mark.parametrize("kind,tight", [("wide", "0.5"), ("wide", "0.3"), ("wide", "0.15"), ("wide", "0.05"),
+                                        ("widef", "0.5"), ("widef", "0.3"), ("widef", "0.15"), ("widef", "0.05"),
                                         ("narrow", "0.5"), ("narrow", "0.3"), ("narrow", "0.15"), ("narrow", "0.05")])
 def test_stress_campaign_nearly_fully_active_without_any_re_solve(kind, tight):
     worst, nflag, flagged = _campaign("stress_tight.py", (kind, 8, 8), 0,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev stress run: NEARLY FULLY ACTIVE problems (many tight rows per step: most of the n variables end up pinned) through the
 default dispatch against the C oracle, for the system widths of the narrow (nx <= 4), wide (nx <= 16) and general stage-wise
-kernels. usage: stress_tight.py [narrow|wide|general] [rounds] [batch]; STRESS_RETRY=1: solve_mpc's setting (items that end
+kernels. usage: stress_tight.py [narrow|wide|widef|general] [rounds] [batch] (widef: constraint matrices fixed along the horizon); STRESS_RETRY=1: solve_mpc's setting (items that end
 MPCQP_MAX_ITER go through the other formulations of the solver, retry_unsolved=True)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -30,13 +30,22 @@ def run(kind, rounds, batch, seed, verbose=True):
     for it in range(rounds):
         if kind == "narrow":
             nx, nu = int(rng.integers(2, 5)), int(rng.integers(1, 3))
-        elif kind == "wide":
+        elif kind in ("wide", "widef"):
             nx, nu = int(rng.integers(5, 17)), int(rng.integers(1, 5))
         else:
             nx, nu = int(rng.integers(17, 33)), int(rng.integers(1, 9))
         N = int(rng.integers(20, 41)); mk = int(rng.integers(4, 7))
+        if kind == "widef":  # constraint matrices FIXED along the horizon, 4 / 8 / 12 / 16 rows per step: the wide kernel's layout in
+            mk = 4 * int(rng.integers(1, 5))  # which the forward sweep forms the rows itself (config 5's)
         w = random_ltv(rng, batch, nx, nu, N, mk, float(os.environ.get("STRESS_TIGHT", "0.5")))  # (smaller: tighter rows, more of them active)
         w["A"] = np.eye(nx) + 0.1 * (w["A"] - np.eye(nx))
+        if kind == "widef":
+            w["C"], w["D"] = w["C"][:, :1].copy(), w["D"][:, :1].copy()
+            for b in range(batch):  # bounds around the free response, as random_ltv makes them (with the fixed C)
+                x = w["x0"][b].copy()
+                for k in range(N):
+                    w["e"][b, k] = w["C"][b, 0] @ x + float(os.environ.get("STRESS_TIGHT", "0.5")) * (0.05 + 0.5 * np.abs(rng.standard_normal(mk)))
+                    x = w["A"][b, k] @ x
         plan = solve_mpc_batch(W.to_batch_problem(w), retry_unsolved=os.environ.get("STRESS_RETRY", "0") == "1"); torch.cuda.synchronize()
         st = plan.status.cpu().numpy()
         Uo, lamo, sto, ito = oracle.solve_workload(w)
