@@ -199,9 +199,11 @@ def solve_stagewise_qr(sp: StageProblem, max_iter: int = 10000, tol: float = 1e-
             U, s = evaluate()
             continue
         # ---- the most violated row and the next ones: their whitened vectors (one backward sweep), their slacks
-        score = np.where(viol, s * invn, np.inf).reshape(-1)
-        order = np.argsort(score, kind="stable")
-        rows = [int(i) for i in order[:cached_rows] if np.isfinite(score[i])]
+        # (the most violated row first, then the inactive rows of smallest scaled slack, violated or not yet: the rows next in line)
+        score = np.where(selectable & ~active, s * invn, np.inf).reshape(-1)
+        first = int(np.argmin(np.where(viol, s * invn, np.inf).reshape(-1)))
+        order = [first] + [int(i) for i in np.argsort(score, kind="stable") if int(i) != first]
+        rows = [i for i in order[:cached_rows] if np.isfinite(score[i])]
         ys = [row_y(i // mk, i % mk) for i in rows]
         crs = [s.reshape(-1)[i] for i in rows]
         cact = [False] * len(rows)

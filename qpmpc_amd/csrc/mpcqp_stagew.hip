@@ -1320,8 +1320,10 @@ __global__ void __launch_bounds__(64)
     using FwInit = std::integral_constant<int, FW_INIT>;
     using FwEval = std::integral_constant<int, FW_EVAL>;
 
-    // the right-hand sides of a backward sweep: column 0 carries the candidate row bi, columns 1 .. R - 1 the next most violated
-    // rows (the whitened vector y_a of a row does not depend on the active set: a row found among them later costs no sweep; which
+    // the right-hand sides of a backward sweep: column 0 carries the candidate row bi, columns 1 .. R - 1 the rows NEXT IN LINE -- the
+    // inactive rows of smallest scaled slack, violated or not yet: a row close to its bound is the likeliest to be asked for by the
+    // steps to come, and a cached row costs a dot product per step where a row that is not costs a backward sweep and an evaluation --
+    // (the whitened vector y_a of a row does not depend on the active set: a row found among them later costs no sweep; which
     // rows ride along has no influence on the iterates). Per lane: its column's row, the row's step, (p_kq, y_kq) to inject there;
     // kmax = the latest of the steps.
     // warm-state record (MpcqpSolveOpts.warm_state): int32 count, then the rows that were active when the last solve ended
@@ -1383,7 +1385,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                         for (int j = 1; j < R; ++j) dup = dup || (j < jstart && rows[j] == i);
                     }
-                    if (i < M && sv[u] < -th[u] && i != bi && !dup) {  // (an active row's threshold is infinite)
+                    if (i < M && th[u] < INF && sv[u] < T(1e29) && i != bi && !dup) {  // (not active -- an active row's threshold is infinite --, a real bound)
                         if (sc < b1) {
                             b2 = b1;
                             i2 = i1;
