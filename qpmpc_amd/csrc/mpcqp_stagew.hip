@@ -1628,7 +1628,7 @@ __global__ void __launch_bounds__(64)
     // a few multi-reductions (multi_sum). Leaves d in cv, z in zq and zlast, g_c in cg[]; returns |z|^2.
     constexpr int K1 = QF == 8 ? 16 : 8;            // first batch: d_0 .. d_{QF-1}, |y|^2
     constexpr int RB = (LOW && sizeof(T) == 4) ? 16 : 4;  // the cached rows' dots per batch (|z|^2 rides in the first one's last cell)
-    auto ortho_small = [&](const T *yp, int hit, int kq, T *zq, T &yy) -> T {
+    auto ortho_small = [&](const T *yp, int hit, int kq, T *zq, T &yy, T &dmine, T &cgmine) -> T {
         const V4 zero4v = {T(0), T(0), T(0), T(0)};
         const int k = lane < N ? lane : N - 1;
         const bool kin = lane < N;
@@ -1689,7 +1689,7 @@ __global__ void __launch_bounds__(64)
                 p2[15] = dot4(zv, zv);
                 const T r2 = multi_sum<T, 16>(p2, lane);
                 zz = lane_get(r2, 15);
-                if (lane < R) cg[lane] = r2;
+                cgmine = r2;  // (lane j: y_j . z)
             } else if constexpr (LOW) {  // groups of three cached rows; |z|^2 in cell 3 of the first group
                 for (int j0 = 0; j0 < R; j0 += 3) {
                     T p2[4];
@@ -1698,7 +1698,8 @@ __global__ void __launch_bounds__(64)
                     p2[3] = dot4(zv, zv);
                     const T r2 = multi_sum<T, 4>(p2, lane);
                     zz = lane_get(r2, 3);
-                    if (lane < 3 && j0 + lane < R) cg[j0 + lane] = r2;
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) cgmine = lane == j0 + u ? lane_get(r2, u) : cgmine;
                 }
             } else {  // groups of four cached rows, a wave_sum each
                 zz = wave_sum(dot4(zv, zv));
@@ -1709,7 +1710,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const T g = wave_sum(dot4(yc[u], zv));
-                        if (lane == 0 && j0 + u < R) cg[j0 + u] = g;
+                        cgmine = lane == j0 + u ? g : cgmine;
                     }
                 }
             }
@@ -1725,13 +1726,9 @@ __global__ void __launch_bounds__(64)
         }
         if (kin) ((V4 *)zq)[k] = zv;
         if constexpr (LOW) zlast = zv;
-        {
-            T mine = T(0);
+        dmine = T(0);
 #pragma unroll
-            for (int u = 0; u < QF; ++u) mine = lane == u ? dd[u] : mine;
-            if (lane < nq) cv[lane] = mine;
-        }
-        lsync();
+        for (int u = 0; u < QF; ++u) dmine = lane == u ? dd[u] : dmine;  // (lane a: d_a)
         return zz;
     };
     // r = R^-1 d (d in cv) into rv: back substitution, column b of R read by the lanes of the rows above it
@@ -1747,10 +1744,11 @@ __global__ void __launch_bounds__(64)
         }
     };
     // ... the same for at most QF active rows whose factor sits in the LDS tile: lane j < nq takes row j of R into registers (one
-    // round trip for all entries), the substitution runs on lane reads -- no LDS hand-over per step. Leaves r in rv as well.
-    auto rsolve_small = [&]() {
+    // round trip for all entries), the substitution runs on lane reads -- no LDS hand-over per step; d arrives and r leaves in a
+    // register (lane a: d_a, r_a).
+    auto rsolve_small = [&](T dmine) -> T {
         const int cp = colp[lane < maxq ? lane : 0];  // (lane b holds the physical column of slot b)
-        T acc = lane < nq ? cv[lane] : T(0);
+        T acc = lane < nq ? dmine : T(0);
         T row[QF], dg = T(1);
 #pragma unroll
         for (int b = 0; b < QF; ++b) {
@@ -1767,8 +1765,7 @@ __global__ void __launch_bounds__(64)
                 acc = lane == b ? rb : acc - row[b] * rb;
             }
         }
-        if (lane < nq) rv[lane] = acc;
-        lsync();
+        return lane < nq ? acc : T(0);
     };
     // w = R^-T rho (rho in cv) into ev: forward substitution, a dot product along column b per step
     auto rtsolve = [&](const T *Rp, int ld) {
@@ -1782,9 +1779,9 @@ __global__ void __launch_bounds__(64)
         }
     };
     // the candidate becomes basis vector nq: Q gains z / |z|, R the column [d; |z|]
-    auto append = [&](T *Rp, int ld, T *zq, T zz, T up, int bi, bool small) {
+    auto append = [&](T *Rp, int ld, T *zq, T zz, T up, int bi, bool small, T dmine) {
         const T zn = (T)sqrt((double)zz), izn = T(1) / zn;
-        if (small) {  // (z is in a register: no load; the small-batch instantiation's copy of Q takes the vector as well)
+        if (LOW && small) {  // (z is in a register: no load; the small-batch instantiation's copy of Q takes the vector as well)
             const V4 qn = zlast * izn;
             if (lane < N) ((V4 *)zq)[lane] = qn;
             if constexpr (VLDS) {
@@ -1797,7 +1794,11 @@ __global__ void __launch_bounds__(64)
             for (int k = lane; k < N; k += 64) ((V4 *)zq)[k] *= izn;
         }
         T *col = Rp + (int64_t)colp[nq] * ld;
-        for (int a = lane; a < nq; a += 64) col[a] = cv[a];
+        if (small) {
+            if (lane < nq) col[lane] = dmine;
+        } else {
+            for (int a = lane; a < nq; a += 64) col[a] = cv[a];
+        }
         if (lane == 0) {
             col[nq] = zn;
             lamv[nq] = up;
@@ -1873,13 +1874,19 @@ __global__ void __launch_bounds__(64)
     T best = selb, sp = selv;
     int bi = seli;
     int polish = 0;
+    // the cached rows' state, one row per lane (lane j < R): row id, slack, threshold, selection metric, whether it is active now --
+    // registers, so that the selection among them and their slacks' updates touch no memory (crow[] also sits in LDS for the
+    // passes that look a row up by its column)
+    int c_row = -1;
+    T c_s = T(0), c_th = INF, c_iv = T(1);
+    bool c_act = false;
     for (;;) {
         tacc(-1);
         if (!(best < INF)) {
             status = MPCQP_SOLVED;
             break;
         }
-        {   // ---- the next R rows: the most violated one and the next ones; their whitened vectors (one backward sweep)
+        {   // ---- the next R rows: the most violated one and the rows next in line; their whitened vectors (one backward sweep)
             int myrow, mykq, kmax;
             MV st;
             T ffs;
@@ -1888,14 +1895,15 @@ __global__ void __launch_bounds__(64)
             candidates(bi, myrow, mykq, kmax, st, ffs);
             backward(std::false_type{}, kmax, st, ffs, mykq);
             const int rj = __shfl(myrow, lane & 15);  // (column j's row sits in the lanes with c16 == j)
-            if (lane < R) {
-                crow[lane] = rj;
-                const unsigned ri = (unsigned)(rj >= 0 ? rj : 0);
-                crs[lane] = sl[ri];
-                cth[lane] = thr[ri];
-                civ[lane] = invn[ri];
-                cact[lane] = 0;
+            c_row = lane < R ? rj : -1;
+            {
+                const unsigned ri = (unsigned)(c_row >= 0 ? c_row : 0);
+                c_s = sl[ri];
+                c_th = thr[ri];
+                c_iv = invn[ri];
+                c_act = false;
             }
+            if (lane < R) crow[lane] = c_row;
             wsync();
             stage_cached();
             lsync();
@@ -1904,16 +1912,12 @@ __global__ void __launch_bounds__(64)
         for (;;) {
             // ---- the most violated cached row
             int hit = lane;
-            T sc = INF;
-            if (lane < R && crow[lane < R ? lane : 0] >= 0 && !cact[lane < R ? lane : 0]) {
-                const T v = crs[lane];
-                if (v < -cth[lane]) sc = v * civ[lane];
-            }
+            T sc = (c_row >= 0 && !c_act && c_s < -c_th) ? c_s * c_iv : INF;
             wave_argmin(sc, hit);
             if (!(sc < INF)) break;  // none: the point is evaluated from scratch
             tacc(8);
-            bi = crow[hit];
-            sp = crs[hit];
+            bi = lane_get(c_row, hit);
+            sp = lane_get(c_s, hit);
             const T *yp = ffv + (int64_t)hit * nv4;
             const int kq = stepof(bi);
             T up = T(0);
@@ -1925,36 +1929,42 @@ __global__ void __launch_bounds__(64)
                 }
                 ++iters;
                 T *zq = Qs + (int64_t)nq * nv4;
-                T yy;
-                T zz;
-                const bool small = N <= 64 && nq <= QF;
+                T yy, zz;
+                // small: the whole iteration on registers -- d, r, the multipliers and the cached rows' gains one per lane
+                const bool small = N <= 64 && nq <= QF && !wglob;
+                T dmine = T(0), cgmine = T(0), rmine = T(0), lam_mine = T(0);
+                T t1 = INF;
+                int l = 0x7fffffff;
                 if (small) {
-                    zz = ortho_small(yp, hit, kq, zq, yy);
+                    lam_mine = lamv[lane < maxq ? lane : 0];  // (requested first: needed last)
+                    zz = ortho_small(yp, hit, kq, zq, yy, dmine, cgmine);
+                    tacc(10);
+                    rmine = rsolve_small(dmine);
+                    if (lane < nq && rmine > T(0)) {  // ---- ratio test on the multipliers
+                        t1 = lam_mine / rmine;
+                        l = lane;
+                    }
                 } else {
                     zz = ortho(yp, kq, zq, yy);
                     cached_dots(zq);
-                }
-                tacc(10);
-                if (LOW && small && !wglob)
-                    rsolve_small();
-                else if (wglob)
-                    rsolve(Wm, maxq);
-                else
-                    rsolve(Rl, WLD);
-                const bool can_move = (nq < nvar) && (zz > DEP * yy) && (zz > T(0));
-                // ---- ratio test on the multipliers
-                T t1 = INF;
-                int l = 0x7fffffff;
-                for (int a = lane; a < nq; a += 64) {
-                    const T ra = rv[a];
-                    if (ra > T(0)) {
-                        const T q = lamv[a] / ra;
-                        if (q < t1) {
-                            t1 = q;
-                            l = a;
+                    cgmine = cg[lane < R ? lane : 0];
+                    tacc(10);
+                    if (wglob)
+                        rsolve(Wm, maxq);
+                    else
+                        rsolve(Rl, WLD);
+                    for (int a = lane; a < nq; a += 64) {
+                        const T ra = rv[a];
+                        if (ra > T(0)) {
+                            const T q = lamv[a] / ra;
+                            if (q < t1) {
+                                t1 = q;
+                                l = a;
+                            }
                         }
                     }
                 }
+                const bool can_move = (nq < nvar) && (zz > DEP * yy) && (zz > T(0));
                 wave_argmin(t1, l);
                 const T t2 = can_move ? -sp / zz : INF;
                 const T t = t1 < t2 ? t1 : t2;
@@ -1982,15 +1992,21 @@ __global__ void __launch_bounds__(64)
                         for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] -= t * ((const V4 *)zq)[k];
                         vreg_ok = false;
                     }
-                    if (lane < R && !cact[lane < R ? lane : 0]) crs[lane] += t * cg[lane];
+                    c_s = c_act ? c_s : c_s + t * cgmine;
                     sp += t * zz;
-                    lsync();
                 }
                 tacc(12);
                 // ---- multipliers
-                for (int a = lane; a < nq; a += 64) {
-                    const T v = lamv[a] - t * rv[a];
-                    lamv[a] = v < T(0) ? T(0) : v;
+                if (small) {
+                    if (lane < nq) {
+                        const T v = lam_mine - t * rmine;
+                        lamv[lane] = v < T(0) ? T(0) : v;
+                    }
+                } else {
+                    for (int a = lane; a < nq; a += 64) {
+                        const T v = lamv[a] - t * rv[a];
+                        lamv[a] = v < T(0) ? T(0) : v;
+                    }
                 }
                 up += t;
                 if (full) {
@@ -2000,15 +2016,15 @@ __global__ void __launch_bounds__(64)
                         wglob = true;
                     }
                     if (wglob)
-                        append(Wm, maxq, zq, zz, up, bi, LOW && small);
+                        append(Wm, maxq, zq, zz, up, bi, small, dmine);
                     else
-                        append(Rl, WLD, zq, zz, up, bi, LOW && small);
+                        append(Rl, WLD, zq, zz, up, bi, small, dmine);
                     ++nq;
                     added = true;
                     if (lane == owner(bi)) thr[bi] = INF;  // (the row's owner) active: infinite threshold
-                    if (lane == 0) {
-                        cact[hit] = 1;
-                        crs[hit] = T(0);
+                    if (lane == hit) {
+                        c_act = true;
+                        c_s = T(0);
                     }
                 } else {
                     const int rowl = actrow[l];
@@ -2018,10 +2034,9 @@ __global__ void __launch_bounds__(64)
                         drop(l, Rl, WLD);
                     --nq;
                     qvalid = qvalid < l ? qvalid : l;  // (the vectors from slot l on were rotated)
-                    // (a cached row that leaves is tracked again, from its bound)
-                    if (lane < R && crow[lane < R ? lane : 0] == rowl) {
-                        cact[lane] = 0;
-                        crs[lane] = T(0);
+                    if (c_row == rowl) {  // (a cached row that leaves is tracked again, from its bound)
+                        c_act = false;
+                        c_s = T(0);
                     }
                 }
                 if (wglob)
