@@ -1632,7 +1632,7 @@ __global__ void __launch_bounds__(64)
         const V4 zero4v = {T(0), T(0), T(0), T(0)};
         const int k = lane < N ? lane : N - 1;
         const bool kin = lane < N;
-        V4 qv[QF], yv;
+        V4 qv[QF], yv, ycu[LOW ? 1 : R];  // (ycu: the cached rows' vectors of the default instantiations, requested up front)
         auto cached = [&](int j) -> V4 {  // the cached row's vector (this lane's four-vector), zero behind the row's step
             if constexpr (VLDS) {
                 return ((const V4 *)(yl + j * 256))[lane];
@@ -1653,6 +1653,10 @@ __global__ void __launch_bounds__(64)
             const V4 yv0 = ((const V4 *)yp)[k];
 #pragma unroll
             for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
+            if constexpr (!LOW) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) ycu[j] = cached(j);
+            }
             yv = (kin && k <= kq) ? yv0 : zero4v;
         }
         T p1[K1], dd[QF];
@@ -1701,17 +1705,12 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                     for (int u = 0; u < 3; ++u) cgmine = lane == j0 + u ? lane_get(r2, u) : cgmine;
                 }
-            } else {  // groups of four cached rows, a wave_sum each
+            } else {  // a wave_sum per cached row (their vectors were requested with Q's: one round trip for the iteration)
                 zz = wave_sum(dot4(zv, zv));
-                for (int j0 = 0; j0 < R; j0 += 4) {
-                    V4 yc[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) yc[u] = cached(j0 + u < R ? j0 + u : R - 1);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const T g = wave_sum(dot4(yc[u], zv));
-                        cgmine = lane == j0 + u ? g : cgmine;
-                    }
+                for (int j = 0; j < R; ++j) {
+                    const T g = wave_sum(dot4(ycu[j], zv));
+                    cgmine = lane == j ? g : cgmine;
                 }
             }
             redo = pass == 0 && nq > 0 && zz < T(0.25) * yy;
