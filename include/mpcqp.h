@@ -164,10 +164,9 @@ typedef struct MpcqpProblem {
                                  state rows per step -- BASELINE configs 1, 2, 4 -- from a few thousand problems up, see
                                  MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check. */
 #define MPCQP_OPT_STAGE_GENERAL 8192 /* mpcqp_stagewise_solve_batch: take the general stage-wise kernel (float64, nx <= 32, nu <= 8) also
-                                 where the narrow or the wide one applies: the formulation the host side re-solves through when one
-                                 of those reports MPCQP_INFEASIBLE or MPCQP_MAX_ITER (their active-set operator is the explicit
-                                 inverse of a Gram matrix; the general kernel keeps a thin QR factor). MPCQP_EUNSUPPORTED for
-                                 float32 and wider systems. */
+                                 where the narrow or the wide one applies (a cross-check; until ABI 10 the formulation the host
+                                 side re-solved through, when only this kernel kept a thin QR factor of the active rows -- the
+                                 wide kernel does since ABI 11). MPCQP_EUNSUPPORTED for float32 and wider systems. */
 #define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
                                  takes it from more than two problems per SIMD of the device up: 2049 and more on an MI355X, where a
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
@@ -323,7 +322,12 @@ int mpcqp_solve_batch(int32_t n, int32_t m, int32_t dtype, const void *P,
 
 /* Replaces the whole of solve_mpc (qpmpc/solve_mpc.py:42-44) for a batch, fused:
  * P, G and their factors never leave the CU. U[batch*n] is the stacked input
- * sequence (Plan.inputs = U.reshape(N, nu), plan.py:36-39). */
+ * sequence (Plan.inputs = U.reshape(N, nu), plan.py:36-39).
+ * status[b] is what an exact backend of the reference would report (found / not found, plan.py:35-40): problems of 17 .. 128
+ * variables with nx <= 4, nu <= 2 -- the narrow stage-wise kernel, whose active-set operator is an explicit inverse -- that this
+ * kernel leaves MPCQP_MAX_ITER or MPCQP_INFEASIBLE are solved once more by the wide stage-wise kernel (thin QR factor of the
+ * active rows) in a second launch on the same stream and in the same workspace, before the call returns (ABI 11; not when the
+ * launch keeps state for a later one: MPCQP_OPT_KEEP_FACTOR / _REUSE_FACTOR / _PIPELINE_FACTOR, a warm state). */
 int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
                             int64_t batch, const MpcqpSolveOpts *opts, void *U,
                             void *lam, int32_t *status, int32_t *iters,
@@ -340,7 +344,7 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
  * rows (<= 0: min(n, m, 128)); a problem that needs more returns status MPCQP_SLOTS_FULL. The workspace is caller-owned
  * (mpcqp_stagewise_workspace_bytes). mpcqp_build_solve_batch reaches the same kernels by itself for every problem that
  * does not fit the on-chip condensed kernels (any n = N nu). MPCQP_OPT_STAGE_GENERAL asks for the general kernel (float64,
- * nx <= 32, nu <= 8: thin-QR active-set operator, the sturdiest of the three on nearly fully active problems) whatever
+ * nx <= 32, nu <= 8: thin-QR active-set operator, like the wide kernel's since ABI 11) whatever
  * the width; its workspace is sized by the query with max_active = -1 (default slots) or -k (k slots). */
 int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes);
 int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
