@@ -72,7 +72,6 @@ namespace mpcqp {
 namespace stagew {
 
 constexpr int NU = 4;   // capacity of the input dimension (register arrays, LDS tiles); nu is a run-time value
-constexpr int KSS = 80;  // a step's entry of the array KS: K' padded to 16 x 4, then 16 cells for the factor of S
 constexpr int LD = 17;  // row stride of the 16 x 16 LDS tiles (odd: the MFMA operand reads are conflict-free)
 // right-hand sides per BACKWARD sweep (columns of the MFMA B operand): the candidate + R - 1 speculated rows. The matrix cores
 // compute all 16 columns whatever their number; a column costs its share of the selection that picks the rows, and the sweep
@@ -85,7 +84,7 @@ constexpr int R_PLAIN = 8, R_FUSE = STAGEW_RF;
 constexpr int R_FUSE_LOW = STAGEW_RLOW, D_LOW = STAGEW_DLOW;
 
 struct Ws {  // per-problem workspace carve, in elements of T (host-computed, passed by value; 32-bit: scalar registers are short)
-    int Mb, Mf, KS, ff, Zs, Gp, s0, s, invn, thr, vpt, ust, junk, Q, W;
+    int Mb, Mf, ff, Zs, Gp, s0, s, invn, thr, vpt, ust, junk, Q, W;
     int maxq, mg;
     int64_t total;
 };
@@ -126,7 +125,6 @@ inline Ws make_ws(int nx, int nu, int N, int mk, int maxq, bool ginv, size_t esz
     const int nq = nxc / 4, na = nxc <= 12 ? 1 : 2;
     w.Mb = take((int64_t)N * rec_elems(na * nq));
     w.Mf = take((int64_t)N * rec_elems(na * (nq + 1)));
-    w.KS = take((int64_t)N * KSS);             // K' (16 x 4) and the factor of S of every step (read at a candidate row's step)
     const bool fuse = fuse_ok(mk, ginv);
     const int R = fuse ? (low ? R_FUSE_LOW : R_FUSE) : R_PLAIN;
     (void)R;
@@ -307,16 +305,6 @@ template <typename T> struct Ldl4 {
     }
 };
 
-// entry i of the stored factor of S: 1 / sqrt(d_0..3), l10, l20, l30, l21, l31, l32 (selected per lane: the store is one instruction)
-template <typename T> __device__ __forceinline__ T ldl_entry(const Ldl4<T> &f, const T (&sid)[4], int i)
-{
-    T v = T(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v = i == j ? sid[j] : v;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) v = i == 4 + j ? f.l[j] : v;
-    return v;
-}
 // The sums over the wavefront of SIXTEEN per-lane values at once: lane l ends with the total of value l % 16. A wave_sum per value is
 // a chain of eight dependent cross-lane steps (~200 cycles for a lone wavefront) and an iteration of the wide kernel's active-set loop
 // needs ~20 of them; here every exchange step HALVES the number of live values -- a lane keeps the half whose index has its own bit
@@ -437,7 +425,7 @@ __global__ void __launch_bounds__(64)
     // (the active set's LDS -- d, r, multipliers, row ids, the tile of R -- is carved behind cst + 8 where the loop starts)
     // ---- workspace
     T *ws = wsbase + prob * wl.total;
-    T *Mb = ws + wl.Mb, *Mf = ws + wl.Mf, *KS = ws + wl.KS, *ffv = ws + wl.ff;
+    T *Mb = ws + wl.Mb, *Mf = ws + wl.Mf, *ffv = ws + wl.ff;
     T *Zs = ws + wl.Zs, *s0 = ws + wl.s0, *sl = ws + wl.s, *invn = ws + wl.invn, *thr = ws + wl.thr;
     V4 *Gp = (V4 *)(ws + wl.Gp);
     const int Mg = wl.mg;
@@ -668,11 +656,8 @@ __global__ void __launch_bounds__(64)
                 rf.v[NQ] = RW[TI];
                 *(RecB *)(Mb + (int64_t)k * SB + lane * LB) = rb;
                 *(RecF *)(Mf + (int64_t)k * SF + lane * LF) = rf;
-                // K' (padded to 16 x 4) and the factor of S (1 / sqrt(d_i), then l10, l20, l30, l21, l31, l32), one value per lane and
-                // NO condition: a store behind a branch costs the loop its request ring (see the forward sweep)
-                T *ks = KS + (unsigned)(k * KSS);
-                ks[lcol * 4 + pg] = -E[TI];
-                ks[64 + c16] = ldl_entry(ldl, sid, c16);
+                // (K' and Ls^-1 of the step, which a candidate row's backward sweep starts from, are IN the forward record -- its
+                // input columns --: rounds 2-5 stored them a second time, 80 values per step)
             }
 #pragma unroll
             for (int t = 0; t < NQ; ++t) P[t] = T(0.5) * (Pk[t] + PT[t]);
@@ -839,12 +824,6 @@ __global__ void __launch_bounds__(64)
                         v.v[j] = (LF * g + j < NF) ? sgnf[LF * g + j < NF ? LF * g + j : 0] * Pm[srcf[LF * g + j < NF ? LF * g + j : 0]] : T(0);
                     *(RecF *)(mf + g * 64 * LF) = v;
                 }
-                T *ks = KS + (unsigned)(k * KSS);
-                ks[lane] = Km[(lane & 3) * LD + (lane >> 2)];  // K' padded to 16 x 4 (the tile is zero outside nu x nx)
-                T sid[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sid[i] = ldl.id[i];  // (1 / sqrt(d_i) by now)
-                ks[64 + c16] = ldl_entry(ldl, sid, c16);
             }
             wsync();
             // P_k = Q_k + sym(A' P Acl)   (x_0 is data: Q_0 = 0)
@@ -1424,33 +1403,37 @@ __global__ void __launch_bounds__(64)
         if (myrow >= 0) {
             const int kq = stepof(myrow), rq = myrow - kq * mk;
             mykq = kq;
-            const T *ks = KS + (unsigned)(kq * KSS);
-            T dd[NU], sid[NU], cq[NQ], kq4[NQ][NU];  // every load first, then the arithmetic
-            Ldl4<T> ldl;
+            // K' and Ls^-1 of step kq are read out of the step's FORWARD record [[Acl, B Ls^-T], [-K, Ls^-T]]: entry e of lane L sits at
+            // (e / LF) 64 LF + L LF + e % LF; K'[c][i] = K[i][c] and Ls^-1[a][j] live in the lanes of row group c % 4 / a whose column
+            // maps to input i / j (stacked layout: columns NXC + i, entries q = c / 4 and NQ; two-block layout: rows i of the second
+            // block, entries NQ + 1 + q and 2 NQ + 1)
+            const T *mf = Mf + (unsigned)(kq * SF);
+            auto unmap = [](int lc) { return sizeof(T) == 4 ? 4 * (lc & 3) + (lc >> 2) : lc; };  // (the inverse of Mfma::rowmap)
+            auto recf = [&](int L, int e) { return mf[(e / LF) * 64 * LF + L * LF + e % LF]; };
+            T dd[NU], cq[NQ], kq4[NQ][NU], li[NU];  // every load first, then the arithmetic
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 dd[i] = (gD && i < nu) ? gD[kq * sD + rq * nu + i] : T(0);
-                sid[i] = ks[64 + i];
-                ldl.id[i] = T(0);
-            }
+                const int L = 16 * pg + unmap(STACK ? NXC + i : i);
+                li[i] = recf(L, STACK ? NQ : 2 * NQ + 1);  // Ls^-1[pg][i]
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ldl.l[i] = ks[64 + 4 + i];
+                for (int q = 0; q < NQ; ++q) kq4[q][i] = -recf(L, STACK ? q : NQ + 1 + q);  // K'[4 q + pg][i]
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int c = 4 * q + pg;
                 cq[q] = (gC && c < nx) ? gC[kq * sC + rq * nx + c] : T(0);
-#pragma unroll
-                for (int i = 0; i < NU; ++i) kq4[q][i] = (c < nx && i < nu) ? ks[c * 4 + i] : T(0);
             }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 T v = -cq[q];
 #pragma unroll
                 for (int i = 0; i < NU; ++i) v += kq4[q][i] * dd[i];
-                st[q] = v;
+                st[q] = (4 * q + pg < nx) ? v : T(0);
             }
-            ldl.wsolve(dd, sid);  // Ls^-1 D'
-            ffs = pg == 0 ? dd[0] : pg == 1 ? dd[1] : pg == 2 ? dd[2] : dd[3];
+            ffs = T(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) ffs += li[i] * dd[i];  // (Ls^-1 D')[pg]
         }
         kmax = -1;
 #pragma unroll
