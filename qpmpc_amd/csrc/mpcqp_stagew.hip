@@ -1441,6 +1441,8 @@ __global__ void __launch_bounds__(64)
             const int kj = rows[j] >= 0 ? stepof(rows[j]) : -1;
             kmax = kj > kmax ? kj : kmax;
         }
+        kmax = __builtin_amdgcn_readfirstlane(kmax);  // (wave-uniform, but it came out of vector registers: the sweep's loop control and
+                                                      // its records' addresses belong on the scalar unit)
     };
 
     // ================================================================= unconstrained minimiser, slacks, first selection
