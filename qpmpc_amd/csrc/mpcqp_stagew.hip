@@ -968,13 +968,22 @@ __global__ void __launch_bounds__(64)
     const int mksh = (mk & (mk - 1)) == 0 ? __builtin_ctz(mk) : -1;
     auto stepof = [&](int i) { return mksh >= 0 ? i >> mksh : i / mk; };
     const T tol = ka.tol;
+    // ---- LDS of the active set (described where the loop starts)
+    constexpr int WL = 32, WLD = 33;
+    T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq, *ev = lamv + maxq;
+    int *actrow = (int *)(ev + maxq), *colp = actrow + maxq, *crow = colp + maxq;
+    T *Rl = (T *)(((uintptr_t)(crow + R) + 15) & ~(uintptr_t)15);
+    T *cg = (T *)(Rl + WL * WLD);  // what the cached rows' slacks gain per unit step (y_c . z): the general path's hand-over (the rows'
+                                   // state itself -- slack, threshold, metric, active or not -- lives in registers, one row per lane)
+    T *invr_l = (T *)(((uintptr_t)(cg + R) + 15) & ~(uintptr_t)15);  // FUSE: 1 / |g_r| of the sixteen rows of a step
+    T *Wl_end = invr_l + 16;                                            // (small-batch instantiation: copies of vectors behind this)
 
     // ---- what happens to a row of G once h_i = g_i . (x_k, u_k) of a forward sweep is known (round 6: the sweeps own the rows).
     // INIT: the sweep of the unconstrained minimiser -- slack, threshold, selection metric; EVAL: the point from scratch
     // (s = e - G (x, u); active rows -- infinite threshold -- checked against their bounds, inactive ones against feasibility).
     // Both also look for the most violated inactive row (sel*). There is no incremental slack update: between two evaluations the
     // iterations only track the rows whose whitened vectors are cached (s_c += t y_c . z, a dot product).
-    enum { FW_INIT = 0, FW_EVAL = 2 };
+    enum { FW_INIT = 0, FW_EVAL = 2, FW_EVALR = 3 };  // (EVALR: an evaluation that also leaves every row's residual in s0, for a polish step)
     T selb = INF, selv = T(0);
     int seli = 0x7fffffff;
     bool offa = false;
@@ -990,7 +999,7 @@ __global__ void __launch_bounds__(64)
         } else {
             th = rb;
             act = th == INF;
-            s0[i] = v;
+            if (mode == FW_EVALR) s0[i] = v;
             sl[i] = act ? T(0) : v;
             // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the terms' magnitudes)
             const T lim = fac * (tol + tol * (T)fabs((double)ra)) +
@@ -1093,7 +1102,7 @@ __global__ void __launch_bounds__(64)
             yv[gs] = ws[yoff + 4u * stp + (unsigned)pg];
             if constexpr (FUSE && !(STAGEW_DBG & 16)) {
                 ev[gs] = ge[valid ? stp * sE32 + r : 0u];
-                if (mode == FW_EVAL) thv[gs] = ws[valid ? (unsigned)wl.thr + stp * mku + r : junk];
+                if (mode != FW_INIT) thv[gs] = ws[valid ? (unsigned)wl.thr + stp * mku + r : junk];
             }
         };
 #pragma unroll
@@ -1161,7 +1170,7 @@ __global__ void __launch_bounds__(64)
                 const T th0 = tol + tol * (T)fabs((double)e_);  // tol (1 + |e|)
                 T th = th0;
                 bool act = false;
-                if constexpr (mode == FW_EVAL) {
+                if constexpr (mode != FW_INIT) {
                     th = thv[gs];
                     act = th == INF;
                     // (float32: plus what the evaluation itself cannot resolve -- STAGEW_VNOISE32 ulps of the magnitude of the
@@ -1176,12 +1185,11 @@ __global__ void __launch_bounds__(64)
                 seli = take ? (int)irow : seli;
                 if constexpr (STAGEW_DBG & 8) {
                     selv += th0 * T(1e-30);
-                } else if constexpr (mode == FW_INIT) {
+                } else if constexpr (mode == FW_INIT) {  // (the selection metric 1 / |g_r| depends on the row of the step only: invr[], no array)
                     ws[live ? (unsigned)wl.thr + irow : junk] = th0;
-                    ws[live ? (unsigned)wl.invn + irow : junk] = myinvn;
                     ws[live ? (unsigned)wl.s + irow : junk] = v;
                 } else {
-                    ws[live ? (unsigned)wl.s0 + irow : junk] = v;
+                    if constexpr (mode == FW_EVALR) ws[live ? (unsigned)wl.s0 + irow : junk] = v;
                     ws[live ? (unsigned)wl.s + irow : junk] = act ? T(0) : v;
                 }
             }
@@ -1298,6 +1306,7 @@ __global__ void __launch_bounds__(64)
     };
     using FwInit = std::integral_constant<int, FW_INIT>;
     using FwEval = std::integral_constant<int, FW_EVAL>;
+    using FwEvalR = std::integral_constant<int, FW_EVALR>;
 
     // the right-hand sides of a backward sweep: column 0 carries the candidate row bi, columns 1 .. R - 1 the rows NEXT IN LINE -- the
     // inactive rows of smallest scaled slack, violated or not yet: a row close to its bound is the likeliest to be asked for by the
@@ -1352,7 +1361,7 @@ __global__ void __launch_bounds__(64)
                 for (int u = 0; u < TU; ++u) {
                     const unsigned i = (unsigned)(i0 + 64 * u < M ? i0 + 64 * u : M - 1);
                     sv[u] = sl[i];
-                    iv[u] = invn[i];
+                    iv[u] = FUSE ? invr_l[(i - stepof((int)i) * mk) & 15] : invn[i];
                     th[u] = thr[i];
                 }
 #pragma unroll
@@ -1463,17 +1472,12 @@ __global__ void __launch_bounds__(64)
     // moves to the workspace when the 33rd row arrives; Q (vectors of nv4 entries) lives in the workspace, every pass over it
     // with the same lane <-> step mapping: no exchange through memory between its passes. d = Q' y (cv), r = R^-1 d (rv), the
     // multipliers, the rows' ids, a scratch vector (ev: re-orthogonalisation, rotations), the rows cached by the backward sweeps.
-    constexpr int WL = 32, WLD = 33;
-    T *cv = cst + 8, *rv = cv + maxq, *lamv = rv + maxq, *ev = lamv + maxq;
-    int *actrow = (int *)(ev + maxq), *colp = actrow + maxq, *crow = colp + maxq;
-    T *Rl = (T *)(((uintptr_t)(crow + R) + 15) & ~(uintptr_t)15);
-    T *crs = (T *)(Rl + WL * WLD), *cth = crs + R, *civ = cth + R;  // the cached rows' slacks, thresholds, selection metric
-    T *cg = civ + R;                                                // ... what their slacks gain per unit step (y_c . z)
-    int *cact = (int *)(cg + R);                                    // ... and whether they are active now
-    T *Wl_end = (T *)(((uintptr_t)(cact + R) + 15) & ~(uintptr_t)15);  // (small-batch instantiation: copies of vectors behind this)
     T *vpt = ws + wl.vpt, *Qs = ws + wl.Q, *Wm = ws + wl.W;
     for (int a = lane; a < maxq; a += 64) colp[a] = a;
     if (lane < R) crow[lane] = -1;
+    if constexpr (FUSE) {
+        if (c16 < 4) invr_l[(4 * pg + c16) & 15] = myinvn;
+    }
     // the point in whitened coordinates: v = y0 (the sweeps' lane <-> step mapping of the vector passes: lane k % 64 owns step k)
     for (int k = lane; k < N; k += 64) ((V4 *)vpt)[k] = ((const V4 *)ffv)[k];
     lsync();
@@ -1884,7 +1888,7 @@ __global__ void __launch_bounds__(64)
                 const unsigned ri = (unsigned)(c_row >= 0 ? c_row : 0);
                 c_s = sl[ri];
                 c_th = thr[ri];
-                c_iv = invn[ri];
+                c_iv = FUSE ? invr_l[((int)ri - stepof((int)ri) * mk) & 15] : invn[ri];
                 c_act = false;
             }
             if (lane < R) crow[lane] = c_row;
@@ -2051,6 +2055,8 @@ __global__ void __launch_bounds__(64)
                 fail = true;
                 break;
             }
+            wsync();
+            fsweep(FwEvalR{}, gx0, (unsigned)wl.vpt, fac);  // (rare: the same evaluation once more, leaving every row's residual in s0)
             wsync();  // (the rows' residuals are read by other lanes)
             for (int a = lane; a < nq; a += 64) cv[a] = s0[actrow[a]];
             lsync();
@@ -2159,7 +2165,7 @@ static int launch_stagew_t(const KernelArgs &ka, int maxq, int64_t batch, void *
     const size_t tiles = (size_t)((NXC <= 12 ? 0 : 6 * 16 * LD + 2 * 16 * 4 + 4 * 4 * LD + 16 + 16) + 8);
     // + d, r, multipliers, a scratch vector; active rows, column permutation of R, the backward sweeps' rows; the 32 x 33 tile of R
     const size_t lds = tiles * sizeof(T) + (size_t)maxq * (4 * sizeof(T) + 2 * sizeof(int)) + (size_t)RR * sizeof(int) + 16 +
-                       (size_t)32 * 33 * sizeof(T) + (size_t)RR * (4 * sizeof(T) + sizeof(int)) + 16 +
+                       (size_t)32 * 33 * sizeof(T) + (size_t)RR * sizeof(T) + 16 + 16 * sizeof(T) +
                        (LOW ? (size_t)(RR + 8) * 256 * sizeof(T) : 0);  // (LOW: copies of the cached rows' vectors and of up to eight vectors of Q)
     auto kern = mpcqp_stagew_kernel<T, NXC, FUSE, LOW>;
     // (developer knob: -DSTAGEW_LDS_PAD=<bytes> of unused LDS per wavefront lowers the number of resident wavefronts)
