@@ -206,3 +206,67 @@ def test_stagewise_oracle_equals_dense_oracle_on_the_reference_fixtures():
         U, lam, st, it = S.solve_stagewise(S.from_mpc_problem(p))
         assert st == 0, name
         assert np.abs(U - z["U_star"]).max() <= 1e-9 * max(1.0, np.abs(z["U_star"]).max()), name
+
+
+def test_thin_qr_stagewise_restatement_equals_the_certified_fixtures_and_the_long_horizons():
+    """oracle/stagewise_qr_np.py -- the method the wide stage-wise kernel runs since round 6 (whitened Riccati records, thin QR of
+    the active rows, evaluations from scratch, the most violated CACHED row first) -- against every certified fixture of the dense
+    path (<= 1e-9) and the reference-built long-horizon minimisers (N = 64, 256: <= 1e-7, cond(P) up to 1e9 on the dense side),
+    in float64; in float32 arithmetic (what config 5's instantiation computes) against the float64 fixtures at 1e-3."""
+    from oracle import stagewise_np as S
+    from oracle import stagewise_qr_np as SQ
+
+    for name in all_cases(solved_only=True):
+        p, z = load_case(name)
+        sp = S.from_mpc_problem(p)
+        for rows in (1, 8):  # (one cached row: every iteration is followed by an evaluation; eight: the kernel's general layout)
+            U, lam, st, it = SQ.solve_stagewise_qr(sp, cached_rows=rows)
+            assert st == 0, (name, rows)
+            assert np.abs(U - z["U_star"]).max() <= 1e-9 * max(1.0, np.abs(z["U_star"]).max()), (name, rows)
+            kk = S.kkt_residuals_stagewise(sp, U, lam)
+            assert kk["stationarity"] <= 1e-8 * (1.0 + np.abs(z["out_q"]).max()) and kk["primal"] <= 1e-9 and kk["dual"] == 0.0, (name, kk)
+        U32, _, st32, _ = SQ.solve_stagewise_qr(sp, tol=1e-6, dtype=np.float32)
+        assert st32 == 0, name
+        assert np.abs(U32 - z["U_star"]).max() <= 1e-3 * max(1.0, np.abs(z["U_star"]).max()), name
+    for name in ("stagewise_triple_n64", "stagewise_triple_n256"):
+        p, z = _load_stagewise(name)
+        U, lam, st, it = SQ.solve_stagewise_qr(S.from_mpc_problem(p))
+        assert st == 0
+        assert np.abs(U - z["U_star"]).max() <= 1e-7 * max(1.0, np.abs(z["U_star"]).max())
+
+
+def test_thin_qr_stagewise_restatement_on_nearly_fully_active_problems():
+    """Random LTV problems with 4-6 tight rows per step (most of the ~40 variables pinned; the family of tools/stress_tight.py,
+    where the explicit-inverse operator of rounds 2-5 lost problems): statuses and plans equal to the dense C oracle's."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from oracle import stagewise_qr_np as SQ
+    from oracle.stagewise_np import StageProblem
+
+    rng = np.random.default_rng(3)
+    nx, nu, N, mk, B = 6, 2, 20, 5, 6
+    A = np.eye(nx) + 0.008 * rng.standard_normal((B, N, nx, nx))
+    Bm = rng.standard_normal((B, N, nx, nu))
+    Cm = rng.standard_normal((B, N, mk, nx))
+    D = rng.standard_normal((B, N, mk, nu))
+    x0 = 0.1 * rng.standard_normal((B, nx))
+    e = np.zeros((B, N, mk))
+    for b in range(B):
+        x = x0[b].copy()
+        for k in range(N):
+            e[b, k] = Cm[b, k] @ x + 0.15 * (0.05 + 0.5 * np.abs(rng.standard_normal(mk)))
+            x = A[b, k] @ x
+    w = dict(A=A, B=Bm, C=Cm, D=D, e=e, N=N, wt=2.0, wx=0.5, wu=1e-2, x0=x0, goal=rng.standard_normal((B, nx)),
+             targets=rng.standard_normal((B, N * nx)))
+    Uo, _, sto, _ = oracle.solve_workload(w)
+    solved = 0
+    for b in range(B):
+        sp = StageProblem(A[b], Bm[b], Cm[b], D[b], e[b], x0[b], w["goal"][b], w["targets"][b].reshape(N, nx), 2.0, 0.5, 1e-2)
+        U, _, st, _ = SQ.solve_stagewise_qr(sp)
+        assert (st == 0) == (sto[b] == 0), (b, st, sto[b])
+        if st == 0:
+            solved += 1
+            assert np.abs(U - Uo[b]).max() <= 1e-7 * max(1.0, np.abs(Uo[b]).max()), b
+    assert solved >= 2
