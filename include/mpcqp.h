@@ -345,7 +345,9 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem,
  * (mpcqp_stagewise_workspace_bytes). mpcqp_build_solve_batch reaches the same kernels by itself for every problem that
  * does not fit the on-chip condensed kernels (any n = N nu). MPCQP_OPT_STAGE_GENERAL asks for the general kernel (float64,
  * nx <= 32, nu <= 8: thin-QR active-set operator, like the wide kernel's since ABI 11) whatever
- * the width; its workspace is sized by the query with max_active = -1 (default slots) or -k (k slots). */
+ * the width; its workspace is sized by the query with max_active = -1 (default slots) or -k (k slots). As in
+ * mpcqp_build_solve_batch, what the narrow kernel leaves MPCQP_MAX_ITER / MPCQP_INFEASIBLE is solved once more by the wide kernel
+ * (same slots, same workspace, same stream) before the call returns. */
 int mpcqp_stagewise_workspace_bytes(const MpcqpDims *dims, int64_t batch, int32_t max_active, size_t *bytes);
 int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, int64_t batch,
                                 const MpcqpSolveOpts *opts, int32_t max_active, void *U, void *lam,

@@ -888,11 +888,19 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     if ((rc = fill_opts(ka, opts, dims->dtype))) return rc;
     if (ka.warm_state) return MPCQP_EUNSUPPORTED;
     const int maxq = max_active > 0 ? max_active : stage_default_maxq(ka);
-    const size_t need = narrow ? stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch
-                               : stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch;
+    const size_t need_w = stagew_supported(ka, dims->dtype) ? stagew_ws_elems(ka, maxq, dims->dtype) * elem_size(dims->dtype) * (size_t)batch : 0;
+    // (as in mpcqp_build_solve_batch: what the narrow kernel leaves MPCQP_MAX_ITER / MPCQP_INFEASIBLE goes through the wide one, with
+    // the same slots, in the same workspace -- mpcqp_stagewise_workspace_bytes reports the larger of the two)
+    const bool second = narrow && second_opinion_applies(ka, dims->dtype);
+    size_t need = narrow ? stage_ws_doubles(ka, maxq) * sizeof(double) * (size_t)batch : need_w;
+    if (second && need_w > need) need = need_w;
     if (!workspace || workspace_bytes < need) return MPCQP_EWORKSPACE;
-    if (narrow) return launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream);
-    return launch_stagew(ka, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
+    if (!narrow) return launch_stagew(ka, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
+    if ((rc = launch_stage(ka, maxq, batch, workspace, (hipStream_t)stream)) || !second) return rc;
+    KernelArgs kb = ka;
+    kb.opt_flags |= kOptSecondOpinion;
+    kb.probe = nullptr;
+    return launch_stagew(kb, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
 }
 
 int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes)

@@ -104,6 +104,17 @@ def test_stress_campaign_nearly_fully_active_without_any_re_solve(kind, tight):
     assert worst <= 1e-7, (kind, tight, worst)
 
 
+@pytest.mark.parametrize("tight", ["0.15", "0.05"])
+def test_stagewise_entry_point_takes_the_second_opinion_too(tight):
+    """mpcqp_stagewise_solve_batch (formulation="stagewise") sends nx <= 4, nu <= 2 to the narrow kernel at every size; what that kernel
+    leaves MPCQP_MAX_ITER / MPCQP_INFEASIBLE is solved by the wide kernel behind it, as in mpcqp_build_solve_batch (include/mpcqp.h)."""
+    worst, nflag, flagged = _campaign("stress_tight.py", ("narrow", 8, 8), 0,
+                                      {"STRESS_SEEDS": ",".join(str(sd) for sd in range(1, 17)), "STRESS_TIGHT": tight, "STRESS_RETRY": "0",
+                                       "STRESS_FORMULATION": "stagewise"})
+    assert nflag == 0, "\n".join(flagged)
+    assert worst <= 1e-7, (tight, worst)
+
+
 def test_solve_mpc_delivers_what_an_exact_backend_would_on_known_hard_problems():
     """The problems of stress_tight's wide family at STRESS_TIGHT=0.3 (seeds 1 and 5; 60-78 of ~80 variables pinned) on which the wide
     stage-wise kernel of rounds 2-5 gave up or said `infeasible` although the oracle solves them: the batched entry point on its own

@@ -2,7 +2,8 @@
 """Dev stress run: NEARLY FULLY ACTIVE problems (many tight rows per step: most of the n variables end up pinned) through the
 default dispatch against the C oracle, for the system widths of the narrow (nx <= 4), wide (nx <= 16) and general stage-wise
 kernels. usage: stress_tight.py [narrow|wide|widef|general] [rounds] [batch] (widef: constraint matrices fixed along the horizon); STRESS_RETRY=1: solve_mpc's setting (items that end
-MPCQP_MAX_ITER go through the other formulations of the solver, retry_unsolved=True)"""
+MPCQP_MAX_ITER go through the other formulations of the solver, retry_unsolved=True); STRESS_FORMULATION=stagewise: through
+mpcqp_stagewise_solve_batch (the narrow kernel where it applies, the wide one behind it) instead of the default entry point"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
@@ -46,7 +47,10 @@ def run(kind, rounds, batch, seed, verbose=True):
                 for k in range(N):
                     w["e"][b, k] = w["C"][b, 0] @ x + float(os.environ.get("STRESS_TIGHT", "0.5")) * (0.05 + 0.5 * np.abs(rng.standard_normal(mk)))
                     x = w["A"][b, k] @ x
-        plan = solve_mpc_batch(W.to_batch_problem(w), retry_unsolved=os.environ.get("STRESS_RETRY", "0") == "1"); torch.cuda.synchronize()
+        kw = {}
+        if os.environ.get("STRESS_FORMULATION") == "stagewise":  # (mpcqp_stagewise_solve_batch instead of the default entry point)
+            kw = dict(formulation="stagewise", max_active=min(N * nu, N * mk))
+        plan = solve_mpc_batch(W.to_batch_problem(w), retry_unsolved=os.environ.get("STRESS_RETRY", "0") == "1", **kw); torch.cuda.synchronize()
         st = plan.status.cpu().numpy()
         Uo, lamo, sto, ito = oracle.solve_workload(w)
         agree = np.array_equal(st == 0, sto == 0)
