@@ -231,7 +231,11 @@ using namespace quad;
 // WPB: wavefronts per workgroup (they share nothing).
 // MODEL: the launch shares one factored model (mpcqp_factor_model: gA points at it); the per-problem vectors are x0, goal, targets and,
 //        optionally, the bounds e. No build, no factorisation: M, L^-T and the linear maps of h and w are read from the model.
-template <int NX, bool ORD, int WPB, bool SLIM, bool MODEL = false>
+// GEN:   the build serves every cost and constraint layout of two rows per step (round 6): input rows D_k next to / instead of the state
+//        rows C_k, a stage cost w_x sum |x_k - xref_k|^2 (the Gram matrix accumulated over every Psi_k of the chain, as
+//        mpcqp_pair.hip's generic build does) -- the reference's own wheeled-inverted-pendulum example
+//        (examples/wheeled_inverted_pendulum.py:90-94: input box, stage + terminal cost) is of this kind.
+template <int NX, bool ORD, int WPB, bool SLIM, bool MODEL = false, bool GEN = false>
 __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     mpcqp_quad_kernel(const double *__restrict__ gA, const double *__restrict__ gB, const double *__restrict__ gC,
                       const double *__restrict__ ge, const double *__restrict__ gx0, const double *__restrict__ ggoal,
@@ -327,16 +331,23 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     // ---------------------------------------------------------------- build (mpc_qp.py:53-114)
     T Pr[NV];  // row l of P, then of L
     T qa;
+    T g15a = T(0), g15b = T(0);
     {
         constexpr int nx = NX;
         const int nu = ka.nu, N = ka.N;
         const T *A = gA + prob * ka.A.batch_stride;
         const T *B = gB + prob * ka.B.batch_stride;
-        const T *Cm = gC + prob * ka.C.batch_stride;
+        const bool hasC = !GEN || gC != nullptr;
+        const T *Cm = hasC ? gC + prob * ka.C.batch_stride : A;  // (no state rows: the lanes load valid addresses, the products are dropped)
         const T *x0 = gx0 + prob * ka.x0.batch_stride;
         const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
-        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0, sC = ka.C.step_stride ? MK * nx : 0;
+        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0, sC = (hasC && ka.C.step_stride) ? MK * nx : 0;
         const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
+        // (GEN) input rows and the stage cost
+        const T *Dm = (GEN && ka.D.ptr) ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
+        const T *tgt = (GEN && gtgt) ? gtgt + prob * ka.targets.batch_stride : nullptr;
+        const int sD = (GEN && ka.D.step_stride) ? MK * nu : 0;
+        const bool stageP = GEN && (ka.flags & MPCQP_P_STAGE), stageQ = GEN && (ka.flags & MPCQP_Q_STAGE) && tgt;
         constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
         const bool col = (l < n);
         const int j = col ? (nu == 1 ? l : l / nu) : -1, ii = col ? l - j * nu : 0;  // (nu == 1: no division before the loads)
@@ -358,6 +369,26 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         }
 #pragma unroll
         for (int r = 0; r < NX; ++r) bcol[r] = col ? B[j * sB + r * nu + ii] : T(0);
+        // (GEN) this lane's column of D_j: the G entries of its variable, rows (j, 0) and (j, 1). Lane 15's cells of the image carry
+        // the free response through the chain: when it owns a variable (n = 16: an input of the LAST step) the two rows of that step
+        // fetch its entries of D straight from memory, behind the chain. Targets: lane e keeps xref element e, e + 16, e + 32, e + 48
+        // (N nx <= 64), the chain fetches them as row broadcasts.
+        T dcol[MK] = {T(0), T(0)}, d15a = T(0), d15b = T(0), tg[4] = {T(0), T(0), T(0), T(0)};
+        if constexpr (GEN) {
+            if (Dm) {
+#pragma unroll
+                for (int i2 = 0; i2 < MK; ++i2) dcol[i2] = (col && !xl15) ? Dm[j * sD + i2 * nu + ii] : T(0);
+                if (n == NV) {
+                    const int j15 = nu == 1 ? NV - 1 : (NV - 1) / nu, i15 = NV - 1 - j15 * nu;
+                    d15a = (isc0 && (row0 >> 1) == j15) ? Dm[j15 * sD + (row0 & 1) * nu + i15] : T(0);
+                    d15b = (isc1 && (row1 >> 1) == j15) ? Dm[j15 * sD + (row1 & 1) * nu + i15] : T(0);
+                }
+            }
+            if (stageQ) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tg[u] = (l + 16 * u < N * NX) ? tgt[l + 16 * u] : T(0);
+            }
+        }
         // lane e of the row keeps element e (and e + 16) of [A_k | C_k] for every step k, straight from HBM; the chain
         // fetches an operand as a DPP row broadcast (lanes without an element load a valid address and are never read)
         T opa[NV], opb[NV];
@@ -376,6 +407,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         }
         tick(8);
         const T wu = (T)ka.wu;
+        qa = T(0);
 #pragma unroll
         for (int b = 0; b < NV; ++b) Pr[b] = (l == b) ? (col ? wu : T(1)) : T(0);
         tick(9);
@@ -399,12 +431,31 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                         constexpr int s2 = decltype(sc)::value;
                         mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
                     });
+                    if constexpr (GEN) acc = (hasC ? acc : T(0)) + ((j == k) ? dcol[i2] : T(0));
                     g[i2] = acc;
                 });
                 // (lane 15 stores C_k Phi_k x0 into column 15 of the image -- zero in G by construction --: the rows read their
                 // entry of it behind the chain)
 #pragma unroll
                 for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
+                if constexpr (GEN && k >= 1) {
+                    // stage cost on x_k: P += w_x Psi_k' Psi_k, q += w_x Psi_k' (Phi_k x0 - xref_k)  (mpc_qp.py:99-105, 129-149; lane 15's
+                    // own column is zero in every Psi_k of the chain, its registers hold the free response)
+                    if (stageP || stageQ) {
+                        const T wxs = (T)ka.wx;
+                        static_for<0, NX>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value;
+                            constexpr int te = k * NX + s2;
+                            T src = xl15 ? T(0) : v[s2];
+                            const T t = wxs * src;
+                            if (stageQ) qa += t * (row_bcast<NV - 1>(v[s2]) - row_bcast<te % 16>(tg[(te / 16) % 4]));
+                            if (stageP) {
+                                dpp_ready(src);
+                                static_for<0, NV>([&](auto bc) { fmac_bcast<decltype(bc)::value>(Pr[decltype(bc)::value], src, t); });
+                            }
+                        });
+                    }
+                }
                 // column j of Psi_k is zero up to step j, so B_j's column enters as the start value of lane j's sums (lane 15 carries
                 // the free response: its own column is put in place behind the chain)
                 const T hk = (j == k && !xl15) ? T(1) : T(0);
@@ -424,7 +475,6 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         });
         tick(10);
         // P = wu I + wt psi_N' psi_N ; q = wt psi_N' (Phi_N x0 - goal)   (mpc_qp.py:99-105, 129-149)
-        qa = T(0);
         const T wt = (T)ka.wt;
         // Phi_N x0 from lane 15, whose own column of Psi_N is B's column of the last step (or nothing)
         T x[NX];
@@ -448,6 +498,10 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         wsync();  // the G image is complete
         hval0 = isc0 ? eval0 - Gimg[(NV - 1) * GS + row0] : INF;  // h_i = e_i - C_k Phi_k x0 (column 15 of the image)
         hval1 = isc1 ? eval1 - Gimg[(NV - 1) * GS + row1] : INF;
+        if constexpr (GEN) {  // (column 15 of G: the last step's input rows)
+            g15a = d15a;
+            g15b = d15b;
+        }
     }
     tick(1);
     // ------------------------------------------------------------ factorise + forward substitution, one pass
@@ -460,8 +514,8 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             // (column 15 of G is zero: the column of the horizon's last step, or of no variable -- its cells hold the free response)
-            RM0[k] = (isc0 && k < NV - 1) ? Gimg[k * GS + row0] : T(0);
-            RM1[k] = (isc1 && k < NV - 1) ? Gimg[k * GS + row1] : T(0);
+            RM0[k] = (isc0 && k < NV - 1) ? Gimg[k * GS + row0] : (GEN && k == NV - 1 ? g15a : T(0));
+            RM1[k] = (isc1 && k < NV - 1) ? Gimg[k * GS + row1] : (GEN && k == NV - 1 ? g15b : T(0));
             RLt[k] = (l == k) ? T(1) : T(0);
         }
         static_for<0, NV>([&](auto jc) {
@@ -949,13 +1003,17 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
 // 45.5 / 74.0 / 231 against 56.9 / 90.9 / 305 us.
 static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_now(); }
 
+// the lean build (terminal cost only, state rows only: BASELINE configs 1, 2, 4) or the general one (GEN: input rows, stage cost)
+static bool quad_general(const KernelArgs &ka) { return !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE)); }
+
 bool quad_applies(const KernelArgs &ka)
 {
-    // the register-pipelined chain: terminal cost only, state rows only, two rows per step; cold launches
-    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || (ka.nx != 3 && ka.nx != 4)) return false;
-    if (!(ka.mk == MK && ka.C.ptr && !ka.D.ptr && !(ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE)))) return false;
+    // the register-pipelined chain: two rows per step (state rows, input rows or both), nx = 2 .. 4; cold launches
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 4) return false;
+    if (ka.mk != MK || (!ka.C.ptr && !ka.D.ptr)) return false;
     if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
     if (ka.warm_state || (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED)) return false;
+    if (quad_general(ka) && ka.order) return false;  // (the general build has no instantiation with a pairing order)
     return true;
 }
 
@@ -977,7 +1035,18 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
     };
     // one round (at most one wavefront per SIMD): the roomy carve; several rounds: the slim one, two wavefronts per SIMD
     const bool slim = waves > device_simds_now();
-    if (ka.order) {
+    if (quad_general(ka)) {
+        auto gen = [&](auto kern, size_t per) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), per * 4 * sizeof(double), st, (const double *)ka.A.ptr,
+                               (const double *)ka.B.ptr, (const double *)ka.C.ptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
+                               (const double *)ka.goal.ptr, (const double *)ka.targets.ptr, (double *)ka.U, (double *)ka.lam, ka.status,
+                               ka.iters, ka, batch);
+        };
+        if (slim)
+            gen(mpcqp_quad_kernel<NX, false, 1, true, false, true>, Carve<true>::PER);
+        else
+            gen(mpcqp_quad_kernel<NX, false, 1, false, false, true>, Carve<false>::PER);
+    } else if (ka.order) {
         if (slim)
             go(mpcqp_quad_kernel<NX, true, 1, true>, Carve<true>::PER);
         else
@@ -992,7 +1061,7 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
 
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
-    return ka.nx == 3 ? launch_quad_t<3>(ka, batch, st) : launch_quad_t<4>(ka, batch, st);
+    return ka.nx == 2 ? launch_quad_t<2>(ka, batch, st) : ka.nx == 3 ? launch_quad_t<3>(ka, batch, st) : launch_quad_t<4>(ka, batch, st);
 }
 
 // Shared-model launches (mpcqp_solve_model_batch / _bounds_batch): any cost and constraint layout the model was factored from, as

@@ -50,6 +50,16 @@ namespace mpcqp {
 #ifndef STAGEW_VPASS32
 #define STAGEW_VPASS32 3
 #endif
+#ifndef STAGEW_QFD
+// active rows up to which an iteration of the default float32 instantiations runs on its "small" path (one four-vector of Q per lane and row)
+#define STAGEW_QFD 4
+#endif
+#ifndef STAGEW_MSUMD
+#define STAGEW_MSUMD 0
+#endif
+#ifndef STAGEW_YCU_LATE
+#define STAGEW_YCU_LATE 0
+#endif
 #ifndef STAGEW_WPE32
 #define STAGEW_WPE32 3
 #endif
@@ -1586,7 +1596,7 @@ __global__ void __launch_bounds__(64)
     // load of the iteration -- the candidate's vector, Q, the cached rows' vectors -- is issued up front (one round trip), Q is
     // read once. Leaves d in cv, z in zq, g_c in cg[]; returns |z|^2.
     // (registers: the default instantiations run three / two wavefronts per SIMD, and float64 four-vectors are eight registers)
-    constexpr int QF = (LOW && sizeof(T) == 4) ? 8 : 4;
+    constexpr int QF = (LOW && sizeof(T) == 4) ? 8 : (sizeof(T) == 4 ? STAGEW_QFD : 4);
     // Small-batch instantiation (one wavefront per SIMD: what an iteration costs is its round trips): copies of the cached rows'
     // vectors and of the first QF vectors of Q in LDS (written behind the backward sweep / by the step that appends a vector; a
     // leaving row invalidates the copies from its slot on, which are read again from the workspace).
@@ -1642,7 +1652,7 @@ __global__ void __launch_bounds__(64)
             const V4 yv0 = ((const V4 *)yp)[k];
 #pragma unroll
             for (int u = 0; u < QF; ++u) qv[u] = Q4(u < nq ? u : 0)[k];
-            if constexpr (!LOW) {
+            if constexpr (!LOW && !STAGEW_YCU_LATE) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) ycu[j] = cached(j);
             }
@@ -1657,7 +1667,7 @@ __global__ void __launch_bounds__(64)
             p1[u] = dot4(qv[u], yv);
         }
         p1[QF] = dot4(yv, yv);
-        if constexpr (LOW) {
+        if constexpr (LOW || (STAGEW_MSUMD && sizeof(T) == 4)) {
             const T r1 = multi_sum<T, K1>(p1, lane);
 #pragma unroll
             for (int u = 0; u < QF; ++u) dd[u] = lane_get(r1, u);
@@ -1670,6 +1680,10 @@ __global__ void __launch_bounds__(64)
         V4 zv = yv;
 #pragma unroll
         for (int u = 0; u < QF; ++u) zv -= dd[u] * qv[u];
+        if constexpr (!LOW && STAGEW_YCU_LATE) {  // (requested behind Q's use: a second round trip, fewer live registers)
+#pragma unroll
+            for (int j = 0; j < R; ++j) ycu[j] = cached(j);
+        }
         T zz = T(0);
         bool redo = false;
         for (int pass = 0; pass < 2; ++pass) {
@@ -1694,6 +1708,16 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
                     for (int u = 0; u < 3; ++u) cgmine = lane == j0 + u ? lane_get(r2, u) : cgmine;
                 }
+            } else if constexpr (STAGEW_MSUMD && sizeof(T) == 4 && R <= 7) {  // the cached rows and |z|^2 in one reduction of eight
+                T p2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p2[u] = T(0);
+#pragma unroll
+                for (int j = 0; j < R; ++j) p2[j] = dot4(ycu[j], zv);
+                p2[7] = dot4(zv, zv);
+                const T r2 = multi_sum<T, 8>(p2, lane);
+                zz = lane_get(r2, 7);
+                cgmine = r2;  // (lane j < R: y_j . z)
             } else {  // a wave_sum per cached row (their vectors were requested with Q's: one round trip for the iteration)
                 zz = wave_sum(dot4(zv, zv));
 #pragma unroll

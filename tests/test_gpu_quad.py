@@ -1,5 +1,6 @@
 """GPU tests (-m gpu): the four-problems-per-wavefront kernel (csrc/mpcqp_quad.hip) -- the cold fused build+solve of problems with
-terminal cost only and two state rows per step (BASELINE configs 1, 2, 4), replacing qpmpc/mpc_qp.py:53-149 and the
+two rows per step and nx = 2 .. 4 (lean build: terminal cost only, state rows only -- BASELINE configs 1, 2, 4; general build, round 6:
+input rows, stage cost), replacing qpmpc/mpc_qp.py:53-149 and the
 qpsolvers call at qpmpc/solve_mpc.py:43 like the two-per-wavefront kernel it is dispatched next to. The dispatch takes it by
 batch size (2049 problems and more on an MI355X; beyond 4096 its slim LDS carve, two wavefronts per SIMD); MPCQP_OPT_FOUR_PER_WAVE
 forces it, MPCQP_OPT_TWO_PER_WAVE keeps the other.
@@ -256,14 +257,14 @@ def test_shared_model_with_bounds_per_problem_and_an_order():
 
 
 def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
-    """MPCQP_OPT_FOUR_PER_WAVE with a stage cost, with input rows, with a warm state or next to another override:
-    MPCQP_EUNSUPPORTED before any launch."""
+    """MPCQP_OPT_FOUR_PER_WAVE with three rows per step, with a warm state, next to another override or on another kernel's
+    dimensions: MPCQP_EUNSUPPORTED before any launch."""
     from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
     from qpmpc_amd import workloads as W
     from stress_stagewise import random_ltv
 
     rng = np.random.default_rng(1)
-    w = random_ltv(rng, 8, 3, 1, 8, 2, 1.0)  # stage cost, C and D
+    w = random_ltv(rng, 8, 3, 1, 8, 3, 1.0)  # three rows per step
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE)
     w = W.triple_integrator_batch(8)
@@ -275,6 +276,77 @@ def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
     wide = random_ltv(rng, 8, 6, 2, 10, 2, 1.0)  # another kernel's dimensions
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(W.to_batch_problem(wide), flags=_capi.OPT_FOUR_PER_WAVE)
+
+
+def _general_family(rng, batch, nx, nu, N, tight, rows, stage):
+    """random LTV problems with two rows per step: state rows, input rows or both; with or without a stage cost"""
+    from stress_stagewise import random_ltv
+
+    w = random_ltv(rng, batch, nx, nu, N, 2, tight)
+    if rows == "c":
+        w["D"] = None
+    elif rows == "d":  # an input box per step: e > 0 keeps u = 0 feasible
+        w["C"] = None
+        w["e"] = tight * (0.05 + 0.5 * np.abs(rng.standard_normal(w["e"].shape)))
+    if not stage:
+        w["wx"] = w["targets"] = None
+    return w
+
+
+@pytest.mark.parametrize("nx,nu", [(2, 1), (2, 2), (3, 1), (4, 1), (3, 2), (4, 2), (3, 3), (4, 4)])
+def test_general_build_every_layout_against_the_oracle(nx, nu):
+    """Round 6: the kernel's general build -- input rows D_k next to / instead of the state rows C_k, a stage cost (the Gram matrix over
+    every Psi_k, targets per step), nx = 2 -- over every horizon that fits sixteen variables, loose to very tight bounds: statuses and
+    plans against the oracle; for nx = 3, 4 iteration counts against the two-per-wavefront kernel's generic build
+    (qpmpc/mpc_qp.py:53-149 both)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(1000 * nx + nu)
+    drops = 0
+    for N in range(2, 16 // nu + 1):
+        for tight, rows, stage in ((3.0, "cd", True), (0.2, "d", True), (0.05, "c", True), (0.05, "cd", False), (0.2, "d", False)):
+            if nx == 2 and rows == "c" and not stage:
+                continue
+            w = _general_family(rng, 61, nx, nu, N, tight, rows, stage)
+            bp = W.to_batch_problem(w)
+            four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+            torch.cuda.synchronize()
+            ok = _check_against_oracle(w, four)
+            if nx > 2:
+                two = solve_mpc_batch(bp, flags=_capi.OPT_TWO_PER_WAVE)
+                torch.cuda.synchronize()
+                same = (four.iters == two.iters).cpu().numpy()[ok]
+                assert same.mean() >= 0.95, (N, tight, rows, stage, same.mean())
+            drops += int((four.iters.cpu().numpy()[ok] > N * nu).sum())
+    assert drops > 0 or nu > 2  # (the partial-step / drop path ran; horizons of at most five steps rarely get there)
+
+
+def test_the_reference_wip_example_at_4096_takes_the_kernel():
+    """The reference's own example problem (examples/wheeled_inverted_pendulum.py:90-94: N = 12, input box, stage + terminal cost),
+    4096 of them with their own states and targets: the default dispatch is the four-per-wavefront kernel (bit-equal to the forced
+    launch), slim carve beyond one round; plans against the oracle and the two-per-wavefront kernel."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    for batch in (4096, 4500):
+        w = W.wip_batch(batch, N=12, sampling_period=0.1, seed=5)
+        w["x0"][: batch // 4, 1] += 0.4  # some loops hit the input box
+        ts = np.stack([w["pendulum"].target_states(x, 0.5) for x in w["x0"]])
+        w["goal"], w["targets"] = ts[:, -4:], ts[:, :-4]
+        bp = W.to_batch_problem(w)
+        auto = solve_mpc_batch(bp)
+        four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+        two = solve_mpc_batch(bp, flags=_capi.OPT_TWO_PER_WAVE)
+        torch.cuda.synchronize()
+        assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters)
+        assert torch.equal(four.status, two.status) and torch.equal(four.iters, two.iters)
+        assert float((four.U - two.U).abs().max()) <= 1e-9 * max(1.0, float(two.U.abs().max()))
+        assert int((four.iters > 0).sum()) > 0  # (the box is active somewhere)
+        Uo, _, sto, _ = oracle.solve_workload(w, count=256)
+        assert (sto == 0).all() and (four.status[:256] == 0).all()
+        scale = np.maximum(1.0, np.abs(Uo).max(axis=1, keepdims=True))
+        assert (np.abs(four.U.cpu().numpy()[:256] - Uo) / scale).max() <= 1e-7
 
 
 def test_stress_campaign_with_drops():
