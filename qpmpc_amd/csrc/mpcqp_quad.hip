@@ -231,8 +231,8 @@ using namespace quad;
 // WPB: wavefronts per workgroup (they share nothing).
 // MODEL: the launch shares one factored model (mpcqp_factor_model: gA points at it); the per-problem vectors are x0, goal, targets and,
 //        optionally, the bounds e. No build, no factorisation: M, L^-T and the linear maps of h and w are read from the model.
-// GEN:   the build serves every cost and constraint layout of two rows per step (round 6): input rows D_k next to / instead of the state
-//        rows C_k, a stage cost w_x sum |x_k - xref_k|^2 (the Gram matrix accumulated over every Psi_k of the chain, as
+// GEN:   the build serves every cost and constraint layout of one to four rows per step (round 6): input rows D_k next to / instead of
+//        the state rows C_k, a stage cost w_x sum |x_k - xref_k|^2 (the Gram matrix accumulated over every Psi_k of the chain, as
 //        mpcqp_pair.hip's generic build does) -- the reference's own wheeled-inverted-pendulum example
 //        (examples/wheeled_inverted_pendulum.py:90-94: input box, stage + terminal cost) is of this kind.
 template <int NX, bool ORD, int WPB, bool SLIM, bool MODEL = false, bool GEN = false>
@@ -335,26 +335,33 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     {
         constexpr int nx = NX;
         const int nu = ka.nu, N = ka.N;
+        // rows per step: two in the lean build; one to four in the general one (a run-time number: the chain's loops over the rows of
+        // a step are unrolled four wide behind wavefront-uniform tests)
+        constexpr int MKG = GEN ? 4 : MK;
+        const int mk = GEN ? ka.mk : MK;
+        auto stepof = [&](int row) { return mk == 2 ? row >> 1 : (mk == 1 ? row : (mk == 4 ? row >> 2 : row / 3)); };
         const T *A = gA + prob * ka.A.batch_stride;
         const T *B = gB + prob * ka.B.batch_stride;
         const bool hasC = !GEN || gC != nullptr;
         const T *Cm = hasC ? gC + prob * ka.C.batch_stride : A;  // (no state rows: the lanes load valid addresses, the products are dropped)
         const T *x0 = gx0 + prob * ka.x0.batch_stride;
         const T *goal = ggoal ? ggoal + prob * ka.goal.batch_stride : nullptr;
-        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0, sC = (hasC && ka.C.step_stride) ? MK * nx : 0;
+        const int sA = ka.A.step_stride ? nx * nx : 0, sB = ka.B.step_stride ? nx * nu : 0, sC = (hasC && ka.C.step_stride) ? mk * nx : 0;
         const bool termP = ka.flags & MPCQP_P_TERMINAL, termQ = (ka.flags & MPCQP_Q_TERMINAL) && goal;
         // (GEN) input rows and the stage cost
         const T *Dm = (GEN && ka.D.ptr) ? (const T *)ka.D.ptr + prob * ka.D.batch_stride : nullptr;
         const T *tgt = (GEN && gtgt) ? gtgt + prob * ka.targets.batch_stride : nullptr;
-        const int sD = (GEN && ka.D.step_stride) ? MK * nu : 0;
+        const int sD = (GEN && ka.D.step_stride) ? mk * nu : 0;
         const bool stageP = GEN && (ka.flags & MPCQP_P_STAGE), stageQ = GEN && (ka.flags & MPCQP_Q_STAGE) && tgt;
-        constexpr int NAe = NX * NX, NEe = NAe + MK * NX;  // elements of [A_k | C_k]
+        constexpr int NAe = NX * NX, NEe = NAe + MKG * NX;  // elements of [A_k | C_k]
+        const int NEr = hasC ? NAe + mk * NX : NAe;          // ... that exist
         const bool col = (l < n);
         const int j = col ? (nu == 1 ? l : l / nu) : -1, ii = col ? l - j * nu : 0;  // (nu == 1: no division before the loads)
         // every load is issued before the first use: the whole build costs ONE HBM latency
         const int64_t eb = prob * ka.e.batch_stride;
-        const T eval0 = isc0 ? ge[eb + (row0 >> 1) * ka.e.step_stride + (row0 & 1)] : INF;
-        const T eval1 = isc1 ? ge[eb + (row1 >> 1) * ka.e.step_stride + (row1 & 1)] : INF;
+        const int kq0 = stepof(row0), kq1 = stepof(row1);
+        const T eval0 = isc0 ? ge[eb + kq0 * ka.e.step_stride + (row0 - kq0 * mk)] : INF;
+        const T eval1 = isc1 ? ge[eb + kq1 * ka.e.step_stride + (row1 - kq1 * mk)] : INF;
         // The free response Phi_k x0 rides in LANE 15 of the row: that lane's own column belongs to the horizon's last step (or to
         // no variable at all), so it is zero in every G_k and enters Psi_N only as B's column itself -- its registers are idle for the
         // whole chain. The lane starts from x0 instead of zero, the chain's FMAs propagate it with everyone else's columns, and a row's
@@ -373,15 +380,17 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         // the free response through the chain: when it owns a variable (n = 16: an input of the LAST step) the two rows of that step
         // fetch its entries of D straight from memory, behind the chain. Targets: lane e keeps xref element e, e + 16, e + 32, e + 48
         // (N nx <= 64), the chain fetches them as row broadcasts.
-        T dcol[MK] = {T(0), T(0)}, d15a = T(0), d15b = T(0), tg[4] = {T(0), T(0), T(0), T(0)};
+        T dcol[MKG], d15a = T(0), d15b = T(0), tg[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int i2 = 0; i2 < MKG; ++i2) dcol[i2] = T(0);
         if constexpr (GEN) {
             if (Dm) {
 #pragma unroll
-                for (int i2 = 0; i2 < MK; ++i2) dcol[i2] = (col && !xl15) ? Dm[j * sD + i2 * nu + ii] : T(0);
+                for (int i2 = 0; i2 < MKG; ++i2) dcol[i2] = (col && !xl15 && i2 < mk) ? Dm[j * sD + i2 * nu + ii] : T(0);
                 if (n == NV) {
                     const int j15 = nu == 1 ? NV - 1 : (NV - 1) / nu, i15 = NV - 1 - j15 * nu;
-                    d15a = (isc0 && (row0 >> 1) == j15) ? Dm[j15 * sD + (row0 & 1) * nu + i15] : T(0);
-                    d15b = (isc1 && (row1 >> 1) == j15) ? Dm[j15 * sD + (row1 & 1) * nu + i15] : T(0);
+                    d15a = (isc0 && kq0 == j15) ? Dm[j15 * sD + (row0 - kq0 * mk) * nu + i15] : T(0);
+                    d15b = (isc1 && kq1 == j15) ? Dm[j15 * sD + (row1 - kq1 * mk) * nu + i15] : T(0);
                 }
             }
             if (stageQ) {
@@ -394,7 +403,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         T opa[NV], opb[NV];
         {
             const int e0 = l, e1 = l + 16;
-            const bool ok0 = e0 < NEe, ok1 = e1 < NEe;
+            const bool ok0 = e0 < NEr, ok1 = e1 < NEr;
             const T *p0 = (e0 < NAe) ? A + e0 : Cm + (ok0 ? e0 - NAe : 0);
             const T *p1 = (e1 < NAe) ? A + e1 : Cm + (ok1 ? e1 - NAe : 0);
             const int s0 = (e0 < NAe) ? sA : sC, s1 = (e1 < NAe) ? sA : sC;
@@ -423,21 +432,37 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         static_for<0, NV>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             if (k < N) {
-                T g[MK];
-                static_for<0, MK>([&](auto i2c) {
-                    constexpr int i2 = decltype(i2c)::value;
-                    T acc = T(0);
-                    static_for<0, NX>([&](auto sc) {
-                        constexpr int s2 = decltype(sc)::value;
-                        mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
-                    });
-                    if constexpr (GEN) acc = (hasC ? acc : T(0)) + ((j == k) ? dcol[i2] : T(0));
-                    g[i2] = acc;
-                });
                 // (lane 15 stores C_k Phi_k x0 into column 15 of the image -- zero in G by construction --: the rows read their
                 // entry of it behind the chain)
+                if constexpr (!GEN) {
+                    T g[MK];
+                    static_for<0, MK>([&](auto i2c) {
+                        constexpr int i2 = decltype(i2c)::value;
+                        T acc = T(0);
+                        static_for<0, NX>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value;
+                            mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                        });
+                        g[i2] = acc;
+                    });
 #pragma unroll
-                for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
+                    for (int i2 = 0; i2 < MK; ++i2) Gimg[l * GS + k * MK + i2] = g[i2];
+                } else {
+                    static_for<0, MKG>([&](auto i2c) {
+                        constexpr int i2 = decltype(i2c)::value;
+                        if (i2 < mk) {  // (wavefront-uniform)
+                            T acc = T(0);
+                            if (hasC) {
+                                static_for<0, NX>([&](auto sc) {
+                                    constexpr int s2 = decltype(sc)::value;
+                                    mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                                });
+                            }
+                            acc += (j == k) ? dcol[i2] : T(0);
+                            Gimg[l * GS + k * mk + i2] = acc;
+                        }
+                    });
+                }
                 if constexpr (GEN && k >= 1) {
                     // stage cost on x_k: P += w_x Psi_k' Psi_k, q += w_x Psi_k' (Phi_k x0 - xref_k)  (mpc_qp.py:99-105, 129-149; lane 15's
                     // own column is zero in every Psi_k of the chain, its registers hold the free response)
@@ -1004,13 +1029,16 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
 static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_now(); }
 
 // the lean build (terminal cost only, state rows only: BASELINE configs 1, 2, 4) or the general one (GEN: input rows, stage cost)
-static bool quad_general(const KernelArgs &ka) { return !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE)); }
+static bool quad_general(const KernelArgs &ka)
+{
+    return ka.mk != MK || !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
+}
 
 bool quad_applies(const KernelArgs &ka)
 {
-    // the register-pipelined chain: two rows per step (state rows, input rows or both), nx = 2 .. 4; cold launches
+    // the register-pipelined chain: one to four rows per step (state rows, input rows or both), nx = 2 .. 4; cold launches
     if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 4) return false;
-    if (ka.mk != MK || (!ka.C.ptr && !ka.D.ptr)) return false;
+    if (ka.mk < 1 || ka.mk > 4 || (!ka.C.ptr && !ka.D.ptr)) return false;
     if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
     if (ka.warm_state || (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED)) return false;
     if (quad_general(ka) && ka.order) return false;  // (the general build has no instantiation with a pairing order)

@@ -257,14 +257,14 @@ def test_shared_model_with_bounds_per_problem_and_an_order():
 
 
 def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
-    """MPCQP_OPT_FOUR_PER_WAVE with three rows per step, with a warm state, next to another override or on another kernel's
+    """MPCQP_OPT_FOUR_PER_WAVE with five rows per step, with a warm state, next to another override or on another kernel's
     dimensions: MPCQP_EUNSUPPORTED before any launch."""
     from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
     from qpmpc_amd import workloads as W
     from stress_stagewise import random_ltv
 
     rng = np.random.default_rng(1)
-    w = random_ltv(rng, 8, 3, 1, 8, 3, 1.0)  # three rows per step
+    w = random_ltv(rng, 8, 3, 1, 6, 5, 1.0)  # five rows per step
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE)
     w = W.triple_integrator_batch(8)
@@ -278,11 +278,11 @@ def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
         solve_mpc_batch(W.to_batch_problem(wide), flags=_capi.OPT_FOUR_PER_WAVE)
 
 
-def _general_family(rng, batch, nx, nu, N, tight, rows, stage):
-    """random LTV problems with two rows per step: state rows, input rows or both; with or without a stage cost"""
+def _general_family(rng, batch, nx, nu, N, tight, rows, stage, mk=2):
+    """random LTV problems with mk rows per step: state rows, input rows or both; with or without a stage cost"""
     from stress_stagewise import random_ltv
 
-    w = random_ltv(rng, batch, nx, nu, N, 2, tight)
+    w = random_ltv(rng, batch, nx, nu, N, mk, tight)
     if rows == "c":
         w["D"] = None
     elif rows == "d":  # an input box per step: e > 0 keeps u = 0 feasible
@@ -320,6 +320,30 @@ def test_general_build_every_layout_against_the_oracle(nx, nu):
                 assert same.mean() >= 0.95, (N, tight, rows, stage, same.mean())
             drops += int((four.iters.cpu().numpy()[ok] > N * nu).sum())
     assert drops > 0 or nu > 2  # (the partial-step / drop path ran; horizons of at most five steps rarely get there)
+
+
+@pytest.mark.parametrize("mk", [1, 3, 4])
+def test_general_build_one_to_four_rows_per_step(mk):
+    """... and with one, three or four rows per step (m = N mk <= 32 rows): against the oracle and the two-per-wavefront kernel."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(50 + mk)
+    checked = 0
+    for nx, nu in ((2, 1), (3, 1), (4, 1), (3, 2), (4, 2)):
+        for N in range(2, min(16 // nu, 32 // mk) + 1):
+            tight, rows, stage = [(3.0, "cd", True), (0.1, "d", False), (0.05, "c", True), (0.2, "cd", False)][(N + nx) % 4]
+            w = _general_family(rng, 61, nx, nu, N, tight, rows, stage, mk)
+            bp = W.to_batch_problem(w)
+            four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+            torch.cuda.synchronize()
+            ok = _check_against_oracle(w, four)
+            checked += int(ok.sum())
+            if nx > 2:
+                two = solve_mpc_batch(bp, flags=_capi.OPT_TWO_PER_WAVE)
+                torch.cuda.synchronize()
+                assert ((four.iters == two.iters).cpu().numpy()[ok]).mean() >= 0.95, (nx, nu, N)
+    assert checked > 1000
 
 
 def test_the_reference_wip_example_at_4096_takes_the_kernel():
