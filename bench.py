@@ -819,6 +819,15 @@ def other_workloads():
     out["midsize_ltv_nx8_nu2_n40_m80_f64_batch4096"] = rate(PreparedSolve(bpm).launch, 4096, 5)
     out["midsize_ltv_nx8_nu2_n40_m80_f64_batch4096_condensed_kernels"] = rate(
         PreparedSolve(bpm, flags=_capi.OPT_FORCE_CONDENSED).launch, 4096, 3)
+    # the reference's own example problem (examples/wheeled_inverted_pendulum.py:90-94: N = 12, input box, stage + terminal cost), 4096
+    # states: the four-per-wavefront kernel's general build since round 6 (the two-per-wavefront kernel's generic build before)
+    wr = W.wip_batch(4096, N=12, sampling_period=0.1, seed=5)
+    wr["x0"][:1024, 1] += 0.4
+    tsr = np.stack([wr["pendulum"].target_states(x, 0.5) for x in wr["x0"]])
+    wr["goal"], wr["targets"] = tsr[:, -4:], tsr[:, :-4]
+    bpr = W.to_batch_problem(wr)
+    out["reference_wip_example_n12_batch4096"] = rate(PreparedSolve(bpr).launch, 4096, 200)
+    out["reference_wip_example_n12_batch4096_two_per_wavefront"] = rate(PreparedSolve(bpr, flags=_capi.OPT_TWO_PER_WAVE).launch, 4096, 200)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
     walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)

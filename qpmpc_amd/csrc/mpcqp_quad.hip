@@ -1,10 +1,12 @@
-// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {3, 4},
-// float64, terminal cost only, state rows only, two rows per step): FOUR PROBLEMS PER WAVEFRONT, one per 16-lane DPP row.
+// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {2, 3, 4},
+// float64, one to four rows per step): FOUR PROBLEMS PER WAVEFRONT, one per 16-lane DPP row.
 //
 // Replaces the same reference code as mpcqp_pair.hip (qpmpc/mpc_qp.py:53-149 for the build, qpsolvers.solve_problem at
-// qpmpc/solve_mpc.py:43 for the solve) for the cold fused build+solve of BASELINE configs 1, 2 and 4 (nx = 3, nu = 1,
-// N = 16 -> n = 16, m = 32). Everything else the small-problem path serves (stage costs, input rows, shared models, warm
-// starts, seed steps) stays on mpcqp_pair.hip, which is also this kernel's cross-check (MPCQP_OPT_TWO_PER_WAVE).
+// qpmpc/solve_mpc.py:43 for the solve) for cold fused build+solve launches: BASELINE configs 1, 2 and 4 (nx = 3, nu = 1,
+// N = 16 -> n = 16, m = 32; terminal cost only, two state rows per step: the lean build) and, since round 6, every other
+// cost / constraint layout of these sizes (input rows, stage cost with per-step targets, mk = 1 .. 4, nx = 2: the general
+// build, template parameter GEN -- the reference's examples/wheeled_inverted_pendulum.py:90-94 is of that kind). Warm
+// starts and seed steps stay on mpcqp_pair.hip, which is also this kernel's cross-check (MPCQP_OPT_TWO_PER_WAVE).
 //
 // Why four per wavefront (round-4 counters on the pair kernel, profiles/r04_pair_m_rocprof_summary.txt): 8.17 M vector
 // instructions per 4096-problem launch of which 4.22 M are float64 arithmetic -- 48 % of vector issue is masks, selects,

@@ -35,6 +35,23 @@ def _lean_family(rng, batch, nx, nu, N, tight, lti):
     return w
 
 
+def shard(w, count):
+    """the first `count` problems of a workload (the oracle is a CPU loop)"""
+    out = dict(w)
+    for k in ("A", "B", "C", "D", "e", "x0", "goal", "targets"):
+        v = w.get(k)
+        if v is not None and getattr(v, "ndim", 0) >= 1 and v.shape[0] == len(w["x0"]):
+            out[k] = v[:count]
+    return out
+
+
+class _first:
+    """the first `count` problems of a plan"""
+
+    def __init__(self, plan, count):
+        self.U, self.status = plan.U[:count], plan.status[:count]
+
+
 def _check_against_oracle(w, plan, tol=1e-7):
     U, st = plan.U.cpu().numpy(), plan.status.cpu().numpy()
     Uo, lamo, sto, _ = oracle.solve_workload(w)
@@ -373,11 +390,43 @@ def test_the_reference_wip_example_at_4096_takes_the_kernel():
         assert (np.abs(four.U.cpu().numpy()[:256] - Uo) / scale).max() <= 1e-7
 
 
+def test_double_integrators_take_the_kernel_by_default_from_2049_problems():
+    """nx = 2 has no two-per-wavefront instantiation: the dispatch hands batches of more than two problems per SIMD to this kernel
+    directly (bit-equal to the forced launch) and keeps smaller ones where they were; both against the oracle."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(8)
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    for batch in (2 * simds + 1, 300):
+        w = _general_family(rng, batch, 2, 1, 14, 0.2, "cd", True)
+        bp = W.to_batch_problem(w)
+        auto = solve_mpc_batch(bp)
+        four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+        torch.cuda.synchronize()
+        if batch > 2 * simds:
+            assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters)
+        else:
+            assert torch.equal(auto.status, four.status)
+            assert float((auto.U - four.U).abs().max()) <= 1e-8 * max(1.0, float(four.U.abs().max()))
+        _check_against_oracle(shard(w, 256), _first(four, 256))
+
+
 def test_stress_campaign_with_drops():
     """tools/stress_pair.py's lean rounds forced through this kernel: statuses equal to the C oracle's and to the one-per-wavefront
     and workgroup kernels', plans within 1e-7 relative."""
     from stress_pair import run
 
     worst, flagged, drops = run(24, 96, seed=20260930, verbose=False, lean_only=True, flags_lean=4096)
+    assert flagged == 0, (worst, flagged)
+    assert worst < 1e-7 and drops > 0
+
+
+def test_stress_campaign_through_the_general_build():
+    """... and tools/stress_pair.py's other rounds (stage costs, input rows, one to four rows per step, nx = 3, 4; tight enough for
+    partial steps and drops) forced through the kernel's general build: the same checks."""
+    from stress_pair import run
+
+    worst, flagged, drops = run(32, 96, seed=20261001, verbose=False, flags_lean=4096, flags_other=4096)
     assert flagged == 0, (worst, flagged)
     assert worst < 1e-7 and drops > 0

@@ -14,9 +14,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from stress_stagewise import random_ltv  # noqa
 
 
-def run(rounds, batch, seed=4242, verbose=True, lean_only=False, flags_lean=0):
+def run(rounds, batch, seed=4242, verbose=True, lean_only=False, flags_lean=0, flags_other=0):
     """lean_only: every round draws the lean family; flags_lean: MpcqpSolveOpts.flags for those rounds (MPCQP_OPT_FOUR_PER_WAVE forces
-    the four-per-wavefront kernel, which the dispatch would only take for thousands of problems)."""
+    the four-per-wavefront kernel, which the dispatch would only take for thousands of problems); flags_other: for the other rounds
+    (stage costs, input rows, one to four rows per step: that kernel's general build)."""
     rng = np.random.default_rng(seed)
     worst, bad, drops = 0.0, 0, 0
     for it in range(rounds):
@@ -43,7 +44,7 @@ def run(rounds, batch, seed=4242, verbose=True, lean_only=False, flags_lean=0):
         if mode == 1 and rng.random() < 0.5:  # state rows only
             w["D"] = None
         bp = W.to_batch_problem(w)
-        fl = _capi.OPT_SEED_VIOLATED if os.environ.get("STRESS_SEEDED") else (flags_lean if mode == 3 else 0)  # (STRESS_SEEDED: the seeded start)
+        fl = _capi.OPT_SEED_VIOLATED if os.environ.get("STRESS_SEEDED") else (flags_lean if mode == 3 else flags_other)  # (STRESS_SEEDED: the seeded start)
         plan = solve_mpc_batch(bp, flags=fl)
         one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
         lds = solve_mpc_batch(bp, flags=_capi.OPT_FORCE_LDS)
@@ -88,5 +89,6 @@ if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     worst, bad, drops = run(rounds, batch, seed=int(os.environ.get("STRESS_SEED", "4242")), lean_only=bool(os.environ.get("STRESS_LEAN")),
-                            flags_lean=_capi.OPT_FOUR_PER_WAVE if os.environ.get("STRESS_FOUR") else 0)
+                            flags_lean=_capi.OPT_FOUR_PER_WAVE if os.environ.get("STRESS_FOUR") else 0,
+                            flags_other=_capi.OPT_FOUR_PER_WAVE if os.environ.get("STRESS_FOUR") else 0)
     print("worst rel diff", worst, "rounds flagged", bad, "problems with more trips than variables", drops)
