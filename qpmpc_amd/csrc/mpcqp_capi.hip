@@ -289,7 +289,8 @@ template <int MODE>
 int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t batch, hipStream_t st)
 {
     if (!force_lds(ka.opt_flags)) {
-        // (nx = 2 has no two-per-wavefront instantiation: the four-per-wavefront kernel takes it where it pays, on its own)
+        // (nx = 2 has no two-per-wavefront instantiation: the four-per-wavefront kernel takes it where it pays -- the general layouts at
+        // every batch size, the lean one from more than two problems per SIMD --, on its own)
         if (MODE == MODE_FUSED && dtype == MPCQP_F64 && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && ka.nx == 2 && quad_eligible(ka, batch))
             return launch_quad(ka, batch, st);
         if (!(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE, dtype)) return launch_pair(ka, batch, st);

@@ -1050,7 +1050,11 @@ bool quad_applies(const KernelArgs &ka)
 bool quad_eligible(const KernelArgs &ka, int64_t batch)
 {
     if (!quad_applies(ka) || (ka.opt_flags & MPCQP_OPT_TWO_PER_WAVE)) return false;
-    return (ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) || quad_pays(batch);
+    // (the general build at every batch size: the two-per-wavefront kernel's generic build stages its operands in LDS and is the slower
+    // one from a single wavefront up -- the reference's WIP example, N = 12: 256 problems 13.2 against 19.3 us, 2048: 14.2 / 21.8,
+    // 4096: 15.1 / 25.8; a random family with C + D rows and a stage cost, 12 iterations: 32.5 / 40.3, 39.5 / 49.7, 45.3 / 61.6;
+    // tools/ab_quad_general.py)
+    return (ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) || quad_general(ka) || quad_pays(batch);
 }
 
 template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, hipStream_t st)

@@ -390,26 +390,34 @@ def test_the_reference_wip_example_at_4096_takes_the_kernel():
         assert (np.abs(four.U.cpu().numpy()[:256] - Uo) / scale).max() <= 1e-7
 
 
-def test_double_integrators_take_the_kernel_by_default_from_2049_problems():
-    """nx = 2 has no two-per-wavefront instantiation: the dispatch hands batches of more than two problems per SIMD to this kernel
-    directly (bit-equal to the forced launch) and keeps smaller ones where they were; both against the oracle."""
+def test_default_dispatch_of_the_general_layouts_and_of_double_integrators():
+    """The general layouts (input rows, stage cost, mk != 2) take this kernel at EVERY batch size (its build beats the two-per-wavefront
+    kernel's generic one from a single wavefront up, tools/ab_quad_general.py); the lean layout from more than two problems per SIMD.
+    nx = 2 has no two-per-wavefront instantiation and is dispatched directly. Default launches are bit-equal to the forced ones;
+    plans against the oracle."""
     from qpmpc_amd import _capi, solve_mpc_batch
     from qpmpc_amd import workloads as W
 
     rng = np.random.default_rng(8)
     simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
-    for batch in (2 * simds + 1, 300):
-        w = _general_family(rng, batch, 2, 1, 14, 0.2, "cd", True)
+    cases = [(2, 1, 14, "cd", True, 300), (2, 2, 7, "d", False, 5), (3, 1, 12, "d", True, 1), (4, 2, 6, "cd", True, 700),
+             (2, 1, 16, "c", False, 2 * simds + 1)]  # (the last one: the lean layout with nx = 2 at the size the rule takes it)
+    for nx, nu, N, rows, stage, batch in cases:
+        w = _general_family(rng, batch, nx, nu, N, 0.2, rows, stage)
         bp = W.to_batch_problem(w)
         auto = solve_mpc_batch(bp)
         four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
         torch.cuda.synchronize()
-        if batch > 2 * simds:
-            assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters)
-        else:
-            assert torch.equal(auto.status, four.status)
-            assert float((auto.U - four.U).abs().max()) <= 1e-8 * max(1.0, float(four.U.abs().max()))
-        _check_against_oracle(shard(w, 256), _first(four, 256))
+        assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters) and torch.equal(auto.status, four.status)
+        count = min(batch, 256)
+        _check_against_oracle(shard(w, count), _first(four, count))
+    # the lean layout of a small batch stays where it was (another kernel): same plans
+    w = _general_family(rng, 300, 2, 1, 16, 0.2, "c", False)
+    bp = W.to_batch_problem(w)
+    auto, four = solve_mpc_batch(bp), solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+    torch.cuda.synchronize()
+    assert torch.equal(auto.status, four.status)
+    assert float((auto.U - four.U).abs().max()) <= 1e-8 * max(1.0, float(four.U.abs().max()))
 
 
 def test_stress_campaign_with_drops():
