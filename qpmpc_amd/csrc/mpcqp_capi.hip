@@ -772,7 +772,8 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
         KernelArgs kb = ka;
         kb.opt_flags |= kOptSecondOpinion;
         kb.probe = nullptr;
-        return launch_stagew(kb, dims->dtype, maxq2, batch, workspace, st);
+        rc = launch_stagew(kb, dims->dtype, maxq2, batch, workspace, st);
+        return rc == MPCQP_ETOOLARGE ? 0 : rc;  // (a horizon beyond the wide kernel's 32-bit offsets: the narrow kernel's verdicts stand)
     }
     if (use_stage_long(ka, dims->dtype)) {
         const int maxq = stage_default_maxq(ka);
@@ -905,7 +906,8 @@ int mpcqp_stagewise_solve_batch(const MpcqpDims *dims, const MpcqpProblem *probl
     KernelArgs kb = ka;
     kb.opt_flags |= kOptSecondOpinion;
     kb.probe = nullptr;
-    return launch_stagew(kb, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
+    rc = launch_stagew(kb, dims->dtype, maxq, batch, workspace, (hipStream_t)stream);
+    return rc == MPCQP_ETOOLARGE ? 0 : rc;  // (a horizon beyond the wide kernel's 32-bit offsets: the narrow kernel's verdicts stand)
 }
 
 int mpcqp_model_bytes(const MpcqpDims *dims, size_t *bytes)
