@@ -1,10 +1,10 @@
-// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {2, 3, 4},
+// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {2, ..., 6},
 // float64, one to four rows per step): FOUR PROBLEMS PER WAVEFRONT, one per 16-lane DPP row.
 //
 // Replaces the same reference code as mpcqp_pair.hip (qpmpc/mpc_qp.py:53-149 for the build, qpsolvers.solve_problem at
 // qpmpc/solve_mpc.py:43 for the solve) for cold fused build+solve launches: BASELINE configs 1, 2 and 4 (nx = 3, nu = 1,
 // N = 16 -> n = 16, m = 32; terminal cost only, two state rows per step: the lean build) and, since round 6, every other
-// cost / constraint layout of these sizes (input rows, stage cost with per-step targets, mk = 1 .. 4, nx = 2: the general
+// cost / constraint layout of these sizes (input rows, stage cost with per-step targets, mk = 1 .. 4, nx = 2, 5, 6: the general
 // build, template parameter GEN -- the reference's examples/wheeled_inverted_pendulum.py:90-94 is of that kind). Warm
 // starts and seed steps stay on mpcqp_pair.hip, which is also this kernel's cross-check (MPCQP_OPT_TWO_PER_WAVE).
 //
@@ -382,7 +382,9 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         // the free response through the chain: when it owns a variable (n = 16: an input of the LAST step) the two rows of that step
         // fetch its entries of D straight from memory, behind the chain. Targets: lane e keeps xref element e, e + 16, e + 32, e + 48
         // (N nx <= 64), the chain fetches them as row broadcasts.
-        T dcol[MKG], d15a = T(0), d15b = T(0), tg[4] = {T(0), T(0), T(0), T(0)};
+        T dcol[MKG], d15a = T(0), d15b = T(0), tg[NX];  // (targets: N nx <= 16 nx values, one per lane and register)
+#pragma unroll
+        for (int u = 0; u < NX; ++u) tg[u] = T(0);
 #pragma unroll
         for (int i2 = 0; i2 < MKG; ++i2) dcol[i2] = T(0);
         if constexpr (GEN) {
@@ -397,25 +399,25 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
             }
             if (stageQ) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tg[u] = (l + 16 * u < N * NX) ? tgt[l + 16 * u] : T(0);
+                for (int u = 0; u < NX; ++u) tg[u] = (l + 16 * u < N * NX) ? tgt[l + 16 * u] : T(0);
             }
         }
         // lane e of the row keeps element e (and e + 16) of [A_k | C_k] for every step k, straight from HBM; the chain
         // fetches an operand as a DPP row broadcast (lanes without an element load a valid address and are never read)
-        T opa[NV], opb[NV];
-        {
-            const int e0 = l, e1 = l + 16;
-            const bool ok0 = e0 < NEr, ok1 = e1 < NEr;
-            const T *p0 = (e0 < NAe) ? A + e0 : Cm + (ok0 ? e0 - NAe : 0);
-            const T *p1 = (e1 < NAe) ? A + e1 : Cm + (ok1 ? e1 - NAe : 0);
-            const int s0 = (e0 < NAe) ? sA : sC, s1 = (e1 < NAe) ? sA : sC;
+        constexpr int NOP = (NEe + 15) / 16;  // operand registers per step: two up to nx = 4, three / four for nx = 5 / 6
+        T op[NOP][NV];
+        static_for<0, NOP>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const int e = l + 16 * r;
+            const bool ok = e < NEr;
+            const T *p = (e < NAe) ? A + e : Cm + (ok ? e - NAe : 0);
+            const int st = (e < NAe) ? sA : sC;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int kc = (k < N) ? k : N - 1;
-                opa[k] = p0[kc * s0];
-                opb[k] = (NEe > 16) ? p1[kc * s1] : T(0);
+                op[r][k] = p[kc * st];
             }
-        }
+        });
         tick(8);
         const T wu = (T)ka.wu;
         qa = T(0);
@@ -423,12 +425,9 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         for (int b = 0; b < NV; ++b) Pr[b] = (l == b) ? (col ? wu : T(1)) : T(0);
         tick(9);
         // acc += (element IDX of [A_k | C_k]) * xx
-        auto mac = [&](auto idx, T &acc, const T &oa, const T &ob, T xx) {
-            constexpr int IDX = decltype(idx)::value;
-            if constexpr (IDX < 16)
-                fmac_bcast<IDX>(acc, oa, xx);
-            else
-                fmac_bcast<IDX - 16>(acc, ob, xx);
+        auto mac = [&](auto idx, auto kc_, T &acc, T xx) {
+            constexpr int IDX = decltype(idx)::value, K = decltype(kc_)::value;
+            fmac_bcast<IDX % 16>(acc, op[IDX / 16][K], xx);
         };
         // [G_k; Psi_{k+1}] = [C_k; A_k] Psi_k (column l in lane l; lane 15: [C_k Phi_k x0; Phi_{k+1} x0])
         static_for<0, NV>([&](auto kk) {
@@ -443,7 +442,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                         T acc = T(0);
                         static_for<0, NX>([&](auto sc) {
                             constexpr int s2 = decltype(sc)::value;
-                            mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                            mac(ic<NAe + i2 * NX + s2>{}, kk, acc, v[s2]);
                         });
                         g[i2] = acc;
                     });
@@ -457,7 +456,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                             if (hasC) {
                                 static_for<0, NX>([&](auto sc) {
                                     constexpr int s2 = decltype(sc)::value;
-                                    mac(ic<NAe + i2 * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                                    mac(ic<NAe + i2 * NX + s2>{}, kk, acc, v[s2]);
                                 });
                             }
                             acc += (j == k) ? dcol[i2] : T(0);
@@ -475,7 +474,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                             constexpr int te = k * NX + s2;
                             T src = xl15 ? T(0) : v[s2];
                             const T t = wxs * src;
-                            if (stageQ) qa += t * (row_bcast<NV - 1>(v[s2]) - row_bcast<te % 16>(tg[(te / 16) % 4]));
+                            if (stageQ) qa += t * (row_bcast<NV - 1>(v[s2]) - row_bcast<te % 16>(tg[te / 16]));
                             if (stageP) {
                                 dpp_ready(src);
                                 static_for<0, NV>([&](auto bc) { fmac_bcast<decltype(bc)::value>(Pr[decltype(bc)::value], src, t); });
@@ -492,7 +491,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                     T acc = hk * bcol[r];
                     static_for<0, NX>([&](auto sc) {
                         constexpr int s2 = decltype(sc)::value;
-                        mac(ic<r * NX + s2>{}, acc, opa[k], opb[k], v[s2]);
+                        mac(ic<r * NX + s2>{}, kk, acc, v[s2]);
                     });
                     w[r] = acc;
                 });
@@ -1033,13 +1032,13 @@ static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_
 // the lean build (terminal cost only, state rows only: BASELINE configs 1, 2, 4) or the general one (GEN: input rows, stage cost)
 static bool quad_general(const KernelArgs &ka)
 {
-    return ka.mk != MK || !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
+    return ka.nx > 4 || ka.mk != MK || !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
 }
 
 bool quad_applies(const KernelArgs &ka)
 {
-    // the register-pipelined chain: one to four rows per step (state rows, input rows or both), nx = 2 .. 4; cold launches
-    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 4) return false;
+    // the register-pipelined chain: one to four rows per step (state rows, input rows or both), nx = 2 .. 6; cold launches
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 6) return false;
     if (ka.mk < 1 || ka.mk > 4 || (!ka.C.ptr && !ka.D.ptr)) return false;
     if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
     if (ka.warm_state || (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED)) return false;
@@ -1069,7 +1068,7 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
     };
     // one round (at most one wavefront per SIMD): the roomy carve; several rounds: the slim one, two wavefronts per SIMD
     const bool slim = waves > device_simds_now();
-    if (quad_general(ka)) {
+    if (NX > 4 || quad_general(ka)) {  // (nx = 5, 6: the general build only -- three / four operand registers per step)
         auto gen = [&](auto kern, size_t per) {
             hipLaunchKernelGGL(kern, dim3((unsigned)waves), dim3(64), per * 4 * sizeof(double), st, (const double *)ka.A.ptr,
                                (const double *)ka.B.ptr, (const double *)ka.C.ptr, (const double *)ka.e.ptr, (const double *)ka.x0.ptr,
@@ -1080,22 +1079,30 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
             gen(mpcqp_quad_kernel<NX, false, 1, true, false, true>, Carve<true>::PER);
         else
             gen(mpcqp_quad_kernel<NX, false, 1, false, false, true>, Carve<false>::PER);
-    } else if (ka.order) {
-        if (slim)
-            go(mpcqp_quad_kernel<NX, true, 1, true>, Carve<true>::PER);
-        else
-            go(mpcqp_quad_kernel<NX, true, 1, false>, Carve<false>::PER);
-    } else if (slim) {
-        go(mpcqp_quad_kernel<NX, false, 1, true>, Carve<true>::PER);
-    } else {
-        go(mpcqp_quad_kernel<NX, false, 1, false>, Carve<false>::PER);
+    } else if constexpr (NX <= 4) {
+        if (ka.order) {
+            if (slim)
+                go(mpcqp_quad_kernel<NX, true, 1, true>, Carve<true>::PER);
+            else
+                go(mpcqp_quad_kernel<NX, true, 1, false>, Carve<false>::PER);
+        } else if (slim) {
+            go(mpcqp_quad_kernel<NX, false, 1, true>, Carve<true>::PER);
+        } else {
+            go(mpcqp_quad_kernel<NX, false, 1, false>, Carve<false>::PER);
+        }
     }
     return (int)hipGetLastError();
 }
 
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
-    return ka.nx == 2 ? launch_quad_t<2>(ka, batch, st) : ka.nx == 3 ? launch_quad_t<3>(ka, batch, st) : launch_quad_t<4>(ka, batch, st);
+    switch (ka.nx) {
+    case 2: return launch_quad_t<2>(ka, batch, st);
+    case 3: return launch_quad_t<3>(ka, batch, st);
+    case 4: return launch_quad_t<4>(ka, batch, st);
+    case 5: return launch_quad_t<5>(ka, batch, st);
+    default: return launch_quad_t<6>(ka, batch, st);
+    }
 }
 
 // Shared-model launches (mpcqp_solve_model_batch / _bounds_batch): any cost and constraint layout the model was factored from, as
