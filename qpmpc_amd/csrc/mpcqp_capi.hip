@@ -139,9 +139,11 @@ bool use_stagew_auto(const KernelArgs &ka, int dtype)
     // Round 3: ... and what DOES fit on chip but is no small problem (n > 24): measured on batches of 512 random LTV problems
     // (tools/probe_f32_dispatch.py), the stage-wise kernel is 2-2.5x the mid-size / LDS condensed kernels in float64 (nx = 6 .. 12,
     // n = 37 .. 64: 590-980 us against 1180-2170 us) and 2-3x in float32, where it is also 5-30x closer to the float64 oracle
-    // (the condensed float32 path squares the conditioning into P: 1e-3 at n ~ 130). Small problems (n <= 24) stay on chip.
+    // (the condensed float32 path squares the conditioning into P: 1e-3 at n ~ 130). Small problems stay on chip: up to n = 20 since
+    // round 6 (4096 problems, float64, default / wide stage-wise, us: (nx, nu, N) = (8, 2, 10) n = 20: 824 / 843; (8, 2, 12) n = 24:
+    // 1471 / 1087; (12, 4, 6): 860 / 490; (7, 1, 24): 2332 / 1123; (6, 2, 12): 683 / 535; n <= 16: the on-chip kernels by 1.2-2.3x).
     return !(ka.opt_flags & override_bits) && !(ka.warm_state && ka.warm_start == MPCQP_WARM_OPERATOR) && stagew_supported(ka, dtype) && ka.m >= 1 &&
-           ((ka.n > 24 && (dtype == MPCQP_F64 || ka.nx <= 12)) || !fits_on_chip(ka, true, true, MODE_FUSED, dtype));
+           ((ka.n > 20 && (dtype == MPCQP_F64 || ka.nx <= 12)) || !fits_on_chip(ka, true, true, MODE_FUSED, dtype));
     // (float32 with nx > 12 -- the LDS-tiled Riccati recursion -- stays on chip while it fits: on borderline problems of that size
     // the condensed float32 kernel was the closer one, 1e-3 against 3e-3)
 }
