@@ -160,10 +160,10 @@ typedef struct MpcqpProblem {
                                  same minimiser), see csrc/mpcqp_stagew.hip. */
 
 #define MPCQP_OPT_TWO_PER_WAVE 2048 /* small-problem fused kernel: keep TWO problems per wavefront (mpcqp_pair.hip) where the
-                                 dispatch would put FOUR on one (mpcqp_quad.hip: cold launches of problems with nx <= 6 and at
+                                 dispatch would put FOUR on one (mpcqp_quad.hip: cold launches of problems with nx <= 16 and at
                                  most four rows per step -- BASELINE configs 1, 2, 4, the reference's WIP example -- from a few
                                  thousand problems up, see MPCQP_OPT_FOUR_PER_WAVE). Same method, same pivots: a cross-check
-                                 (nx = 2, 5, 6 have no two-per-wavefront instantiation: the flag sends them to the one-per-wavefront kernel). */
+                                 (nx = 2 and nx >= 5 have no two-per-wavefront instantiation: the flag sends them to the one-per-wavefront kernel). */
 #define MPCQP_OPT_STAGE_GENERAL 8192 /* mpcqp_stagewise_solve_batch: take the general stage-wise kernel (float64, nx <= 32, nu <= 8) also
                                  where the narrow or the wide one applies (a cross-check; until ABI 10 the formulation the host
                                  side re-solved through, when only this kernel kept a thin QR factor of the active rows -- the
@@ -172,7 +172,7 @@ typedef struct MpcqpProblem {
                                  takes it from more than two problems per SIMD of the device up: 2049 and more on an MI355X, where a
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
                                  rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way).
-                                 MPCQP_EUNSUPPORTED where the kernel does not apply (nx > 6, more than four rows per step, warm
+                                 MPCQP_EUNSUPPORTED where the kernel does not apply (nx > 16, more than four rows per step, warm
                                  starts, seed steps, a pairing order together with input rows / a stage cost). The shared-model solves (mpcqp_solve_model_batch / _bounds_batch) take
                                  it too, with the same batch-size rule, for every model with n <= 16, m <= 32. */
 

@@ -1,10 +1,10 @@
-// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx in {2, ..., 6},
+// mpcqp_quad.hip -- gfx950 kernel for SMALL problems (n <= 16 variables, m <= 32 inequality rows, nx <= 16,
 // float64, one to four rows per step): FOUR PROBLEMS PER WAVEFRONT, one per 16-lane DPP row.
 //
 // Replaces the same reference code as mpcqp_pair.hip (qpmpc/mpc_qp.py:53-149 for the build, qpsolvers.solve_problem at
 // qpmpc/solve_mpc.py:43 for the solve) for cold fused build+solve launches: BASELINE configs 1, 2 and 4 (nx = 3, nu = 1,
 // N = 16 -> n = 16, m = 32; terminal cost only, two state rows per step: the lean build) and, since round 6, every other
-// cost / constraint layout of these sizes (input rows, stage cost with per-step targets, mk = 1 .. 4, nx = 2, 5, 6: the general
+// cost / constraint layout of these sizes (input rows, stage cost with per-step targets, mk = 1 .. 4, nx = 2, 5 .. 16: the general
 // build, template parameter GEN -- the reference's examples/wheeled_inverted_pendulum.py:90-94 is of that kind). Warm
 // starts and seed steps stay on mpcqp_pair.hip, which is also this kernel's cross-check (MPCQP_OPT_TWO_PER_WAVE).
 //
@@ -335,7 +335,10 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
     T qa;
     T g15a = T(0), g15b = T(0);
     {
-        constexpr int nx = NX;
+        // WIDE (round 6, NX = 8 / 12 / 16 as padded sizes for nx = 7 .. 16): the operands of a step do not fit registers for the whole
+        // horizon -- they are streamed, two steps ahead of the chain, and the chain is a loop over the steps (see below)
+        constexpr bool WIDE = GEN && NX > 6;
+        const int nx = WIDE ? ka.nx : NX;
         const int nu = ka.nu, N = ka.N;
         // rows per step: two in the lean build; one to four in the general one (a run-time number: the chain's loops over the rows of
         // a step are unrolled four wide behind wavefront-uniform tests)
@@ -373,11 +376,11 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         T v[NX], gref[NX], bcol[NX];
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
-            v[s] = xl15 ? x0[s] : T(0);
-            gref[s] = termQ ? goal[s] : T(0);
+            v[s] = (xl15 && s < nx) ? x0[s < nx ? s : 0] : T(0);
+            gref[s] = (termQ && s < nx) ? goal[s < nx ? s : 0] : T(0);
         }
 #pragma unroll
-        for (int r = 0; r < NX; ++r) bcol[r] = col ? B[j * sB + r * nu + ii] : T(0);
+        for (int r = 0; r < NX; ++r) bcol[r] = (col && r < nx) ? B[j * sB + (r < nx ? r : 0) * nu + ii] : T(0);
         // (GEN) this lane's column of D_j: the G entries of its variable, rows (j, 0) and (j, 1). Lane 15's cells of the image carry
         // the free response through the chain: when it owns a variable (n = 16: an input of the LAST step) the two rows of that step
         // fetch its entries of D straight from memory, behind the chain. Targets: lane e keeps xref element e, e + 16, e + 32, e + 48
@@ -397,11 +400,12 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                     d15b = (isc1 && kq1 == j15) ? Dm[j15 * sD + (row1 - kq1 * mk) * nu + i15] : T(0);
                 }
             }
-            if (stageQ) {
+            if (stageQ && !WIDE) {
 #pragma unroll
                 for (int u = 0; u < NX; ++u) tg[u] = (l + 16 * u < N * NX) ? tgt[l + 16 * u] : T(0);
             }
         }
+        if constexpr (!WIDE) {
         // lane e of the row keeps element e (and e + 16) of [A_k | C_k] for every step k, straight from HBM; the chain
         // fetches an operand as a DPP row broadcast (lanes without an element load a valid address and are never read)
         constexpr int NOP = (NEe + 15) / 16;  // operand registers per step: two up to nx = 4, three / four for nx = 5 / 6
@@ -499,6 +503,98 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
                 for (int r = 0; r < NX; ++r) v[r] = w[r];
             }
         });
+        } else {
+        tick(8);
+        const T wu = (T)ka.wu;
+        qa = T(0);
+#pragma unroll
+        for (int b = 0; b < NV; ++b) Pr[b] = (l == b) ? (col ? wu : T(1)) : T(0);
+        tick(9);
+        // ---- streamed operands. Element e of a step's [A_k (NX x NX) | C_k (4 x NX) | xref_k (NX)] -- padded to NX, entries beyond nx /
+        // mk read as zero -- sits in lane e % 16 of register e / 16; every register holds one kind of element (NX^2 and 4 NX are
+        // multiples of 16). Two steps' registers are alive: step k + 2 is requested when step k has been consumed.
+        constexpr int NAw = NX * NX, NCw = 4 * NX, NEw = NAw + NCw + NX, NOPW = (NEw + 15) / 16;
+        T opw[2][NOPW];
+        auto fetch = [&](auto dc, int k) {
+            constexpr int d = decltype(dc)::value;
+            const int kc = k < N ? k : N - 1;
+            static_for<0, NOPW>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int e0 = 16 * r;
+                const int e = e0 + l;
+                T val;
+                if constexpr (e0 < NAw) {
+                    const int rr = e / NX, ss = e - rr * NX;
+                    const bool ok = rr < nx && ss < nx;
+                    val = A[kc * sA + (ok ? rr * nx + ss : 0)];
+                    val = ok ? val : T(0);
+                } else if constexpr (e0 < NAw + NCw) {
+                    const int e2 = e - NAw, i2 = e2 / NX, ss = e2 - i2 * NX;
+                    const bool ok = hasC && i2 < mk && ss < nx;
+                    val = Cm[ok ? kc * sC + i2 * nx + ss : 0];
+                    val = ok ? val : T(0);
+                } else {
+                    const int ss = e - NAw - NCw;
+                    const bool ok = stageQ && ss < nx;
+                    val = ok ? tgt[kc * nx + ss] : T(0);
+                }
+                opw[d][r] = val;
+            });
+        };
+        fetch(ic<0>{}, 0);
+        fetch(ic<1>{}, 1);
+        const T wxs = (T)ka.wx;
+        auto cstep = [&](auto dc, int k) {
+            constexpr int d = decltype(dc)::value;
+            // G rows of step k from Psi_k (lane 15: C_k Phi_k x0)
+            static_for<0, 4>([&](auto i2c) {
+                constexpr int i2 = decltype(i2c)::value;
+                if (i2 < mk) {  // (wavefront-uniform)
+                    T acc = T(0);
+                    if (hasC) {
+                        static_for<0, NX>([&](auto sc) {
+                            constexpr int s2 = decltype(sc)::value, E = NAw + i2 * NX + s2;
+                            fmac_bcast<E % 16>(acc, opw[d][E / 16], v[s2]);
+                        });
+                    }
+                    acc += (j == k) ? dcol[i2] : T(0);
+                    Gimg[l * GS + k * mk + i2] = acc;
+                }
+            });
+            // stage cost on x_k (k >= 1)
+            if (k >= 1 && (stageP || stageQ)) {
+                static_for<0, NX>([&](auto sc) {
+                    constexpr int s2 = decltype(sc)::value, E = NAw + NCw + s2;
+                    T src = xl15 ? T(0) : v[s2];
+                    const T t = wxs * src;
+                    if (stageQ) qa += t * (row_bcast<NV - 1>(v[s2]) - row_bcast<E % 16>(opw[d][E / 16]));
+                    if (stageP) {
+                        dpp_ready(src);
+                        static_for<0, NV>([&](auto bc) { fmac_bcast<decltype(bc)::value>(Pr[decltype(bc)::value], src, t); });
+                    }
+                });
+            }
+            // Psi_{k+1} = A_k Psi_k, B_k's column entering at step j
+            const T hk = (j == k && !xl15) ? T(1) : T(0);
+            T w[NX];
+            static_for<0, NX>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                T acc = hk * bcol[r];
+                static_for<0, NX>([&](auto sc) {
+                    constexpr int s2 = decltype(sc)::value, E = r * NX + s2;
+                    fmac_bcast<E % 16>(acc, opw[d][E / 16], v[s2]);
+                });
+                w[r] = acc;
+            });
+#pragma unroll
+            for (int r = 0; r < NX; ++r) v[r] = w[r];
+            fetch(dc, k + 2);
+        };
+        for (int k = 0; k < N; k += 2) {
+            cstep(ic<0>{}, k);
+            if (k + 1 < N) cstep(ic<1>{}, k + 1);
+        }
+        }
         tick(10);
         // P = wu I + wt psi_N' psi_N ; q = wt psi_N' (Phi_N x0 - goal)   (mpc_qp.py:99-105, 129-149)
         const T wt = (T)ka.wt;
@@ -1027,7 +1123,7 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
 // round (up to four problems per SIMD) runs the roomy carve: config 2 at 4096: 22.4 against 24.8 us; anything larger the slim one,
 // two wavefronts per SIMD: config 2 at 8192 / 16,384: 37.8 / 65.0 against 47.3 / 85.6 us; config 4 at 8192 / 16,384 / 65,536:
 // 45.5 / 74.0 / 231 against 56.9 / 90.9 / 305 us.
-static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_now(); }
+[[maybe_unused]] static bool quad_pays(int64_t batch) { return batch > 2 * (int64_t)device_simds_now(); }
 
 // the lean build (terminal cost only, state rows only: BASELINE configs 1, 2, 4) or the general one (GEN: input rows, stage cost)
 static bool quad_general(const KernelArgs &ka)
@@ -1035,10 +1131,14 @@ static bool quad_general(const KernelArgs &ka)
     return ka.nx > 4 || ka.mk != MK || !ka.C.ptr || ka.D.ptr || (ka.flags & (MPCQP_P_STAGE | MPCQP_Q_STAGE));
 }
 
+// (this file is compiled twice: as itself -- nx = 2 .. 4 and the shared-model mode -- and, with MPCQP_QUAD_WIDE_UNIT defined, through
+// mpcqp_quadw.hip -- the general build's instantiations for nx = 5 .. 16 --: two units of two minutes instead of one of four)
+#ifndef MPCQP_QUAD_WIDE_UNIT
 bool quad_applies(const KernelArgs &ka)
 {
-    // the register-pipelined chain: one to four rows per step (state rows, input rows or both), nx = 2 .. 6; cold launches
-    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 6) return false;
+    // the register-pipelined chain: one to four rows per step (state rows, input rows or both), nx = 2 .. 16 (from nx = 7 with the
+    // operands streamed per step); cold launches
+    if (ka.n > NV || ka.m > MMAX || ka.m < 1 || ka.nx < 2 || ka.nx > 16) return false;
     if (ka.mk < 1 || ka.mk > 4 || (!ka.C.ptr && !ka.D.ptr)) return false;
     if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
     if (ka.warm_state || (ka.opt_flags & MPCQP_OPT_SEED_VIOLATED)) return false;
@@ -1055,6 +1155,8 @@ bool quad_eligible(const KernelArgs &ka, int64_t batch)
     // tools/ab_quad_general.py)
     return (ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) || quad_general(ka) || quad_pays(batch);
 }
+
+#endif
 
 template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
@@ -1094,14 +1196,24 @@ template <int NX> static int launch_quad_t(const KernelArgs &ka, int64_t batch, 
     return (int)hipGetLastError();
 }
 
+#ifdef MPCQP_QUAD_WIDE_UNIT
+int launch_quad_wide(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    if (ka.nx == 5) return launch_quad_t<5>(ka, batch, st);
+    if (ka.nx == 6) return launch_quad_t<6>(ka, batch, st);
+    // nx = 7 .. 16: the streamed build, compiled for the padded sizes 8, 12, 16
+    return ka.nx <= 8 ? launch_quad_t<8>(ka, batch, st) : ka.nx <= 12 ? launch_quad_t<12>(ka, batch, st) : launch_quad_t<16>(ka, batch, st);
+}
+#else
+int launch_quad_wide(const KernelArgs &ka, int64_t batch, hipStream_t st);  // (mpcqp_quadw.hip)
+
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     switch (ka.nx) {
     case 2: return launch_quad_t<2>(ka, batch, st);
     case 3: return launch_quad_t<3>(ka, batch, st);
     case 4: return launch_quad_t<4>(ka, batch, st);
-    case 5: return launch_quad_t<5>(ka, batch, st);
-    default: return launch_quad_t<6>(ka, batch, st);
+    default: return launch_quad_wide(ka, batch, st);
     }
 }
 
@@ -1136,5 +1248,7 @@ int launch_quad_model(const KernelArgs &ka, int64_t batch, hipStream_t st)
     }
     return (int)hipGetLastError();
 }
+
+#endif  // MPCQP_QUAD_WIDE_UNIT
 
 }  // namespace mpcqp

@@ -290,7 +290,7 @@ def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
         solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE | _capi.OPT_TWO_PER_WAVE)
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE, warm_state=WarmState(bp))
-    wide = random_ltv(rng, 8, 7, 2, 8, 2, 1.0)  # another kernel's dimensions (nx > 6)
+    wide = random_ltv(rng, 8, 17, 2, 8, 2, 1.0)  # another kernel's dimensions (nx > 16)
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(W.to_batch_problem(wide), flags=_capi.OPT_FOUR_PER_WAVE)
 
@@ -310,10 +310,12 @@ def _general_family(rng, batch, nx, nu, N, tight, rows, stage, mk=2):
     return w
 
 
-@pytest.mark.parametrize("nx,nu", [(2, 1), (2, 2), (3, 1), (4, 1), (3, 2), (4, 2), (3, 3), (4, 4), (5, 1), (5, 2), (6, 1), (6, 2), (6, 3)])
+@pytest.mark.parametrize("nx,nu", [(2, 1), (2, 2), (3, 1), (4, 1), (3, 2), (4, 2), (3, 3), (4, 4), (5, 1), (5, 2), (6, 1), (6, 2), (6, 3),
+                                   (7, 1), (8, 2), (9, 3), (10, 1), (12, 4), (13, 2), (16, 1), (16, 4)])
 def test_general_build_every_layout_against_the_oracle(nx, nu):
     """Round 6: the kernel's general build -- input rows D_k next to / instead of the state rows C_k, a stage cost (the Gram matrix over
-    every Psi_k, targets per step), nx = 2, 5, 6 (three / four operand registers per step) -- over every horizon that fits sixteen variables, loose to very tight bounds: statuses and
+    every Psi_k, targets per step), nx = 2, 5, 6 (three / four operand registers per step), nx = 7 .. 16 (operands streamed per step,
+    padded sizes 8 / 12 / 16) -- over every horizon that fits sixteen variables, loose to very tight bounds: statuses and
     plans against the oracle; for nx = 3, 4 iteration counts against the two-per-wavefront kernel's generic build
     (qpmpc/mpc_qp.py:53-149 both)."""
     from qpmpc_amd import _capi, solve_mpc_batch
@@ -401,7 +403,7 @@ def test_default_dispatch_of_the_general_layouts_and_of_double_integrators():
     rng = np.random.default_rng(8)
     simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     cases = [(2, 1, 14, "cd", True, 300), (2, 2, 7, "d", False, 5), (3, 1, 12, "d", True, 1), (4, 2, 6, "cd", True, 700),
-             (5, 1, 16, "c", False, 9), (6, 2, 8, "cd", True, 130),
+             (5, 1, 16, "c", False, 9), (6, 2, 8, "cd", True, 130), (8, 2, 8, "cd", True, 70), (12, 4, 4, "c", False, 33),
              (2, 1, 16, "c", False, 2 * simds + 1)]  # (the last one: the lean layout with nx = 2 at the size the rule takes it)
     for nx, nu, N, rows, stage, batch in cases:
         w = _general_family(rng, batch, nx, nu, N, 0.2, rows, stage)

@@ -265,7 +265,7 @@ def test_wip_model_constants_match_reference():
 
 
 def test_hand_written_dpp_instructions_keep_their_wait_states():
-    """The v_fmac_f64_dpp of mpcqp_pair.hip and mpcqp_quad.hip are inline asm: the compiler cannot insert the two wait states a DPP read needs
+    """The v_fmac_f64_dpp of mpcqp_pair.hip and mpcqp_quad.hip (+ its second unit, mpcqp_quadw.hip) are inline asm: the compiler cannot insert the two wait states a DPP read needs
     after a VALU write of the same register, the source does (dpp_ready). tools/check_dpp_hazards.py verifies it on the
     gfx950 assembly of every instantiation (hipcc cross-compiles without a GPU), and flags a made-up violation."""
     import os, sys
@@ -281,9 +281,15 @@ def test_hand_written_dpp_instructions_keep_their_wait_states():
     assert not bad
     # (mpcqp_stage.hip used the same instruction in round 4; its sweeps and recursion run on v_mfma_f64_4x4x4 since round 5, whose
     # wait states the compiler inserts itself)
-    for unit in ("mpcqp_pair.hip", "mpcqp_quad.hip"):
-        src = os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", unit)
-        bad, ndpp, nasm = chk.check(chk.device_asm(src))
+    # (the three units are compiled to assembly side by side: mpcqp_quadw.hip -- the wide instantiations of mpcqp_quad.hip -- alone takes
+    # two minutes)
+    from concurrent.futures import ThreadPoolExecutor
+
+    units = ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip")
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        asms = list(pool.map(lambda u: chk.device_asm(os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", u)), units))
+    for unit, asm in zip(units, asms):
+        bad, ndpp, nasm = chk.check(asm)
         assert nasm > 1000 and not bad, (unit, bad[:3])
 
 

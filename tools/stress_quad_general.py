@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev stress run for the four-per-wavefront kernel's general build (csrc/mpcqp_quad.hip, GEN): random LTV problems over its whole
-envelope -- nx 2..6, nu 1..4, every horizon with n <= 16, 1..4 rows per step (m <= 32), state rows / input rows / both, with and
+envelope -- nx 2..16, nu 1..4, every horizon with n <= 16, 1..4 rows per step (m <= 32), state rows / input rows / both, with and
 without a stage cost, time-invariant or per-step operands, loose to very tight bounds -- forced through the kernel
 (MPCQP_OPT_FOUR_PER_WAVE) against the C oracle: statuses equal, plans within 1e-7 relative.
 usage: stress_quad_general.py [rounds] [batch]   (STRESS_SEED)"""
@@ -16,7 +16,7 @@ def run(rounds, batch, seed, verbose=True):
     rng = np.random.default_rng(seed)
     worst, bad, solved, drops = 0.0, 0, 0, 0
     for it in range(rounds):
-        nx, nu = int(rng.integers(2, 7)), int(rng.integers(1, 5))
+        nx, nu = int(rng.integers(2, 17)), int(rng.integers(1, 5))
         N = int(rng.integers(1, 16 // nu + 1))
         mk = int(rng.integers(1, min(4, 32 // N) + 1))
         tight = float(rng.choice([0.05, 0.2, 1.0, 3.0]))
