@@ -828,6 +828,12 @@ def other_workloads():
     bpr = W.to_batch_problem(wr)
     out["reference_wip_example_n12_batch4096"] = rate(PreparedSolve(bpr).launch, 4096, 200)
     out["reference_wip_example_n12_batch4096_two_per_wavefront"] = rate(PreparedSolve(bpr, flags=_capi.OPT_TWO_PER_WAVE).launch, 4096, 200)
+    # small problems of wider systems (n = 16): the four-per-wavefront kernel's general build since round 6 (three / four operand
+    # registers per step for nx = 5, 6, streamed operands from nx = 7); they ran on the one-per-wavefront kernel before
+    for key, (nxs, nus, Ns) in (("small_nx6_nu2_n16_m16_f64_batch4096", (6, 2, 8)), ("small_nx12_nu4_n16_m16_f64_batch4096", (12, 4, 4)),
+                                ("small_nx7_nu1_n16_m32_f64_batch4096", (7, 1, 16))):
+        ws = random_ltv(np.random.default_rng(3), 4096, nxs, nus, Ns, 16 // Ns if Ns < 8 else 2, 0.5)
+        out[key] = rate(PreparedSolve(W.to_batch_problem(ws)).launch, 4096, 50)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
     walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)
