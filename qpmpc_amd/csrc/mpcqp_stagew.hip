@@ -50,6 +50,9 @@ namespace mpcqp {
 #ifndef STAGEW_VPASS32
 #define STAGEW_VPASS32 3
 #endif
+#ifndef STAGEW_PDD
+#define STAGEW_PDD 2 /* steps ahead of the recursion at which the default instantiations request a step's operands */
+#endif
 #ifndef STAGEW_QFD
 // active rows up to which an iteration of the default float32 instantiations runs on its "small" path (one four-vector of Q per lane and row)
 #define STAGEW_QFD 4
@@ -532,7 +535,7 @@ __global__ void __launch_bounds__(64)
                 if (4 * q + pg < nx) pst[q] = -(T)ka.wt * ggoal[4 * q + pg];
         }
         const T *tp0 = stageQ ? gtgt : gA;  // (a readable address when there are no targets)
-        constexpr int PD = LOW ? 4 : 2;  // operands are requested this many steps ahead (a lone wavefront: deeper)
+        constexpr int PD = LOW ? 4 : STAGEW_PDD;  // operands are requested this many steps ahead (a lone wavefront: deeper)
         T pw[PD][NQ], pa[PD][NQ], pb[PD], ptg[PD][NQ];
         auto request = [&](int d, int k) {
             const T *w = baseW + k * stW, *a = gA + k * sA, *b = gB + k * sB;
