@@ -171,7 +171,9 @@ typedef struct MpcqpProblem {
 #define MPCQP_OPT_FOUR_PER_WAVE 4096 /* ... and FOUR per wavefront for every batch size that kernel is eligible for (the dispatch
                                  takes it from more than two problems per SIMD of the device up: 2049 and more on an MI355X, where a
                                  wavefront per SIMD with four problems beats two wavefronts with two, and launches of several
-                                 rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way).
+                                 rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way;
+                                 problems of 33 .. 64 rows with nx <= 8 run on its four-rows-per-lane copy, mpcqp_quad4.hip, at
+                                 every batch size).
                                  MPCQP_EUNSUPPORTED where the kernel does not apply (nx > 16, more than four rows per step, warm
                                  starts, seed steps, a pairing order together with input rows / a stage cost). The shared-model solves (mpcqp_solve_model_batch / _bounds_batch) take
                                  it too, with the same batch-size rule, for every model with n <= 16, m <= 32. */

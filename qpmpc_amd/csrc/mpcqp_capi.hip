@@ -293,6 +293,9 @@ int run_solver(const KernelArgs &ka, bool stepA, bool stepB, int dtype, int64_t 
     if (!force_lds(ka.opt_flags)) {
         // (nx = 2 and nx > 4 have no two-per-wavefront instantiation: the four-per-wavefront kernel takes them where it pays -- the general
         // layouts and nx > 4 at every batch size, the lean layout of nx = 2 from more than two problems per SIMD --, on its own)
+        // (more than 32 rows at n <= 16: the four-rows-per-lane copy of that kernel, at every batch size -- the workgroup / one-per-wavefront
+        // kernels it replaces there are 5-9 x slower)
+        if (MODE == MODE_FUSED && dtype == MPCQP_F64 && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && quad4_applies(ka)) return launch_quad4(ka, batch, st);
         if (MODE == MODE_FUSED && dtype == MPCQP_F64 && !(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && (ka.nx == 2 || ka.nx > 4) && quad_eligible(ka, batch))
             return launch_quad(ka, batch, st);
         if (!(ka.opt_flags & MPCQP_OPT_ONE_PER_WAVE) && pair_eligible(ka, MODE, dtype)) return launch_pair(ka, batch, st);
@@ -691,7 +694,7 @@ int mpcqp_build_solve_batch(const MpcqpDims *dims, const MpcqpProblem *problem, 
     // four problems per wavefront on request: only where that kernel applies (the dispatch picks it by batch size otherwise)
     if ((ka.opt_flags & MPCQP_OPT_FOUR_PER_WAVE) &&
         ((ka.opt_flags & (MPCQP_OPT_FORCE_LDS | MPCQP_OPT_ONE_PER_WAVE | MPCQP_OPT_TWO_PER_WAVE)) ||
-         (!pair_eligible(ka, MODE_FUSED, MPCQP_F64) && ka.nx != 2 && ka.nx <= 4) || !quad_applies(ka)))
+         (!pair_eligible(ka, MODE_FUSED, MPCQP_F64) && ka.nx != 2 && ka.nx <= 4 && !quad4_applies(ka)) || (!quad_applies(ka) && !quad4_applies(ka))))
         return MPCQP_EUNSUPPORTED;
     const bool stepA = problem->A.step_stride != 0, stepB = problem->B.step_stride != 0;
     hipStream_t st = (hipStream_t)stream;

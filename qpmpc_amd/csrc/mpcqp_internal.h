@@ -263,6 +263,9 @@ bool quad_model_eligible(const KernelArgs &ka, int64_t batch);  // shared-model 
 int launch_quad_model(const KernelArgs &ka, int64_t batch, hipStream_t st);
 bool quad_eligible(const KernelArgs &ka, int64_t batch);  // ... and the dispatch takes it (batch size, MPCQP_OPT_TWO / FOUR_PER_WAVE)
 int launch_quad(const KernelArgs &ka, int64_t batch, hipStream_t st);
+// ... and its four-rows-per-lane copy for 33 .. 64 rows (mpcqp_quad4.hip): cold launches, any batch size
+bool quad4_applies(const KernelArgs &ka);
+int launch_quad4(const KernelArgs &ka, int64_t batch, hipStream_t st);
 // small-problem kernel (mpcqp_w64.hip): one problem per wavefront
 bool w64_eligible(const KernelArgs &ka, int mode, int dtype);
 int launch_w64(const KernelArgs &ka, int mode, int dtype, int64_t batch, hipStream_t st);

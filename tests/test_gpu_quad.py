@@ -452,3 +452,56 @@ def test_random_campaign_over_the_whole_envelope_of_the_general_build():
     worst, flagged, solved, drops = run(80, 64, seed=7, verbose=False)
     assert flagged == 0 and worst <= 1e-7, (worst, flagged)
     assert solved > 4000 and drops > 0
+
+
+@pytest.mark.parametrize("nx", [2, 3, 4, 5, 6, 8])
+def test_more_than_32_rows_take_the_four_rows_per_lane_copy(nx):
+    """csrc/mpcqp_quad4.hip (end of round 6): n <= 16 with 33 .. 64 rows (three / four rows per step on horizons of 9 .. 16 steps) --
+    default dispatch = forced launch, bit for bit; statuses and plans against the oracle; iteration counts against the
+    one-per-wavefront kernel that served these problems before (same method)."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(640 + nx)
+    drops = solved = 0
+    for N, mk in ((16, 4), (16, 3), (13, 3), (12, 4), (9, 4), (11, 3)):
+        for tight, rows, stage in ((3.0, "cd", True), (0.2, "c", False), (0.05, "cd", True), (0.1, "d", False)):
+            w = _general_family(rng, 45, nx, 1, N, tight, rows, stage, mk)
+            bp = W.to_batch_problem(w)
+            auto = solve_mpc_batch(bp)
+            four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+            one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
+            torch.cuda.synchronize()
+            assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters) and torch.equal(auto.status, four.status)
+            ok = _check_against_oracle(w, four)
+            same = (four.iters == one.iters).cpu().numpy()[ok]
+            assert ok.sum() == 0 or same.mean() >= 0.9, (N, mk, tight, rows, stage, same.mean())
+            solved += int(ok.sum())
+            drops += int((four.iters.cpu().numpy()[ok] > N).sum())
+    assert solved > 500 and drops > 0
+
+
+def test_more_than_32_rows_launches_beyond_three_wavefronts_per_cu_take_the_slim_carve():
+    """... and its second LDS carve (36.9 KB per wavefront: four on a CU, still one per SIMD) for launches of more than three wavefronts
+    per CU (3073 problems and more on an MI355X): the same problems in two launches of the roomy carve give the same statuses and
+    iteration counts bit for bit and plans within 1e-9; the first 256 against the oracle."""
+    from qpmpc_amd import solve_mpc_batch
+    from qpmpc_amd import workloads as W
+    from qpmpc_amd.distributed import shard_workload
+
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    batch = 3 * simds + 120
+    rng = np.random.default_rng(64)
+    for nx, N, mk, tight, rows, stage in ((3, 16, 4, 0.2, "cd", True), (6, 12, 3, 0.05, "c", False)):
+        w = _general_family(rng, batch, nx, 1, N, tight, rows, stage, mk)
+        slim = solve_mpc_batch(W.to_batch_problem(w))
+        parts = [solve_mpc_batch(W.to_batch_problem(shard_workload(w, r, 2))) for r in range(2)]
+        torch.cuda.synchronize()
+        st = torch.cat([p.status for p in parts])
+        it = torch.cat([p.iters for p in parts])
+        U = torch.cat([p.U for p in parts])
+        assert torch.equal(st, slim.status) and torch.equal(it, slim.iters)
+        good = st == 0
+        assert int(good.sum()) > batch // 2
+        assert float((U[good] - slim.U[good]).abs().max()) <= 1e-9 * max(1.0, float(U[good].abs().max()))
+        _check_against_oracle(shard(w, 256), _first(slim, 256))

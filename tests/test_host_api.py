@@ -281,12 +281,12 @@ def test_hand_written_dpp_instructions_keep_their_wait_states():
     assert not bad
     # (mpcqp_stage.hip used the same instruction in round 4; its sweeps and recursion run on v_mfma_f64_4x4x4 since round 5, whose
     # wait states the compiler inserts itself)
-    # (the three units are compiled to assembly side by side: mpcqp_quadw.hip -- the wide instantiations of mpcqp_quad.hip -- alone takes
-    # two minutes)
+    # (the units are compiled to assembly side by side: mpcqp_quadw.hip -- the wide instantiations of mpcqp_quad.hip -- and
+    # mpcqp_quad4.hip -- its four-rows-per-lane copy -- take two to three minutes each)
     from concurrent.futures import ThreadPoolExecutor
 
-    units = ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip")
-    with ThreadPoolExecutor(max_workers=3) as pool:
+    units = ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip", "mpcqp_quad4.hip")
+    with ThreadPoolExecutor(max_workers=4) as pool:
         asms = list(pool.map(lambda u: chk.device_asm(os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", u)), units))
     for unit, asm in zip(units, asms):
         bad, ndpp, nasm = chk.check(asm)

@@ -3,7 +3,8 @@
 envelope -- nx 2..16, nu 1..4, every horizon with n <= 16, 1..4 rows per step (m <= 32), state rows / input rows / both, with and
 without a stage cost, time-invariant or per-step operands, loose to very tight bounds -- forced through the kernel
 (MPCQP_OPT_FOUR_PER_WAVE) against the C oracle: statuses equal, plans within 1e-7 relative.
-usage: stress_quad_general.py [rounds] [batch]   (STRESS_SEED)"""
+usage: stress_quad_general.py [rounds] [batch]   (STRESS_SEED; STRESS_ROWS64=1: also problems of 33 .. 64 rows, the four-rows-per-lane
+copy of the kernel in csrc/mpcqp_quad4.hip)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
@@ -18,7 +19,9 @@ def run(rounds, batch, seed, verbose=True):
     for it in range(rounds):
         nx, nu = int(rng.integers(2, 17)), int(rng.integers(1, 5))
         N = int(rng.integers(1, 16 // nu + 1))
-        mk = int(rng.integers(1, min(4, 32 // N) + 1))
+        mk = int(rng.integers(1, min(4, (64 if os.environ.get("STRESS_ROWS64") else 32) // N) + 1))  # (STRESS_ROWS64: up to 64 rows -- mpcqp_quad4.hip)
+        if N * mk > 32 and nx > 8:
+            nx = int(rng.integers(2, 9))  # (more than 32 rows: that kernel serves nx <= 8)
         tight = float(rng.choice([0.05, 0.2, 1.0, 3.0]))
         rows = str(rng.choice(["c", "d", "cd"]))
         stage = bool(rng.integers(0, 2))
