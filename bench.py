@@ -834,6 +834,9 @@ def other_workloads():
                                 ("small_nx7_nu1_n16_m32_f64_batch4096", (7, 1, 16))):
         ws = random_ltv(np.random.default_rng(3), 4096, nxs, nus, Ns, 16 // Ns if Ns < 8 else 2, 0.5)
         out[key] = rate(PreparedSolve(W.to_batch_problem(ws)).launch, 4096, 50)
+    # ... and with more than 32 rows (four rows per step at N = 16: m = 64): the four-rows-per-lane copy of that kernel (mpcqp_quad4.hip)
+    w64 = random_ltv(np.random.default_rng(3), 4096, 3, 1, 16, 4, 0.5)
+    out["small_nx3_nu1_n16_m64_f64_batch4096"] = rate(PreparedSolve(W.to_batch_problem(w64)).launch, 4096, 50)
     walkers = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096))
     out["lipm_walking_loops_4096"] = rate(walkers.step, 4096, 100)
     walkers_m = LIPMWalkingLoop(4096, index=rng.integers(0, 8, 4096), shared_model=True)

@@ -11,6 +11,7 @@ for k in wide widef narrow general; do for t in 0.5 0.3 0.15 0.05; do
   echo "stress_tight $k STRESS_TIGHT=$t seeds 1-16 (no re-solve): $(STRESS_TIGHT=$t STRESS_SEEDS=1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16 timeout 1200 python tools/stress_tight.py $k 8 8 2>&1 | grep -E 'CHECK|^worst' | tail -3 | cut -c1-300 | tr '\n' ' ')"
 done; done
 for s in 1 2 3 4 5 6; do echo "stress_quad_general 150x96 seed $s (nx 2..16, every layout, forced four per wavefront): $(STRESS_QUIET=1 STRESS_SEED=$s timeout 600 python tools/stress_quad_general.py 150 96 2>&1 | grep -E 'CHECK|^worst' | tail -3 | tr '\n' ' ')"; done
+for s in 1 2 3 4; do echo "stress_quad_general 150x96 seed $s with up to 64 rows (mpcqp_quad4.hip where m > 32): $(STRESS_ROWS64=1 STRESS_QUIET=1 STRESS_SEED=$s timeout 600 python tools/stress_quad_general.py 150 96 2>&1 | grep -E 'CHECK|^worst' | tail -3 | tr '\n' ' ')"; done
 for t in 0.15 0.05; do
   echo "stress_tight narrow STRESS_TIGHT=$t seeds 1-16 through mpcqp_stagewise_solve_batch: $(STRESS_FORMULATION=stagewise STRESS_TIGHT=$t STRESS_SEEDS=1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16 timeout 1200 python tools/stress_tight.py narrow 8 8 2>&1 | grep -E 'CHECK|^worst' | tail -3 | cut -c1-300 | tr '\n' ' ')"
 done
