@@ -16,11 +16,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-_UNITS = ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip", "mpcqp_quad4.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip",
+_UNITS = ("mpcqp_lds.hip", "mpcqp_w64.hip", "mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip", "mpcqp_quad4.hip", "mpcqp_quad4w.hip", "mpcqp_big.hip", "mpcqp_bigsolve.hip",
           "mpcqp_model.hip", "mpcqp_stage.hip", "mpcqp_stagew.hip", "mpcqp_stageg.hip", "mpcqp_capi.hip")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in _UNITS]
 # units that include another unit's source (mpcqp_quadw.hip compiles the wide instantiations of mpcqp_quad.hip): rebuilt with it
-_INCLUDES = {"mpcqp_quadw.hip": ("mpcqp_quad.hip",)}
+_INCLUDES = {"mpcqp_quadw.hip": ("mpcqp_quad.hip",), "mpcqp_quad4w.hip": ("mpcqp_quad4.hip",)}
 # every header a unit may include: the public one and everything under csrc/ (mpcqp_internal.h, mpcqp_plant.h, ...)
 HEADERS = [os.path.join(_ROOT, "include", "mpcqp.h")] + sorted(glob.glob(os.path.join(_PKG, "csrc", "*.h")))
 LIB_PATH = os.path.join(_PKG, "lib", "libmpcqp_hip.so")

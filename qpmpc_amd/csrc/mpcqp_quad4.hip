@@ -1104,6 +1104,7 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
 // ------------------------------------------------------------ host side
 // cold launches of problems with n <= 16 and 33 .. 64 rows, one to four rows per step, nx <= 8 (the streamed build's padded size 8
 // serves nx = 7, 8); everything else keeps the kernel it had
+#ifndef MPCQP_QUAD_WIDE_UNIT
 bool quad4_applies(const KernelArgs &ka)
 {
     if (ka.n > NV || ka.m > MMAX || ka.m <= 32 || ka.nx < 2 || ka.nx > 8) return false;
@@ -1112,6 +1113,8 @@ bool quad4_applies(const KernelArgs &ka)
     if (ka.warm_state || ka.order || (ka.opt_flags & (MPCQP_OPT_SEED_VIOLATED | MPCQP_OPT_TWO_PER_WAVE))) return false;
     return true;
 }
+
+#endif
 
 template <int NX> static int launch_quad4_t(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
@@ -1135,16 +1138,27 @@ template <int NX> static int launch_quad4_t(const KernelArgs &ka, int64_t batch,
                 : go(mpcqp_quad4_kernel<NX, false, 1, false, false, true>, Carve<false>::PER);
 }
 
+// (compiled twice, like mpcqp_quad.hip: as itself -- nx = 2 .. 4 -- and through mpcqp_quad4w.hip -- nx = 5 .. 8 --: two units of a
+// minute and a half instead of one of three)
+#ifdef MPCQP_QUAD_WIDE_UNIT
+int launch_quad4_wide(const KernelArgs &ka, int64_t batch, hipStream_t st)
+{
+    if (ka.nx == 5) return launch_quad4_t<5>(ka, batch, st);
+    if (ka.nx == 6) return launch_quad4_t<6>(ka, batch, st);
+    return launch_quad4_t<8>(ka, batch, st);
+}
+#else
+int launch_quad4_wide(const KernelArgs &ka, int64_t batch, hipStream_t st);  // (mpcqp_quad4w.hip)
+
 int launch_quad4(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
     switch (ka.nx) {
     case 2: return launch_quad4_t<2>(ka, batch, st);
     case 3: return launch_quad4_t<3>(ka, batch, st);
     case 4: return launch_quad4_t<4>(ka, batch, st);
-    case 5: return launch_quad4_t<5>(ka, batch, st);
-    case 6: return launch_quad4_t<6>(ka, batch, st);
-    default: return launch_quad4_t<8>(ka, batch, st);
+    default: return launch_quad4_wide(ka, batch, st);
     }
 }
+#endif
 
 }  // namespace mpcqp

@@ -285,8 +285,8 @@ def test_hand_written_dpp_instructions_keep_their_wait_states():
     # mpcqp_quad4.hip -- its four-rows-per-lane copy -- take two to three minutes each)
     from concurrent.futures import ThreadPoolExecutor
 
-    units = ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip", "mpcqp_quad4.hip")
-    with ThreadPoolExecutor(max_workers=4) as pool:
+    units = ("mpcqp_pair.hip", "mpcqp_quad.hip", "mpcqp_quadw.hip", "mpcqp_quad4.hip", "mpcqp_quad4w.hip")
+    with ThreadPoolExecutor(max_workers=5) as pool:
         asms = list(pool.map(lambda u: chk.device_asm(os.path.join(os.path.dirname(tools), "qpmpc_amd", "csrc", u)), units))
     for unit, asm in zip(units, asms):
         bad, ndpp, nasm = chk.check(asm)
