@@ -178,19 +178,17 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS carve of ONE problem, in doubles. Two of them:
-//  * ROOMY (launches of one round: at most one wavefront per SIMD, so LDS is free): M image 32 x 18, the full L^-T image, a T image
-//    for the rare refinement, the leaving slot's row, the slots' constraint ids: 1112 doubles = 35.6 KB per wavefront, four on a CU.
-//  * SLIM (launches of several rounds): 640 doubles = 5120 B, 20 KB per wavefront -- EIGHT wavefronts on a CU's 160 KB, two per SIMD
-//    (256-register budget), which is what those launches live on: 65,536 config-4 problems 231 us against 324 us roomy and 305 us
-//    for the two-per-wavefront kernel (tools/ab_quad_c4.py). Kept in LDS: M (32 x 16: its stores conflict, +2.6 k cycles once)
-//    and the strict upper triangle of L^-T, packed (the diagonal stays in a register). Gone: the T image (T' rho by row sums over
-//    the lanes), the leaving slot's row (fetched from its lane by ds_bpermute in the rare drop trip), the slots' ids (DPP). On a
-//    one-round launch the slim carve costs 3.8 us (its prologue and epilogue are longer): hence both.
+// LDS carve of ONE problem, in doubles. Two of them, ONE wavefront per SIMD in both (the kernel holds 334 / 373 registers):
+//  * ROOMY (up to three wavefronts per CU): M image 64 x 16, the full L^-T image, a T image for the rare refinement, the leaving slot's
+//    row, the slots' constraint ids: 1560 doubles = 12.2 KB per problem, 49.9 KB per wavefront, three on a CU's 160 KB.
+//  * SLIM (launches beyond three wavefronts per CU: 3073 problems and more on an MI355X): the M image and the strict upper triangle of
+//    L^-T, packed (the diagonal stays in a register): 1152 doubles, 36.9 KB per wavefront, FOUR on a CU. Gone: the T image (T' rho by
+//    row sums over the lanes), the leaving slot's row (fetched from its lane by ds_bpermute in the rare drop trip), the slots' ids
+//    (DPP). 4096 problems with m = 64: 119 us roomy (two rounds of three per CU), 81 us slim (one round).
 template <bool SLIM> struct Carve {
     static constexpr int LDM = 16;  // (64 x 16: three wavefronts of 49.9 KB on a CU; with 18 only two)
-    static constexpr int OFF_M = 0;  // build: G image by column, 16 x GS (GS = 33: 528 doubles; slim: over the start of the region
-                                     // behind it, which is not alive yet) | main: M image, 32 x LDM
+    static constexpr int OFF_M = 0;  // build: G image by column, 16 x GS (GS = 65: 1040 doubles, over the start of the region behind the
+                                     // M image, which is not alive yet) | main: M image, 64 x LDM
     static constexpr int OFF_LT = MMAX * LDM;  // roomy: rows of L^-T, 16 x 16 | slim: strict upper triangle by rows, packed: row l at
                                                // l (31 - l) / 2, 15 - l entries
     static constexpr int NLT = SLIM ? NV * (NV - 1) / 2 + 8 : NV * NV;  // (slim: eight spare doubles keep the G image inside the carve)
@@ -1078,7 +1076,7 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) lo[r] = T(0);
     if (olam) {  // multipliers by constraint: every occupied slot drops its multiplier at its row's place
-        T *lamv = Ml;  // (the M image is dead: every row has finished; 32 doubles)
+        T *lamv = Ml;  // (the M image is dead: every row has finished; 64 doubles)
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) lamv[rowi[r]] = T(0);
         wsync();
