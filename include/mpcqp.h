@@ -174,7 +174,7 @@ typedef struct MpcqpProblem {
                                  rounds keep two such wavefronts on every SIMD; smaller batches leave SIMDs idle either way;
                                  problems of 33 .. 64 rows with nx <= 8 run on its four-rows-per-lane copy, mpcqp_quad4.hip, at
                                  every batch size).
-                                 MPCQP_EUNSUPPORTED where the kernel does not apply (nx > 16, more than four rows per step, warm
+                                 MPCQP_EUNSUPPORTED where the kernel does not apply (nx > 16, more than four rows per step -- eight with nx <= 8 --, warm
                                  starts, seed steps, a pairing order together with input rows / a stage cost). The shared-model solves (mpcqp_solve_model_batch / _bounds_batch) take
                                  it too, with the same batch-size rule, for every model with n <= 16, m <= 32. */
 

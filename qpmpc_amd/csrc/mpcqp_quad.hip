@@ -546,6 +546,10 @@ __global__ void __launch_bounds__(64 * WPB, SLIM ? 2 : 1)
         const T wxs = (T)ka.wx;
         auto cstep = [&](auto dc, int k) {
             constexpr int d = decltype(dc)::value;
+            // (the step's operand registers are DPP sources of hand-written instructions: pinned in vector registers two wait states
+            // ahead -- an instantiation that runs on more than 256 registers may otherwise fetch one from an accumulation register
+            // right in front of its first use)
+            static_for<0, NOPW>([&](auto rc) { dpp_ready(opw[d][decltype(rc)::value]); });
             // G rows of step k from Psi_k (lane 15: C_k Phi_k x0)
             static_for<0, 4>([&](auto i2c) {
                 constexpr int i2 = decltype(i2c)::value;

@@ -25,6 +25,9 @@ namespace quad4 {
 constexpr int NV = 16;    // padded number of variables / slots = lanes per problem
 constexpr int MMAX = 64;  // constraints a problem can hold (four per lane)
 constexpr int ROWS = 4;   // constraint rows per lane
+#ifndef QUAD4_MKG
+#define QUAD4_MKG 8       // rows per step the general build is unrolled for
+#endif
 // row stride of the M image: 18 (144 B: rows start in distinct 16-B slots, conflict-free stores) in the roomy carve, 16 in the slim one
 constexpr int MK = 2;     // inequality rows per step
 
@@ -294,9 +297,9 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
         const int nu = ka.nu, N = ka.N;
         // rows per step: two in the lean build; one to four in the general one (a run-time number: the chain's loops over the rows of
         // a step are unrolled four wide behind wavefront-uniform tests)
-        constexpr int MKG = GEN ? 4 : MK;
+        constexpr int MKG = GEN ? QUAD4_MKG : MK;  // (this file: up to EIGHT rows per step -- m <= 64 holds them for horizons of up to eight steps)
         const int mk = GEN ? ka.mk : MK;
-        auto stepof = [&](int row) { return mk == 2 ? row >> 1 : (mk == 1 ? row : (mk == 4 ? row >> 2 : row / 3)); };
+        auto stepof = [&](int row) { return mk == 2 ? row >> 1 : (mk == 1 ? row : (mk == 4 ? row >> 2 : (mk == 8 ? row >> 3 : row / mk))); };
         const T *A = gA + prob * ka.A.batch_stride;
         const T *B = gB + prob * ka.B.batch_stride;
         const bool hasC = !GEN || gC != nullptr;
@@ -395,6 +398,7 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
         static_for<0, NV>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             if (k < N) {
+                static_for<0, NOP>([&](auto rc) { dpp_ready(op[decltype(rc)::value][k]); });  // (as in the streamed build below)
                 // (lane 15 stores C_k Phi_k x0 into column 15 of the image -- zero in G by construction --: the rows read their
                 // entry of it behind the chain)
                 if constexpr (!GEN) {
@@ -471,7 +475,7 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
         // ---- streamed operands. Element e of a step's [A_k (NX x NX) | C_k (4 x NX) | xref_k (NX)] -- padded to NX, entries beyond nx /
         // mk read as zero -- sits in lane e % 16 of register e / 16; every register holds one kind of element (NX^2 and 4 NX are
         // multiples of 16). Two steps' registers are alive: step k + 2 is requested when step k has been consumed.
-        constexpr int NAw = NX * NX, NCw = 4 * NX, NEw = NAw + NCw + NX, NOPW = (NEw + 15) / 16;
+        constexpr int NAw = NX * NX, NCw = MKG * NX, NEw = NAw + NCw + NX, NOPW = (NEw + 15) / 16;
         T opw[2][NOPW];
         auto fetch = [&](auto dc, int k) {
             constexpr int d = decltype(dc)::value;
@@ -504,8 +508,12 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
         const T wxs = (T)ka.wx;
         auto cstep = [&](auto dc, int k) {
             constexpr int d = decltype(dc)::value;
+            // (the step's operand registers are DPP sources of hand-written instructions: pinned in vector registers two wait states
+            // ahead -- an instantiation that runs on more than 256 registers may otherwise fetch one from an accumulation register
+            // right in front of its first use)
+            static_for<0, NOPW>([&](auto rc) { dpp_ready(opw[d][decltype(rc)::value]); });
             // G rows of step k from Psi_k (lane 15: C_k Phi_k x0)
-            static_for<0, 4>([&](auto i2c) {
+            static_for<0, MKG>([&](auto i2c) {
                 constexpr int i2 = decltype(i2c)::value;
                 if (i2 < mk) {  // (wavefront-uniform)
                     T acc = T(0);
@@ -1100,13 +1108,13 @@ __global__ void __launch_bounds__(64 * WPB, 1)  // (one wavefront per SIMD in bo
 }
 
 // ------------------------------------------------------------ host side
-// cold launches of problems with n <= 16 and 33 .. 64 rows, one to four rows per step, nx <= 8 (the streamed build's padded size 8
-// serves nx = 7, 8); everything else keeps the kernel it had
+// cold launches of problems with n <= 16 and 33 .. 64 rows, or five to eight rows per step (m <= 64), nx <= 8 (the streamed build's
+// padded size 8 serves nx = 7, 8); everything else keeps the kernel it had
 #ifndef MPCQP_QUAD_WIDE_UNIT
 bool quad4_applies(const KernelArgs &ka)
 {
-    if (ka.n > NV || ka.m > MMAX || ka.m <= 32 || ka.nx < 2 || ka.nx > 8) return false;
-    if (ka.mk < 1 || ka.mk > 4 || (!ka.C.ptr && !ka.D.ptr)) return false;
+    if (ka.n > NV || ka.m > MMAX || (ka.m <= 32 && ka.mk <= 4) || ka.nx < 2 || ka.nx > 8) return false;  // (m <= 32 with mk <= 4: mpcqp_quad.hip)
+    if (ka.mk < 1 || ka.mk > 8 || (!ka.C.ptr && !ka.D.ptr)) return false;
     if (ka.N * ka.mk != ka.m || ka.N > NV) return false;
     if (ka.warm_state || ka.order || (ka.opt_flags & (MPCQP_OPT_SEED_VIOLATED | MPCQP_OPT_TWO_PER_WAVE))) return false;
     return true;
@@ -1136,13 +1144,14 @@ template <int NX> static int launch_quad4_t(const KernelArgs &ka, int64_t batch,
                 : go(mpcqp_quad4_kernel<NX, false, 1, false, false, true>, Carve<false>::PER);
 }
 
-// (compiled twice, like mpcqp_quad.hip: as itself -- nx = 2 .. 4 -- and through mpcqp_quad4w.hip -- nx = 5 .. 8 --: two units of a
-// minute and a half instead of one of three)
+// (compiled twice, like mpcqp_quad.hip: as itself -- nx = 2 .. 4 -- and through mpcqp_quad4w.hip -- nx = 5 .. 8, the streamed build --)
 #ifdef MPCQP_QUAD_WIDE_UNIT
 int launch_quad4_wide(const KernelArgs &ka, int64_t batch, hipStream_t st)
 {
-    if (ka.nx == 5) return launch_quad4_t<5>(ka, batch, st);
-    if (ka.nx == 6) return launch_quad4_t<6>(ka, batch, st);
+    // nx = 5 .. 8: the streamed build in its padded size 8. (Not the all-steps-in-registers build for nx = 5, 6: with eight rows per
+    // step it keeps 80 / 96 operand registers alive next to this kernel's ~330, the allocator parks some in accumulation registers and
+    // moves them back right in front of the hand-written v_fmac_f64_dpp that reads them -- without the two wait states a DPP read
+    // needs: wrong plans (tools/check_dpp_hazards.py finds some of those sites, the oracle found the rest).)
     return launch_quad4_t<8>(ka, batch, st);
 }
 #else

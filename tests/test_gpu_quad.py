@@ -274,14 +274,14 @@ def test_shared_model_with_bounds_per_problem_and_an_order():
 
 
 def test_forcing_the_kernel_where_it_does_not_apply_is_refused():
-    """MPCQP_OPT_FOUR_PER_WAVE with five rows per step, with a warm state, next to another override or on another kernel's
+    """MPCQP_OPT_FOUR_PER_WAVE with nine rows per step, with a warm state, next to another override or on another kernel's
     dimensions: MPCQP_EUNSUPPORTED before any launch."""
     from qpmpc_amd import BackendError, WarmState, _capi, solve_mpc_batch
     from qpmpc_amd import workloads as W
     from stress_stagewise import random_ltv
 
     rng = np.random.default_rng(1)
-    w = random_ltv(rng, 8, 3, 1, 6, 5, 1.0)  # five rows per step
+    w = random_ltv(rng, 8, 3, 1, 6, 9, 1.0)  # nine rows per step
     with pytest.raises(BackendError, match="-6"):
         solve_mpc_batch(W.to_batch_problem(w), flags=_capi.OPT_FOUR_PER_WAVE)
     w = W.triple_integrator_batch(8)
@@ -505,3 +505,28 @@ def test_more_than_32_rows_launches_beyond_three_wavefronts_per_cu_take_the_slim
         assert int(good.sum()) > batch // 2
         assert float((U[good] - slim.U[good]).abs().max()) <= 1e-9 * max(1.0, float(U[good].abs().max()))
         _check_against_oracle(shard(w, 256), _first(slim, 256))
+
+
+def test_five_to_eight_rows_per_step_take_the_four_rows_per_lane_copy_too():
+    """... and up to EIGHT rows per step (a box on two states next to a box on two inputs: mk = 8), m <= 64: horizons of up to eight
+    steps, any nu -- also where m <= 32 (mk > 4 is outside mpcqp_quad.hip's build). Default = forced launch; oracle; iteration counts
+    against the one-per-wavefront kernel."""
+    from qpmpc_amd import _capi, solve_mpc_batch
+    from qpmpc_amd import workloads as W
+
+    rng = np.random.default_rng(88)
+    solved = 0
+    for nx, nu, N, mk in ((4, 2, 8, 8), (3, 1, 8, 5), (4, 2, 6, 6), (2, 2, 4, 8), (6, 2, 5, 7), (8, 4, 4, 8), (5, 1, 9, 7), (7, 2, 8, 8)):
+        for tight, rows, stage in ((3.0, "cd", True), (0.2, "c", False), (0.05, "cd", False), (0.1, "d", True)):
+            w = _general_family(rng, 37, nx, nu, N, tight, rows, stage, mk)
+            bp = W.to_batch_problem(w)
+            auto = solve_mpc_batch(bp)
+            four = solve_mpc_batch(bp, flags=_capi.OPT_FOUR_PER_WAVE)
+            one = solve_mpc_batch(bp, flags=_capi.OPT_ONE_PER_WAVE)
+            torch.cuda.synchronize()
+            assert torch.equal(auto.U, four.U) and torch.equal(auto.iters, four.iters) and torch.equal(auto.status, four.status)
+            ok = _check_against_oracle(w, four)
+            same = (four.iters == one.iters).cpu().numpy()[ok]
+            assert ok.sum() == 0 or same.mean() >= 0.9, (nx, nu, N, mk, tight, rows, stage, same.mean())
+            solved += int(ok.sum())
+    assert solved > 600

@@ -19,8 +19,9 @@ def run(rounds, batch, seed, verbose=True):
     for it in range(rounds):
         nx, nu = int(rng.integers(2, 17)), int(rng.integers(1, 5))
         N = int(rng.integers(1, 16 // nu + 1))
-        mk = int(rng.integers(1, min(4, (64 if os.environ.get("STRESS_ROWS64") else 32) // N) + 1))  # (STRESS_ROWS64: up to 64 rows -- mpcqp_quad4.hip)
-        if N * mk > 32 and nx > 8:
+        rows64 = bool(os.environ.get("STRESS_ROWS64"))  # (up to 64 rows and up to eight rows per step: mpcqp_quad4.hip)
+        mk = int(rng.integers(1, min(8 if rows64 else 4, (64 if rows64 else 32) // N) + 1))
+        if (N * mk > 32 or mk > 4) and nx > 8:
             nx = int(rng.integers(2, 9))  # (more than 32 rows: that kernel serves nx <= 8)
         tight = float(rng.choice([0.05, 0.2, 1.0, 3.0]))
         rows = str(rng.choice(["c", "d", "cd"]))
